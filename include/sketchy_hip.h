@@ -1,0 +1,158 @@
+/*
+ * sketchy_hip.h -- C ABI of libsketchy_hip.so: the MI355X (gfx950) implementation of
+ * sketchy's streaming read-vs-reference MinHash path.
+ *
+ * The reference (esteinig/sketchy v0.6.0) has no FFI/plugin interface; it is one Rust
+ * binary.  The boundary below sits exactly at the seam its hot loop uses internally
+ * (paths are under the reference tree):
+ *
+ *   skx_ref_create         <- the in-RAM reference collection `Vec<Sketch>` returned by
+ *                             Sketchy::_read_sketch (src/sketchy.rs:497-536) and consumed at
+ *                             :337-339; k / seed / s are the sketch params of :82, :520-527
+ *   skx_stream_create      <- state of Sketchy::_sum_of_shared_hashes (src/sketchy.rs:326-327):
+ *                             `sum_of_shared_hashes: Vec<u64>` + read counter; `top` is
+ *                             PredictConfig::top (src/sketchy.rs:43-50)
+ *   skx_stream_push        <- one or more iterations of the loop body src/sketchy.rs:328-354:
+ *                             create_sketcher/process/to_vec (:331-335, finch MashSketcher),
+ *                             N x _common_hashes (:337-341, :419-459), stable sort (:348),
+ *                             first `top` rows (:391)
+ *   skx_stream_table[_add] <- read / seed `sum_of_shared_hashes` (:326, :341)
+ *   skx_common_hashes      <- Sketchy::_common_hashes (src/sketchy.rs:419-459) for sketch
+ *                             collections (the `shared` all-pairs use at :251-261)
+ *   skx_sketch_reads       <- finch SketchScheme::{process,to_vec} as called at :331-335
+ *
+ * Conventions: every function returns 0 (SKX_OK) or a negative SKX_ERR_* code and never
+ * throws; skx_last_error() returns a thread-local message for the last failure.  Handles
+ * are opaque and owned by the library.  Host buffers are caller-owned and only borrowed for
+ * the duration of the call.  A stream handle is driven by one host thread at a time (the
+ * reference loop is single-threaded); different handles may be used from different threads.
+ * There is NO CPU fallback: with no usable gfx950 device every entry point that needs one
+ * fails with SKX_ERR_NO_DEVICE.
+ */
+#ifndef SKETCHY_HIP_H
+#define SKETCHY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKX_OK 0
+#define SKX_ERR_INVALID (-1)      /* bad argument (NULL, k out of range, top > n_genomes ...) */
+#define SKX_ERR_NO_DEVICE (-2)    /* no HIP device / device index out of range */
+#define SKX_ERR_HIP (-3)          /* a HIP runtime call failed; see skx_last_error() */
+#define SKX_ERR_UNSORTED (-4)     /* a reference column is not strictly ascending */
+#define SKX_ERR_CAPACITY (-5)     /* batch exceeds the capacity given at skx_stream_create */
+#define SKX_ERR_COMM (-6)         /* RCCL failure */
+#define SKX_ERR_UNSUPPORTED (-7)  /* parameter combination outside what the kernels support */
+
+#define SKX_MAX_K 32u             /* k-mer length 1..32 (sketchy default 16, src/cli.rs:39-41) */
+#define SKX_MAX_TOP 64u           /* rows ranked per read (sketchy default 1, src/cli.rs:118-119) */
+
+typedef struct skx_ref skx_ref;
+typedef struct skx_stream skx_stream;
+typedef struct skx_comm skx_comm;
+
+/* ---- library / device ------------------------------------------------------------- */
+const char *skx_last_error(void);
+const char *skx_version(void);
+int skx_device_count(void);
+/* name (<= name_cap bytes), number of CUs and bytes of device memory of `device` */
+int skx_device_info(int device, char *name, size_t name_cap, int *compute_units, uint64_t *total_mem);
+
+/* ---- reference sketch collection, resident in HBM --------------------------------- */
+/*
+ * hashes: genome g's ascending distinct 64-bit hashes at [g*s, g*s + col_len[g]), col_len[g] <= s.
+ * k, seed, s are the reference's sketch parameters (reads are sketched with the same ones,
+ * src/sketchy.rs:82/:331).  The library keeps its own device copy (a tiled, rank-major
+ * s x N matrix); `hashes` may be freed after the call.
+ */
+int skx_ref_create(skx_ref **out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
+                   const uint64_t *hashes, const uint32_t *col_len);
+int skx_ref_n_genomes(const skx_ref *ref, uint32_t *n_genomes);
+/* bytes of reference hashes one scoring pass streams from HBM (8*s*n_genomes) */
+int skx_ref_pass_bytes(const skx_ref *ref, uint64_t *bytes);
+void skx_ref_destroy(skx_ref *ref);
+
+/* ---- streaming predictor ----------------------------------------------------------- */
+/*
+ * top_k: rows ranked after every read, 0..min(n_genomes, SKX_MAX_TOP) (0 = no per-read ranking,
+ * table only).  max_batch_reads / max_batch_bases bound one skx_stream_push call.
+ */
+int skx_stream_create(skx_stream **out, const skx_ref *ref, uint32_t top_k, uint32_t max_batch_reads,
+                      uint64_t max_batch_bases);
+/*
+ * Consume n_reads reads: read r is the raw (un-normalised) ASCII bytes bases[offsets[r] .. offsets[r+1]).
+ * Outputs are optional (NULL to skip), caller-allocated host arrays:
+ *   topk_idx [n_reads][top_k]  genome indices after that read, order = (cumulative sum desc, index asc)
+ *   topk_sum [n_reads][top_k]  the cumulative sums of those genomes after that read
+ *   per_read_shared [n_reads][n_genomes]  this read's shared-hash count per genome (parity/debug)
+ *   sketches [n_reads][s], sketch_len [n_reads]  the read's bottom-s sketch, ascending (parity/debug)
+ * Synchronous: on return the running table includes these reads.
+ */
+int skx_stream_push(skx_stream *st, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                    uint32_t *topk_idx, uint64_t *topk_sum, uint32_t *per_read_shared, uint64_t *sketches,
+                    uint32_t *sketch_len);
+/*
+ * Same, with every pointer a DEVICE pointer on the stream's device (bench path: inputs already
+ * resident in HBM; only the optional topk outputs are produced).  Asynchronous on the stream's
+ * HIP stream except for the library's own internal synchronisation points; call
+ * skx_stream_sync() before reading the outputs.
+ */
+int skx_stream_push_device(skx_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                           uint64_t n_bases, uint32_t *d_topk_idx, uint64_t *d_topk_sum);
+int skx_stream_sync(skx_stream *st);
+/* running sum-of-shared-hashes table, u64[n_genomes] (host) */
+int skx_stream_table(skx_stream *st, uint64_t *cum);
+/* cum[g] += add[g]: resume from a checkpoint, or offset a shard by the totals of earlier shards */
+int skx_stream_table_add(skx_stream *st, const uint64_t *add);
+/* zero the table and the read counter */
+int skx_stream_reset(skx_stream *st);
+/* reads consumed so far (the reference's `read` counter minus one, src/sketchy.rs:327/:350) */
+int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
+/* rank the CURRENT table: first top_k of (sum desc, index asc); idx/sum are host arrays [top_k] */
+int skx_stream_rank(skx_stream *st, uint32_t top_k, uint32_t *idx, uint64_t *sum);
+void skx_stream_destroy(skx_stream *st);
+
+/*
+ * Per-stage device time, measured with HIP events on the stream's own HIP stream when enabled.
+ * Stages: 0 sketch, 1 dictionary (sort/unique/windows), 2 reference scan (the roofline kernel),
+ * 3 bit-matrix transpose, 4 rank (segment sums, prefix, per-read top-k, merge).
+ */
+#define SKX_N_STAGES 5
+int skx_stream_set_profiling(skx_stream *st, int enabled);
+/* ms[SKX_N_STAGES] accumulated milliseconds, launches[SKX_N_STAGES] timed intervals; resets the counters */
+int skx_stream_profile(skx_stream *st, double *ms, uint64_t *launches);
+
+/* ---- stand-alone operators (parity / `shared` subcommand) --------------------------- */
+/* sketch n_reads reads with (k, seed, s); outputs as in skx_stream_push (host arrays) */
+int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, const uint8_t *bases,
+                     const uint64_t *offsets, uint32_t n_reads, uint64_t *sketches, uint32_t *sketch_len);
+/*
+ * common[q][g] = |query sketch q  intersect  reference genome g|  (src/sketchy.rs:419-438) for
+ * n_query ascending sketches laid out like skx_ref_create's input (row stride q_stride).
+ */
+int skx_common_hashes(const skx_ref *ref, const uint64_t *query, const uint32_t *query_len, uint32_t n_query,
+                      uint32_t q_stride, uint32_t *common);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------- */
+#define SKX_COMM_ID_BYTES 128
+int skx_comm_unique_id(uint8_t id[SKX_COMM_ID_BYTES]);                 /* rank 0; broadcast it out of band */
+int skx_comm_create(skx_comm **out, int device, int rank, int n_ranks, const uint8_t id[SKX_COMM_ID_BYTES]);
+/* in-place sum of the running tables of all ranks' streams (u64, exact) */
+int skx_stream_allreduce(skx_stream *st, skx_comm *comm);
+void skx_comm_destroy(skx_comm *comm);
+
+/* ---- raw device buffers (so a host without a HIP binding can stage inputs in HBM) ---- */
+int skx_dev_malloc(int device, void **d_ptr, size_t bytes);
+int skx_dev_free(int device, void *d_ptr);
+int skx_dev_upload(int device, void *d_dst, const void *h_src, size_t bytes);
+int skx_dev_download(int device, void *h_dst, const void *d_src, size_t bytes);
+int skx_dev_synchronize(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKETCHY_HIP_H */

@@ -1,0 +1,347 @@
+/*
+ * oracle.c -- CPU restatement of sketchy's streaming read-vs-reference MinHash path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call anything in oracle/.  The
+ * product path (sketchy_amd/, libsketchy_hip.so) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference (esteinig/sketchy v0.6.0, Rust) ships no tests, golden
+ * vectors or fixtures for this path, and its toolchain (cargo/rustc) and its crates
+ * (finch 0.4.1, murmurhash3 0.0.5, needletail 0.4.1 -- Cargo.lock:220-236, :341-345,
+ * :360-372) are absent here, so it cannot be run to generate any.  This file restates
+ * the published algorithms of those crates and follows the reference's own call sites;
+ * it is pinned only by public MurmurHash3 known answers (SMHasher verification value
+ * 0x6384BA69, mmh3.hash64("foo")) and by self-consistency vectors (tests/golden/).
+ *
+ * What follows what (paths under /root/reference):
+ *   orc_murmur3_x64_128   murmurhash3 0.0.5 src/mmh3_128.rs (canonical MurmurHash3_x64_128,
+ *                         u64 seed into both lanes); finch hash_f keeps .0
+ *                         (finch 0.4.1 src/sketch_schemes/hashing.rs)
+ *   orc_normalize         needletail 0.4.1 src/sequence.rs normalize(seq, iupac=false)
+ *   orc_sketch_heap       finch 0.4.1 src/sketch_schemes/mash.rs MashSketcher::{new,process,
+ *                         push,to_vec}; called at src/sketchy.rs:331-335
+ *   orc_sketch_sort       the net semantics of the above, an
+ *                         independent second implementation used to cross-check the heap one
+ *   orc_common_hashes     src/sketchy.rs:419-459 (_common_hashes; min_scale = 0 for Mash
+ *                         sketches, :84-87, so the tail loops :441-457 are not taken)
+ *   orc_stream            src/sketchy.rs:317-356 (_sum_of_shared_hashes) with the stable
+ *                         descending sort of :348 and the top rows of :391
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ murmur3 x64 128 */
+
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+static inline uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+static inline uint64_t load_le64(const uint8_t *p) {
+    uint64_t v = 0;
+    for (int i = 7; i >= 0; --i) v = (v << 8) | p[i];
+    return v;
+}
+
+ORC_EXPORT void orc_murmur3_x64_128(const uint8_t *key, uint64_t len, uint64_t seed, uint64_t out[2]) {
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    uint64_t h1 = seed, h2 = seed;
+    const uint64_t nblocks = len / 16;
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        uint64_t k1 = load_le64(key + 16 * b), k2 = load_le64(key + 16 * b + 8);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+    }
+    const uint8_t *tail = key + 16 * nblocks;
+    uint64_t k1 = 0, k2 = 0;
+    switch (len & 15) {
+    case 15: k2 ^= (uint64_t)tail[14] << 48; /* fallthrough */
+    case 14: k2 ^= (uint64_t)tail[13] << 40; /* fallthrough */
+    case 13: k2 ^= (uint64_t)tail[12] << 32; /* fallthrough */
+    case 12: k2 ^= (uint64_t)tail[11] << 24; /* fallthrough */
+    case 11: k2 ^= (uint64_t)tail[10] << 16; /* fallthrough */
+    case 10: k2 ^= (uint64_t)tail[9] << 8;   /* fallthrough */
+    case 9:  k2 ^= (uint64_t)tail[8];
+             k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; /* fallthrough */
+    case 8:  k1 ^= (uint64_t)tail[7] << 56; /* fallthrough */
+    case 7:  k1 ^= (uint64_t)tail[6] << 48; /* fallthrough */
+    case 6:  k1 ^= (uint64_t)tail[5] << 40; /* fallthrough */
+    case 5:  k1 ^= (uint64_t)tail[4] << 32; /* fallthrough */
+    case 4:  k1 ^= (uint64_t)tail[3] << 24; /* fallthrough */
+    case 3:  k1 ^= (uint64_t)tail[2] << 16; /* fallthrough */
+    case 2:  k1 ^= (uint64_t)tail[1] << 8;  /* fallthrough */
+    case 1:  k1 ^= (uint64_t)tail[0];
+             k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2; h2 += h1;
+    out[0] = h1; out[1] = h2;
+}
+
+/* finch hash_f: murmurhash3_x64_128(item, seed).0 */
+static inline uint64_t hash_f(const uint8_t *kmer, uint32_t k, uint64_t seed) {
+    uint64_t o[2];
+    orc_murmur3_x64_128(kmer, k, seed, o);
+    return o[0];
+}
+
+/* ------------------------------------------------------------------ normalise / canonical */
+
+/* needletail normalize(seq, false): returns number of bytes written to out (<= n). */
+ORC_EXPORT uint64_t orc_normalize(const uint8_t *seq, uint64_t n, uint8_t *out) {
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t c = seq[i], o;
+        switch (c) {
+        case 'A': case 'C': case 'G': case 'T': case 'N': case '-': o = c; break;
+        case 'a': o = 'A'; break;
+        case 'c': o = 'C'; break;
+        case 'g': o = 'G'; break;
+        case 't': case 'u': case 'U': o = 'T'; break;
+        case '.': case '~': o = '-'; break;
+        case ' ': case '\t': case '\r': case '\n': continue; /* whitespace removed */
+        default: o = 'N'; break; /* IUPAC codes are not allowed -> N */
+        }
+        out[w++] = o;
+    }
+    return w;
+}
+
+static inline uint8_t complement(uint8_t c) {
+    switch (c) {
+    case 'A': return 'T';
+    case 'T': return 'A';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    default:  return c; /* N, - unchanged; such windows are skipped anyway */
+    }
+}
+
+static inline int is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
+/*
+ * Enumerate the canonical k-mers of an (un-normalised) sequence in position order and
+ * write their hashes to out (capacity >= n).  Returns the number of valid k-mers.
+ * needletail CanonicalKmers: windows with any non-ACGT byte are skipped;
+ * canonical = fwd if fwd < rc (bytewise) else rc.
+ */
+ORC_EXPORT uint64_t orc_kmer_hashes(const uint8_t *seq, uint64_t n, uint32_t k, uint64_t seed,
+                                    uint64_t *out, uint8_t *is_rc /* may be NULL */) {
+    if (k == 0 || k > 255) return 0;
+    uint8_t *norm = (uint8_t *)malloc(n + 1), *rc = (uint8_t *)malloc(n + 1);
+    uint64_t L = orc_normalize(seq, n, norm), m = 0;
+    for (uint64_t i = 0; i < L; ++i) rc[i] = complement(norm[L - 1 - i]);
+    if (L >= k) {
+        uint64_t bad = 0; /* number of non-ACGT bytes in the current window */
+        for (uint64_t i = 0; i < k - 1; ++i) bad += !is_acgt(norm[i]);
+        for (uint64_t p = 0; p + k <= L; ++p) {
+            bad += !is_acgt(norm[p + k - 1]);
+            if (bad == 0) {
+                const uint8_t *fwd = norm + p, *rev = rc + (L - p - k);
+                int use_rc = !(memcmp(fwd, rev, k) < 0);
+                out[m] = hash_f(use_rc ? rev : fwd, k, seed);
+                if (is_rc) is_rc[m] = (uint8_t)use_rc;
+                ++m;
+            }
+            bad -= !is_acgt(norm[p]);
+        }
+    }
+    free(norm); free(rc);
+    return m;
+}
+
+/* ------------------------------------------------------------------ bottom-s sketchers */
+
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* net semantics: ascending min(s, #distinct) smallest distinct hashes */
+static uint64_t bottom_s_sort(uint64_t *h, uint64_t m, uint64_t s, uint64_t *out) {
+    qsort(h, m, sizeof(uint64_t), cmp_u64);
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < m && w < s; ++i)
+        if (i == 0 || h[i] != h[i - 1]) out[w++] = h[i];
+    return w;
+}
+
+ORC_EXPORT uint64_t orc_sketch_sort(const uint8_t *seq, uint64_t n, uint32_t k, uint64_t seed,
+                                    uint64_t s, uint64_t *out /* capacity >= s */) {
+    uint64_t *h = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+    uint64_t m = orc_kmer_hashes(seq, n, k, seed, h, NULL);
+    uint64_t w = bottom_s_sort(h, m, s, out);
+    free(h);
+    return w;
+}
+
+/*
+ * Faithful MashSketcher: binary max-heap of hashes bounded by s plus a membership set
+ * (finch keys a HashMap<u64,_> by hash with a pass-through hasher; here an open-addressing
+ * table with tombstone-free deletion by rebuild is overkill -- membership is tested on the
+ * heap's content through a small chained table).
+ */
+typedef struct { uint64_t *heap; uint64_t len, cap; uint64_t *tab; uint8_t *used; uint64_t tcap; } msk_t;
+
+static void set_insert(msk_t *m, uint64_t h) {
+    uint64_t i = (h * 0x9E3779B97F4A7C15ULL) >> 32;
+    for (i &= m->tcap - 1; m->used[i] == 1; i = (i + 1) & (m->tcap - 1)) {}
+    m->used[i] = 1; m->tab[i] = h;
+}
+static int set_contains(const msk_t *m, uint64_t h) {
+    uint64_t i = (h * 0x9E3779B97F4A7C15ULL) >> 32;
+    for (i &= m->tcap - 1; m->used[i] != 0; i = (i + 1) & (m->tcap - 1))
+        if (m->used[i] == 1 && m->tab[i] == h) return 1;
+    return 0;
+}
+static void set_remove(msk_t *m, uint64_t h) {
+    uint64_t i = (h * 0x9E3779B97F4A7C15ULL) >> 32;
+    for (i &= m->tcap - 1; m->used[i] != 0; i = (i + 1) & (m->tcap - 1))
+        if (m->used[i] == 1 && m->tab[i] == h) { m->used[i] = 2; return; } /* tombstone */
+}
+static void heap_push(msk_t *m, uint64_t h) {
+    uint64_t i = m->len++;
+    m->heap[i] = h;
+    while (i > 0) {
+        uint64_t p = (i - 1) / 2;
+        if (m->heap[p] >= m->heap[i]) break;
+        uint64_t t = m->heap[p]; m->heap[p] = m->heap[i]; m->heap[i] = t; i = p;
+    }
+}
+static uint64_t heap_pop(msk_t *m) {
+    uint64_t top = m->heap[0];
+    m->heap[0] = m->heap[--m->len];
+    uint64_t i = 0;
+    for (;;) {
+        uint64_t l = 2 * i + 1, r = l + 1, b = i;
+        if (l < m->len && m->heap[l] > m->heap[b]) b = l;
+        if (r < m->len && m->heap[r] > m->heap[b]) b = r;
+        if (b == i) break;
+        uint64_t t = m->heap[b]; m->heap[b] = m->heap[i]; m->heap[i] = t; i = b;
+    }
+    return top;
+}
+
+ORC_EXPORT uint64_t orc_sketch_heap(const uint8_t *seq, uint64_t n, uint32_t k, uint64_t seed,
+                                    uint64_t s, uint64_t *out /* capacity >= s */) {
+    uint64_t *h = (uint64_t *)malloc((n + 1) * sizeof(uint64_t));
+    uint64_t nk = orc_kmer_hashes(seq, n, k, seed, h, NULL);
+    msk_t m;
+    m.cap = s + 1; m.len = 0;
+    m.heap = (uint64_t *)malloc((m.cap + 1) * sizeof(uint64_t));
+    /* tombstones accumulate with evictions: size for every push ever made */
+    m.tcap = 64; while (m.tcap < 4 * (nk + 1)) m.tcap <<= 1;
+    m.tab = (uint64_t *)malloc(m.tcap * sizeof(uint64_t));
+    m.used = (uint8_t *)calloc(m.tcap, 1);
+    for (uint64_t i = 0; i < nk; ++i) {
+        uint64_t nh = h[i];
+        /* MashSketcher::push */
+        int add = (m.len == 0) || (nh <= m.heap[0]) || (m.len < s);
+        if (!add) continue;
+        if (set_contains(&m, nh)) continue; /* count bump only */
+        heap_push(&m, nh);
+        set_insert(&m, nh);
+        if (m.len > s) { uint64_t ev = heap_pop(&m); set_remove(&m, ev); }
+    }
+    /* to_vec: into_sorted_vec ascending */
+    uint64_t w = m.len;
+    memcpy(out, m.heap, w * sizeof(uint64_t));
+    qsort(out, w, sizeof(uint64_t), cmp_u64);
+    free(h); free(m.heap); free(m.tab); free(m.used);
+    return w;
+}
+
+/* ------------------------------------------------------------------ intersection */
+
+/* src/sketchy.rs:425-438 two-pointer merge; both ascending */
+ORC_EXPORT uint64_t orc_common_hashes(const uint64_t *ref_h, uint64_t nref, const uint64_t *query_h, uint64_t nq) {
+    uint64_t i = 0, j = 0, common = 0;
+    while (i < nq && j < nref) {
+        if (query_h[i] < ref_h[j]) ++i;
+        else if (query_h[i] > ref_h[j]) ++j;
+        else { ++common; ++i; ++j; }
+    }
+    return common;
+}
+
+/* ------------------------------------------------------------------ stable rank */
+
+/* stable merge sort of idx by sum descending == Rust sort_by(|a,b| b.1.cmp(&a.1)) on (i,sum[i]) */
+static void stable_rank(const uint64_t *sum, uint32_t n, uint32_t *idx, uint32_t *tmp) {
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+    for (uint32_t w = 1; w < n; w *= 2) {
+        for (uint32_t lo = 0; lo < n; lo += 2 * w) {
+            uint32_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            uint32_t a = lo, b = mid, o = lo;
+            while (a < mid && b < hi) {
+                /* take from the right run only if strictly greater: keeps equal sums in index order */
+                if (sum[idx[b]] > sum[idx[a]]) tmp[o++] = idx[b++]; else tmp[o++] = idx[a++];
+            }
+            while (a < mid) tmp[o++] = idx[a++];
+            while (b < hi) tmp[o++] = idx[b++];
+        }
+        memcpy(idx, tmp, n * sizeof(uint32_t));
+    }
+}
+
+ORC_EXPORT void orc_stable_rank(const uint64_t *sum, uint32_t n, uint32_t *idx_out) {
+    uint32_t *tmp = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+    stable_rank(sum, n, idx_out, tmp);
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ streaming driver */
+
+/*
+ * _sum_of_shared_hashes (src/sketchy.rs:317-356) over a packed batch of reads.
+ *   ref_hashes: genome g's ascending hashes at [g*s, g*s + col_len[g])
+ *   cum:        in/out running table (u64[n_genomes]); start with zeros for a fresh stream
+ * Optional outputs (NULL to skip): topk_idx/topk_sum [n_reads][top_k], per_read_shared
+ * [n_reads][n_genomes], sketches [n_reads][s] + sketch_len [n_reads].
+ * rank_every_read = 0 skips the per-read sort (used only to time the scoring loop alone).
+ */
+ORC_EXPORT int orc_stream(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
+                          const uint64_t *ref_hashes, const uint32_t *col_len,
+                          const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                          uint32_t top_k, uint64_t *cum,
+                          uint32_t *topk_idx, uint64_t *topk_sum, uint32_t *per_read_shared,
+                          uint64_t *sketches, uint32_t *sketch_len, int rank_every_read) {
+    if (top_k > n_genomes) return -1; /* the reference panics on [..top] (src/sketchy.rs:391) */
+    uint64_t *sk = (uint64_t *)malloc(((uint64_t)s + 1) * sizeof(uint64_t));
+    uint32_t *idx = (uint32_t *)malloc(((uint64_t)n_genomes + 1) * sizeof(uint32_t));
+    uint32_t *tmp = (uint32_t *)malloc(((uint64_t)n_genomes + 1) * sizeof(uint32_t));
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint8_t *seq = bases + offsets[r];
+        uint64_t n = offsets[r + 1] - offsets[r];
+        uint64_t len = orc_sketch_heap(seq, n, k, seed, s, sk); /* fresh sketcher per read, :331 */
+        if (sketches) memcpy(sketches + (uint64_t)r * s, sk, len * sizeof(uint64_t));
+        if (sketch_len) sketch_len[r] = (uint32_t)len;
+        for (uint32_t g = 0; g < n_genomes; ++g) { /* :337-347 */
+            uint64_t sh = orc_common_hashes(ref_hashes + (uint64_t)g * s, col_len[g], sk, len);
+            cum[g] += sh;
+            if (per_read_shared) per_read_shared[(uint64_t)r * n_genomes + g] = (uint32_t)sh;
+        }
+        if (rank_every_read && top_k > 0) { /* :348-349 */
+            stable_rank(cum, n_genomes, idx, tmp);
+            for (uint32_t t = 0; t < top_k; ++t) {
+                if (topk_idx) topk_idx[(uint64_t)r * top_k + t] = idx[t];
+                if (topk_sum) topk_sum[(uint64_t)r * top_k + t] = cum[idx[t]];
+            }
+        }
+    }
+    free(sk); free(idx); free(tmp);
+    return 0;
+}

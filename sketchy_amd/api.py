@@ -1,0 +1,216 @@
+"""Thin Python handles over the C ABI (numpy in, numpy out; no torch, no CPU fallback).
+
+Names follow the reference's own vocabulary for this path:
+  ReferenceSketch              the `Vec<Sketch>` returned by Sketchy::_read_sketch (src/sketchy.rs:497-536)
+  SumOfSharedHashes            the state and loop body of Sketchy::_sum_of_shared_hashes (src/sketchy.rs:317-356)
+  common_hashes / sketch_reads Sketchy::_common_hashes (:419-459) and finch's process/to_vec (:331-335)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    return _lib.load().skx_device_count()
+
+
+def device_info(device=0):
+    L = _lib.load()
+    name = C.create_string_buffer(256)
+    cu, mem = C.c_int(0), C.c_uint64(0)
+    _lib.check(L.skx_device_info(device, name, 256, C.byref(cu), C.byref(mem)))
+    return dict(name=name.value.decode(), compute_units=cu.value, total_mem=mem.value)
+
+
+class ReferenceSketch:
+    """Reference sketch collection resident in HBM.  hashes: [n_genomes, s] uint64, row g =
+    genome g's ascending distinct hashes, first col_len[g] valid."""
+
+    def __init__(self, hashes, col_len=None, k=16, seed=0, device=0):
+        L = _lib.load()
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        if hashes.ndim != 2:
+            raise ValueError("hashes must be [n_genomes, s]")
+        self.n_genomes, self.s = int(hashes.shape[0]), int(hashes.shape[1])
+        col_len = np.full(self.n_genomes, self.s, np.uint32) if col_len is None else np.ascontiguousarray(col_len, np.uint32)
+        self.k, self.seed, self.device = int(k), int(seed), int(device)
+        h = C.c_void_p()
+        _lib.check(L.skx_ref_create(C.byref(h), device, self.k, self.seed, self.s, self.n_genomes, _p(hashes), _p(col_len)))
+        self._h = h
+
+    @property
+    def pass_bytes(self) -> int:
+        b = C.c_uint64(0)
+        _lib.check(_lib.load().skx_ref_pass_bytes(self._h, C.byref(b)))
+        return b.value
+
+    def common_hashes(self, query, query_len=None) -> np.ndarray:
+        """[n_query, n_genomes] uint32 intersection sizes (Sketchy::_common_hashes for every pair)."""
+        query = np.ascontiguousarray(query, np.uint64)
+        nq, stride = query.shape
+        query_len = np.full(nq, stride, np.uint32) if query_len is None else np.ascontiguousarray(query_len, np.uint32)
+        out = np.zeros((nq, self.n_genomes), np.uint32)
+        _lib.check(_lib.load().skx_common_hashes(self._h, _p(query), _p(query_len), nq, stride, _p(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().skx_ref_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SumOfSharedHashes:
+    """Streaming predictor: running sum-of-shared-hashes table + per-read top rows."""
+
+    def __init__(self, ref: ReferenceSketch, top=1, max_batch_reads=4096, max_batch_bases=None):
+        L = _lib.load()
+        self.ref, self.top = ref, int(top)
+        self.max_batch_reads = int(max_batch_reads)
+        self.max_batch_bases = int(max_batch_bases if max_batch_bases is not None else max_batch_reads * 2063)
+        h = C.c_void_p()
+        _lib.check(L.skx_stream_create(C.byref(h), ref._h, self.top, self.max_batch_reads, self.max_batch_bases))
+        self._h = h
+
+    def push(self, bases, offsets, want_shared=False, want_sketches=False):
+        """Consume a packed batch; returns dict(topk_idx, topk_sum[, shared, sketches, sketch_len])."""
+        L = _lib.load()
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        out = {}
+        ti = np.zeros((n, self.top), np.uint32) if self.top else None
+        ts = np.zeros((n, self.top), np.uint64) if self.top else None
+        sh = np.zeros((n, self.ref.n_genomes), np.uint32) if want_shared else None
+        sk = np.zeros((n, self.ref.s), np.uint64) if want_sketches else None
+        sl = np.zeros(n, np.uint32) if want_sketches else None
+        b = bases if len(bases) else np.zeros(1, np.uint8)
+        _lib.check(L.skx_stream_push(self._h, _p(b), _p(offsets), n, _p(ti), _p(ts), _p(sh), _p(sk), _p(sl)))
+        out.update(topk_idx=ti, topk_sum=ts, shared=sh, sketches=sk, sketch_len=sl)
+        return out
+
+    def push_device(self, d_bases, d_offsets, n_reads, n_bases, d_topk_idx=None, d_topk_sum=None):
+        _lib.check(_lib.load().skx_stream_push_device(self._h, d_bases, d_offsets, n_reads, n_bases, d_topk_idx, d_topk_sum))
+
+    def sync(self):
+        _lib.check(_lib.load().skx_stream_sync(self._h))
+
+    def table(self) -> np.ndarray:
+        cum = np.zeros(self.ref.n_genomes, np.uint64)
+        _lib.check(_lib.load().skx_stream_table(self._h, _p(cum)))
+        return cum
+
+    def table_add(self, add):
+        add = np.ascontiguousarray(add, np.uint64)
+        assert len(add) == self.ref.n_genomes
+        _lib.check(_lib.load().skx_stream_table_add(self._h, _p(add)))
+
+    def reset(self):
+        _lib.check(_lib.load().skx_stream_reset(self._h))
+
+    @property
+    def reads(self) -> int:
+        n = C.c_uint64(0)
+        _lib.check(_lib.load().skx_stream_reads(self._h, C.byref(n)))
+        return n.value
+
+    def rank(self, top=None):
+        top = self.top if top is None else int(top)
+        idx, sm = np.zeros(top, np.uint32), np.zeros(top, np.uint64)
+        _lib.check(_lib.load().skx_stream_rank(self._h, top, _p(idx), _p(sm)))
+        return idx, sm
+
+    def set_profiling(self, on=True):
+        _lib.check(_lib.load().skx_stream_set_profiling(self._h, 1 if on else 0))
+
+    def profile(self):
+        ms = (C.c_double * _lib.N_STAGES)()
+        n = (C.c_uint64 * _lib.N_STAGES)()
+        _lib.check(_lib.load().skx_stream_profile(self._h, ms, n))
+        return {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.STAGE_NAMES)}
+
+    def allreduce(self, comm):
+        _lib.check(_lib.load().skx_stream_allreduce(self._h, comm._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().skx_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator (one process per GPU)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        _lib.check(_lib.load().skx_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, device, rank, n_ranks, uid: bytes):
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(uid)
+        h = C.c_void_p()
+        _lib.check(_lib.load().skx_comm_create(C.byref(h), device, rank, n_ranks, buf))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().skx_comm_destroy(self._h)
+            self._h = None
+
+
+def sketch_reads(bases, offsets, k=16, seed=0, s=1000, device=0):
+    """finch MashSketcher process/to_vec per read: ([n_reads, s] uint64 ascending, lengths)."""
+    bases = np.ascontiguousarray(bases, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    n = len(offsets) - 1
+    sk = np.zeros((n, s), np.uint64)
+    sl = np.zeros(n, np.uint32)
+    b = bases if len(bases) else np.zeros(1, np.uint8)
+    _lib.check(_lib.load().skx_sketch_reads(device, k, seed, s, _p(b), _p(offsets), n, _p(sk), _p(sl)))
+    return sk, sl
+
+
+class DeviceBuffer:
+    """A raw HBM allocation (bench path: inputs resident on the device before timing starts)."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        _lib.check(_lib.load().skx_dev_malloc(device, C.byref(p), self.nbytes))
+        self.ptr = p
+
+    @classmethod
+    def from_numpy(cls, a, device=0):
+        a = np.ascontiguousarray(a)
+        buf = cls(max(a.nbytes, 1), device)
+        if a.nbytes:
+            _lib.check(_lib.load().skx_dev_upload(device, buf.ptr, _p(a), a.nbytes))
+        return buf
+
+    def to_numpy(self, dtype, shape):
+        out = np.zeros(shape, dtype)
+        _lib.check(_lib.load().skx_dev_download(self.device, _p(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.load().skx_dev_free(self.device, self.ptr)
+            self.ptr = None

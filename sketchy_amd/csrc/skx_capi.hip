@@ -1,0 +1,754 @@
+// skx_capi.hip -- implementation of the C ABI declared in include/sketchy_hip.h.
+//
+// Host-side orchestration of one skx_stream_push (the body of the reference's hot loop,
+// src/sketchy.rs:328-354, for a whole batch of reads):
+//   sketch every read -> cut the batch into passes that fit the pass workspace ->
+//   per pass: dictionary (sort/unique of the query hashes that can match), windows,
+//   reference scan, bit transpose, running table + per-read top-k.
+// No CPU fallback exists: without a HIP device the calls fail with SKX_ERR_NO_DEVICE.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sketchy_hip.h"
+#include "skx_common.hpp"
+#include "skx_kernels.hpp"
+
+using skx::u32;
+using skx::u64;
+
+#define SKX_API extern "C" __attribute__((visibility("default")))
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(SKX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define SKXCHK(expr)             \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != SKX_OK) return rc_; \
+    } while (0)
+
+SKX_API const char* skx_last_error(void) { return g_err.c_str(); }
+SKX_API const char* skx_version(void) { return "sketchy-hip 0.1.0 (gfx950)"; }
+
+SKX_API int skx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+static int use_device(int device) {
+    int n = skx_device_count();
+    if (n <= 0) return fail(SKX_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(SKX_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    return SKX_OK;
+}
+SKX_API int skx_device_info(int device, char* name, size_t name_cap, int* compute_units, uint64_t* total_mem) {
+    SKXCHK(use_device(device));
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (total_mem) *total_mem = p.totalGlobalMem;
+    return SKX_OK;
+}
+
+// ------------------------------------------------------------------ raw device buffers
+SKX_API int skx_dev_malloc(int device, void** d_ptr, size_t bytes) {
+    if (!d_ptr) return fail(SKX_ERR_INVALID, "d_ptr is NULL");
+    SKXCHK(use_device(device));
+    HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return SKX_OK;
+}
+SKX_API int skx_dev_free(int device, void* d_ptr) {
+    SKXCHK(use_device(device));
+    HIPCHK(hipFree(d_ptr));
+    return SKX_OK;
+}
+SKX_API int skx_dev_upload(int device, void* d_dst, const void* h_src, size_t bytes) {
+    SKXCHK(use_device(device));
+    HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return SKX_OK;
+}
+SKX_API int skx_dev_download(int device, void* h_dst, const void* d_src, size_t bytes) {
+    SKXCHK(use_device(device));
+    HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return SKX_OK;
+}
+SKX_API int skx_dev_synchronize(int device) {
+    SKXCHK(use_device(device));
+    HIPCHK(hipDeviceSynchronize());
+    return SKX_OK;
+}
+
+// ------------------------------------------------------------------ reference
+struct skx_ref {
+    int device = 0;
+    u32 k = 0, s = 0, n_genomes = 0, n_tiles = 0, n_pad = 0, rb = 0, n_bands = 0;
+    u64 seed = 0;
+    u64* d_mat = nullptr;  // [n_tiles][s][256]
+    u64 *d_lo = nullptr, *d_hi = nullptr;  // [n_bands * n_tiles]
+    u64 max_ref = 0;       // largest hash in the matrix (queries above it cannot match)
+    bool any = false;      // at least one real hash
+    u32 n_exc = 0;         // hashes >= kEmpty lifted out of the matrix
+    u32* d_exc_g = nullptr;
+    u64* d_exc_h = nullptr;
+};
+
+static void ref_free(skx_ref* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    (void)hipFree(r->d_mat); (void)hipFree(r->d_lo); (void)hipFree(r->d_hi);
+    (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h);
+    delete r;
+}
+
+SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
+                           const uint64_t* hashes, const uint32_t* col_len) {
+    if (!out || !hashes || !col_len) return fail(SKX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (k < 1 || k > SKX_MAX_K) return fail(SKX_ERR_INVALID, "k=%u outside 1..%u", k, SKX_MAX_K);
+    if (s < 1 || n_genomes < 1) return fail(SKX_ERR_INVALID, "empty reference (s=%u, n_genomes=%u)", s, n_genomes);
+    SKXCHK(use_device(device));
+
+    // validate (the reference assumes ascending columns, src/sketchy.rs:416-418; here it is checked)
+    std::vector<u32> eff(n_genomes);
+    std::vector<u32> exc_g;
+    std::vector<u64> exc_h;
+    u64 max_ref = 0;
+    bool any = false;
+    for (u32 g = 0; g < n_genomes; ++g) {
+        const u32 len = col_len[g];
+        if (len > s) return fail(SKX_ERR_INVALID, "col_len[%u]=%u exceeds s=%u", g, len, s);
+        const uint64_t* col = hashes + (size_t)g * s;
+        for (u32 i = 1; i < len; ++i)
+            if (col[i] <= col[i - 1]) return fail(SKX_ERR_UNSORTED, "genome %u: hashes not strictly ascending at %u", g, i);
+        u32 e = len;
+        while (e > 0 && col[e - 1] >= skx::kEmpty) {  // would alias table markers: handled as exceptions
+            exc_g.push_back(g); exc_h.push_back(col[e - 1]); --e;
+        }
+        eff[g] = e;
+        if (e > 0) { any = true; max_ref = std::max<u64>(max_ref, col[e - 1]); }
+    }
+    if (!exc_h.empty()) { any = true; max_ref = std::max<u64>(max_ref, *std::max_element(exc_h.begin(), exc_h.end())); }
+
+    skx_ref* r = new skx_ref;
+    r->device = device; r->k = k; r->seed = seed; r->s = s; r->n_genomes = n_genomes;
+    r->n_tiles = (n_genomes + skx::kTileGenomes - 1) / skx::kTileGenomes;
+    r->n_pad = r->n_tiles * skx::kTileGenomes;
+    r->rb = 64;
+    r->n_bands = (s + r->rb - 1) / r->rb;
+    r->max_ref = max_ref; r->any = any;
+    r->n_exc = (u32)exc_h.size();
+
+    hipError_t e;
+#define RCHK(expr) do { e = (expr); if (e != hipSuccess) { ref_free(r); return fail(SKX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
+    const size_t mat_elems = (size_t)r->n_tiles * s * skx::kTileGenomes;
+    RCHK(hipMalloc(&r->d_mat, mat_elems * 8));
+    RCHK(hipMalloc(&r->d_lo, (size_t)r->n_bands * r->n_tiles * 8));
+    RCHK(hipMalloc(&r->d_hi, (size_t)r->n_bands * r->n_tiles * 8));
+    u32* d_eff = nullptr;
+    RCHK(hipMalloc(&d_eff, (size_t)n_genomes * 4));
+    RCHK(hipMemcpy(d_eff, eff.data(), (size_t)n_genomes * 4, hipMemcpyHostToDevice));
+    // upload in chunks of whole tiles (bounded staging), re-tiling on the device
+    const u32 chunk_tiles = std::max<u32>(1u, (u32)((256ull << 20) / ((size_t)skx::kTileGenomes * s * 8)));
+    const u32 chunk_g = chunk_tiles * skx::kTileGenomes;
+    u64* d_stage = nullptr;
+    RCHK(hipMalloc(&d_stage, (size_t)std::min<u32>(chunk_g, r->n_pad) * s * 8));
+    for (u32 g0 = 0; g0 < n_genomes; g0 += chunk_g) {
+        const u32 cnt = std::min<u32>(chunk_g, n_genomes - g0);
+        RCHK(hipMemcpy(d_stage, hashes + (size_t)g0 * s, (size_t)cnt * s * 8, hipMemcpyHostToDevice));
+        const u32 cnt_pad = ((cnt + skx::kTileGenomes - 1) / skx::kTileGenomes) * skx::kTileGenomes;
+        skx::launch_ref_tile(nullptr, d_stage, d_eff, r->d_mat, s, g0, n_genomes, cnt_pad);
+        RCHK(hipGetLastError());
+        RCHK(hipDeviceSynchronize());
+    }
+    (void)hipFree(d_stage);
+    (void)hipFree(d_eff);
+    skx::launch_band_bounds(nullptr, r->d_mat, s, r->n_tiles, r->rb, r->n_bands, r->d_lo, r->d_hi);
+    RCHK(hipGetLastError());
+    if (r->n_exc) {
+        RCHK(hipMalloc(&r->d_exc_g, (size_t)r->n_exc * 4));
+        RCHK(hipMalloc(&r->d_exc_h, (size_t)r->n_exc * 8));
+        RCHK(hipMemcpy(r->d_exc_g, exc_g.data(), (size_t)r->n_exc * 4, hipMemcpyHostToDevice));
+        RCHK(hipMemcpy(r->d_exc_h, exc_h.data(), (size_t)r->n_exc * 8, hipMemcpyHostToDevice));
+    }
+    RCHK(hipDeviceSynchronize());
+#undef RCHK
+    *out = r;
+    return SKX_OK;
+}
+SKX_API int skx_ref_n_genomes(const skx_ref* ref, uint32_t* n_genomes) {
+    if (!ref || !n_genomes) return fail(SKX_ERR_INVALID, "NULL argument");
+    *n_genomes = ref->n_genomes;
+    return SKX_OK;
+}
+SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
+    if (!ref || !bytes) return fail(SKX_ERR_INVALID, "NULL argument");
+    *bytes = 8ull * ref->s * ref->n_genomes;
+    return SKX_OK;
+}
+SKX_API void skx_ref_destroy(skx_ref* ref) { ref_free(ref); }
+
+// ------------------------------------------------------------------ stream
+struct TimedSpan { int stage; hipEvent_t a, b; };
+
+struct skx_stream {
+    const skx_ref* ref = nullptr;
+    int device = 0;
+    hipStream_t hs = nullptr;
+    u32 top_k = 0, max_reads = 0, sk_stride = 0;
+    u64 max_bases = 0;
+    u32 pcap = 0;        // pairs per pass
+    u32 rpass = 0;       // reads per pass
+    u64 reads_total = 0;
+    // staging for host pushes
+    uint8_t* d_bases = nullptr;
+    u64* d_offsets = nullptr;
+    // sketch outputs for the whole batch
+    u64* d_sk = nullptr;
+    u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
+    // pass workspace
+    u64 *d_pair_h = nullptr, *d_sorted = nullptr, *d_q = nullptr;
+    u32 *d_pair_r = nullptr, *d_pair_q = nullptr, *d_nq = nullptr, *d_win = nullptr;
+    u64 *d_m = nullptr, *d_mq = nullptr;
+    u32* d_inc = nullptr;
+    u64 *d_start = nullptr, *d_cand_sum = nullptr;
+    u32* d_cand_idx = nullptr;
+    u64* d_cum = nullptr;
+    u32* d_topk_idx = nullptr;
+    u64* d_topk_sum = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    u32* h_poff = nullptr;   // pinned
+    u64* h_offsets = nullptr;  // pinned
+    // profiling
+    bool profiling = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> ev_pool;
+    double ms[SKX_N_STAGES] = {0, 0, 0, 0, 0};
+    u64 launches[SKX_N_STAGES] = {0, 0, 0, 0, 0};
+};
+
+static void stream_free(skx_stream* st) {
+    if (!st) return;
+    (void)hipSetDevice(st->device);
+    if (st->hs) (void)hipStreamSynchronize(st->hs);
+    void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
+                    st->d_q, st->d_pair_r, st->d_pair_q, st->d_nq, st->d_win, st->d_m, st->d_mq, st->d_inc, st->d_start,
+                    st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_topk_idx, st->d_topk_sum, st->d_tmp};
+    for (void* p : ptrs) (void)hipFree(p);
+    if (st->h_poff) (void)hipHostFree(st->h_poff);
+    if (st->h_offsets) (void)hipHostFree(st->h_offsets);
+    for (auto& sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto ev : st->ev_pool) (void)hipEventDestroy(ev);
+    if (st->hs) (void)hipStreamDestroy(st->hs);
+    delete st;
+}
+
+static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_k, u32 max_reads, u64 max_bases,
+                                  u32 sk_stride) {
+    SKXCHK(use_device(ref->device));
+    skx_stream* st = new skx_stream;
+    st->ref = ref; st->device = ref->device; st->top_k = top_k; st->max_reads = max_reads; st->max_bases = max_bases;
+    st->sk_stride = sk_stride;
+    const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
+    // pass capacity: keep each of M / Mq around 256 MB, and never below one read's worth of pairs
+    u64 pc = (256ull << 20) * 8 / n_pad;
+    pc = std::min<u64>(pc, 1u << 20);
+    pc = std::max<u64>(pc, sk_stride);
+    pc = (pc + 63) / 64 * 64;
+    st->pcap = (u32)pc;
+    u64 rp = std::min<u64>(max_reads, 16384);
+    if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (1ull << 30) / ((u64)n_gw * top_k * 12)));
+    rp = std::max<u64>(rp, 1);
+    st->rpass = (u32)rp;
+    const u32 n_seg_max = (st->rpass + skx::kSegLen - 1) / skx::kSegLen;
+    const u32 n_bt = ref->n_bands * ref->n_tiles;
+
+    hipError_t e;
+#define SCHK(expr) do { e = (expr); if (e != hipSuccess) { stream_free(st); return fail(SKX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
+    SCHK(hipStreamCreateWithFlags(&st->hs, hipStreamNonBlocking));
+    SCHK(hipMalloc(&st->d_bases, std::max<u64>(max_bases, 1)));
+    SCHK(hipMalloc(&st->d_offsets, ((size_t)max_reads + 1) * 8));
+    SCHK(hipMalloc(&st->d_sk, (size_t)max_reads * sk_stride * 8));
+    SCHK(hipMalloc(&st->d_len, ((size_t)max_reads + 1) * 4));
+    SCHK(hipMalloc(&st->d_cnt, ((size_t)max_reads + 1) * 4));
+    SCHK(hipMalloc(&st->d_poff, ((size_t)max_reads + 2) * 4));
+    SCHK(hipMalloc(&st->d_pair_h, (size_t)st->pcap * 8));
+    SCHK(hipMalloc(&st->d_sorted, (size_t)st->pcap * 8));
+    SCHK(hipMalloc(&st->d_q, (size_t)st->pcap * 8));
+    SCHK(hipMalloc(&st->d_pair_r, (size_t)st->pcap * 4));
+    SCHK(hipMalloc(&st->d_pair_q, (size_t)st->pcap * 4));
+    SCHK(hipMalloc(&st->d_nq, 64));
+    SCHK(hipMalloc(&st->d_win, (size_t)n_bt * 8));
+    SCHK(hipMalloc(&st->d_m, (size_t)(st->pcap / 64) * n_pad * 8));
+    SCHK(hipMalloc(&st->d_mq, (size_t)st->pcap * n_gw * 8));
+    SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
+    SCHK(hipMalloc(&st->d_start, (size_t)n_seg_max * n_pad * 8));
+    if (top_k) {
+        SCHK(hipMalloc(&st->d_cand_sum, (size_t)st->rpass * n_gw * top_k * 8));
+        SCHK(hipMalloc(&st->d_cand_idx, (size_t)st->rpass * n_gw * top_k * 4));
+        SCHK(hipMalloc(&st->d_topk_idx, (size_t)max_reads * top_k * 4));
+        SCHK(hipMalloc(&st->d_topk_sum, (size_t)max_reads * top_k * 8));
+    }
+    SCHK(hipMalloc(&st->d_cum, (size_t)n_pad * 8));
+    SCHK(hipMemset(st->d_cum, 0, (size_t)n_pad * 8));
+    st->tmp_bytes = std::max({skx::prim_scan_tmp_bytes(max_reads + 1), skx::prim_sort_tmp_bytes(st->pcap),
+                              skx::prim_unique_tmp_bytes(st->pcap)}) + 256;
+    SCHK(hipMalloc(&st->d_tmp, st->tmp_bytes));
+    SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
+    SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
+#undef SCHK
+    *out = st;
+    return SKX_OK;
+}
+
+SKX_API int skx_stream_create(skx_stream** out, const skx_ref* ref, uint32_t top_k, uint32_t max_batch_reads,
+                              uint64_t max_batch_bases) {
+    if (!out || !ref) return fail(SKX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    // the reference slices result_vec[..top] and panics when top > N (src/sketchy.rs:391)
+    if (top_k > ref->n_genomes) return fail(SKX_ERR_INVALID, "top_k=%u exceeds n_genomes=%u", top_k, ref->n_genomes);
+    if (top_k > SKX_MAX_TOP) return fail(SKX_ERR_INVALID, "top_k=%u exceeds SKX_MAX_TOP=%u", top_k, SKX_MAX_TOP);
+    if (max_batch_reads < 1) return fail(SKX_ERR_INVALID, "max_batch_reads must be >= 1");
+    const u32 sk_stride = std::min<u32>(ref->s, (u32)skx::kSketchCap);
+    return stream_create_internal(out, ref, top_k, max_batch_reads, max_batch_bases, sk_stride);
+}
+SKX_API void skx_stream_destroy(skx_stream* st) { stream_free(st); }
+
+// ---- profiling spans
+static hipEvent_t get_event(skx_stream* st) {
+    if (!st->ev_pool.empty()) { hipEvent_t ev = st->ev_pool.back(); st->ev_pool.pop_back(); return ev; }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+struct Span {
+    skx_stream* st; int stage; hipEvent_t a = nullptr;
+    Span(skx_stream* s, int stg) : st(s), stage(stg) {
+        if (st->profiling) { a = get_event(st); (void)hipEventRecord(a, st->hs); }
+    }
+    ~Span() {
+        if (st->profiling) { hipEvent_t b = get_event(st); (void)hipEventRecord(b, st->hs); st->spans.push_back({stage, a, b}); }
+    }
+};
+static void collect_spans(skx_stream* st) {
+    for (auto& sp : st->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { st->ms[sp.stage] += ms; st->launches[sp.stage] += 1; }
+        st->ev_pool.push_back(sp.a); st->ev_pool.push_back(sp.b);
+    }
+    st->spans.clear();
+}
+SKX_API int skx_stream_set_profiling(skx_stream* st, int enabled) {
+    if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
+    st->profiling = enabled != 0;
+    return SKX_OK;
+}
+SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
+    if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
+    SKXCHK(use_device(st->device));
+    HIPCHK(hipStreamSynchronize(st->hs));
+    collect_spans(st);
+    for (int i = 0; i < SKX_N_STAGES; ++i) {
+        if (ms) ms[i] = st->ms[i];
+        if (launches) launches[i] = st->launches[i];
+        st->ms[i] = 0; st->launches[i] = 0;
+    }
+    return SKX_OK;
+}
+
+// ---- one pass: reads [ra, rb) of the batch, pairs [p_base, p_base + P)
+static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_topk_idx, u64* d_topk_sum,
+                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table) {
+    const skx_ref* ref = st->ref;
+    hipStream_t hs = st->hs;
+    const u32 n_pad = ref->n_pad, n_gw = n_pad / 64, n_reads = rb - ra;
+    const u32 n_bt = ref->n_bands * ref->n_tiles;
+    if (P > 0) {
+        const u32 n_words = (P + 63) / 64;
+        {
+            Span sp(st, 1);
+            skx::launch_gather_pairs(hs, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, st->d_pair_r);
+            HIPCHK(skx::prim_sort_u64(hs, st->d_tmp, st->tmp_bytes, st->d_pair_h, st->d_sorted, P));
+            HIPCHK(skx::prim_unique_u64(hs, st->d_tmp, st->tmp_bytes, st->d_sorted, st->d_q, st->d_nq, P));
+            skx::launch_pair_q(hs, st->d_pair_h, P, st->d_q, st->d_nq, st->d_pair_q);
+            skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, st->d_q, st->d_nq, st->d_win);
+            HIPCHK(hipMemsetAsync(st->d_m, 0, (size_t)n_words * n_pad * 8, hs));
+            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, st->d_q, st->d_nq, st->d_m, n_pad);
+        }
+        {
+            Span sp(st, 2);
+            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, st->d_q, st->d_win, st->d_m, n_pad);
+        }
+        {
+            Span sp(st, 3);
+            skx::launch_transpose_bits(hs, st->d_m, n_pad, n_words, st->d_mq);
+        }
+    }
+    if (update_table) {
+        Span sp(st, 4);
+        const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
+        skx::launch_seg_sum(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq, n_pad, st->d_inc);
+        skx::launch_seg_prefix(hs, st->d_inc, n_seg, n_pad, st->d_cum, st->d_start);
+        if (st->top_k && d_topk_idx && d_topk_sum) {
+            skx::launch_rank_seg(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq,
+                                 n_pad, ref->n_genomes, st->d_start, st->top_k, st->d_cand_sum, st->d_cand_idx);
+            skx::launch_topk_merge(hs, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw * st->top_k, st->top_k, d_topk_idx,
+                                   d_topk_sum, ra);
+        }
+    }
+    if (d_shared)
+        skx::launch_shared_debug(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad, ref->n_genomes,
+                                 d_shared, 0);
+    HIPCHK(hipGetLastError());
+    return SKX_OK;
+}
+
+// partition [0, n_reads) into passes by the pair counts in h_poff; calls fn(ra, rb, p_base, P)
+template <class F>
+static int for_each_pass(skx_stream* st, u32 n_reads, F fn) {
+    u32 ra = 0;
+    while (ra < n_reads) {
+        u32 rb = ra;
+        while (rb < n_reads && rb - ra < st->rpass && st->h_poff[rb + 1] - st->h_poff[ra] <= st->pcap) ++rb;
+        if (rb == ra) return fail(SKX_ERR_CAPACITY, "read %u alone has %u candidate hashes > pass capacity %u", ra,
+                                  st->h_poff[ra + 1] - st->h_poff[ra], st->pcap);
+        SKXCHK(fn(ra, rb, st->h_poff[ra], st->h_poff[rb] - st->h_poff[ra]));
+        ra = rb;
+    }
+    return SKX_OK;
+}
+
+// sketch + score + rank a batch already resident on the device.
+// h_shared / h_sketches / h_sketch_len: optional HOST outputs (parity/debug).
+static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u32* d_topk_idx,
+                         u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
+    const skx_ref* ref = st->ref;
+    hipStream_t hs = st->hs;
+    if (n_reads == 0) return SKX_OK;
+    // read-length limit of the one-wave-per-read sketcher
+    HIPCHK(hipMemcpyAsync(st->h_offsets, d_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, hs));
+    HIPCHK(hipStreamSynchronize(hs));
+    const u64 lim = (u64)skx::kSketchCap + ref->k - 1;
+    for (u32 r = 0; r < n_reads; ++r) {
+        if (st->h_offsets[r + 1] < st->h_offsets[r]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", r);
+        if (st->h_offsets[r + 1] - st->h_offsets[r] > lim)
+            return fail(SKX_ERR_UNSUPPORTED, "read %u has %llu bases; this build sketches reads of up to %llu bases", r,
+                        (unsigned long long)(st->h_offsets[r + 1] - st->h_offsets[r]), (unsigned long long)lim);
+    }
+    {
+        Span sp(st, 0);
+        if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
+        skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, ref->any ? ref->max_ref : 0,
+                                st->d_sk, st->sk_stride, st->d_len, st->d_cnt);
+        HIPCHK(hipGetLastError());
+        if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
+        // exclusive scan over n_reads+1 entries: poff[n_reads] = total pairs
+        HIPCHK(hipMemsetAsync(st->d_cnt + n_reads, 0, 4, hs));
+        HIPCHK(skx::prim_exclusive_scan_u32(hs, st->d_tmp, st->tmp_bytes, st->d_cnt, st->d_poff, n_reads + 1));
+    }
+    HIPCHK(hipMemcpyAsync(st->h_poff, st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, hs));
+    HIPCHK(hipStreamSynchronize(hs));
+
+    u32* d_shared = nullptr;
+    SKXCHK(for_each_pass(st, n_reads, [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
+        if (h_shared) {
+            if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
+            HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
+        }
+        SKXCHK(run_pass(st, ra, rb, p_base, P, d_topk_idx, d_topk_sum, d_shared, true));
+        if (h_shared) {
+            HIPCHK(hipMemcpyAsync(h_shared + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
+                                  hipMemcpyDeviceToHost, hs));
+            HIPCHK(hipStreamSynchronize(hs));
+        }
+        return SKX_OK;
+    }));
+    if (d_shared) (void)hipFree(d_shared);
+    if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
+    if (h_sketches) {
+        memset(h_sketches, 0, (size_t)n_reads * ref->s * 8);
+        HIPCHK(hipMemcpy2DAsync(h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
+                                (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
+    }
+    st->reads_total += n_reads;
+    return SKX_OK;
+}
+
+SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                            uint32_t* topk_idx, uint64_t* topk_sum, uint32_t* per_read_shared, uint64_t* sketches,
+                            uint32_t* sketch_len) {
+    if (!st || !offsets) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (n_reads == 0) return SKX_OK;
+    if (n_reads > st->max_reads) return fail(SKX_ERR_CAPACITY, "n_reads=%u exceeds max_batch_reads=%u", n_reads, st->max_reads);
+    for (u32 r = 0; r < n_reads; ++r)
+        if (offsets[r + 1] < offsets[r]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", r);
+    const u64 base0 = offsets[0], n_bases = offsets[n_reads] - base0;
+    if (n_bases > st->max_bases) return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu",
+                                             (unsigned long long)n_bases, (unsigned long long)st->max_bases);
+    if (n_bases && !bases) return fail(SKX_ERR_INVALID, "bases is NULL");
+    if ((topk_idx || topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
+    SKXCHK(use_device(st->device));
+    hipStream_t hs = st->hs;
+    // rebase offsets to 0 on the way in
+    for (u32 r = 0; r <= n_reads; ++r) st->h_offsets[r] = offsets[r] - base0;
+    HIPCHK(hipMemcpyAsync(st->d_offsets, st->h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, hs));
+    if (n_bases) HIPCHK(hipMemcpyAsync(st->d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, hs));
+    HIPCHK(hipStreamSynchronize(hs));  // h_offsets is reused by process_batch
+    SKXCHK(process_batch(st, st->d_bases, st->d_offsets, n_reads, st->d_topk_idx, st->d_topk_sum, per_read_shared,
+                         reinterpret_cast<u64*>(sketches), sketch_len));
+    if (topk_idx) HIPCHK(hipMemcpyAsync(topk_idx, st->d_topk_idx, (size_t)n_reads * st->top_k * 4, hipMemcpyDeviceToHost, hs));
+    if (topk_sum) HIPCHK(hipMemcpyAsync(topk_sum, st->d_topk_sum, (size_t)n_reads * st->top_k * 8, hipMemcpyDeviceToHost, hs));
+    HIPCHK(hipStreamSynchronize(hs));
+    if (st->profiling) collect_spans(st);
+    return SKX_OK;
+}
+
+SKX_API int skx_stream_push_device(skx_stream* st, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads,
+                                   uint64_t n_bases, uint32_t* d_topk_idx, uint64_t* d_topk_sum) {
+    if (!st || !d_offsets) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (n_reads == 0) return SKX_OK;
+    if (n_reads > st->max_reads) return fail(SKX_ERR_CAPACITY, "n_reads=%u exceeds max_batch_reads=%u", n_reads, st->max_reads);
+    if (n_bases && !d_bases) return fail(SKX_ERR_INVALID, "d_bases is NULL");
+    if ((d_topk_idx || d_topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
+    SKXCHK(use_device(st->device));
+    u32* ti = d_topk_idx ? d_topk_idx : st->d_topk_idx;
+    u64* ts = d_topk_sum ? reinterpret_cast<u64*>(d_topk_sum) : st->d_topk_sum;
+    return process_batch(st, d_bases, reinterpret_cast<const u64*>(d_offsets), n_reads, ti, ts, nullptr, nullptr, nullptr);
+}
+
+SKX_API int skx_stream_sync(skx_stream* st) {
+    if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
+    SKXCHK(use_device(st->device));
+    HIPCHK(hipStreamSynchronize(st->hs));
+    if (st->profiling) collect_spans(st);
+    return SKX_OK;
+}
+
+SKX_API int skx_stream_table(skx_stream* st, uint64_t* cum) {
+    if (!st || !cum) return fail(SKX_ERR_INVALID, "NULL argument");
+    SKXCHK(use_device(st->device));
+    HIPCHK(hipMemcpyAsync(cum, st->d_cum, (size_t)st->ref->n_genomes * 8, hipMemcpyDeviceToHost, st->hs));
+    HIPCHK(hipStreamSynchronize(st->hs));
+    return SKX_OK;
+}
+SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
+    if (!st || !add) return fail(SKX_ERR_INVALID, "NULL argument");
+    SKXCHK(use_device(st->device));
+    u64* d_add = nullptr;
+    const u32 n = st->ref->n_genomes;
+    HIPCHK(hipMalloc(&d_add, (size_t)n * 8));
+    hipError_t e = hipMemcpyAsync(d_add, add, (size_t)n * 8, hipMemcpyHostToDevice, st->hs);
+    if (e == hipSuccess) { skx::launch_add_table(st->hs, st->d_cum, d_add, n); e = hipStreamSynchronize(st->hs); }
+    (void)hipFree(d_add);
+    if (e != hipSuccess) return fail(SKX_ERR_HIP, "table_add failed: %s", hipGetErrorString(e));
+    return SKX_OK;
+}
+SKX_API int skx_stream_reset(skx_stream* st) {
+    if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
+    SKXCHK(use_device(st->device));
+    HIPCHK(hipMemsetAsync(st->d_cum, 0, (size_t)st->ref->n_pad * 8, st->hs));
+    HIPCHK(hipStreamSynchronize(st->hs));
+    st->reads_total = 0;
+    return SKX_OK;
+}
+SKX_API int skx_stream_reads(const skx_stream* st, uint64_t* n_reads) {
+    if (!st || !n_reads) return fail(SKX_ERR_INVALID, "NULL argument");
+    *n_reads = st->reads_total;
+    return SKX_OK;
+}
+SKX_API int skx_stream_rank(skx_stream* st, uint32_t top_k, uint32_t* idx, uint64_t* sum) {
+    if (!st || !idx || !sum) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (top_k < 1 || top_k > st->ref->n_genomes) return fail(SKX_ERR_INVALID, "top_k=%u outside 1..n_genomes", top_k);
+    SKXCHK(use_device(st->device));
+    u32* d_i = nullptr; u64* d_s = nullptr;
+    HIPCHK(hipMalloc(&d_i, (size_t)top_k * 4));
+    hipError_t e = hipMalloc(&d_s, (size_t)top_k * 8);
+    if (e == hipSuccess) {
+        skx::launch_rank_table(st->hs, st->d_cum, st->ref->n_genomes, top_k, d_i, d_s);
+        e = hipMemcpyAsync(idx, d_i, (size_t)top_k * 4, hipMemcpyDeviceToHost, st->hs);
+        if (e == hipSuccess) e = hipMemcpyAsync(sum, d_s, (size_t)top_k * 8, hipMemcpyDeviceToHost, st->hs);
+        if (e == hipSuccess) e = hipStreamSynchronize(st->hs);
+    }
+    (void)hipFree(d_i); (void)hipFree(d_s);
+    if (e != hipSuccess) return fail(SKX_ERR_HIP, "rank failed: %s", hipGetErrorString(e));
+    return SKX_OK;
+}
+
+// ------------------------------------------------------------------ stand-alone operators
+SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, const uint8_t* bases,
+                             const uint64_t* offsets, uint32_t n_reads, uint64_t* sketches, uint32_t* sketch_len) {
+    if (!offsets || !sketches || !sketch_len) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (k < 1 || k > SKX_MAX_K || s < 1) return fail(SKX_ERR_INVALID, "bad k/s");
+    if (n_reads == 0) return SKX_OK;
+    SKXCHK(use_device(device));
+    const u64 base0 = offsets[0], n_bases = offsets[n_reads] - base0;
+    const u64 lim = (u64)skx::kSketchCap + k - 1;
+    std::vector<u64> off(n_reads + 1);
+    for (u32 r = 0; r <= n_reads; ++r) {
+        off[r] = offsets[r] - base0;
+        if (r && offsets[r] < offsets[r - 1]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", r - 1);
+        if (r && offsets[r] - offsets[r - 1] > lim) return fail(SKX_ERR_UNSUPPORTED, "read %u longer than %llu bases", r - 1, (unsigned long long)lim);
+    }
+    const u32 stride = std::min<u32>(s, (u32)skx::kSketchCap);
+    uint8_t* d_b = nullptr; u64 *d_o = nullptr, *d_sk = nullptr; u32 *d_len = nullptr, *d_cnt = nullptr;
+    int rc = SKX_OK;
+    hipError_t e = hipSuccess;
+    do {
+        if ((e = hipMalloc(&d_b, std::max<u64>(n_bases, 1))) != hipSuccess) break;
+        if ((e = hipMalloc(&d_o, ((size_t)n_reads + 1) * 8)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_sk, (size_t)n_reads * stride * 8)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_len, (size_t)n_reads * 4)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_cnt, (size_t)n_reads * 4)) != hipSuccess) break;
+        if (n_bases && (e = hipMemcpy(d_b, bases + base0, n_bases, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipMemcpy(d_o, off.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipMemset(d_sk, 0, (size_t)n_reads * stride * 8)) != hipSuccess) break;
+        skx::launch_sketch_wave(nullptr, d_b, d_o, n_reads, k, seed, s, 0, d_sk, stride, d_len, d_cnt);
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        memset(sketches, 0, (size_t)n_reads * s * 8);
+        if ((e = hipMemcpy2D(sketches, (size_t)s * 8, d_sk, (size_t)stride * 8, (size_t)stride * 8, n_reads, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(sketch_len, d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    } while (0);
+    if (e != hipSuccess) rc = fail(SKX_ERR_HIP, "skx_sketch_reads: %s", hipGetErrorString(e));
+    (void)hipFree(d_b); (void)hipFree(d_o); (void)hipFree(d_sk); (void)hipFree(d_len); (void)hipFree(d_cnt);
+    return rc;
+}
+
+SKX_API int skx_common_hashes(const skx_ref* ref, const uint64_t* query, const uint32_t* query_len, uint32_t n_query,
+                              uint32_t q_stride, uint32_t* common) {
+    if (!ref || !query || !query_len || !common) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (n_query == 0) return SKX_OK;
+    u32 max_len = 1;
+    for (u32 i = 0; i < n_query; ++i) {
+        if (query_len[i] > q_stride) return fail(SKX_ERR_INVALID, "query_len[%u] exceeds q_stride", i);
+        const uint64_t* row = query + (size_t)i * q_stride;
+        for (u32 j = 1; j < query_len[i]; ++j)
+            if (row[j] <= row[j - 1]) return fail(SKX_ERR_UNSORTED, "query %u not strictly ascending at %u", i, j);
+        max_len = std::max(max_len, query_len[i]);
+    }
+    skx_stream* st = nullptr;
+    SKXCHK(stream_create_internal(&st, ref, 0, n_query, 1, max_len));
+    int rc = SKX_OK;
+    do {
+        // candidate prefix of every query: hashes <= max_ref (ascending rows)
+        std::vector<u32> cnt(n_query + 1, 0);
+        st->h_poff[0] = 0;
+        for (u32 i = 0; i < n_query; ++i) {
+            const uint64_t* row = query + (size_t)i * q_stride;
+            u32 c = ref->any ? (u32)(std::upper_bound(row, row + query_len[i], (uint64_t)ref->max_ref) - row) : 0;
+            st->h_poff[i + 1] = st->h_poff[i] + c;
+        }
+        hipError_t e = hipMemcpy2D(st->d_sk, (size_t)max_len * 8, query, (size_t)q_stride * 8, (size_t)max_len * 8, n_query, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(st->d_poff, st->h_poff, ((size_t)n_query + 1) * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rc = fail(SKX_ERR_HIP, "skx_common_hashes upload: %s", hipGetErrorString(e)); break; }
+        u32* d_shared = nullptr;
+        rc = for_each_pass(st, n_query, [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
+            if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
+            HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
+            if (P == 0) {
+                HIPCHK(hipMemsetAsync(d_shared, 0, (size_t)(rb - ra) * ref->n_genomes * 4, st->hs));
+            } else {
+                SKXCHK(run_pass(st, ra, rb, p_base, P, nullptr, nullptr, d_shared, false));
+            }
+            HIPCHK(hipMemcpyAsync(common + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
+                                  hipMemcpyDeviceToHost, st->hs));
+            HIPCHK(hipStreamSynchronize(st->hs));
+            return SKX_OK;
+        });
+        if (d_shared) (void)hipFree(d_shared);
+    } while (0);
+    stream_free(st);
+    return rc;
+}
+
+// ------------------------------------------------------------------ RCCL (loaded on first use)
+struct RcclApi {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+    if (g_rccl.h) return SKX_OK;
+    // soname first: a process that already loaded an RCCL (e.g. through torch) reuses that copy
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(SKX_ERR_COMM, "cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(SKX_ERR_COMM, "librccl lacks the expected symbols");
+    g_rccl.h = h;
+    return SKX_OK;
+}
+struct skx_comm { int device; int rank, n_ranks; ncclComm_t comm; };
+static_assert(sizeof(ncclUniqueId) == SKX_COMM_ID_BYTES, "RCCL unique id size");
+
+SKX_API int skx_comm_unique_id(uint8_t id[SKX_COMM_ID_BYTES]) {
+    if (!id) return fail(SKX_ERR_INVALID, "NULL argument");
+    SKXCHK(rccl_load());
+    ncclUniqueId u;
+    ncclResult_t r = g_rccl.GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    memcpy(id, &u, SKX_COMM_ID_BYTES);
+    return SKX_OK;
+}
+SKX_API int skx_comm_create(skx_comm** out, int device, int rank, int n_ranks, const uint8_t id[SKX_COMM_ID_BYTES]) {
+    if (!out || !id) return fail(SKX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(SKX_ERR_INVALID, "bad rank %d of %d", rank, n_ranks);
+    SKXCHK(use_device(device));
+    SKXCHK(rccl_load());
+    ncclUniqueId u;
+    memcpy(&u, id, SKX_COMM_ID_BYTES);
+    ncclComm_t c;
+    ncclResult_t r = g_rccl.CommInitRank(&c, n_ranks, u, rank);
+    if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    *out = new skx_comm{device, rank, n_ranks, c};
+    return SKX_OK;
+}
+SKX_API int skx_stream_allreduce(skx_stream* st, skx_comm* comm) {
+    if (!st || !comm) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (comm->device != st->device) return fail(SKX_ERR_INVALID, "communicator and stream are on different devices");
+    SKXCHK(use_device(st->device));
+    // one sum all-reduce of the u64 table (8*N bytes: latency-bound); in place
+    ncclResult_t r = g_rccl.AllReduce(st->d_cum, st->d_cum, st->ref->n_genomes, ncclUint64, ncclSum, comm->comm, st->hs);
+    if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    HIPCHK(hipStreamSynchronize(st->hs));
+    return SKX_OK;
+}
+SKX_API void skx_comm_destroy(skx_comm* comm) {
+    if (!comm) return;
+    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->comm);
+    delete comm;
+}

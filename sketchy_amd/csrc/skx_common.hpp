@@ -1,0 +1,105 @@
+// skx_common.hpp -- shared constants and device helpers for the gfx950 kernels.
+//
+// Algorithms follow the reference's dependencies as restated in SURVEY.md 8(a):
+//   murmur3 (A6)   murmurhash3 0.0.5 src/mmh3_128.rs, h1 of MurmurHash3_x64_128, u64 seed
+//   classify (A4)  needletail 0.4.1 src/sequence.rs normalize(iupac=false)
+//   canonical (A4) needletail 0.4.1 src/kmer.rs CanonicalKmers (min(fwd, revcomp) bytewise)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace skx {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr u64 kPad = 0xFFFFFFFFFFFFFFFFull;    // matrix padding: never a query (queries <= max_ref < kEmpty)
+constexpr u64 kEmpty = 0xFFFFFFFFFFFFFFFEull;  // empty slot of an LDS probe table
+constexpr int kTileGenomes = 256;              // genomes per reference tile (one lane per genome)
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ void wave_sync() {
+    // LDS hand-off between lanes of ONE wave: order the DS ops and stop the compiler from
+    // caching LDS values across the point.  No s_barrier: waves of a block run independent reads.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+    u32 lo = __builtin_amdgcn_readlane((u32)v, l);
+    u32 hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
+    u32 lo = __shfl_xor((u32)v, m, 64);
+    u32 hi = __shfl_xor((u32)(v >> 32), m, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------- murmur3 x64_128 (h1)
+__host__ __device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+__host__ __device__ __forceinline__ u64 fmix64(u64 k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+// w0..w3: the k key bytes as little-endian u64 words, zero beyond k (k <= 32)
+__host__ __device__ __forceinline__ u64 murmur3_h1_words(u64 w0, u64 w1, u64 w2, u64 w3, u32 k, u64 seed) {
+    const u64 c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+    u64 h1 = seed, h2 = seed;
+#define SKX_MM_BLOCK(K1, K2)                                                      \
+    {                                                                             \
+        u64 k1 = (K1), k2 = (K2);                                                 \
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;                        \
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ull;               \
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;                        \
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ull;               \
+    }
+    if (k >= 16) SKX_MM_BLOCK(w0, w1)
+    if (k >= 32) SKX_MM_BLOCK(w2, w3)
+#undef SKX_MM_BLOCK
+    const u32 tail = k & 15u;
+    const u64 t1 = (k >= 16) ? w2 : w0, t2 = (k >= 16) ? w3 : w1;
+    if (tail > 8) { u64 k2 = t2; k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+    if (tail > 0) { u64 k1 = t1; k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+    h1 ^= k; h2 ^= k;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    return h1;
+}
+
+// ---------------------------------------------------------------- bases
+// 0..3 = A,C,G,T ; 4 = any other retained byte (N, '-', IUPAC -> N) ; 5 = removed (whitespace)
+__host__ __device__ __forceinline__ u32 classify_base(u32 c) {
+    const u32 u = c & 0xDFu;
+    u32 code = 4u;
+    code = (u == 'A') ? 0u : code;
+    code = (u == 'C') ? 1u : code;
+    code = (u == 'G') ? 2u : code;
+    code = (u == 'T' || u == 'U') ? 3u : code;
+    code = (c == ' ' || c == '\t' || c == '\r' || c == '\n') ? 5u : code;
+    return code;
+}
+
+// canonical k-mer as 2-bit codes, first base in the most significant position; returns its hash.
+// fwd/rc ordering on the packed value == bytewise order of the ASCII strings (A<C<G<T).
+// KT > 0: compile-time k (fully unrolled); KT == 0: run-time k (1..32).
+template <int KT>
+__host__ __device__ __forceinline__ u64 hash_canonical_packed(u64 canon, u32 k_rt, u64 seed) {
+    const u32 k = KT > 0 ? (u32)KT : k_rt;
+    u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+    for (u32 j = 0; j < (KT > 0 ? (u32)KT : 32u); ++j) {
+        if (j < k) {
+            const u32 c = (u32)(canon >> (2 * (k - 1 - j))) & 3u;
+            const u64 ascii = (u64)((0x54474341u >> (8 * c)) & 0xFFu) << (8 * (j & 7));  // "ACGT"[c]
+            if (j < 8) w0 |= ascii; else if (j < 16) w1 |= ascii; else if (j < 24) w2 |= ascii; else w3 |= ascii;
+        }
+    }
+    return murmur3_h1_words(w0, w1, w2, w3, k, seed);
+}
+
+}  // namespace skx

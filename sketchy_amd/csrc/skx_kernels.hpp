@@ -1,0 +1,62 @@
+// skx_kernels.hpp -- launch wrappers of the gfx950 kernels (skx_kernels.hip) and of the
+// rocPRIM-backed dictionary primitives (skx_prim.hip).  Internal to libsketchy_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace skx {
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int kSketchCap = 2048;   // k-mers per read the one-wave-per-read sketcher holds in LDS
+constexpr int kScanSlots = 2048;   // LDS probe-table slots of the scan kernel (1024 entries per build)
+constexpr u32 kSegLen = 64;        // reads per ranking segment
+
+// reference upload
+void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 g_base, u32 n_genomes,
+                     u32 g_count);
+void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, u64* lo, u64* hi);
+
+// sketching
+size_t sketch_wave_lds_bytes();
+void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
+                        u64 max_ref, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in);
+
+// dictionary
+void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
+                         u32 p_base, u64* pair_h, u32* pair_r);
+void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q);
+void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win);
+void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
+                       u64* m_bits, u32 n_pad);
+
+// scan + transpose
+void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
+                 u64* m_bits, u32 n_pad);
+void launch_transpose_bits(hipStream_t st, const u64* m_bits, u32 n_pad, u32 n_words, u64* mq);
+
+// ranking
+void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
+                    u32 seg_len, const u64* mq, u32 n_pad, u32* inc);
+void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u64* cum, u64* start);
+void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
+                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 n_genomes, const u64* start, u32 top_k,
+                     u64* cand_sum, u32* cand_idx);
+void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_cand, u32 top_k,
+                       u32* out_idx, u64* out_sum, u32 out_r0);
+void launch_rank_table(hipStream_t st, const u64* cum, u32 n_genomes, u32 top_k, u32* out_idx, u64* out_sum);
+void launch_shared_debug(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
+                         const u64* mq, u32 n_pad, u32 n_genomes, u32* shared, u32 out_r0);
+void launch_add_table(hipStream_t st, u64* cum, const u64* add, u32 n);
+
+// rocPRIM-backed primitives (skx_prim.hip).  `tmp`/`tmp_bytes`: caller-provided scratch; each
+// *_tmp_bytes() returns what the matching call needs for up to `n` items.
+size_t prim_scan_tmp_bytes(u32 n);
+hipError_t prim_exclusive_scan_u32(hipStream_t st, void* tmp, size_t tmp_bytes, const u32* in, u32* out, u32 n);
+size_t prim_sort_tmp_bytes(u32 n);
+hipError_t prim_sort_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32 n);
+size_t prim_unique_tmp_bytes(u32 n);
+hipError_t prim_unique_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32* n_out, u32 n);
+
+}  // namespace skx

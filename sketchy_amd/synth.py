@@ -1,0 +1,218 @@
+"""Seeded synthetic workloads for the read-vs-reference MinHash path.
+
+Uniform-random reference hashes would make every shared count 0 and every rank a tie, so
+the generator creates real sharing:
+
+  1. one random ancestor genome G (uniform ACGT); its canonical k-mer MurmurHash3 values
+     (same hashing as the path under test, restated here in vectorised numpy) give the
+     pool of smallest genome hashes;
+  2. a two-level clone tree: each lineage keeps a fraction ``p_lineage`` of the pool and
+     replaces the rest by fresh uniform hashes (standing in for mutated k-mers, whose
+     murmur values are uniform anyway); each strain does the same to its lineage with
+     ``p_strain``; a strain's sketch is the bottom-s of its set;
+  3. reads are sampled from G itself (random strand, substitution errors), so their
+     k-mers genuinely hit the reference hashes.
+
+Nothing here imports oracle/: bench.py and the tests hand the same arrays to the HIP path
+and to the oracle.
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_C1 = np.uint64(0x87C37B91114253D5)
+_C2 = np.uint64(0x4CF5AD432745937F)
+
+
+def _rotl(x, r):
+    return (x << np.uint64(r)) | (x >> np.uint64(64 - r))
+
+
+def _fmix(k):
+    k = k ^ (k >> np.uint64(33))
+    k = k * np.uint64(0xFF51AFD7ED558CCD)
+    k = k ^ (k >> np.uint64(33))
+    k = k * np.uint64(0xC4CEB9FE1A85EC53)
+    k = k ^ (k >> np.uint64(33))
+    return k
+
+
+def murmur3_h1_rows(rows: np.ndarray, seed: int) -> np.ndarray:
+    """MurmurHash3_x64_128 h1 of every row of a [m, k] uint8 matrix (vectorised)."""
+    rows = np.ascontiguousarray(rows, np.uint8)
+    m, k = rows.shape
+    with np.errstate(over="ignore"):
+        h1 = np.full(m, seed, np.uint64)
+        h2 = np.full(m, seed, np.uint64)
+
+        def le64(cols):
+            v = np.zeros(m, np.uint64)
+            for i in range(cols.shape[1]):
+                v |= cols[:, i].astype(np.uint64) << np.uint64(8 * i)
+            return v
+
+        nb = k // 16
+        for b in range(nb):
+            k1 = le64(rows[:, 16 * b:16 * b + 8])
+            k2 = le64(rows[:, 16 * b + 8:16 * b + 16])
+            k1 = k1 * _C1; k1 = _rotl(k1, 31); k1 = k1 * _C2; h1 = h1 ^ k1
+            h1 = _rotl(h1, 27); h1 = h1 + h2; h1 = h1 * np.uint64(5) + np.uint64(0x52DCE729)
+            k2 = k2 * _C2; k2 = _rotl(k2, 33); k2 = k2 * _C1; h2 = h2 ^ k2
+            h2 = _rotl(h2, 31); h2 = h2 + h1; h2 = h2 * np.uint64(5) + np.uint64(0x38495AB5)
+        t = k - 16 * nb
+        if t > 8:
+            k2 = le64(rows[:, 16 * nb + 8:])
+            k2 = k2 * _C2; k2 = _rotl(k2, 33); k2 = k2 * _C1; h2 = h2 ^ k2
+        if t > 0:
+            k1 = le64(rows[:, 16 * nb:16 * nb + min(t, 8)])
+            k1 = k1 * _C1; k1 = _rotl(k1, 31); k1 = k1 * _C2; h1 = h1 ^ k1
+        h1 = h1 ^ np.uint64(k); h2 = h2 ^ np.uint64(k)
+        h1 = h1 + h2; h2 = h2 + h1
+        h1 = _fmix(h1); h2 = _fmix(h2)
+        h1 = h1 + h2
+    return h1
+
+
+_COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGT", b"TGCA"):
+    _COMP[_a] = _b
+
+
+def canonical_kmer_hashes(seq: np.ndarray, k: int, seed: int, chunk: int = 1 << 20) -> np.ndarray:
+    """Hashes of the canonical k-mers of an upper-case ACGT sequence (position order)."""
+    seq = np.ascontiguousarray(seq, np.uint8)
+    m = len(seq) - k + 1
+    if m <= 0:
+        return np.zeros(0, np.uint64)
+    out = np.empty(m, np.uint64)
+    for lo in range(0, m, chunk):
+        hi = min(m, lo + chunk)
+        win = np.lib.stride_tricks.sliding_window_view(seq[lo:hi + k - 1], k)
+        rc = _COMP[win[:, ::-1]]
+        # bytewise lexicographic fwd < rc ?
+        diff = win != rc
+        first = np.argmax(diff, axis=1)
+        rows = np.arange(hi - lo)
+        fwd_less = diff[rows, first] & (win[rows, first] < rc[rows, first])
+        canon = np.where(fwd_less[:, None], win, rc)
+        out[lo:hi] = murmur3_h1_rows(canon, seed)
+    return out
+
+
+def random_genome(length: int, rng: np.random.Generator) -> np.ndarray:
+    return np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=length)]
+
+
+def make_reference(n_genomes: int, s: int, k: int = 16, hash_seed: int = 0, genome_len: int = 0,
+                   n_lineages: int = 0, p_lineage: float = 0.85, p_strain: float = 0.99,
+                   rng_seed: int = 1, shuffle: bool = True, device: str = "auto"):
+    """Returns dict(genome [uint8], ref [n_genomes, s] uint64 ascending rows, col_len)."""
+    rng = np.random.default_rng(rng_seed)
+    if genome_len <= 0:
+        genome_len = max(20000, 280 * s)  # keeps (bottom-s range)/(hash space) near real data
+    if n_lineages <= 0:
+        n_lineages = max(1, int(round(n_genomes ** 0.5)))
+    genome = random_genome(genome_len, rng)
+    hg = np.unique(canonical_kmer_hashes(genome, k, hash_seed))
+    pool_n = int(np.ceil(1.35 * s)) + 8
+    if len(hg) < pool_n:
+        raise ValueError("genome too short for requested sketch size")
+    pool = hg[:pool_n]
+    pool_max = int(pool[-1])
+    per_lin = -(-n_genomes // n_lineages)
+
+    use_torch = False
+    if device != "numpy":
+        try:
+            import torch
+            if device == "auto":
+                device = "cuda" if torch.cuda.is_available() else "numpy"
+            use_torch = device != "numpy"
+        except ImportError:
+            device = "numpy"
+
+    ref = np.empty((n_genomes, s), np.uint64)
+    done = 0
+    if use_torch:
+        import torch
+        dev = torch.device(device)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(rng_seed * 7919 + 13)
+        assert pool_max < (1 << 62)
+        pool_t = torch.from_numpy(pool.astype(np.int64)).to(dev)
+        for lin in range(n_lineages):
+            n_here = min(per_lin, n_genomes - done)
+            if n_here <= 0:
+                break
+            keep = torch.rand(pool_n, generator=gen, device=dev) < p_lineage
+            fresh = (torch.rand(pool_n, generator=gen, device=dev, dtype=torch.float64) * pool_max).to(torch.int64)
+            base = torch.where(keep, pool_t, fresh)
+            keep2 = torch.rand((n_here, pool_n), generator=gen, device=dev) < p_strain
+            fresh2 = (torch.rand((n_here, pool_n), generator=gen, device=dev, dtype=torch.float64) * pool_max).to(torch.int64)
+            rows = torch.where(keep2, base[None, :], fresh2)
+            rows, _ = torch.sort(rows, dim=1)
+            ref[done:done + n_here] = _dedup_take(rows.cpu().numpy().view(np.uint64), s)
+            done += n_here
+    else:
+        for lin in range(n_lineages):
+            n_here = min(per_lin, n_genomes - done)
+            if n_here <= 0:
+                break
+            keep = rng.random(pool_n) < p_lineage
+            fresh = rng.integers(0, pool_max, size=pool_n, dtype=np.uint64)
+            base = np.where(keep, pool, fresh)
+            keep2 = rng.random((n_here, pool_n)) < p_strain
+            fresh2 = rng.integers(0, pool_max, size=(n_here, pool_n), dtype=np.uint64)
+            rows = np.sort(np.where(keep2, base[None, :], fresh2), axis=1)
+            ref[done:done + n_here] = _dedup_take(rows, s)
+            done += n_here
+    if shuffle:
+        ref = ref[rng.permutation(n_genomes)]
+    col_len = np.full(n_genomes, s, np.uint32)
+    return dict(genome=genome, ref=np.ascontiguousarray(ref), col_len=col_len, k=k, seed=hash_seed, s=s)
+
+
+def _dedup_take(rows: np.ndarray, s: int) -> np.ndarray:
+    """rows ascending per row; make each row strictly ascending (columns must be distinct
+    hashes) by bumping the rare duplicate, then keep the first s."""
+    rows = rows.copy()
+    dup = rows[:, 1:] == rows[:, :-1]
+    if dup.any():
+        for r in np.nonzero(dup.any(axis=1))[0]:
+            u = np.unique(rows[r])
+            extra = rows[r].max() + np.arange(1, len(rows[r]) - len(u) + 1, dtype=np.uint64)
+            rows[r] = np.concatenate([u, extra])
+    return rows[:, :s]
+
+
+def make_reads(genome: np.ndarray, n_reads: int, read_len=1500, err: float = 0.05, rng_seed: int = 2,
+               lognormal_sigma: float = 0.0, min_len: int = 200, max_len: int = 50000):
+    """Reads sampled from ``genome``: random start and strand, substitution errors.
+    read_len fixed, or log-normal around read_len when lognormal_sigma > 0 (clipped).
+    Returns (bases uint8 concatenated, offsets uint64 [n_reads+1])."""
+    rng = np.random.default_rng(rng_seed)
+    G = len(genome)
+    if lognormal_sigma > 0:
+        lens = np.exp(rng.normal(np.log(read_len), lognormal_sigma, size=n_reads))
+        lens = np.clip(lens, min_len, min(max_len, G)).astype(np.int64)
+    else:
+        lens = np.full(n_reads, min(read_len, G), np.int64)
+    offsets = np.zeros(n_reads + 1, np.uint64)
+    offsets[1:] = np.cumsum(lens).astype(np.uint64)
+    total = int(offsets[-1])
+    starts = (rng.random(n_reads) * (G - lens + 1)).astype(np.int64)
+    # gather indices for all reads at once
+    read_id = np.repeat(np.arange(n_reads), lens)
+    within = np.arange(total, dtype=np.int64) - np.repeat(offsets[:-1].astype(np.int64), lens)
+    strand = rng.integers(0, 2, size=n_reads).astype(bool)
+    rev = strand[read_id]
+    pos = np.where(rev, starts[read_id] + lens[read_id] - 1 - within, starts[read_id] + within)
+    bases = genome[pos]
+    bases = np.where(rev, _COMP[bases], bases)
+    if err > 0:
+        hit = rng.random(total) < err
+        nh = int(hit.sum())
+        alphabet = np.frombuffer(b"ACGT", np.uint8)
+        code = np.searchsorted(alphabet, bases[hit])  # A,C,G,T -> 0..3
+        bases = bases.copy()
+        bases[hit] = alphabet[(code + rng.integers(1, 4, size=nh)) % 4]
+    return np.ascontiguousarray(bases, np.uint8), offsets

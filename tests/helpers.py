@@ -1,0 +1,35 @@
+"""Shared builders for the parity tests: seeded workloads handed to BOTH the oracle and the HIP path."""
+import numpy as np
+
+from sketchy_amd import synth
+
+
+def pack_reads(reads):
+    """list[bytes] -> (bases uint8, offsets uint64)"""
+    offsets = np.zeros(len(reads) + 1, np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads]).astype(np.uint64)
+    bases = np.frombuffer(b"".join(reads), np.uint8).copy() if reads else np.zeros(0, np.uint8)
+    return bases, offsets
+
+
+def unpack_reads(bases, offsets):
+    b = bases.tobytes()
+    return [b[int(offsets[i]):int(offsets[i + 1])] for i in range(len(offsets) - 1)]
+
+
+def workload(n_genomes, s, n_reads, read_len=1500, k=16, seed=0, genome_len=0, rng_seed=1, err=0.05, **kw):
+    ref = synth.make_reference(n_genomes, s, k=k, hash_seed=seed, genome_len=genome_len, rng_seed=rng_seed,
+                               device="numpy", **kw)
+    bases, offsets = synth.make_reads(ref["genome"], n_reads, read_len, err=err, rng_seed=rng_seed + 1)
+    return ref, bases, offsets
+
+
+def assert_stream_equal(got, exp, top, what=""):
+    if top:
+        np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"], err_msg=f"{what} topk_sum")
+        np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"], err_msg=f"{what} topk_idx")
+    if got.get("shared") is not None and exp.get("shared") is not None:
+        np.testing.assert_array_equal(got["shared"], exp["shared"], err_msg=f"{what} per-read shared")
+    if got.get("sketches") is not None and exp.get("sketches") is not None:
+        np.testing.assert_array_equal(got["sketch_len"], exp["sketch_len"], err_msg=f"{what} sketch_len")
+        np.testing.assert_array_equal(got["sketches"], exp["sketches"], err_msg=f"{what} sketches")

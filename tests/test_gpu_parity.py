@@ -1,0 +1,221 @@
+"""Bit-exact parity of the HIP path (through the C ABI) with the CPU oracle.
+
+The oracle restates the reference's _sum_of_shared_hashes loop (src/sketchy.rs:317-356);
+integer work throughout, so every comparison is exact equality.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_stream_equal, pack_reads, workload
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(ref, bases, offsets, top, k=16, seed=0, col_len=None, batches=1, want_shared=True, want_sketches=True):
+    from sketchy_amd import api
+    hashes = ref["ref"] if isinstance(ref, dict) else ref
+    n, s = hashes.shape
+    col_len = np.full(n, s, np.uint32) if col_len is None else col_len
+    exp = orc.stream(k, seed, s, hashes, col_len, bases, offsets, top_k=max(top, 1), want_shared=True, want_sketches=True)
+    R = api.ReferenceSketch(hashes, col_len, k=k, seed=seed)
+    n_reads = len(offsets) - 1
+    S = api.SumOfSharedHashes(R, top=top, max_batch_reads=max(1, n_reads), max_batch_bases=max(1, len(bases)))
+    # feed in `batches` pushes to exercise table continuity
+    cuts = np.linspace(0, n_reads, batches + 1).astype(int)
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            parts.append(S.push(bases, offsets[a:b + 1], want_shared=want_shared, want_sketches=want_sketches))
+    got = {}
+    for key in ("topk_idx", "topk_sum", "shared", "sketches", "sketch_len"):
+        vals = [p[key] for p in parts if p.get(key) is not None]
+        got[key] = np.concatenate(vals) if vals else None
+    got["cum"] = S.table()
+    assert S.reads == n_reads
+    return got, exp, R, S
+
+
+def check(ref, bases, offsets, top, **kw):
+    got, exp, R, S = run_both(ref, bases, offsets, top, **kw)
+    np.testing.assert_array_equal(got["cum"], exp["cum"], err_msg="running table")
+    assert_stream_equal(got, exp, top)
+    return got, exp, R, S
+
+
+def test_c0_plumbing_config(gpu):
+    """BASELINE configs[0]: 1k synthetic 1.5 kb reads vs 500-genome s=1000 k=16 sketch."""
+    ref, bases, offsets = workload(500, 1000, 1000)
+    got, exp, R, S = check(ref, bases, offsets, top=5)
+    assert exp["shared"].max() > 0  # the workload really shares hashes
+    idx, sm = S.rank(10)
+    order = orc.stable_rank(exp["cum"])[:10]
+    np.testing.assert_array_equal(idx, order)
+    np.testing.assert_array_equal(sm, exp["cum"][order])
+
+
+def test_multiple_pushes_continue_the_table(gpu):
+    ref, bases, offsets = workload(300, 500, 257, rng_seed=7)
+    check(ref, bases, offsets, top=3, batches=5)
+
+
+def test_top1_default_and_table_only(gpu):
+    ref, bases, offsets = workload(130, 400, 100, rng_seed=3)
+    check(ref, bases, offsets, top=1)
+    got, exp, R, S = run_both(ref, bases, offsets, top=0)
+    np.testing.assert_array_equal(got["cum"], exp["cum"])
+
+
+@pytest.mark.parametrize("k,seed", [(16, 42), (21, 0), (11, 7), (32, 1), (15, 3), (17, 9), (8, 0)])
+def test_other_kmer_sizes_and_seeds(gpu, k, seed):
+    ref, bases, offsets = workload(70, 300, 60, read_len=400, k=k, seed=seed, rng_seed=11 + k)
+    check(ref, bases, offsets, top=2, k=k, seed=seed)
+
+
+def test_s_larger_than_read(gpu):
+    """s=10000-style regime: m < s, the sketch is every distinct k-mer hash of the read."""
+    ref, bases, offsets = workload(64, 3000, 80, read_len=700, genome_len=400000, rng_seed=5)
+    got, exp, _, _ = check(ref, bases, offsets, top=4)
+    assert (exp["sketch_len"] < 3000).all()
+
+
+def test_edge_reads(gpu):
+    ref, _, _ = workload(40, 200, 1, read_len=300, rng_seed=21)
+    g = ref["genome"].tobytes()
+    reads = [
+        b"",                                   # empty read still counts and ranks
+        b"ACGT",                               # shorter than k
+        g[100:115],                            # exactly k-1
+        g[100:116],                            # exactly k
+        g[1000:1400].lower(),                  # lower case is folded
+        g[2000:2200] + b"N" + g[2201:2500],    # N breaks windows
+        g[3000:3100] + b"\n" + g[3100:3200] + b"\r\n" + g[3200:3300] + b" \t",  # whitespace is removed
+        g[4000:4300].replace(b"T", b"U"),      # U -> T
+        b"RYKMSWBDHV" * 20,                    # IUPAC -> N: no valid k-mer
+        b"A" * 500,                            # one distinct k-mer
+        b"ACGTACGTACGTACGTACGT" * 10,          # palindromic / repeated k-mers
+        g[5000:5000 + 2063],                   # the longest read the wave sketcher takes (2048 k-mers)
+        g[7000:7300] + b"-" + g[7301:7600] + b"." + g[7601:7700] + b"~",
+    ]
+    bases, offsets = pack_reads(reads)
+    check(ref, bases, offsets, top=3)
+
+
+def test_ragged_columns_and_ties(gpu):
+    rng = np.random.default_rng(9)
+    ref, bases, offsets = workload(90, 256, 50, read_len=600, rng_seed=31)
+    hashes = ref["ref"].copy()
+    # duplicate genomes -> exact ties, resolved by reference order (stable sort, src/sketchy.rs:348)
+    hashes[10] = hashes[3]
+    hashes[77] = hashes[3]
+    hashes[40] = hashes[41]
+    col_len = rng.integers(0, 257, size=90).astype(np.uint32)
+    col_len[3] = col_len[10] = col_len[77] = 256
+    col_len[5] = 0  # an empty reference sketch
+    col_len[6] = 1
+    check(hashes, bases, offsets, top=7, col_len=col_len)
+
+
+def test_no_shared_hashes_all_ties(gpu):
+    """Reads unrelated to the reference: every sum is 0, rows are the first genomes in order."""
+    ref, _, _ = workload(33, 128, 1, rng_seed=41)
+    rng = np.random.default_rng(1)
+    reads = [bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 300)]) for _ in range(20)]
+    bases, offsets = pack_reads(reads)
+    got, exp, _, _ = check(ref, bases, offsets, top=5)
+    np.testing.assert_array_equal(got["topk_idx"], np.tile(np.arange(5, dtype=np.uint32), (20, 1)))
+
+
+def test_single_genome_and_top_equals_n(gpu):
+    ref, bases, offsets = workload(1, 64, 10, read_len=300, genome_len=30000, rng_seed=51)
+    check(ref, bases, offsets, top=1)
+    ref, bases, offsets = workload(5, 64, 10, read_len=300, genome_len=30000, rng_seed=52)
+    check(ref, bases, offsets, top=5)
+
+
+def test_genome_counts_across_tile_boundaries(gpu):
+    for n in (255, 256, 257, 513):
+        ref, bases, offsets = workload(n, 96, 24, read_len=500, genome_len=40000, rng_seed=60 + n)
+        check(ref, bases, offsets, top=2, want_sketches=False)
+
+
+def test_sentinel_like_reference_hashes(gpu):
+    """Reference hashes at the very top of the u64 range (the values the kernels use as padding /
+    empty markers) must still be matched exactly."""
+    ref, bases, offsets = workload(20, 64, 12, read_len=400, genome_len=30000, rng_seed=71)
+    hashes = ref["ref"].copy()
+    sk = orc.sketch(bases[int(offsets[0]):int(offsets[1])].tobytes(), 16, 0, 10 ** 6)
+    hashes[2, -2:] = [0xFFFFFFFFFFFFFFFE, 0xFFFFFFFFFFFFFFFF]
+    hashes[4, -1] = 0xFFFFFFFFFFFFFFFF
+    hashes[7, -1] = int(sk[-1])  # a genome that contains the first read's largest hash
+    hashes[7] = np.sort(hashes[7])
+    assert len(np.unique(hashes[7])) == 64
+    check(hashes, bases, offsets, top=3)
+
+
+def test_errors(gpu):
+    from sketchy_amd import _lib, api
+    ref, bases, offsets = workload(8, 32, 4, read_len=200, genome_len=30000, rng_seed=81)
+    R = api.ReferenceSketch(ref["ref"])
+    with pytest.raises(_lib.SketchyHipError) as e:  # the reference panics on top > N (src/sketchy.rs:391)
+        api.SumOfSharedHashes(R, top=9)
+    assert e.value.code == _lib.ERR_INVALID
+    bad = ref["ref"].copy()
+    bad[3, 5], bad[3, 6] = bad[3, 6], bad[3, 5]
+    with pytest.raises(_lib.SketchyHipError) as e:
+        api.ReferenceSketch(bad)
+    assert e.value.code == _lib.ERR_UNSORTED
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=2, max_batch_bases=10 ** 6)
+    with pytest.raises(_lib.SketchyHipError) as e:
+        S.push(bases, offsets)
+    assert e.value.code == _lib.ERR_CAPACITY
+    with pytest.raises(_lib.SketchyHipError) as e:
+        api.ReferenceSketch(ref["ref"], k=33)
+    assert e.value.code == _lib.ERR_INVALID
+
+
+def test_table_add_reset_and_shard_invariance(gpu):
+    """Reads shard across GPUs; the table is an integer sum, so shard tables add up exactly and a
+    shard seeded with the totals of earlier shards reproduces the single-stream ranks."""
+    from sketchy_amd import api
+    ref, bases, offsets = workload(150, 300, 120, read_len=800, rng_seed=91)
+    exp = orc.stream(16, 0, 300, ref["ref"], ref["col_len"], bases, offsets, top_k=3)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=3, max_batch_reads=120, max_batch_bases=len(bases))
+    a = S.push(bases, offsets[:61])
+    t0 = S.table()
+    S.reset()
+    assert S.reads == 0 and not S.table().any()
+    b = S.push(bases, offsets[60:])
+    t1 = S.table()
+    np.testing.assert_array_equal(t0 + t1, exp["cum"])
+    # second shard again, offset by the first shard's totals -> identical per-read rows
+    S.reset()
+    S.table_add(t0)
+    b2 = S.push(bases, offsets[60:])
+    np.testing.assert_array_equal(np.concatenate([a["topk_idx"], b2["topk_idx"]]), exp["topk_idx"])
+    np.testing.assert_array_equal(np.concatenate([a["topk_sum"], b2["topk_sum"]]), exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+
+
+def test_common_hashes_operator(gpu):
+    """`sketchy shared`: all-pairs _common_hashes; self-vs-self = sketch size (docs/index.md:145-149)."""
+    from sketchy_amd import api
+    ref, _, _ = workload(60, 500, 1, rng_seed=101)
+    R = api.ReferenceSketch(ref["ref"])
+    q = ref["ref"][:17]
+    got = R.common_hashes(q)
+    exp = np.array([[orc.common_hashes(ref["ref"][g], q[i]) for g in range(60)] for i in range(17)], np.uint32)
+    np.testing.assert_array_equal(got, exp)
+    assert (np.diag(got[:, :17]) == 500).all()
+
+
+def test_sketch_reads_operator(gpu):
+    from sketchy_amd import api
+    ref, bases, offsets = workload(4, 64, 40, read_len=1500, genome_len=50000, rng_seed=111)
+    for s in (10, 1000, 5000):
+        sk, sl = api.sketch_reads(bases, offsets, k=16, seed=42, s=s)
+        for r in range(40):
+            e = orc.sketch(bases[int(offsets[r]):int(offsets[r + 1])].tobytes(), 16, 42, s)
+            assert sl[r] == len(e)
+            np.testing.assert_array_equal(sk[r, :len(e)], e)
