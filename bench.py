@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/sec of the streaming read-vs-reference MinHash path on MI355X.
+
+One "step" = one skx_stream_push_device of a batch of B synthetic reads that are already
+resident in HBM: sketch every read, score it against every genome of the resident reference
+sketch (one or more scans of the s x N matrix), update the running sum-of-shared-hashes table
+and rank the top row(s) after every read -- the whole loop body of the reference's
+_sum_of_shared_hashes (src/sketchy.rs:328-354), nothing skipped.
+
+Workload (BASELINE.json configs): default "c2" = 100k x 1.5 kb reads vs a 40 000-genome
+s=10 000 k=16 reference (3.2 GB of hashes, the HBM-bound scan the metric is quoted on).
+N > 1: one process per GPU (torchrun), reference replicated, the read stream sharded; the only
+exchange is the final RCCL all-reduce of the u64 table (inside the timed region).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {
+    # name: (n_genomes, s, read_len, description)
+    "c0": (500, 1000, 1500, "C0: 1.5 kb reads vs 500-genome s=1000 k=16 sketch (plumbing)"),
+    "c1": (5000, 1000, 1500, "C1: 1.5 kb reads vs 5k-genome s=1000 k=16 sketch (cache-resident)"),
+    "c2": (40000, 10000, 1500, "C2: 100k x 1.5 kb reads vs 40000-genome s=10000 k=16 sketch (HBM-bound scan)"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=4096, help="reads per step")
+    ap.add_argument("--top", type=int, default=1, help="rows ranked after every read (sketchy default 1)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    args = ap.parse_args()
+
+    import torch  # first: its bundled HIP runtime must be the one the process ends up with
+    from sketchy_amd import api, shard, synth
+
+    rank, local_rank, world = shard.env_rank()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        shard.init_process_group()
+    if api.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: no HIP device {local_rank} (the bench has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = local_rank
+
+    n_genomes, s, read_len, desc = CONFIGS[args.config]
+    k, hash_seed, B, K, W = 16, 0, args.batch, args.steps, args.warmup
+
+    # ---- synthetic data (identical reference on every rank; each rank its own shard of the stream)
+    t0 = time.time()
+    ref = synth.make_reference(n_genomes, s, k=k, hash_seed=hash_seed, rng_seed=1, device=f"cuda:{local_rank}")
+    t_ref = time.time() - t0
+    n_steps = K + W
+    bases, offsets = synth.make_reads(ref["genome"], n_steps * B, read_len, err=0.05, rng_seed=1000 + rank)
+    t_gen = time.time() - t0
+
+    R = api.ReferenceSketch(ref["ref"], ref["col_len"], k=k, seed=hash_seed, device=dev)
+    S = api.SumOfSharedHashes(R, top=args.top, max_batch_reads=B, max_batch_bases=int(B * (read_len + 8)))
+    d_bases = api.DeviceBuffer.from_numpy(bases, dev)
+    d_offs = [api.DeviceBuffer.from_numpy(offsets[i * B:(i + 1) * B + 1], dev) for i in range(n_steps)]
+    d_ti = api.DeviceBuffer(B * max(args.top, 1) * 4, dev)
+    d_ts = api.DeviceBuffer(B * max(args.top, 1) * 8, dev)
+    reducer = shard.TableReducer(dev)
+    t_setup = time.time() - t0
+
+    def step(i):
+        S.push_device(d_bases.ptr, d_offs[i].ptr, B, len(bases), d_ti.ptr if args.top else None,
+                      d_ts.ptr if args.top else None)
+
+    # ---- warmup (untimed)
+    for i in range(W):
+        step(i)
+    S.sync()
+    S.profile()  # clear counters
+    if not args.no_profile:
+        S.set_profiling(True)
+
+    # ---- timed region: exactly K steps + the final table all-reduce
+    shard.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    reducer.allreduce(S)
+    S.sync()
+    torch.cuda.synchronize()
+    shard.barrier()
+    elapsed = time.perf_counter() - t1
+    elapsed = shard.max_over_ranks(elapsed)
+    prof = S.profile() if not args.no_profile else None
+    S.set_profiling(False)
+
+    total_reads = K * B * world
+    value = total_reads / elapsed
+
+    out = {
+        "metric": "reads/sec streamed (s=10000,k=16,40k-genome ref)" if args.config == "c2" else f"reads/sec streamed ({args.config})",
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": desc, "reads_per_step": B, "read_len": read_len, "n_genomes": n_genomes, "s": s, "k": k,
+                   "top": args.top, "parallelism": f"reads sharded x{world}, reference replicated, final table all-reduce via {reducer.how}"},
+    }
+
+    if rank == 0:
+        pass_bytes = R.pass_bytes
+        if prof and prof["scan"]["launches"]:
+            scan_ms = prof["scan"]["ms"] / prof["scan"]["launches"]
+            achieved = pass_bytes / (scan_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "scan_kernel", "avg_launch_ms": scan_ms, "launches_per_step": prof["scan"]["launches"] / K,
+                               "algorithmic_bytes_per_launch": pass_bytes}
+            out["stage_ms_per_step"] = {n: v["ms"] / K for n, v in prof.items()}
+        out["setup_s"] = {"reference": round(t_ref, 2), "reads": round(t_gen - t_ref, 2), "total": round(t_setup, 2)}
+
+        # ---- CPU baseline + full-size parity sample (rank 0, N=1 only)
+        if world == 1 and args.cpu_seconds > 0:
+            from oracle import oracle as orc  # checker / baseline only
+            S2 = api.SumOfSharedHashes(R, top=max(args.top, 1), max_batch_reads=64, max_batch_bases=64 * (read_len + 8))
+            n_done, t_cpu, cum = 0, 0.0, None
+            exp_idx, exp_sum = [], []
+            while n_done < 64 and (t_cpu < args.cpu_seconds or n_done < 4):
+                a, b = int(offsets[n_done]), int(offsets[n_done + 1])
+                tc = time.perf_counter()
+                e = orc.stream(k, hash_seed, s, ref["ref"], ref["col_len"], bases[a:b], np.array([0, b - a], np.uint64),
+                               top_k=max(args.top, 1), cum=cum)
+                t_cpu += time.perf_counter() - tc
+                cum = e["cum"]
+                exp_idx.append(e["topk_idx"][0]); exp_sum.append(e["topk_sum"][0])
+                n_done += 1
+            got = S2.push(bases, offsets[:n_done + 1])
+            ok = (np.array_equal(got["topk_idx"], np.array(exp_idx)) and np.array_equal(got["topk_sum"], np.array(exp_sum))
+                  and np.array_equal(S2.table(), cum))
+            out["cpu_baseline"] = {"value": n_done / t_cpu, "unit": "reads/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {n_done} reads of the same stream, full {n_genomes}x{s} reference, "
+                                             f"oracle/orc_stream single thread ({t_cpu:.1f} s)",
+                                   "host_cpus": os.cpu_count(), "gpu_matches_cpu_on_sample": bool(ok)}
+            if not ok:
+                out["parity_error"] = "GPU top rows / table differ from the CPU oracle on the sample"
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        shard.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

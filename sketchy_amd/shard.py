@@ -1,0 +1,143 @@
+"""Read-sharding across GPUs: one process per GPU, the reference sketch is
+replicated in every GPU's HBM, the read stream is cut into contiguous shards, and the only
+exchange is one sum all-reduce of the u64 running table at the end (exact: integer sums).
+
+The control plane (rendezvous, barrier, timing max) uses torch.distributed; the table itself is
+reduced by RCCL through the C ABI (skx_stream_allreduce) when GPUs are present, and by a
+gloo all-reduce of the host copy otherwise (CPU tests, or if RCCL cannot initialise).
+"""
+import os
+
+import numpy as np
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of rank; shards differ by at most one item."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the torchrun environment (MASTER_ADDR/PORT, RANK, ...)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    rank, _, world = env_rank()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        import torch
+        backend = "cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return dist
+
+
+def barrier():
+    """Control-plane barrier on the CPU (gloo) side."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.zeros(1, dtype=torch.int64)
+        dist.all_reduce(t)
+
+
+def max_over_ranks(x: float) -> float:
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return x
+    t = torch.tensor([x], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks_int(x: int) -> int:
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return x
+    t = torch.tensor([x], dtype=torch.int64)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def broadcast_bytes(b: bytes, n: int, src=0) -> bytes:
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(n, dtype=torch.uint8)
+    if dist.get_rank() == src:
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).clone()
+    dist.broadcast(t, src=src)
+    return bytes(t.numpy().tobytes())
+
+
+def allreduce_table_host(table: np.ndarray) -> np.ndarray:
+    """Sum of u64 tables over ranks through gloo (int64 two's-complement add == u64 add mod 2^64)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return table.copy()
+    t = torch.from_numpy(np.ascontiguousarray(table, np.uint64).view(np.int64).copy())
+    dist.all_reduce(t)
+    return t.numpy().view(np.uint64).copy()
+
+
+def exclusive_prefix_tables(table: np.ndarray) -> np.ndarray:
+    """Sum of the tables of all LOWER ranks (shard r adds it with table_add to reproduce the
+    single-stream per-read cumulative sums): all-gather then local prefix."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return np.zeros_like(table)
+    mine = torch.from_numpy(np.ascontiguousarray(table, np.uint64).view(np.int64).copy())
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    acc = np.zeros(len(table), np.uint64)
+    for r in range(dist.get_rank()):
+        acc += parts[r].numpy().view(np.uint64)
+    return acc
+
+
+class TableReducer:
+    """Reduces a stream's running table over ranks: RCCL over xGMI through the C ABI, with a
+    gloo fallback.  `how` records which transport ran."""
+
+    def __init__(self, device: int):
+        import torch.distributed as dist
+        from . import api
+        self.how = "single"
+        self.comm = None
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        rank, world = dist.get_rank(), dist.get_world_size()
+        self.how = "gloo-host"
+        try:
+            uid = api.Comm.unique_id() if rank == 0 else b"\0" * 128
+            uid = broadcast_bytes(uid, 128, src=0)
+            self.comm = api.Comm(device, rank, world, uid)
+            self.how = "rccl"
+        except Exception as e:  # noqa: BLE001  (RCCL unavailable: stay on the host path)
+            self.err = repr(e)
+            self.comm = None
+        # every rank must take the same path
+        ok = sum_over_ranks_int(1 if self.comm is not None else 0)
+        if ok != world:
+            if self.comm is not None:
+                self.comm.close()
+            self.comm, self.how = None, "gloo-host"
+
+    def allreduce(self, stream):
+        if self.how == "single":
+            return
+        if self.comm is not None:
+            stream.allreduce(self.comm)
+            return
+        mine = stream.table()
+        total = allreduce_table_host(mine)
+        stream.table_add(total - mine)  # u64 wrap-around arithmetic is exact here

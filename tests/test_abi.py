@@ -1,0 +1,75 @@
+"""The C-ABI library builds, loads and exports every symbol include/sketchy_hip.h declares.
+No compute calls here (no GPU in the CPU container): only entry points that need no device."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sketchy_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(skx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_is_built_and_loads():
+    from sketchy_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    assert b"gfx950" in lib.skx_version()
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from sketchy_amd import _lib
+    lib = _lib.load()
+    decl = declared_symbols()
+    assert len(decl) >= 30
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert set(decl) == bound, (set(decl) ^ bound)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (skx_[a-z0-9_]+)", out))
+    assert set(decl) <= exported, set(decl) - exported
+    for n in decl:
+        assert hasattr(lib, n)
+
+
+def test_library_contains_gfx950_code_object():
+    from sketchy_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"scan_kernel" in blob
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a device the product path fails loudly instead of computing on the host."""
+    import ctypes as C
+    from sketchy_amd import _lib
+    lib = _lib.load()
+    if lib.skx_device_count() > 0:
+        pytest.skip("a device is present")
+    p = C.c_void_p()
+    assert lib.skx_dev_malloc(0, C.byref(p), 16) == _lib.ERR_NO_DEVICE
+    assert b"no HIP device" in lib.skx_last_error()
+    import numpy as np
+    from sketchy_amd import api
+    with pytest.raises(_lib.SketchyHipError) as e:
+        api.ReferenceSketch(np.arange(8, dtype=np.uint64).reshape(1, 8))
+    assert e.value.code == _lib.ERR_NO_DEVICE
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under sketchy_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("sketchy_amd", "include"):
+        for dp, dn, fn in os.walk(os.path.join(ROOT, base)):
+            if "build" in dp.split(os.sep):
+                continue
+            for f in fn:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|orc_", txt, flags=re.M):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
