@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=None, help="default: ~100k reads / batch")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=4096, help="reads per step")
@@ -62,7 +62,10 @@ def main():
     dev = local_rank
 
     n_genomes, s, read_len, desc = CONFIGS[args.config]
-    k, hash_seed, B, K, W = 16, 0, args.batch, args.steps, args.warmup
+    B = args.batch
+    if args.steps is None:
+        args.steps = max(1, 98304 // B)  # the C2 stream is ~100k reads
+    k, hash_seed, K, W = 16, 0, args.steps, args.warmup
 
     # ---- synthetic data (identical reference on every rank; each rank its own shard of the stream)
     t0 = time.time()

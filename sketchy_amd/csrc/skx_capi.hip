@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -157,7 +158,7 @@ SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed,
     r->device = device; r->k = k; r->seed = seed; r->s = s; r->n_genomes = n_genomes;
     r->n_tiles = (n_genomes + skx::kTileGenomes - 1) / skx::kTileGenomes;
     r->n_pad = r->n_tiles * skx::kTileGenomes;
-    r->rb = 64;
+    r->rb = 64;  // rows per band (measured best of 64/128/256/512 on MI355X)
     r->n_bands = (s + r->rb - 1) / r->rb;
     r->max_ref = max_ref; r->any = any;
     r->n_exc = (u32)exc_h.size();
@@ -274,8 +275,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     st->ref = ref; st->device = ref->device; st->top_k = top_k; st->max_reads = max_reads; st->max_bases = max_bases;
     st->sk_stride = sk_stride;
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
-    // pass capacity: keep each of M / Mq around 256 MB, and never below one read's worth of pairs
-    u64 pc = (256ull << 20) * 8 / n_pad;
+    // pass capacity: keep each of M / Mq within ~1 GB, and never below one read's worth of pairs
+    u64 pc = (1024ull << 20) * 8 / n_pad;
     pc = std::min<u64>(pc, 1u << 20);
     pc = std::max<u64>(pc, sk_stride);
     pc = (pc + 63) / 64 * 64;
@@ -413,7 +414,11 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
         skx::launch_seg_sum(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq, n_pad, st->d_inc);
         skx::launch_seg_prefix(hs, st->d_inc, n_seg, n_pad, st->d_cum, st->d_start);
-        if (st->top_k && d_topk_idx && d_topk_sum) {
+        if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
+            skx::launch_rank_seg_top1(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad,
+                                      ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx);
+            skx::launch_top1_merge(hs, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
+        } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq,
                                  n_pad, ref->n_genomes, st->d_start, st->top_k, st->d_cand_sum, st->d_cand_idx);
             skx::launch_topk_merge(hs, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw * st->top_k, st->top_k, d_topk_idx,
@@ -462,8 +467,10 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     {
         Span sp(st, 0);
         if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
+        // production path: only the part of each sketch that can meet the reference is built
         skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, ref->any ? ref->max_ref : 0,
-                                st->d_sk, st->sk_stride, st->d_len, st->d_cnt);
+                                /*inrange_only=*/!(h_sketches || h_sketch_len), st->d_sk, st->sk_stride, st->d_len,
+                                st->d_cnt);
         HIPCHK(hipGetLastError());
         if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
         // exclusive scan over n_reads+1 entries: poff[n_reads] = total pairs
@@ -626,7 +633,7 @@ SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, 
         if (n_bases && (e = hipMemcpy(d_b, bases + base0, n_bases, hipMemcpyHostToDevice)) != hipSuccess) break;
         if ((e = hipMemcpy(d_o, off.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
         if ((e = hipMemset(d_sk, 0, (size_t)n_reads * stride * 8)) != hipSuccess) break;
-        skx::launch_sketch_wave(nullptr, d_b, d_o, n_reads, k, seed, s, 0, d_sk, stride, d_len, d_cnt);
+        skx::launch_sketch_wave(nullptr, d_b, d_o, n_reads, k, seed, s, 0, false, d_sk, stride, d_len, d_cnt);
         if ((e = hipGetLastError()) != hipSuccess) break;
         memset(sketches, 0, (size_t)n_reads * s * 8);
         if ((e = hipMemcpy2D(sketches, (size_t)s * 8, d_sk, (size_t)stride * 8, (size_t)stride * 8, n_reads, hipMemcpyDeviceToHost)) != hipSuccess) break;

@@ -16,6 +16,8 @@
 //                          running table and per-read (sum desc, index asc) top-k       (A1, A7)
 //
 // Integer work throughout (u64 hash compares, bit counts): no MFMA.
+#include <cstdlib>
+
 #include "skx_common.hpp"
 #include "skx_kernels.hpp"
 
@@ -87,7 +89,10 @@ __global__ __launch_bounds__(256) void band_bounds_kernel(const u64* __restrict_
 // read sketching: one wavefront per read
 // =====================================================================================
 // LDS per wave: hashes[CAP] u64, then codes[CAP + 64] bytes.
-template <int KT, int CAP>
+// INRANGE: keep only hashes <= max_ref before sorting.  Every such hash is smaller than every
+// dropped one, so the first min(s, #distinct kept) of them ARE the part of the bottom-s sketch that
+// can meet the reference (the only part scoring needs); out_len is then that count, not |sketch|.
+template <int KT, int CAP, bool INRANGE>
 __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
                                                           const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
                                                           u64 seed, u32 s, u64 max_ref, u64* __restrict__ out_sk,
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
         valid = valid && (bad == 0);
         const u64 canon = fwd < rc ? fwd : rc;
         const u64 h = hash_canonical_packed<KT>(canon, k, seed);
+        if (INRANGE) valid = valid && (h <= max_ref);
         const u64 mask = __ballot(valid);
         if (valid) hashes[m + __popcll(mask & lt)] = h;
         m += __popcll(mask);
@@ -259,24 +265,32 @@ __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __re
 // =====================================================================================
 // One block per (band, tile): 256 lanes = 256 genome columns, rows [b*rb, (b+1)*rb).
 // LDS: open-addressing table of the band's slice of Q (keys 8 B + local index 2 B per slot).
-// A lane meets its column's hits in ascending q, so it ORs them into one 64-bit word in a
-// register and flushes that word to M[word][genome] when the word index moves on.
-template <int TSLOTS>
+// A lane meets its column's hits in ascending q, so it ORs them into one 64-bit word in a register and
+// flushes that word to M[word][genome] when the word index moves on.  The OR is atomic: the neighbouring
+// band can own bits of the same word.
+// Measured alternatives that were all slower on MI355X ("scan kernel experiments"): plain
+// stores for the words only one band can touch, parking finished words in LDS and writing them out after
+// the last row (per lane or as contiguous 2 KB rows), taller bands, runs of bands per block.
+// ABLATE (profiling aid, results invalid unless 0; env SKX_SCAN_ABLATE):
+//   1 = no write to M, 2 = no probe at all (pure streaming), 3 = probe but ignore hits
+template <int TSLOTS, int ABLATE>
 __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                    const u64* __restrict__ q, const u32* __restrict__ win,
                                                    u64* __restrict__ m_bits, u32 n_pad) {
-    __shared__ u64 keys[TSLOTS];
-    __shared__ unsigned short vals[TSLOTS];
     constexpr u32 kMask = TSLOTS - 1;
     constexpr u32 kSub = TSLOTS / 2;  // entries per table build (load factor <= 0.5)
+    __shared__ u64 keys[TSLOTS];
+    __shared__ unsigned short vals[TSLOTS];
     const u32 bt = blockIdx.x;
     const u32 t = bt % n_tiles, b = bt / n_tiles, c = threadIdx.x;
     const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
     if (qa >= qb) return;
-    const u32 i0 = b * rb, i1 = min(s, i0 + rb);
+    const u32 i0 = b * rb, rows = min(s, i0 + rb) - i0;
     const u64* col = mat + ((size_t)t * s + i0) * kTileGenomes + c;
     const u32 g = t * kTileGenomes + c;
 
+    // a slice larger than one table build is walked in sub-window passes over the same rows (correct for any
+    // slice size; slower, because the band is streamed once per pass)
     for (u32 sub = qa; sub < qb; sub += kSub) {
         const u32 n = min(kSub, qb - sub);
         for (u32 j = c; j < TSLOTS; j += 256u) keys[j] = kEmpty;
@@ -292,47 +306,49 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
         }
         __syncthreads();
 
-        u32 cur_w = 0xFFFFFFFFu;
+        u32 cur_w = 0xFFFFFFFFu;  // absolute word index (q >> 6)
         u64 cur_bits = 0;
-        const u32 rows = i1 - i0;
+        auto hit = [&](u32 qi) {
+            const u32 w = qi >> 6;
+            if (w != cur_w) {
+                if (ABLATE != 1 && cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
+                cur_w = w; cur_bits = 0;
+            }
+            cur_bits |= 1ull << (qi & 63u);
+        };
+        auto probe = [&](u64 hv) {
+            if (ABLATE == 2) { cur_bits ^= hv; return; }
+            u32 slot = (u32)hv & kMask;
+            u64 e = keys[slot];
+            while (e != kEmpty && e != hv) { slot = (slot + 1u) & kMask; e = keys[slot]; }
+            if (ABLATE == 3) { cur_bits ^= e; return; }
+            if (e == hv) hit(sub + vals[slot]);
+        };
+        // software-pipelined: the next 8 rows are in flight while the current 8 are probed
         u32 i = 0;
-        // 8 independent loads in flight per lane
-        for (; i + 8u <= rows; i += 8u) {
+        if (rows >= 8u) {
             u64 h[8];
 #pragma unroll
-            for (u32 u = 0; u < 8u; ++u) h[u] = col[(size_t)(i + u) * kTileGenomes];
+            for (u32 u = 0; u < 8u; ++u) h[u] = col[(size_t)u * kTileGenomes];
+            for (i = 8u; i + 8u <= rows; i += 8u) {
+                u64 hn[8];
 #pragma unroll
-            for (u32 u = 0; u < 8u; ++u) {
-                u32 slot = (u32)h[u] & kMask;
-                u64 e = keys[slot];
-                while (e != kEmpty && e != h[u]) { slot = (slot + 1u) & kMask; e = keys[slot]; }
-                if (e == h[u]) {
-                    const u32 qi = sub + vals[slot];
-                    const u32 w = qi >> 6;
-                    if (w != cur_w) {
-                        if (cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
-                        cur_w = w; cur_bits = 0;
-                    }
-                    cur_bits |= 1ull << (qi & 63u);
-                }
+                for (u32 u = 0; u < 8u; ++u) hn[u] = col[(size_t)(i + u) * kTileGenomes];
+#pragma unroll
+                for (u32 u = 0; u < 8u; ++u) probe(h[u]);
+#pragma unroll
+                for (u32 u = 0; u < 8u; ++u) h[u] = hn[u];
             }
+#pragma unroll
+            for (u32 u = 0; u < 8u; ++u) probe(h[u]);
         }
-        for (; i < rows; ++i) {
-            const u64 hh = col[(size_t)i * kTileGenomes];
-            u32 slot = (u32)hh & kMask;
-            u64 e = keys[slot];
-            while (e != kEmpty && e != hh) { slot = (slot + 1u) & kMask; e = keys[slot]; }
-            if (e == hh) {
-                const u32 qi = sub + vals[slot];
-                const u32 w = qi >> 6;
-                if (w != cur_w) {
-                    if (cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
-                    cur_w = w; cur_bits = 0;
-                }
-                cur_bits |= 1ull << (qi & 63u);
-            }
+        for (; i < rows; ++i) probe(col[(size_t)i * kTileGenomes]);
+
+        if (ABLATE >= 1) {
+            if (cur_bits == 0x123456789ull) m_bits[g] = cur_bits;  // keep the work alive
+        } else if (cur_bits) {
+            atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
         }
-        if (cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
         __syncthreads();  // table is rebuilt by the next sub-window
     }
 }
@@ -340,20 +356,28 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
 // =====================================================================================
 // M[word][genome] (bit j of the word = query 64*word + j)  ->  Mq[query][genome word]
 // =====================================================================================
-// one wave per (word w, genome group gw): 64 ballots transpose a 64x64 bit block.
-__global__ __launch_bounds__(256) void transpose_bits_kernel(const u64* __restrict__ m_bits, u32 n_pad, u32 n_words,
-                                                             u64* __restrict__ mq, u32 n_gw) {
-    const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
-    const u32 gw = wave % n_gw, w = wave / n_gw;
-    if (w >= n_words) return;
-    const u64 word = m_bits[(size_t)w * n_pad + gw * 64u + lane];
-    u64 mine = 0;
+// One block = 16 waves = one word w x 16 consecutive genome groups: each wave transposes a 64x64
+// bit block with 64 ballots, the block stages [64 queries][16 groups] in LDS and writes 128-byte rows.
+__global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restrict__ m_bits, u32 n_pad, u32 n_words,
+                                                              u64* __restrict__ mq, u32 n_gw) {
+    __shared__ u64 tile[64][17];
+    const u32 n_gblk = (n_gw + 15u) / 16u;
+    const u32 w = blockIdx.x / n_gblk, gw0 = (blockIdx.x % n_gblk) * 16u;
+    const u32 wv = threadIdx.x >> 6, lane = lane_id();
+    const u32 gw = gw0 + wv;
+    if (gw < n_gw) {
+        const u64 word = m_bits[(size_t)w * n_pad + gw * 64u + lane];
+        u64 mine = 0;
 #pragma unroll
-    for (u32 j = 0; j < 64u; ++j) {
-        const u64 bal = __ballot((word >> j) & 1ull);
-        if (lane == j) mine = bal;
+        for (u32 j = 0; j < 64u; ++j) {
+            const u64 bal = __ballot((word >> j) & 1ull);
+            if (lane == j) mine = bal;
+        }
+        tile[lane][wv] = mine;
     }
-    mq[(size_t)(w * 64u + lane) * n_gw + gw] = mine;
+    __syncthreads();
+    const u32 row = threadIdx.x >> 4, col = threadIdx.x & 15u;
+    if (gw0 + col < n_gw) mq[(size_t)(w * 64u + row) * n_gw + gw0 + col] = tile[row][col];
 }
 
 // =====================================================================================
@@ -362,28 +386,53 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(const u64* __restri
 // Reads of a pass are cut into segments of seg_len reads.  pair_r/pair_q are sorted by read;
 // poff[r] (absolute, minus p_base) delimits read r's pairs.
 //
-// seg_sum: inc[seg][g] = sum over the segment's pairs of bit(Mq[q][g]).  One wave per (gw, seg).
+// acc += bit `lane` of a wave-uniform 64-bit mask: ONE VALU op (the mask is the carry-in of v_addc).
+__device__ __forceinline__ u32 add_lane_bit(u32 acc, u64 mask) {
+    u32 out;
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %1, %2" : "=v"(out) : "v"(acc), "s"(mask) : "vcc");
+    return out;
+}
+
+// One pair's 4 mask words (256 genomes of one reference tile): 32 contiguous bytes of a row of Mq.
+struct __attribute__((aligned(16))) MaskQuad { u64 w[4]; };
+
+// Lane j of the wave fetches the mask quad of pair p0 + j: 64 independent 32-byte gathers in flight.
+__device__ __forceinline__ MaskQuad gather_quad(const u64* __restrict__ mq, u32 q, u32 n_gw, u32 t, bool on) {
+    MaskQuad m = {{0, 0, 0, 0}};
+    if (on) m = *reinterpret_cast<const MaskQuad*>(mq + (size_t)q * n_gw + 4u * t);
+    return m;
+}
+
+// seg_sum: inc[seg][g] = sum over the segment's pairs of bit(Mq[q][g]).
+// One wave per (reference tile t = 256 genomes = 4 mask words, seg).  Pairs are taken 64 at a time:
+// one gather per lane, then each pair's words are broadcast (v_readlane) and added with one VALU op per
+// word.  The next chunk's gather is issued before the current one is consumed.
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                       u32* __restrict__ inc) {
-    const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
-    const u32 n_seg = (n_reads + seg_len - 1) / seg_len;
-    const u32 gw = wave % n_gw, seg = wave / n_gw;
+    const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
+    const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_tiles = n_gw >> 2;
+    const u32 t = wave % n_tiles, seg = wave / n_tiles;
     if (seg >= n_seg) return;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
-    u32 acc = 0;
+    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    MaskQuad nxt = gather_quad(mq, (pa + lane < pz) ? pair_q[pa + lane] : 0u, n_gw, t, pa + lane < pz);
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
         const u32 n = min(64u, pz - p0);
-        u64 myword = 0;
-        if (lane < n) myword = mq[(size_t)pair_q[p0 + lane] * n_gw + gw];
+        const MaskQuad cur = nxt;
+        const u32 pn = p0 + 64u + lane;
+        nxt = gather_quad(mq, pn < pz ? pair_q[pn] : 0u, n_gw, t, pn < pz);
         for (u32 j = 0; j < n; ++j) {
-            const u64 word = readlane64(myword, (int)j);
-            acc += (u32)((word >> lane) & 1ull);
+            a0 = add_lane_bit(a0, readlane64(cur.w[0], (int)j));
+            a1 = add_lane_bit(a1, readlane64(cur.w[1], (int)j));
+            a2 = add_lane_bit(a2, readlane64(cur.w[2], (int)j));
+            a3 = add_lane_bit(a3, readlane64(cur.w[3], (int)j));
         }
     }
-    inc[(size_t)seg * n_pad + gw * 64u + lane] = acc;
+    u32* o = inc + (size_t)seg * n_pad + t * 256u + lane;
+    o[0] = a0; o[64] = a1; o[128] = a2; o[192] = a3;
 }
 
 // start[seg][g] = cum[g] + sum_{seg' < seg} inc[seg'][g];  cum[g] += sum of all.  One thread per genome.
@@ -497,6 +546,113 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__
     }
 }
 
+// ---- top-1 fast path -------------------------------------------------------------------
+// wave-wide max of a u32 (DPP within rows of 16 lanes, then 4 readlanes); every lane returns it.
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row_mirror
+    const u32 a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const u32 c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// rank_seg for top_k == 1.  One wave per (reference tile t = 256 genomes, seg); lane l holds genomes
+// t*256 + 64*j + l, j = 0..3.  Within one segment a genome gains at most G = (#pairs of the segment),
+// so only genomes within G of the tile's best starting sum can ever lead it, and for those
+//   key = ((G - (best - start) + gained + 1) << 8) | ((3 - j) << 6) | (63 - l)
+// fits 32 bits and orders exactly like (sum desc, genome index asc).  The segment's <= 64 results are
+// kept one per lane and stored once: best_sum/best_idx[t * n_reads + r].
+__global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restrict__ pair_q,
+                                                            const u32* __restrict__ pair_r,
+                                                            const u32* __restrict__ poff, u32 p_base, u32 r_begin,
+                                                            u32 n_reads, u32 seg_len /* == 64 */,
+                                                            const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
+                                                            u32 n_genomes, const u64* __restrict__ start,
+                                                            u64* __restrict__ best_sum, u32* __restrict__ best_idx) {
+    const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
+    const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_tiles = n_gw >> 2;
+    const u32 t = wave % n_tiles, seg = wave / n_tiles;
+    if (seg >= n_seg) return;
+    const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
+    const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
+    const u32 g0 = t * 256u + lane;
+    const u64* sp = start + (size_t)seg * n_pad + g0;
+    const u64 s0 = sp[0], s1 = sp[64], s2 = sp[128], s3 = sp[192];
+    const bool r0 = g0 < n_genomes, r1 = g0 + 64u < n_genomes, r2 = g0 + 128u < n_genomes, r3 = g0 + 192u < n_genomes;
+    // tile's best starting sum among real genomes (ties do not matter here: only the value is used)
+    u64 bs = 0; u32 bi = 0xFFFFFFFFu;
+    if (r0) { bs = s0; bi = g0; }
+    if (r1 && (bi == 0xFFFFFFFFu || s1 > bs)) { bs = s1; bi = g0 + 64u; }
+    if (r2 && (bi == 0xFFFFFFFFu || s2 > bs)) { bs = s2; bi = g0 + 128u; }
+    if (r3 && (bi == 0xFFFFFFFFu || s3 > bs)) { bs = s3; bi = g0 + 192u; }
+    wave_best(bs, bi, bi != 0xFFFFFFFFu);
+    const bool any_real = bi != 0xFFFFFFFFu;
+    const u32 gain = pz - pa;
+    const bool e0 = r0 && bs - s0 <= (u64)gain, e1 = r1 && bs - s1 <= (u64)gain;
+    const bool e2 = r2 && bs - s2 <= (u64)gain, e3 = r3 && bs - s3 <= (u64)gain;
+    u32 v0 = gain - (u32)(bs - s0) + 1u, v1 = gain - (u32)(bs - s1) + 1u;  // garbage where !e*: masked at emit
+    u32 v2 = gain - (u32)(bs - s2) + 1u, v3 = gain - (u32)(bs - s3) + 1u;
+    const u64 base = bs - gain - 1u;  // winner sum = base + (key >> 8)   (mod 2^64)
+    const u32 c0 = (3u << 6) | (63u - lane), c1 = (2u << 6) | (63u - lane), c2 = (1u << 6) | (63u - lane), c3 = 63u - lane;
+    u32 cur = ra, res_key = 0;
+
+    auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
+        if (cur >= r_stop) return;
+        const u32 k0 = e0 ? ((v0 << 8) | c0) : 0u, k1 = e1 ? ((v1 << 8) | c1) : 0u;
+        const u32 k2 = e2 ? ((v2 << 8) | c2) : 0u, k3 = e3 ? ((v3 << 8) | c3) : 0u;
+        const u32 key = wave_max_u32(max(max(k0, k1), max(k2, k3)));
+        if (lane >= cur - ra && lane < r_stop - ra) res_key = key;
+        cur = r_stop;
+    };
+
+    MaskQuad nxt = gather_quad(mq, (pa + lane < pz) ? pair_q[pa + lane] : 0u, n_gw, t, pa + lane < pz);
+    u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
+    for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+        const u32 n = min(64u, pz - p0);
+        const MaskQuad cur_m = nxt;
+        const u32 rv = rnxt;
+        const u32 pn = p0 + 64u + lane;
+        nxt = gather_quad(mq, pn < pz ? pair_q[pn] : 0u, n_gw, t, pn < pz);
+        rnxt = pn < pz ? pair_r[pn] : 0u;
+        for (u32 j = 0; j < n; ++j) {
+            emit_upto(__builtin_amdgcn_readlane(rv, (int)j));
+            v0 = add_lane_bit(v0, readlane64(cur_m.w[0], (int)j));
+            v1 = add_lane_bit(v1, readlane64(cur_m.w[1], (int)j));
+            v2 = add_lane_bit(v2, readlane64(cur_m.w[2], (int)j));
+            v3 = add_lane_bit(v3, readlane64(cur_m.w[3], (int)j));
+        }
+    }
+    emit_upto(rz);
+    if (lane < rz - ra) {
+        const size_t o = (size_t)t * n_reads + ra + lane;
+        const bool none = !any_real || res_key == 0;
+        const u32 wl = 63u - (res_key & 63u), wj = 3u - ((res_key >> 6) & 3u);
+        best_sum[o] = none ? 0 : base + (u64)(res_key >> 8);
+        best_idx[o] = none ? 0xFFFFFFFFu : t * 256u + wj * 64u + wl;
+    }
+}
+
+// merge for top_k == 1: one lane per read, walking the tiles in index order.  grid: reads/256
+__global__ __launch_bounds__(256) void top1_merge_kernel(const u64* __restrict__ best_sum,
+                                                         const u32* __restrict__ best_idx, u32 n_reads, u32 n_tiles,
+                                                         u32* __restrict__ out_idx, u64* __restrict__ out_sum,
+                                                         u32 out_r0) {
+    const u32 r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_reads) return;
+    u64 bs = 0; u32 bi = 0xFFFFFFFFu;
+#pragma unroll 8
+    for (u32 t = 0; t < n_tiles; ++t) {
+        const u64 s_ = best_sum[(size_t)t * n_reads + r];
+        const u32 i_ = best_idx[(size_t)t * n_reads + r];
+        // tiles come in ascending index order: a later tile wins only with a strictly larger sum
+        if (i_ != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || s_ > bs)) { bs = s_; bi = i_; }
+    }
+    out_idx[out_r0 + r] = bi;
+    out_sum[out_r0 + r] = bs;
+}
+
 // rank the table itself: one block, top_k rounds.  (skx_stream_rank; also the all-reduced table)
 __global__ __launch_bounds__(1024) void rank_table_kernel(const u64* __restrict__ cum, u32 n_genomes, u32 top_k,
                                                           u32* __restrict__ out_idx, u64* __restrict__ out_sum) {
@@ -563,24 +719,25 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
 size_t sketch_wave_lds_bytes() { return 4 * (size_t)(kSketchCap * 8 + kSketchCap + 64); }
 
 void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
-                        u64 max_ref, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in) {
+                        u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in) {
     if (n_reads == 0) return;
     const size_t lds = sketch_wave_lds_bytes();
     dim3 grid(cdiv(n_reads, 4));
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
+#define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, IR>
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_wave_kernel<16, kSketchCap>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sketch_wave_kernel<0, kSketchCap>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const void* fns[] = {(const void*)&SKX_SK(16, false), (const void*)&SKX_SK(16, true),
+                             (const void*)&SKX_SK(0, false), (const void*)&SKX_SK(0, true)};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    if (k == 16)
-        hipLaunchKernelGGL((sketch_wave_kernel<16, kSketchCap>), grid, dim3(256), lds, st, bases, offsets, n_reads, k,
-                           seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in);
-    else
-        hipLaunchKernelGGL((sketch_wave_kernel<0, kSketchCap>), grid, dim3(256), lds, st, bases, offsets, n_reads, k,
-                           seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in);
+#define SKX_SK_LAUNCH(KT, IR)                                                                                    \
+    hipLaunchKernelGGL((SKX_SK(KT, IR)), grid, dim3(256), lds, st, bases, offsets, n_reads, k, seed, s, max_ref, \
+                       out_sk, sk_stride, out_len, out_cnt_in)
+    if (k == 16) { if (inrange_only) SKX_SK_LAUNCH(16, true); else SKX_SK_LAUNCH(16, false); }
+    else { if (inrange_only) SKX_SK_LAUNCH(0, true); else SKX_SK_LAUNCH(0, false); }
+#undef SKX_SK_LAUNCH
+#undef SKX_SK
 }
 
 void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
@@ -602,21 +759,31 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
     hipLaunchKernelGGL(exceptions_kernel, dim3(cdiv(n_exc, 256)), dim3(256), 0, st, exc_g, exc_h, n_exc, q, n_q,
                        m_bits, n_pad);
 }
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u32 n_pad) {
-    hipLaunchKernelGGL((scan_kernel<kScanSlots>), dim3(n_tiles * n_bands), dim3(256), 0, st, mat, s, n_tiles, rb, q,
-                       win, m_bits, n_pad);
+    static const int ablate = env_int("SKX_SCAN_ABLATE", 0);  // profiling aid only
+    dim3 grid(n_tiles * n_bands), block(256);
+#define SKX_SCAN(A) hipLaunchKernelGGL((scan_kernel<2048, A>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad)
+    switch (ablate) {
+        case 1: SKX_SCAN(1); break;
+        case 2: SKX_SCAN(2); break;
+        case 3: SKX_SCAN(3); break;
+        default: SKX_SCAN(0); break;
+    }
+#undef SKX_SCAN
 }
 void launch_transpose_bits(hipStream_t st, const u64* m_bits, u32 n_pad, u32 n_words, u64* mq) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
-    hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv((u64)n_words * n_gw, 4)), dim3(256), 0, st, m_bits, n_pad,
+    hipLaunchKernelGGL(transpose_bits_kernel, dim3(n_words * cdiv(n_gw, 16)), dim3(1024), 0, st, m_bits, n_pad,
                        n_words, mq, n_gw);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32* inc) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(cdiv((u64)n_seg * n_gw, 4)), dim3(256), 0, st, pair_q, poff, p_base,
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(cdiv((u64)n_seg * (n_gw / 4), 4)), dim3(256), 0, st, pair_q, poff, p_base,
                        r_begin, n_reads, seg_len, mq, n_gw, n_pad, inc);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u64* cum, u64* start) {
@@ -629,6 +796,19 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
     hipLaunchKernelGGL(rank_seg_kernel, dim3(cdiv((u64)n_seg * n_gw, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, seg_len, mq, n_gw, n_pad, n_genomes, start, top_k, cand_sum,
                        cand_idx);
+}
+void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 n_genomes, const u64* start, u64* best_sum,
+                          u32* best_idx) {
+    const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64);
+    hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * (n_gw / 4), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
+                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx);
+}
+void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
+                       u64* out_sum, u32 out_r0) {
+    if (n_reads == 0) return;
+    hipLaunchKernelGGL(top1_merge_kernel, dim3(cdiv(n_reads, 256)), dim3(256), 0, st, best_sum, best_idx, n_reads, n_gw / 4,
+                       out_idx, out_sum, out_r0);
 }
 void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_cand, u32 top_k,
                        u32* out_idx, u64* out_sum, u32 out_r0) {

@@ -10,7 +10,6 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 constexpr int kSketchCap = 2048;   // k-mers per read the one-wave-per-read sketcher holds in LDS
-constexpr int kScanSlots = 2048;   // LDS probe-table slots of the scan kernel (1024 entries per build)
 constexpr u32 kSegLen = 64;        // reads per ranking segment
 
 // reference upload
@@ -21,7 +20,7 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
 // sketching
 size_t sketch_wave_lds_bytes();
 void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
-                        u64 max_ref, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in);
+                        u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in);
 
 // dictionary
 void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
@@ -43,6 +42,11 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u64
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 n_genomes, const u64* start, u32 top_k,
                      u64* cand_sum, u32* cand_idx);
+void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 n_genomes, const u64* start, u64* best_sum,
+                          u32* best_idx);
+void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
+                       u64* out_sum, u32 out_r0);
 void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_cand, u32 top_k,
                        u32* out_idx, u64* out_sum, u32 out_r0);
 void launch_rank_table(hipStream_t st, const u64* cum, u32 n_genomes, u32 top_k, u32* out_idx, u64* out_sum);

@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Condense a bench.py JSON line (stdin) to one short line: tools/bench_line.py [label]"""
+import json
+import sys
+
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+r = d.get("roofline", {})
+st = {k: round(v, 3) for k, v in d.get("stage_ms_per_step", {}).items()}
+print(" ".join(sys.argv[1:]), "B=%d" % d["config"]["reads_per_step"], "reads/s=%d" % d["value"],
+      "ms/step=%.3f" % d["ms_per_step"], "scan_ms=%.4f" % r.get("avg_launch_ms", 0), "frac=%.3f" % r.get("frac", 0),
+      "launches/step=%.2f" % r.get("launches_per_step", 0), st)
