@@ -1,0 +1,121 @@
+"""Full-size (BASELINE config C2: 40 000 genomes x s=10 000, 3.2 GB of hashes) checks through
+size-independent properties, plus a small oracle sample at full size.  The reference matrix is
+generated in a SUBPROCESS with torch on the GPU (this process must not import torch after the HIP
+library: two HIP runtimes in one process)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, S_, B = 40000, 10000, 4096
+
+
+@pytest.fixture(scope="module")
+def c2(gpu):
+    d = tempfile.mkdtemp(prefix="skx_c2_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from sketchy_amd import synth\n"
+        "ref = synth.make_reference(%d, %d, rng_seed=1, device='cuda' if torch.cuda.is_available() else 'numpy')\n"
+        "bases, offsets = synth.make_reads(ref['genome'], %d, 1500, rng_seed=4242)\n"
+        "np.save(%r + '/ref.npy', ref['ref']); np.save(%r + '/bases.npy', bases); np.save(%r + '/offsets.npy', offsets)\n"
+    ) % (ROOT, N, S_, 2 * B, d, d, d)
+    subprocess.check_call([sys.executable, "-c", code])
+    ref = np.load(d + "/ref.npy", mmap_mode="r")
+    out = dict(ref=np.ascontiguousarray(ref), bases=np.load(d + "/bases.npy"), offsets=np.load(d + "/offsets.npy"))
+    for f in os.listdir(d):
+        os.remove(os.path.join(d, f))
+    os.rmdir(d)
+    from sketchy_amd import api
+    out["R"] = api.ReferenceSketch(out["ref"])
+    yield out
+    out["R"].close()
+
+
+def _rank_np(table, k):
+    order = np.lexsort((np.arange(len(table)), -table.astype(np.int64)))  # sum desc, index asc
+    return order[:k].astype(np.uint32)
+
+
+def test_shard_invariance_determinism_and_rank(c2):
+    from sketchy_amd import api
+    R, bases, offsets = c2["R"], c2["bases"], c2["offsets"]
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=B, max_batch_bases=B * 1500)
+    a = S.push(bases, offsets[:B + 1])
+    ta = S.table()
+    b = S.push(bases, offsets[B:])
+    tab = S.table()
+    assert S.reads == 2 * B
+    # running sums only grow, and the emitted top row is the table's leader at that read
+    sums = np.concatenate([a["topk_sum"][:, 0], b["topk_sum"][:, 0]])
+    assert (np.diff(sums.astype(np.int64)) >= 0).all()
+    assert sums[B - 1] == ta.max() and a["topk_idx"][-1, 0] == _rank_np(ta, 1)[0]
+    assert sums[-1] == tab.max() and b["topk_idx"][-1, 0] == _rank_np(tab, 1)[0]
+    idx, sm = S.rank(25)
+    np.testing.assert_array_equal(idx, _rank_np(tab, 25))
+    np.testing.assert_array_equal(sm, tab[idx])
+    # shards add up exactly (integer sums): table(second half alone) == table(all) - table(first half)
+    S.reset()
+    b2 = S.push(bases, offsets[B:])
+    np.testing.assert_array_equal(S.table(), tab - ta)
+    # determinism: same input, same bytes
+    S.reset()
+    b3 = S.push(bases, offsets[B:])
+    np.testing.assert_array_equal(b2["topk_idx"], b3["topk_idx"])
+    np.testing.assert_array_equal(b2["topk_sum"], b3["topk_sum"])
+    # seeding the second shard with the first shard's totals reproduces the single-stream rows
+    S.reset()
+    S.table_add(ta)
+    b4 = S.push(bases, offsets[B:])
+    np.testing.assert_array_equal(b4["topk_idx"], b["topk_idx"])
+    np.testing.assert_array_equal(b4["topk_sum"], b["topk_sum"])
+    # different batch cuts give the same stream (B=4096 vs 8 x 512)
+    S2 = api.SumOfSharedHashes(R, top=1, max_batch_reads=512, max_batch_bases=512 * 1500)
+    parts = [S2.push(bases, offsets[i:i + 513]) for i in range(0, B, 512)]
+    np.testing.assert_array_equal(np.concatenate([p["topk_idx"] for p in parts]), a["topk_idx"])
+    np.testing.assert_array_equal(np.concatenate([p["topk_sum"] for p in parts]), a["topk_sum"])
+    np.testing.assert_array_equal(S2.table(), ta)
+
+
+def test_top5_rows_are_consistent_with_top1(c2):
+    from sketchy_amd import api
+    R, bases, offsets = c2["R"], c2["bases"], c2["offsets"]
+    S1 = api.SumOfSharedHashes(R, top=1, max_batch_reads=1024, max_batch_bases=1024 * 1500)
+    S5 = api.SumOfSharedHashes(R, top=5, max_batch_reads=1024, max_batch_bases=1024 * 1500)
+    a = S1.push(bases, offsets[:1025])
+    b = S5.push(bases, offsets[:1025])
+    np.testing.assert_array_equal(a["topk_idx"][:, 0], b["topk_idx"][:, 0])
+    np.testing.assert_array_equal(a["topk_sum"][:, 0], b["topk_sum"][:, 0])
+    assert (np.diff(b["topk_sum"].astype(np.int64), axis=1) <= 0).all()      # rows sorted by sum desc
+    ties = b["topk_sum"][:, :-1] == b["topk_sum"][:, 1:]
+    assert (b["topk_idx"][:, :-1][ties] < b["topk_idx"][:, 1:][ties]).all()  # ties in reference order
+    np.testing.assert_array_equal(S1.table(), S5.table())
+
+
+def test_self_intersection_is_sketch_size(c2):
+    """docs/index.md:145-149: a sketch shares all of its s hashes with itself."""
+    R, ref = c2["R"], c2["ref"]
+    pick = np.array([0, 1, 255, 256, 20000, N - 1])
+    common = R.common_hashes(ref[pick])
+    assert (common[np.arange(len(pick)), pick] == S_).all()
+    assert (common <= S_).all()
+
+
+def test_oracle_sample_at_full_size(c2):
+    from oracle import oracle as orc
+    from sketchy_amd import api
+    R, ref, bases, offsets = c2["R"], c2["ref"], c2["bases"], c2["offsets"]
+    n = 6
+    exp = orc.stream(16, 0, S_, ref, np.full(N, S_, np.uint32), bases, offsets[:n + 1], top_k=3, want_shared=True)
+    S = api.SumOfSharedHashes(R, top=3, max_batch_reads=n, max_batch_bases=n * 1500)
+    got = S.push(bases, offsets[:n + 1], want_shared=True)
+    np.testing.assert_array_equal(got["shared"], exp["shared"])
+    np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"])
+    np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])

@@ -219,3 +219,16 @@ def test_sketch_reads_operator(gpu):
             e = orc.sketch(bases[int(offsets[r]):int(offsets[r + 1])].tobytes(), 16, 42, s)
             assert sl[r] == len(e)
             np.testing.assert_array_equal(sk[r, :len(e)], e)
+
+
+def test_frozen_golden_fixture(gpu):
+    """tests/golden/stream_small.npz (inputs + expected outputs frozen by tests/golden/make_golden.py)."""
+    import os
+    from sketchy_amd import api
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stream_small.npz"))
+    R = api.ReferenceSketch(z["hashes"], z["col_len"], k=int(z["k"]), seed=int(z["seed"]))
+    S = api.SumOfSharedHashes(R, top=4, max_batch_reads=len(z["offsets"]) - 1, max_batch_bases=len(z["bases"]))
+    got = S.push(z["bases"], z["offsets"], want_shared=True, want_sketches=True)
+    for key in ("topk_idx", "topk_sum", "shared", "sketches", "sketch_len"):
+        np.testing.assert_array_equal(got[key], z[key], err_msg=key)
+    np.testing.assert_array_equal(S.table(), z["cum"])
