@@ -212,6 +212,65 @@ SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
 }
 SKX_API void skx_ref_destroy(skx_ref* ref) { ref_free(ref); }
 
+// ------------------------------------------------------------------ sketching (short + long reads)
+// scratch of the long-read path, allocated on first use
+struct LongWork {
+    uint8_t* d_codes = nullptr;
+    u64 *d_hbuf = nullptr, *d_hsorted = nullptr;
+    u32 *d_idx = nullptr, *d_sb = nullptr, *d_se = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    u64 cap_bases = 0;
+    u32 cap_reads = 0;
+};
+static void long_free(LongWork& w) {
+    (void)hipFree(w.d_codes); (void)hipFree(w.d_hbuf); (void)hipFree(w.d_hsorted);
+    (void)hipFree(w.d_idx); (void)hipFree(w.d_sb); (void)hipFree(w.d_se); (void)hipFree(w.d_tmp);
+    w = LongWork();
+}
+static int long_ensure(LongWork& w, u64 bases, u32 reads) {
+    if (bases <= w.cap_bases && reads <= w.cap_reads) return SKX_OK;
+    long_free(w);
+    if (bases >= (1ull << 32)) return fail(SKX_ERR_CAPACITY, "a batch with long reads must hold fewer than 2^32 bases");
+    HIPCHK(hipMalloc(&w.d_codes, bases));
+    HIPCHK(hipMalloc(&w.d_hbuf, bases * 8));
+    HIPCHK(hipMalloc(&w.d_hsorted, bases * 8));
+    HIPCHK(hipMalloc(&w.d_idx, (size_t)reads * 4));
+    HIPCHK(hipMalloc(&w.d_sb, (size_t)reads * 4));
+    HIPCHK(hipMalloc(&w.d_se, (size_t)reads * 4));
+    w.tmp_bytes = skx::prim_segsort_tmp_bytes((u32)bases, reads) + 256;
+    HIPCHK(hipMalloc(&w.d_tmp, w.tmp_bytes));
+    w.cap_bases = bases; w.cap_reads = reads;
+    return SKX_OK;
+}
+
+// Sketch every read of a device-resident batch (h_offsets = host copy of d_offsets).  Reads with at most
+// kSketchCap k-mers go through the one-wave-per-read kernel, longer ones through the block-per-read path.
+static int sketch_all(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
+                      const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
+                      bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
+    skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len, d_cnt);
+    HIPCHK(hipGetLastError());
+    const u64 lim = (u64)skx::kSketchCap + k - 1;
+    std::vector<u32> longs;
+    for (u32 r = 0; r < n_reads; ++r)
+        if (h_offsets[r + 1] - h_offsets[r] > lim) longs.push_back(r);
+    if (longs.empty()) return SKX_OK;
+    const u64 n_bases = h_offsets[n_reads] - h_offsets[0];
+    SKXCHK(long_ensure(lw, std::max<u64>(cap_bases, n_bases), std::max<u32>(cap_reads, n_reads)));
+    const u32 nl = (u32)longs.size();
+    HIPCHK(hipMemcpyAsync(lw.d_idx, longs.data(), (size_t)nl * 4, hipMemcpyHostToDevice, hs));
+    HIPCHK(hipStreamSynchronize(hs));  // `longs` is a local
+    const u64 off0 = h_offsets[0];
+    skx::launch_long_read_hash(hs, d_bases, d_offsets, lw.d_idx, nl, k, seed, max_ref, inrange_only, lw.d_codes, lw.d_hbuf,
+                               lw.d_sb, lw.d_se, off0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(skx::prim_segsort_u64(hs, lw.d_tmp, lw.tmp_bytes, lw.d_hbuf, lw.d_hsorted, (u32)n_bases, nl, lw.d_sb, lw.d_se));
+    skx::launch_long_read_finish(hs, lw.d_hsorted, lw.d_idx, nl, lw.d_sb, lw.d_se, s, max_ref, d_sk, sk_stride, d_len, d_cnt);
+    HIPCHK(hipGetLastError());
+    return SKX_OK;
+}
+
 // ------------------------------------------------------------------ stream
 struct TimedSpan { int stage; hipEvent_t a, b; };
 
@@ -244,6 +303,7 @@ struct skx_stream {
     size_t tmp_bytes = 0;
     u32* h_poff = nullptr;   // pinned
     u64* h_offsets = nullptr;  // pinned
+    LongWork lw;
     // profiling
     bool profiling = false;
     std::vector<TimedSpan> spans;
@@ -260,6 +320,7 @@ static void stream_free(skx_stream* st) {
                     st->d_q, st->d_pair_r, st->d_pair_q, st->d_nq, st->d_win, st->d_m, st->d_mq, st->d_inc, st->d_start,
                     st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_topk_idx, st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
+    long_free(st->lw);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     for (auto& sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -334,7 +395,10 @@ SKX_API int skx_stream_create(skx_stream** out, const skx_ref* ref, uint32_t top
     if (top_k > ref->n_genomes) return fail(SKX_ERR_INVALID, "top_k=%u exceeds n_genomes=%u", top_k, ref->n_genomes);
     if (top_k > SKX_MAX_TOP) return fail(SKX_ERR_INVALID, "top_k=%u exceeds SKX_MAX_TOP=%u", top_k, SKX_MAX_TOP);
     if (max_batch_reads < 1) return fail(SKX_ERR_INVALID, "max_batch_reads must be >= 1");
-    const u32 sk_stride = std::min<u32>(ref->s, (u32)skx::kSketchCap);
+    // a read contributes at most min(s, #k-mers) hashes; short reads (<= kSketchCap k-mers) are the floor
+    const u64 longest = std::max<u64>(max_batch_bases, (u64)skx::kSketchCap);
+    const u32 sk_stride = (u32)std::min<u64>(ref->s, longest);
+    if (max_batch_bases >= (1ull << 32)) return fail(SKX_ERR_CAPACITY, "max_batch_bases must be below 2^32");
     return stream_create_internal(out, ref, top_k, max_batch_reads, max_batch_bases, sk_stride);
 }
 SKX_API void skx_stream_destroy(skx_stream* st) { stream_free(st); }
@@ -454,24 +518,21 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     const skx_ref* ref = st->ref;
     hipStream_t hs = st->hs;
     if (n_reads == 0) return SKX_OK;
-    // read-length limit of the one-wave-per-read sketcher
+    // the host needs the read lengths (long reads take a different kernel)
     HIPCHK(hipMemcpyAsync(st->h_offsets, d_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, hs));
     HIPCHK(hipStreamSynchronize(hs));
-    const u64 lim = (u64)skx::kSketchCap + ref->k - 1;
-    for (u32 r = 0; r < n_reads; ++r) {
+    for (u32 r = 0; r < n_reads; ++r)
         if (st->h_offsets[r + 1] < st->h_offsets[r]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", r);
-        if (st->h_offsets[r + 1] - st->h_offsets[r] > lim)
-            return fail(SKX_ERR_UNSUPPORTED, "read %u has %llu bases; this build sketches reads of up to %llu bases", r,
-                        (unsigned long long)(st->h_offsets[r + 1] - st->h_offsets[r]), (unsigned long long)lim);
-    }
+    if (st->h_offsets[n_reads] - st->h_offsets[0] > st->max_bases)
+        return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu",
+                    (unsigned long long)(st->h_offsets[n_reads] - st->h_offsets[0]), (unsigned long long)st->max_bases);
     {
         Span sp(st, 0);
         if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
         // production path: only the part of each sketch that can meet the reference is built
-        skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, ref->any ? ref->max_ref : 0,
-                                /*inrange_only=*/!(h_sketches || h_sketch_len), st->d_sk, st->sk_stride, st->d_len,
-                                st->d_cnt);
-        HIPCHK(hipGetLastError());
+        SKXCHK(sketch_all(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, st->h_offsets, n_reads, ref->k,
+                          ref->seed, ref->s, ref->any ? ref->max_ref : 0, /*inrange_only=*/!(h_sketches || h_sketch_len),
+                          st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
         if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
         // exclusive scan over n_reads+1 entries: poff[n_reads] = total pairs
         HIPCHK(hipMemsetAsync(st->d_cnt + n_reads, 0, 4, hs));
@@ -613,15 +674,17 @@ SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, 
     if (n_reads == 0) return SKX_OK;
     SKXCHK(use_device(device));
     const u64 base0 = offsets[0], n_bases = offsets[n_reads] - base0;
-    const u64 lim = (u64)skx::kSketchCap + k - 1;
+    if (n_bases && !bases) return fail(SKX_ERR_INVALID, "bases is NULL");
     std::vector<u64> off(n_reads + 1);
+    u64 longest = 1;
     for (u32 r = 0; r <= n_reads; ++r) {
         off[r] = offsets[r] - base0;
         if (r && offsets[r] < offsets[r - 1]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", r - 1);
-        if (r && offsets[r] - offsets[r - 1] > lim) return fail(SKX_ERR_UNSUPPORTED, "read %u longer than %llu bases", r - 1, (unsigned long long)lim);
+        if (r) longest = std::max<u64>(longest, offsets[r] - offsets[r - 1]);
     }
-    const u32 stride = std::min<u32>(s, (u32)skx::kSketchCap);
+    const u32 stride = (u32)std::min<u64>(s, std::max<u64>(longest, 1));
     uint8_t* d_b = nullptr; u64 *d_o = nullptr, *d_sk = nullptr; u32 *d_len = nullptr, *d_cnt = nullptr;
+    LongWork lw;
     int rc = SKX_OK;
     hipError_t e = hipSuccess;
     do {
@@ -633,13 +696,14 @@ SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, 
         if (n_bases && (e = hipMemcpy(d_b, bases + base0, n_bases, hipMemcpyHostToDevice)) != hipSuccess) break;
         if ((e = hipMemcpy(d_o, off.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
         if ((e = hipMemset(d_sk, 0, (size_t)n_reads * stride * 8)) != hipSuccess) break;
-        skx::launch_sketch_wave(nullptr, d_b, d_o, n_reads, k, seed, s, 0, false, d_sk, stride, d_len, d_cnt);
-        if ((e = hipGetLastError()) != hipSuccess) break;
+        rc = sketch_all(nullptr, lw, n_bases, n_reads, d_b, d_o, off.data(), n_reads, k, seed, s, 0, false, d_sk, stride, d_len, d_cnt);
+        if (rc != SKX_OK) break;
         memset(sketches, 0, (size_t)n_reads * s * 8);
         if ((e = hipMemcpy2D(sketches, (size_t)s * 8, d_sk, (size_t)stride * 8, (size_t)stride * 8, n_reads, hipMemcpyDeviceToHost)) != hipSuccess) break;
         if ((e = hipMemcpy(sketch_len, d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
     } while (0);
     if (e != hipSuccess) rc = fail(SKX_ERR_HIP, "skx_sketch_reads: %s", hipGetErrorString(e));
+    long_free(lw);
     (void)hipFree(d_b); (void)hipFree(d_o); (void)hipFree(d_sk); (void)hipFree(d_len); (void)hipFree(d_cnt);
     return rc;
 }

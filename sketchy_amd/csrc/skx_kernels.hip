@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
     uint8_t* codes = smem + (size_t)wv * kPerWave + CAP * 8;
     const u32 k = KT > 0 ? (u32)KT : k_rt;
     const u64 o0 = offsets[r], o1 = offsets[r + 1];
-    const u32 lraw = (u32)(o1 - o0);  // host guarantees lraw <= CAP + k - 1
+    if (o1 - o0 > (u64)CAP + k - 1u) return;  // long read: sketched by the long_read_* kernels instead
+    const u32 lraw = (u32)(o1 - o0);
     const u64 lt = lanemask_lt();
 
     // 1. normalise into 2-bit codes (whitespace dropped, everything not ACGTU -> 4)
@@ -192,6 +193,110 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
         out_len[r] = min(outn, s);
         out_cnt_in[r] = cin;
     }
+}
+
+// =====================================================================================
+// long reads (more k-mers than the one-wave sketcher holds): one block per read
+// =====================================================================================
+// Phase 1 (long_read_hash_kernel): normalise into codes[] (global scratch, whitespace removed), hash every
+// valid canonical k-mer and append the hashes that matter (all of them, or with INRANGE only those <= max_ref)
+// to the read's segment of hbuf[] in arbitrary order.  Phase 2: rocPRIM segmented radix sort of the
+// segments.  Phase 3 (long_read_finish_kernel): distinct, truncate to s, count the in-range prefix.
+// Segment of read r: hbuf[offsets[r] .. offsets[r] + seg_cnt[i]) (a read has fewer k-mers than bases).
+template <int KT, bool INRANGE>
+__global__ __launch_bounds__(1024) void long_read_hash_kernel(const uint8_t* __restrict__ bases,
+                                                              const u64* __restrict__ offsets,
+                                                              const u32* __restrict__ long_idx, u32 k_rt, u64 seed,
+                                                              u64 max_ref, uint8_t* __restrict__ codes,
+                                                              u64* __restrict__ hbuf, u32* __restrict__ seg_begin,
+                                                              u32* __restrict__ seg_end, u64 off0) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 s_base, s_cnt;
+    const u32 i = blockIdx.x, r = long_idx[i], tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 k = KT > 0 ? (u32)KT : k_rt;
+    const u64 o0 = offsets[r], o1 = offsets[r + 1];
+    const u32 lraw = (u32)(o1 - o0);
+    uint8_t* cd = codes + (o0 - off0);  // scratch is indexed relative to the batch's first base
+    if (tid == 0) { s_base = 0; s_cnt = 0; }
+    __syncthreads();
+    // 1. normalise + compact, 1024 bytes per step
+    for (u32 base = 0; base < lraw; base += 1024u) {
+        const u32 idx = base + tid;
+        const u32 code = classify_base(idx < lraw ? (u32)bases[o0 + idx] : (u32)' ');
+        const bool keep = code != 5u;
+        const u64 mask = __ballot(keep);
+        if (lane == 0) wsum[wv] = __popcll(mask);
+        __syncthreads();
+        u32 before = s_base;
+        for (u32 w = 0; w < wv; ++w) before += wsum[w];
+        if (keep) cd[before + __popcll(mask & lanemask_lt())] = (uint8_t)code;
+        __syncthreads();
+        if (tid == 0) { u32 t = 0; for (u32 w = 0; w < 16u; ++w) t += wsum[w]; s_base += t; }
+        __syncthreads();
+    }
+    const u32 nb = s_base;
+    const u32 nk = nb >= k ? nb - k + 1u : 0u;
+    u64* seg = hbuf + (o0 - off0);
+    // 2. hash every valid k-mer; append in arbitrary order (the segment is sorted afterwards)
+    for (u32 p = tid; p < nk; p += 1024u) {
+        u64 fwd = 0, rc = 0;
+        u32 bad = 0;
+#pragma unroll
+        for (u32 j = 0; j < (KT > 0 ? (u32)KT : 32u); ++j) {
+            if (j < k) {
+                u32 c = cd[p + j];
+                bad |= c >> 2;
+                c &= 3u;
+                fwd = (fwd << 2) | c;
+                rc |= (u64)(3u - c) << (2 * j);
+            }
+        }
+        if (bad) continue;
+        const u64 h = hash_canonical_packed<KT>(fwd < rc ? fwd : rc, k, seed);
+        if (INRANGE && h > max_ref) continue;
+        seg[atomicAdd(&s_cnt, 1u)] = h;
+    }
+    __syncthreads();
+    if (tid == 0) { seg_begin[i] = (u32)(o0 - off0); seg_end[i] = (u32)(o0 - off0) + s_cnt; }
+}
+
+// sorted segment -> distinct, truncate to s, in-range count.  One block (256) per long read.
+__global__ __launch_bounds__(256) void long_read_finish_kernel(const u64* __restrict__ sorted,
+                                                               const u32* __restrict__ long_idx,
+                                                               const u32* __restrict__ seg_begin,
+                                                               const u32* __restrict__ seg_end, u32 s, u64 max_ref,
+                                                               u64* __restrict__ out_sk, u32 sk_stride,
+                                                               u32* __restrict__ out_len, u32* __restrict__ out_cnt_in) {
+    __shared__ u32 wsum[4];
+    __shared__ u32 s_out, s_in;
+    const u32 i = blockIdx.x, r = long_idx[i], tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u64* seg = sorted + seg_begin[i];
+    const u32 m = seg_end[i] - seg_begin[i];
+    u64* out = out_sk + (size_t)r * sk_stride;
+    if (tid == 0) { s_out = 0; s_in = 0; }
+    __syncthreads();
+    for (u32 base = 0; base < m; base += 256u) {
+        if (s_out >= s) break;  // uniform: s_out is only updated between barriers
+        const u32 idx = base + tid;
+        const bool v = idx < m;
+        const u64 h = v ? seg[idx] : 0;
+        const bool head = v && (idx == 0 || seg[idx - 1] != h);
+        const u64 mask = __ballot(head);
+        if (lane == 0) wsum[wv] = __popcll(mask);
+        __syncthreads();
+        u32 pos = s_out;
+        for (u32 w = 0; w < wv; ++w) pos += wsum[w];
+        pos += __popcll(mask & lanemask_lt());
+        const bool take = head && pos < s;
+        if (take) out[pos] = h;
+        const u32 n_in = __popcll(__ballot(take && h <= max_ref));
+        if (lane == 0 && n_in) atomicAdd(&s_in, n_in);
+        __syncthreads();
+        if (tid == 0) s_out += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) { out_len[r] = min(s_out, s); out_cnt_in[r] = s_in; }
 }
 
 // =====================================================================================
@@ -740,6 +845,23 @@ void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets
 #undef SKX_SK
 }
 
+void launch_long_read_hash(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* long_idx, u32 n_long, u32 k,
+                           u64 seed, u64 max_ref, bool inrange_only, uint8_t* codes, u64* hbuf, u32* seg_begin,
+                           u32* seg_end, u64 off0) {
+    if (n_long == 0) return;
+#define SKX_LR(KT, IR) hipLaunchKernelGGL((long_read_hash_kernel<KT, IR>), dim3(n_long), dim3(1024), 0, st, bases, offsets, \
+                                          long_idx, k, seed, max_ref, codes, hbuf, seg_begin, seg_end, off0)
+    if (k == 16) { if (inrange_only) SKX_LR(16, true); else SKX_LR(16, false); }
+    else { if (inrange_only) SKX_LR(0, true); else SKX_LR(0, false); }
+#undef SKX_LR
+}
+void launch_long_read_finish(hipStream_t st, const u64* sorted, const u32* long_idx, u32 n_long, const u32* seg_begin,
+                             const u32* seg_end, u32 s, u64 max_ref, u64* out_sk, u32 sk_stride, u32* out_len,
+                             u32* out_cnt_in) {
+    if (n_long == 0) return;
+    hipLaunchKernelGGL(long_read_finish_kernel, dim3(n_long), dim3(256), 0, st, sorted, long_idx, seg_begin, seg_end, s,
+                       max_ref, out_sk, sk_stride, out_len, out_cnt_in);
+}
 void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
                          u32 p_base, u64* pair_h, u32* pair_r) {
     if (r_end <= r_begin) return;

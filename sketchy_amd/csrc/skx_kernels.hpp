@@ -22,6 +22,14 @@ size_t sketch_wave_lds_bytes();
 void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                         u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in);
 
+// long reads: hash + append (phase 1), [segmented sort], distinct/truncate (phase 3)
+void launch_long_read_hash(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* long_idx, u32 n_long, u32 k,
+                           u64 seed, u64 max_ref, bool inrange_only, uint8_t* codes, u64* hbuf, u32* seg_begin,
+                           u32* seg_end, u64 off0);
+void launch_long_read_finish(hipStream_t st, const u64* sorted, const u32* long_idx, u32 n_long, const u32* seg_begin,
+                             const u32* seg_end, u32 s, u64 max_ref, u64* out_sk, u32 sk_stride, u32* out_len,
+                             u32* out_cnt_in);
+
 // dictionary
 void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
                          u32 p_base, u64* pair_h, u32* pair_r);
@@ -62,5 +70,8 @@ size_t prim_sort_tmp_bytes(u32 n);
 hipError_t prim_sort_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32 n);
 size_t prim_unique_tmp_bytes(u32 n);
 hipError_t prim_unique_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32* n_out, u32 n);
+size_t prim_segsort_tmp_bytes(u32 n, u32 n_seg);
+hipError_t prim_segsort_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32 n, u32 n_seg,
+                            const u32* seg_begin, const u32* seg_end);
 
 }  // namespace skx

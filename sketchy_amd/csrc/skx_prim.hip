@@ -6,6 +6,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 
 #include "skx_kernels.hpp"
@@ -40,6 +41,18 @@ size_t prim_unique_tmp_bytes(u32 n) {
 }
 hipError_t prim_unique_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32* n_out, u32 n) {
     return rocprim::unique(tmp, tmp_bytes, in, out, n_out, n, rocprim::equal_to<u64>(), st);
+}
+
+size_t prim_segsort_tmp_bytes(u32 n, u32 n_seg) {
+    size_t b = 0;
+    (void)rocprim::segmented_radix_sort_keys(nullptr, b, (const u64*)nullptr, (u64*)nullptr, n, n_seg, (const u32*)nullptr,
+                                             (const u32*)nullptr);
+    return b;
+}
+hipError_t prim_segsort_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32 n, u32 n_seg,
+                            const u32* seg_begin, const u32* seg_end) {
+    if (n == 0 || n_seg == 0) return hipSuccess;
+    return rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, in, out, n, n_seg, seg_begin, seg_end, 0, 64, st);
 }
 
 }  // namespace skx

@@ -232,3 +232,63 @@ def test_frozen_golden_fixture(gpu):
     for key in ("topk_idx", "topk_sum", "shared", "sketches", "sketch_len"):
         np.testing.assert_array_equal(got[key], z[key], err_msg=key)
     np.testing.assert_array_equal(S.table(), z["cum"])
+
+
+def _wrap(seq: bytes, width=60) -> bytes:
+    return b"\n".join(seq[i:i + width] for i in range(0, len(seq), width)) + b"\n"
+
+
+def test_long_reads_mixed_lengths(gpu):
+    """BASELINE configs[4] style: log-normal read lengths (200 .. 50 000); reads with more than 2048 k-mers
+    take the block-per-read kernels.  s=300 < #k-mers (truncation matters) and s=5000 > most reads."""
+    from sketchy_amd import synth
+    for s, n_gen, rng_seed in ((300, 70, 5), (5000, 40, 6)):
+        ref = synth.make_reference(n_gen, s, genome_len=max(120000, 280 * s), rng_seed=rng_seed, device="numpy")
+        bases, offsets = synth.make_reads(ref["genome"], 60, 3000, err=0.03, rng_seed=rng_seed + 100, lognormal_sigma=1.0,
+                                          min_len=200, max_len=50000)
+        lens = np.diff(offsets.astype(np.int64))
+        assert lens.max() > 2063 and lens.min() < 2063
+        check(ref, bases, offsets, top=3)
+        check(ref, bases, offsets, top=1, batches=3, want_sketches=False)  # production (in-range only) sketch path
+
+
+def test_long_read_edge_cases(gpu):
+    ref, _, _ = workload(30, 400, 1, read_len=300, genome_len=150000, rng_seed=141)
+    g = ref["genome"].tobytes()
+    reads = [
+        g[0:2064],                                   # one base past the wave sketcher's limit
+        g[1000:2063 + 1000],                         # exactly at the limit
+        _wrap(g[5000:45000]),                        # multi-line FASTA style: newlines are removed
+        g[50000:70000].lower(),
+        g[70000:75000] + b"N" * 40 + g[75040:90000],  # N run inside a long read
+        b"ACGT" * 3000,                              # 12 kb of a 4-periodic sequence: 4 distinct k-mers... (2 canonical)
+        b"N" * 5000,
+        g[90000:140000],                             # 50 kb
+        b"",
+        g[200:1700],
+    ]
+    bases, offsets = pack_reads(reads)
+    check(ref, bases, offsets, top=2)
+    check(ref, bases, offsets, top=1, want_sketches=False)
+
+
+def test_long_reads_other_k(gpu):
+    for k, seed in ((21, 3), (11, 0)):
+        ref, _, _ = workload(20, 200, 1, read_len=300, k=k, seed=seed, genome_len=100000, rng_seed=150 + k)
+        g = ref["genome"].tobytes()
+        bases, offsets = pack_reads([g[0:9000], g[10000:10500], g[20000:60000]])
+        check(ref, bases, offsets, top=2, k=k, seed=seed)
+
+
+def test_sketch_reads_operator_long(gpu):
+    from sketchy_amd import api, synth
+    rng = np.random.default_rng(3)
+    g = synth.random_genome(120000, rng).tobytes()
+    reads = [g[0:30000], g[30000:31000], _wrap(g[40000:100000]), g[100000:102063], g[100000:102064]]
+    bases, offsets = pack_reads(reads)
+    for s in (50, 1000, 100000):
+        sk, sl = api.sketch_reads(bases, offsets, k=16, seed=0, s=s)
+        for r, rd in enumerate(reads):
+            e = orc.sketch(rd, 16, 0, s)
+            assert sl[r] == len(e), (s, r)
+            np.testing.assert_array_equal(sk[r, :len(e)], e)
