@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--top", type=int, default=1, help="rows ranked after every read (sketchy default 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--no-shuffle", action="store_true", help="experiment: keep genomes grouped by lineage")
     args = ap.parse_args()
 
     import torch  # first: its bundled HIP runtime must be the one the process ends up with
@@ -69,7 +70,8 @@ def main():
 
     # ---- synthetic data (identical reference on every rank; each rank its own shard of the stream)
     t0 = time.time()
-    ref = synth.make_reference(n_genomes, s, k=k, hash_seed=hash_seed, rng_seed=1, device=f"cuda:{local_rank}")
+    ref = synth.make_reference(n_genomes, s, k=k, hash_seed=hash_seed, rng_seed=1, device=f"cuda:{local_rank}",
+                               shuffle=not args.no_shuffle)
     t_ref = time.time() - t0
     n_steps = K + W
     bases, offsets = synth.make_reads(ref["genome"], n_steps * B, read_len, err=0.05, rng_seed=1000 + rank)
