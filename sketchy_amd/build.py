@@ -49,7 +49,25 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    build_host(force=force, verbose=verbose)
     return LIB
+
+
+HOST_BIN = os.path.join(HERE, "sketchy-hip")
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host (sketchy_amd/host): `sketchy-hip predict|shared|info` above the C ABI."""
+    hdir = os.path.join(HERE, "host")
+    srcs = [os.path.join(hdir, "sketchy_host.cpp")]
+    deps = srcs + [os.path.join(hdir, "formats.hpp"), os.path.join(ROOT, "include", "sketchy_hip.h"), LIB]
+    if force or _stale(HOST_BIN, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", hdir, *srcs, "-o", HOST_BIN,
+               "-L", HERE, "-lsketchy_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_BIN
 
 
 if __name__ == "__main__":

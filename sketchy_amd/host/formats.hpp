@@ -1,0 +1,281 @@
+// formats.hpp -- the data formats either side of the hot path, as the C++ host needs them:
+//   * Mash `.msh` reference sketches (un-packed Cap'n Proto, Mash's MinHash.capnp) -- what finch's
+//     read_mash_file gives Sketchy::_read_sketch (src/sketchy.rs:497-536): only name, length64, numValidKmers,
+//     comment and hashes64 of every reference plus kmerSize / hashSeed are used
+//   * the genotype table (tab separated, header row; src/sketchy.rs:538-571)
+//   * FASTA / FASTQ records, optionally gzip-compressed (needletail's parse_fastx_file, src/sketchy.rs:89-92)
+// [UPSTREAM-RECALL] The MinHash.capnp field layout below is restated from the public schema (it is not in the
+// reference tree and no Mash/capnp tool exists in this image to confirm it): struct MinHash = 3 data words
+// {kmerSize u32 @0, windowSize u32 @4, minHashesPerWindow u32 @8, bools @12, error f32 @16, hashSeed u32 @20
+// (default 42, stored XOR 42)} + 4 pointers {referenceListOld, locusList, alphabet, referenceList};
+// ReferenceList = 1 pointer {references}; Reference = 3 data words {length u32 @0, length64 u64 @8,
+// numValidKmers u64 @16} + 7 pointers {sequence, quality, name, comment, hashes32, hashes64, counts32}.
+#pragma once
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace sketchy {
+
+struct Sketch {  // the fields of finch::serialization::Sketch the path touches
+    std::string name, comment;
+    uint64_t seq_length = 0, num_valid_kmers = 0;
+    std::vector<uint64_t> hashes;  // ascending
+    uint32_t kmer_length = 0;
+    uint64_t hash_seed = 0;
+};
+
+// ------------------------------------------------------------------ Cap'n Proto (read side)
+class CapnpMessage {
+  public:
+    explicit CapnpMessage(std::vector<uint64_t>&& words_) : words(std::move(words_)) {
+        if (words.empty()) throw std::runtime_error("empty capnp message");
+        const uint32_t* h = reinterpret_cast<const uint32_t*>(words.data());
+        const uint64_t nseg = (uint64_t)h[0] + 1;
+        const uint64_t header_words = (4 + 4 * nseg + 7) / 8;
+        uint64_t pos = header_words;
+        for (uint64_t i = 0; i < nseg; ++i) {
+            if (header_words * 2 <= 1 + i) throw std::runtime_error("capnp segment table truncated");
+            const uint64_t len = h[1 + i];
+            if (pos + len > words.size()) throw std::runtime_error("capnp segment exceeds file");
+            seg_off.push_back(pos); seg_len.push_back(len);
+            pos += len;
+        }
+    }
+    struct Loc { uint32_t seg; uint64_t off; };  // a word inside a segment
+    struct Obj {                                  // a resolved struct or list
+        int kind = -1;                            // 0 struct, 1 list, -1 null
+        Loc at{0, 0};                             // first word of the content
+        uint32_t data_words = 0, ptr_words = 0;   // struct (or list element, composite)
+        uint32_t elem_code = 0; uint64_t count = 0;
+    };
+    uint64_t word(Loc l) const {
+        if (l.seg >= seg_off.size() || l.off >= seg_len[l.seg]) throw std::runtime_error("capnp pointer out of bounds");
+        return words[seg_off[l.seg] + l.off];
+    }
+    Obj root() const { return follow({0, 0}); }
+    // resolve the pointer stored at `p`
+    Obj follow(Loc p) const {
+        uint64_t w = word(p);
+        Loc base = p;  // offsets are relative to the word after `base`
+        if ((w & 3) == 2) {  // far pointer
+            const bool dbl = (w >> 2) & 1;
+            Loc pad{(uint32_t)(w >> 32), (uint64_t)((w >> 3) & 0x1FFFFFFF)};
+            if (!dbl) { w = word(pad); base = pad; }
+            else {
+                const uint64_t far = word(pad), tag = word({pad.seg, pad.off + 1});
+                Loc content{(uint32_t)(far >> 32), (uint64_t)((far >> 3) & 0x1FFFFFFF)};
+                return decode(tag, content, true);
+            }
+        }
+        if (w == 0) return Obj();
+        const int64_t off = (int64_t)((int32_t)(uint32_t)(w & 0xFFFFFFFFu)) >> 2;
+        Loc content{base.seg, (uint64_t)((int64_t)base.off + 1 + off)};
+        return decode(w, content, false);
+    }
+    Obj decode(uint64_t w, Loc content, bool) const {
+        Obj o;
+        o.at = content;
+        if ((w & 3) == 0) { o.kind = 0; o.data_words = (w >> 32) & 0xFFFF; o.ptr_words = (w >> 48) & 0xFFFF; }
+        else if ((w & 3) == 1) {
+            o.kind = 1; o.elem_code = (w >> 32) & 7; o.count = w >> 35;
+            if (o.elem_code == 7) {  // composite: tag word first
+                const uint64_t tag = word(content);
+                o.count = (tag >> 2) & 0x3FFFFFFF;
+                o.data_words = (tag >> 32) & 0xFFFF; o.ptr_words = (tag >> 48) & 0xFFFF;
+                o.at = {content.seg, content.off + 1};
+            }
+        } else throw std::runtime_error("unsupported capnp pointer kind");
+        return o;
+    }
+    uint64_t data_u64(const Obj& s, uint32_t word_idx) const { return word_idx < s.data_words ? word({s.at.seg, s.at.off + word_idx}) : 0; }
+    uint32_t data_u32(const Obj& s, uint32_t byte_off) const { return (uint32_t)(data_u64(s, byte_off / 8) >> (8 * (byte_off % 8))); }
+    Obj ptr(const Obj& s, uint32_t idx) const {
+        if (s.kind != 0 && !(s.kind == 1 && s.elem_code == 7)) return Obj();
+        if (idx >= s.ptr_words) return Obj();
+        return follow({s.at.seg, s.at.off + s.data_words + idx});
+    }
+    Obj element(const Obj& l, uint64_t i) const {  // composite list element as a struct
+        Obj e; e.kind = 0; e.data_words = l.data_words; e.ptr_words = l.ptr_words;
+        e.at = {l.at.seg, l.at.off + i * (l.data_words + l.ptr_words)};
+        return e;
+    }
+    std::string text(const Obj& l) const {
+        if (l.kind != 1 || l.elem_code != 2 || l.count == 0) return std::string();
+        std::string s((size_t)l.count - 1, '\0');
+        for (uint64_t i = 0; i + 1 < l.count; ++i) s[i] = (char)(word({l.at.seg, l.at.off + i / 8}) >> (8 * (i % 8)));
+        return s;
+    }
+    std::vector<uint64_t> list_u64(const Obj& l) const {
+        std::vector<uint64_t> v;
+        if (l.kind != 1 || l.elem_code != 5) return v;
+        v.resize((size_t)l.count);
+        for (uint64_t i = 0; i < l.count; ++i) v[i] = word({l.at.seg, l.at.off + i});
+        return v;
+    }
+  private:
+    std::vector<uint64_t> words;
+    std::vector<uint64_t> seg_off, seg_len;
+};
+
+inline std::vector<uint64_t> read_words(const std::string& path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw std::runtime_error("failed to open file: " + path);
+    const std::streamsize n = f.tellg();
+    f.seekg(0);
+    std::vector<uint64_t> w((size_t)(n + 7) / 8, 0);
+    if (n > 0 && !f.read(reinterpret_cast<char*>(w.data()), n)) throw std::runtime_error("failed to read file: " + path);
+    return w;
+}
+
+// finch read_mash_file + the parameter fix-up of src/sketchy.rs:513-530 (s := number of hashes)
+inline std::vector<Sketch> read_mash_file(const std::string& path) {
+    CapnpMessage m(read_words(path));
+    const auto root = m.root();
+    if (root.kind != 0) throw std::runtime_error("not a Mash sketch file: " + path);
+    const uint32_t kmer = m.data_u32(root, 0);
+    const uint32_t seed = m.data_u32(root, 20) ^ 42u;
+    auto rl = m.ptr(root, 3);                          // referenceList
+    if (rl.kind != 0) rl = m.ptr(root, 0);             // referenceListOld
+    const auto refs = m.ptr(rl, 0);
+    std::vector<Sketch> out;
+    if (refs.kind != 1) return out;
+    out.reserve((size_t)refs.count);
+    for (uint64_t i = 0; i < refs.count; ++i) {
+        const auto r = m.element(refs, i);
+        Sketch s;
+        s.name = m.text(m.ptr(r, 2));
+        s.comment = m.text(m.ptr(r, 3));
+        s.seq_length = m.data_u64(r, 1);
+        if (s.seq_length == 0) s.seq_length = m.data_u32(r, 0);
+        s.num_valid_kmers = m.data_u64(r, 2);
+        s.hashes = m.list_u64(m.ptr(r, 5));            // hashes64 only, as finch does
+        s.kmer_length = kmer; s.hash_seed = seed;
+        out.push_back(std::move(s));
+    }
+    return out;
+}
+
+// single-segment writer (tests, and `sketch`-style output later)
+inline void write_mash_file(const std::string& path, const std::vector<Sketch>& sk, uint32_t kmer, uint32_t seed) {
+    std::vector<uint64_t> w;
+    auto struct_ptr = [](int64_t off, uint32_t dw, uint32_t pw) { return (uint64_t)((uint32_t)(off << 2)) | ((uint64_t)dw << 32) | ((uint64_t)pw << 48); };
+    auto list_ptr = [](int64_t off, uint32_t code, uint64_t count) { return (uint64_t)((uint32_t)(off << 2) | 1u) | ((uint64_t)code << 32) | (count << 35); };
+    w.push_back(0);                                    // root pointer (word 0)
+    const size_t root = w.size(); w.resize(root + 3 + 4, 0);
+    w[0] = struct_ptr(0, 3, 4);
+    w[root + 0] = (uint64_t)kmer;                      // kmerSize @0, windowSize @4 = 0
+    w[root + 2] = (uint64_t)(seed ^ 42u) << 32;        // hashSeed at byte 20
+    const size_t rl = w.size(); w.resize(rl + 1, 0);   // ReferenceList {references}
+    w[root + 3 + 3] = struct_ptr((int64_t)rl - (int64_t)(root + 3 + 3) - 1, 0, 1);
+    const size_t tag = w.size();
+    const uint64_t n = sk.size(), esz = 3 + 7;
+    w.resize(tag + 1 + n * esz, 0);
+    w[rl] = list_ptr((int64_t)tag - (int64_t)rl - 1, 7, n * esz);
+    w[tag] = ((uint64_t)n << 2) | (3ull << 32) | (7ull << 48);
+    for (uint64_t i = 0; i < n; ++i) {
+        const size_t e = tag + 1 + i * esz;
+        w[e + 0] = (uint32_t)std::min<uint64_t>(sk[i].seq_length, 0xFFFFFFFFu);
+        w[e + 1] = sk[i].seq_length;
+        w[e + 2] = sk[i].num_valid_kmers;
+        auto put_text = [&](size_t pidx, const std::string& s) {
+            const size_t at = w.size(); const uint64_t cnt = s.size() + 1;
+            w.resize(at + (cnt + 7) / 8, 0);
+            memcpy(&w[at], s.data(), s.size());
+            w[e + 3 + pidx] = list_ptr((int64_t)at - (int64_t)(e + 3 + pidx) - 1, 2, cnt);
+        };
+        put_text(2, sk[i].name);
+        put_text(3, sk[i].comment);
+        const size_t at = w.size();
+        w.insert(w.end(), sk[i].hashes.begin(), sk[i].hashes.end());
+        w[e + 3 + 5] = list_ptr((int64_t)at - (int64_t)(e + 3 + 5) - 1, 5, sk[i].hashes.size());
+    }
+    if (w.size() - 1 >= (1ull << 29)) throw std::runtime_error("sketch too large for the single-segment writer");
+    std::ofstream f(path, std::ios::binary);
+    const uint32_t hdr[2] = {0u, (uint32_t)w.size()};
+    f.write(reinterpret_cast<const char*>(hdr), 8);
+    f.write(reinterpret_cast<const char*>(w.data()), (std::streamsize)w.size() * 8);
+    if (!f) throw std::runtime_error("failed to write " + path);
+}
+
+// ------------------------------------------------------------------ genotype table
+struct Genotypes {
+    std::string header;                                          // columns 1.. joined by tab (src/sketchy.rs:557)
+    std::unordered_map<std::string, std::vector<std::string>> map;  // name -> columns 1..   (:561-571)
+    size_t rows = 0;
+};
+inline std::vector<std::string> split_tab(const std::string& line) {
+    std::vector<std::string> f; size_t a = 0;
+    for (;;) { size_t b = line.find('\t', a); f.push_back(line.substr(a, b == std::string::npos ? b : b - a)); if (b == std::string::npos) break; a = b + 1; }
+    return f;
+}
+inline std::string join_tab(const std::vector<std::string>& v, size_t from = 0) {
+    std::string s; for (size_t i = from; i < v.size(); ++i) { if (i > from) s += '\t'; s += v[i]; } return s;
+}
+inline Genotypes read_genotypes(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("failed to open genotype file: " + path);
+    Genotypes g; std::string line; bool first = true;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        auto cols = split_tab(line);
+        if (first) { g.header = join_tab(cols, 1); first = false; continue; }
+        g.map[cols[0]] = std::vector<std::string>(cols.begin() + 1, cols.end());
+        g.rows++;
+    }
+    return g;
+}
+
+// ------------------------------------------------------------------ FASTA / FASTQ (+gzip)
+class FastxReader {
+  public:
+    explicit FastxReader(const std::string& path) {  // "-" = stdin; gzip is detected by zlib itself
+        gz = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+        if (!gz) throw std::runtime_error("failed to open Fastx file: " + path);
+        gzbuffer(gz, 1 << 20);
+    }
+    ~FastxReader() { if (gz) gzclose(gz); }
+    // next record's sequence bytes (as in the file: case kept, line breaks of multi-line FASTA removed)
+    bool next(std::string& seq) {
+        std::string line;
+        while (pending.empty()) { if (!getline(line)) return false; if (!line.empty()) pending = line; }
+        seq.clear();
+        if (pending[0] == '>') {
+            pending.clear();
+            while (getline(line)) { if (!line.empty() && line[0] == '>') { pending = line; break; } seq += line; }
+            return true;
+        }
+        if (pending[0] == '@') {
+            pending.clear();
+            if (!getline(seq)) throw std::runtime_error("truncated FASTQ record");
+            std::string plus, qual;
+            if (!getline(plus) || plus.empty() || plus[0] != '+') throw std::runtime_error("malformed FASTQ record (no '+' line)");
+            if (!getline(qual)) throw std::runtime_error("truncated FASTQ record");
+            return true;
+        }
+        throw std::runtime_error("input is neither FASTA nor FASTQ");
+    }
+  private:
+    bool getline(std::string& line) {
+        line.clear();
+        char buf[1 << 16];
+        for (;;) {
+            if (!gzgets(gz, buf, sizeof buf)) return !line.empty();
+            line += buf;
+            if (!line.empty() && line.back() == '\n') { line.pop_back(); if (!line.empty() && line.back() == '\r') line.pop_back(); return true; }
+        }
+    }
+    gzFile gz = nullptr;
+    std::string pending;
+};
+
+}  // namespace sketchy

@@ -1,0 +1,137 @@
+"""The C++ host (sketchy_amd/host): parsers on CPU, `predict` / `shared` text output on the GPU against rows built
+from the oracle.  Output grammar: src/sketchy.rs:99-101 (header), :391-398 (rows)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import unpack_reads, workload
+from mshio import write_msh
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "sketchy_amd", "sketchy-hip")
+
+
+def _run(*args, stdin=None):
+    p = subprocess.run([BIN, *args], input=stdin, capture_output=True)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def _fixture(tmp_path, n=40, s=128, n_reads=30, k=16, seed=0):
+    ref, bases, offsets = workload(n, s, n_reads, read_len=500, k=k, seed=seed, genome_len=40000, rng_seed=321)
+    names = [f"genome{i:03d}.fa" for i in range(n)]
+    msh = str(tmp_path / "ref.msh")
+    write_msh(msh, names, ref["ref"], kmer=k, seed=seed, lengths=[40000] * n)
+    tsv = str(tmp_path / "geno.tsv")
+    with open(tsv, "w") as f:
+        f.write("id\tmlst\tmeca\tpvl\n")
+        for i, nm in enumerate(names):
+            f.write(f"{nm}\tST{i % 7}\t{'R' if i % 3 else 'S'}\t{'+' if i % 5 == 0 else '-'}\n")
+    reads = unpack_reads(bases, offsets)
+    return ref, names, msh, tsv, reads, bases, offsets
+
+
+def test_binary_is_built():
+    from sketchy_amd import build
+    build.build()
+    assert os.path.exists(BIN)
+
+
+def test_info_reads_msh_written_by_python(tmp_path):
+    ref, names, msh, tsv, reads, _, _ = _fixture(tmp_path)
+    rc, out, err = _run("info", "-i", msh)
+    assert rc == 0, err
+    lines = out.strip().split("\n")
+    assert lines == [f"{nm} 40000 128" for nm in names]
+    rc, out, err = _run("info", "-i", msh, "-p")
+    assert rc == 0 and "sketch_size=128" in out and "kmer_size=16" in out and "seed=0" in out
+    write_msh(str(tmp_path / "s42.msh"), names[:2], ref["ref"][:2], kmer=21, seed=42)
+    rc, out, err = _run("info", "-i", str(tmp_path / "s42.msh"), "-p")
+    assert "kmer_size=21" in out and "seed=42" in out
+
+
+def test_errors_without_gpu_work(tmp_path):
+    rc, out, err = _run("info", "-i", str(tmp_path / "nope.msh"))
+    assert rc == 1 and "failed to open" in err
+    (tmp_path / "x.txt").write_text("x")
+    rc, out, err = _run("info", "-i", str(tmp_path / "x.txt"))
+    assert rc == 1 and "must have Mash (.msh) or Finch (.fsh) extension" in err
+    ref, names, msh, tsv, reads, _, _ = _fixture(tmp_path)
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-c", "-t", "2", "-i", msh)
+    assert rc == 1 and "--top must be an odd number" in err  # src/sketchy.rs:74-79
+
+
+def _expected_stream(ref, names, tsv, bases, offsets, top, limit=0, header=False):
+    n = len(offsets) - 1 if not limit else min(limit, len(offsets) - 1)
+    exp = orc.stream(16, 0, ref["ref"].shape[1], ref["ref"], ref["col_len"], bases, offsets[:n + 1], top_k=top)
+    geno = {l.split("\t")[0]: l.rstrip("\n").split("\t")[1:] for l in open(tsv).readlines()[1:]}
+    lines = ["reads\tsketch_id\tshared_hashes\tmlst\tmeca\tpvl"] if header else []
+    for r in range(n):
+        for j in range(top):
+            nm = names[exp["topk_idx"][r, j]]
+            lines.append(f"{r + 1}\t{nm}\t{exp['topk_sum'][r, j]}\t" + "\t".join(geno[nm]))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.gpu
+def test_predict_stream_rows_fastq_fasta_gz_stdin(gpu, tmp_path):
+    ref, names, msh, tsv, reads, bases, offsets = _fixture(tmp_path)
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@read{i} desc\n{r.decode()}\n+\n{'I' * len(r)}\n")
+    fa = str(tmp_path / "reads.fa.gz")
+    with gzip.open(fa, "wt") as f:
+        for i, r in enumerate(reads):
+            s = r.decode()
+            f.write(f">read{i}\n" + "\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + "\n")
+    want = _expected_stream(ref, names, tsv, bases, offsets, top=3, header=True)
+    for src in (fq, fa):
+        rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", src, "-t", "3", "-s", "-H", "-b", "7")
+        assert rc == 0, err
+        assert out == want
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-t", "3", "--stream", "--header", stdin=open(fq, "rb").read())
+    assert rc == 0 and out == want
+    # --limit (src/sketchy.rs:350-353) and default top = 1
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", fq, "-s", "-l", "11")
+    assert rc == 0 and out == _expected_stream(ref, names, tsv, bases, offsets, top=1, limit=11)
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", fq, "-s", "-t", "41")
+    assert rc == 1 and "--top exceeds" in err
+
+
+@pytest.mark.gpu
+def test_predict_offline_pools_all_reads(gpu, tmp_path):
+    """Offline mode (src/sketchy.rs:281-315): ONE sketcher over all reads, one ranking."""
+    ref, names, msh, tsv, reads, bases, offsets = _fixture(tmp_path)
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@r{i}\n{r.decode()}\n+\n{'I' * len(r)}\n")
+    s = ref["ref"].shape[1]
+    for limit in (0, 9):
+        use = reads if not limit else reads[:limit]
+        pooled = sorted({int(h) for r in use for h in orc.sketch(r, 16, 0, 10 ** 7)})[:s]
+        common = np.array([orc.common_hashes(ref["ref"][g], np.array(pooled, np.uint64)) for g in range(len(names))])
+        order = orc.stable_rank(common.astype(np.uint64))[:5]
+        geno = {l.split("\t")[0]: l.rstrip("\n").split("\t")[1:] for l in open(tsv).readlines()[1:]}
+        want = "".join(f"{len(use)}\t{names[g]}\t{common[g]}\t" + "\t".join(geno[names[g]]) + "\n" for g in order)
+        args = ["predict", "-r", msh, "-g", tsv, "-i", fq, "-t", "5", "-b", "8"] + (["-l", str(limit)] if limit else [])
+        rc, out, err = _run(*args)
+        assert rc == 0, err
+        assert out == want
+
+
+@pytest.mark.gpu
+def test_shared_subcommand(gpu, tmp_path):
+    ref, names, msh, tsv, reads, _, _ = _fixture(tmp_path)
+    q = str(tmp_path / "query.msh")
+    write_msh(q, names[:3], ref["ref"][:3])
+    rc, out, err = _run("shared", "-r", msh, "-q", q)
+    assert rc == 0, err
+    want = "".join(f"{names[r]} {names[i]} {orc.common_hashes(ref['ref'][r], ref['ref'][i])}\n"
+                   for r in range(len(names)) for i in range(3))
+    assert out == want
+    assert f"{names[1]} {names[1]} 128\n" in out  # docs/index.md:145-149
