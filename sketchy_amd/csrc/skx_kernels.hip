@@ -369,7 +369,11 @@ __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __re
 // the reference scan
 // =====================================================================================
 // One block per (band, tile): 256 lanes = 256 genome columns, rows [b*rb, (b+1)*rb).
-// LDS: open-addressing table of the band's slice of Q (keys 8 B + local index 2 B per slot).
+// LDS: the band's slice of Q itself (sorted, up to CAP entries, 8 B each, plus an end sentinel) and an
+// interpolation directory: the hash range [slice[0], slice[n-1]] is cut into power-of-two wide buckets and
+// dir[b] = index of the first entry whose bucket is >= b.  Query hashes are uniform, so a probe is one u16
+// directory read plus ~1.5 entry reads, and the position found IS the index into Q (no value array, no
+// hashing, no CAS build; twice the entries of an open-addressing table in the same LDS).
 // A lane meets its column's hits in ascending q, so it ORs them into one 64-bit word in a register and
 // flushes that word to M[word][genome] when the word index moves on.  The OR is atomic: the neighbouring
 // band can own bits of the same word.
@@ -378,14 +382,13 @@ __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __re
 // the last row (per lane or as contiguous 2 KB rows), taller bands, runs of bands per block.
 // ABLATE (profiling aid, results invalid unless 0; env SKX_SCAN_ABLATE):
 //   1 = no write to M, 2 = no probe at all (pure streaming), 3 = probe but ignore hits
-template <int TSLOTS, int ABLATE>
+template <int CAP, int ABLATE>
 __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                    const u64* __restrict__ q, const u32* __restrict__ win,
                                                    u64* __restrict__ m_bits, u32 n_pad) {
-    constexpr u32 kMask = TSLOTS - 1;
-    constexpr u32 kSub = TSLOTS / 2;  // entries per table build (load factor <= 0.5)
-    __shared__ u64 keys[TSLOTS];
-    __shared__ unsigned short vals[TSLOTS];
+    constexpr u32 kBuckets = 2048;  // directory entries (power of two); CAP = 2040 keeps the block at 20 KB of LDS
+    __shared__ u64 slice[CAP + 1];
+    __shared__ unsigned short dir[kBuckets + 1];
     const u32 bt = blockIdx.x;
     const u32 t = bt % n_tiles, b = bt / n_tiles, c = threadIdx.x;
     const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
@@ -394,40 +397,46 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
     const u64* col = mat + ((size_t)t * s + i0) * kTileGenomes + c;
     const u32 g = t * kTileGenomes + c;
 
-    // a slice larger than one table build is walked in sub-window passes over the same rows (correct for any
-    // slice size; slower, because the band is streamed once per pass)
-    for (u32 sub = qa; sub < qb; sub += kSub) {
-        const u32 n = min(kSub, qb - sub);
-        for (u32 j = c; j < TSLOTS; j += 256u) keys[j] = kEmpty;
+    // a slice larger than CAP is walked in sub-window passes over the same rows (correct for any slice
+    // size; slower, because the band is streamed once per pass)
+    for (u32 sub = qa; sub < qb; sub += CAP) {
+        const u32 n = min((u32)CAP, qb - sub);
+        const u64 lo = q[sub], hi = q[sub + n - 1];
+        // bucket(h) = (h - lo) >> shift, with (hi - lo) >> shift < kBuckets
+        const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
+        const u32 shift = span_bits > (u32)__builtin_ctz(kBuckets) ? span_bits - (u32)__builtin_ctz(kBuckets) : 0u;
+        for (u32 j = c; j < n; j += 256u) slice[j] = q[sub + j];
+        if (c == 0) slice[n] = kPad;
         __syncthreads();
-        for (u32 j = c; j < n; j += 256u) {
-            const u64 h = q[sub + j];
-            u32 slot = (u32)h & kMask;
-            for (;;) {
-                const u64 old = atomicCAS(&keys[slot], kEmpty, h);
-                if (old == kEmpty) { vals[slot] = (unsigned short)j; break; }
-                slot = (slot + 1u) & kMask;
-            }
+        for (u32 j = c; j <= n; j += 256u) {
+            // entry j opens every bucket in (bucket(j-1), bucket(j)]; the sentinel closes the rest
+            const u32 bj = j < n ? (u32)((slice[j] - lo) >> shift) : kBuckets;
+            const u32 bp = j == 0 ? 0xFFFFFFFFu : (u32)((slice[j - 1] - lo) >> shift);
+            for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned short)j;
         }
         __syncthreads();
 
         u32 cur_w = 0xFFFFFFFFu;  // absolute word index (q >> 6)
         u64 cur_bits = 0;
+        u32 kslot = 0;
         auto hit = [&](u32 qi) {
             const u32 w = qi >> 6;
             if (w != cur_w) {
-                if (ABLATE != 1 && cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
+                if (ABLATE == 4) {  // timing only: plain store into a slot nobody else writes
+                    if (cur_bits) { m_bits[((size_t)(bt & 4095u) * 16u + (kslot & 15u)) * 256u + c] = cur_bits ^ cur_w; ++kslot; }
+                } else if (ABLATE != 1 && cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
                 cur_w = w; cur_bits = 0;
             }
             cur_bits |= 1ull << (qi & 63u);
         };
         auto probe = [&](u64 hv) {
             if (ABLATE == 2) { cur_bits ^= hv; return; }
-            u32 slot = (u32)hv & kMask;
-            u64 e = keys[slot];
-            while (e != kEmpty && e != hv) { slot = (slot + 1u) & kMask; e = keys[slot]; }
+            if (hv < lo || hv > hi) return;  // also drops the padding value
+            u32 j = dir[(u32)((hv - lo) >> shift)];
+            u64 e = slice[j];
+            while (e < hv) e = slice[++j];   // the sentinel (all ones) ends every walk
             if (ABLATE == 3) { cur_bits ^= e; return; }
-            if (e == hv) hit(sub + vals[slot]);
+            if (e == hv) hit(sub + j);
         };
         // software-pipelined: the next 8 rows are in flight while the current 8 are probed
         u32 i = 0;
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
         } else if (cur_bits) {
             atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
         }
-        __syncthreads();  // table is rebuilt by the next sub-window
+        __syncthreads();  // slice and directory are rebuilt by the next sub-window
     }
 }
 
@@ -471,13 +480,22 @@ __global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restr
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     const u32 gw = gw0 + wv;
     if (gw < n_gw) {
-        const u64 word = m_bits[(size_t)w * n_pad + gw * 64u + lane];
-        u64 mine = 0;
-#pragma unroll
-        for (u32 j = 0; j < 64u; ++j) {
-            const u64 bal = __ballot((word >> j) & 1ull);
-            if (lane == j) mine = bal;
-        }
+        // 64x64 bit transpose across the wave: lane l holds row l (bit j = query j of genome l); six butterfly
+        // steps swap the off-diagonal d x d blocks between lanes l and l^d; afterwards lane l holds column l.
+        u64 x = m_bits[(size_t)w * n_pad + gw * 64u + lane];
+#define SKX_BFLY(D, LO)                                                                             \
+    {                                                                                              \
+        const u64 p = shfl_xor64(x, D);                                                            \
+        x = (lane & D) ? ((x & ~(LO)) | ((p >> D) & (LO))) : ((x & (LO)) | ((p << D) & ~(LO)));    \
+    }
+        SKX_BFLY(32, 0x00000000FFFFFFFFull)  // LO = bits whose index has bit D clear
+        SKX_BFLY(16, 0x0000FFFF0000FFFFull)
+        SKX_BFLY(8, 0x00FF00FF00FF00FFull)
+        SKX_BFLY(4, 0x0F0F0F0F0F0F0F0Full)
+        SKX_BFLY(2, 0x3333333333333333ull)
+        SKX_BFLY(1, 0x5555555555555555ull)
+#undef SKX_BFLY
+        const u64 mine = x;
         tile[lane][wv] = mine;
     }
     __syncthreads();
@@ -887,11 +905,12 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
                  u64* m_bits, u32 n_pad) {
     static const int ablate = env_int("SKX_SCAN_ABLATE", 0);  // profiling aid only
     dim3 grid(n_tiles * n_bands), block(256);
-#define SKX_SCAN(A) hipLaunchKernelGGL((scan_kernel<2048, A>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad)
+#define SKX_SCAN(A) hipLaunchKernelGGL((scan_kernel<2040, A>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad)
     switch (ablate) {
         case 1: SKX_SCAN(1); break;
         case 2: SKX_SCAN(2); break;
         case 3: SKX_SCAN(3); break;
+        case 4: SKX_SCAN(4); break;
         default: SKX_SCAN(0); break;
     }
 #undef SKX_SCAN
