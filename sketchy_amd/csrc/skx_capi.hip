@@ -452,6 +452,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     hipStream_t hs = st->hs;
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64, n_reads = rb - ra;
     const u32 n_bt = ref->n_bands * ref->n_tiles;
+    const u32 nq_rows = ((P + 63) / 64) * 64;  // rows per tile of the tile-major bit matrix of this pass
     if (P > 0) {
         const u32 n_words = (P + 63) / 64;
         {
@@ -476,21 +477,21 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     if (update_table) {
         Span sp(st, 4);
         const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
-        skx::launch_seg_sum(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq, n_pad, st->d_inc);
+        skx::launch_seg_sum(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq, n_pad, nq_rows, st->d_inc);
         skx::launch_seg_prefix(hs, st->d_inc, n_seg, n_pad, st->d_cum, st->d_start);
         if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad,
-                                      ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx);
+                                      nq_rows, ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx);
             skx::launch_top1_merge(hs, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq,
-                                 n_pad, ref->n_genomes, st->d_start, st->top_k, st->d_cand_sum, st->d_cand_idx);
+                                 n_pad, nq_rows, ref->n_genomes, st->d_start, st->top_k, st->d_cand_sum, st->d_cand_idx);
             skx::launch_topk_merge(hs, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw * st->top_k, st->top_k, d_topk_idx,
                                    d_topk_sum, ra);
         }
     }
     if (d_shared)
-        skx::launch_shared_debug(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad, ref->n_genomes,
+        skx::launch_shared_debug(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad, nq_rows, ref->n_genomes,
                                  d_shared, 0);
     HIPCHK(hipGetLastError());
     return SKX_OK;

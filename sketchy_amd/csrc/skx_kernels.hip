@@ -470,6 +470,24 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
 // =====================================================================================
 // M[word][genome] (bit j of the word = query 64*word + j)  ->  Mq[query][genome word]
 // =====================================================================================
+// 64x64 bit transpose across the wave: lane l holds row l; six butterfly steps swap the off-diagonal d x d
+// blocks between lanes l and l^d; afterwards lane l holds column l (bit j = old bit l of lane j).
+__device__ __forceinline__ u64 transpose64(u64 x, u32 lane) {
+#define SKX_BFLY(D, LO)                                                                             \
+    {                                                                                              \
+        const u64 p = shfl_xor64(x, D);                                                            \
+        x = (lane & D) ? ((x & ~(LO)) | ((p >> D) & (LO))) : ((x & (LO)) | ((p << D) & ~(LO)));    \
+    }
+    SKX_BFLY(32, 0x00000000FFFFFFFFull)  // LO = bits whose index has bit D clear
+    SKX_BFLY(16, 0x0000FFFF0000FFFFull)
+    SKX_BFLY(8, 0x00FF00FF00FF00FFull)
+    SKX_BFLY(4, 0x0F0F0F0F0F0F0F0Full)
+    SKX_BFLY(2, 0x3333333333333333ull)
+    SKX_BFLY(1, 0x5555555555555555ull)
+#undef SKX_BFLY
+    return x;
+}
+
 // One block = 16 waves = one word w x 16 consecutive genome groups: each wave transposes a 64x64
 // bit block with 64 ballots, the block stages [64 queries][16 groups] in LDS and writes 128-byte rows.
 __global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restrict__ m_bits, u32 n_pad, u32 n_words,
@@ -480,27 +498,16 @@ __global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restr
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     const u32 gw = gw0 + wv;
     if (gw < n_gw) {
-        // 64x64 bit transpose across the wave: lane l holds row l (bit j = query j of genome l); six butterfly
-        // steps swap the off-diagonal d x d blocks between lanes l and l^d; afterwards lane l holds column l.
-        u64 x = m_bits[(size_t)w * n_pad + gw * 64u + lane];
-#define SKX_BFLY(D, LO)                                                                             \
-    {                                                                                              \
-        const u64 p = shfl_xor64(x, D);                                                            \
-        x = (lane & D) ? ((x & ~(LO)) | ((p >> D) & (LO))) : ((x & (LO)) | ((p << D) & ~(LO)));    \
-    }
-        SKX_BFLY(32, 0x00000000FFFFFFFFull)  // LO = bits whose index has bit D clear
-        SKX_BFLY(16, 0x0000FFFF0000FFFFull)
-        SKX_BFLY(8, 0x00FF00FF00FF00FFull)
-        SKX_BFLY(4, 0x0F0F0F0F0F0F0F0Full)
-        SKX_BFLY(2, 0x3333333333333333ull)
-        SKX_BFLY(1, 0x5555555555555555ull)
-#undef SKX_BFLY
-        const u64 mine = x;
+        const u64 mine = transpose64(m_bits[(size_t)w * n_pad + gw * 64u + lane], lane);
         tile[lane][wv] = mine;
     }
     __syncthreads();
     const u32 row = threadIdx.x >> 4, col = threadIdx.x & 15u;
-    if (gw0 + col < n_gw) mq[(size_t)(w * 64u + row) * n_gw + gw0 + col] = tile[row][col];
+    // Mq is tile-major: mq[((tile * nq_rows) + q) * 4 + word-in-tile]; a block writes 64 x 32 B contiguous per tile
+    if (gw0 + col < n_gw) {
+        const u32 gwx = gw0 + col;
+        mq[((size_t)(gwx >> 2) * ((size_t)n_words * 64u) + (w * 64u + row)) * 4u + (gwx & 3u)] = tile[row][col];
+    }
 }
 
 // =====================================================================================
@@ -520,9 +527,10 @@ __device__ __forceinline__ u32 add_lane_bit(u32 acc, u64 mask) {
 struct __attribute__((aligned(16))) MaskQuad { u64 w[4]; };
 
 // Lane j of the wave fetches the mask quad of pair p0 + j: 64 independent 32-byte gathers in flight.
-__device__ __forceinline__ MaskQuad gather_quad(const u64* __restrict__ mq, u32 q, u32 n_gw, u32 t, bool on) {
+// mq_t = this tile's [nq_rows][4] slice of the tile-major bit matrix.
+__device__ __forceinline__ MaskQuad gather_quad(const u64* __restrict__ mq_t, u32 q, bool on) {
     MaskQuad m = {{0, 0, 0, 0}};
-    if (on) m = *reinterpret_cast<const MaskQuad*>(mq + (size_t)q * n_gw + 4u * t);
+    if (on) m = *reinterpret_cast<const MaskQuad*>(mq_t + (size_t)q * 4u);
     return m;
 }
 
@@ -533,26 +541,26 @@ __device__ __forceinline__ MaskQuad gather_quad(const u64* __restrict__ mq, u32 
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
-                                                      u32* __restrict__ inc) {
+                                                      u32 nq_rows, u32* __restrict__ inc) {
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_tiles = n_gw >> 2;
     const u32 t = wave % n_tiles, seg = wave / n_tiles;
     if (seg >= n_seg) return;
+    const u64* mq_t = mq + (size_t)t * nq_rows * 4u;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    MaskQuad nxt = gather_quad(mq, (pa + lane < pz) ? pair_q[pa + lane] : 0u, n_gw, t, pa + lane < pz);
+    MaskQuad nxt = gather_quad(mq_t, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
         const u32 n = min(64u, pz - p0);
         const MaskQuad cur = nxt;
         const u32 pn = p0 + 64u + lane;
-        nxt = gather_quad(mq, pn < pz ? pair_q[pn] : 0u, n_gw, t, pn < pz);
-        for (u32 j = 0; j < n; ++j) {
-            a0 = add_lane_bit(a0, readlane64(cur.w[0], (int)j));
-            a1 = add_lane_bit(a1, readlane64(cur.w[1], (int)j));
-            a2 = add_lane_bit(a2, readlane64(cur.w[2], (int)j));
-            a3 = add_lane_bit(a3, readlane64(cur.w[3], (int)j));
-        }
+        nxt = gather_quad(mq_t, pn < pz ? pair_q[pn] : 0u, pn < pz);
+        // lane p holds pair p's four mask words; after the transposes lane g holds, per word, a 64-bit value whose
+        // bit p says "pair p hits my genome": the chunk's contribution is a popcount
+        (void)n;
+        a0 += __popcll(transpose64(cur.w[0], lane)); a1 += __popcll(transpose64(cur.w[1], lane));
+        a2 += __popcll(transpose64(cur.w[2], lane)); a3 += __popcll(transpose64(cur.w[3], lane));
     }
     u32* o = inc + (size_t)seg * n_pad + t * 256u + lane;
     o[0] = a0; o[64] = a1; o[128] = a2; o[192] = a3;
@@ -596,7 +604,8 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
                                                        u32 n_reads, u32 seg_len, const u64* __restrict__ mq,
                                                        u32 n_gw, u32 n_pad, u32 n_genomes,
                                                        const u64* __restrict__ start, u32 top_k,
-                                                       u64* __restrict__ cand_sum, u32* __restrict__ cand_idx) {
+                                                       u64* __restrict__ cand_sum, u32* __restrict__ cand_idx,
+                                                       u32 nq_rows) {
     const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len;
     const u32 gw = wave % n_gw, seg = wave / n_gw;
@@ -631,7 +640,10 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
         const u32 n = min(64u, pz - p0);
         u64 myword = 0; u32 myread = 0;
-        if (lane < n) { myword = mq[(size_t)pair_q[p0 + lane] * n_gw + gw]; myread = pair_r[p0 + lane]; }
+        if (lane < n) {
+            myword = mq[((size_t)(gw >> 2) * nq_rows + pair_q[p0 + lane]) * 4u + (gw & 3u)];
+            myread = pair_r[p0 + lane];
+        }
         for (u32 j = 0; j < n; ++j) {
             const u64 word = readlane64(myword, (int)j);
             const u32 rd = __builtin_amdgcn_readlane(myread, (int)j);
@@ -693,11 +705,13 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u32 n_reads, u32 seg_len /* == 64 */,
                                                             const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                             u32 n_genomes, const u64* __restrict__ start,
-                                                            u64* __restrict__ best_sum, u32* __restrict__ best_idx) {
+                                                            u64* __restrict__ best_sum, u32* __restrict__ best_idx,
+                                                            u32 nq_rows) {
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_tiles = n_gw >> 2;
     const u32 t = wave % n_tiles, seg = wave / n_tiles;
     if (seg >= n_seg) return;
+    const u64* mq_t = mq + (size_t)t * nq_rows * 4u;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g0 = t * 256u + lane;
@@ -730,21 +744,24 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         cur = r_stop;
     };
 
-    MaskQuad nxt = gather_quad(mq, (pa + lane < pz) ? pair_q[pa + lane] : 0u, n_gw, t, pa + lane < pz);
+    MaskQuad nxt = gather_quad(mq_t, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
     u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
         const u32 n = min(64u, pz - p0);
         const MaskQuad cur_m = nxt;
         const u32 rv = rnxt;
         const u32 pn = p0 + 64u + lane;
-        nxt = gather_quad(mq, pn < pz ? pair_q[pn] : 0u, n_gw, t, pn < pz);
+        nxt = gather_quad(mq_t, pn < pz ? pair_q[pn] : 0u, pn < pz);
         rnxt = pn < pz ? pair_r[pn] : 0u;
-        for (u32 j = 0; j < n; ++j) {
-            emit_upto(__builtin_amdgcn_readlane(rv, (int)j));
-            v0 = add_lane_bit(v0, readlane64(cur_m.w[0], (int)j));
-            v1 = add_lane_bit(v1, readlane64(cur_m.w[1], (int)j));
-            v2 = add_lane_bit(v2, readlane64(cur_m.w[2], (int)j));
-            v3 = add_lane_bit(v3, readlane64(cur_m.w[3], (int)j));
+        const u64 x0 = transpose64(cur_m.w[0], lane), x1 = transpose64(cur_m.w[1], lane);
+        const u64 x2 = transpose64(cur_m.w[2], lane), x3 = transpose64(cur_m.w[3], lane);
+        for (u32 j = 0; j < n;) {
+            const u32 rd = __builtin_amdgcn_readlane(rv, (int)j);
+            emit_upto(rd);                                   // reads before rd see the state without rd's pairs
+            const u64 m = __ballot(lane < n && rv == rd);    // rd's pairs inside this chunk (contiguous from j)
+            v0 += __popcll(x0 & m); v1 += __popcll(x1 & m);
+            v2 += __popcll(x2 & m); v3 += __popcll(x3 & m);
+            j += __popcll(m);
         }
     }
     emit_upto(rz);
@@ -810,12 +827,13 @@ __global__ __launch_bounds__(1024) void rank_table_kernel(const u64* __restrict_
 __global__ __launch_bounds__(256) void shared_debug_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                            u32 p_base, u32 r_begin, const u64* __restrict__ mq,
                                                            u32 n_gw, u32 n_genomes, u32* __restrict__ shared,
-                                                           u32 out_r0) {
+                                                           u32 out_r0, u32 nq_rows) {
     const u32 r = blockIdx.x;
     const u32 pa = poff[r_begin + r] - p_base, pz = poff[r_begin + r + 1] - p_base;
     for (u32 g = threadIdx.x; g < n_genomes; g += 256u) {
         u32 acc = 0;
-        for (u32 p = pa; p < pz; ++p) acc += (u32)((mq[(size_t)pair_q[p] * n_gw + (g >> 6)] >> (g & 63u)) & 1ull);
+        for (u32 p = pa; p < pz; ++p)
+            acc += (u32)((mq[((size_t)(g >> 8) * nq_rows + pair_q[p]) * 4u + ((g >> 6) & 3u)] >> (g & 63u)) & 1ull);
         shared[(size_t)(out_r0 + r) * n_genomes + g] = acc;
     }
 }
@@ -922,28 +940,28 @@ void launch_transpose_bits(hipStream_t st, const u64* m_bits, u32 n_pad, u32 n_w
                        n_words, mq, n_gw);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32* inc) {
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     hipLaunchKernelGGL(seg_sum_kernel, dim3(cdiv((u64)n_seg * (n_gw / 4), 4)), dim3(256), 0, st, pair_q, poff, p_base,
-                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, inc);
+                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u64* cum, u64* start) {
     hipLaunchKernelGGL(seg_prefix_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, inc, n_seg, n_pad, cum, start);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 n_genomes, const u64* start, u32 top_k,
-                     u64* cand_sum, u32* cand_idx) {
+                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
+                     u32 top_k, u64* cand_sum, u32* cand_idx) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     hipLaunchKernelGGL(rank_seg_kernel, dim3(cdiv((u64)n_seg * n_gw, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, seg_len, mq, n_gw, n_pad, n_genomes, start, top_k, cand_sum,
-                       cand_idx);
+                       cand_idx, nq_rows);
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                          u32 n_reads, const u64* mq, u32 n_pad, u32 n_genomes, const u64* start, u64* best_sum,
-                          u32* best_idx) {
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
+                          u64* best_sum, u32* best_idx) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * (n_gw / 4), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx);
+                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx, nq_rows);
 }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0) {
@@ -961,10 +979,10 @@ void launch_rank_table(hipStream_t st, const u64* cum, u32 n_genomes, u32 top_k,
     hipLaunchKernelGGL(rank_table_kernel, dim3(1), dim3(1024), 0, st, cum, n_genomes, top_k, out_idx, out_sum);
 }
 void launch_shared_debug(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                         const u64* mq, u32 n_pad, u32 n_genomes, u32* shared, u32 out_r0) {
+                         const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, u32* shared, u32 out_r0) {
     if (n_reads == 0) return;
     hipLaunchKernelGGL(shared_debug_kernel, dim3(n_reads), dim3(256), 0, st, pair_q, poff, p_base, r_begin, mq,
-                       n_pad / 64, n_genomes, shared, out_r0);
+                       n_pad / 64, n_genomes, shared, out_r0, nq_rows);
 }
 void launch_add_table(hipStream_t st, u64* cum, const u64* add, u32 n) {
     hipLaunchKernelGGL(add_table_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, cum, add, n);
