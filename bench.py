@@ -34,13 +34,25 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def _pmc_traffic(config, batch):
+    """HBM bytes per scan_kernel launch from the committed rocprofv3 PMC passes (profiles/scan_traffic.json:
+    FETCH_SIZE x 1024 x 2 [gfx950 under-reports wide streaming reads 2x] + WRITE_SIZE x 1024), for the
+    same config and batch; None when no matching profile is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "scan_traffic.json")) as f:
+            t = json.load(f)
+        return t.get(f"{config}_b{batch}", {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default: ~100k reads / batch")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=4096, help="reads per step")
+    ap.add_argument("--batch", type=int, default=16384, help="reads per step (scan amortised over this many reads)")
     ap.add_argument("--top", type=int, default=1, help="rows ranked after every read (sketchy default 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
@@ -131,7 +143,7 @@ def main():
             scan_ms = prof["scan"]["ms"] / prof["scan"]["launches"]
             achieved = pass_bytes / (scan_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(args.config, B),
                                "kernel": "scan_kernel", "avg_launch_ms": scan_ms, "launches_per_step": prof["scan"]["launches"] / K,
                                "algorithmic_bytes_per_launch": pass_bytes}
             out["stage_ms_per_step"] = {n: v["ms"] / K for n, v in prof.items()}

@@ -292,7 +292,7 @@ struct skx_stream {
     // pass workspace
     u64 *d_pair_h = nullptr, *d_sorted = nullptr, *d_q = nullptr;
     u32 *d_pair_r = nullptr, *d_pair_q = nullptr, *d_nq = nullptr, *d_win = nullptr;
-    u64 *d_m = nullptr, *d_mq = nullptr;
+    u64 *d_m = nullptr, *d_mint = nullptr, *d_mq = nullptr;
     u32* d_inc = nullptr;
     u64 *d_start = nullptr, *d_cand_sum = nullptr;
     u32* d_cand_idx = nullptr;
@@ -317,7 +317,7 @@ static void stream_free(skx_stream* st) {
     (void)hipSetDevice(st->device);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
-                    st->d_q, st->d_pair_r, st->d_pair_q, st->d_nq, st->d_win, st->d_m, st->d_mq, st->d_inc, st->d_start,
+                    st->d_q, st->d_pair_r, st->d_pair_q, st->d_nq, st->d_win, st->d_m, st->d_mint, st->d_mq, st->d_inc, st->d_start,
                     st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_topk_idx, st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
@@ -336,13 +336,13 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     st->ref = ref; st->device = ref->device; st->top_k = top_k; st->max_reads = max_reads; st->max_bases = max_bases;
     st->sk_stride = sk_stride;
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
-    // pass capacity: keep each of M / Mq within ~1 GB, and never below one read's worth of pairs
-    u64 pc = (1024ull << 20) * 8 / n_pad;
+    // pass capacity: keep each of the three bit matrices within ~2 GB, and never below one read's worth of pairs
+    u64 pc = (2048ull << 20) * 8 / n_pad;
     pc = std::min<u64>(pc, 1u << 20);
     pc = std::max<u64>(pc, sk_stride);
     pc = (pc + 63) / 64 * 64;
     st->pcap = (u32)pc;
-    u64 rp = std::min<u64>(max_reads, 16384);
+    u64 rp = std::min<u64>(max_reads, 65536);
     if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (1ull << 30) / ((u64)n_gw * top_k * 12)));
     rp = std::max<u64>(rp, 1);
     st->rpass = (u32)rp;
@@ -366,6 +366,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_nq, 64));
     SCHK(hipMalloc(&st->d_win, (size_t)n_bt * 8));
     SCHK(hipMalloc(&st->d_m, (size_t)(st->pcap / 64) * n_pad * 8));
+    SCHK(hipMalloc(&st->d_mint, (size_t)(st->pcap / 64) * n_pad * 8));
     SCHK(hipMalloc(&st->d_mq, (size_t)st->pcap * n_gw * 8));
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_start, (size_t)n_seg_max * n_pad * 8));
@@ -455,6 +456,9 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     const u32 nq_rows = ((P + 63) / 64) * 64;  // rows per tile of the tile-major bit matrix of this pass
     if (P > 0) {
         const u32 n_words = (P + 63) / 64;
+        // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
+        static const int split_env = getenv("SKX_SCAN_SPLIT") ? atoi(getenv("SKX_SCAN_SPLIT")) : -1;
+        const bool split = split_env >= 0 ? split_env != 0 : ((u64)P * ref->rb / ref->s >= 192);
         {
             Span sp(st, 1);
             skx::launch_gather_pairs(hs, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, st->d_pair_r);
@@ -463,15 +467,17 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
             skx::launch_pair_q(hs, st->d_pair_h, P, st->d_q, st->d_nq, st->d_pair_q);
             skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, st->d_q, st->d_nq, st->d_win);
             HIPCHK(hipMemsetAsync(st->d_m, 0, (size_t)n_words * n_pad * 8, hs));
+            if (split) HIPCHK(hipMemsetAsync(st->d_mint, 0, (size_t)n_words * n_pad * 8, hs));
             skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, st->d_q, st->d_nq, st->d_m, n_pad);
         }
         {
             Span sp(st, 2);
-            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, st->d_q, st->d_win, st->d_m, n_pad);
+            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, st->d_q, st->d_win, st->d_m,
+                             split ? st->d_mint : nullptr, n_pad);
         }
         {
             Span sp(st, 3);
-            skx::launch_transpose_bits(hs, st->d_m, n_pad, n_words, st->d_mq);
+            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, st->d_mq);
         }
     }
     if (update_table) {

@@ -88,23 +88,27 @@ __global__ __launch_bounds__(256) void band_bounds_kernel(const u64* __restrict_
 // =====================================================================================
 // read sketching: one wavefront per read
 // =====================================================================================
-// LDS per wave: hashes[CAP] u64, then codes[CAP + 64] bytes.
+// LDS per wave: hashes[HCAP] u64, then codes[CAP + 64] bytes (CAP = most k-mers a read may have here).
 // INRANGE: keep only hashes <= max_ref before sorting.  Every such hash is smaller than every
 // dropped one, so the first min(s, #distinct kept) of them ARE the part of the bottom-s sketch that
 // can meet the reference (the only part scoring needs); out_len is then that count, not |sketch|.
-template <int KT, int CAP, bool INRANGE>
+// HCAP < CAP (INRANGE only): small hash buffer for full occupancy; a read with more than HCAP kept hashes is
+// flagged (out_len = kSketchRetry) and redone by a second launch with HCAP = CAP and only_flagged = 1.
+constexpr u32 kSketchRetry = 0xFFFFFFFFu;
+template <int KT, int CAP, int HCAP, bool INRANGE>
 __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
                                                           const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
                                                           u64 seed, u32 s, u64 max_ref, u64* __restrict__ out_sk,
                                                           u32 sk_stride, u32* __restrict__ out_len,
-                                                          u32* __restrict__ out_cnt_in) {
+                                                          u32* __restrict__ out_cnt_in, u32 only_flagged) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr u32 kPerWave = CAP * 8 + CAP + 64;
+    constexpr u32 kPerWave = HCAP * 8 + CAP + 64;
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     const u32 r = blockIdx.x * 4u + wv;
     if (r >= n_reads) return;
+    if (only_flagged && out_len[r] != kSketchRetry) return;
     u64* hashes = reinterpret_cast<u64*>(smem + (size_t)wv * kPerWave);
-    uint8_t* codes = smem + (size_t)wv * kPerWave + CAP * 8;
+    uint8_t* codes = smem + (size_t)wv * kPerWave + HCAP * 8;
     const u32 k = KT > 0 ? (u32)KT : k_rt;
     const u64 o0 = offsets[r], o1 = offsets[r + 1];
     if (o1 - o0 > (u64)CAP + k - 1u) return;  // long read: sketched by the long_read_* kernels instead
@@ -149,6 +153,10 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
         const u64 h = hash_canonical_packed<KT>(canon, k, seed);
         if (INRANGE) valid = valid && (h <= max_ref);
         const u64 mask = __ballot(valid);
+        if (HCAP < CAP && m + (u32)__popcll(mask) > (u32)HCAP) {  // uniform: hand the read to the big-buffer launch
+            if (lane == 0) { out_len[r] = kSketchRetry; out_cnt_in[r] = 0; }
+            return;
+        }
         if (valid) hashes[m + __popcll(mask & lt)] = h;
         m += __popcll(mask);
     }
@@ -382,10 +390,14 @@ __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __re
 // the last row (per lane or as contiguous 2 KB rows), taller bands, runs of bands per block.
 // ABLATE (profiling aid, results invalid unless 0; env SKX_SCAN_ABLATE):
 //   1 = no write to M, 2 = no probe at all (pure streaming), 3 = probe but ignore hits
-template <int CAP, int ABLATE>
+// SPLIT: only the first and the last word a lane touches in a band can be shared with a neighbouring band; with
+// SPLIT those go (atomically) to m_bits and every word in between -- complete, owned by the lane -- is stored
+// plainly into m_int; the transpose ORs the two arrays.  Atomics cost a memory-side transaction each (~90 G/s),
+// plain stores into exclusively owned words a fraction of that; the two kinds never share a cache line.
+template <int CAP, int ABLATE, bool SPLIT>
 __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                    const u64* __restrict__ q, const u32* __restrict__ win,
-                                                   u64* __restrict__ m_bits, u32 n_pad) {
+                                                   u64* __restrict__ m_bits, u64* __restrict__ m_int, u32 n_pad) {
     constexpr u32 kBuckets = 2048;  // directory entries (power of two); CAP = 2040 keeps the block at 20 KB of LDS
     __shared__ u64 slice[CAP + 1];
     __shared__ unsigned short dir[kBuckets + 1];
@@ -418,13 +430,16 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
 
         u32 cur_w = 0xFFFFFFFFu;  // absolute word index (q >> 6)
         u64 cur_bits = 0;
-        u32 kslot = 0;
+        bool first = true;        // the next flush is this lane's first of the (sub-)pass
+        const bool multi = qb - qa > (u32)CAP;  // several sub-window passes: hits are not in q order across passes
         auto hit = [&](u32 qi) {
             const u32 w = qi >> 6;
             if (w != cur_w) {
-                if (ABLATE == 4) {  // timing only: plain store into a slot nobody else writes
-                    if (cur_bits) { m_bits[((size_t)(bt & 4095u) * 16u + (kslot & 15u)) * 256u + c] = cur_bits ^ cur_w; ++kslot; }
-                } else if (ABLATE != 1 && cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
+                if (ABLATE != 1 && cur_bits) {
+                    if (SPLIT && !first && !multi) m_int[(size_t)cur_w * n_pad + g] = cur_bits;
+                    else atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
+                    first = false;
+                }
                 cur_w = w; cur_bits = 0;
             }
             cur_bits |= 1ull << (qi & 63u);
@@ -490,7 +505,8 @@ __device__ __forceinline__ u64 transpose64(u64 x, u32 lane) {
 
 // One block = 16 waves = one word w x 16 consecutive genome groups: each wave transposes a 64x64
 // bit block with 64 ballots, the block stages [64 queries][16 groups] in LDS and writes 128-byte rows.
-__global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restrict__ m_bits, u32 n_pad, u32 n_words,
+__global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restrict__ m_bits,
+                                                              const u64* __restrict__ m_int, u32 n_pad, u32 n_words,
                                                               u64* __restrict__ mq, u32 n_gw) {
     __shared__ u64 tile[64][17];
     const u32 n_gblk = (n_gw + 15u) / 16u;
@@ -498,7 +514,9 @@ __global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restr
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     const u32 gw = gw0 + wv;
     if (gw < n_gw) {
-        const u64 mine = transpose64(m_bits[(size_t)w * n_pad + gw * 64u + lane], lane);
+        u64 word = m_bits[(size_t)w * n_pad + gw * 64u + lane];
+        if (m_int) word |= m_int[(size_t)w * n_pad + gw * 64u + lane];
+        const u64 mine = transpose64(word, lane);
         tile[lane][wv] = mine;
     }
     __syncthreads();
@@ -572,6 +590,7 @@ __global__ void seg_prefix_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_pad) return;
     u64 run = cum[g];
+#pragma unroll 8
     for (u32 sgi = 0; sgi < n_seg; ++sgi) {
         start[(size_t)sgi * n_pad + g] = run;
         run += inc[(size_t)sgi * n_pad + g];
@@ -858,26 +877,35 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
 }
 
 size_t sketch_wave_lds_bytes() { return 4 * (size_t)(kSketchCap * 8 + kSketchCap + 64); }
+constexpr int kSketchSmallHashes = 256;  // hash slots per read of the in-range fast variant
 
 void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                         u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in) {
     if (n_reads == 0) return;
     const size_t lds = sketch_wave_lds_bytes();
+    const size_t lds_small = 4 * (size_t)(kSketchSmallHashes * 8 + kSketchCap + 64);
     dim3 grid(cdiv(n_reads, 4));
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
-#define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, IR>
+#define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, kSketchCap, IR>
+#define SKX_SK_SMALL(KT) sketch_wave_kernel<KT, kSketchCap, kSketchSmallHashes, true>
     if (!attr_set) {
         const void* fns[] = {(const void*)&SKX_SK(16, false), (const void*)&SKX_SK(16, true),
                              (const void*)&SKX_SK(0, false), (const void*)&SKX_SK(0, true)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-#define SKX_SK_LAUNCH(KT, IR)                                                                                    \
-    hipLaunchKernelGGL((SKX_SK(KT, IR)), grid, dim3(256), lds, st, bases, offsets, n_reads, k, seed, s, max_ref, \
-                       out_sk, sk_stride, out_len, out_cnt_in)
-    if (k == 16) { if (inrange_only) SKX_SK_LAUNCH(16, true); else SKX_SK_LAUNCH(16, false); }
-    else { if (inrange_only) SKX_SK_LAUNCH(0, true); else SKX_SK_LAUNCH(0, false); }
+#define SKX_SK_LAUNCH(KERNEL, LDS, FLAGGED)                                                                      \
+    hipLaunchKernelGGL((KERNEL), grid, dim3(256), LDS, st, bases, offsets, n_reads, k, seed, s, max_ref, out_sk, \
+                       sk_stride, out_len, out_cnt_in, FLAGGED)
+    if (inrange_only) {
+        // fast variant first (full occupancy); reads it flags are redone with the full-size hash buffer
+        if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); }
+        else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); }
+    } else {
+        if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u);
+    }
 #undef SKX_SK_LAUNCH
+#undef SKX_SK_SMALL
 #undef SKX_SK
 }
 
@@ -920,24 +948,24 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
-                 u64* m_bits, u32 n_pad) {
+                 u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad) {
     static const int ablate = env_int("SKX_SCAN_ABLATE", 0);  // profiling aid only
     dim3 grid(n_tiles * n_bands), block(256);
-#define SKX_SCAN(A) hipLaunchKernelGGL((scan_kernel<2040, A>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad)
+#define SKX_SCAN(A, SP) \
+    hipLaunchKernelGGL((scan_kernel<2040, A, SP>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
     switch (ablate) {
-        case 1: SKX_SCAN(1); break;
-        case 2: SKX_SCAN(2); break;
-        case 3: SKX_SCAN(3); break;
-        case 4: SKX_SCAN(4); break;
-        default: SKX_SCAN(0); break;
+        case 1: SKX_SCAN(1, false); break;
+        case 2: SKX_SCAN(2, false); break;
+        case 3: SKX_SCAN(3, false); break;
+        default: if (m_int) SKX_SCAN(0, true); else SKX_SCAN(0, false); break;
     }
 #undef SKX_SCAN
 }
-void launch_transpose_bits(hipStream_t st, const u64* m_bits, u32 n_pad, u32 n_words, u64* mq) {
+void launch_transpose_bits(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, u32 n_words, u64* mq) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
-    hipLaunchKernelGGL(transpose_bits_kernel, dim3(n_words * cdiv(n_gw, 16)), dim3(1024), 0, st, m_bits, n_pad,
-                       n_words, mq, n_gw);
+    hipLaunchKernelGGL(transpose_bits_kernel, dim3(n_words * cdiv(n_gw, 16)), dim3(1024), 0, st, m_bits, m_int,
+                       n_pad, n_words, mq, n_gw);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc) {

@@ -292,3 +292,13 @@ def test_sketch_reads_operator_long(gpu):
             e = orc.sketch(rd, 16, 0, s)
             assert sl[r] == len(e), (s, r)
             np.testing.assert_array_equal(sk[r, :len(e)], e)
+
+
+def test_dense_reference_most_read_hashes_in_range(gpu):
+    """A reference whose sketches cover most of the hash space (s close to the genome's k-mer count): nearly
+    every read hash can match, so the in-range fast sketcher overflows its small buffer and the read is redone
+    by the full-size variant; pairs per read are in the hundreds."""
+    ref, bases, offsets = workload(12, 20000, 40, read_len=1500, genome_len=30000, rng_seed=171)
+    got, exp, _, _ = check(ref, bases, offsets, top=2, want_sketches=False, batches=2)
+    assert exp["shared"].max() > 256
+    check(ref, bases, offsets, top=1)
