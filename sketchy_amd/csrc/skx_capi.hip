@@ -296,7 +296,7 @@ struct skx_stream {
     u32* d_inc = nullptr;
     u64 *d_start = nullptr, *d_cand_sum = nullptr;
     u32* d_cand_idx = nullptr;
-    u64* d_cum = nullptr;
+    u64 *d_cum = nullptr, *d_cum2 = nullptr;  // running table (current) and the buffer the next pass writes
     u32* d_topk_idx = nullptr;
     u64* d_topk_sum = nullptr;
     void* d_tmp = nullptr;
@@ -318,7 +318,7 @@ static void stream_free(skx_stream* st) {
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
                     st->d_q, st->d_pair_r, st->d_pair_q, st->d_nq, st->d_win, st->d_m, st->d_mint, st->d_mq, st->d_inc, st->d_start,
-                    st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_topk_idx, st->d_topk_sum, st->d_tmp};
+                    st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx, st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
@@ -367,7 +367,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_win, (size_t)n_bt * 8));
     SCHK(hipMalloc(&st->d_m, (size_t)(st->pcap / 64) * n_pad * 8));
     SCHK(hipMalloc(&st->d_mint, (size_t)(st->pcap / 64) * n_pad * 8));
-    SCHK(hipMalloc(&st->d_mq, (size_t)st->pcap * n_gw * 8));
+    SCHK(hipMalloc(&st->d_mq, (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_start, (size_t)n_seg_max * n_pad * 8));
     if (top_k) {
@@ -378,6 +378,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     }
     SCHK(hipMalloc(&st->d_cum, (size_t)n_pad * 8));
     SCHK(hipMemset(st->d_cum, 0, (size_t)n_pad * 8));
+    SCHK(hipMalloc(&st->d_cum2, (size_t)n_pad * 8));
+    SCHK(hipMemset(st->d_cum2, 0, (size_t)n_pad * 8));
     st->tmp_bytes = std::max({skx::prim_scan_tmp_bytes(max_reads + 1), skx::prim_sort_tmp_bytes(st->pcap),
                               skx::prim_unique_tmp_bytes(st->pcap)}) + 256;
     SCHK(hipMalloc(&st->d_tmp, st->tmp_bytes));
@@ -484,7 +486,8 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         Span sp(st, 4);
         const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
         skx::launch_seg_sum(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq, n_pad, nq_rows, st->d_inc);
-        skx::launch_seg_prefix(hs, st->d_inc, n_seg, n_pad, st->d_cum, st->d_start);
+        skx::launch_seg_prefix(hs, st->d_inc, n_seg, n_pad, st->d_cum, st->d_cum2, st->d_start);
+        std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on this stream sees the new table
         if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad,
                                       nq_rows, ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx);

@@ -23,6 +23,11 @@
 
 namespace skx {
 
+// position of genome word gw of query row q in the group-major bit matrix Mq (nq_rows rows per group)
+__host__ __device__ __forceinline__ size_t mq_index(u32 gw, u32 q, u32 nq_rows) {
+    return ((size_t)(gw / kRankWords) * nq_rows + q) * kRankWords + gw % kRankWords;
+}
+
 // =====================================================================================
 // reference upload: genome-major columns -> tiled rank-major matrix
 // =====================================================================================
@@ -485,12 +490,35 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
 // =====================================================================================
 // M[word][genome] (bit j of the word = query 64*word + j)  ->  Mq[query][genome word]
 // =====================================================================================
+// Partner exchange x[lane ^ D] for the butterfly, without the LDS crossbar (one LDS pipe per CU is shared by
+// all waves): gfx950's v_permlane32_swap / v_permlane16_swap for D = 32 / 16, DPP row ops for D <= 8.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int D>
+__device__ __forceinline__ u32 xor_lane(u32 v, u32 lane) {
+    if constexpr (D == 32) {
+        const u32x2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r.x = [lo|lo], r.y = [hi|hi]
+        return (lane & 32u) ? r.x : r.y;
+    } else if constexpr (D == 16) {
+        const u32x2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // per 32-lane half, at 16
+        return (lane & 16u) ? r.x : r.y;
+    } else if constexpr (D == 8) {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);            // row_ror:8
+    } else if constexpr (D == 4) {
+        int p = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);                  // row_shl:4 -> lanes 0-3, 8-11
+        return (u32)__builtin_amdgcn_update_dpp(p, (int)v, 0x114, 0xF, 0xA, false);              // row_shr:4 -> lanes 4-7, 12-15
+    } else if constexpr (D == 2) {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);               // quad_perm [2,3,0,1]
+    } else {
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);               // quad_perm [1,0,3,2]
+    }
+}
+
 // 64x64 bit transpose across the wave: lane l holds row l; six butterfly steps swap the off-diagonal d x d
 // blocks between lanes l and l^d; afterwards lane l holds column l (bit j = old bit l of lane j).
 __device__ __forceinline__ u64 transpose64(u64 x, u32 lane) {
 #define SKX_BFLY(D, LO)                                                                             \
     {                                                                                              \
-        const u64 p = shfl_xor64(x, D);                                                            \
+        const u64 p = ((u64)xor_lane<D>((u32)(x >> 32), lane) << 32) | xor_lane<D>((u32)x, lane);   \
         x = (lane & D) ? ((x & ~(LO)) | ((p >> D) & (LO))) : ((x & (LO)) | ((p << D) & ~(LO)));    \
     }
     SKX_BFLY(32, 0x00000000FFFFFFFFull)  // LO = bits whose index has bit D clear
@@ -521,11 +549,9 @@ __global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restr
     }
     __syncthreads();
     const u32 row = threadIdx.x >> 4, col = threadIdx.x & 15u;
-    // Mq is tile-major: mq[((tile * nq_rows) + q) * 4 + word-in-tile]; a block writes 64 x 32 B contiguous per tile
-    if (gw0 + col < n_gw) {
-        const u32 gwx = gw0 + col;
-        mq[((size_t)(gwx >> 2) * ((size_t)n_words * 64u) + (w * 64u + row)) * 4u + (gwx & 3u)] = tile[row][col];
-    }
+    // Mq is group-major (group = kRankWords genome words = 512 genomes): mq[(grp * nq_rows + q) * kRankWords + j];
+    // a block writes 64 x 64 B contiguous per group
+    if (gw0 + col < n_gw) mq[mq_index(gw0 + col, w * 64u + row, n_words * 64u)] = tile[row][col];
 }
 
 // =====================================================================================
@@ -541,61 +567,75 @@ __device__ __forceinline__ u32 add_lane_bit(u32 acc, u64 mask) {
     return out;
 }
 
-// One pair's 4 mask words (256 genomes of one reference tile): 32 contiguous bytes of a row of Mq.
-struct __attribute__((aligned(16))) MaskQuad { u64 w[4]; };
+// One pair's kRankWords mask words (one rank group = 512 genomes): 64 contiguous bytes = one memory sector.
+struct __attribute__((aligned(16))) MaskVec { u64 w[kRankWords]; };
 
-// Lane j of the wave fetches the mask quad of pair p0 + j: 64 independent 32-byte gathers in flight.
-// mq_t = this tile's [nq_rows][4] slice of the tile-major bit matrix.
-__device__ __forceinline__ MaskQuad gather_quad(const u64* __restrict__ mq_t, u32 q, bool on) {
-    MaskQuad m = {{0, 0, 0, 0}};
-    if (on) m = *reinterpret_cast<const MaskQuad*>(mq_t + (size_t)q * 4u);
+// Lane j of the wave fetches the mask words of pair p0 + j: 64 independent 64-byte gathers in flight.
+// mq_g = this group's [nq_rows][kRankWords] slice of the group-major bit matrix.
+__device__ __forceinline__ MaskVec gather_vec(const u64* __restrict__ mq_g, u32 q, bool on) {
+    MaskVec m;
+#pragma unroll
+    for (int j = 0; j < kRankWords; ++j) m.w[j] = 0;
+    if (on) m = *reinterpret_cast<const MaskVec*>(mq_g + (size_t)q * kRankWords);
     return m;
 }
 
 // seg_sum: inc[seg][g] = sum over the segment's pairs of bit(Mq[q][g]).
-// One wave per (reference tile t = 256 genomes = 4 mask words, seg).  Pairs are taken 64 at a time:
-// one gather per lane, then each pair's words are broadcast (v_readlane) and added with one VALU op per
-// word.  The next chunk's gather is issued before the current one is consumed.
+// One wave per (rank group of 512 genomes = 8 mask words, segment).  Pairs are taken 64 at a time: lane p gathers
+// pair p's 8 words (one 64-byte sector), 8 butterfly transposes give lane g, per word, a 64-bit value whose bit p
+// says "pair p hits my genome", and the chunk's contribution is a popcount.  The next chunk's gather is issued
+// before the current one is consumed.
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                       u32 nq_rows, u32* __restrict__ inc) {
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
-    const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_tiles = n_gw >> 2;
-    const u32 t = wave % n_tiles, seg = wave / n_tiles;
+    const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + kRankWords - 1) / kRankWords;
+    const u32 grp = wave % n_grp, seg = wave / n_grp;
     if (seg >= n_seg) return;
-    const u64* mq_t = mq + (size_t)t * nq_rows * 4u;
+    const u64* mq_g = mq + (size_t)grp * nq_rows * kRankWords;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
-    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    MaskQuad nxt = gather_quad(mq_t, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
+    u32 acc[kRankWords];
+#pragma unroll
+    for (int j = 0; j < kRankWords; ++j) acc[j] = 0;
+    MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
-        const u32 n = min(64u, pz - p0);
-        const MaskQuad cur = nxt;
+        const MaskVec cur = nxt;
         const u32 pn = p0 + 64u + lane;
-        nxt = gather_quad(mq_t, pn < pz ? pair_q[pn] : 0u, pn < pz);
-        // lane p holds pair p's four mask words; after the transposes lane g holds, per word, a 64-bit value whose
-        // bit p says "pair p hits my genome": the chunk's contribution is a popcount
-        (void)n;
-        a0 += __popcll(transpose64(cur.w[0], lane)); a1 += __popcll(transpose64(cur.w[1], lane));
-        a2 += __popcll(transpose64(cur.w[2], lane)); a3 += __popcll(transpose64(cur.w[3], lane));
+        nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
+#pragma unroll
+        for (int j = 0; j < kRankWords; ++j) acc[j] += __popcll(transpose64(cur.w[j], lane));
     }
-    u32* o = inc + (size_t)seg * n_pad + t * 256u + lane;
-    o[0] = a0; o[64] = a1; o[128] = a2; o[192] = a3;
+#pragma unroll
+    for (int j = 0; j < kRankWords; ++j) {
+        const u32 gw = grp * kRankWords + j;
+        if (gw < n_gw) inc[(size_t)seg * n_pad + gw * 64u + lane] = acc[j];  // words past n_gw hold no genomes
+    }
 }
 
-// start[seg][g] = cum[g] + sum_{seg' < seg} inc[seg'][g];  cum[g] += sum of all.  One thread per genome.
-__global__ void seg_prefix_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad, u64* __restrict__ cum,
-                                  u64* __restrict__ start) {
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+// start[seg][g] = cum_in[g] + sum_{seg' < seg} inc[seg'][g];  cum_out[g] = cum_in[g] + sum of all.
+// One thread per (genome, chunk of 16 segments): the chunk's base is re-summed from the increments (independent,
+// L2-resident loads) instead of waiting on a 256-step serial chain per genome.  grid: (n_pad/256, n_chunks)
+__global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad,
+                                                         const u64* __restrict__ cum_in, u64* __restrict__ cum_out,
+                                                         u64* __restrict__ start) {
+    const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
-    u64 run = cum[g];
+    const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
+    u64 run = cum_in[g];
+    u32 part = 0;  // a chunk's increments fit 32 bits (<= 16 segments x 64 reads x s)
 #pragma unroll 8
-    for (u32 sgi = 0; sgi < n_seg; ++sgi) {
+    for (u32 sgi = 0; sgi < s0; ++sgi) {
+        part += inc[(size_t)sgi * n_pad + g];
+        if ((sgi & 15u) == 15u) { run += part; part = 0; }
+    }
+    run += part;
+    for (u32 sgi = s0; sgi < s1; ++sgi) {
         start[(size_t)sgi * n_pad + g] = run;
         run += inc[(size_t)sgi * n_pad + g];
     }
-    cum[g] = run;
+    if (s1 == n_seg) cum_out[g] = run;
 }
 
 // (sum desc, index asc) ordering: a ranks before b
@@ -660,7 +700,7 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
         const u32 n = min(64u, pz - p0);
         u64 myword = 0; u32 myread = 0;
         if (lane < n) {
-            myword = mq[((size_t)(gw >> 2) * nq_rows + pair_q[p0 + lane]) * 4u + (gw & 3u)];
+            myword = mq[mq_index(gw, pair_q[p0 + lane], nq_rows)];
             myread = pair_r[p0 + lane];
         }
         for (u32 j = 0; j < n; ++j) {
@@ -712,12 +752,12 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return max(max(a, b), max(c, d));
 }
 
-// rank_seg for top_k == 1.  One wave per (reference tile t = 256 genomes, seg); lane l holds genomes
-// t*256 + 64*j + l, j = 0..3.  Within one segment a genome gains at most G = (#pairs of the segment),
-// so only genomes within G of the tile's best starting sum can ever lead it, and for those
-//   key = ((G - (best - start) + gained + 1) << 8) | ((3 - j) << 6) | (63 - l)
-// fits 32 bits and orders exactly like (sum desc, genome index asc).  The segment's <= 64 results are
-// kept one per lane and stored once: best_sum/best_idx[t * n_reads + r].
+// rank_seg for top_k == 1.  One wave per (rank group of 512 genomes, segment); lane l holds genomes
+// (grp*8 + j)*64 + l, j = 0..7.  Within one segment a genome gains at most G = (#pairs of the segment), so only
+// genomes within G of the group's best starting sum can ever lead it, and for those
+//   key = ((G - (best - start) + gained + 1) << 9) | ((7 - j) << 6) | (63 - l)
+// fits 32 bits and orders exactly like (sum desc, genome index asc).  The segment's <= 64 results are kept one
+// per lane and stored once: best_sum/best_idx[grp * n_reads + r].
 __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restrict__ pair_q,
                                                             const u32* __restrict__ pair_r,
                                                             const u32* __restrict__ poff, u32 p_base, u32 r_begin,
@@ -726,86 +766,95 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u32 n_genomes, const u64* __restrict__ start,
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
                                                             u32 nq_rows) {
+    constexpr int NW = kRankWords, SH = 6 + 3;
+    static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
-    const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_tiles = n_gw >> 2;
-    const u32 t = wave % n_tiles, seg = wave / n_tiles;
+    const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + NW - 1) / NW;
+    const u32 grp = wave % n_grp, seg = wave / n_grp;
     if (seg >= n_seg) return;
-    const u64* mq_t = mq + (size_t)t * nq_rows * 4u;
+    const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
-    const u32 g0 = t * 256u + lane;
-    const u64* sp = start + (size_t)seg * n_pad + g0;
-    const u64 s0 = sp[0], s1 = sp[64], s2 = sp[128], s3 = sp[192];
-    const bool r0 = g0 < n_genomes, r1 = g0 + 64u < n_genomes, r2 = g0 + 128u < n_genomes, r3 = g0 + 192u < n_genomes;
-    // tile's best starting sum among real genomes (ties do not matter here: only the value is used)
+    const u32 g0 = grp * NW * 64u + lane;
+    u64 st0[NW];
+    bool real[NW];
     u64 bs = 0; u32 bi = 0xFFFFFFFFu;
-    if (r0) { bs = s0; bi = g0; }
-    if (r1 && (bi == 0xFFFFFFFFu || s1 > bs)) { bs = s1; bi = g0 + 64u; }
-    if (r2 && (bi == 0xFFFFFFFFu || s2 > bs)) { bs = s2; bi = g0 + 128u; }
-    if (r3 && (bi == 0xFFFFFFFFu || s3 > bs)) { bs = s3; bi = g0 + 192u; }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u32 g = g0 + (u32)j * 64u;
+        real[j] = g < n_genomes;  // also false for words past n_gw (n_genomes <= n_pad)
+        st0[j] = real[j] ? start[(size_t)seg * n_pad + g] : 0;
+        // group's best starting sum among real genomes (ties do not matter here: only the value is used)
+        if (real[j] && (bi == 0xFFFFFFFFu || st0[j] > bs)) { bs = st0[j]; bi = g; }
+    }
     wave_best(bs, bi, bi != 0xFFFFFFFFu);
     const bool any_real = bi != 0xFFFFFFFFu;
     const u32 gain = pz - pa;
-    const bool e0 = r0 && bs - s0 <= (u64)gain, e1 = r1 && bs - s1 <= (u64)gain;
-    const bool e2 = r2 && bs - s2 <= (u64)gain, e3 = r3 && bs - s3 <= (u64)gain;
-    u32 v0 = gain - (u32)(bs - s0) + 1u, v1 = gain - (u32)(bs - s1) + 1u;  // garbage where !e*: masked at emit
-    u32 v2 = gain - (u32)(bs - s2) + 1u, v3 = gain - (u32)(bs - s3) + 1u;
-    const u64 base = bs - gain - 1u;  // winner sum = base + (key >> 8)   (mod 2^64)
-    const u32 c0 = (3u << 6) | (63u - lane), c1 = (2u << 6) | (63u - lane), c2 = (1u << 6) | (63u - lane), c3 = 63u - lane;
+    // Genomes further than G behind the group's best start can never lead within the segment; they (and padding)
+    // get base 0, so their value stays <= G, strictly below the leader's (>= G + 1): no masking needed at emit.
+    u32 val[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) val[j] = (real[j] && bs - st0[j] <= (u64)gain) ? gain - (u32)(bs - st0[j]) + 1u : 0u;
+    const u64 base = bs - gain - 1u;  // winner sum = base + (key >> SH)   (mod 2^64)
+    u32 tiec[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) tiec[j] = ((u32)(NW - 1 - j) << 6) | (63u - lane);
     u32 cur = ra, res_key = 0;
 
     auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
         if (cur >= r_stop) return;
-        const u32 k0 = e0 ? ((v0 << 8) | c0) : 0u, k1 = e1 ? ((v1 << 8) | c1) : 0u;
-        const u32 k2 = e2 ? ((v2 << 8) | c2) : 0u, k3 = e3 ? ((v3 << 8) | c3) : 0u;
-        const u32 key = wave_max_u32(max(max(k0, k1), max(k2, k3)));
+        u32 k = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) k = max(k, (val[j] << SH) | tiec[j]);
+        const u32 key = wave_max_u32(k);
         if (lane >= cur - ra && lane < r_stop - ra) res_key = key;
         cur = r_stop;
     };
 
-    MaskQuad nxt = gather_quad(mq_t, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
+    MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
     u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
         const u32 n = min(64u, pz - p0);
-        const MaskQuad cur_m = nxt;
+        const MaskVec cur_m = nxt;
         const u32 rv = rnxt;
         const u32 pn = p0 + 64u + lane;
-        nxt = gather_quad(mq_t, pn < pz ? pair_q[pn] : 0u, pn < pz);
+        nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
         rnxt = pn < pz ? pair_r[pn] : 0u;
-        const u64 x0 = transpose64(cur_m.w[0], lane), x1 = transpose64(cur_m.w[1], lane);
-        const u64 x2 = transpose64(cur_m.w[2], lane), x3 = transpose64(cur_m.w[3], lane);
+        u64 x[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) x[j] = transpose64(cur_m.w[j], lane);
         for (u32 j = 0; j < n;) {
             const u32 rd = __builtin_amdgcn_readlane(rv, (int)j);
             emit_upto(rd);                                   // reads before rd see the state without rd's pairs
             const u64 m = __ballot(lane < n && rv == rd);    // rd's pairs inside this chunk (contiguous from j)
-            v0 += __popcll(x0 & m); v1 += __popcll(x1 & m);
-            v2 += __popcll(x2 & m); v3 += __popcll(x3 & m);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) val[w] += __popcll(x[w] & m);
             j += __popcll(m);
         }
     }
     emit_upto(rz);
     if (lane < rz - ra) {
-        const size_t o = (size_t)t * n_reads + ra + lane;
-        const bool none = !any_real || res_key == 0;
-        const u32 wl = 63u - (res_key & 63u), wj = 3u - ((res_key >> 6) & 3u);
-        best_sum[o] = none ? 0 : base + (u64)(res_key >> 8);
-        best_idx[o] = none ? 0xFFFFFFFFu : t * 256u + wj * 64u + wl;
+        const size_t o = (size_t)grp * n_reads + ra + lane;
+        const bool none = !any_real;  // (a group with a real genome always has a leader with value >= 1)
+        const u32 wl = 63u - (res_key & 63u), wj = (u32)(NW - 1) - ((res_key >> 6) & (u32)(NW - 1));
+        best_sum[o] = none ? 0 : base + (u64)(res_key >> SH);
+        best_idx[o] = none ? 0xFFFFFFFFu : (grp * NW + wj) * 64u + wl;
     }
 }
 
-// merge for top_k == 1: one lane per read, walking the tiles in index order.  grid: reads/256
+// merge for top_k == 1: one lane per read, walking the rank groups in index order.  grid: reads/256
 __global__ __launch_bounds__(256) void top1_merge_kernel(const u64* __restrict__ best_sum,
-                                                         const u32* __restrict__ best_idx, u32 n_reads, u32 n_tiles,
+                                                         const u32* __restrict__ best_idx, u32 n_reads, u32 n_grp,
                                                          u32* __restrict__ out_idx, u64* __restrict__ out_sum,
                                                          u32 out_r0) {
     const u32 r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n_reads) return;
     u64 bs = 0; u32 bi = 0xFFFFFFFFu;
 #pragma unroll 8
-    for (u32 t = 0; t < n_tiles; ++t) {
+    for (u32 t = 0; t < n_grp; ++t) {
         const u64 s_ = best_sum[(size_t)t * n_reads + r];
         const u32 i_ = best_idx[(size_t)t * n_reads + r];
-        // tiles come in ascending index order: a later tile wins only with a strictly larger sum
+        // groups come in ascending index order: a later group wins only with a strictly larger sum
         if (i_ != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || s_ > bs)) { bs = s_; bi = i_; }
     }
     out_idx[out_r0 + r] = bi;
@@ -852,7 +901,7 @@ __global__ __launch_bounds__(256) void shared_debug_kernel(const u32* __restrict
     for (u32 g = threadIdx.x; g < n_genomes; g += 256u) {
         u32 acc = 0;
         for (u32 p = pa; p < pz; ++p)
-            acc += (u32)((mq[((size_t)(g >> 8) * nq_rows + pair_q[p]) * 4u + ((g >> 6) & 3u)] >> (g & 63u)) & 1ull);
+            acc += (u32)((mq[mq_index(g >> 6, pair_q[p], nq_rows)] >> (g & 63u)) & 1ull);
         shared[(size_t)(out_r0 + r) * n_genomes + g] = acc;
     }
 }
@@ -970,11 +1019,13 @@ void launch_transpose_bits(hipStream_t st, const u64* m_bits, const u64* m_int, 
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(cdiv((u64)n_seg * (n_gw / 4), 4)), dim3(256), 0, st, pair_q, poff, p_base,
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, poff, p_base,
                        r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
 }
-void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u64* cum, u64* start) {
-    hipLaunchKernelGGL(seg_prefix_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, inc, n_seg, n_pad, cum, start);
+void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
+                       u64* start) {
+    hipLaunchKernelGGL(seg_prefix_kernel, dim3(cdiv(n_pad, 256), cdiv(n_seg, 16)), dim3(256), 0, st, inc, n_seg, n_pad,
+                       cum_in, cum_out, start);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
@@ -988,14 +1039,14 @@ void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, 
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
                           u64* best_sum, u32* best_idx) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64);
-    hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * (n_gw / 4), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
+    hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx, nq_rows);
 }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0) {
     if (n_reads == 0) return;
-    hipLaunchKernelGGL(top1_merge_kernel, dim3(cdiv(n_reads, 256)), dim3(256), 0, st, best_sum, best_idx, n_reads, n_gw / 4,
-                       out_idx, out_sum, out_r0);
+    hipLaunchKernelGGL(top1_merge_kernel, dim3(cdiv(n_reads, 256)), dim3(256), 0, st, best_sum, best_idx, n_reads,
+                       cdiv(n_gw, kRankWords), out_idx, out_sum, out_r0);
 }
 void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_cand, u32 top_k,
                        u32* out_idx, u64* out_sum, u32 out_r0) {

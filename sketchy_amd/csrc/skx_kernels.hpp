@@ -11,6 +11,7 @@ typedef unsigned int u32;
 
 constexpr int kSketchCap = 2048;   // k-mers per read the one-wave-per-read sketcher holds in LDS
 constexpr u32 kSegLen = 64;        // reads per ranking segment
+constexpr int kRankWords = 8;      // genome words (x64 genomes) per ranking wave = one 64-byte sector of Mq per pair
 
 // reference upload
 void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 g_base, u32 n_genomes,
@@ -46,7 +47,8 @@ void launch_transpose_bits(hipStream_t st, const u64* m_bits, const u64* m_int, 
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc);
-void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u64* cum, u64* start);
+void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
+                       u64* start);
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
                      u32 top_k, u64* cand_sum, u32* cand_idx);
