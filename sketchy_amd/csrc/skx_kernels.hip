@@ -133,37 +133,70 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
     }
     wave_sync();
 
-    // 2. canonical k-mer hashes, compacted in position order
+    // 2. canonical k-mer hashes, compacted (any order: they are sorted next)
     u32 m = 0;
     const u32 nk = nb >= k ? nb - k + 1u : 0u;
-    for (u32 base = 0; base < nk; base += 64u) {
-        const u32 p = base + lane;
-        bool valid = p < nk;
-        u64 fwd = 0, rc = 0;
-        u32 bad = 0;
-        if (valid) {
-#pragma unroll
-            for (u32 j = 0; j < (KT > 0 ? (u32)KT : 32u); ++j) {
-                if (j < k) {
-                    u32 c = codes[p + j];
-                    bad |= c >> 2;
-                    c &= 3u;
-                    fwd = (fwd << 2) | c;
-                    rc |= (u64)(3u - c) << (2 * j);
-                }
-            }
-        }
-        valid = valid && (bad == 0);
-        const u64 canon = fwd < rc ? fwd : rc;
-        const u64 h = hash_canonical_packed<KT>(canon, k, seed);
+    auto append = [&](bool valid, u64 h) -> bool {  // false: the small hash buffer overflowed (read flagged)
         if (INRANGE) valid = valid && (h <= max_ref);
         const u64 mask = __ballot(valid);
         if (HCAP < CAP && m + (u32)__popcll(mask) > (u32)HCAP) {  // uniform: hand the read to the big-buffer launch
             if (lane == 0) { out_len[r] = kSketchRetry; out_cnt_in[r] = 0; }
-            return;
+            return false;
         }
         if (valid) hashes[m + __popcll(mask & lt)] = h;
         m += __popcll(mask);
+        return true;
+    };
+    if constexpr (KT == 16) {
+        // Each lane walks a contiguous run of positions with ROLLING windows: the 2-bit forward / reverse-
+        // complement codes (for the canonical choice) and their 16 ASCII bytes as two little-endian words each
+        // (the murmur3 block) -- one LDS byte read and a few shifts per k-mer instead of rebuilding all 16 bases.
+        const u32 run = (nk + 63u) / 64u;
+        const u32 p0 = lane * run;
+        u64 fwd = 0, rc = 0;            // 32 significant bits each
+        u64 fa0 = 0, fa1 = 0, ra0 = 0, ra1 = 0;
+        u32 clean = 0;                  // consecutive valid bases ending at the newest one
+        auto push = [&](u32 c) {
+            clean = (c >> 2) ? 0u : clean + 1u;
+            c &= 3u;
+            fwd = ((fwd << 2) | c) & 0xFFFFFFFFull;
+            rc = (rc >> 2) | ((u64)(3u - c) << 30);
+            const u64 a = (0x54474341u >> (8u * c)) & 0xFFu;   // "ACGT"[c]
+            const u64 ca = (0x41434754u >> (8u * c)) & 0xFFu;  // complement: "TGCA"[c]
+            fa0 = (fa0 >> 8) | (fa1 << 56); fa1 = (fa1 >> 8) | (a << 56);
+            ra1 = (ra1 << 8) | (ra0 >> 56); ra0 = (ra0 << 8) | ca;
+        };
+        for (u32 j = 0; j < 15u; ++j) push(p0 + j < nb ? (u32)codes[p0 + j] : 4u);
+        for (u32 t = 0; t < run; ++t) {
+            const u32 p = p0 + t;
+            const bool in = p < nk;
+            push(in ? (u32)codes[p + 15u] : 4u);
+            const bool use_f = fwd < rc;
+            const u64 h = murmur3_h1_words(use_f ? fa0 : ra0, use_f ? fa1 : ra1, 0, 0, 16u, seed);
+            if (!append(in && clean >= 16u, h)) return;
+        }
+    } else {
+        for (u32 base = 0; base < nk; base += 64u) {
+            const u32 p = base + lane;
+            bool valid = p < nk;
+            u64 fwd = 0, rc = 0;
+            u32 bad = 0;
+            if (valid) {
+#pragma unroll
+                for (u32 j = 0; j < 32u; ++j) {
+                    if (j < k) {
+                        u32 c = codes[p + j];
+                        bad |= c >> 2;
+                        c &= 3u;
+                        fwd = (fwd << 2) | c;
+                        rc |= (u64)(3u - c) << (2 * j);
+                    }
+                }
+            }
+            valid = valid && (bad == 0);
+            const u64 h = hash_canonical_packed<KT>(fwd < rc ? fwd : rc, k, seed);
+            if (!append(valid, h)) return;
+        }
     }
     // pad to a power of two (>= 64) for the bitonic network
     u32 p2 = 64;
