@@ -294,6 +294,7 @@ struct skx_stream {
     u32 *d_pair_r = nullptr, *d_pair_q = nullptr, *d_nq = nullptr, *d_win = nullptr;
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq = nullptr;
     u32* d_inc = nullptr;
+    u64* d_csum = nullptr;
     u64 *d_start = nullptr, *d_cand_sum = nullptr;
     u32* d_cand_idx = nullptr;
     u64 *d_cum = nullptr, *d_cum2 = nullptr;  // running table (current) and the buffer the next pass writes
@@ -317,7 +318,7 @@ static void stream_free(skx_stream* st) {
     (void)hipSetDevice(st->device);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
-                    st->d_q, st->d_pair_r, st->d_pair_q, st->d_nq, st->d_win, st->d_m, st->d_mint, st->d_mq, st->d_inc, st->d_start,
+                    st->d_q, st->d_pair_r, st->d_pair_q, st->d_nq, st->d_win, st->d_m, st->d_mint, st->d_mq, st->d_inc, st->d_csum, st->d_start,
                     st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx, st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
@@ -370,6 +371,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_mq, (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_start, (size_t)n_seg_max * n_pad * 8));
+    SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 8));
     if (top_k) {
         SCHK(hipMalloc(&st->d_cand_sum, (size_t)st->rpass * n_gw * top_k * 8));
         SCHK(hipMalloc(&st->d_cand_idx, (size_t)st->rpass * n_gw * top_k * 4));
@@ -461,6 +463,8 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
         static const int split_env = getenv("SKX_SCAN_SPLIT") ? atoi(getenv("SKX_SCAN_SPLIT")) : -1;
         const bool split = split_env >= 0 ? split_env != 0 : ((u64)P * ref->rb / ref->s >= 192);
+        static const int big_env = getenv("SKX_SCAN_BIG") ? atoi(getenv("SKX_SCAN_BIG")) : -1;
+        const bool big = big_env >= 0 ? big_env != 0 : ((u64)P * ref->rb / ref->s >= 900);
         {
             Span sp(st, 1);
             skx::launch_gather_pairs(hs, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, st->d_pair_r);
@@ -475,7 +479,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         {
             Span sp(st, 2);
             skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, st->d_q, st->d_win, st->d_m,
-                             split ? st->d_mint : nullptr, n_pad);
+                             split ? st->d_mint : nullptr, n_pad, big);
         }
         {
             Span sp(st, 3);
@@ -486,7 +490,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         Span sp(st, 4);
         const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
         skx::launch_seg_sum(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq, n_pad, nq_rows, st->d_inc);
-        skx::launch_seg_prefix(hs, st->d_inc, n_seg, n_pad, st->d_cum, st->d_cum2, st->d_start);
+        skx::launch_seg_prefix(hs, st->d_inc, n_seg, n_pad, st->d_cum, st->d_cum2, st->d_start, st->d_csum);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on this stream sees the new table
         if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad,

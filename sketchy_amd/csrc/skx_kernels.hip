@@ -436,7 +436,7 @@ template <int CAP, int ABLATE, bool SPLIT>
 __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                    const u64* __restrict__ q, const u32* __restrict__ win,
                                                    u64* __restrict__ m_bits, u64* __restrict__ m_int, u32 n_pad) {
-    constexpr u32 kBuckets = 2048;  // directory entries (power of two); CAP = 2040 keeps the block at 20 KB of LDS
+    constexpr u32 kBuckets = CAP > 2048 ? 4096 : 2048;  // directory entries (power of two); CAP = 2040 -> 20 KB of LDS
     __shared__ u64 slice[CAP + 1];
     __shared__ unsigned short dir[kBuckets + 1];
     const u32 bt = blockIdx.x;
@@ -647,23 +647,30 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     }
 }
 
-// start[seg][g] = cum_in[g] + sum_{seg' < seg} inc[seg'][g];  cum_out[g] = cum_in[g] + sum of all.
-// One thread per (genome, chunk of 16 segments): the chunk's base is re-summed from the increments (independent,
-// L2-resident loads) instead of waiting on a 256-step serial chain per genome.  grid: (n_pad/256, n_chunks)
-__global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad,
-                                                         const u64* __restrict__ cum_in, u64* __restrict__ cum_out,
-                                                         u64* __restrict__ start) {
+// Segment start values, two-level so no thread walks a long serial chain:
+//   chunk_sum_kernel : csum[c][g] = sum of inc over the 16 segments of chunk c
+//   seg_prefix_kernel: start[seg][g] = cum_in[g] + sum_{seg' < seg} inc[seg'][g]  (base of the chunk from csum, then
+//                      its 16 segments);  the last chunk also writes cum_out[g] = cum_in[g] + sum of all.
+// One thread per (genome, chunk).  grid: (n_pad/256, n_chunks)
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad,
+                                                        u64* __restrict__ csum) {
+    const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
+    if (g >= n_pad) return;
+    const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
+    u64 t = 0;
+#pragma unroll 16
+    for (u32 sgi = s0; sgi < s1; ++sgi) t += inc[(size_t)sgi * n_pad + g];
+    csum[(size_t)c * n_pad + g] = t;
+}
+__global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, const u64* __restrict__ csum,
+                                                         u32 n_seg, u32 n_pad, const u64* __restrict__ cum_in,
+                                                         u64* __restrict__ cum_out, u64* __restrict__ start) {
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
     const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
     u64 run = cum_in[g];
-    u32 part = 0;  // a chunk's increments fit 32 bits (<= 16 segments x 64 reads x s)
 #pragma unroll 8
-    for (u32 sgi = 0; sgi < s0; ++sgi) {
-        part += inc[(size_t)sgi * n_pad + g];
-        if ((sgi & 15u) == 15u) { run += part; part = 0; }
-    }
-    run += part;
+    for (u32 cc = 0; cc < c; ++cc) run += csum[(size_t)cc * n_pad + g];
     for (u32 sgi = s0; sgi < s1; ++sgi) {
         start[(size_t)sgi * n_pad + g] = run;
         run += inc[(size_t)sgi * n_pad + g];
@@ -1030,11 +1037,16 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
-                 u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad) {
+                 u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table) {
     static const int ablate = env_int("SKX_SCAN_ABLATE", 0);  // profiling aid only
     dim3 grid(n_tiles * n_bands), block(256);
 #define SKX_SCAN(A, SP) \
     hipLaunchKernelGGL((scan_kernel<2040, A, SP>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
+    if (big_table && ablate == 0 && m_int) {
+        // very dense passes: 4088-entry slices (40 KB of LDS, 3 blocks per CU) instead of re-streaming the band
+        hipLaunchKernelGGL((scan_kernel<4088, 0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
+        return;
+    }
     switch (ablate) {
         case 1: SKX_SCAN(1, false); break;
         case 2: SKX_SCAN(2, false); break;
@@ -1056,9 +1068,10 @@ void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_ba
                        r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
-                       u64* start) {
-    hipLaunchKernelGGL(seg_prefix_kernel, dim3(cdiv(n_pad, 256), cdiv(n_seg, 16)), dim3(256), 0, st, inc, n_seg, n_pad,
-                       cum_in, cum_out, start);
+                       u64* start, u64* csum /* [ceil(n_seg/16)][n_pad] scratch */) {
+    dim3 grid(cdiv(n_pad, 256), cdiv(n_seg, 16));
+    hipLaunchKernelGGL(chunk_sum_kernel, grid, dim3(256), 0, st, inc, n_seg, n_pad, csum);
+    hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, cum_in, cum_out, start);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,

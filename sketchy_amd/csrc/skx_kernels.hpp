@@ -41,14 +41,14 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
 
 // scan + transpose
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
-                 u64* m_bits, u64* m_int, u32 n_pad);
+                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table);
 void launch_transpose_bits(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, u32 n_words, u64* mq);
 
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc);
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
-                       u64* start);
+                       u64* start, u64* csum);
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
                      u32 top_k, u64* cand_sum, u32* cand_idx);

@@ -119,3 +119,13 @@ def test_oracle_sample_at_full_size(c2):
     np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"])
     np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"])
     np.testing.assert_array_equal(S.table(), exp["cum"])
+
+
+@pytest.mark.parametrize("split,big", [("0", "0"), ("1", "0"), ("1", "1")])
+def test_forced_scan_kernel_variants(gpu, split, big):
+    """The split-array and big-table scan variants are picked automatically only for dense full-size passes;
+    force each of them (env, read once per process) on small ragged inputs and compare with the oracle."""
+    env = dict(os.environ, SKX_SCAN_SPLIT=split, SKX_SCAN_BIG=big)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "variant ok" in out.stdout
