@@ -277,7 +277,18 @@ struct TimedSpan { int stage; hipEvent_t a, b; };
 struct skx_stream {
     const skx_ref* ref = nullptr;
     int device = 0;
-    hipStream_t hs = nullptr;
+    // Three HIP streams form a pipeline over passes, so the stages of consecutive batches overlap:
+    //   hs0  sketch + dictionary (small VALU/latency-bound kernels; independent of the previous batch)
+    //   hs   memsets + reference scan + bit transpose (HBM-bound)
+    //   hs2  running table + per-read ranking (VALU-bound)
+    // Everything handed from one stage to the next (Q, windows, pair lists, Mq, the pass's slice of the pair
+    // offsets) is double-buffered; events order the hand-offs and the reuse of a buffer set two passes later.
+    hipStream_t hs0 = nullptr, hs = nullptr, hs2 = nullptr;  // hs0 / hs2 alias hs at lower pipeline depths
+    int depth = 2;
+    int buf = 0;
+    hipEvent_t ev_dict[2] = {nullptr, nullptr}, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
+    bool front_pending[2] = {false, false};
+    bool back_pending[2] = {false, false};
     u32 top_k = 0, max_reads = 0, sk_stride = 0;
     u64 max_bases = 0;
     u32 pcap = 0;        // pairs per pass
@@ -290,9 +301,10 @@ struct skx_stream {
     u64* d_sk = nullptr;
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
     // pass workspace
-    u64 *d_pair_h = nullptr, *d_sorted = nullptr, *d_q = nullptr;
-    u32 *d_pair_r = nullptr, *d_pair_q = nullptr, *d_nq = nullptr, *d_win = nullptr;
-    u64 *d_m = nullptr, *d_mint = nullptr, *d_mq = nullptr;
+    u64 *d_pair_h = nullptr, *d_sorted = nullptr, *d_q[2] = {nullptr, nullptr};
+    u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
+    u32 *d_pair_r[2] = {nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[2] = {nullptr, nullptr};
+    u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
     u32* d_inc = nullptr;
     u64* d_csum = nullptr;
     u64 *d_start = nullptr, *d_cand_sum = nullptr;
@@ -316,16 +328,27 @@ struct skx_stream {
 static void stream_free(skx_stream* st) {
     if (!st) return;
     (void)hipSetDevice(st->device);
+    if (st->hs0) (void)hipStreamSynchronize(st->hs0);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
+    if (st->hs2) (void)hipStreamSynchronize(st->hs2);
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
-                    st->d_q, st->d_pair_r, st->d_pair_q, st->d_nq, st->d_win, st->d_m, st->d_mint, st->d_mq, st->d_inc, st->d_csum, st->d_start,
-                    st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx, st->d_topk_sum, st->d_tmp};
+                    st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
+                    st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
+                    st->d_csum, st->d_start, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     for (auto& sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : st->ev_pool) (void)hipEventDestroy(ev);
+    for (int i = 0; i < 2; ++i) {
+        if (st->ev_dict[i]) (void)hipEventDestroy(st->ev_dict[i]);
+        if (st->ev_front[i]) (void)hipEventDestroy(st->ev_front[i]);
+        if (st->ev_back[i]) (void)hipEventDestroy(st->ev_back[i]);
+    }
+    if (st->hs0 && st->hs0 != st->hs) (void)hipStreamDestroy(st->hs0);
+    if (st->hs2 && st->hs2 != st->hs) (void)hipStreamDestroy(st->hs2);
     if (st->hs) (void)hipStreamDestroy(st->hs);
     delete st;
 }
@@ -352,7 +375,20 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
 
     hipError_t e;
 #define SCHK(expr) do { e = (expr); if (e != hipSuccess) { stream_free(st); return fail(SKX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
+    // pipeline depth (env SKX_PIPELINE, default 2): 1 = one stream (strictly serial), 2 = {sketch, dictionary, scan,
+    // transpose} | {ranking}, 3 = {sketch, dictionary} | {scan, transpose} | {ranking}.  Measured on MI355X (C2,
+    // B=49152): 9.9 / 10.3 / 10.0 M reads/s -- with three streams the HBM-bound scan loses more from sharing the
+    // CUs (1.55 -> 2.4 ms) than the overlap returns.
+    static const int depth_env = getenv("SKX_PIPELINE") ? atoi(getenv("SKX_PIPELINE")) : 2;
+    st->depth = depth_env < 1 ? 1 : depth_env > 3 ? 3 : depth_env;
     SCHK(hipStreamCreateWithFlags(&st->hs, hipStreamNonBlocking));
+    if (st->depth >= 3) SCHK(hipStreamCreateWithFlags(&st->hs0, hipStreamNonBlocking)); else st->hs0 = st->hs;
+    if (st->depth >= 2) SCHK(hipStreamCreateWithFlags(&st->hs2, hipStreamNonBlocking)); else st->hs2 = st->hs;
+    for (int i = 0; i < 2; ++i) {
+        SCHK(hipEventCreateWithFlags(&st->ev_dict[i], hipEventDisableTiming));
+        SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
+        SCHK(hipEventCreateWithFlags(&st->ev_back[i], hipEventDisableTiming));
+    }
     SCHK(hipMalloc(&st->d_bases, std::max<u64>(max_bases, 1)));
     SCHK(hipMalloc(&st->d_offsets, ((size_t)max_reads + 1) * 8));
     SCHK(hipMalloc(&st->d_sk, (size_t)max_reads * sk_stride * 8));
@@ -361,14 +397,20 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_poff, ((size_t)max_reads + 2) * 4));
     SCHK(hipMalloc(&st->d_pair_h, (size_t)st->pcap * 8));
     SCHK(hipMalloc(&st->d_sorted, (size_t)st->pcap * 8));
-    SCHK(hipMalloc(&st->d_q, (size_t)st->pcap * 8));
-    SCHK(hipMalloc(&st->d_pair_r, (size_t)st->pcap * 4));
-    SCHK(hipMalloc(&st->d_pair_q, (size_t)st->pcap * 4));
-    SCHK(hipMalloc(&st->d_nq, 64));
-    SCHK(hipMalloc(&st->d_win, (size_t)n_bt * 8));
+    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_q[i], (size_t)st->pcap * 8));
+    for (int i = 0; i < 2; ++i) {
+        SCHK(hipMalloc(&st->d_pair_r[i], (size_t)st->pcap * 4));
+        SCHK(hipMalloc(&st->d_pair_q[i], (size_t)st->pcap * 4));
+        SCHK(hipMalloc(&st->d_poff_pass[i], ((size_t)st->rpass + 2) * 4));
+    }
+    for (int i = 0; i < 2; ++i) {
+        SCHK(hipMalloc(&st->d_nq[i], 64));
+        SCHK(hipMalloc(&st->d_win[i], (size_t)n_bt * 8));
+    }
     SCHK(hipMalloc(&st->d_m, (size_t)(st->pcap / 64) * n_pad * 8));
     SCHK(hipMalloc(&st->d_mint, (size_t)(st->pcap / 64) * n_pad * 8));
-    SCHK(hipMalloc(&st->d_mq, (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
+    for (int i = 0; i < 2; ++i)
+        SCHK(hipMalloc(&st->d_mq[i], (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_start, (size_t)n_seg_max * n_pad * 8));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 8));
@@ -416,12 +458,12 @@ static hipEvent_t get_event(skx_stream* st) {
     return ev;
 }
 struct Span {
-    skx_stream* st; int stage; hipEvent_t a = nullptr;
-    Span(skx_stream* s, int stg) : st(s), stage(stg) {
-        if (st->profiling) { a = get_event(st); (void)hipEventRecord(a, st->hs); }
+    skx_stream* st; int stage; hipStream_t on; hipEvent_t a = nullptr;
+    Span(skx_stream* s, int stg, hipStream_t on_ = nullptr) : st(s), stage(stg), on(on_ ? on_ : s->hs0) {
+        if (st->profiling) { a = get_event(st); (void)hipEventRecord(a, on); }
     }
     ~Span() {
-        if (st->profiling) { hipEvent_t b = get_event(st); (void)hipEventRecord(b, st->hs); st->spans.push_back({stage, a, b}); }
+        if (st->profiling) { hipEvent_t b = get_event(st); (void)hipEventRecord(b, on); st->spans.push_back({stage, a, b}); }
     }
 };
 static void collect_spans(skx_stream* st) {
@@ -440,7 +482,9 @@ SKX_API int skx_stream_set_profiling(skx_stream* st, int enabled) {
 SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
+    HIPCHK(hipStreamSynchronize(st->hs0));
     HIPCHK(hipStreamSynchronize(st->hs));
+    HIPCHK(hipStreamSynchronize(st->hs2));
     collect_spans(st);
     for (int i = 0; i < SKX_N_STAGES; ++i) {
         if (ms) ms[i] = st->ms[i];
@@ -454,10 +498,34 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_topk_idx, u64* d_topk_sum,
                     u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table) {
     const skx_ref* ref = st->ref;
-    hipStream_t hs = st->hs;
+    hipStream_t hs0 = st->hs0, hs = st->hs, hs2 = st->hs2;
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64, n_reads = rb - ra;
     const u32 n_bt = ref->n_bands * ref->n_tiles;
-    const u32 nq_rows = ((P + 63) / 64) * 64;  // rows per tile of the tile-major bit matrix of this pass
+    const u32 nq_rows = ((P + 63) / 64) * 64;  // rows per group of the group-major bit matrix of this pass
+    const int b = st->buf;                      // buffer set handed from stage to stage for this pass
+    st->buf ^= 1;
+    u32 *d_pair_r = st->d_pair_r[b], *d_pair_q = st->d_pair_q[b], *d_poff = st->d_poff_pass[b];
+    u32 *d_nq = st->d_nq[b], *d_win = st->d_win[b];
+    u64 *d_mq = st->d_mq[b], *d_q = st->d_q[b];
+
+    // ---- dictionary (stream hs0): set b was last used two passes ago -- by that pass's scan (Q, windows) and
+    // ranking (pair lists, offsets, Mq); wait for both before overwriting it
+    if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs0, st->ev_front[b], 0)); st->front_pending[b] = false; }
+    if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs0, st->ev_back[b], 0)); st->back_pending[b] = false; }
+    HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs0));
+    if (P > 0) {
+        Span sp(st, 1, hs0);
+        skx::launch_gather_pairs(hs0, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r);
+        HIPCHK(skx::prim_sort_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_pair_h, st->d_sorted, P));
+        HIPCHK(skx::prim_unique_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_sorted, d_q, d_nq, P));
+        skx::launch_pair_q(hs0, st->d_pair_h, P, d_q, d_nq, d_pair_q);
+        skx::launch_window(hs0, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(st->ev_dict[b], hs0));
+
+    // ---- scan + transpose (stream hs, HBM-bound)
+    HIPCHK(hipStreamWaitEvent(hs, st->ev_dict[b], 0));
     if (P > 0) {
         const u32 n_words = (P + 63) / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
@@ -466,47 +534,49 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         static const int big_env = getenv("SKX_SCAN_BIG") ? atoi(getenv("SKX_SCAN_BIG")) : -1;
         const bool big = big_env >= 0 ? big_env != 0 : ((u64)P * ref->rb / ref->s >= 900);
         {
-            Span sp(st, 1);
-            skx::launch_gather_pairs(hs, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, st->d_pair_r);
-            HIPCHK(skx::prim_sort_u64(hs, st->d_tmp, st->tmp_bytes, st->d_pair_h, st->d_sorted, P));
-            HIPCHK(skx::prim_unique_u64(hs, st->d_tmp, st->tmp_bytes, st->d_sorted, st->d_q, st->d_nq, P));
-            skx::launch_pair_q(hs, st->d_pair_h, P, st->d_q, st->d_nq, st->d_pair_q);
-            skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, st->d_q, st->d_nq, st->d_win);
+            Span sp(st, 1, hs);
             HIPCHK(hipMemsetAsync(st->d_m, 0, (size_t)n_words * n_pad * 8, hs));
             if (split) HIPCHK(hipMemsetAsync(st->d_mint, 0, (size_t)n_words * n_pad * 8, hs));
-            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, st->d_q, st->d_nq, st->d_m, n_pad);
+            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad);
         }
         {
-            Span sp(st, 2);
-            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, st->d_q, st->d_win, st->d_m,
+            Span sp(st, 2, hs);
+            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, d_q, d_win, st->d_m,
                              split ? st->d_mint : nullptr, n_pad, big);
         }
         {
-            Span sp(st, 3);
-            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, st->d_mq);
+            Span sp(st, 3, hs);
+            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq);
         }
     }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(st->ev_front[b], hs));
+    st->front_pending[b] = true;
+
+    // ---- back half (stream hs2): running table, per-read rows; overlaps the next pass's front half
+    HIPCHK(hipStreamWaitEvent(hs2, st->ev_front[b], 0));
     if (update_table) {
-        Span sp(st, 4);
+        Span sp(st, 4, hs2);
         const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
-        skx::launch_seg_sum(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq, n_pad, nq_rows, st->d_inc);
-        skx::launch_seg_prefix(hs, st->d_inc, n_seg, n_pad, st->d_cum, st->d_cum2, st->d_start, st->d_csum);
-        std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on this stream sees the new table
+        skx::launch_seg_sum(hs2, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, st->d_inc);
+        skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, st->d_cum, st->d_cum2, st->d_start, st->d_csum);
+        std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
-            skx::launch_rank_seg_top1(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad,
-                                      nq_rows, ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx);
-            skx::launch_top1_merge(hs, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
+            skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
+                                      ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx);
+            skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
-            skx::launch_rank_seg(hs, st->d_pair_q, st->d_pair_r, st->d_poff, p_base, ra, n_reads, skx::kSegLen, st->d_mq,
-                                 n_pad, nq_rows, ref->n_genomes, st->d_start, st->top_k, st->d_cand_sum, st->d_cand_idx);
-            skx::launch_topk_merge(hs, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw * st->top_k, st->top_k, d_topk_idx,
+            skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
+                                 ref->n_genomes, st->d_start, st->top_k, st->d_cand_sum, st->d_cand_idx);
+            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw * st->top_k, st->top_k, d_topk_idx,
                                    d_topk_sum, ra);
         }
     }
     if (d_shared)
-        skx::launch_shared_debug(hs, st->d_pair_q, st->d_poff, p_base, ra, n_reads, st->d_mq, n_pad, nq_rows, ref->n_genomes,
-                                 d_shared, 0);
+        skx::launch_shared_debug(hs2, d_pair_q, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, ref->n_genomes, d_shared, 0);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(st->ev_back[b], hs2));
+    st->back_pending[b] = true;
     return SKX_OK;
 }
 
@@ -530,7 +600,7 @@ static int for_each_pass(skx_stream* st, u32 n_reads, F fn) {
 static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u32* d_topk_idx,
                          u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
     const skx_ref* ref = st->ref;
-    hipStream_t hs = st->hs;
+    hipStream_t hs = st->hs0;  // sketching and everything the host reads back run on the first pipeline stream
     if (n_reads == 0) return SKX_OK;
     // the host needs the read lengths (long reads take a different kernel)
     HIPCHK(hipMemcpyAsync(st->h_offsets, d_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, hs));
@@ -564,8 +634,8 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         SKXCHK(run_pass(st, ra, rb, p_base, P, d_topk_idx, d_topk_sum, d_shared, true));
         if (h_shared) {
             HIPCHK(hipMemcpyAsync(h_shared + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
-                                  hipMemcpyDeviceToHost, hs));
-            HIPCHK(hipStreamSynchronize(hs));
+                                  hipMemcpyDeviceToHost, st->hs2));
+            HIPCHK(hipStreamSynchronize(st->hs2));
         }
         return SKX_OK;
     }));
@@ -594,7 +664,7 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     if (n_bases && !bases) return fail(SKX_ERR_INVALID, "bases is NULL");
     if ((topk_idx || topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
     SKXCHK(use_device(st->device));
-    hipStream_t hs = st->hs;
+    hipStream_t hs = st->hs0;
     // rebase offsets to 0 on the way in
     for (u32 r = 0; r <= n_reads; ++r) st->h_offsets[r] = offsets[r] - base0;
     HIPCHK(hipMemcpyAsync(st->d_offsets, st->h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, hs));
@@ -602,9 +672,10 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     HIPCHK(hipStreamSynchronize(hs));  // h_offsets is reused by process_batch
     SKXCHK(process_batch(st, st->d_bases, st->d_offsets, n_reads, st->d_topk_idx, st->d_topk_sum, per_read_shared,
                          reinterpret_cast<u64*>(sketches), sketch_len));
-    if (topk_idx) HIPCHK(hipMemcpyAsync(topk_idx, st->d_topk_idx, (size_t)n_reads * st->top_k * 4, hipMemcpyDeviceToHost, hs));
-    if (topk_sum) HIPCHK(hipMemcpyAsync(topk_sum, st->d_topk_sum, (size_t)n_reads * st->top_k * 8, hipMemcpyDeviceToHost, hs));
-    HIPCHK(hipStreamSynchronize(hs));
+    HIPCHK(hipStreamSynchronize(hs));  // sketch copies (first stream)
+    if (topk_idx) HIPCHK(hipMemcpyAsync(topk_idx, st->d_topk_idx, (size_t)n_reads * st->top_k * 4, hipMemcpyDeviceToHost, st->hs2));
+    if (topk_sum) HIPCHK(hipMemcpyAsync(topk_sum, st->d_topk_sum, (size_t)n_reads * st->top_k * 8, hipMemcpyDeviceToHost, st->hs2));
+    HIPCHK(hipStreamSynchronize(st->hs2));  // the rows are written by the back half
     if (st->profiling) collect_spans(st);
     return SKX_OK;
 }
@@ -625,7 +696,9 @@ SKX_API int skx_stream_push_device(skx_stream* st, const uint8_t* d_bases, const
 SKX_API int skx_stream_sync(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
+    HIPCHK(hipStreamSynchronize(st->hs0));
     HIPCHK(hipStreamSynchronize(st->hs));
+    HIPCHK(hipStreamSynchronize(st->hs2));
     if (st->profiling) collect_spans(st);
     return SKX_OK;
 }
@@ -633,8 +706,9 @@ SKX_API int skx_stream_sync(skx_stream* st) {
 SKX_API int skx_stream_table(skx_stream* st, uint64_t* cum) {
     if (!st || !cum) return fail(SKX_ERR_INVALID, "NULL argument");
     SKXCHK(use_device(st->device));
-    HIPCHK(hipMemcpyAsync(cum, st->d_cum, (size_t)st->ref->n_genomes * 8, hipMemcpyDeviceToHost, st->hs));
-    HIPCHK(hipStreamSynchronize(st->hs));
+    // the running table belongs to the back stream
+    HIPCHK(hipMemcpyAsync(cum, st->d_cum, (size_t)st->ref->n_genomes * 8, hipMemcpyDeviceToHost, st->hs2));
+    HIPCHK(hipStreamSynchronize(st->hs2));
     return SKX_OK;
 }
 SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
@@ -643,8 +717,8 @@ SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
     u64* d_add = nullptr;
     const u32 n = st->ref->n_genomes;
     HIPCHK(hipMalloc(&d_add, (size_t)n * 8));
-    hipError_t e = hipMemcpyAsync(d_add, add, (size_t)n * 8, hipMemcpyHostToDevice, st->hs);
-    if (e == hipSuccess) { skx::launch_add_table(st->hs, st->d_cum, d_add, n); e = hipStreamSynchronize(st->hs); }
+    hipError_t e = hipMemcpyAsync(d_add, add, (size_t)n * 8, hipMemcpyHostToDevice, st->hs2);
+    if (e == hipSuccess) { skx::launch_add_table(st->hs2, st->d_cum, d_add, n); e = hipStreamSynchronize(st->hs2); }
     (void)hipFree(d_add);
     if (e != hipSuccess) return fail(SKX_ERR_HIP, "table_add failed: %s", hipGetErrorString(e));
     return SKX_OK;
@@ -652,8 +726,10 @@ SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
 SKX_API int skx_stream_reset(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
-    HIPCHK(hipMemsetAsync(st->d_cum, 0, (size_t)st->ref->n_pad * 8, st->hs));
+    HIPCHK(hipStreamSynchronize(st->hs0));
     HIPCHK(hipStreamSynchronize(st->hs));
+    HIPCHK(hipMemsetAsync(st->d_cum, 0, (size_t)st->ref->n_pad * 8, st->hs2));
+    HIPCHK(hipStreamSynchronize(st->hs2));
     st->reads_total = 0;
     return SKX_OK;
 }
@@ -670,10 +746,10 @@ SKX_API int skx_stream_rank(skx_stream* st, uint32_t top_k, uint32_t* idx, uint6
     HIPCHK(hipMalloc(&d_i, (size_t)top_k * 4));
     hipError_t e = hipMalloc(&d_s, (size_t)top_k * 8);
     if (e == hipSuccess) {
-        skx::launch_rank_table(st->hs, st->d_cum, st->ref->n_genomes, top_k, d_i, d_s);
-        e = hipMemcpyAsync(idx, d_i, (size_t)top_k * 4, hipMemcpyDeviceToHost, st->hs);
-        if (e == hipSuccess) e = hipMemcpyAsync(sum, d_s, (size_t)top_k * 8, hipMemcpyDeviceToHost, st->hs);
-        if (e == hipSuccess) e = hipStreamSynchronize(st->hs);
+        skx::launch_rank_table(st->hs2, st->d_cum, st->ref->n_genomes, top_k, d_i, d_s);
+        e = hipMemcpyAsync(idx, d_i, (size_t)top_k * 4, hipMemcpyDeviceToHost, st->hs2);
+        if (e == hipSuccess) e = hipMemcpyAsync(sum, d_s, (size_t)top_k * 8, hipMemcpyDeviceToHost, st->hs2);
+        if (e == hipSuccess) e = hipStreamSynchronize(st->hs2);
     }
     (void)hipFree(d_i); (void)hipFree(d_s);
     if (e != hipSuccess) return fail(SKX_ERR_HIP, "rank failed: %s", hipGetErrorString(e));
@@ -754,13 +830,13 @@ SKX_API int skx_common_hashes(const skx_ref* ref, const uint64_t* query, const u
             if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
             if (P == 0) {
-                HIPCHK(hipMemsetAsync(d_shared, 0, (size_t)(rb - ra) * ref->n_genomes * 4, st->hs));
+                HIPCHK(hipMemsetAsync(d_shared, 0, (size_t)(rb - ra) * ref->n_genomes * 4, st->hs2));
             } else {
                 SKXCHK(run_pass(st, ra, rb, p_base, P, nullptr, nullptr, d_shared, false));
             }
             HIPCHK(hipMemcpyAsync(common + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
-                                  hipMemcpyDeviceToHost, st->hs));
-            HIPCHK(hipStreamSynchronize(st->hs));
+                                  hipMemcpyDeviceToHost, st->hs2));
+            HIPCHK(hipStreamSynchronize(st->hs2));
             return SKX_OK;
         });
         if (d_shared) (void)hipFree(d_shared);
@@ -827,9 +903,9 @@ SKX_API int skx_stream_allreduce(skx_stream* st, skx_comm* comm) {
     if (comm->device != st->device) return fail(SKX_ERR_INVALID, "communicator and stream are on different devices");
     SKXCHK(use_device(st->device));
     // one sum all-reduce of the u64 table (8*N bytes: latency-bound); in place
-    ncclResult_t r = g_rccl.AllReduce(st->d_cum, st->d_cum, st->ref->n_genomes, ncclUint64, ncclSum, comm->comm, st->hs);
+    ncclResult_t r = g_rccl.AllReduce(st->d_cum, st->d_cum, st->ref->n_genomes, ncclUint64, ncclSum, comm->comm, st->hs2);
     if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
-    HIPCHK(hipStreamSynchronize(st->hs));
+    HIPCHK(hipStreamSynchronize(st->hs2));
     return SKX_OK;
 }
 SKX_API void skx_comm_destroy(skx_comm* comm) {
