@@ -564,27 +564,36 @@ __device__ __forceinline__ u64 transpose64(u64 x, u32 lane) {
     return x;
 }
 
-// One block = 16 waves = one word w x 16 consecutive genome groups: each wave transposes a 64x64
-// bit block with 64 ballots, the block stages [64 queries][16 groups] in LDS and writes 128-byte rows.
-__global__ __launch_bounds__(1024) void transpose_bits_kernel(const u64* __restrict__ m_bits,
-                                                              const u64* __restrict__ m_int, u32 n_pad, u32 n_words,
-                                                              u64* __restrict__ mq, u32 n_gw) {
-    __shared__ u64 tile[64][17];
-    const u32 n_gblk = (n_gw + 15u) / 16u;
-    const u32 w = blockIdx.x / n_gblk, gw0 = (blockIdx.x % n_gblk) * 16u;
+// One block = 8 waves = one rank group (8 genome words = 512 genomes) x kWordsPerBlock consecutive query words.
+// Per word: every wave loads its 64 genomes' words (512 contiguous bytes), transposes the 64x64 bit block with the
+// butterfly, and the block stages [64 queries][8 words] in LDS and writes 64 x 64 B = 4 KB contiguous of the
+// group-major Mq.  The next word's load is in flight while the current one is transposed and written.
+constexpr u32 kWordsPerBlock = 4;
+__global__ __launch_bounds__(512) void transpose_bits_kernel(const u64* __restrict__ m_bits,
+                                                             const u64* __restrict__ m_int, u32 n_pad, u32 n_words,
+                                                             u64* __restrict__ mq, u32 n_gw) {
+    __shared__ u64 tile[2][64][kRankWords + 1];
+    const u32 grp = blockIdx.x, w0 = blockIdx.y * kWordsPerBlock, w1 = min(n_words, w0 + kWordsPerBlock);
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
-    const u32 gw = gw0 + wv;
-    if (gw < n_gw) {
-        u64 word = m_bits[(size_t)w * n_pad + gw * 64u + lane];
-        if (m_int) word |= m_int[(size_t)w * n_pad + gw * 64u + lane];
-        const u64 mine = transpose64(word, lane);
-        tile[lane][wv] = mine;
+    const u32 gw = grp * kRankWords + wv;
+    const bool on = gw < n_gw;
+    const size_t col = (size_t)gw * 64u + lane;
+    auto load = [&](u32 w) -> u64 {
+        if (!on || w >= w1) return 0;
+        u64 x = m_bits[(size_t)w * n_pad + col];
+        if (m_int) x |= m_int[(size_t)w * n_pad + col];
+        return x;
+    };
+    const u32 row = threadIdx.x >> 3, cw = threadIdx.x & 7u;
+    u64 nxt = load(w0);
+    for (u32 w = w0; w < w1; ++w) {
+        const u64 cur = nxt;
+        nxt = load(w + 1u);
+        const u32 bsel = (w - w0) & 1u;
+        tile[bsel][lane][wv] = transpose64(cur, lane);
+        __syncthreads();  // (double-buffered tile: one barrier per word is enough)
+        if (grp * kRankWords + cw < n_gw) mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = tile[bsel][row][cw];
     }
-    __syncthreads();
-    const u32 row = threadIdx.x >> 4, col = threadIdx.x & 15u;
-    // Mq is group-major (group = kRankWords genome words = 512 genomes): mq[(grp * nq_rows + q) * kRankWords + j];
-    // a block writes 64 x 64 B contiguous per group
-    if (gw0 + col < n_gw) mq[mq_index(gw0 + col, w * 64u + row, n_words * 64u)] = tile[row][col];
 }
 
 // =====================================================================================
@@ -1058,8 +1067,8 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 void launch_transpose_bits(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, u32 n_words, u64* mq) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
-    hipLaunchKernelGGL(transpose_bits_kernel, dim3(n_words * cdiv(n_gw, 16)), dim3(1024), 0, st, m_bits, m_int,
-                       n_pad, n_words, mq, n_gw);
+    hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
+                       m_bits, m_int, n_pad, n_words, mq, n_gw);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc) {
