@@ -409,6 +409,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     }
     SCHK(hipMalloc(&st->d_m, (size_t)(st->pcap / 64) * n_pad * 8));
     SCHK(hipMalloc(&st->d_mint, (size_t)(st->pcap / 64) * n_pad * 8));
+    SCHK(hipMemset(st->d_m, 0, (size_t)(st->pcap / 64) * n_pad * 8));      // kept all-zero between passes
+    SCHK(hipMemset(st->d_mint, 0, (size_t)(st->pcap / 64) * n_pad * 8));   // (the transpose re-zeroes what it reads)
     for (int i = 0; i < 2; ++i)
         SCHK(hipMalloc(&st->d_mq[i], (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
@@ -535,8 +537,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         const bool big = big_env >= 0 ? big_env != 0 : ((u64)P * ref->rb / ref->s >= 900);
         {
             Span sp(st, 1, hs);
-            HIPCHK(hipMemsetAsync(st->d_m, 0, (size_t)n_words * n_pad * 8, hs));
-            if (split) HIPCHK(hipMemsetAsync(st->d_mint, 0, (size_t)n_words * n_pad * 8, hs));
+            // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
             skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad);
         }
         {

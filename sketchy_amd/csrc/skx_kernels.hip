@@ -569,9 +569,10 @@ __device__ __forceinline__ u64 transpose64(u64 x, u32 lane) {
 // butterfly, and the block stages [64 queries][8 words] in LDS and writes 64 x 64 B = 4 KB contiguous of the
 // group-major Mq.  The next word's load is in flight while the current one is transposed and written.
 constexpr u32 kWordsPerBlock = 4;
-__global__ __launch_bounds__(512) void transpose_bits_kernel(const u64* __restrict__ m_bits,
-                                                             const u64* __restrict__ m_int, u32 n_pad, u32 n_words,
-                                                             u64* __restrict__ mq, u32 n_gw) {
+// The kernel also restores the "all zero between passes" state of the word arrays (only words that were set are
+// written back): no memset of 2 x |M| bytes per pass.
+__global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m_bits, u64* __restrict__ m_int,
+                                                             u32 n_pad, u32 n_words, u64* __restrict__ mq, u32 n_gw) {
     __shared__ u64 tile[2][64][kRankWords + 1];
     const u32 grp = blockIdx.x, w0 = blockIdx.y * kWordsPerBlock, w1 = min(n_words, w0 + kWordsPerBlock);
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
@@ -581,7 +582,11 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(const u64* __restri
     auto load = [&](u32 w) -> u64 {
         if (!on || w >= w1) return 0;
         u64 x = m_bits[(size_t)w * n_pad + col];
-        if (m_int) x |= m_int[(size_t)w * n_pad + col];
+        if (x) m_bits[(size_t)w * n_pad + col] = 0;
+        if (m_int) {
+            const u64 y = m_int[(size_t)w * n_pad + col];
+            if (y) { m_int[(size_t)w * n_pad + col] = 0; x |= y; }
+        }
         return x;
     };
     const u32 row = threadIdx.x >> 3, cw = threadIdx.x & 7u;
@@ -1064,7 +1069,7 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
     }
 #undef SKX_SCAN
 }
-void launch_transpose_bits(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, u32 n_words, u64* mq) {
+void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
