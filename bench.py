@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--no-shuffle", action="store_true", help="experiment: keep genomes grouped by lineage")
+    ap.add_argument("--lognormal", type=float, default=0.0,
+                    help="read lengths log-normal around the config's length with this sigma, 200..50000 (C4-style mixed stream)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: every rank uses device 0 (exercises the multi-rank control flow on a 1-GPU box)")
     args = ap.parse_args()
@@ -91,7 +93,8 @@ def main():
     t_ref = time.time() - t0
     n_steps = K + W
     n_distinct = min(n_steps, 8)  # distinct read batches held in HBM; longer runs cycle through them
-    bases, offsets = synth.make_reads(ref["genome"], n_distinct * B, read_len, err=0.05, rng_seed=1000 + rank)
+    bases, offsets = synth.make_reads(ref["genome"], n_distinct * B, read_len, err=0.05, rng_seed=1000 + rank,
+                                      lognormal_sigma=args.lognormal)
     t_gen = time.time() - t0
 
     R = api.ReferenceSketch(ref["ref"], ref["col_len"], k=k, seed=hash_seed, device=dev)
@@ -104,7 +107,8 @@ def main():
     t_setup = time.time() - t0
 
     def step(i):
-        S.push_device(d_bases.ptr, d_offs[i % n_distinct].ptr, B, len(bases), d_ti.ptr if args.top else None,
+        j = i % n_distinct
+        S.push_device(d_bases.ptr, d_offs[j].ptr, B, int(offsets[(j + 1) * B] - offsets[j * B]), d_ti.ptr if args.top else None,
                       d_ts.ptr if args.top else None)
 
     # ---- warmup (untimed)
@@ -161,13 +165,14 @@ def main():
         # a launch is almost pure streaming -- its roofline fraction shows the kernel's HBM efficiency, while the
         # timed run above trades per-launch efficiency for reads/s by amortising each scan over 12x more reads
         if world == 1 and args.config == "c2" and B > 4096:
-            Sb = api.SumOfSharedHashes(R, top=args.top, max_batch_reads=4096, max_batch_bases=4096 * (read_len + 8))
+            nb_small = int(offsets[4096] - offsets[0])
+            Sb = api.SumOfSharedHashes(R, top=args.top, max_batch_reads=4096, max_batch_bases=nb_small)
             d_o = api.DeviceBuffer.from_numpy(offsets[:4097], dev)
             for _ in range(2):
-                Sb.push_device(d_bases.ptr, d_o.ptr, 4096, 4096 * read_len, None, None)
+                Sb.push_device(d_bases.ptr, d_o.ptr, 4096, nb_small, None, None)
             Sb.sync(); Sb.profile(); Sb.set_profiling(True)
             for _ in range(6):
-                Sb.push_device(d_bases.ptr, d_o.ptr, 4096, 4096 * read_len, None, None)
+                Sb.push_device(d_bases.ptr, d_o.ptr, 4096, nb_small, None, None)
             Sb.sync()
             pb = Sb.profile()
             ms_b = pb["scan"]["ms"] / max(1, pb["scan"]["launches"])
@@ -180,7 +185,7 @@ def main():
         # ---- CPU baseline + full-size parity sample (rank 0, N=1 only)
         if world == 1 and args.cpu_seconds > 0:
             from oracle import oracle as orc  # checker / baseline only
-            S2 = api.SumOfSharedHashes(R, top=max(args.top, 1), max_batch_reads=64, max_batch_bases=64 * (read_len + 8))
+            S2 = api.SumOfSharedHashes(R, top=max(args.top, 1), max_batch_reads=64, max_batch_bases=int(offsets[64]) + 1)
             n_done, t_cpu, cum = 0, 0.0, None
             exp_idx, exp_sum = [], []
             while n_done < 64 and (t_cpu < args.cpu_seconds or n_done < 4):
