@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--no-shuffle", action="store_true", help="experiment: keep genomes grouped by lineage")
+    ap.add_argument("--lineages", type=int, default=0, help="experiment: number of lineages of the synthetic clone tree")
     ap.add_argument("--lognormal", type=float, default=0.0,
                     help="read lengths log-normal around the config's length with this sigma, 200..50000 (C4-style mixed stream)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -89,7 +90,7 @@ def main():
     # ---- synthetic data (identical reference on every rank; each rank its own shard of the stream)
     t0 = time.time()
     ref = synth.make_reference(n_genomes, s, k=k, hash_seed=hash_seed, rng_seed=1, device=f"cuda:{local_rank}",
-                               shuffle=not args.no_shuffle)
+                               shuffle=not args.no_shuffle, n_lineages=args.lineages)
     t_ref = time.time() - t0
     n_steps = K + W
     n_distinct = min(n_steps, 8)  # distinct read batches held in HBM; longer runs cycle through them

@@ -381,9 +381,14 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // CUs (1.55 -> 2.4 ms) than the overlap returns.
     static const int depth_env = getenv("SKX_PIPELINE") ? atoi(getenv("SKX_PIPELINE")) : 2;
     st->depth = depth_env < 1 ? 1 : depth_env > 3 ? 3 : depth_env;
-    SCHK(hipStreamCreateWithFlags(&st->hs, hipStreamNonBlocking));
-    if (st->depth >= 3) SCHK(hipStreamCreateWithFlags(&st->hs0, hipStreamNonBlocking)); else st->hs0 = st->hs;
-    if (st->depth >= 2) SCHK(hipStreamCreateWithFlags(&st->hs2, hipStreamNonBlocking)); else st->hs2 = st->hs;
+    // the HBM-bound scan stream gets the higher priority (it needs its full occupancy); the others fill what is left
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
+    static const int prio_env = getenv("SKX_PRIO") ? atoi(getenv("SKX_PRIO")) : 1;
+    if (!prio_env) prio_hi = prio_lo;
+    SCHK(hipStreamCreateWithPriority(&st->hs, hipStreamNonBlocking, prio_hi));
+    if (st->depth >= 3) SCHK(hipStreamCreateWithPriority(&st->hs0, hipStreamNonBlocking, prio_lo)); else st->hs0 = st->hs;
+    if (st->depth >= 2) SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, prio_lo)); else st->hs2 = st->hs;
     for (int i = 0; i < 2; ++i) {
         SCHK(hipEventCreateWithFlags(&st->ev_dict[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
@@ -583,11 +588,12 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
 
 // partition [0, n_reads) into passes by the pair counts in h_poff; calls fn(ra, rb, p_base, P)
 template <class F>
-static int for_each_pass(skx_stream* st, u32 n_reads, F fn) {
+static int for_each_pass(skx_stream* st, u32 n_reads, u32 max_pass_reads, F fn) {
+    const u32 cap = std::max<u32>(1u, std::min<u32>(st->rpass, max_pass_reads));
     u32 ra = 0;
     while (ra < n_reads) {
         u32 rb = ra;
-        while (rb < n_reads && rb - ra < st->rpass && st->h_poff[rb + 1] - st->h_poff[ra] <= st->pcap) ++rb;
+        while (rb < n_reads && rb - ra < cap && st->h_poff[rb + 1] - st->h_poff[ra] <= st->pcap) ++rb;
         if (rb == ra) return fail(SKX_ERR_CAPACITY, "read %u alone has %u candidate hashes > pass capacity %u", ra,
                                   st->h_poff[ra + 1] - st->h_poff[ra], st->pcap);
         SKXCHK(fn(ra, rb, st->h_poff[ra], st->h_poff[rb] - st->h_poff[ra]));
@@ -627,7 +633,9 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     HIPCHK(hipStreamSynchronize(hs));
 
     u32* d_shared = nullptr;
-    SKXCHK(for_each_pass(st, n_reads, [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
+    // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
+    const u32 dbg_cap = h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
+    const int pass_rc = for_each_pass(st, n_reads, dbg_cap, [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
         if (h_shared) {
             if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
@@ -639,8 +647,9 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             HIPCHK(hipStreamSynchronize(st->hs2));
         }
         return SKX_OK;
-    }));
+    });
     if (d_shared) (void)hipFree(d_shared);
+    SKXCHK(pass_rc);
     if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
     if (h_sketches) {
         memset(h_sketches, 0, (size_t)n_reads * ref->s * 8);
@@ -827,7 +836,8 @@ SKX_API int skx_common_hashes(const skx_ref* ref, const uint64_t* query, const u
         if (e == hipSuccess) e = hipMemcpy(st->d_poff, st->h_poff, ((size_t)n_query + 1) * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) { rc = fail(SKX_ERR_HIP, "skx_common_hashes upload: %s", hipGetErrorString(e)); break; }
         u32* d_shared = nullptr;
-        rc = for_each_pass(st, n_query, [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
+        const u32 out_cap = (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4));
+        rc = for_each_pass(st, n_query, out_cap, [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
             if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
             if (P == 0) {
