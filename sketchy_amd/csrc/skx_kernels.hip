@@ -635,7 +635,8 @@ __device__ __forceinline__ MaskVec gather_vec(const u64* __restrict__ mq_g, u32 
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
-                                                      u32 nq_rows, u32* __restrict__ inc) {
+                                                      u32 nq_rows, u32* __restrict__ inc, u64* __restrict__ xt,
+                                                      u32 xt_slots) {
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + kRankWords - 1) / kRankWords;
     const u32 grp = wave % n_grp, seg = wave / n_grp;
@@ -646,13 +647,21 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     u32 acc[kRankWords];
 #pragma unroll
     for (int j = 0; j < kRankWords; ++j) acc[j] = 0;
+    // The transposed chunks are kept for rank_seg_top1_kernel (same chunks, same order): chunk c of this segment
+    // goes to slot pa/64 + seg + c (distinct for all chunks of the pass), 8 words x 64 lanes, coalesced.
+    u64* xt_out = xt ? xt + ((size_t)grp * xt_slots + (pa >> 6) + seg) * (kRankWords * 64u) + lane : nullptr;
     MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
         const MaskVec cur = nxt;
         const u32 pn = p0 + 64u + lane;
         nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
 #pragma unroll
-        for (int j = 0; j < kRankWords; ++j) acc[j] += __popcll(transpose64(cur.w[j], lane));
+        for (int j = 0; j < kRankWords; ++j) {
+            const u64 x = transpose64(cur.w[j], lane);
+            acc[j] += __popcll(x);
+            if (xt_out) xt_out[j * 64] = x;
+        }
+        if (xt_out) xt_out += kRankWords * 64u;
     }
 #pragma unroll
     for (int j = 0; j < kRankWords; ++j) {
@@ -819,7 +828,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                             u32 n_genomes, const u64* __restrict__ start,
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
-                                                            u32 nq_rows) {
+                                                            u32 nq_rows, const u64* __restrict__ xt, u32 xt_slots) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
@@ -865,18 +874,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         cur = r_stop;
     };
 
-    MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
-    u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
-    for (u32 p0 = pa; p0 < pz; p0 += 64u) {
-        const u32 n = min(64u, pz - p0);
-        const MaskVec cur_m = nxt;
-        const u32 rv = rnxt;
-        const u32 pn = p0 + 64u + lane;
-        nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
-        rnxt = pn < pz ? pair_r[pn] : 0u;
-        u64 x[NW];
-#pragma unroll
-        for (int j = 0; j < NW; ++j) x[j] = transpose64(cur_m.w[j], lane);
+    auto replay = [&](const u64 (&x)[NW], u32 rv, u32 n) {  // x: transposed chunk, rv: read index of pair `lane`
         for (u32 j = 0; j < n;) {
             const u32 rd = __builtin_amdgcn_readlane(rv, (int)j);
             emit_upto(rd);                                   // reads before rd see the state without rd's pairs
@@ -884,6 +882,44 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
 #pragma unroll
             for (int w = 0; w < NW; ++w) val[w] += __popcll(x[w] & m);
             j += __popcll(m);
+        }
+    };
+    if (xt) {
+        // transposed chunks left by seg_sum_kernel: plain coalesced loads, no gather, no butterfly
+        const u64* xin = xt + ((size_t)grp * xt_slots + (pa >> 6) + seg) * (NW * 64u) + lane;
+        u64 nx[NW];
+        u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) nx[j] = pa < pz ? xin[j * 64] : 0;
+        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+            const u32 n = min(64u, pz - p0);
+            u64 x[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) x[j] = nx[j];
+            const u32 rv = rnxt;
+            xin += NW * 64u;
+            const u32 pn = p0 + 64u + lane;
+            if (p0 + 64u < pz) {
+#pragma unroll
+                for (int j = 0; j < NW; ++j) nx[j] = xin[j * 64];
+            }
+            rnxt = pn < pz ? pair_r[pn] : 0u;
+            replay(x, rv, n);
+        }
+    } else {
+        MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
+        u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
+        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+            const u32 n = min(64u, pz - p0);
+            const MaskVec cur_m = nxt;
+            const u32 rv = rnxt;
+            const u32 pn = p0 + 64u + lane;
+            nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
+            rnxt = pn < pz ? pair_r[pn] : 0u;
+            u64 x[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) x[j] = transpose64(cur_m.w[j], lane);
+            replay(x, rv, n);
         }
     }
     emit_upto(rz);
@@ -1076,10 +1112,10 @@ void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u
                        m_bits, m_int, n_pad, n_words, mq, n_gw);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc) {
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, u64* xt, u32 xt_slots) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     hipLaunchKernelGGL(seg_sum_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, poff, p_base,
-                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
+                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, xt, xt_slots);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
                        u64* start, u64* csum /* [ceil(n_seg/16)][n_pad] scratch */) {
@@ -1097,10 +1133,10 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
-                          u64* best_sum, u32* best_idx) {
+                          u64* best_sum, u32* best_idx, const u64* xt, u32 xt_slots) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx, nq_rows);
+                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx, nq_rows, xt, xt_slots);
 }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0) {
