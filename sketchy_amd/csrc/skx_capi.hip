@@ -115,13 +115,17 @@ struct skx_ref {
     u32 n_exc = 0;         // hashes >= kEmpty lifted out of the matrix
     u32* d_exc_g = nullptr;
     u64* d_exc_h = nullptr;
+    // membership filter over the union of all reference hashes: bit (h >> filt_shift) of d_filt
+    u32* d_filt = nullptr;
+    u32 filt_shift = 0;
+    u64 filt_bits = 0;
 };
 
 static void ref_free(skx_ref* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     (void)hipFree(r->d_mat); (void)hipFree(r->d_lo); (void)hipFree(r->d_hi);
-    (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h);
+    (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h); (void)hipFree(r->d_filt);
     delete r;
 }
 
@@ -194,6 +198,20 @@ SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed,
         RCHK(hipMalloc(&r->d_exc_h, (size_t)r->n_exc * 8));
         RCHK(hipMemcpy(r->d_exc_g, exc_g.data(), (size_t)r->n_exc * 4, hipMemcpyHostToDevice));
         RCHK(hipMemcpy(r->d_exc_h, exc_h.data(), (size_t)r->n_exc * 8, hipMemcpyHostToDevice));
+    }
+    {
+        // bitmap size: 64 bits per reference hash, between 2^16 and 2^33 bits (1 GB); shift so that max_ref fits
+        const u64 want = 64ull * s * n_genomes;
+        u32 lg = 16;
+        while (lg < 33 && (1ull << lg) < want) ++lg;
+        const u32 max_bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
+        r->filt_shift = max_bits > lg ? max_bits - lg : 0u;
+        r->filt_bits = 1ull << lg;
+        RCHK(hipMalloc(&r->d_filt, r->filt_bits / 8));
+        RCHK(hipMemset(r->d_filt, 0, r->filt_bits / 8));
+        skx::launch_filter_build(nullptr, r->d_mat, mat_elems, r->filt_shift, r->d_filt, false);
+        skx::launch_filter_build(nullptr, r->d_exc_h, r->n_exc, r->filt_shift, r->d_filt, true);
+        RCHK(hipGetLastError());
     }
     RCHK(hipDeviceSynchronize());
 #undef RCHK
@@ -318,6 +336,12 @@ struct skx_stream {
     size_t tmp_bytes = 0;
     u32* h_poff = nullptr;   // pinned
     u64* h_offsets = nullptr;  // pinned
+    // |Q| / pairs of the most recent pass whose dictionary has finished: the host only knows the pair count of a
+    // pass when it picks the scan variant; reads of one sample share most of their matching hashes, so |Q| can be
+    // far below it.  A hint only -- every variant gives the same bits.
+    u32* h_nq = nullptr;     // pinned [2]
+    u32 hint_pairs[2] = {0, 0};
+    double nq_per_pair = 1.0;
     LongWork lw;
     // profiling
     bool profiling = false;
@@ -342,6 +366,7 @@ static void stream_free(skx_stream* st) {
     long_free(st->lw);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
+    if (st->h_nq) (void)hipHostFree(st->h_nq);
     for (auto& sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : st->ev_pool) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; ++i) {
@@ -442,6 +467,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_tmp, st->tmp_bytes));
     SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
+    SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocDefault));
+    st->h_nq[0] = st->h_nq[1] = 0;
 #undef SCHK
     *out = st;
     return SKX_OK;
@@ -521,6 +548,14 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     u32 *d_nq = st->d_nq[b], *d_win = st->d_win[b];
     u64 *d_mq = st->d_mq[b], *d_q = st->d_q[b];
 
+    // |Q| per pair from the latest pass whose dictionary is known to be complete
+    for (int i = 0; i < 2; ++i)
+        if (st->hint_pairs[i] && hipEventQuery(st->ev_dict[i]) == hipSuccess) {
+            st->nq_per_pair = std::min(1.0, (double)st->h_nq[i] / st->hint_pairs[i]);
+            st->hint_pairs[i] = 0;
+        }
+    const u64 nq_est = std::max<u64>(1, (u64)(P * st->nq_per_pair));
+
     // ---- dictionary (stream hs0): set b was last used two passes ago -- by that pass's scan (Q, windows) and
     // ranking (pair lists, offsets, Mq); wait for both before overwriting it
     if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs0, st->ev_front[b], 0)); st->front_pending[b] = false; }
@@ -533,6 +568,8 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         HIPCHK(skx::prim_unique_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_sorted, d_q, d_nq, P));
         skx::launch_pair_q(hs0, st->d_pair_h, P, d_q, d_nq, d_pair_q);
         skx::launch_window(hs0, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win);
+        HIPCHK(hipMemcpyAsync(&st->h_nq[b], d_nq, 4, hipMemcpyDeviceToHost, hs0));
+        st->hint_pairs[b] = P;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->ev_dict[b], hs0));
@@ -543,9 +580,9 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         const u32 n_words = (P + 63) / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
         static const int split_env = getenv("SKX_SCAN_SPLIT") ? atoi(getenv("SKX_SCAN_SPLIT")) : -1;
-        const bool split = split_env >= 0 ? split_env != 0 : ((u64)P * ref->rb / ref->s >= 192);
+        const bool split = split_env >= 0 ? split_env != 0 : (nq_est * ref->rb / ref->s >= 192);
         static const int big_env = getenv("SKX_SCAN_BIG") ? atoi(getenv("SKX_SCAN_BIG")) : -1;
-        const bool big = big_env >= 0 ? big_env != 0 : ((u64)P * ref->rb / ref->s >= 900);
+        const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
         {
             Span sp(st, 1, hs);
             // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
@@ -558,7 +595,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         }
         {
             Span sp(st, 3, hs);
-            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq);
+            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq);
         }
     }
     HIPCHK(hipGetLastError());
@@ -633,6 +670,17 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
                           ref->seed, ref->s, ref->any ? ref->max_ref : 0, /*inrange_only=*/!(h_sketches || h_sketch_len),
                           st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
         if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
+        // optional sketch outputs leave now: the filter below compacts the rows in place
+        if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
+        if (h_sketches) {
+            memset(h_sketches, 0, (size_t)n_reads * ref->s * 8);
+            HIPCHK(hipMemcpy2DAsync(h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
+                                    (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
+        }
+        // only hashes some genome holds become pairs (exact: the others share nothing with anyone)
+        static const bool no_filter = getenv("SKX_NO_FILTER") != nullptr;  // measurement aid
+        if (ref->any && !no_filter)
+            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, ref->d_filt, ref->filt_shift);
         // exclusive scan over n_reads+1 entries: poff[n_reads] = total pairs
         HIPCHK(hipMemsetAsync(st->d_cnt + n_reads, 0, 4, hs));
         HIPCHK(skx::prim_exclusive_scan_u32(hs, st->d_tmp, st->tmp_bytes, st->d_cnt, st->d_poff, n_reads + 1));
@@ -658,12 +706,6 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     });
     if (d_shared) (void)hipFree(d_shared);
     SKXCHK(pass_rc);
-    if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
-    if (h_sketches) {
-        memset(h_sketches, 0, (size_t)n_reads * ref->s * 8);
-        HIPCHK(hipMemcpy2DAsync(h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
-                                (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
-    }
     st->reads_total += n_reads;
     return SKX_OK;
 }

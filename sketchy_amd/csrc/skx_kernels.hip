@@ -16,6 +16,7 @@
 //                          running table and per-read (sum desc, index asc) top-k       (A1, A7)
 //
 // Integer work throughout (u64 hash compares, bit counts): no MFMA.
+#include <algorithm>
 #include <cstdlib>
 
 #include "skx_common.hpp"
@@ -346,6 +347,50 @@ __global__ __launch_bounds__(256) void long_read_finish_kernel(const u64* __rest
 }
 
 // =====================================================================================
+// membership filter: which read hashes occur in ANY reference genome
+// =====================================================================================
+// A read hash that no genome holds adds 0 to every shared-hash count, so dropping it before the dictionary changes
+// no result -- and for real reads (sequencing errors, novel k-mers) that is most of them: at C2 / B=49152 the
+// in-range read hashes number ~517 k per pass of which ~10 k exist in the collection; everything downstream (Q, the
+// bit matrices, the pair lists) shrinks by that factor.  The filter is a direct-mapped bitmap over hash >> shift
+// (hashes are uniform, so no second hash function is needed): no false negatives, and a false positive only costs
+// an all-zero row of M.  Built once per reference from the resident matrix.
+__global__ void filter_build_kernel(const u64* __restrict__ vals, u64 n, u32 shift, u32* __restrict__ bits,
+                                    bool markers_are_values) {
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 v = vals[i];
+        if (!markers_are_values && v >= kEmpty) continue;  // padding / empty cells of the tiled matrix
+        const u64 idx = v >> shift;
+        atomicOr(&bits[idx >> 5], 1u << (u32)(idx & 31u));
+    }
+}
+
+// One wave per read: keeps, in order, those of the first cnt[r] hashes of the read's sketch row that pass the
+// filter (in-place compaction: a hash only ever moves towards the front) and stores the new count.
+__global__ __launch_bounds__(256) void filter_apply_kernel(u64* __restrict__ sk, u32 sk_stride, u32* __restrict__ cnt,
+                                                           u32 n_reads, const u32* __restrict__ bits, u32 shift) {
+    const u32 r = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
+    if (r >= n_reads) return;
+    u64* row = sk + (size_t)r * sk_stride;
+    const u32 n = cnt[r];
+    u32 kept = 0;
+    for (u32 i0 = 0; i0 < n; i0 += 64u) {
+        const u32 i = i0 + lane;
+        u64 h = 0;
+        bool keep = false;
+        if (i < n) {
+            h = row[i];
+            const u64 idx = h >> shift;
+            keep = (bits[idx >> 5] >> (u32)(idx & 31u)) & 1u;
+        }
+        const u64 b = __ballot(keep);
+        if (keep) row[kept + (u32)__popcll(b & ((1ull << lane) - 1ull))] = h;
+        kept += (u32)__popcll(b);
+    }
+    if (lane == 0) cnt[r] = kept;
+}
+
+// =====================================================================================
 // dictionary of the batch's query hashes
 // =====================================================================================
 // pair_h[p], pair_r[p] for p in [poff[r]-p_base, ...): the first cnt_in[r] hashes of read r's sketch
@@ -572,9 +617,14 @@ constexpr u32 kWordsPerBlock = 4;
 // The kernel also restores the "all zero between passes" state of the word arrays (only words that were set are
 // written back): no memset of 2 x |M| bytes per pass.
 __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m_bits, u64* __restrict__ m_int,
-                                                             u32 n_pad, u32 n_words, u64* __restrict__ mq, u32 n_gw) {
+                                                             u32 n_pad, u32 n_words, u64* __restrict__ mq, u32 n_gw,
+                                                             const u32* __restrict__ n_q) {
     __shared__ u64 tile[2][64][kRankWords + 1];
-    const u32 grp = blockIdx.x, w0 = blockIdx.y * kWordsPerBlock, w1 = min(n_words, w0 + kWordsPerBlock);
+    // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
+    // index Q, so rows of Mq beyond nq are never read
+    const u32 live_words = min(n_words, (*n_q + 63u) >> 6);
+    const u32 grp = blockIdx.x, w0 = blockIdx.y * kWordsPerBlock, w1 = min(live_words, w0 + kWordsPerBlock);
+    if (w0 >= w1) return;
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     const u32 gw = grp * kRankWords + wv;
     const bool on = gw < n_gw;
@@ -1097,6 +1147,16 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
         hipLaunchKernelGGL((scan_kernel<4088, 0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
         return;
     }
+#define SKX_SCAN_BIG(A) \
+    hipLaunchKernelGGL((scan_kernel<4088, A, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
+    if (big_table && m_int) {
+        switch (ablate) {
+            case 1: SKX_SCAN_BIG(1); return;
+            case 2: SKX_SCAN_BIG(2); return;
+            default: SKX_SCAN_BIG(3); return;
+        }
+    }
+#undef SKX_SCAN_BIG
     switch (ablate) {
         case 1: SKX_SCAN(1, false); break;
         case 2: SKX_SCAN(2, false); break;
@@ -1105,11 +1165,20 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
     }
 #undef SKX_SCAN
 }
-void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq) {
+void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
-                       m_bits, m_int, n_pad, n_words, mq, n_gw);
+                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q);
+}
+void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values) {
+    if (n == 0) return;
+    const u32 blocks = (u32)std::min<u64>((n + 255) / 256, 1u << 16);
+    hipLaunchKernelGGL(filter_build_kernel, dim3(blocks), dim3(256), 0, st, vals, n, shift, bits, markers_are_values);
+}
+void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n_reads, const u32* bits, u32 shift) {
+    if (n_reads == 0) return;
+    hipLaunchKernelGGL(filter_apply_kernel, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, sk, sk_stride, cnt, n_reads, bits, shift);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, u64* xt, u32 xt_slots) {
