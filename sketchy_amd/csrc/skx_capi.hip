@@ -325,6 +325,7 @@ struct skx_stream {
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
     u32* d_inc = nullptr;
     u64* d_csum = nullptr;
+    u64* d_seg_lead = nullptr;  // [segments of a pass] largest segment start value (ranking prunes against it)
     u64* d_xt = nullptr;   // transposed pair chunks handed from seg_sum to rank_seg_top1 (top_k == 1 only)
     u32 xt_slots = 0;
     u64 *d_start = nullptr, *d_cand_sum = nullptr;
@@ -360,7 +361,7 @@ static void stream_free(skx_stream* st) {
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
-                    st->d_csum, st->d_xt, st->d_start, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_csum, st->d_seg_lead, st->d_xt, st->d_start, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
@@ -448,6 +449,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_start, (size_t)n_seg_max * n_pad * 8));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 8));
+    SCHK(hipMalloc(&st->d_seg_lead, (size_t)n_seg_max * 8));
     if (top_k == 1 && !getenv("SKX_NO_XT")) {
         st->xt_slots = st->pcap / 64 + n_seg_max + 2;
         SCHK(hipMalloc(&st->d_xt, (size_t)((n_gw + skx::kRankWords - 1) / skx::kRankWords) * st->xt_slots * skx::kRankWords * 64 * 8));
@@ -614,7 +616,8 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
-                                      ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx, xt, st->xt_slots);
+                                      ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx, xt, st->xt_slots,
+                                      st->d_inc, st->d_seg_lead);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,

@@ -751,6 +751,20 @@ __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__
     if (s1 == n_seg) cum_out[g] = run;
 }
 
+// lead[seg] = the largest segment start value over all genomes = a lower bound of the leading sum at every read of
+// the segment (sums never decrease).  One block per segment.
+__global__ __launch_bounds__(256) void seg_lead_kernel(const u64* __restrict__ start, u32 n_pad, u64* __restrict__ lead) {
+    __shared__ u64 part[4];
+    const u32 seg = blockIdx.x;
+    u64 m = 0;
+    for (u32 g = threadIdx.x; g < n_pad; g += 256u) m = max(m, start[(size_t)seg * n_pad + g]);  // padding columns hold 0
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, shfl_xor64(m, d));
+    if (lane_id() == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) lead[seg] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
 // (sum desc, index asc) ordering: a ranks before b
 __device__ __forceinline__ bool ranks_before(u64 sa, u32 ia, u64 sb, u32 ib) {
     return sa > sb || (sa == sb && ia < ib);
@@ -878,7 +892,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                             u32 n_genomes, const u64* __restrict__ start,
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
-                                                            u32 nq_rows, const u64* __restrict__ xt, u32 xt_slots) {
+                                                            u32 nq_rows, const u64* __restrict__ xt, u32 xt_slots,
+                                                            const u32* __restrict__ inc, const u64* __restrict__ seg_lead) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
@@ -889,26 +904,34 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
-    u64 st0[NW];
-    bool real[NW];
-    u64 bs = 0; u32 bi = 0xFFFFFFFFu;
+    // Pruning (exact): the leading sum at any read of the segment is at least lead = max over ALL genomes of the
+    // segment start values, and a genome ends the segment at start + inc, so only genomes with start + inc >= lead
+    // can lead at any read of it.  Once a sample has a clear best match that leaves a handful of genomes: a group
+    // without any reports "none" straight away, and inside a live group words without any are neither loaded nor
+    // counted.  The others (and padding) get value 0, strictly below every candidate's (>= 1).
+    const u64 lead = seg_lead[seg];
+    const u32 gain = pz - pa;
+    u32 val[NW];
+    u32 wmask = 0;  // wave-uniform: words holding at least one candidate
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const u32 g = g0 + (u32)j * 64u;
-        real[j] = g < n_genomes;  // also false for words past n_gw (n_genomes <= n_pad)
-        st0[j] = real[j] ? start[(size_t)seg * n_pad + g] : 0;
-        // group's best starting sum among real genomes (ties do not matter here: only the value is used)
-        if (real[j] && (bi == 0xFFFFFFFFu || st0[j] > bs)) { bs = st0[j]; bi = g; }
+        const bool real = g < n_genomes;  // also false for words past n_gw (n_genomes <= n_pad)
+        const u64 st0 = real ? start[(size_t)seg * n_pad + g] : 0;
+        const u32 ic = real ? inc[(size_t)seg * n_pad + g] : 0;
+        const bool cand = real && st0 + ic >= lead;          // (then lead - st0 <= inc <= gain)
+        val[j] = cand ? gain - (u32)(lead - st0) + 1u : 0u;
+        if (__ballot(cand)) wmask |= 1u << j;
     }
-    wave_best(bs, bi, bi != 0xFFFFFFFFu);
-    const bool any_real = bi != 0xFFFFFFFFu;
-    const u32 gain = pz - pa;
-    // Genomes further than G behind the group's best start can never lead within the segment; they (and padding)
-    // get base 0, so their value stays <= G, strictly below the leader's (>= G + 1): no masking needed at emit.
-    u32 val[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) val[j] = (real[j] && bs - st0[j] <= (u64)gain) ? gain - (u32)(bs - st0[j]) + 1u : 0u;
-    const u64 base = bs - gain - 1u;  // winner sum = base + (key >> SH)   (mod 2^64)
+    if (wmask == 0) {
+        if (lane < rz - ra) {
+            const size_t o = (size_t)grp * n_reads + ra + lane;
+            best_sum[o] = 0;
+            best_idx[o] = 0xFFFFFFFFu;
+        }
+        return;
+    }
+    const u64 base = lead - gain - 1u;  // winner sum = base + (key >> SH)   (mod 2^64)
     u32 tiec[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) tiec[j] = ((u32)(NW - 1 - j) << 6) | (63u - lane);
@@ -930,7 +953,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
             emit_upto(rd);                                   // reads before rd see the state without rd's pairs
             const u64 m = __ballot(lane < n && rv == rd);    // rd's pairs inside this chunk (contiguous from j)
 #pragma unroll
-            for (int w = 0; w < NW; ++w) val[w] += __popcll(x[w] & m);
+            for (int w = 0; w < NW; ++w)
+                if (wmask >> w & 1u) val[w] += __popcll(x[w] & m);  // (value 0 stays 0 only where nobody is a candidate)
             j += __popcll(m);
         }
     };
@@ -940,7 +964,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         u64 nx[NW];
         u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
 #pragma unroll
-        for (int j = 0; j < NW; ++j) nx[j] = pa < pz ? xin[j * 64] : 0;
+        for (int j = 0; j < NW; ++j) nx[j] = (pa < pz && (wmask >> j & 1u)) ? xin[j * 64] : 0;
         for (u32 p0 = pa; p0 < pz; p0 += 64u) {
             const u32 n = min(64u, pz - p0);
             u64 x[NW];
@@ -951,7 +975,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
             const u32 pn = p0 + 64u + lane;
             if (p0 + 64u < pz) {
 #pragma unroll
-                for (int j = 0; j < NW; ++j) nx[j] = xin[j * 64];
+                for (int j = 0; j < NW; ++j)
+                    if (wmask >> j & 1u) nx[j] = xin[j * 64];
             }
             rnxt = pn < pz ? pair_r[pn] : 0u;
             replay(x, rv, n);
@@ -975,10 +1000,12 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     emit_upto(rz);
     if (lane < rz - ra) {
         const size_t o = (size_t)grp * n_reads + ra + lane;
-        const bool none = !any_real;  // (a group with a real genome always has a leader with value >= 1)
+        // A non-candidate sitting in a live word counts up from 0 and can out-number this group's candidates; what
+        // is reported for it is below `lead` (value <= gain), hence below the true leader's entry (>= lead, from the
+        // leader's own group, where its value >= gain + 1 beats every non-candidate): the merge never picks it.
         const u32 wl = 63u - (res_key & 63u), wj = (u32)(NW - 1) - ((res_key >> 6) & (u32)(NW - 1));
-        best_sum[o] = none ? 0 : base + (u64)(res_key >> SH);
-        best_idx[o] = none ? 0xFFFFFFFFu : (grp * NW + wj) * 64u + wl;
+        best_sum[o] = base + (u64)(res_key >> SH);
+        best_idx[o] = (grp * NW + wj) * 64u + wl;
     }
 }
 
@@ -1202,10 +1229,12 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
-                          u64* best_sum, u32* best_idx, const u64* xt, u32 xt_slots) {
+                          u64* best_sum, u32* best_idx, const u64* xt, u32 xt_slots, const u32* inc, u64* seg_lead) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64);
+    hipLaunchKernelGGL(seg_lead_kernel, dim3(n_seg), dim3(256), 0, st, start, n_pad, seg_lead);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx, nq_rows, xt, xt_slots);
+                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx, nq_rows, xt, xt_slots,
+                       inc, seg_lead);
 }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0) {
