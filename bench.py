@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="default: ~100k reads / batch")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=49152, help="reads per step (one reference scan is amortised over this many reads)")
+    ap.add_argument("--batch", type=int, default=98304, help="reads per step (one reference scan is amortised over this many reads)")
     ap.add_argument("--top", type=int, default=1, help="rows ranked after every read (sketchy default 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")

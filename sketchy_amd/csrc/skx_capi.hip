@@ -324,11 +324,13 @@ struct skx_stream {
     u32 *d_pair_r[2] = {nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[2] = {nullptr, nullptr};
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
     u32* d_inc = nullptr;
-    u64* d_csum = nullptr;
-    u64* d_seg_lead = nullptr;  // [segments of a pass] largest segment start value (ranking prunes against it)
+    u32* d_csum = nullptr;
+    u32* d_leader = nullptr;      // device scalar: genome leading the table when the current pass began
+    u64* d_leader_sum = nullptr;
     u64* d_xt = nullptr;   // transposed pair chunks handed from seg_sum to rank_seg_top1 (top_k == 1 only)
     u32 xt_slots = 0;
-    u64 *d_start = nullptr, *d_cand_sum = nullptr;
+    u32* d_rel = nullptr;         // [segments of a pass][n_pad] segment start values relative to the pass-start table
+    u64* d_cand_sum = nullptr;
     u32* d_cand_idx = nullptr;
     u64 *d_cum = nullptr, *d_cum2 = nullptr;  // running table (current) and the buffer the next pass writes
     u32* d_topk_idx = nullptr;
@@ -361,7 +363,7 @@ static void stream_free(skx_stream* st) {
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
-                    st->d_csum, st->d_seg_lead, st->d_xt, st->d_start, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_csum, st->d_leader, st->d_leader_sum, st->d_xt, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
@@ -388,13 +390,20 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     st->ref = ref; st->device = ref->device; st->top_k = top_k; st->max_reads = max_reads; st->max_bases = max_bases;
     st->sk_stride = sk_stride;
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
-    // pass capacity: keep each of the three bit matrices within ~2 GB, and never below one read's worth of pairs
-    u64 pc = (2048ull << 20) * 8 / n_pad;
-    pc = std::min<u64>(pc, 1u << 20);
+    // pass capacity: bounded by the size of the bit matrices, and never below one read's worth of pairs
+    // (the host cannot know how many DISTINCT hashes a pass will have, so the matrices are sized by its pair count:
+    // 1/32 of the free device memory each, at most 8 GB -- env SKX_PASS_MB overrides)
+    size_t mem_free = 0, mem_total = 0;
+    (void)hipMemGetInfo(&mem_free, &mem_total);
+    static const u64 pass_mb_env = getenv("SKX_PASS_MB") ? (u64)atoll(getenv("SKX_PASS_MB")) : 0;
+    const u64 pass_mb = pass_mb_env ? pass_mb_env : std::min<u64>(8192, std::max<u64>(256, (u64)(mem_free >> 20) / 32));
+    u64 pc = (pass_mb << 20) * 8 / n_pad;
+    pc = std::min<u64>(pc, max_reads > 65536 ? (1u << 22) : (1u << 20));
     pc = std::max<u64>(pc, sk_stride);
     pc = (pc + 63) / 64 * 64;
     st->pcap = (u32)pc;
-    u64 rp = std::min<u64>(max_reads, 65536);
+    static const u64 pass_reads = getenv("SKX_PASS_READS") ? (u64)atoll(getenv("SKX_PASS_READS")) : 131072;
+    u64 rp = std::min<u64>(max_reads, pass_reads);
     if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (1ull << 30) / ((u64)n_gw * top_k * 12)));
     rp = std::max<u64>(rp, 1);
     st->rpass = (u32)rp;
@@ -447,9 +456,10 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     for (int i = 0; i < 2; ++i)
         SCHK(hipMalloc(&st->d_mq[i], (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
-    SCHK(hipMalloc(&st->d_start, (size_t)n_seg_max * n_pad * 8));
-    SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 8));
-    SCHK(hipMalloc(&st->d_seg_lead, (size_t)n_seg_max * 8));
+    SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
+    SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
+    SCHK(hipMalloc(&st->d_leader, 64));
+    SCHK(hipMalloc(&st->d_leader_sum, 64));
     if (top_k == 1 && !getenv("SKX_NO_XT")) {
         st->xt_slots = st->pcap / 64 + n_seg_max + 2;
         SCHK(hipMalloc(&st->d_xt, (size_t)((n_gw + skx::kRankWords - 1) / skx::kRankWords) * st->xt_slots * skx::kRankWords * 64 * 8));
@@ -471,6 +481,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocDefault));
     st->h_nq[0] = st->h_nq[1] = 0;
+    // the zero-fills above ran on the null stream, which the (non-blocking) pipeline streams do not wait for
+    SCHK(hipDeviceSynchronize());
 #undef SCHK
     *out = st;
     return SKX_OK;
@@ -612,16 +624,17 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         u64* xt = (st->top_k == 1 && d_topk_idx && d_topk_sum) ? st->d_xt : nullptr;
         skx::launch_seg_sum(hs2, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, st->d_inc, xt,
                             st->xt_slots);
-        skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, st->d_cum, st->d_cum2, st->d_start, st->d_csum);
+        skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, st->d_cum, st->d_cum2, st->d_rel, st->d_csum);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
+        const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
         if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
-                                      ref->n_genomes, st->d_start, st->d_cand_sum, st->d_cand_idx, xt, st->xt_slots,
-                                      st->d_inc, st->d_seg_lead);
+                                      ref->n_genomes, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, xt, st->xt_slots,
+                                      st->d_inc, st->d_leader, st->d_leader_sum);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
-                                 ref->n_genomes, st->d_start, st->top_k, st->d_cand_sum, st->d_cand_idx);
+                                 ref->n_genomes, cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx);
             skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw * st->top_k, st->top_k, d_topk_idx,
                                    d_topk_sum, ra);
         }

@@ -720,49 +720,47 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     }
 }
 
-// Segment start values, two-level so no thread walks a long serial chain:
-//   chunk_sum_kernel : csum[c][g] = sum of inc over the 16 segments of chunk c
-//   seg_prefix_kernel: start[seg][g] = cum_in[g] + sum_{seg' < seg} inc[seg'][g]  (base of the chunk from csum, then
-//                      its 16 segments);  the last chunk also writes cum_out[g] = cum_in[g] + sum of all.
-// One thread per (genome, chunk).  grid: (n_pad/256, n_chunks)
+// Segment start values, relative to the table at the start of the pass (32 bits: a pass gains at most its pair
+// count), in three levels so no thread walks a long chain and nothing is read twice:
+//   chunk_sum_kernel   : csum[c][g] = sum of inc over the 16 segments of chunk c
+//   chunk_prefix_kernel: csum[.][g] -> exclusive prefix over the chunks (in place);  cum_out[g] = cum_in[g] + total
+//   seg_prefix_kernel  : rel[seg][g] = csum[chunk of seg][g] + inc of the chunk's earlier segments
+// so that the running sum of genome g before the first read of segment seg is cum_in[g] + rel[seg][g].
+// grids: (n_pad/256, n_chunks), (n_pad/256), (n_pad/256, n_chunks)
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad,
-                                                        u64* __restrict__ csum) {
+                                                        u32* __restrict__ csum) {
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
     const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
-    u64 t = 0;
+    u32 t = 0;
 #pragma unroll 16
     for (u32 sgi = s0; sgi < s1; ++sgi) t += inc[(size_t)sgi * n_pad + g];
     csum[(size_t)c * n_pad + g] = t;
 }
-__global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, const u64* __restrict__ csum,
-                                                         u32 n_seg, u32 n_pad, const u64* __restrict__ cum_in,
-                                                         u64* __restrict__ cum_out, u64* __restrict__ start) {
+__global__ __launch_bounds__(256) void chunk_prefix_kernel(u32* __restrict__ csum, u32 n_chunks, u32 n_pad,
+                                                           const u64* __restrict__ cum_in, u64* __restrict__ cum_out) {
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_pad) return;
+    u32 run = 0;
+#pragma unroll 8
+    for (u32 c = 0; c < n_chunks; ++c) {
+        const u32 t = csum[(size_t)c * n_pad + g];
+        csum[(size_t)c * n_pad + g] = run;
+        run += t;
+    }
+    cum_out[g] = cum_in[g] + run;
+}
+__global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, const u32* __restrict__ csum,
+                                                         u32 n_seg, u32 n_pad, u32* __restrict__ rel) {
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
     const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
-    u64 run = cum_in[g];
-#pragma unroll 8
-    for (u32 cc = 0; cc < c; ++cc) run += csum[(size_t)cc * n_pad + g];
+    u32 run = csum[(size_t)c * n_pad + g];
+#pragma unroll 16
     for (u32 sgi = s0; sgi < s1; ++sgi) {
-        start[(size_t)sgi * n_pad + g] = run;
+        rel[(size_t)sgi * n_pad + g] = run;
         run += inc[(size_t)sgi * n_pad + g];
     }
-    if (s1 == n_seg) cum_out[g] = run;
-}
-
-// lead[seg] = the largest segment start value over all genomes = a lower bound of the leading sum at every read of
-// the segment (sums never decrease).  One block per segment.
-__global__ __launch_bounds__(256) void seg_lead_kernel(const u64* __restrict__ start, u32 n_pad, u64* __restrict__ lead) {
-    __shared__ u64 part[4];
-    const u32 seg = blockIdx.x;
-    u64 m = 0;
-    for (u32 g = threadIdx.x; g < n_pad; g += 256u) m = max(m, start[(size_t)seg * n_pad + g]);  // padding columns hold 0
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, shfl_xor64(m, d));
-    if (lane_id() == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) lead[seg] = max(max(part[0], part[1]), max(part[2], part[3]));
 }
 
 // (sum desc, index asc) ordering: a ranks before b
@@ -789,9 +787,9 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
                                                        const u32* __restrict__ poff, u32 p_base, u32 r_begin,
                                                        u32 n_reads, u32 seg_len, const u64* __restrict__ mq,
                                                        u32 n_gw, u32 n_pad, u32 n_genomes,
-                                                       const u64* __restrict__ start, u32 top_k,
-                                                       u64* __restrict__ cand_sum, u32* __restrict__ cand_idx,
-                                                       u32 nq_rows) {
+                                                       const u64* __restrict__ cum_in, const u32* __restrict__ rel,
+                                                       u32 top_k, u64* __restrict__ cand_sum,
+                                                       u32* __restrict__ cand_idx, u32 nq_rows) {
     const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len;
     const u32 gw = wave % n_gw, seg = wave / n_gw;
@@ -800,7 +798,7 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g = gw * 64u + lane;
     const bool real = g < n_genomes;
-    u64 state = start[(size_t)seg * n_pad + g];
+    u64 state = cum_in[g] + rel[(size_t)seg * n_pad + g];
     u32 cur = ra;  // next read to emit
 
     auto emit = [&](u32 r) {
@@ -890,10 +888,11 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             const u32* __restrict__ poff, u32 p_base, u32 r_begin,
                                                             u32 n_reads, u32 seg_len /* == 64 */,
                                                             const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
-                                                            u32 n_genomes, const u64* __restrict__ start,
+                                                            u32 n_genomes, const u64* __restrict__ cum_in,
+                                                            const u32* __restrict__ rel,
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
                                                             u32 nq_rows, const u64* __restrict__ xt, u32 xt_slots,
-                                                            const u32* __restrict__ inc, const u64* __restrict__ seg_lead) {
+                                                            const u32* __restrict__ inc, const u32* __restrict__ leader) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
@@ -904,23 +903,37 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
-    // Pruning (exact): the leading sum at any read of the segment is at least lead = max over ALL genomes of the
-    // segment start values, and a genome ends the segment at start + inc, so only genomes with start + inc >= lead
-    // can lead at any read of it.  Once a sample has a clear best match that leaves a handful of genomes: a group
-    // without any reports "none" straight away, and inside a live group words without any are neither loaded nor
-    // counted.  The others (and padding) get value 0, strictly below every candidate's (>= 1).
-    const u64 lead = seg_lead[seg];
+    // Pruning (exact).  Sums never decrease and a genome ends the segment at start + inc, so with ANY lower bound
+    // `lead` of the leading sum over the segment, only genomes with start + inc >= lead can lead at one of its
+    // reads.  The bound: the segment start value of the genome that led when the pass began (one scalar load; for a
+    // sample with a stable best match that IS the leading sum) or this group's own best start, whichever is larger
+    // (the latter also keeps every start of the group <= lead, which the 32-bit keys need).  Once a sample has a
+    // clear best match a handful of genomes are left: a group without any reports "none" straight away, and inside
+    // a live group words without any are neither loaded nor counted.  Non-candidates (and padding) get value 0.
+    const u32 gl = *leader;
+    u64 lead = cum_in[gl] + rel[(size_t)seg * n_pad + gl];
     const u32 gain = pz - pa;
+    u64 st0[NW];
+    u32 ic[NW];
+    bool real[NW];
+    u64 gmax = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u32 g = g0 + (u32)j * 64u;
+        real[j] = g < n_genomes;  // also false for words past n_gw (n_genomes <= n_pad)
+        st0[j] = real[j] ? cum_in[g] + rel[(size_t)seg * n_pad + g] : 0;
+        ic[j] = real[j] ? inc[(size_t)seg * n_pad + g] : 0;
+        gmax = max(gmax, st0[j]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) gmax = max(gmax, shfl_xor64(gmax, d));
+    lead = max(lead, gmax);
     u32 val[NW];
     u32 wmask = 0;  // wave-uniform: words holding at least one candidate
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-        const u32 g = g0 + (u32)j * 64u;
-        const bool real = g < n_genomes;  // also false for words past n_gw (n_genomes <= n_pad)
-        const u64 st0 = real ? start[(size_t)seg * n_pad + g] : 0;
-        const u32 ic = real ? inc[(size_t)seg * n_pad + g] : 0;
-        const bool cand = real && st0 + ic >= lead;          // (then lead - st0 <= inc <= gain)
-        val[j] = cand ? gain - (u32)(lead - st0) + 1u : 0u;
+        const bool cand = real[j] && st0[j] + ic[j] >= lead;   // (then lead - st0 <= inc <= gain)
+        val[j] = cand ? gain - (u32)(lead - st0[j]) + 1u : 0u;
         if (__ballot(cand)) wmask |= 1u << j;
     }
     if (wmask == 0) {
@@ -1214,27 +1227,31 @@ void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_ba
                        r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, xt, xt_slots);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
-                       u64* start, u64* csum /* [ceil(n_seg/16)][n_pad] scratch */) {
-    dim3 grid(cdiv(n_pad, 256), cdiv(n_seg, 16));
+                       u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */) {
+    const u32 n_chunks = cdiv(n_seg, 16);
+    dim3 grid(cdiv(n_pad, 256), n_chunks);
     hipLaunchKernelGGL(chunk_sum_kernel, grid, dim3(256), 0, st, inc, n_seg, n_pad, csum);
-    hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, cum_in, cum_out, start);
+    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, csum, n_chunks, n_pad, cum_in, cum_out);
+    hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
-                     u32 top_k, u64* cand_sum, u32* cand_idx) {
+                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                     const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     hipLaunchKernelGGL(rank_seg_kernel, dim3(cdiv((u64)n_seg * n_gw, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, seg_len, mq, n_gw, n_pad, n_genomes, start, top_k, cand_sum,
+                       p_base, r_begin, n_reads, seg_len, mq, n_gw, n_pad, n_genomes, cum_in, rel, top_k, cand_sum,
                        cand_idx, nq_rows);
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* start,
-                          u64* best_sum, u32* best_idx, const u64* xt, u32 xt_slots, const u32* inc, u64* seg_lead) {
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                          const u32* rel, u64* best_sum, u32* best_idx, const u64* xt, u32 xt_slots, const u32* inc,
+                          u32* leader, u64* leader_sum) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64);
-    hipLaunchKernelGGL(seg_lead_kernel, dim3(n_seg), dim3(256), 0, st, start, n_pad, seg_lead);
+    // the genome leading the table as the pass begins (ties: lowest index) -- its start values bound the pruning
+    hipLaunchKernelGGL(rank_table_kernel, dim3(1), dim3(1024), 0, st, cum_in, n_genomes, 1u, leader, leader_sum);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, start, best_sum, best_idx, nq_rows, xt, xt_slots,
-                       inc, seg_lead);
+                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, cum_in, rel, best_sum, best_idx, nq_rows, xt, xt_slots,
+                       inc, leader);
 }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0) {
