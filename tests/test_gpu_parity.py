@@ -302,3 +302,28 @@ def test_dense_reference_most_read_hashes_in_range(gpu):
     got, exp, _, _ = check(ref, bases, offsets, top=2, want_sketches=False, batches=2)
     assert exp["shared"].max() > 256
     check(ref, bases, offsets, top=1)
+
+
+def test_leader_changes_mid_pass_and_ties(gpu):
+    """The per-read top-1 replay prunes genomes that cannot lead within a 64-read segment, against a bound taken
+    from the genome that led when the pass began.  Here the leader moves from one clone family to another in the
+    middle of a single pass (and back in a second push), with duplicated genomes giving exact ties for the lead."""
+    refA, basesA, offsA = workload(300, 500, 1100, rng_seed=61)
+    refB, basesB, offsB = workload(300, 500, 1100, rng_seed=67)
+    hashes = np.concatenate([refA["ref"], refB["ref"]])
+    hashes[450] = hashes[310]          # ties inside family B (resolved by reference order)
+    hashes[7] = hashes[299]            # and inside family A, across rank groups of 512 genomes? (same group here)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(hashes))  # families interleaved over words and groups
+    hashes = np.ascontiguousarray(hashes[perm])
+    ra = [basesA[int(offsA[i]):int(offsA[i + 1])].tobytes() for i in range(1100)]
+    rb = [basesB[int(offsB[i]):int(offsB[i + 1])].tobytes() for i in range(1100)]
+    # A leads, B overtakes mid-pass, then they alternate read by read, then A catches up again
+    reads = ra[:150] + rb[:500] + [x for p in zip(ra[150:350], rb[500:700]) for x in p] + ra[350:1100]
+    bases, offsets = pack_reads(reads)
+    got, exp, _, _ = check(hashes, bases, offsets, top=1, want_shared=False, want_sketches=False)
+    lead = exp["topk_idx"][:, 0]
+    fam = (perm[lead] >= 300).astype(int)
+    assert fam[100] == 0 and fam[600] == 1 and fam[-1] == 0 and (np.diff(fam) != 0).sum() >= 2
+    check(hashes, bases, offsets, top=1, batches=3, want_shared=False, want_sketches=False)
+    check(hashes, bases, offsets, top=4, batches=2, want_shared=False, want_sketches=False)
