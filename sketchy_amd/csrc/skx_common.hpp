@@ -45,6 +45,16 @@ __host__ __device__ __forceinline__ u64 fmix64(u64 k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
     return k;
 }
+// x * 5 as one shift-add (v_lshl_add_u64 on gfx950) instead of two quarter-rate 32-bit multiplies
+__host__ __device__ __forceinline__ u64 mul5(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r;
+    asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x * 5;
+#endif
+}
 // w0..w3: the k key bytes as little-endian u64 words, zero beyond k (k <= 32)
 __host__ __device__ __forceinline__ u64 murmur3_h1_words(u64 w0, u64 w1, u64 w2, u64 w3, u32 k, u64 seed) {
     const u64 c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
@@ -53,9 +63,9 @@ __host__ __device__ __forceinline__ u64 murmur3_h1_words(u64 w0, u64 w1, u64 w2,
     {                                                                             \
         u64 k1 = (K1), k2 = (K2);                                                 \
         k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;                        \
-        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ull;               \
+        h1 = rotl64(h1, 27); h1 += h2; h1 = mul5(h1) + 0x52dce729ull;             \
         k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;                        \
-        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ull;               \
+        h2 = rotl64(h2, 31); h2 += h1; h2 = mul5(h2) + 0x38495ab5ull;             \
     }
     if (k >= 16) SKX_MM_BLOCK(w0, w1)
     if (k >= 32) SKX_MM_BLOCK(w2, w3)

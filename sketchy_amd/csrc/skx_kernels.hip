@@ -685,8 +685,7 @@ __device__ __forceinline__ MaskVec gather_vec(const u64* __restrict__ mq_g, u32 
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
-                                                      u32 nq_rows, u32* __restrict__ inc, u64* __restrict__ xt,
-                                                      u32 xt_slots) {
+                                                      u32 nq_rows, u32* __restrict__ inc) {
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + kRankWords - 1) / kRankWords;
     const u32 grp = wave % n_grp, seg = wave / n_grp;
@@ -697,21 +696,13 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     u32 acc[kRankWords];
 #pragma unroll
     for (int j = 0; j < kRankWords; ++j) acc[j] = 0;
-    // The transposed chunks are kept for rank_seg_top1_kernel (same chunks, same order): chunk c of this segment
-    // goes to slot pa/64 + seg + c (distinct for all chunks of the pass), 8 words x 64 lanes, coalesced.
-    u64* xt_out = xt ? xt + ((size_t)grp * xt_slots + (pa >> 6) + seg) * (kRankWords * 64u) + lane : nullptr;
     MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
         const MaskVec cur = nxt;
         const u32 pn = p0 + 64u + lane;
         nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
 #pragma unroll
-        for (int j = 0; j < kRankWords; ++j) {
-            const u64 x = transpose64(cur.w[j], lane);
-            acc[j] += __popcll(x);
-            if (xt_out) xt_out[j * 64] = x;
-        }
-        if (xt_out) xt_out += kRankWords * 64u;
+        for (int j = 0; j < kRankWords; ++j) acc[j] += __popcll(transpose64(cur.w[j], lane));
     }
 #pragma unroll
     for (int j = 0; j < kRankWords; ++j) {
@@ -891,8 +882,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u32 n_genomes, const u64* __restrict__ cum_in,
                                                             const u32* __restrict__ rel,
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
-                                                            u32 nq_rows, const u64* __restrict__ xt, u32 xt_slots,
-                                                            const u32* __restrict__ inc, const u32* __restrict__ leader) {
+                                                            u32 nq_rows, const u32* __restrict__ inc,
+                                                            const u32* __restrict__ leader) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
@@ -971,44 +962,19 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
             j += __popcll(m);
         }
     };
-    if (xt) {
-        // transposed chunks left by seg_sum_kernel: plain coalesced loads, no gather, no butterfly
-        const u64* xin = xt + ((size_t)grp * xt_slots + (pa >> 6) + seg) * (NW * 64u) + lane;
-        u64 nx[NW];
-        u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
+    MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
+    u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
+    for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+        const u32 n = min(64u, pz - p0);
+        const MaskVec cur_m = nxt;
+        const u32 rv = rnxt;
+        const u32 pn = p0 + 64u + lane;
+        nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
+        rnxt = pn < pz ? pair_r[pn] : 0u;
+        u64 x[NW];
 #pragma unroll
-        for (int j = 0; j < NW; ++j) nx[j] = (pa < pz && (wmask >> j & 1u)) ? xin[j * 64] : 0;
-        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
-            const u32 n = min(64u, pz - p0);
-            u64 x[NW];
-#pragma unroll
-            for (int j = 0; j < NW; ++j) x[j] = nx[j];
-            const u32 rv = rnxt;
-            xin += NW * 64u;
-            const u32 pn = p0 + 64u + lane;
-            if (p0 + 64u < pz) {
-#pragma unroll
-                for (int j = 0; j < NW; ++j)
-                    if (wmask >> j & 1u) nx[j] = xin[j * 64];
-            }
-            rnxt = pn < pz ? pair_r[pn] : 0u;
-            replay(x, rv, n);
-        }
-    } else {
-        MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
-        u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
-        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
-            const u32 n = min(64u, pz - p0);
-            const MaskVec cur_m = nxt;
-            const u32 rv = rnxt;
-            const u32 pn = p0 + 64u + lane;
-            nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
-            rnxt = pn < pz ? pair_r[pn] : 0u;
-            u64 x[NW];
-#pragma unroll
-            for (int j = 0; j < NW; ++j) x[j] = transpose64(cur_m.w[j], lane);
-            replay(x, rv, n);
-        }
+        for (int j = 0; j < NW; ++j) x[j] = (wmask >> j & 1u) ? transpose64(cur_m.w[j], lane) : 0;  // live words only
+        replay(x, rv, n);
     }
     emit_upto(rz);
     if (lane < rz - ra) {
@@ -1221,10 +1187,10 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
     hipLaunchKernelGGL(filter_apply_kernel, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, sk, sk_stride, cnt, n_reads, bits, shift);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, u64* xt, u32 xt_slots) {
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     hipLaunchKernelGGL(seg_sum_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, poff, p_base,
-                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, xt, xt_slots);
+                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */) {
@@ -1244,14 +1210,12 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
-                          const u32* rel, u64* best_sum, u32* best_idx, const u64* xt, u32 xt_slots, const u32* inc,
-                          u32* leader, u64* leader_sum) {
+                          const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, u32* leader, u64* leader_sum) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64);
     // the genome leading the table as the pass begins (ties: lowest index) -- its start values bound the pruning
     hipLaunchKernelGGL(rank_table_kernel, dim3(1), dim3(1024), 0, st, cum_in, n_genomes, 1u, leader, leader_sum);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, cum_in, rel, best_sum, best_idx, nq_rows, xt, xt_slots,
-                       inc, leader);
+                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader);
 }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0) {

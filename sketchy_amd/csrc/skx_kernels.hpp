@@ -50,7 +50,7 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, u64* xt, u32 xt_slots);
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc);
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
                        u32* rel /* [n_seg][n_pad]: segment start values minus cum_in */, u32* csum);
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
@@ -58,7 +58,7 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
                      const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx);
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
-                          const u32* rel, u64* best_sum, u32* best_idx, const u64* xt, u32 xt_slots, const u32* inc,
+                          const u32* rel, u64* best_sum, u32* best_idx, const u32* inc,
                           u32* leader, u64* leader_sum /* device scalars (scratch) */);
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0);
