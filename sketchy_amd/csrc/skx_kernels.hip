@@ -678,38 +678,127 @@ __device__ __forceinline__ MaskVec gather_vec(const u64* __restrict__ mq_g, u32 
 }
 
 // seg_sum: inc[seg][g] = sum over the segment's pairs of bit(Mq[q][g]).
-// One wave per (rank group of 512 genomes = 8 mask words, segment).  Pairs are taken 64 at a time: lane p gathers
-// pair p's 8 words (one 64-byte sector), 8 butterfly transposes give lane g, per word, a 64-bit value whose bit p
-// says "pair p hits my genome", and the chunk's contribution is a popcount.  The next chunk's gather is issued
-// before the current one is consumed.
+// One wave per (rank group of 512 genomes = 8 mask words, segment), counting with BIT-SLICED counters instead of
+// transposing the pair x genome bit matrix:
+//   * lane = (sub = lane / 8, word j = lane % 8): one load instruction fetches the 64-byte mask rows of 8 pairs
+//     (pair p0 + 8u + sub for row slot u), 8 lanes per row;
+//   * each lane adds its rows (about 37 for a 64-read segment at C2) into counter planes ones / twos / fours / ...
+//     with a Harley-Seal carry-save tree: 7 CSAs per 8 rows, bit g of plane b = bit b of the number of this lane's
+//     rows that hit genome g of word j;
+//   * the 8 sub-slots of a word are merged by a bit-sliced reduce-scatter -- lanes l and l^32 exchange the halves
+//     they do not keep (one v_permlane32_swap per plane), then l^16 (v_permlane16_swap), then l^8 (DPP row_ror:8),
+//     each followed by a ripple add of the two plane stacks -- after which lane (sub, j) holds 9 planes x 8 bits:
+//     the totals of genomes sub*8 .. sub*8+7 of word j;
+//   * those 8 counts are extracted once per block of <= 448 pairs and stored as 32 contiguous bytes per lane.
+#define SKX_CSA(H, L, A, B, C)                 \
+    {                                          \
+        const u64 u_ = (A) ^ (B);              \
+        const u64 h_ = ((A) & (B)) | (u_ & (C)); \
+        L = u_ ^ (C);                          \
+        H = h_;                                \
+    }
+// x (N planes) += y (N planes), both bit-sliced little-endian; the carry out becomes plane N of x
+template <int N>
+__device__ __forceinline__ void add_planes(u32 (&x)[10], const u32 (&y)[10]) {
+    u32 c = 0;
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+        const u32 u = x[b] ^ y[b];
+        const u32 cn = (x[b] & y[b]) | (u & c);
+        x[b] = u ^ c;
+        c = cn;
+    }
+    x[N] = c;
+}
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                       u32 nq_rows, u32* __restrict__ inc) {
-    const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
+    static_assert(kRankWords == 8, "lane = (sub, word) layout assumes 8 words per rank group");
+    const u32 lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + kRankWords - 1) / kRankWords;
-    const u32 grp = wave % n_grp, seg = wave / n_grp;
-    if (seg >= n_seg) return;
-    const u64* mq_g = mq + (size_t)grp * nq_rows * kRankWords;
+    // XCD-aware task order: workgroups go round-robin to the 8 XCDs, each with its own 4 MB L2.  XCD x takes the
+    // groups x, x+8, ... and walks them one after the other (all segments of a group before the next group), so the
+    // rows being gathered -- one group's slice of Mq, 64 B x |Q| -- stay in that XCD's L2.
+    const u32 xcd = blockIdx.x & 7u;
+    const u32 task = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6));
+    const u32 grp = (task / n_seg) * 8u + xcd, seg = task % n_seg;
+    if (grp >= n_grp) return;
+    const u32 sub = lane >> 3, j = lane & 7u;
+    const u64* mq_gj = mq + (size_t)grp * nq_rows * kRankWords + j;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
-    u32 acc[kRankWords];
+    u32 acc[8];
 #pragma unroll
-    for (int j = 0; j < kRankWords; ++j) acc[j] = 0;
-    MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
-    for (u32 p0 = pa; p0 < pz; p0 += 64u) {
-        const MaskVec cur = nxt;
-        const u32 pn = p0 + 64u + lane;
-        nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
+    for (int i = 0; i < 8; ++i) acc[i] = 0;
+    constexpr u32 kBlockPairs = 8u * 56u;  // <= 56 rows per lane and block: six planes hold the lane's counts
+    for (u32 b0 = pa; b0 < pz; b0 += kBlockPairs) {
+        const u32 bz = min(pz, b0 + kBlockPairs);
+        u64 ones = 0, twos = 0, fours = 0, eights = 0, sixteens = 0, thirtytwos = 0;
+        for (u32 p0 = b0; p0 < bz; p0 += 64u) {
+            u64 x[8];
 #pragma unroll
-        for (int j = 0; j < kRankWords; ++j) acc[j] += __popcll(transpose64(cur.w[j], lane));
+            for (u32 u = 0; u < 8u; ++u) {
+                const u32 p = p0 + 8u * u + sub;
+                x[u] = p < bz ? mq_gj[(size_t)pair_q[p] * kRankWords] : 0ull;
+            }
+            u64 twos_a, twos_b, fours_a, fours_b, eights_a;
+            SKX_CSA(twos_a, ones, ones, x[0], x[1])
+            SKX_CSA(twos_b, ones, ones, x[2], x[3])
+            SKX_CSA(fours_a, twos, twos, twos_a, twos_b)
+            SKX_CSA(twos_a, ones, ones, x[4], x[5])
+            SKX_CSA(twos_b, ones, ones, x[6], x[7])
+            SKX_CSA(fours_b, twos, twos, twos_a, twos_b)
+            SKX_CSA(eights_a, fours, fours, fours_a, fours_b)
+            const u64 c8 = eights & eights_a;
+            eights ^= eights_a;
+            const u64 c16 = sixteens & c8;
+            sixteens ^= c8;
+            thirtytwos ^= c16;  // (<= 56 rows: no carry out of the sixth plane)
+        }
+        // ---- merge the 8 sub-slots of every word (reduce-scatter over lane bits 5, 4, 3), planes get narrower
+        const u64 pl[6] = {ones, twos, fours, eights, sixteens, thirtytwos};
+        u32 x[10], y[10];
+        // lanes l / l^32: lower lanes keep genomes 0..31 of the word, upper lanes 32..63
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const u32x2_t r = __builtin_amdgcn_permlane32_swap((u32)pl[b], (u32)(pl[b] >> 32), false, false);
+            x[b] = r.x; y[b] = r.y;  // lower lanes: (own low half, partner's low half); upper: (partner's high, own high)
+        }
+        add_planes<6>(x, y);  // 7 planes x 32 bits
+        // lanes l / l^16: 16 genomes each
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const u32x2_t r = __builtin_amdgcn_permlane16_swap(x[b] & 0xFFFFu, x[b] >> 16, false, false);
+            x[b] = r.x; y[b] = r.y;
+        }
+        add_planes<7>(x, y);  // 8 planes x 16 bits
+        // lanes l / l^8: 8 genomes each
+        const bool up = (lane & 8u) != 0u;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const u32 lo = x[b] & 0xFFu, hi = x[b] >> 8;
+            const u32 send = up ? lo : hi;
+            x[b] = up ? hi : lo;
+            y[b] = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xF, 0xF, false);  // row_ror:8 = lane ^ 8
+        }
+        add_planes<8>(x, y);  // 9 planes x 8 bits: bit i of plane b = bit b of the count of genome sub*8 + i
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            u32 c = 0;
+#pragma unroll
+            for (int b = 0; b < 9; ++b) c |= ((x[b] >> i) & 1u) << b;
+            acc[i] += c;
+        }
     }
-#pragma unroll
-    for (int j = 0; j < kRankWords; ++j) {
-        const u32 gw = grp * kRankWords + j;
-        if (gw < n_gw) inc[(size_t)seg * n_pad + gw * 64u + lane] = acc[j];  // words past n_gw hold no genomes
+    const u32 gw = grp * kRankWords + j;
+    if (gw < n_gw) {  // words past n_gw hold no genomes
+        u32* out = inc + (size_t)seg * n_pad + gw * 64u + sub * 8u;
+        *reinterpret_cast<uint4*>(out) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<uint4*>(out + 4) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
     }
 }
+#undef SKX_CSA
 
 // Segment start values, relative to the table at the start of the pass (32 bits: a pass gains at most its pair
 // count), in three levels so no thread walks a long chain and nothing is read twice:
@@ -1189,7 +1278,9 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, poff, p_base,
+    const u32 n_grp = cdiv(n_gw, kRankWords);
+    // 8 XCDs x ceil(groups / 8) groups each x n_seg segments, 4 waves (segments) per workgroup
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv((u64)cdiv(n_grp, 8) * n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
                        r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
