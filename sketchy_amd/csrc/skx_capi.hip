@@ -325,8 +325,7 @@ struct skx_stream {
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
     u32* d_inc = nullptr;
     u32* d_csum = nullptr;
-    u32* d_leader = nullptr;      // device scalar: genome leading the table when the current pass began
-    u64* d_leader_sum = nullptr;
+    u32* d_leader = nullptr;      // [chunks of 16 segments] genome leading the table as the chunk begins
     u32* d_rel = nullptr;         // [segments of a pass][n_pad] segment start values relative to the pass-start table
     u64* d_cand_sum = nullptr;
     u32* d_cand_idx = nullptr;
@@ -361,7 +360,7 @@ static void stream_free(skx_stream* st) {
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
-                    st->d_csum, st->d_leader, st->d_leader_sum, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_csum, st->d_leader, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
@@ -456,8 +455,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
-    SCHK(hipMalloc(&st->d_leader, 64));
-    SCHK(hipMalloc(&st->d_leader_sum, 64));
+    SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * 4 + 64));
     if (top_k) {
         SCHK(hipMalloc(&st->d_cand_sum, (size_t)st->rpass * n_gw * top_k * 8));
         SCHK(hipMalloc(&st->d_cand_idx, (size_t)st->rpass * n_gw * top_k * 4));
@@ -622,7 +620,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
                                       ref->n_genomes, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_inc,
-                                      st->d_leader, st->d_leader_sum);
+                                      st->d_csum, st->d_leader);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,

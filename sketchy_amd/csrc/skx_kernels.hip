@@ -861,6 +861,28 @@ __device__ __forceinline__ void wave_best(u64& sum, u32& idx, bool ok) {
     }
 }
 
+// leader[c] = the genome leading (sum desc, index asc) as chunk c (16 segments = 1024 reads) begins, from the
+// pass-start table and the prefixed chunk sums.  One block per chunk.
+__global__ __launch_bounds__(1024) void chunk_leader_kernel(const u64* __restrict__ cum_in, const u32* __restrict__ csum,
+                                                            u32 n_pad, u32 n_genomes, u32* __restrict__ leader) {
+    __shared__ u64 ssum[16];
+    __shared__ u32 sidx[16];
+    const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    u64 bs = 0; u32 bi = 0xFFFFFFFFu;
+    for (u32 g = tid; g < n_genomes; g += 1024u) {
+        const u64 v = cum_in[g] + csum[(size_t)c * n_pad + g];
+        if (bi == 0xFFFFFFFFu || v > bs) { bs = v; bi = g; }  // ascending g: ties keep the lower index
+    }
+    wave_best(bs, bi, bi != 0xFFFFFFFFu);
+    if (lane == 0) { ssum[wv] = bs; sidx[wv] = bi; }
+    __syncthreads();
+    if (wv == 0) {
+        u64 s2 = lane < 16 ? ssum[lane] : 0; u32 i2 = lane < 16 ? sidx[lane] : 0xFFFFFFFFu;
+        wave_best(s2, i2, i2 != 0xFFFFFFFFu);
+        if (lane == 0) leader[c] = i2;
+    }
+}
+
 // rank_seg: walk a segment's reads in order from start[seg]; after every read emit this genome
 // group's top_k candidates cand_sum/cand_idx[(r * n_gw + gw) * top_k + j].  One wave per (gw, seg).
 __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ pair_r,
@@ -977,6 +999,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + NW - 1) / NW;
+    // (groups interleaved over the workgroups, NOT the XCD-aware order of seg_sum_kernel: after pruning the work sits
+    // in the few groups that hold candidates, and walking one group per XCD would leave 7 XCDs idle -- measured)
     const u32 grp = wave % n_grp, seg = wave / n_grp;
     if (seg >= n_seg) return;
     const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
@@ -985,12 +1009,13 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     const u32 g0 = grp * NW * 64u + lane;
     // Pruning (exact).  Sums never decrease and a genome ends the segment at start + inc, so with ANY lower bound
     // `lead` of the leading sum over the segment, only genomes with start + inc >= lead can lead at one of its
-    // reads.  The bound: the segment start value of the genome that led when the pass began (one scalar load; for a
-    // sample with a stable best match that IS the leading sum) or this group's own best start, whichever is larger
+    // reads.  The bound: the segment start value of the genome that led when the segment's chunk of 1024 reads began
+    // (one scalar load; for a sample with a stable best match that IS the leading sum) or this group's own best
+    // start, whichever is larger
     // (the latter also keeps every start of the group <= lead, which the 32-bit keys need).  Once a sample has a
     // clear best match a handful of genomes are left: a group without any reports "none" straight away, and inside
     // a live group words without any are neither loaded nor counted.  Non-candidates (and padding) get value 0.
-    const u32 gl = *leader;
+    const u32 gl = leader[seg >> 4];
     u64 lead = cum_in[gl] + rel[(size_t)seg * n_pad + gl];
     const u32 gain = pz - pa;
     u64 st0[NW];
@@ -1301,11 +1326,11 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
-                          const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, u32* leader, u64* leader_sum) {
-    const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64);
-    // the genome leading the table as the pass begins (ties: lowest index) -- its start values bound the pruning
-    hipLaunchKernelGGL(rank_table_kernel, dim3(1), dim3(1024), 0, st, cum_in, n_genomes, 1u, leader, leader_sum);
-    hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * cdiv(n_gw, kRankWords), 4)), dim3(256), 0, st, pair_q, pair_r, poff,
+                          const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* csum, u32* leader) {
+    const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
+    // the genome leading as each chunk of 16 segments begins -- its start values bound the pruning
+    hipLaunchKernelGGL(chunk_leader_kernel, dim3(cdiv(n_seg, 16)), dim3(1024), 0, st, cum_in, csum, n_pad, n_genomes, leader);
+    hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader);
 }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,

@@ -59,7 +59,8 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc,
-                          u32* leader, u64* leader_sum /* device scalars (scratch) */);
+                          const u32* csum /* prefixed chunk sums of launch_seg_prefix */,
+                          u32* leader /* [ceil(n_seg / 16)] scratch */);
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0);
 void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_cand, u32 top_k,
