@@ -262,13 +262,12 @@ static int long_ensure(LongWork& w, u64 bases, u32 reads) {
     return SKX_OK;
 }
 
-// Sketch every read of a device-resident batch (h_offsets = host copy of d_offsets).  Reads with at most
-// kSketchCap k-mers go through the one-wave-per-read kernel, longer ones through the block-per-read path.
-static int sketch_all(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
-                      const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
-                      bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
-    skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len, d_cnt);
-    HIPCHK(hipGetLastError());
+// Sketch the reads of a device-resident batch that have more than kSketchCap k-mers (h_offsets = host copy of
+// d_offsets): block-per-read hashing into global segments, segmented sort, distinct / truncate.  The one-wave-per-read
+// kernel (launch_sketch_wave) skips exactly these reads.
+static int sketch_long(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
+                       const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
+                       bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
     const u64 lim = (u64)skx::kSketchCap + k - 1;
     std::vector<u32> longs;
     for (u32 r = 0; r < n_reads; ++r)
@@ -287,6 +286,15 @@ static int sketch_all(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads
     skx::launch_long_read_finish(hs, lw.d_hsorted, lw.d_idx, nl, lw.d_sb, lw.d_se, s, max_ref, d_sk, sk_stride, d_len, d_cnt);
     HIPCHK(hipGetLastError());
     return SKX_OK;
+}
+// every read of the batch: short ones by the wave kernel, long ones as above
+static int sketch_all(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
+                      const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
+                      bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
+    skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len, d_cnt);
+    HIPCHK(hipGetLastError());
+    return sketch_long(hs, lw, cap_bases, cap_reads, d_bases, d_offsets, h_offsets, n_reads, k, seed, s, max_ref,
+                       inrange_only, d_sk, sk_stride, d_len, d_cnt);
 }
 
 // ------------------------------------------------------------------ stream
@@ -339,6 +347,8 @@ struct skx_stream {
     // |Q| / pairs of the most recent pass whose dictionary has finished: the host only knows the pair count of a
     // pass when it picks the scan variant; reads of one sample share most of their matching hashes, so |Q| can be
     // far below it.  A hint only -- every variant gives the same bits.
+    u32* d_chk = nullptr;    // [8] device-side look at a batch's offsets (batch_check_kernel)
+    u32* h_chk = nullptr;    // pinned [16]: d_chk, then [8] = total pairs of the batch
     u32* h_nq = nullptr;     // pinned [2]
     u32 hint_pairs[2] = {0, 0};
     double nq_per_pair = 1.0;
@@ -367,6 +377,8 @@ static void stream_free(skx_stream* st) {
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
+    if (st->h_chk) (void)hipHostFree(st->h_chk);
+    (void)hipFree(st->d_chk);
     for (auto& sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : st->ev_pool) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; ++i) {
@@ -471,6 +483,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_tmp, st->tmp_bytes));
     SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
+    SCHK(hipHostMalloc((void**)&st->h_chk, 16 * 4, hipHostMallocDefault));
+    SCHK(hipMalloc(&st->d_chk, 64));
     SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocDefault));
     st->h_nq[0] = st->h_nq[1] = 0;
     // the zero-fills above ran on the null stream, which the (non-blocking) pipeline streams do not wait for
@@ -654,50 +668,81 @@ static int for_each_pass(skx_stream* st, u32 n_reads, u32 max_pass_reads, F fn) 
 }
 
 // sketch + score + rank a batch already resident on the device.
+// h_off: host copy of the offsets when the caller has one (validated, st->h_offsets), else NULL -- then a small
+// kernel looks at them on the device and the host reads back 24 bytes instead of every offset.
 // h_shared / h_sketches / h_sketch_len: optional HOST outputs (parity/debug).
-static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u32* d_topk_idx,
-                         u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
+static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, const u64* h_off, u32 n_reads,
+                         u32* d_topk_idx, u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
     const skx_ref* ref = st->ref;
     hipStream_t hs = st->hs0;  // sketching and everything the host reads back run on the first pipeline stream
     if (n_reads == 0) return SKX_OK;
-    // the host needs the read lengths (long reads take a different kernel)
-    HIPCHK(hipMemcpyAsync(st->h_offsets, d_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, hs));
-    HIPCHK(hipStreamSynchronize(hs));
-    for (u32 r = 0; r < n_reads; ++r)
-        if (st->h_offsets[r + 1] < st->h_offsets[r]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", r);
-    if (st->h_offsets[n_reads] - st->h_offsets[0] > st->max_bases)
-        return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu",
-                    (unsigned long long)(st->h_offsets[n_reads] - st->h_offsets[0]), (unsigned long long)st->max_bases);
+    const bool inrange_only = !(h_sketches || h_sketch_len);  // production: only what can meet the reference is built
+    const u64 max_ref = ref->any ? ref->max_ref : 0;
+    static const bool no_filter = getenv("SKX_NO_FILTER") != nullptr;  // measurement aid
+    // counts -> (filter) -> pair offsets; poff[n_reads] = total pairs
+    auto finish_counts = [&]() -> int {
+        if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
+        // only hashes some genome holds become pairs (exact: the others share nothing with anyone)
+        if (ref->any && !no_filter)
+            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, ref->d_filt, ref->filt_shift);
+        HIPCHK(hipMemsetAsync(st->d_cnt + n_reads, 0, 4, hs));
+        HIPCHK(skx::prim_exclusive_scan_u32(hs, st->d_tmp, st->tmp_bytes, st->d_cnt, st->d_poff, n_reads + 1));
+        HIPCHK(hipMemcpyAsync(st->h_chk + 8, st->d_poff + n_reads, 4, hipMemcpyDeviceToHost, hs));
+        return SKX_OK;
+    };
+    bool have_long = false;
     {
         Span sp(st, 0);
+        if (!h_off) {
+            HIPCHK(hipMemsetAsync(st->d_chk, 0, 32, hs));
+            skx::launch_batch_check(hs, d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk);
+            HIPCHK(hipMemcpyAsync(st->h_chk, st->d_chk, 32, hipMemcpyDeviceToHost, hs));
+        }
         if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
-        // production path: only the part of each sketch that can meet the reference is built
-        SKXCHK(sketch_all(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, st->h_offsets, n_reads, ref->k,
-                          ref->seed, ref->s, ref->any ? ref->max_ref : 0, /*inrange_only=*/!(h_sketches || h_sketch_len),
-                          st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
-        if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
-        // optional sketch outputs leave now: the filter below compacts the rows in place
+        skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
+                                st->sk_stride, st->d_len, st->d_cnt);
+        HIPCHK(hipGetLastError());
+        if (h_off) {
+            SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, h_off, n_reads, ref->k,
+                               ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
+        } else if (h_sketches || h_sketch_len) {
+            return fail(SKX_ERR_INVALID, "sketch outputs need host offsets");  // (not reachable through the ABI)
+        }
+        // optional sketch outputs leave now: the filter compacts the rows in place
         if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
         if (h_sketches) {
             memset(h_sketches, 0, (size_t)n_reads * ref->s * 8);
             HIPCHK(hipMemcpy2DAsync(h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
                                     (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
         }
-        // only hashes some genome holds become pairs (exact: the others share nothing with anyone)
-        static const bool no_filter = getenv("SKX_NO_FILTER") != nullptr;  // measurement aid
-        if (ref->any && !no_filter)
-            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, ref->d_filt, ref->filt_shift);
-        // exclusive scan over n_reads+1 entries: poff[n_reads] = total pairs
-        HIPCHK(hipMemsetAsync(st->d_cnt + n_reads, 0, 4, hs));
-        HIPCHK(skx::prim_exclusive_scan_u32(hs, st->d_tmp, st->tmp_bytes, st->d_cnt, st->d_poff, n_reads + 1));
+        SKXCHK(finish_counts());
     }
-    HIPCHK(hipMemcpyAsync(st->h_poff, st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, hs));
-    HIPCHK(hipStreamSynchronize(hs));
+    HIPCHK(hipStreamSynchronize(hs));  // the one host synchronisation of a push without long reads
+    if (!h_off) {
+        const u32* c = st->h_chk;
+        if (c[0]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
+        const u64 o_first = ((u64)c[3] << 32) | c[2], o_last = ((u64)c[5] << 32) | c[4];
+        if (o_last - o_first > st->max_bases)
+            return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu", (unsigned long long)(o_last - o_first),
+                        (unsigned long long)st->max_bases);
+        have_long = c[1] != 0;
+        if (have_long) {
+            // rare for short-read streams: fetch the offsets after all, sketch the long reads, redo the counts
+            HIPCHK(hipMemcpyAsync(st->h_offsets, d_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, hs));
+            HIPCHK(hipStreamSynchronize(hs));
+            Span sp(st, 0);
+            SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, st->h_offsets, n_reads, ref->k,
+                               ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
+            SKXCHK(finish_counts());  // (the filter is idempotent on the rows it has already compacted)
+            HIPCHK(hipStreamSynchronize(hs));
+        }
+    }
+    const u32 total_pairs = st->h_chk[8];
 
     u32* d_shared = nullptr;
     // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
     const u32 dbg_cap = h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
-    const int pass_rc = for_each_pass(st, n_reads, dbg_cap, [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
+    auto one_pass = [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
         if (h_shared) {
             if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
@@ -709,7 +754,15 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             HIPCHK(hipStreamSynchronize(st->hs2));
         }
         return SKX_OK;
-    });
+    };
+    int pass_rc;
+    if (n_reads <= std::min(st->rpass, dbg_cap) && total_pairs <= st->pcap) {
+        pass_rc = one_pass(0, n_reads, 0, total_pairs);  // the whole batch is one pass: no per-read offsets needed
+    } else {
+        HIPCHK(hipMemcpyAsync(st->h_poff, st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, hs));
+        HIPCHK(hipStreamSynchronize(hs));
+        pass_rc = for_each_pass(st, n_reads, dbg_cap, one_pass);
+    }
     if (d_shared) (void)hipFree(d_shared);
     SKXCHK(pass_rc);
     st->reads_total += n_reads;
@@ -735,9 +788,8 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     for (u32 r = 0; r <= n_reads; ++r) st->h_offsets[r] = offsets[r] - base0;
     HIPCHK(hipMemcpyAsync(st->d_offsets, st->h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, hs));
     if (n_bases) HIPCHK(hipMemcpyAsync(st->d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, hs));
-    HIPCHK(hipStreamSynchronize(hs));  // h_offsets is reused by process_batch
-    SKXCHK(process_batch(st, st->d_bases, st->d_offsets, n_reads, st->d_topk_idx, st->d_topk_sum, per_read_shared,
-                         reinterpret_cast<u64*>(sketches), sketch_len));
+    SKXCHK(process_batch(st, st->d_bases, st->d_offsets, st->h_offsets, n_reads, st->d_topk_idx, st->d_topk_sum,
+                         per_read_shared, reinterpret_cast<u64*>(sketches), sketch_len));
     HIPCHK(hipStreamSynchronize(hs));  // sketch copies (first stream)
     if (topk_idx) HIPCHK(hipMemcpyAsync(topk_idx, st->d_topk_idx, (size_t)n_reads * st->top_k * 4, hipMemcpyDeviceToHost, st->hs2));
     if (topk_sum) HIPCHK(hipMemcpyAsync(topk_sum, st->d_topk_sum, (size_t)n_reads * st->top_k * 8, hipMemcpyDeviceToHost, st->hs2));
@@ -756,7 +808,7 @@ SKX_API int skx_stream_push_device(skx_stream* st, const uint8_t* d_bases, const
     SKXCHK(use_device(st->device));
     u32* ti = d_topk_idx ? d_topk_idx : st->d_topk_idx;
     u64* ts = d_topk_sum ? reinterpret_cast<u64*>(d_topk_sum) : st->d_topk_sum;
-    return process_batch(st, d_bases, reinterpret_cast<const u64*>(d_offsets), n_reads, ti, ts, nullptr, nullptr, nullptr);
+    return process_batch(st, d_bases, reinterpret_cast<const u64*>(d_offsets), nullptr, n_reads, ti, ts, nullptr, nullptr, nullptr);
 }
 
 SKX_API int skx_stream_sync(skx_stream* st) {

@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
     uint8_t* codes = smem + (size_t)wv * kPerWave + HCAP * 8;
     const u32 k = KT > 0 ? (u32)KT : k_rt;
     const u64 o0 = offsets[r], o1 = offsets[r + 1];
-    if (o1 - o0 > (u64)CAP + k - 1u) return;  // long read: sketched by the long_read_* kernels instead
+    if (o1 - o0 > (u64)CAP + k - 1u) {  // long read (or garbage offsets): sketched by the long_read_* kernels instead
+        if (!only_flagged && lane == 0) { out_len[r] = 0; out_cnt_in[r] = 0; }
+        return;
+    }
     const u32 lraw = (u32)(o1 - o0);
     const u64 lt = lanemask_lt();
 
@@ -344,6 +347,24 @@ __global__ __launch_bounds__(256) void long_read_finish_kernel(const u64* __rest
     }
     __syncthreads();
     if (tid == 0) { out_len[r] = min(s_out, s); out_cnt_in[r] = s_in; }
+}
+
+// =====================================================================================
+// device-side look at a batch's offsets, so the host reads back 24 bytes instead of every offset
+// =====================================================================================
+// chk[0] = 0xFFFFFFFF - (first r with offsets[r+1] < offsets[r])   (0: offsets are monotonic)
+// chk[1] = number of reads with more than `lim` bases (they need the long-read kernels)
+// chk[2..3] = offsets[0], chk[4..5] = offsets[n_reads]               (chk zeroed by the caller)
+__global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads, u64 lim, u32* __restrict__ chk) {
+    for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+        const u64 o0 = offsets[r], o1 = offsets[r + 1];
+        if (o1 < o0) atomicMax(&chk[0], 0xFFFFFFFFu - r);
+        else if (o1 - o0 > lim) atomicAdd(&chk[1], 1u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const u64 a = offsets[0], b = offsets[n_reads];
+        chk[2] = (u32)a; chk[3] = (u32)(a >> 32); chk[4] = (u32)b; chk[5] = (u32)(b >> 32);
+    }
 }
 
 // =====================================================================================
@@ -1290,6 +1311,9 @@ void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u
     const u32 n_gw = n_pad / 64;
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
                        m_bits, m_int, n_pad, n_words, mq, n_gw, n_q);
+}
+void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk) {
+    hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk);
 }
 void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values) {
     if (n == 0) return;

@@ -44,6 +44,8 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
                  u64* m_bits, u64* m_int, u32 n_pad, bool big_table);
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
                            const u32* n_q);  // also re-zeroes m_bits / m_int; words beyond *n_q are skipped
+// chk[0..5] (zeroed by the caller): non-monotonic marker, long-read count, offsets[0], offsets[n_reads]
+void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk);
 // membership filter over the union of the reference hashes (bitmap over hash >> shift)
 void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values);
 void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n_reads, const u32* bits, u32 shift);
