@@ -327,3 +327,65 @@ def test_leader_changes_mid_pass_and_ties(gpu):
     assert fam[100] == 0 and fam[600] == 1 and fam[-1] == 0 and (np.diff(fam) != 0).sum() >= 2
     check(hashes, bases, offsets, top=1, batches=3, want_shared=False, want_sketches=False)
     check(hashes, bases, offsets, top=4, batches=2, want_shared=False, want_sketches=False)
+
+
+def _push_device(S, bases, offsets, top):
+    """skx_stream_push_device with everything resident on the device; returns rows like push()."""
+    from sketchy_amd import api
+    n = len(offsets) - 1
+    d_b = api.DeviceBuffer.from_numpy(bases if len(bases) else np.zeros(1, np.uint8))
+    d_o = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets, np.uint64))
+    d_i = api.DeviceBuffer(max(1, n * top) * 4)
+    d_s = api.DeviceBuffer(max(1, n * top) * 8)
+    try:
+        S.push_device(d_b.ptr, d_o.ptr, n, int(offsets[-1] - offsets[0]), d_i.ptr, d_s.ptr)
+        S.sync()
+        return dict(topk_idx=d_i.to_numpy(np.uint32, (n, top)), topk_sum=d_s.to_numpy(np.uint64, (n, top)))
+    finally:
+        for d in (d_b, d_o, d_i, d_s):
+            d.free()
+
+
+def test_push_device_matches_oracle_short_and_long_reads(gpu):
+    """The device-resident entry point looks at the offsets on the device (no host copy): short reads take the
+    one-synchronisation fast path, a batch with long reads the fallback that fetches the offsets after all."""
+    from sketchy_amd import api, synth
+    ref, bases, offsets = workload(200, 400, 300, rng_seed=71)
+    exp = orc.stream(16, 0, 400, ref["ref"], np.full(200, 400, np.uint32), bases, offsets, top_k=2)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=2, max_batch_reads=300, max_batch_bases=len(bases))
+    got = _push_device(S, bases, offsets[:181], 2)
+    got2 = _push_device(S, bases, offsets[180:], 2)  # offsets need not start at 0
+    np.testing.assert_array_equal(np.concatenate([got["topk_idx"], got2["topk_idx"]]), exp["topk_idx"])
+    np.testing.assert_array_equal(np.concatenate([got["topk_sum"], got2["topk_sum"]]), exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    # mixed lengths
+    ref = synth.make_reference(60, 300, genome_len=120000, rng_seed=72, device="numpy")
+    bases, offsets = synth.make_reads(ref["genome"], 50, 3000, err=0.03, rng_seed=73, lognormal_sigma=1.0, min_len=200, max_len=40000)
+    assert np.diff(offsets.astype(np.int64)).max() > 2063
+    exp = orc.stream(16, 0, 300, ref["ref"], np.full(60, 300, np.uint32), bases, offsets, top_k=1)
+    R2 = api.ReferenceSketch(ref["ref"])
+    S2 = api.SumOfSharedHashes(R2, top=1, max_batch_reads=50, max_batch_bases=len(bases))
+    got = _push_device(S2, bases, offsets, 1)
+    np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"])
+    np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"])
+    np.testing.assert_array_equal(S2.table(), exp["cum"])
+
+
+def test_push_device_errors_leave_the_table_alone(gpu):
+    from sketchy_amd import api, _lib
+    ref, bases, offsets = workload(40, 200, 20, rng_seed=75)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=20, max_batch_bases=len(bases))
+    bad = offsets.copy()
+    bad[7], bad[8] = bad[8], bad[7]  # not monotonic
+    with pytest.raises(_lib.SketchyHipError) as e:
+        _push_device(S, bases, bad, 1)
+    assert e.value.code == _lib.ERR_INVALID
+    S_small = api.SumOfSharedHashes(R, top=1, max_batch_reads=20, max_batch_bases=1000)
+    with pytest.raises(_lib.SketchyHipError) as e:
+        _push_device(S_small, bases, offsets, 1)
+    assert e.value.code == _lib.ERR_CAPACITY
+    assert S.reads == 0 and not S.table().any()
+    _push_device(S, bases, offsets, 1)  # the stream is still usable
+    assert S.reads == 20
