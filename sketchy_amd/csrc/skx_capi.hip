@@ -267,11 +267,12 @@ static int long_ensure(LongWork& w, u64 bases, u32 reads) {
 // kernel (launch_sketch_wave) skips exactly these reads.
 static int sketch_long(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
                        const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
-                       bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
+                       bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt, bool* any_long = nullptr) {
     const u64 lim = (u64)skx::kSketchCap + k - 1;
     std::vector<u32> longs;
     for (u32 r = 0; r < n_reads; ++r)
         if (h_offsets[r + 1] - h_offsets[r] > lim) longs.push_back(r);
+    if (any_long) *any_long = !longs.empty();
     if (longs.empty()) return SKX_OK;
     const u64 n_bases = h_offsets[n_reads] - h_offsets[0];
     SKXCHK(long_ensure(lw, std::max<u64>(cap_bases, n_bases), std::max<u32>(cap_reads, n_reads)));
@@ -291,7 +292,8 @@ static int sketch_long(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_read
 static int sketch_all(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
                       const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
                       bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
-    skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len, d_cnt);
+    skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len, d_cnt,
+                            nullptr, 0);
     HIPCHK(hipGetLastError());
     return sketch_long(hs, lw, cap_bases, cap_reads, d_bases, d_offsets, h_offsets, n_reads, k, seed, s, max_ref,
                        inrange_only, d_sk, sk_stride, d_len, d_cnt);
@@ -680,11 +682,14 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     const u64 max_ref = ref->any ? ref->max_ref : 0;
     static const bool no_filter = getenv("SKX_NO_FILTER") != nullptr;  // measurement aid
     // counts -> (filter) -> pair offsets; poff[n_reads] = total pairs
-    auto finish_counts = [&]() -> int {
+    const u32* filt = (ref->any && !no_filter) ? ref->d_filt : nullptr;
+    // Only hashes some genome holds become pairs (exact: the others share nothing with anyone).  The wave kernel
+    // applies the filter itself in production mode; rows it did not filter (long reads, full sketches for the
+    // debug outputs) get the separate pass.
+    auto finish_counts = [&](bool filter_pass) -> int {
         if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
-        // only hashes some genome holds become pairs (exact: the others share nothing with anyone)
-        if (ref->any && !no_filter)
-            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, ref->d_filt, ref->filt_shift);
+        if (filt && filter_pass)
+            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
         HIPCHK(hipMemsetAsync(st->d_cnt + n_reads, 0, 4, hs));
         HIPCHK(skx::prim_exclusive_scan_u32(hs, st->d_tmp, st->tmp_bytes, st->d_cnt, st->d_poff, n_reads + 1));
         HIPCHK(hipMemcpyAsync(st->h_chk + 8, st->d_poff + n_reads, 4, hipMemcpyDeviceToHost, hs));
@@ -700,11 +705,12 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         }
         if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
         skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
-                                st->sk_stride, st->d_len, st->d_cnt);
+                                st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift);
         HIPCHK(hipGetLastError());
         if (h_off) {
             SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, h_off, n_reads, ref->k,
-                               ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
+                               ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt,
+                               &have_long));
         } else if (h_sketches || h_sketch_len) {
             return fail(SKX_ERR_INVALID, "sketch outputs need host offsets");  // (not reachable through the ABI)
         }
@@ -715,7 +721,7 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             HIPCHK(hipMemcpy2DAsync(h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
                                     (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
         }
-        SKXCHK(finish_counts());
+        SKXCHK(finish_counts(have_long || !inrange_only));
     }
     HIPCHK(hipStreamSynchronize(hs));  // the one host synchronisation of a push without long reads
     if (!h_off) {
@@ -733,7 +739,7 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             Span sp(st, 0);
             SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, st->h_offsets, n_reads, ref->k,
                                ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
-            SKXCHK(finish_counts());  // (the filter is idempotent on the rows it has already compacted)
+            SKXCHK(finish_counts(true));  // (the filter is idempotent on the rows that are already compacted)
             HIPCHK(hipStreamSynchronize(hs));
         }
     }

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
                                                           const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
                                                           u64 seed, u32 s, u64 max_ref, u64* __restrict__ out_sk,
                                                           u32 sk_stride, u32* __restrict__ out_len,
-                                                          u32* __restrict__ out_cnt_in, u32 only_flagged) {
+                                                          u32* __restrict__ out_cnt_in, u32 only_flagged,
+                                                          const u32* __restrict__ filt, u32 filt_shift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr u32 kPerWave = HCAP * 8 + CAP + 64;
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
@@ -201,6 +202,26 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
             const u64 h = hash_canonical_packed<KT>(fwd < rc ? fwd : rc, k, seed);
             if (!append(valid, h)) return;
         }
+    }
+    // INRANGE: of the candidates only those some genome holds can score (membership bitmap of the reference, see
+    // "membership filter" below): drop the others here, in LDS, before they are sorted and written out
+    if (INRANGE && filt != nullptr) {
+        wave_sync();
+        u32 kept = 0;
+        for (u32 base = 0; base < m; base += 64u) {
+            const u32 i = base + lane;
+            u64 h = 0;
+            bool keep = false;
+            if (i < m) {
+                h = hashes[i];
+                const u64 idx = h >> filt_shift;
+                keep = (filt[idx >> 5] >> (u32)(idx & 31u)) & 1u;
+            }
+            const u64 b = __ballot(keep);
+            if (keep) hashes[kept + __popcll(b & lt)] = h;  // (a hash only moves towards the front)
+            kept += __popcll(b);
+        }
+        m = kept;
     }
     // pad to a power of two (>= 64) for the bitonic network
     u32 p2 = 64;
@@ -1210,7 +1231,8 @@ size_t sketch_wave_lds_bytes() { return 4 * (size_t)(kSketchCap * 8 + kSketchCap
 constexpr int kSketchSmallHashes = 256;  // hash slots per read of the in-range fast variant
 
 void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
-                        u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in) {
+                        u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
+                        const u32* filt, u32 filt_shift) {
     if (n_reads == 0) return;
     const size_t lds = sketch_wave_lds_bytes();
     const size_t lds_small = 4 * (size_t)(kSketchSmallHashes * 8 + kSketchCap + 64);
@@ -1226,7 +1248,7 @@ void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets
     }
 #define SKX_SK_LAUNCH(KERNEL, LDS, FLAGGED)                                                                      \
     hipLaunchKernelGGL((KERNEL), grid, dim3(256), LDS, st, bases, offsets, n_reads, k, seed, s, max_ref, out_sk, \
-                       sk_stride, out_len, out_cnt_in, FLAGGED)
+                       sk_stride, out_len, out_cnt_in, FLAGGED, filt, filt_shift)
     if (inrange_only) {
         // fast variant first (full occupancy); reads it flags are redone with the full-size hash buffer
         if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); }
