@@ -151,6 +151,11 @@ int skx_dev_free(int device, void *d_ptr);
 int skx_dev_upload(int device, void *d_dst, const void *h_src, size_t bytes);
 int skx_dev_download(int device, void *h_dst, const void *d_src, size_t bytes);
 int skx_dev_synchronize(int device);
+/* page-locked host memory for batch buffers handed to skx_stream_push / skx_sketch_reads: the H2D copy then runs at
+ * full PCIe rate and asynchronously (what a double-buffered FASTX front-end wants; needletail's reader in
+ * src/sketchy.rs:89-92 has no counterpart, the reference never leaves the host) */
+int skx_host_alloc(int device, void **h_ptr, size_t bytes);
+int skx_host_free(int device, void *h_ptr);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,8 @@ SYMBOLS = [
     ("skx_dev_upload", _i, [_i, _vp, _vp, _sz]),
     ("skx_dev_download", _i, [_i, _vp, _vp, _sz]),
     ("skx_dev_synchronize", _i, [_i]),
+    ("skx_host_alloc", _i, [_i, _pp, _sz]),
+    ("skx_host_free", _i, [_i, _vp]),
 ]
 
 _LIB = None

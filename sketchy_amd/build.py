@@ -62,7 +62,7 @@ def build_host(force=False, verbose=False):
     srcs = [os.path.join(hdir, "sketchy_host.cpp")]
     deps = srcs + [os.path.join(hdir, "formats.hpp"), os.path.join(ROOT, "include", "sketchy_hip.h"), LIB]
     if force or _stale(HOST_BIN, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", hdir, *srcs, "-o", HOST_BIN,
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", hdir, *srcs, "-o", HOST_BIN,
                "-L", HERE, "-lsketchy_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

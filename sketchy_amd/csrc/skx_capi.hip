@@ -97,6 +97,17 @@ SKX_API int skx_dev_download(int device, void* h_dst, const void* d_src, size_t 
     HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
     return SKX_OK;
 }
+SKX_API int skx_host_alloc(int device, void** h_ptr, size_t bytes) {
+    if (!h_ptr) return fail(SKX_ERR_INVALID, "h_ptr is NULL");
+    SKXCHK(use_device(device));
+    HIPCHK(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return SKX_OK;
+}
+SKX_API int skx_host_free(int device, void* h_ptr) {
+    SKXCHK(use_device(device));
+    HIPCHK(hipHostFree(h_ptr));
+    return SKX_OK;
+}
 SKX_API int skx_dev_synchronize(int device) {
     SKXCHK(use_device(device));
     HIPCHK(hipDeviceSynchronize());

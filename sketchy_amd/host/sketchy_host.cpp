@@ -8,13 +8,23 @@
 //   Sketchy::_print_results           src/sketchy.rs:358-402  (rows / consensus)
 //   Sketchy::shared                   src/sketchy.rs:238-279                                       -> skx_common_hashes
 //   Sketchy::info (names only)        src/sketchy.rs:172-208
-// Command line: the reference's flag names and defaults (src/cli.rs:51-132).
+//   Sketchy::sketch + _sketch_files   src/sketchy.rs:128-167, :465-494  (genome files -> Mash .msh)      -> skx_sketch_reads
+// Command line: the reference's flag names and defaults (src/cli.rs:25-132).
+//
+// Streaming runs as a three-stage pipeline (the reference reads, scores and prints one record at a time on one
+// thread): a reader thread parses FASTX into page-locked batch buffers, this thread pushes batches through the C ABI,
+// a writer thread formats the rows -- so parsing, the H2D copy + device work, and printing overlap.
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
+#include <exception>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <optional>
+#include <thread>
 
 #include "formats.hpp"
 #include "sketchy_hip.h"
@@ -31,7 +41,7 @@ static void hip_check(int rc, const char* what) {
 
 class Sketchy {
   public:
-    explicit Sketchy(int device = 0, size_t batch_reads = 4096) : device_(device), batch_(batch_reads) {}
+    explicit Sketchy(int device = 0, size_t batch_reads = 16384) : device_(device), batch_(batch_reads) {}
 
     void predict(const std::optional<std::string>& fastx, const std::string& reference, const std::string& genotypes,
                  const PredictConfig& config, std::ostream& out) {
@@ -80,6 +90,63 @@ class Sketchy {
         for (const auto& s : sk) out << s.name << " " << s.seq_length << " " << s.hashes.size() << "\n";
     }
 
+    // `sketchy sketch` (src/sketchy.rs:128-167; _sketch_files :465-494): one Mash sketch per input FILE over all of its
+    // records (k-mers never span records), name = file name (:484).  Every record is sketched on the device
+    // (skx_sketch_reads: genomes take the block-per-read + segmented-sort path); the bottom-s of a file is the
+    // bottom-s of the union of its records' bottom-s sketches, merged here.
+    void sketch(const std::vector<std::string>& files, const std::string& output, size_t sketch_size, uint32_t kmer, uint64_t seed) {
+        const auto dot = output.rfind('.');
+        const std::string ext = dot == std::string::npos ? "" : output.substr(dot + 1);
+        if (ext == "fsh") throw SketchyError("Finch scaled sketches (.fsh) are outside the accelerated path");
+        if (ext != "msh") throw SketchyError("output sketch file must have Mash (.msh) or Finch (.fsh) extension");  // :573-600
+        if (sketch_size < 1) throw SketchyError("sketch size must be at least 1");
+        if (kmer < 1 || kmer > SKX_MAX_K) throw SketchyError("k-mer size must be between 1 and " + std::to_string(SKX_MAX_K));
+        if (seed > 0xFFFFFFFFull) throw SketchyError("the Mash format stores a 32-bit hash seed");
+        std::vector<Sketch> out;
+        for (const auto& file : files) {
+            FastxReader reader(file);
+            Sketch sk;
+            const auto slash = file.find_last_of('/');
+            sk.name = slash == std::string::npos ? file : file.substr(slash + 1);
+            sk.kmer_length = kmer; sk.hash_seed = seed;
+            Batch b; std::string seq;
+            std::vector<uint64_t> rows, merged; std::vector<uint32_t> len;
+            auto flush = [&]() {
+                if (b.n() == 0) return;
+                rows.assign(b.n() * sketch_size, 0); len.assign(b.n(), 0);
+                hip_check(skx_sketch_reads(device_, kmer, seed, (uint32_t)sketch_size, b.bases.data(), b.offsets.data(), (uint32_t)b.n(), rows.data(), len.data()), "sketch");
+                for (size_t r = 0; r < b.n(); ++r) {
+                    merged.clear();
+                    std::set_union(sk.hashes.begin(), sk.hashes.end(), rows.begin() + r * sketch_size, rows.begin() + r * sketch_size + len[r], std::back_inserter(merged));
+                    if (merged.size() > sketch_size) merged.resize(sketch_size);
+                    sk.hashes.swap(merged);
+                }
+                b.clear();
+            };
+            while (reader.next(seq)) {
+                sk.seq_length += seq.size();                       // [UPSTREAM-RECALL] finch: total bases of the records
+                sk.num_valid_kmers += count_valid_kmers(seq, kmer);  // [UPSTREAM-RECALL] finch: k-mers pushed to the sketcher
+                if (b.n() && (b.bases.size() + seq.size() > (1ull << 30) || b.n() * sketch_size > (1ull << 24))) flush();
+                if (seq.size() >= (1ull << 32)) throw SketchyError("a record of " + file + " exceeds 4 Gbases");
+                b.add(seq);
+            }
+            flush();
+            out.push_back(std::move(sk));
+        }
+        write_mash_file(output, out, kmer, (uint32_t)seed);
+    }
+    // windows of k bases that are all A/C/G/T/U (any case), as needletail's normalize + canonical_kmers see them
+    static uint64_t count_valid_kmers(const std::string& seq, uint32_t k) {
+        uint64_t n = 0; uint32_t run = 0;
+        for (unsigned char c : seq) {
+            if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
+            const unsigned char u = c & 0xDF;
+            run = (u == 'A' || u == 'C' || u == 'G' || u == 'T' || u == 'U') ? run + 1 : 0;
+            if (run >= k) ++n;
+        }
+        return n;
+    }
+
     static std::vector<Sketch> read_sketch(const std::string& path) {  // src/sketchy.rs:497-536
         const auto dot = path.rfind('.');
         const std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
@@ -115,31 +182,118 @@ class Sketchy {
                    void add(const std::string& seq) { bases.insert(bases.end(), seq.begin(), seq.end()); offsets.push_back(bases.size()); }
                    void clear() { bases.clear(); offsets.assign(1, 0); } };
 
+    // ---- streaming pipeline plumbing
+    template <class T>
+    class Channel {  // unbounded FIFO between two threads; close() wakes the consumer for good
+      public:
+        void put(T v) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(v)); } cv.notify_one(); }
+        bool get(T& v) {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return !q.empty() || closed; });
+            if (q.empty()) return false;
+            v = std::move(q.front()); q.pop_front();
+            return true;
+        }
+        void close() { { std::lock_guard<std::mutex> l(m); closed = true; } cv.notify_all(); }
+      private:
+        std::mutex m; std::condition_variable cv; std::deque<T> q; bool closed = false;
+    };
+    struct Slot {  // one batch travelling reader -> device -> writer and back
+        uint8_t* bases = nullptr; size_t cap = 0, len = 0;   // page-locked (skx_host_alloc)
+        std::vector<uint64_t> offsets{0};
+        size_t first_read = 1;
+        std::vector<uint32_t> idx; std::vector<uint64_t> sum;
+        size_t n() const { return offsets.size() - 1; }
+        void clear() { len = 0; offsets.assign(1, 0); }
+    };
+
     // streaming mode
     void sum_of_shared_hashes(FastxReader& reader, const std::vector<Sketch>& sketches, Ref& ref, const Genotypes& geno,
                               const PredictConfig& config, std::ostream& out) {
         if (ref.stride_ != ref.s) throw SketchyError("reference sketches of unequal size are not supported in stream mode");
+        const size_t cap = 256ull << 20;  // bases per batch buffer (a single record must fit)
         skx_stream* st = nullptr;
-        hip_check(skx_stream_create(&st, ref.h, (uint32_t)config.top, (uint32_t)batch_, 1ull << 30), "stream");
+        hip_check(skx_stream_create(&st, ref.h, (uint32_t)config.top, (uint32_t)batch_, cap), "stream");
         struct Guard { skx_stream* s; ~Guard() { skx_stream_destroy(s); } } guard{st};
-        Batch b; std::string seq;
-        size_t read = 1;  // :327
-        std::vector<uint32_t> idx; std::vector<uint64_t> sum;
-        auto flush = [&]() {
-            if (b.n() == 0) return;
-            idx.assign(b.n() * config.top, 0); sum.assign(b.n() * config.top, 0);
-            hip_check(skx_stream_push(st, b.bases.data(), b.offsets.data(), (uint32_t)b.n(), idx.data(), sum.data(), nullptr, nullptr, nullptr), "push");
-            for (size_t r = 0; r < b.n(); ++r, ++read) print_results(sketches, geno, &idx[r * config.top], &sum[r * config.top], read, config, out);
-            b.clear();
-        };
-        size_t fed = 0;
-        while (reader.next(seq)) {
-            b.add(seq); ++fed;
-            const bool last = config.limit > 0 && fed == config.limit;  // :350-353
-            if (b.n() == batch_ || b.bases.size() > (1ull << 29) || last) flush();
-            if (last) break;
+        constexpr int kSlots = 3;
+        Slot slots[kSlots];
+        struct SlotGuard { Slot* s; int n, dev; ~SlotGuard() { for (int i = 0; i < n; ++i) if (s[i].bases) skx_host_free(dev, s[i].bases); } } sguard{slots, kSlots, device_};
+        Channel<Slot*> free_slots, to_device, to_writer;
+        for (auto& sl : slots) {
+            void* p = nullptr;
+            hip_check(skx_host_alloc(device_, &p, cap), "batch buffer");
+            sl.bases = static_cast<uint8_t*>(p); sl.cap = cap;
+            free_slots.put(&sl);
         }
-        flush();
+        std::exception_ptr reader_err, writer_err;
+
+        // stage 1: parse (src/sketchy.rs:328-333: one record at a time; --limit at :350-353)
+        std::thread reader_thread([&] {
+            try {
+                std::string seq; size_t fed = 0; Slot* sl = nullptr;
+                auto hand_over = [&] { if (sl && sl->n()) { to_device.put(sl); sl = nullptr; } };
+                bool stop = false;
+                while (!stop && reader.next(seq)) {
+                    if (seq.size() > cap) throw SketchyError("a record exceeds the batch buffer");
+                    if (sl && sl->len + seq.size() > sl->cap) hand_over();
+                    if (!sl) { if (!free_slots.get(sl)) break; sl->clear(); sl->first_read = fed + 1; }
+                    memcpy(sl->bases + sl->len, seq.data(), seq.size());
+                    sl->len += seq.size(); sl->offsets.push_back(sl->len); ++fed;
+                    stop = config.limit > 0 && fed == config.limit;
+                    if (sl->n() == batch_ || stop) hand_over();
+                }
+                hand_over();
+            } catch (...) { reader_err = std::current_exception(); }
+            to_device.close();
+        });
+        // stage 3: rows (src/sketchy.rs:389-400)
+        std::thread writer_thread([&] {
+            try {
+                std::vector<std::string> tail;  // per reference sketch: "\t<name>\t" and "\t<genotype columns>\n"
+                std::vector<std::string> geno_tail;
+                if (!config.consensus)
+                    for (const auto& sk : sketches) { tail.push_back("\t" + sk.name + "\t"); geno_tail.push_back("\t" + join_tab(geno.map.at(sk.name)) + "\n"); }
+                std::string text;
+                Slot* sl = nullptr;
+                while (to_writer.get(sl)) {
+                    if (config.consensus) {
+                        for (size_t r = 0; r < sl->n(); ++r)
+                            print_results(sketches, geno, &sl->idx[r * config.top], &sl->sum[r * config.top], sl->first_read + r, config, out);
+                    } else {
+                        text.clear();
+                        for (size_t r = 0; r < sl->n(); ++r) {
+                            const std::string rd = std::to_string(sl->first_read + r);
+                            for (size_t t = 0; t < config.top; ++t) {
+                                const uint32_t g = sl->idx[r * config.top + t];
+                                text += rd; text += tail[g]; text += std::to_string(sl->sum[r * config.top + t]); text += geno_tail[g];
+                            }
+                        }
+                        out.write(text.data(), (std::streamsize)text.size());
+                    }
+                    free_slots.put(sl);
+                }
+            } catch (...) { writer_err = std::current_exception(); free_slots.close(); }
+        });
+        // stage 2: the device path
+        std::exception_ptr device_err;
+        try {
+            Slot* sl = nullptr;
+            while (to_device.get(sl)) {
+                sl->idx.assign(sl->n() * config.top, 0); sl->sum.assign(sl->n() * config.top, 0);
+                hip_check(skx_stream_push(st, sl->bases, sl->offsets.data(), (uint32_t)sl->n(), sl->idx.data(), sl->sum.data(), nullptr, nullptr, nullptr), "push");
+                to_writer.put(sl);
+            }
+        } catch (...) { device_err = std::current_exception(); free_slots.close(); }
+        to_writer.close();
+        if (device_err) {  // unblock the reader (it may wait for a free slot) and drain what it still hands over
+            Slot* sl = nullptr;
+            while (to_device.get(sl)) {}
+        }
+        reader_thread.join();
+        writer_thread.join();
+        if (device_err) std::rethrow_exception(device_err);
+        if (reader_err) std::rethrow_exception(reader_err);
+        if (writer_err) std::rethrow_exception(writer_err);
     }
 
     // offline mode: one sketcher over all reads == bottom-s of the union of the per-read bottom-s sketches
@@ -205,6 +359,7 @@ class Sketchy {
 // ------------------------------------------------------------------ command line (src/cli.rs flag names)
 static void usage() {
     std::fprintf(stderr,
+                 "sketchy-hip sketch  -o OUT.msh [-i GENOME.fa[.gz] ...] [-s SIZE=1000] [-k K=16] [-e SEED=0]   (paths on stdin without -i)\n"
                  "sketchy-hip predict -r REF.msh -g GENO.tsv [-i READS.fx[.gz]] [-t TOP] [-l LIMIT] [-s] [-c] [-H]\n"
                  "sketchy-hip shared  -r REF.msh -q QUERY.msh\n"
                  "sketchy-hip info    -i SKETCH.msh [-p]\n");
@@ -214,19 +369,29 @@ int main(int argc, char** argv) {
     if (argc < 2) { usage(); return 2; }
     const std::string cmd = argv[1];
     std::map<std::string, std::string> opt; std::map<std::string, bool> flag;
+    std::vector<std::string> inputs;  // `sketch -i` takes several paths (src/cli.rs:27-28: multiple = true)
     const std::map<std::string, std::string> longnames = {{"--input", "-i"}, {"--reference", "-r"}, {"--genotypes", "-g"}, {"--top", "-t"}, {"--limit", "-l"},
                                                           {"--stream", "-s"}, {"--consensus", "-c"}, {"--header", "-H"}, {"--query", "-q"}, {"--params", "-p"},
-                                                          {"--device", "-d"}, {"--batch", "-b"}};
+                                                          {"--device", "-d"}, {"--batch", "-b"}, {"--output", "-o"}, {"--sketch-size", "-s"},
+                                                          {"--kmer-size", "-k"}, {"--seed", "-e"}};
+    const bool is_sketch = cmd == "sketch";  // there -s takes a value (sketch size), elsewhere it is --stream
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
+        if (is_sketch && a == "--stream") { usage(); return 2; }
         if (longnames.count(a)) a = longnames.at(a);
-        if (a == "-s" || a == "-c" || a == "-H" || a == "-p") flag[a] = true;
+        if (is_sketch && a == "-i") { while (i + 1 < argc && argv[i + 1][0] != '-') inputs.push_back(argv[++i]); continue; }
+        if ((!is_sketch && a == "-s") || a == "-c" || a == "-H" || a == "-p") flag[a] = true;
         else if (i + 1 < argc) opt[a] = argv[++i];
         else { usage(); return 2; }
     }
     try {
-        sketchy::Sketchy app(opt.count("-d") ? std::atoi(opt["-d"].c_str()) : 0, opt.count("-b") ? (size_t)std::atol(opt["-b"].c_str()) : 4096);
-        if (cmd == "predict") {
+        sketchy::Sketchy app(opt.count("-d") ? std::atoi(opt["-d"].c_str()) : 0, opt.count("-b") ? (size_t)std::atol(opt["-b"].c_str()) : 16384);
+        if (cmd == "sketch") {
+            if (!opt.count("-o")) { usage(); return 2; }
+            if (inputs.empty()) { std::string line; while (std::getline(std::cin, line)) if (!line.empty()) inputs.push_back(line); }  // src/sketchy.rs:137-146
+            app.sketch(inputs, opt["-o"], opt.count("-s") ? (size_t)std::atol(opt["-s"].c_str()) : 1000,
+                       opt.count("-k") ? (uint32_t)std::atoi(opt["-k"].c_str()) : 16u, opt.count("-e") ? std::strtoull(opt["-e"].c_str(), nullptr, 10) : 0ull);
+        } else if (cmd == "predict") {
             if (!opt.count("-r") || !opt.count("-g")) { usage(); return 2; }
             sketchy::PredictConfig cfg;
             cfg.top = opt.count("-t") ? (size_t)std::atol(opt["-t"].c_str()) : 1;

@@ -45,3 +45,46 @@ def write_msh(path, names, hashes_list, kmer=16, seed=0, lengths=None):
     with open(path, "wb") as f:
         f.write(struct.pack("<II", 0, len(arr)))
         f.write(arr.tobytes())
+
+
+def read_msh(path):
+    """Reads back a single-segment `.msh` (as written above or by the C++ host's write_mash_file):
+    returns (kmer, seed, [dict(name, length, num_valid_kmers, hashes)])."""
+    raw = open(path, "rb").read()
+    nseg, seg_len = struct.unpack("<II", raw[:8])
+    assert nseg == 0, "single segment expected"
+    w = np.frombuffer(raw[8:8 + 8 * seg_len], dtype=np.uint64)
+
+    def sptr(at):  # -> (first content word, data words, pointer words)
+        p = int(w[at])
+        assert p & 3 == 0
+        off = ((p & 0xFFFFFFFF) >> 2)
+        off = off - (1 << 30) if off >= (1 << 29) else off
+        return at + 1 + off, (p >> 32) & 0xFFFF, (p >> 48) & 0xFFFF
+
+    def lptr(at):  # -> (first content word, element code, count)
+        p = int(w[at])
+        if p == 0:
+            return None
+        assert p & 3 == 1
+        off = ((p & 0xFFFFFFFF) >> 2)
+        off = off - (1 << 30) if off >= (1 << 29) else off
+        return at + 1 + off, (p >> 32) & 7, p >> 35
+
+    root, dw, pw = sptr(0)
+    kmer = int(w[root]) & 0xFFFFFFFF
+    seed = ((int(w[root + 2]) >> 32) & 0xFFFFFFFF) ^ 42
+    rl, _, _ = sptr(root + dw + 3)
+    tag, code, _ = lptr(rl)
+    assert code == 7
+    n = (int(w[tag]) & 0xFFFFFFFF) >> 2
+    edw, epw = (int(w[tag]) >> 32) & 0xFFFF, (int(w[tag]) >> 48) & 0xFFFF
+    out = []
+    for i in range(n):
+        e = tag + 1 + i * (edw + epw)
+        name_at, _, cnt = lptr(e + edw + 2)
+        name = w[name_at:name_at + (cnt + 7) // 8].tobytes()[:cnt - 1].decode()
+        hl = lptr(e + edw + 5)
+        hashes = np.array(w[hl[0]:hl[0] + hl[2]], dtype=np.uint64) if hl else np.zeros(0, np.uint64)
+        out.append(dict(name=name, length=int(w[e + 1]), num_valid_kmers=int(w[e + 2]), hashes=hashes))
+    return kmer, seed, out

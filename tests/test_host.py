@@ -135,3 +135,85 @@ def test_shared_subcommand(gpu, tmp_path):
                    for r in range(len(names)) for i in range(3))
     assert out == want
     assert f"{names[1]} {names[1]} 128\n" in out  # docs/index.md:145-149
+
+
+def test_msh_python_roundtrip(tmp_path):
+    from mshio import read_msh
+    rng = np.random.default_rng(3)
+    hs = [np.sort(rng.integers(0, 2 ** 63, size=n, dtype=np.uint64)) for n in (5, 0, 17)]
+    write_msh(str(tmp_path / "a.msh"), ["x.fa", "y", "zzzzzzzzz.fasta"], hs, kmer=21, seed=7, lengths=[10, 0, 2 ** 33])
+    k, seed, recs = read_msh(str(tmp_path / "a.msh"))
+    assert (k, seed) == (21, 7) and [r["name"] for r in recs] == ["x.fa", "y", "zzzzzzzzz.fasta"]
+    assert recs[2]["length"] == 2 ** 33
+    for r, h in zip(recs, hs):
+        np.testing.assert_array_equal(r["hashes"], h)
+
+
+@pytest.mark.gpu
+def test_sketch_subcommand_builds_msh(gpu, tmp_path):
+    """`sketchy sketch` (src/sketchy.rs:128-167, :465-494): one sketch per FILE over all of its records, name = file
+    name; genomes go through the device's long-read kernels.  Checked hash by hash against the oracle."""
+    from mshio import read_msh
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    files, contigs_of = [], []
+    for gi, sizes in enumerate(([60000, 3000, 10], [25000] * 4, [900])):  # multi-contig, a contig shorter than k, a tiny genome
+        contigs = [bytes(acgt[rng.integers(0, 4, n)]) for n in sizes]
+        if gi == 0:
+            contigs[1] = contigs[1][:1000] + b"NNNNNRYK" + contigs[1][1000:].lower()  # ambiguity codes break k-mers; case folds
+        path = str(tmp_path / f"genome{gi}.fa") + (".gz" if gi == 1 else "")
+        opener = gzip.open if gi == 1 else open
+        with opener(path, "wt") as f:
+            for ci, c in enumerate(contigs):
+                s = c.decode()
+                f.write(f">contig{ci} some description\n" + "\n".join(s[j:j + 60] for j in range(0, len(s), 60)) + "\n")
+        files.append(path); contigs_of.append(contigs)
+    out = str(tmp_path / "db.msh")
+    for s, k, seed in ((1000, 16, 0), (64, 21, 5)):
+        rc, so, err = _run("sketch", "-i", *files, "-o", out, "-s", str(s), "-k", str(k), "-e", str(seed))
+        assert rc == 0, err
+        kk, sd, recs = read_msh(out)
+        assert (kk, sd) == (k, seed)
+        assert [r["name"] for r in recs] == [os.path.basename(p) for p in files]
+        for r, contigs in zip(recs, contigs_of):
+            want = sorted({int(h) for c in contigs for h in orc.sketch(c, k, seed, 10 ** 7)})[:s]
+            np.testing.assert_array_equal(r["hashes"], np.array(want, np.uint64))
+            assert r["length"] == sum(len(c) for c in contigs)
+            valid = sum(sum(1 for i in range(len(c) - k + 1) if all(ch in b"ACGTacgt" for ch in c[i:i + k])) for c in contigs if len(c) < 5000) \
+                if max(len(c) for c in contigs) < 5000 else None
+            if valid is not None:
+                assert r["num_valid_kmers"] == valid
+    # paths on stdin when -i is absent (src/sketchy.rs:137-146); the result feeds `info` and `shared`
+    rc, so, err = _run("sketch", "-o", out, "-s", "200", stdin="\n".join(files).encode() + b"\n")
+    assert rc == 0, err
+    rc, so, err = _run("info", "-i", out)
+    assert rc == 0 and so.split("\n")[0] == f"genome0.fa {60000 + 3008 + 10} 200"
+    rc, so, err = _run("shared", "-r", out, "-q", out)
+    assert rc == 0 and "genome0.fa genome0.fa 200\n" in so and "genome0.fa genome1.fa.gz 0\n" in so
+    rc, so, err = _run("sketch", "-i", files[0], "-o", str(tmp_path / "x.fsh"))
+    assert rc == 1 and "outside the accelerated path" in err
+    rc, so, err = _run("sketch", "-i", files[0], "-o", str(tmp_path / "x.txt"))
+    assert rc == 1 and "extension" in err
+
+
+@pytest.mark.gpu
+def test_predict_stream_many_batches_through_the_pipeline(gpu, tmp_path):
+    """Reader -> device -> writer pipeline: 700 reads in batches of 64 (11 batches over 3 recycled buffers)."""
+    ref, bases, offsets = workload(60, 200, 700, read_len=400, genome_len=40000, rng_seed=555)
+    names = [f"g{i}" for i in range(60)]
+    msh, tsv, fq = str(tmp_path / "r.msh"), str(tmp_path / "g.tsv"), str(tmp_path / "reads.fq")
+    write_msh(msh, names, ref["ref"])
+    with open(tsv, "w") as f:
+        f.write("id\ta\tb\n" + "".join(f"{n}\tA{i % 4}\tB{i % 3}\n" for i, n in enumerate(names)))
+    with open(fq, "w") as f:
+        for i, r in enumerate(unpack_reads(bases, offsets)):
+            f.write(f"@r{i}\n{r.decode()}\n+\n{'#' * len(r)}\n")
+    want = _expected_stream(ref, names, tsv, bases, offsets, top=2)
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", fq, "-s", "-t", "2", "-b", "64")
+    assert rc == 0, err
+    assert out == want
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", fq, "-s", "-t", "2", "-b", "64", "-l", "130")
+    assert rc == 0 and out == _expected_stream(ref, names, tsv, bases, offsets, top=2, limit=130)
+    (tmp_path / "bad.fq").write_text("@r0\nACGT\n+\nIIII\n@r1\nACGT\nIIII\n")  # malformed second record: error, no hang
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", str(tmp_path / "bad.fq"), "-s")
+    assert rc == 1 and "malformed FASTQ" in err
