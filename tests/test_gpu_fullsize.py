@@ -129,3 +129,14 @@ def test_forced_scan_kernel_variants(gpu, split, big):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=env, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "variant ok" in out.stdout
+
+
+@pytest.mark.parametrize("knobs", [{"SKX_PASS_READS": "64"}, {"SKX_PASS_READS": "100", "SKX_PIPELINE": "1"},
+                                   {"SKX_PASS_READS": "37", "SKX_PIPELINE": "3"}, {"SKX_NO_FILTER": "1"}])
+def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
+    """Several passes per push (the path that needs the per-read pair offsets on the host), the three pipeline depths
+    and the unfiltered dictionary all give the oracle's rows."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=dict(os.environ, **knobs),
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "variant ok" in out.stdout

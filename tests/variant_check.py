@@ -1,5 +1,7 @@
-"""Run by tests/test_gpu_fullsize.py in a subprocess with SKX_SCAN_SPLIT / SKX_SCAN_BIG forced (the library reads
-them once per process): parity of the forced scan-kernel variant against the oracle on small and ragged inputs."""
+"""Run by tests/test_gpu_fullsize.py in a subprocess with library knobs forced through the environment (the
+library reads them once per process): SKX_SCAN_SPLIT / SKX_SCAN_BIG (scan-kernel variant), SKX_PASS_READS (reads per
+pass: several passes per push), SKX_PIPELINE (stream depth), SKX_NO_FILTER.  Parity against the oracle on small and
+ragged inputs, top-3 with the debug outputs and top-1 (pruned path) through host and device pushes."""
 import os
 import sys
 
@@ -27,4 +29,18 @@ for n, s, n_reads, seed in ((300, 500, 400, 1), (513, 96, 50, 2), (40, 3000, 64,
     assert np.array_equal(got["shared"], exp["shared"]), "shared"
     assert np.array_equal(got["topk_idx"], exp["topk_idx"]) and np.array_equal(got["topk_sum"], exp["topk_sum"]), "rows"
     assert np.array_equal(S.table(), exp["cum"]), "table"
+    # production path (no debug outputs), top-1, two pushes: host buffers then device-resident buffers
+    S1 = api.SumOfSharedHashes(R, top=1, max_batch_reads=n_reads, max_batch_bases=len(bases))
+    half = n_reads // 2
+    a = S1.push(bases, offsets[:half + 1])
+    d_b, d_o = api.DeviceBuffer.from_numpy(bases), api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[half:]))
+    d_i, d_s = api.DeviceBuffer((n_reads - half) * 4), api.DeviceBuffer((n_reads - half) * 8)
+    S1.push_device(d_b.ptr, d_o.ptr, n_reads - half, int(offsets[-1] - offsets[half]), d_i.ptr, d_s.ptr)
+    S1.sync()
+    idx = np.concatenate([a["topk_idx"][:, 0], d_i.to_numpy(np.uint32, (n_reads - half,))])
+    sm = np.concatenate([a["topk_sum"][:, 0], d_s.to_numpy(np.uint64, (n_reads - half,))])
+    assert np.array_equal(idx, exp["topk_idx"][:, 0]) and np.array_equal(sm, exp["topk_sum"][:, 0]), "top-1 rows"
+    assert np.array_equal(S1.table(), exp["cum"]), "top-1 table"
+    for d in (d_b, d_o, d_i, d_s):
+        d.free()
 print("variant ok", os.environ.get("SKX_SCAN_SPLIT"), os.environ.get("SKX_SCAN_BIG"))
