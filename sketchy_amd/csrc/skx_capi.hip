@@ -426,7 +426,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     st->pcap = (u32)pc;
     static const u64 pass_reads = getenv("SKX_PASS_READS") ? (u64)atoll(getenv("SKX_PASS_READS")) : 131072;
     u64 rp = std::min<u64>(max_reads, pass_reads);
-    if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (1ull << 30) / ((u64)n_gw * top_k * 12)));
+    // candidate arrays of the ranking: per (read, rank group, row) for top_k <= 16, per (read, genome word, row) beyond
+    const u32 n_cand_units = (top_k >= 1 && top_k <= skx::rank_topk_fast_max()) ? (n_gw + skx::kRankWords - 1) / skx::kRankWords : n_gw;
+    if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (4ull << 30) / ((u64)n_cand_units * top_k * 12)));
     rp = std::max<u64>(rp, 1);
     st->rpass = (u32)rp;
     const u32 n_seg_max = (st->rpass + skx::kSegLen - 1) / skx::kSegLen;
@@ -480,10 +482,10 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
-    SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * 4 + 64));
+    SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * std::max<u32>(top_k, 1) * 4 + 64));
     if (top_k) {
-        SCHK(hipMalloc(&st->d_cand_sum, (size_t)st->rpass * n_gw * top_k * 8));
-        SCHK(hipMalloc(&st->d_cand_idx, (size_t)st->rpass * n_gw * top_k * 4));
+        SCHK(hipMalloc(&st->d_cand_sum, (size_t)st->rpass * n_cand_units * top_k * 8));
+        SCHK(hipMalloc(&st->d_cand_idx, (size_t)st->rpass * n_cand_units * top_k * 4));
         SCHK(hipMalloc(&st->d_topk_idx, (size_t)max_reads * top_k * 4));
         SCHK(hipMalloc(&st->d_topk_sum, (size_t)max_reads * top_k * 8));
     }
@@ -649,6 +651,13 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
                                       ref->n_genomes, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_inc,
                                       st->d_csum, st->d_leader);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
+        } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
+            const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
+            skx::launch_rank_seg_topk(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, ref->n_genomes,
+                                      cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, st->d_inc, st->d_csum,
+                                      st->d_leader);
+            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp * st->top_k, st->top_k, d_topk_idx,
+                                   d_topk_sum, ra);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
                                  ref->n_genomes, cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx);

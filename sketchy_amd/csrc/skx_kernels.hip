@@ -903,25 +903,34 @@ __device__ __forceinline__ void wave_best(u64& sum, u32& idx, bool ok) {
     }
 }
 
-// leader[c] = the genome leading (sum desc, index asc) as chunk c (16 segments = 1024 reads) begins, from the
-// pass-start table and the prefixed chunk sums.  One block per chunk.
+// leader[c * top_k + j] = the genome ranked j-th (sum desc, index asc) as chunk c (16 segments = 1024 reads) begins,
+// from the pass-start table and the prefixed chunk sums.  One block per chunk, top_k rounds.
 __global__ __launch_bounds__(1024) void chunk_leader_kernel(const u64* __restrict__ cum_in, const u32* __restrict__ csum,
-                                                            u32 n_pad, u32 n_genomes, u32* __restrict__ leader) {
+                                                            u32 n_pad, u32 n_genomes, u32 top_k, u32* __restrict__ leader) {
     __shared__ u64 ssum[16];
     __shared__ u32 sidx[16];
+    __shared__ u64 wsum;
+    __shared__ u32 widx;
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    u64 bs = 0; u32 bi = 0xFFFFFFFFu;
-    for (u32 g = tid; g < n_genomes; g += 1024u) {
-        const u64 v = cum_in[g] + csum[(size_t)c * n_pad + g];
-        if (bi == 0xFFFFFFFFu || v > bs) { bs = v; bi = g; }  // ascending g: ties keep the lower index
-    }
-    wave_best(bs, bi, bi != 0xFFFFFFFFu);
-    if (lane == 0) { ssum[wv] = bs; sidx[wv] = bi; }
-    __syncthreads();
-    if (wv == 0) {
-        u64 s2 = lane < 16 ? ssum[lane] : 0; u32 i2 = lane < 16 ? sidx[lane] : 0xFFFFFFFFu;
-        wave_best(s2, i2, i2 != 0xFFFFFFFFu);
-        if (lane == 0) leader[c] = i2;
+    u64 ps = 0; u32 pi = 0; bool first = true;
+    for (u32 j = 0; j < top_k; ++j) {
+        u64 bs = 0; u32 bi = 0xFFFFFFFFu;
+        for (u32 g = tid; g < n_genomes; g += 1024u) {
+            const u64 v = cum_in[g] + csum[(size_t)c * n_pad + g];
+            if (!first && !ranks_before(ps, pi, v, g)) continue;  // already taken in an earlier round
+            if (bi == 0xFFFFFFFFu || v > bs) { bs = v; bi = g; }  // ascending g: ties keep the lower index
+        }
+        wave_best(bs, bi, bi != 0xFFFFFFFFu);
+        if (lane == 0) { ssum[wv] = bs; sidx[wv] = bi; }
+        __syncthreads();
+        if (wv == 0) {
+            u64 s2 = lane < 16 ? ssum[lane] : 0; u32 i2 = lane < 16 ? sidx[lane] : 0xFFFFFFFFu;
+            wave_best(s2, i2, i2 != 0xFFFFFFFFu);
+            if (lane == 0) { wsum = s2; widx = i2; leader[c * top_k + j] = i2; }
+        }
+        __syncthreads();
+        ps = wsum; pi = widx; first = false;
+        __syncthreads();
     }
 }
 
@@ -1057,7 +1066,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     // (the latter also keeps every start of the group <= lead, which the 32-bit keys need).  Once a sample has a
     // clear best match a handful of genomes are left: a group without any reports "none" straight away, and inside
     // a live group words without any are neither loaded nor counted.  Non-candidates (and padding) get value 0.
-    const u32 gl = leader[seg >> 4];
+    const u32 gl = leader[seg >> 4];  // (top_k == 1: one leader per chunk)
     u64 lead = cum_in[gl] + rel[(size_t)seg * n_pad + gl];
     const u32 gain = pz - pa;
     u64 st0[NW];
@@ -1141,6 +1150,120 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         const u32 wl = 63u - (res_key & 63u), wj = (u32)(NW - 1) - ((res_key >> 6) & (u32)(NW - 1));
         best_sum[o] = base + (u64)(res_key >> SH);
         best_idx[o] = (grp * NW + wj) * 64u + wl;
+    }
+}
+
+// wave-wide max of a u64 given as (hi, lo); every lane returns it
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+    const u32 hi = (u32)(v >> 32);
+    const u32 mh = wave_max_u32(hi);
+    const u32 ml = wave_max_u32(hi == mh ? (u32)v : 0u);
+    return ((u64)mh << 32) | ml;
+}
+
+// rank_seg for 2 <= top_k <= kTopkFast, pruned like the top-1 kernel.  One wave per (rank group of 512 genomes,
+// segment).  The k-th best sum never decreases either, and it is at least the smallest segment start value among the
+// k genomes that ranked first when the segment's chunk began (`lead`); so only genomes with start + inc >= lead can be
+// in the top k at any read of the segment.  Those candidates are replayed read by read with 64-bit keys
+// (sum << 9 | tie) -- the leader may be far ahead of the k-th, so the keys cannot be made relative as for top-1 --
+// and every read takes k rounds of "largest key below the previous winner" over the group's candidates.
+// Non-candidates never take part.  Output: cand_sum / cand_idx[(r * n_grp + grp) * top_k + j], idx 0xFFFFFFFF = none.
+constexpr u32 kTopkFast = 16;
+__global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ pair_r,
+                                                            const u32* __restrict__ poff, u32 p_base, u32 r_begin,
+                                                            u32 n_reads, const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
+                                                            u32 n_genomes, const u64* __restrict__ cum_in,
+                                                            const u32* __restrict__ rel, u32 top_k,
+                                                            u64* __restrict__ cand_sum, u32* __restrict__ cand_idx,
+                                                            u32 nq_rows, const u32* __restrict__ inc,
+                                                            const u32* __restrict__ leader) {
+    constexpr int NW = kRankWords, SH = 6 + 3;
+    const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
+    const u32 n_seg = (n_reads + 63u) / 64u, n_grp = (n_gw + NW - 1) / NW;
+    const u32 grp = wave % n_grp, seg = wave / n_grp;
+    if (seg >= n_seg) return;
+    const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
+    const u32 ra = seg * 64u, rz = min(n_reads, ra + 64u);
+    const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
+    const u32 g0 = grp * NW * 64u + lane;
+    // lower bound of the k-th best sum over the segment
+    u64 lead = ~0ull;
+    for (u32 j = 0; j < top_k; ++j) {
+        const u32 gl = leader[(seg >> 4) * top_k + j];
+        lead = min(lead, cum_in[gl] + rel[(size_t)seg * n_pad + gl]);
+    }
+    u64 sum[NW];
+    bool cand[NW];
+    u32 wmask = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u32 g = g0 + (u32)j * 64u;
+        const bool real = g < n_genomes;
+        sum[j] = real ? cum_in[g] + rel[(size_t)seg * n_pad + g] : 0;
+        const u32 ic = real ? inc[(size_t)seg * n_pad + g] : 0;
+        cand[j] = real && sum[j] + ic >= lead;
+        if (__ballot(cand[j])) wmask |= 1u << j;
+    }
+    u64 res[kTopkFast];  // lane l: the k winners (keys) of read ra + l
+#pragma unroll
+    for (u32 j = 0; j < kTopkFast; ++j) res[j] = 0;
+    if (wmask != 0) {
+        u32 cur = ra;
+        auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
+            if (cur >= r_stop) return;
+            const bool mine = lane >= cur - ra && lane < r_stop - ra;
+            u64 prev = ~0ull;
+#pragma unroll
+            for (u32 j = 0; j < kTopkFast; ++j) {
+                if (j < top_k) {
+                    u64 k = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const u64 key = cand[w] ? (((sum[w] + 1ull) << SH) | ((u64)(NW - 1 - w) << 6) | (63u - lane)) : 0ull;
+                        if (key < prev) k = max(k, key);
+                    }
+                    const u64 best = wave_max_u64(k);  // 0: fewer than j+1 candidates in this group
+                    if (mine) res[j] = best;
+                    prev = best ? best : 0ull;         // (0 ends it: nothing is below 0)
+                }
+            }
+            cur = r_stop;
+        };
+        MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
+        u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
+        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+            const u32 n = min(64u, pz - p0);
+            const MaskVec cur_m = nxt;
+            const u32 rv = rnxt;
+            const u32 pn = p0 + 64u + lane;
+            nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
+            rnxt = pn < pz ? pair_r[pn] : 0u;
+            u64 x[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) x[j] = (wmask >> j & 1u) ? transpose64(cur_m.w[j], lane) : 0;  // live words only
+            for (u32 j = 0; j < n;) {
+                const u32 rd = __builtin_amdgcn_readlane(rv, (int)j);
+                emit_upto(rd);                                   // reads before rd see the state without rd's pairs
+                const u64 m = __ballot(lane < n && rv == rd);    // rd's pairs inside this chunk (contiguous from j)
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    if (wmask >> w & 1u) sum[w] += __popcll(x[w] & m);
+                j += __popcll(m);
+            }
+        }
+        emit_upto(rz);
+    }
+    if (lane < rz - ra) {
+        const size_t o = ((size_t)(ra + lane) * n_grp + grp) * top_k;
+#pragma unroll
+        for (u32 j = 0; j < kTopkFast; ++j) {
+            if (j < top_k) {
+                const u64 key = res[j];
+                const u32 wl = 63u - (u32)(key & 63u), wj = (u32)(NW - 1) - (u32)((key >> 6) & (u64)(NW - 1));
+                cand_sum[o + j] = key ? (key >> SH) - 1ull : 0ull;
+                cand_idx[o + j] = key ? (grp * NW + wj) * 64u + wl : 0xFFFFFFFFu;
+            }
+        }
     }
 }
 
@@ -1375,10 +1498,21 @@ void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, 
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* csum, u32* leader) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     // the genome leading as each chunk of 16 segments begins -- its start values bound the pruning
-    hipLaunchKernelGGL(chunk_leader_kernel, dim3(cdiv(n_seg, 16)), dim3(1024), 0, st, cum_in, csum, n_pad, n_genomes, leader);
+    hipLaunchKernelGGL(chunk_leader_kernel, dim3(cdiv(n_seg, 16)), dim3(1024), 0, st, cum_in, csum, n_pad, n_genomes, 1u, leader);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader);
 }
+void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                          const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* csum,
+                          u32* leader) {
+    const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
+    hipLaunchKernelGGL(chunk_leader_kernel, dim3(cdiv(n_seg, 16)), dim3(1024), 0, st, cum_in, csum, n_pad, n_genomes, top_k, leader);
+    hipLaunchKernelGGL(rank_seg_topk_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
+                       p_base, r_begin, n_reads, mq, n_gw, n_pad, n_genomes, cum_in, rel, top_k, cand_sum, cand_idx, nq_rows,
+                       inc, leader);
+}
+u32 rank_topk_fast_max() { return kTopkFast; }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0) {
     if (n_reads == 0) return;

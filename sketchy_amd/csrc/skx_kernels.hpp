@@ -64,6 +64,13 @@ void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, 
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc,
                           const u32* csum /* prefixed chunk sums of launch_seg_prefix */,
                           u32* leader /* [ceil(n_seg / 16)] scratch */);
+// 2 <= top_k <= rank_topk_fast_max(): pruned, one wave per (rank group, segment);
+// cand_sum / cand_idx[(r * n_grp + grp) * top_k + j], leader: [ceil(n_seg / 16) * top_k] scratch
+void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                          const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* csum,
+                          u32* leader);
+u32 rank_topk_fast_max();
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0);
 void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_cand, u32 top_k,
