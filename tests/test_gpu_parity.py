@@ -389,3 +389,14 @@ def test_push_device_errors_leave_the_table_alone(gpu):
     assert S.reads == 0 and not S.table().any()
     _push_device(S, bases, offsets, 1)  # the stream is still usable
     assert S.reads == 20
+
+
+@pytest.mark.parametrize("top", [2, 16, 17, 40])
+def test_topk_fast_and_generic_paths(gpu, top):
+    """2..16 rows: pruned per-group kernel; 17..64: generic per-word kernel.  Duplicated genomes give ties that span
+    rank groups of 512 genomes."""
+    ref, bases, offsets = workload(1100, 160, 150, read_len=700, rng_seed=91)
+    hashes = ref["ref"].copy()
+    hashes[1000] = hashes[5]
+    hashes[600] = hashes[5]
+    check(hashes, bases, offsets, top=top, batches=2, want_shared=False, want_sketches=False)
