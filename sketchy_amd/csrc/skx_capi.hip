@@ -360,6 +360,10 @@ struct skx_stream {
     // |Q| / pairs of the most recent pass whose dictionary has finished: the host only knows the pair count of a
     // pass when it picks the scan variant; reads of one sample share most of their matching hashes, so |Q| can be
     // far below it.  A hint only -- every variant gives the same bits.
+    // dictionary builder scratch (launch_dictionary): hash set, per-key bucket offsets, bucket counts / bases, counters
+    u64* d_ht = nullptr;
+    u32 ht_slots = 0;
+    u32 *d_slot_off = nullptr, *d_bcount = nullptr, *d_bbase = nullptr, *d_btot = nullptr, *d_dict_ctr = nullptr;
     u32* d_chk = nullptr;    // [8] device-side look at a batch's offsets (batch_check_kernel)
     u32* h_chk = nullptr;    // pinned [16]: d_chk, then [8] = total pairs of the batch
     u32* h_nq = nullptr;     // pinned [2]
@@ -392,6 +396,8 @@ static void stream_free(skx_stream* st) {
     if (st->h_nq) (void)hipHostFree(st->h_nq);
     if (st->h_chk) (void)hipHostFree(st->h_chk);
     (void)hipFree(st->d_chk);
+    (void)hipFree(st->d_ht); (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
+    (void)hipFree(st->d_btot); (void)hipFree(st->d_dict_ctr);
     for (auto& sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : st->ev_pool) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; ++i) {
@@ -498,6 +504,17 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_tmp, st->tmp_bytes));
     SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
+    st->ht_slots = 1024;
+    while (st->ht_slots < 2ull * st->pcap) st->ht_slots <<= 1;
+    SCHK(hipMalloc(&st->d_ht, (size_t)st->ht_slots * 8));
+    SCHK(hipMemset(st->d_ht, 0xFF, (size_t)st->ht_slots * 8));  // all-ones = empty; the compaction empties it again
+    SCHK(hipMalloc(&st->d_slot_off, (size_t)st->ht_slots * 4));
+    SCHK(hipMalloc(&st->d_btot, 256 * 4));
+    SCHK(hipMalloc(&st->d_bcount, (size_t)skx::dict_buckets() * 4));
+    SCHK(hipMemset(st->d_bcount, 0, (size_t)skx::dict_buckets() * 4));
+    SCHK(hipMalloc(&st->d_bbase, (size_t)skx::dict_buckets() * 4));
+    SCHK(hipMalloc(&st->d_dict_ctr, 64));
+    SCHK(hipMemset(st->d_dict_ctr, 0, 64));
     SCHK(hipHostMalloc((void**)&st->h_chk, 16 * 4, hipHostMallocDefault));
     SCHK(hipMalloc(&st->d_chk, 64));
     SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocDefault));
@@ -598,9 +615,16 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs0));
     if (P > 0) {
         Span sp(st, 1, hs0);
-        skx::launch_gather_pairs(hs0, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r);
-        HIPCHK(skx::prim_sort_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_pair_h, st->d_sorted, P));
-        HIPCHK(skx::prim_unique_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_sorted, d_q, d_nq, P));
+        static const bool own_dict = !(getenv("SKX_DICT") && atoi(getenv("SKX_DICT")) == 0);
+        if (own_dict) {
+            skx::launch_dictionary(hs0, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r, st->d_ht,
+                                   st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
+                                   st->d_dict_ctr, d_q, d_nq);
+        } else {  // general-purpose path: radix sort of all pair hashes + unique
+            skx::launch_gather_pairs(hs0, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r);
+            HIPCHK(skx::prim_sort_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_pair_h, st->d_sorted, P));
+            HIPCHK(skx::prim_unique_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_sorted, d_q, d_nq, P));
+        }
         skx::launch_pair_q(hs0, st->d_pair_h, P, d_q, d_nq, d_pair_q);
         skx::launch_window(hs0, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win);
         HIPCHK(hipMemcpyAsync(&st->h_nq[b], d_nq, 4, hipMemcpyDeviceToHost, hs0));

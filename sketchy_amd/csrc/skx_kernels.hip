@@ -450,6 +450,110 @@ __global__ void gather_pairs_kernel(const u64* __restrict__ sk, u32 sk_stride, c
     }
 }
 
+// ---- purpose-built dictionary (default; the rocPRIM sort + unique path remains behind SKX_DICT=0) ---------------
+// The surviving pairs of a pass repeat a few distinct hashes many times (C2 / B=98304: ~450 k pairs, ~11 k distinct),
+// and a general radix sort of all of them costs 16 launches on the front stream's critical path.  Instead:
+//   dict_insert   (fused with the pair gather) every pair hash goes into an open-addressing hash SET in HBM
+//   dict_count    used slots: bucket = top bits of the hash (uniform), count per bucket, place inside the bucket
+//   dict_scan_a/b exclusive scan of the 2^17 bucket counts (two levels) -> bucket bases, |Q|
+//   dict_scatter  used slots -> Q by bucket (and the set is emptied)
+//   dict_bucket_sort  one thread per bucket: insertion sort of its handful of keys  => Q sorted and distinct
+constexpr u32 kDictBuckets = 1u << 17;
+__device__ __forceinline__ u32 dict_bucket(u64 key, u32 bshift) { return (u32)min((u64)(kDictBuckets - 1u), key >> bshift); }
+
+__global__ void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, const u32* __restrict__ poff, u32 r_begin,
+                                   u32 r_end, u32 p_base, u64* __restrict__ pair_h, u32* __restrict__ pair_r,
+                                   u64* __restrict__ ht, u32 ht_mask, u32* __restrict__ ctr) {
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();  // one wave per read
+    const u32 r = r_begin + wave;
+    if (r >= r_end) return;
+    const u32 a = poff[r], b = poff[r + 1];
+    for (u32 j = lane; j < b - a; j += 64u) {
+        const u64 key = sk[(size_t)r * sk_stride + j];
+        pair_h[a - p_base + j] = key;
+        pair_r[a - p_base + j] = r - r_begin;
+        if (key == kPad) { atomicOr(&ctr[1], 1u); continue; }  // the empty marker itself: appended to Q at the end
+        u32 slot = (u32)(key ^ (key >> 29)) & ht_mask;
+        for (;;) {
+            const u64 prev = atomicCAS(&ht[slot], kPad, key);
+            if (prev == kPad || prev == key) break;
+            slot = (slot + 1u) & ht_mask;
+        }
+    }
+}
+// used slots: count per bucket; the slot remembers its place inside the bucket (atomics spread over 2^17 addresses)
+__global__ __launch_bounds__(256) void dict_count_kernel(const u64* __restrict__ ht, u32 ht_slots, u32 bshift,
+                                                         u32* __restrict__ slot_off, u32* __restrict__ bcount) {
+    for (u32 slot = blockIdx.x * 256u + threadIdx.x; slot < ht_slots; slot += gridDim.x * 256u) {
+        const u64 key = ht[slot];
+        if (key != kPad) slot_off[slot] = atomicAdd(&bcount[dict_bucket(key, bshift)], 1u);
+    }
+}
+// exclusive scan of the bucket counts, two levels: (a) inside every block of 1024 buckets, (b) over the block totals
+__global__ __launch_bounds__(1024) void dict_scan_a_kernel(u32* __restrict__ bcount, u32* __restrict__ bbase,
+                                                           u32* __restrict__ btot) {
+    __shared__ u32 part[1024];
+    const u32 t = threadIdx.x, b = blockIdx.x * 1024u + t;
+    const u32 c = bcount[b];
+    bcount[b] = 0;  // zero again for the next pass
+    part[t] = c;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele inclusive scan
+        const u32 v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    bbase[b] = part[t] - c;
+    if (t == 1023u) btot[blockIdx.x] = part[t];
+}
+__global__ __launch_bounds__(128) void dict_scan_b_kernel(u32* __restrict__ btot, const u32* __restrict__ ctr,
+                                                          u32* __restrict__ n_q) {
+    static_assert(kDictBuckets / 1024u == 128u, "one thread per block of buckets");
+    __shared__ u32 part[128];
+    const u32 t = threadIdx.x;
+    const u32 c = btot[t];
+    part[t] = c;
+    __syncthreads();
+    for (u32 d = 1; d < 128u; d <<= 1) {
+        const u32 v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    btot[t] = part[t] - c;  // exclusive: first position of the block's buckets in Q
+    if (t == 127u) { btot[128] = part[t]; *n_q = part[t] + (ctr[1] & 1u); }
+}
+// used slots -> Q by bucket; the set is emptied for the next pass
+__global__ __launch_bounds__(256) void dict_scatter_kernel(u64* __restrict__ ht, u32 ht_slots, u32 bshift,
+                                                           const u32* __restrict__ slot_off, const u32* __restrict__ bbase,
+                                                           const u32* __restrict__ btot, const u32* __restrict__ ctr,
+                                                           u64* __restrict__ q) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (ctr[1] & 1u)) q[btot[128]] = kPad;  // the largest possible hash goes last
+    for (u32 slot = blockIdx.x * 256u + threadIdx.x; slot < ht_slots; slot += gridDim.x * 256u) {
+        const u64 key = ht[slot];
+        if (key != kPad) {
+            const u32 b = dict_bucket(key, bshift);
+            q[btot[b >> 10] + bbase[b] + slot_off[slot]] = key;
+            ht[slot] = kPad;
+        }
+    }
+}
+__global__ void dict_bucket_sort_kernel(u64* __restrict__ q, const u32* __restrict__ bbase, const u32* __restrict__ btot,
+                                        u32* __restrict__ ctr) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= kDictBuckets) return;
+    const u32 a = btot[b >> 10] + bbase[b];
+    const u32 z = (b + 1u < kDictBuckets) ? btot[(b + 1u) >> 10] + bbase[b + 1u] : btot[128];
+    for (u32 i = a + 1; i < z; ++i) {  // buckets hold a handful of keys (uniform hashes, 2^17 buckets)
+        const u64 v = q[i];
+        u32 j = i;
+        while (j > a && q[j - 1] > v) { q[j] = q[j - 1]; --j; }
+        q[j] = v;
+    }
+    if (b == 0) ctr[1] = 0;  // (the "saw the all-ones hash" flag; its readers ran in earlier kernels)
+}
+
 __device__ __forceinline__ u32 lower_bound_u64(const u64* __restrict__ a, u32 n, u64 v) {
     u32 lo = 0, hi = n;
     while (lo < hi) {
@@ -1407,6 +1511,22 @@ void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32
     hipLaunchKernelGGL(gather_pairs_kernel, dim3(cdiv(r_end - r_begin, 4)), dim3(256), 0, st, sk, sk_stride, poff,
                        r_begin, r_end, p_base, pair_h, pair_r);
 }
+void launch_dictionary(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
+                       u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase,
+                       u32* btot, u32* ctr, u64* q, u32* n_q) {
+    if (r_end <= r_begin) return;
+    const u32 bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
+    const u32 bshift = bits > 17u ? bits - 17u : 0u;  // hashes <= max_ref  =>  hash >> bshift < 2^17
+    const u32 walk = std::min<u32>(cdiv(ht_slots, 256), 8192u);
+    hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 4)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
+                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr);
+    hipLaunchKernelGGL(dict_count_kernel, dim3(walk), dim3(256), 0, st, ht, ht_slots, bshift, slot_off, bcount);
+    hipLaunchKernelGGL(dict_scan_a_kernel, dim3(kDictBuckets / 1024u), dim3(1024), 0, st, bcount, bbase, btot);
+    hipLaunchKernelGGL(dict_scan_b_kernel, dim3(1), dim3(128), 0, st, btot, ctr, n_q);
+    hipLaunchKernelGGL(dict_scatter_kernel, dim3(walk), dim3(256), 0, st, ht, ht_slots, bshift, slot_off, bbase, btot, ctr, q);
+    hipLaunchKernelGGL(dict_bucket_sort_kernel, dim3(kDictBuckets / 256), dim3(256), 0, st, q, bbase, btot, ctr);
+}
+u32 dict_buckets() { return kDictBuckets; }
 void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q) {
     if (n_pairs == 0) return;
     hipLaunchKernelGGL(pair_q_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pair_h, n_pairs, q, n_q, pair_q);

@@ -36,6 +36,13 @@ void launch_long_read_finish(hipStream_t st, const u64* sorted, const u32* long_
 void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
                          u32 p_base, u64* pair_h, u32* pair_r);
 void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q);
+// gather the pairs of reads [r_begin, r_end) AND build the sorted distinct dictionary q / n_q of their hashes.
+// ht: hash set of ht_slots (power of two, >= 2 x pairs) u64, all-ones between passes; slot_off: [ht_slots] scratch;
+// bcount: [dict_buckets()] zero between passes; bbase: [dict_buckets()]; btot: [129]; ctr: [4] zero between passes
+void launch_dictionary(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
+                       u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase,
+                       u32* btot, u32* ctr, u64* q, u32* n_q);
+u32 dict_buckets();
 void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win);
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
                        u64* m_bits, u32 n_pad);
