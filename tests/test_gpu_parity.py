@@ -400,3 +400,28 @@ def test_topk_fast_and_generic_paths(gpu, top):
     hashes[1000] = hashes[5]
     hashes[600] = hashes[5]
     check(hashes, bases, offsets, top=top, batches=2, want_shared=False, want_sketches=False)
+
+
+def test_common_hashes_extreme_query_values(gpu):
+    """Arbitrary query hashes reach the dictionary builder through `shared`: 0, the all-ones value (the hash set's
+    empty marker), the table markers, heavy duplication across queries, and a query the reference never meets."""
+    from sketchy_amd import api
+    top = 0xFFFFFFFFFFFFFFFF
+    ref = np.array([[0, 5, 9, top - 1, top],
+                    [1, 5, 7, 8, top],
+                    [0, 1, 2, 3, 4],
+                    [10, 11, 12, top - 2, top - 1]], np.uint64)
+    R = api.ReferenceSketch(ref)
+    q = np.array([[0, 5, top - 1, top, 0],
+                  [top, 0, 0, 0, 0],
+                  [6, 13, 14, 15, 16],
+                  [0, 1, 5, 9, top]], np.uint64)
+    q_len = np.array([4, 1, 5, 5], np.uint32)
+    got = R.common_hashes(q, q_len)
+    exp = np.array([[orc.common_hashes(ref[g], q[i, :q_len[i]]) for g in range(4)] for i in range(4)], np.uint32)
+    np.testing.assert_array_equal(got, exp)
+    assert got[1].tolist() == [1, 1, 0, 0] and not got[2].any()
+    # many queries sharing the same few hashes (the hash set sees heavy duplication)
+    q2 = np.tile(np.array([[0, 5, 9, top - 1, top]], np.uint64), (300, 1))
+    got2 = R.common_hashes(q2)
+    assert (got2 == np.array([5, 2, 1, 1], np.uint32)).all()
