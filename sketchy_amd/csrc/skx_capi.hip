@@ -346,7 +346,11 @@ struct skx_stream {
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
     u32* d_inc = nullptr;
     u32* d_csum = nullptr;
-    u32* d_leader = nullptr;      // [chunks of 16 segments] genome leading the table as the chunk begins
+    u32* d_leader = nullptr;      // [chunks of 16 segments][top_k] genomes ranked first as the chunk begins
+    u64* d_lead_val = nullptr;    // [chunks] value of the top_k-th of them
+    u64* d_gmax = nullptr;        // [chunks + 1][half rank groups] best value inside 256 genomes at every chunk boundary
+    u64* d_lpart_sum = nullptr;   // per-slice leader candidates (chunk_leader_part_kernel)
+    u32* d_lpart_idx = nullptr;
     u32* d_rel = nullptr;         // [segments of a pass][n_pad] segment start values relative to the pass-start table
     u64* d_cand_sum = nullptr;
     u32* d_cand_idx = nullptr;
@@ -387,7 +391,7 @@ static void stream_free(skx_stream* st) {
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
-                    st->d_csum, st->d_leader, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_csum, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tmp};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
@@ -489,6 +493,10 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
     SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * std::max<u32>(top_k, 1) * 4 + 64));
+    SCHK(hipMalloc(&st->d_lead_val, (size_t)((n_seg_max + 15) / 16) * 8 + 64));
+    SCHK(hipMalloc(&st->d_lpart_sum, (size_t)((n_seg_max + 15) / 16) * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 8 + 64));
+    SCHK(hipMalloc(&st->d_lpart_idx, (size_t)((n_seg_max + 15) / 16) * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 4 + 64));
+    SCHK(hipMalloc(&st->d_gmax, (size_t)((n_seg_max + 15) / 16 + 1) * (n_pad / 256) * 8 + 64));
     if (top_k) {
         SCHK(hipMalloc(&st->d_cand_sum, (size_t)st->rpass * n_cand_units * top_k * 8));
         SCHK(hipMalloc(&st->d_cand_idx, (size_t)st->rpass * n_cand_units * top_k * 4));
@@ -667,19 +675,22 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         Span sp(st, 4, hs2);
         const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
         skx::launch_seg_sum(hs2, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, st->d_inc);
-        skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, st->d_cum, st->d_cum2, st->d_rel, st->d_csum);
+        const bool ranked = st->top_k && d_topk_idx && d_topk_sum;
+        const u32 prune_k = (ranked && st->top_k <= skx::rank_topk_fast_max()) ? st->top_k : 0u;
+        skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, ref->n_genomes, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, prune_k,
+                               st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
         if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
                                       ref->n_genomes, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_inc,
-                                      st->d_csum, st->d_leader);
+                                      st->d_leader, st->d_gmax, st->d_lead_val);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
         } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
             const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
             skx::launch_rank_seg_topk(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, ref->n_genomes,
-                                      cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, st->d_inc, st->d_csum,
-                                      st->d_leader);
+                                      cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, st->d_inc, st->d_leader,
+                                      st->d_gmax, st->d_lead_val);
             skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp * st->top_k, st->top_k, d_topk_idx,
                                    d_topk_sum, ra);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {

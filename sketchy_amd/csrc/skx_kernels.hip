@@ -946,6 +946,33 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
 }
 #undef SKX_CSA
 
+// Chunk-level pruning.  gmax[c][h] = largest value any genome of HALF rank group h (256 genomes) has as chunk c begins
+// (row n_chunks: as the pass ends), lead_val[c] = the value of the k-th ranked genome as chunk c begins.  No genome of
+// the half group can be among the first k at any read of chunk c unless the best value at the END of the chunk reaches
+// lead_val[c] (sums never decrease; the k-th best never decreases either).
+__device__ __forceinline__ bool chunk_half_live(const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
+                                                u32 n_half, u32 c, u32 h) {
+    return h < n_half && gmax[(size_t)(c + 1u) * n_half + h] >= lead_val[c];
+}
+__device__ __forceinline__ bool chunk_group_live(const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
+                                                 u32 n_half, u32 c, u32 grp) {
+    return chunk_half_live(gmax, lead_val, n_half, c, 2u * grp) || chunk_half_live(gmax, lead_val, n_half, c, 2u * grp + 1u);
+}
+// grid: (n_half, n_chunks + 1), 256 threads = 256 genomes (small blocks: they must find wave slots next to the front half)
+__global__ __launch_bounds__(256) void chunk_gmax_kernel(const u64* __restrict__ cum_in, const u64* __restrict__ cum_out,
+                                                         const u32* __restrict__ csum, u32 n_chunks, u32 n_pad,
+                                                         u32 n_genomes, u32 n_half, u64* __restrict__ gmax) {
+    __shared__ u64 part[4];
+    const u32 h = blockIdx.x, c = blockIdx.y, g = h * 256u + threadIdx.x;
+    u64 v = 0;
+    if (g < n_genomes) v = c < n_chunks ? cum_in[g] + csum[(size_t)c * n_pad + g] : cum_out[g];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, shfl_xor64(v, d));
+    if (lane_id() == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) gmax[(size_t)c * n_half + h] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
 // Segment start values, relative to the table at the start of the pass (32 bits: a pass gains at most its pair
 // count), in three levels so no thread walks a long chain and nothing is read twice:
 //   chunk_sum_kernel   : csum[c][g] = sum of inc over the 16 segments of chunk c
@@ -977,9 +1004,14 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(u32* __restrict__ csu
     cum_out[g] = cum_in[g] + run;
 }
 __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, const u32* __restrict__ csum,
-                                                         u32 n_seg, u32 n_pad, u32* __restrict__ rel) {
+                                                         u32 n_seg, u32 n_pad, u32* __restrict__ rel,
+                                                         const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
+                                                         u32 n_half) {
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
+    // a (chunk, rank group) without any possible candidate is never looked at by the ranking: skip its start values
+    // (both halves of a live group are written: the ranking reads the whole group)
+    if (gmax && !chunk_group_live(gmax, lead_val, n_half, c, blockIdx.x >> 1)) return;
     const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
     u32 run = csum[(size_t)c * n_pad + g];
 #pragma unroll 16
@@ -1008,18 +1040,25 @@ __device__ __forceinline__ void wave_best(u64& sum, u32& idx, bool ok) {
 }
 
 // leader[c * top_k + j] = the genome ranked j-th (sum desc, index asc) as chunk c (16 segments = 1024 reads) begins,
-// from the pass-start table and the prefixed chunk sums.  One block per chunk, top_k rounds.
-__global__ __launch_bounds__(1024) void chunk_leader_kernel(const u64* __restrict__ cum_in, const u32* __restrict__ csum,
-                                                            u32 n_pad, u32 n_genomes, u32 top_k, u32* __restrict__ leader) {
-    __shared__ u64 ssum[16];
-    __shared__ u32 sidx[16];
+// lead_val[c] = the value of the top_k-th, from the pass-start table and the prefixed chunk sums.  Two steps so the
+// first one consists of many small blocks -- a 1024-thread block needs 16 free wave slots on one CU and starves for
+// hundreds of microseconds next to the front half's sketch kernel, 4-wave blocks slip in: (a) every one of
+// kLeaderParts blocks per chunk finds the first top_k of its slice of the genomes, (b) one wave per chunk merges the
+// kLeaderParts x top_k candidates.
+constexpr u32 kLeaderParts = 32;
+__global__ __launch_bounds__(256) void chunk_leader_part_kernel(const u64* __restrict__ cum_in, const u32* __restrict__ csum,
+                                                                 u32 n_pad, u32 n_genomes, u32 top_k,
+                                                                 u64* __restrict__ part_sum, u32* __restrict__ part_idx) {
+    __shared__ u64 ssum[4];
+    __shared__ u32 sidx[4];
     __shared__ u64 wsum;
     __shared__ u32 widx;
-    const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 c = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 per = (n_genomes + kLeaderParts - 1) / kLeaderParts, g_lo = part * per, g_hi = min(n_genomes, g_lo + per);
     u64 ps = 0; u32 pi = 0; bool first = true;
     for (u32 j = 0; j < top_k; ++j) {
         u64 bs = 0; u32 bi = 0xFFFFFFFFu;
-        for (u32 g = tid; g < n_genomes; g += 1024u) {
+        for (u32 g = g_lo + tid; g < g_hi; g += 256u) {
             const u64 v = cum_in[g] + csum[(size_t)c * n_pad + g];
             if (!first && !ranks_before(ps, pi, v, g)) continue;  // already taken in an earlier round
             if (bi == 0xFFFFFFFFu || v > bs) { bs = v; bi = g; }  // ascending g: ties keep the lower index
@@ -1028,14 +1067,42 @@ __global__ __launch_bounds__(1024) void chunk_leader_kernel(const u64* __restric
         if (lane == 0) { ssum[wv] = bs; sidx[wv] = bi; }
         __syncthreads();
         if (wv == 0) {
-            u64 s2 = lane < 16 ? ssum[lane] : 0; u32 i2 = lane < 16 ? sidx[lane] : 0xFFFFFFFFu;
+            u64 s2 = lane < 4 ? ssum[lane] : 0; u32 i2 = lane < 4 ? sidx[lane] : 0xFFFFFFFFu;
             wave_best(s2, i2, i2 != 0xFFFFFFFFu);
-            if (lane == 0) { wsum = s2; widx = i2; leader[c * top_k + j] = i2; }
+            if (lane == 0) {
+                wsum = s2; widx = i2;
+                part_sum[((size_t)c * kLeaderParts + part) * top_k + j] = s2;
+                part_idx[((size_t)c * kLeaderParts + part) * top_k + j] = i2;  // 0xFFFFFFFF: the slice is exhausted
+            }
         }
         __syncthreads();
-        ps = wsum; pi = widx; first = false;
+        ps = wsum; pi = widx; first = widx == 0xFFFFFFFFu ? first : false;
+        if (widx == 0xFFFFFFFFu) {  // nothing left in this slice: the remaining rounds are empty too
+            for (u32 jj = j + 1; jj < top_k && tid == 0; ++jj) part_idx[((size_t)c * kLeaderParts + part) * top_k + jj] = 0xFFFFFFFFu;
+            break;
+        }
         __syncthreads();
     }
+}
+// one wave per chunk
+__global__ __launch_bounds__(64) void chunk_leader_merge_kernel(const u64* __restrict__ part_sum, const u32* __restrict__ part_idx,
+                                                                u32 top_k, u32* __restrict__ leader, u64* __restrict__ lead_val) {
+    const u32 c = blockIdx.x, lane = lane_id(), n_cand = kLeaderParts * top_k;
+    u64 ps = 0; u32 pi = 0; bool first = true;
+    for (u32 j = 0; j < top_k; ++j) {
+        u64 bs = 0; u32 bi = 0xFFFFFFFFu;
+        for (u32 x = lane; x < n_cand; x += 64u) {
+            const u64 v = part_sum[(size_t)c * n_cand + x];
+            const u32 g = part_idx[(size_t)c * n_cand + x];
+            if (g == 0xFFFFFFFFu) continue;
+            if (!first && !ranks_before(ps, pi, v, g)) continue;
+            if (bi == 0xFFFFFFFFu || ranks_before(v, g, bs, bi)) { bs = v; bi = g; }
+        }
+        wave_best(bs, bi, bi != 0xFFFFFFFFu);
+        if (lane == 0) leader[c * top_k + j] = bi;
+        ps = bs; pi = bi; first = false;
+    }
+    if (lane == 0) lead_val[c] = ps;  // value of the top_k-th ranked genome as the chunk begins (top_k <= n_genomes)
 }
 
 // rank_seg: walk a segment's reads in order from start[seg]; after every read emit this genome
@@ -1149,7 +1216,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             const u32* __restrict__ rel,
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
                                                             u32 nq_rows, const u32* __restrict__ inc,
-                                                            const u32* __restrict__ leader) {
+                                                            const u32* __restrict__ leader, const u64* __restrict__ gmax,
+                                                            const u64* __restrict__ lead_val) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
@@ -1160,6 +1228,14 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     if (seg >= n_seg) return;
     const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
+    if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp)) {  // (its start values were not even written)
+        if (lane < rz - ra) {
+            const size_t o = (size_t)grp * n_reads + ra + lane;
+            best_sum[o] = 0;
+            best_idx[o] = 0xFFFFFFFFu;
+        }
+        return;
+    }
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
     // Pruning (exact).  Sums never decrease and a genome ends the segment at start + inc, so with ANY lower bound
@@ -1176,18 +1252,18 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     u64 st0[NW];
     u32 ic[NW];
     bool real[NW];
-    u64 gmax = 0;
+    u64 grp_best = 0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const u32 g = g0 + (u32)j * 64u;
         real[j] = g < n_genomes;  // also false for words past n_gw (n_genomes <= n_pad)
         st0[j] = real[j] ? cum_in[g] + rel[(size_t)seg * n_pad + g] : 0;
         ic[j] = real[j] ? inc[(size_t)seg * n_pad + g] : 0;
-        gmax = max(gmax, st0[j]);
+        grp_best = max(grp_best, st0[j]);
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) gmax = max(gmax, shfl_xor64(gmax, d));
-    lead = max(lead, gmax);
+    for (int d = 32; d > 0; d >>= 1) grp_best = max(grp_best, shfl_xor64(grp_best, d));
+    lead = max(lead, grp_best);
     u32 val[NW];
     u32 wmask = 0;  // wave-uniform: words holding at least one candidate
 #pragma unroll
@@ -1280,7 +1356,8 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
                                                             const u32* __restrict__ rel, u32 top_k,
                                                             u64* __restrict__ cand_sum, u32* __restrict__ cand_idx,
                                                             u32 nq_rows, const u32* __restrict__ inc,
-                                                            const u32* __restrict__ leader) {
+                                                            const u32* __restrict__ leader, const u64* __restrict__ gmax,
+                                                            const u64* __restrict__ lead_val) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + 63u) / 64u, n_grp = (n_gw + NW - 1) / NW;
@@ -1288,6 +1365,13 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
     if (seg >= n_seg) return;
     const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
     const u32 ra = seg * 64u, rz = min(n_reads, ra + 64u);
+    if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp)) {  // (its start values were not even written)
+        if (lane < rz - ra) {
+            const size_t o = ((size_t)(ra + lane) * n_grp + grp) * top_k;
+            for (u32 j = 0; j < top_k; ++j) { cand_sum[o + j] = 0; cand_idx[o + j] = 0xFFFFFFFFu; }
+        }
+        return;
+    }
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
     // lower bound of the k-th best sum over the segment
@@ -1597,13 +1681,24 @@ void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_ba
     hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv((u64)cdiv(n_grp, 8) * n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
                        r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
 }
-void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
-                       u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */) {
+void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u32 n_genomes, const u64* cum_in, u64* cum_out,
+                       u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32 prune_top_k, u32* leader,
+                       u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx) {
     const u32 n_chunks = cdiv(n_seg, 16);
     dim3 grid(cdiv(n_pad, 256), n_chunks);
     hipLaunchKernelGGL(chunk_sum_kernel, grid, dim3(256), 0, st, inc, n_seg, n_pad, csum);
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, csum, n_chunks, n_pad, cum_in, cum_out);
-    hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel);
+    if (prune_top_k) {
+        // who leads as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
+        hipLaunchKernelGGL(chunk_leader_part_kernel, dim3(n_chunks, kLeaderParts), dim3(256), 0, st, cum_in, csum, n_pad,
+                           n_genomes, prune_top_k, part_sum, part_idx);
+        hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
+                           lead_val);
+        hipLaunchKernelGGL(chunk_gmax_kernel, dim3(n_pad / 256, n_chunks + 1), dim3(256), 0, st, cum_in, cum_out, csum, n_chunks,
+                           n_pad, n_genomes, n_pad / 256, gmax);
+    }
+    hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
+                       lead_val, n_pad / 256);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
@@ -1615,24 +1710,24 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
-                          const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* csum, u32* leader) {
+                          const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
+                          const u64* lead_val) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
-    // the genome leading as each chunk of 16 segments begins -- its start values bound the pruning
-    hipLaunchKernelGGL(chunk_leader_kernel, dim3(cdiv(n_seg, 16)), dim3(1024), 0, st, cum_in, csum, n_pad, n_genomes, 1u, leader);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader);
+                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader,
+                       gmax, lead_val);
 }
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
-                          const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* csum,
-                          u32* leader) {
+                          const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
+                          const u64* gmax, const u64* lead_val) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
-    hipLaunchKernelGGL(chunk_leader_kernel, dim3(cdiv(n_seg, 16)), dim3(1024), 0, st, cum_in, csum, n_pad, n_genomes, top_k, leader);
     hipLaunchKernelGGL(rank_seg_topk_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, mq, n_gw, n_pad, n_genomes, cum_in, rel, top_k, cand_sum, cand_idx, nq_rows,
-                       inc, leader);
+                       inc, leader, gmax, lead_val);
 }
 u32 rank_topk_fast_max() { return kTopkFast; }
+u32 rank_leader_parts() { return kLeaderParts; }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0) {
     if (n_reads == 0) return;

@@ -61,22 +61,27 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc);
-void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const u64* cum_in, u64* cum_out,
-                       u32* rel /* [n_seg][n_pad]: segment start values minus cum_in */, u32* csum);
+// prune_top_k > 0 (1..rank_topk_fast_max()): also find the first prune_top_k genomes as each chunk of 16 segments begins
+// (leader [n_chunks * k], lead_val [n_chunks]) and every half rank group's best value per chunk boundary (gmax
+// [(n_chunks + 1) * n_pad / 256]); start values are then only written for (chunk, group)s that can hold a candidate.
+void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u32 n_genomes, const u64* cum_in, u64* cum_out,
+                       u32* rel /* [n_seg][n_pad]: segment start values minus cum_in */, u32* csum, u32 prune_top_k,
+                       u32* leader, u64* lead_val, u64* gmax,
+                       u64* part_sum, u32* part_idx /* [n_chunks * rank_leader_parts() * k] scratch */);
+u32 rank_leader_parts();
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
                      const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx);
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
-                          const u32* rel, u64* best_sum, u32* best_idx, const u32* inc,
-                          const u32* csum /* prefixed chunk sums of launch_seg_prefix */,
-                          u32* leader /* [ceil(n_seg / 16)] scratch */);
+                          const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
+                          const u64* lead_val);
 // 2 <= top_k <= rank_topk_fast_max(): pruned, one wave per (rank group, segment);
-// cand_sum / cand_idx[(r * n_grp + grp) * top_k + j], leader: [ceil(n_seg / 16) * top_k] scratch
+// cand_sum / cand_idx[(r * n_grp + grp) * top_k + j]
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
-                          const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* csum,
-                          u32* leader);
+                          const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
+                          const u64* gmax, const u64* lead_val);
 u32 rank_topk_fast_max();
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
                        u64* out_sum, u32 out_r0);
