@@ -118,7 +118,7 @@ void skx_stream_destroy(skx_stream *st);
 
 /*
  * Per-stage device time, measured with HIP events on the stream's own HIP stream when enabled.
- * Stages: 0 sketch, 1 dictionary (sort/unique/windows), 2 reference scan (the roofline kernel),
+ * Stages: 0 sketch (+ membership filter), 1 dictionary (distinct query hashes, windows), 2 reference scan (the roofline kernel),
  * 3 bit-matrix transpose, 4 rank (segment sums, prefix, per-read top-k, merge).
  */
 #define SKX_N_STAGES 5

@@ -2,9 +2,9 @@
 //
 // Host-side orchestration of one skx_stream_push (the body of the reference's hot loop,
 // src/sketchy.rs:328-354, for a whole batch of reads):
-//   sketch every read -> cut the batch into passes that fit the pass workspace ->
-//   per pass: dictionary (sort/unique of the query hashes that can match), windows,
-//   reference scan, bit transpose, running table + per-read top-k.
+//   sketch every read (keeping only hashes some genome holds) -> normally ONE pass per push, else cut the batch
+//   into passes that fit the pass workspace -> per pass: dictionary of the distinct query hashes, windows,
+//   reference scan, bit transpose, running table + per-read top-k (pruned).
 // No CPU fallback exists: without a HIP device the calls fail with SKX_ERR_NO_DEVICE.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -318,7 +318,7 @@ struct skx_stream {
     int device = 0;
     // Three HIP streams form a pipeline over passes, so the stages of consecutive batches overlap:
     //   hs0  sketch + dictionary (small VALU/latency-bound kernels; independent of the previous batch)
-    //   hs   memsets + reference scan + bit transpose (HBM-bound)
+    //   hs   reference scan + bit transpose (HBM-bound)
     //   hs2  running table + per-read ranking (VALU-bound)
     // Everything handed from one stage to the next (Q, windows, pair lists, Mq, the pass's slice of the pair
     // offsets) is double-buffered; events order the hand-offs and the reuse of a buffer set two passes later.

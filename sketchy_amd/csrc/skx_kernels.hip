@@ -2,18 +2,18 @@
 //
 // Pipeline of one scoring pass over a batch of B reads (DESIGN.md has the full picture):
 //
-//   sketch_wave_kernel     one wavefront per read: normalise, canonical k-mers, murmur3,
-//                          bitonic sort in LDS, dedup, truncate to s          (A3-A6 of SURVEY 8(a))
-//   gather_pairs_kernel    the part of every read sketch that can match at all (hash <= largest
-//                          reference hash) becomes (read, hash) pairs
-//   [sort + unique]        -> Q: the batch's sorted distinct query hashes        (skx_prim.hip)
+//   sketch_wave_kernel     one wavefront per read: normalise, canonical k-mers, murmur3; of the hashes that can
+//                          match at all (<= largest reference hash) those some genome holds (membership bitmap)
+//                          are kept, sorted in LDS, deduplicated, truncated to s       (A3-A6 of SURVEY 8(a))
+//   long_read_* kernels    the same for reads with more k-mers than one wave's LDS holds
+//   dict_* kernels         (read, hash) pairs + Q: the pass's sorted distinct query hashes (hash set + bucket sort)
 //   pair_q_kernel          pair -> index of its hash in Q
 //   window_kernel          per reference tile-band: the slice [qa,qb) of Q its hashes can meet
 //   scan_kernel            THE roofline kernel: streams the resident s x N matrix once, probes an
 //                          LDS table of the slice, ORs hit bits into M[word][genome]   (A2)
 //   transpose_bits_kernel  M[word][genome] -> Mq[query][genome word] (64x64 bit transposes)
-//   seg_sum / seg_prefix / rank_seg / topk_merge
-//                          running table and per-read (sum desc, index asc) top-k       (A1, A7)
+//   seg_sum / chunk_* / seg_prefix / rank_seg_top1 | rank_seg_topk | rank_seg / *_merge
+//                          running table and per-read (sum desc, index asc) top-k, pruned      (A1, A7)
 //
 // Integer work throughout (u64 hash compares, bit counts): no MFMA.
 #include <algorithm>
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(64) void chunk_leader_merge_kernel(const u64* __res
     if (lane == 0) lead_val[c] = ps;  // value of the top_k-th ranked genome as the chunk begins (top_k <= n_genomes)
 }
 
-// rank_seg: walk a segment's reads in order from start[seg]; after every read emit this genome
+// rank_seg (generic, top_k > 16): walk a segment's reads in order from its start values; after every read emit this genome
 // group's top_k candidates cand_sum/cand_idx[(r * n_gw + gw) * top_k + j].  One wave per (gw, seg).
 __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ pair_r,
                                                        const u32* __restrict__ poff, u32 p_base, u32 r_begin,
