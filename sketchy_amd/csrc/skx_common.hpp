@@ -40,7 +40,25 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
 }
 
 // ---------------------------------------------------------------- murmur3 x64_128 (h1)
-__host__ __device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+// rotate left by a compile-time amount; on the device two v_alignbit_b32 (the compiler's shift/or sequences cost 3-4)
+template <int R>
+__host__ __device__ __forceinline__ u64 rotl64c(u64 x) {
+    static_assert(R > 0 && R < 64 && R != 32, "rotation amount");
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    if constexpr (R < 32) {
+        // new_hi = (hi << R) | (lo >> (32 - R)) = alignbit(hi, lo, 32 - R); new_lo = alignbit(lo, hi, 32 - R)
+        const u32 nh = __builtin_amdgcn_alignbit(hi, lo, 32 - R), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
+        return ((u64)nh << 32) | nl;
+    } else {
+        // rotate by 32 (swap the halves), then by R - 32
+        const u32 nh = __builtin_amdgcn_alignbit(lo, hi, 64 - R), nl = __builtin_amdgcn_alignbit(hi, lo, 64 - R);
+        return ((u64)nh << 32) | nl;
+    }
+#else
+    return (x << R) | (x >> (64 - R));
+#endif
+}
 __host__ __device__ __forceinline__ u64 fmix64(u64 k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
     return k;
@@ -62,18 +80,18 @@ __host__ __device__ __forceinline__ u64 murmur3_h1_words(u64 w0, u64 w1, u64 w2,
 #define SKX_MM_BLOCK(K1, K2)                                                      \
     {                                                                             \
         u64 k1 = (K1), k2 = (K2);                                                 \
-        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;                        \
-        h1 = rotl64(h1, 27); h1 += h2; h1 = mul5(h1) + 0x52dce729ull;             \
-        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;                        \
-        h2 = rotl64(h2, 31); h2 += h1; h2 = mul5(h2) + 0x38495ab5ull;             \
+        k1 *= c1; k1 = rotl64c<31>(k1); k1 *= c2; h1 ^= k1;                       \
+        h1 = rotl64c<27>(h1); h1 += h2; h1 = mul5(h1) + 0x52dce729ull;            \
+        k2 *= c2; k2 = rotl64c<33>(k2); k2 *= c1; h2 ^= k2;                       \
+        h2 = rotl64c<31>(h2); h2 += h1; h2 = mul5(h2) + 0x38495ab5ull;            \
     }
     if (k >= 16) SKX_MM_BLOCK(w0, w1)
     if (k >= 32) SKX_MM_BLOCK(w2, w3)
 #undef SKX_MM_BLOCK
     const u32 tail = k & 15u;
     const u64 t1 = (k >= 16) ? w2 : w0, t2 = (k >= 16) ? w3 : w1;
-    if (tail > 8) { u64 k2 = t2; k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
-    if (tail > 0) { u64 k1 = t1; k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+    if (tail > 8) { u64 k2 = t2; k2 *= c2; k2 = rotl64c<33>(k2); k2 *= c1; h2 ^= k2; }
+    if (tail > 0) { u64 k1 = t1; k1 *= c1; k1 = rotl64c<31>(k1); k1 *= c2; h1 ^= k1; }
     h1 ^= k; h2 ^= k;
     h1 += h2; h2 += h1;
     h1 = fmix64(h1); h2 = fmix64(h2);
