@@ -40,6 +40,18 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
 }
 
 // ---------------------------------------------------------------- murmur3 x64_128 (h1)
+// a u64 from its two halves as a plain register pair (an `(hi << 32) | lo` expression tends to be folded into the
+// neighbouring additions and costs moves + 64-bit adds instead)
+__host__ __device__ __forceinline__ u64 make_u64(u32 lo, u32 hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef u32 u32x2_ __attribute__((ext_vector_type(2)));
+    u32x2_ v;
+    v.x = lo; v.y = hi;
+    return __builtin_bit_cast(u64, v);
+#else
+    return ((u64)hi << 32) | lo;
+#endif
+}
 // rotate left by a compile-time amount; on the device two v_alignbit_b32 (the compiler's shift/or sequences cost 3-4)
 template <int R>
 __host__ __device__ __forceinline__ u64 rotl64c(u64 x) {
@@ -49,11 +61,11 @@ __host__ __device__ __forceinline__ u64 rotl64c(u64 x) {
     if constexpr (R < 32) {
         // new_hi = (hi << R) | (lo >> (32 - R)) = alignbit(hi, lo, 32 - R); new_lo = alignbit(lo, hi, 32 - R)
         const u32 nh = __builtin_amdgcn_alignbit(hi, lo, 32 - R), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - R);
-        return ((u64)nh << 32) | nl;
+        return make_u64(nl, nh);
     } else {
         // rotate by 32 (swap the halves), then by R - 32
         const u32 nh = __builtin_amdgcn_alignbit(lo, hi, 64 - R), nl = __builtin_amdgcn_alignbit(hi, lo, 64 - R);
-        return ((u64)nh << 32) | nl;
+        return make_u64(nl, nh);
     }
 #else
     return (x << R) | (x >> (64 - R));

@@ -158,18 +158,27 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
         // (the murmur3 block) -- one LDS byte read and a few shifts per k-mer instead of rebuilding all 16 bases.
         const u32 run = (nk + 63u) / 64u;
         const u32 p0 = lane * run;
-        u64 fwd = 0, rc = 0;            // 32 significant bits each
-        u64 fa0 = 0, fa1 = 0, ra0 = 0, ra1 = 0;
+        u32 fwd = 0, rc = 0;            // 16 bases x 2 bits: forward (first base highest) / reverse complement
+        u32 f0 = 0, f1 = 0, f2 = 0, f3 = 0;  // the 16 ASCII bytes of the forward k-mer, first base in the lowest byte
+        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // ... of its reverse complement
         u32 clean = 0;                  // consecutive valid bases ending at the newest one
         auto push = [&](u32 c) {
             clean = (c >> 2) ? 0u : clean + 1u;
             c &= 3u;
-            fwd = ((fwd << 2) | c) & 0xFFFFFFFFull;
-            rc = (rc >> 2) | ((u64)(3u - c) << 30);
-            const u64 a = (0x54474341u >> (8u * c)) & 0xFFu;   // "ACGT"[c]
-            const u64 ca = (0x41434754u >> (8u * c)) & 0xFFu;  // complement: "TGCA"[c]
-            fa0 = (fa0 >> 8) | (fa1 << 56); fa1 = (fa1 >> 8) | (a << 56);
-            ra1 = (ra1 << 8) | (ra0 >> 56); ra0 = (ra0 << 8) | ca;
+            fwd = (fwd << 2) | c;
+            rc = __builtin_amdgcn_alignbit(c ^ 3u, rc, 2);        // (rc >> 2) | (complement << 30)
+            const u32 a = (0x54474341u >> (8u * c)) & 0xFFu;   // "ACGT"[c]
+            const u32 ca = (0x41434754u >> (8u * c)) & 0xFFu;  // complement: "TGCA"[c]
+            // one byte per step: the forward window drops its lowest byte and takes the new base on top, the reverse
+            // complement shifts up and takes the complement at the bottom (v_alignbit_b32 each)
+            f0 = __builtin_amdgcn_alignbit(f1, f0, 8);
+            f1 = __builtin_amdgcn_alignbit(f2, f1, 8);
+            f2 = __builtin_amdgcn_alignbit(f3, f2, 8);
+            f3 = __builtin_amdgcn_alignbit(a, f3, 8);
+            r3 = __builtin_amdgcn_alignbit(r3, r2, 24);
+            r2 = __builtin_amdgcn_alignbit(r2, r1, 24);
+            r1 = __builtin_amdgcn_alignbit(r1, r0, 24);
+            r0 = (r0 << 8) | ca;
         };
         for (u32 j = 0; j < 15u; ++j) push(p0 + j < nb ? (u32)codes[p0 + j] : 4u);
         for (u32 t = 0; t < run; ++t) {
@@ -177,7 +186,8 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
             const bool in = p < nk;
             push(in ? (u32)codes[p + 15u] : 4u);
             const bool use_f = fwd < rc;
-            const u64 h = murmur3_h1_words(use_f ? fa0 : ra0, use_f ? fa1 : ra1, 0, 0, 16u, seed);
+            const u64 h = murmur3_h1_words(make_u64(use_f ? f0 : r0, use_f ? f1 : r1), make_u64(use_f ? f2 : r2, use_f ? f3 : r3),
+                                           0, 0, 16u, seed);
             if (!append(in && clean >= 16u, h)) return;
         }
     } else {
