@@ -8,6 +8,7 @@
 //   Sketchy::_print_results           src/sketchy.rs:358-402  (rows / consensus)
 //   Sketchy::shared                   src/sketchy.rs:238-279                                       -> skx_common_hashes
 //   Sketchy::info (names only)        src/sketchy.rs:172-208
+//   Sketchy::check                    src/sketchy.rs:212-236
 //   Sketchy::sketch + _sketch_files   src/sketchy.rs:128-167, :465-494  (genome files -> Mash .msh)      -> skx_sketch_reads
 // Command line: the reference's flag names and defaults (src/cli.rs:25-132).
 //
@@ -81,6 +82,15 @@ class Sketchy {
                     throw SketchyError("reference (" + refs[r].name + ") does not match query (" + qs[q].name + ")");
                 out << refs[r].name << " " << qs[q].name << " " << common[q * refs.size() + r] << "\n";
             }
+    }
+
+    // `sketchy check` (src/sketchy.rs:212-236): the per-row identifier comparison builds an error and discards it
+    // (:219-228), so only the size check has an effect -- kept that way
+    void check(const std::string& reference, const std::string& genotypes, std::ostream& out) {
+        const auto sk = read_sketch(reference);
+        const auto geno = read_genotypes(genotypes);
+        if (sk.size() != geno.rows) throw SketchyError("reference sketch and genotype table must have the same length");
+        out << "ok\n";
     }
 
     void info(const std::string& input, bool params, std::ostream& out) {
@@ -362,7 +372,8 @@ static void usage() {
                  "sketchy-hip sketch  -o OUT.msh [-i GENOME.fa[.gz] ...] [-s SIZE=1000] [-k K=16] [-e SEED=0]   (paths on stdin without -i)\n"
                  "sketchy-hip predict -r REF.msh -g GENO.tsv [-i READS.fx[.gz]] [-t TOP] [-l LIMIT] [-s] [-c] [-H]\n"
                  "sketchy-hip shared  -r REF.msh -q QUERY.msh\n"
-                 "sketchy-hip info    -i SKETCH.msh [-p]\n");
+                 "sketchy-hip info    -i SKETCH.msh [-p]\n"
+                 "sketchy-hip check   -r REF.msh -g GENO.tsv\n");
 }
 
 int main(int argc, char** argv) {
@@ -401,6 +412,9 @@ int main(int argc, char** argv) {
         } else if (cmd == "shared") {
             if (!opt.count("-r") || !opt.count("-q")) { usage(); return 2; }
             app.shared(opt["-r"], opt["-q"], std::cout);
+        } else if (cmd == "check") {
+            if (!opt.count("-r") || !opt.count("-g")) { usage(); return 2; }
+            app.check(opt["-r"], opt["-g"], std::cout);
         } else if (cmd == "info") {
             if (!opt.count("-i")) { usage(); return 2; }
             app.info(opt["-i"], flag["-p"], std::cout);

@@ -64,6 +64,17 @@ def test_errors_without_gpu_work(tmp_path):
     assert rc == 1 and "--top must be an odd number" in err  # src/sketchy.rs:74-79
 
 
+def test_check_subcommand(tmp_path):
+    """src/sketchy.rs:212-236: only the length comparison has an effect."""
+    ref, names, msh, tsv, reads, _, _ = _fixture(tmp_path)
+    rc, out, err = _run("check", "-r", msh, "-g", tsv)
+    assert rc == 0 and out == "ok\n"
+    with open(tsv, "a") as f:
+        f.write("extra.fa\tST1\tR\t-\n")
+    rc, out, err = _run("check", "-r", msh, "-g", tsv)
+    assert rc == 1 and "must have the same length" in err
+
+
 def _expected_stream(ref, names, tsv, bases, offsets, top, limit=0, header=False):
     n = len(offsets) - 1 if not limit else min(limit, len(offsets) - 1)
     exp = orc.stream(16, 0, ref["ref"].shape[1], ref["ref"], ref["col_len"], bases, offsets[:n + 1], top_k=top)
