@@ -373,6 +373,7 @@ struct skx_stream {
     u32* h_nq = nullptr;     // pinned [2]
     u32 hint_pairs[2] = {0, 0};
     double nq_per_pair = 1.0;
+    bool have_hint = false;  // false until one dictionary size has been seen
     LongWork lw;
     // profiling
     bool profiling = false;
@@ -613,8 +614,9 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         if (st->hint_pairs[i] && hipEventQuery(st->ev_dict[i]) == hipSuccess) {
             st->nq_per_pair = std::min(1.0, (double)st->h_nq[i] / st->hint_pairs[i]);
             st->hint_pairs[i] = 0;
+            st->have_hint = true;
         }
-    const u64 nq_est = std::max<u64>(1, (u64)(P * st->nq_per_pair));
+    u64 nq_est = std::max<u64>(1, (u64)(P * st->nq_per_pair));
 
     // ---- dictionary (stream hs0): set b was last used two passes ago -- by that pass's scan (Q, windows) and
     // ranking (pair lists, offsets, Mq); wait for both before overwriting it
@@ -640,6 +642,15 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->ev_dict[b], hs0));
+
+    // the very first pass of a stream has no hint: wait for its dictionary once rather than run the heaviest variant
+    if (!st->have_hint && P > 0) {
+        HIPCHK(hipStreamSynchronize(hs0));
+        st->nq_per_pair = std::min(1.0, (double)st->h_nq[b] / P);
+        st->hint_pairs[b] = 0;
+        st->have_hint = true;
+        nq_est = std::max<u64>(1, st->h_nq[b]);
+    }
 
     // ---- scan + transpose (stream hs, HBM-bound)
     HIPCHK(hipStreamWaitEvent(hs, st->ev_dict[b], 0));
