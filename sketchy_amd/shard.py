@@ -117,14 +117,20 @@ class TableReducer:
             return
         rank, world = dist.get_rank(), dist.get_world_size()
         self.how = "gloo-host"
-        try:
-            uid = api.Comm.unique_id() if rank == 0 else b"\0" * 128
-            uid = broadcast_bytes(uid, 128, src=0)
-            self.comm = api.Comm(device, rank, world, uid)
-            self.how = "rccl"
-        except Exception as e:  # noqa: BLE001  (RCCL unavailable: stay on the host path)
-            self.err = repr(e)
-            self.comm = None
+        uid = b"\0" * 128
+        if rank == 0:
+            try:
+                uid = api.Comm.unique_id()
+            except Exception as e:  # noqa: BLE001  (RCCL unavailable on rank 0: everybody stays on the host path)
+                self.err = repr(e)
+        uid = broadcast_bytes(uid, 128, src=0)  # always: the other ranks are waiting in it
+        if any(uid):
+            try:
+                self.comm = api.Comm(device, rank, world, uid)
+                self.how = "rccl"
+            except Exception as e:  # noqa: BLE001  (RCCL unavailable: stay on the host path)
+                self.err = repr(e)
+                self.comm = None
         # every rank must take the same path
         ok = sum_over_ranks_int(1 if self.comm is not None else 0)
         if ok != world:
