@@ -117,14 +117,20 @@ class TableReducer:
             return
         rank, world = dist.get_rank(), dist.get_world_size()
         self.how = "gloo-host"
+        # every rank first proves it can load RCCL (making an id does; only rank 0's is used): a rank that cannot
+        # would otherwise leave the others blocked inside ncclCommInitRank
         uid = b"\0" * 128
-        if rank == 0:
-            try:
-                uid = api.Comm.unique_id()
-            except Exception as e:  # noqa: BLE001  (RCCL unavailable on rank 0: everybody stays on the host path)
-                self.err = repr(e)
+        can_load = 1
+        try:
+            mine = api.Comm.unique_id()
+            if rank == 0:
+                uid = mine
+        except Exception as e:  # noqa: BLE001  (RCCL unavailable: everybody stays on the host path)
+            self.err = repr(e)
+            can_load = 0
+        all_can = sum_over_ranks_int(can_load) == world
         uid = broadcast_bytes(uid, 128, src=0)  # always: the other ranks are waiting in it
-        if any(uid):
+        if all_can and any(uid):
             try:
                 self.comm = api.Comm(device, rank, world, uid)
                 self.how = "rccl"
