@@ -304,7 +304,7 @@ static int sketch_all(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads
                       const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
                       bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
     skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len, d_cnt,
-                            nullptr, 0);
+                            nullptr, 0, nullptr);
     HIPCHK(hipGetLastError());
     return sketch_long(hs, lw, cap_bases, cap_reads, d_bases, d_offsets, h_offsets, n_reads, k, seed, s, max_ref,
                        inrange_only, d_sk, sk_stride, d_len, d_cnt);
@@ -369,7 +369,10 @@ struct skx_stream {
     u32 ht_slots = 0;
     u32 *d_slot_off = nullptr, *d_bcount = nullptr, *d_bbase = nullptr, *d_btot = nullptr, *d_dict_ctr = nullptr;
     u32* d_chk = nullptr;    // [8] device-side look at a batch's offsets (batch_check_kernel)
-    u32* h_chk = nullptr;    // pinned [16]: d_chk, then [8] = total pairs of the batch
+    u32* h_chk = nullptr;    // page-locked, coherent [16]: written by publish_kernel: d_chk, [8] = total pairs, [15] = sequence
+    u32 pub_seq = 0;         // sequence number of the latest publish
+    bool chk_dirty = false;  // a push failed between arming and publishing: re-zero the device-side counters first
+    u32* d_retry = nullptr;  // [1 + max_reads] reads the fast sketch variant hands to the full-size one ([0] = count)
     u32* h_nq = nullptr;     // pinned [2]
     u32 hint_pairs[2] = {0, 0};
     double nq_per_pair = 1.0;
@@ -400,7 +403,7 @@ static void stream_free(skx_stream* st) {
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
     if (st->h_chk) (void)hipHostFree(st->h_chk);
-    (void)hipFree(st->d_chk);
+    (void)hipFree(st->d_chk); (void)hipFree(st->d_retry);
     (void)hipFree(st->d_ht); (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
     (void)hipFree(st->d_btot); (void)hipFree(st->d_dict_ctr);
     for (auto& sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -524,9 +527,13 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_bbase, (size_t)skx::dict_buckets() * 4));
     SCHK(hipMalloc(&st->d_dict_ctr, 64));
     SCHK(hipMemset(st->d_dict_ctr, 0, 64));
-    SCHK(hipHostMalloc((void**)&st->h_chk, 16 * 4, hipHostMallocDefault));
+    SCHK(hipHostMalloc((void**)&st->h_chk, 16 * 4, hipHostMallocCoherent));  // kernels write it, the host polls it
+    memset(st->h_chk, 0, 16 * 4);
     SCHK(hipMalloc(&st->d_chk, 64));
-    SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocDefault));
+    SCHK(hipMemset(st->d_chk, 0, 64));
+    SCHK(hipMalloc(&st->d_retry, ((size_t)max_reads + 1) * 4));
+    SCHK(hipMemset(st->d_retry, 0, 4));
+    SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocCoherent));
     st->h_nq[0] = st->h_nq[1] = 0;
     // the zero-fills above ran on the null stream, which the (non-blocking) pipeline streams do not wait for
     SCHK(hipDeviceSynchronize());
@@ -636,8 +643,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
             HIPCHK(skx::prim_unique_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_sorted, d_q, d_nq, P));
         }
         skx::launch_pair_q(hs0, st->d_pair_h, P, d_q, d_nq, d_pair_q);
-        skx::launch_window(hs0, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win);
-        HIPCHK(hipMemcpyAsync(&st->h_nq[b], d_nq, 4, hipMemcpyDeviceToHost, hs0));
+        skx::launch_window(hs0, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);  // (also hands |Q| to the host)
         st->hint_pairs[b] = P;
     }
     HIPCHK(hipGetLastError());
@@ -752,26 +758,48 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     // Only hashes some genome holds become pairs (exact: the others share nothing with anyone).  The wave kernel
     // applies the filter itself in production mode; rows it did not filter (long reads, full sketches for the
     // debug outputs) get the separate pass.
+    // ... and the few words the host needs (offsets check, total pairs) are published to page-locked memory
+    u32 seq = 0;
     auto finish_counts = [&](bool filter_pass) -> int {
         if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
         if (filt && filter_pass)
             skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
-        HIPCHK(hipMemsetAsync(st->d_cnt + n_reads, 0, 4, hs));
         HIPCHK(skx::prim_exclusive_scan_u32(hs, st->d_tmp, st->tmp_bytes, st->d_cnt, st->d_poff, n_reads + 1));
-        HIPCHK(hipMemcpyAsync(st->h_chk + 8, st->d_poff + n_reads, 4, hipMemcpyDeviceToHost, hs));
+        seq = ++st->pub_seq;
+        skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_poff + n_reads, st->h_chk, seq);
+        HIPCHK(hipGetLastError());
         return SKX_OK;
     };
+    // spin on the published sequence number (looking at the stream now and then so a fault cannot hang the caller)
+    auto wait_published = [&]() -> int {
+        volatile u32* pub = st->h_chk;
+        for (u64 spins = 1; pub[15] != seq; ++spins) {
+            if ((spins & 0xFFF) == 0) {
+                const hipError_t e = hipStreamQuery(hs);
+                if (e == hipSuccess) {
+                    if (pub[15] == seq) break;
+                    HIPCHK(hipStreamSynchronize(hs));
+                    if (pub[15] != seq) return fail(SKX_ERR_HIP, "publish kernel finished without raising its sequence number");
+                } else if (e != hipErrorNotReady) {
+                    return fail(SKX_ERR_HIP, "stream failed while waiting for the batch summary: %s", hipGetErrorString(e));
+                }
+            }
+        }
+        return SKX_OK;
+    };
+    if (st->chk_dirty) {  // an earlier push failed half-way
+        HIPCHK(hipMemsetAsync(st->d_chk, 0, 64, hs));
+        HIPCHK(hipMemsetAsync(st->d_retry, 0, 4, hs));
+    }
+    st->chk_dirty = true;
     bool have_long = false;
     {
         Span sp(st, 0);
-        if (!h_off) {
-            HIPCHK(hipMemsetAsync(st->d_chk, 0, 32, hs));
-            skx::launch_batch_check(hs, d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk);
-            HIPCHK(hipMemcpyAsync(st->h_chk, st->d_chk, 32, hipMemcpyDeviceToHost, hs));
-        }
+        // offsets are looked at on the device in any case (cheap); it also zeroes entry n_reads of the pair counts
+        skx::launch_batch_check(hs, d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk, st->d_cnt + n_reads);
         if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
         skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
-                                st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift);
+                                st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, inrange_only ? st->d_retry : nullptr);
         HIPCHK(hipGetLastError());
         if (h_off) {
             SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, h_off, n_reads, ref->k,
@@ -789,9 +817,12 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         }
         SKXCHK(finish_counts(have_long || !inrange_only));
     }
-    HIPCHK(hipStreamSynchronize(hs));  // the one host synchronisation of a push without long reads
+    SKXCHK(wait_published());  // the one wait of a push without long reads: 36 bytes, no copy, no stream synchronisation
+    if (h_sketches || h_sketch_len) HIPCHK(hipStreamSynchronize(hs));  // (debug outputs: their copies must have landed)
+    st->chk_dirty = false;
     if (!h_off) {
-        const u32* c = st->h_chk;
+        u32 c[8];
+        for (int i = 0; i < 8; ++i) c[i] = st->h_chk[i];
         if (c[0]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
         const u64 o_first = ((u64)c[3] << 32) | c[2], o_last = ((u64)c[5] << 32) | c[4];
         if (o_last - o_first > st->max_bases)
@@ -803,10 +834,12 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             HIPCHK(hipMemcpyAsync(st->h_offsets, d_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, hs));
             HIPCHK(hipStreamSynchronize(hs));
             Span sp(st, 0);
+            st->chk_dirty = true;
             SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, st->h_offsets, n_reads, ref->k,
                                ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
             SKXCHK(finish_counts(true));  // (the filter is idempotent on the rows that are already compacted)
-            HIPCHK(hipStreamSynchronize(hs));
+            SKXCHK(wait_published());
+            st->chk_dirty = false;
         }
     }
     const u32 total_pairs = st->h_chk[8];

@@ -99,27 +99,23 @@ __global__ __launch_bounds__(256) void band_bounds_kernel(const u64* __restrict_
 // dropped one, so the first min(s, #distinct kept) of them ARE the part of the bottom-s sketch that
 // can meet the reference (the only part scoring needs); out_len is then that count, not |sketch|.
 // HCAP < CAP (INRANGE only): small hash buffer for full occupancy; a read with more than HCAP kept hashes is
-// flagged (out_len = kSketchRetry) and redone by a second launch with HCAP = CAP and only_flagged = 1.
+// flagged (out_len = kSketchRetry, index appended to the retry list) and redone by a second launch with HCAP = CAP.
 constexpr u32 kSketchRetry = 0xFFFFFFFFu;
+// retry: [0] = number of flagged reads, [1..] = their indices (appended by the HCAP < CAP variant)
 template <int KT, int CAP, int HCAP, bool INRANGE>
-__global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
-                                                          const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
-                                                          u64 seed, u32 s, u64 max_ref, u64* __restrict__ out_sk,
-                                                          u32 sk_stride, u32* __restrict__ out_len,
-                                                          u32* __restrict__ out_cnt_in, u32 only_flagged,
-                                                          const u32* __restrict__ filt, u32 filt_shift) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, const uint8_t* __restrict__ bases,
+                                                const u64* __restrict__ offsets, u32 k_rt, u64 seed, u32 s, u64 max_ref,
+                                                u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
+                                                u32* __restrict__ out_cnt_in, u32* __restrict__ retry,
+                                                const u32* __restrict__ filt, u32 filt_shift) {
     constexpr u32 kPerWave = HCAP * 8 + CAP + 64;
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
-    const u32 r = blockIdx.x * 4u + wv;
-    if (r >= n_reads) return;
-    if (only_flagged && out_len[r] != kSketchRetry) return;
     u64* hashes = reinterpret_cast<u64*>(smem + (size_t)wv * kPerWave);
     uint8_t* codes = smem + (size_t)wv * kPerWave + HCAP * 8;
     const u32 k = KT > 0 ? (u32)KT : k_rt;
     const u64 o0 = offsets[r], o1 = offsets[r + 1];
     if (o1 - o0 > (u64)CAP + k - 1u) {  // long read (or garbage offsets): sketched by the long_read_* kernels instead
-        if (!only_flagged && lane == 0) { out_len[r] = 0; out_cnt_in[r] = 0; }
+        if (lane == 0) { out_len[r] = 0; out_cnt_in[r] = 0; }
         return;
     }
     const u32 lraw = (u32)(o1 - o0);
@@ -145,7 +141,10 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
         if (INRANGE) valid = valid && (h <= max_ref);
         const u64 mask = __ballot(valid);
         if (HCAP < CAP && m + (u32)__popcll(mask) > (u32)HCAP) {  // uniform: hand the read to the big-buffer launch
-            if (lane == 0) { out_len[r] = kSketchRetry; out_cnt_in[r] = 0; }
+            if (lane == 0) {
+                out_len[r] = kSketchRetry; out_cnt_in[r] = 0;
+                if (retry) retry[1u + atomicAdd(&retry[0], 1u)] = r;
+            }
             return false;
         }
         if (valid) hashes[m + __popcll(mask & lt)] = h;
@@ -275,6 +274,32 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
         out_cnt_in[r] = cin;
     }
 }
+// from_list = 0: wave w of the grid sketches read w.  from_list = 1 (HCAP = CAP): a small fixed grid walks the reads
+// the fast variant appended to `retry` -- usually none, and then the launch costs a few microseconds instead of one
+// nearly empty wave per read of the batch.
+template <int KT, int CAP, int HCAP, bool INRANGE>
+__global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
+                                                          const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
+                                                          u64 seed, u32 s, u64 max_ref, u64* __restrict__ out_sk,
+                                                          u32 sk_stride, u32* __restrict__ out_len,
+                                                          u32* __restrict__ out_cnt_in, u32 from_list,
+                                                          u32* __restrict__ retry, const u32* __restrict__ filt,
+                                                          u32 filt_shift) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (!from_list) {
+        if (w < n_reads)
+            sketch_one_read<KT, CAP, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
+                                                    out_cnt_in, retry, filt, filt_shift);
+        return;
+    }
+    const u32 n = retry[0];
+    for (u32 i = w; i < n; i += gridDim.x * 4u) {
+        sketch_one_read<KT, CAP, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
+                                                out_len, out_cnt_in, nullptr, filt, filt_shift);
+        wave_sync();  // the wave's LDS region is reused by its next read
+    }
+}
 
 // =====================================================================================
 // long reads (more k-mers than the one-wave sketcher holds): one block per read
@@ -386,7 +411,8 @@ __global__ __launch_bounds__(256) void long_read_finish_kernel(const u64* __rest
 // chk[0] = 0xFFFFFFFF - (first r with offsets[r+1] < offsets[r])   (0: offsets are monotonic)
 // chk[1] = number of reads with more than `lim` bases (they need the long-read kernels)
 // chk[2..3] = offsets[0], chk[4..5] = offsets[n_reads]               (chk zeroed by the caller)
-__global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads, u64 lim, u32* __restrict__ chk) {
+__global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads, u64 lim, u32* __restrict__ chk,
+                                   u32* __restrict__ cnt_tail) {
     for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
         const u64 o0 = offsets[r], o1 = offsets[r + 1];
         if (o1 < o0) atomicMax(&chk[0], 0xFFFFFFFFu - r);
@@ -395,7 +421,22 @@ __global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const u64 a = offsets[0], b = offsets[n_reads];
         chk[2] = (u32)a; chk[3] = (u32)(a >> 32); chk[4] = (u32)b; chk[5] = (u32)(b >> 32);
+        *cnt_tail = 0;  // entry n_reads of the per-read pair counts: the exclusive scan runs over n_reads + 1 entries
     }
+}
+// Hands the few words the host needs per push -- chk[0..7] and the total pair count -- to PAGE-LOCKED HOST memory and
+// raises a sequence number there; the host spins on it.  A blit copy + stream synchronisation for the same 36 bytes
+// cost ~100 us of idle front stream per push (kernel timeline), this costs a launch.  Also re-arms the device-side
+// counters (chk, the retry list) for the next push.
+__global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, const u32* __restrict__ total_pairs,
+                               volatile u32* __restrict__ h_pub, u32 seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < 8; ++i) { h_pub[i] = chk[i]; chk[i] = 0; }
+    if (retry) retry[0] = 0;
+    h_pub[8] = *total_pairs;
+    __threadfence_system();
+    h_pub[15] = seq;
+    __threadfence_system();
 }
 
 // =====================================================================================
@@ -589,8 +630,10 @@ __global__ void pair_q_kernel(const u64* __restrict__ pair_h, u32 n_pairs, const
 
 // win[2*bt] = qa, win[2*bt+1] = qb : Q[qa..qb) are the query hashes inside [lo[bt], hi[bt]]
 __global__ void window_kernel(const u64* __restrict__ lo, const u64* __restrict__ hi, u32 n_bt,
-                              const u64* __restrict__ q, const u32* __restrict__ n_q, u32* __restrict__ win) {
+                              const u64* __restrict__ q, const u32* __restrict__ n_q, u32* __restrict__ win,
+                              volatile u32* __restrict__ h_nq) {
     const u32 bt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bt == 0 && h_nq) { *h_nq = *n_q; __threadfence_system(); }  // |Q| for the host (page-locked memory), a hint only
     if (bt >= n_bt) return;
     const u32 nq = *n_q;
     u32 qa = 0, qb = 0;
@@ -1553,7 +1596,7 @@ constexpr int kSketchSmallHashes = 256;  // hash slots per read of the in-range 
 
 void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                         u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                        const u32* filt, u32 filt_shift) {
+                        const u32* filt, u32 filt_shift, u32* retry) {
     if (n_reads == 0) return;
     const size_t lds = sketch_wave_lds_bytes();
     const size_t lds_small = 4 * (size_t)(kSketchSmallHashes * 8 + kSketchCap + 64);
@@ -1568,9 +1611,12 @@ void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets
         attr_set = true;
     }
 #define SKX_SK_LAUNCH(KERNEL, LDS, FLAGGED)                                                                      \
-    hipLaunchKernelGGL((KERNEL), grid, dim3(256), LDS, st, bases, offsets, n_reads, k, seed, s, max_ref, out_sk, \
-                       sk_stride, out_len, out_cnt_in, FLAGGED, filt, filt_shift)
-    if (inrange_only) {
+    hipLaunchKernelGGL((KERNEL), (FLAGGED) ? dim3(std::min<u32>(cdiv(n_reads, 4), 256u)) : grid, dim3(256), LDS, st, bases, \
+                       offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, FLAGGED, retry, filt,    \
+                       filt_shift)
+    if (inrange_only && !retry) {  // no retry list: everything through the full-size variant
+        if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, true), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, true), lds, 0u);
+    } else if (inrange_only) {
         // fast variant first (full occupancy); reads it flags are redone with the full-size hash buffer
         if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); }
         else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); }
@@ -1625,8 +1671,8 @@ void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q,
     if (n_pairs == 0) return;
     hipLaunchKernelGGL(pair_q_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pair_h, n_pairs, q, n_q, pair_q);
 }
-void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win) {
-    hipLaunchKernelGGL(window_kernel, dim3(cdiv(n_bt, 256)), dim3(256), 0, st, lo, hi, n_bt, q, n_q, win);
+void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win, u32* h_nq) {
+    hipLaunchKernelGGL(window_kernel, dim3(cdiv(n_bt, 256)), dim3(256), 0, st, lo, hi, n_bt, q, n_q, win, h_nq);
 }
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
                        u64* m_bits, u32 n_pad) {
@@ -1671,8 +1717,12 @@ void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
                        m_bits, m_int, n_pad, n_words, mq, n_gw, n_q);
 }
-void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk) {
-    hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk);
+void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail) {
+    hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk,
+                       cnt_tail);
+}
+void launch_publish(hipStream_t st, u32* chk, u32* retry, const u32* total_pairs, u32* h_pub, u32 seq) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, st, chk, retry, total_pairs, h_pub, seq);
 }
 void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values) {
     if (n == 0) return;

@@ -22,7 +22,8 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
 size_t sketch_wave_lds_bytes();
 void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                         u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                        const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift);
+                        const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
+                        u32* retry /* [1 + n_reads], [0] zero on entry: reads the fast variant hands to the full one; or NULL */);
 
 // long reads: hash + append (phase 1), [segmented sort], distinct/truncate (phase 3)
 void launch_long_read_hash(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* long_idx, u32 n_long, u32 k,
@@ -43,7 +44,8 @@ void launch_dictionary(hipStream_t st, const u64* sk, u32 sk_stride, const u32* 
                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase,
                        u32* btot, u32* ctr, u64* q, u32* n_q);
 u32 dict_buckets();
-void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win);
+void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win,
+                   u32* h_nq /* page-locked host word that receives *n_q, or NULL */);
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
                        u64* m_bits, u32 n_pad);
 
@@ -53,7 +55,9 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
                            const u32* n_q);  // also re-zeroes m_bits / m_int; words beyond *n_q are skipped
 // chk[0..5] (zeroed by the caller): non-monotonic marker, long-read count, offsets[0], offsets[n_reads]
-void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk);
+void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail /* zeroed */);
+// h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
+void launch_publish(hipStream_t st, u32* chk, u32* retry, const u32* total_pairs, u32* h_pub, u32 seq);
 // membership filter over the union of the reference hashes (bitmap over hash >> shift)
 void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values);
 void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n_reads, const u32* bits, u32 shift);
