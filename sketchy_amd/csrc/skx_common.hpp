@@ -111,6 +111,31 @@ __host__ __device__ __forceinline__ u64 murmur3_h1_words(u64 w0, u64 w1, u64 w2,
     return h1;
 }
 
+// the same for exactly 16 key bytes (k = 16, one block, no tail); SEED0: the seed is known to be 0 (sketchy's default,
+// src/cli.rs:47-48), which folds the seed's xors and one 64-bit add away
+template <bool SEED0>
+__host__ __device__ __forceinline__ u64 murmur3_h1_16(u64 w0, u64 w1, u64 seed) {
+    const u64 c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+    u64 k1 = w0, k2 = w1;
+    k1 *= c1; k1 = rotl64c<31>(k1); k1 *= c2;
+    k2 *= c2; k2 = rotl64c<33>(k2); k2 *= c1;
+    u64 h1, h2;
+    if (SEED0) {
+        h1 = rotl64c<27>(k1);                      // (0 ^ k1) rotated, + h2 (= 0)
+        h1 = mul5(h1) + 0x52dce729ull;
+        h2 = rotl64c<31>(k2) + h1;
+    } else {
+        h1 = rotl64c<27>(seed ^ k1) + seed;
+        h1 = mul5(h1) + 0x52dce729ull;
+        h2 = rotl64c<31>(seed ^ k2) + h1;
+    }
+    h2 = mul5(h2) + 0x38495ab5ull;
+    h1 ^= 16u; h2 ^= 16u;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    return h1 + h2;
+}
+
 // ---------------------------------------------------------------- bases
 // 0..3 = A,C,G,T ; 4 = any other retained byte (N, '-', IUPAC -> N) ; 5 = removed (whitespace)
 __host__ __device__ __forceinline__ u32 classify_base(u32 c) {

@@ -185,8 +185,8 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
             const bool in = p < nk;
             push(in ? (u32)codes[p + 15u] : 4u);
             const bool use_f = fwd < rc;
-            const u64 h = murmur3_h1_words(make_u64(use_f ? f0 : r0, use_f ? f1 : r1), make_u64(use_f ? f2 : r2, use_f ? f3 : r3),
-                                           0, 0, 16u, seed);
+            const u64 w0 = make_u64(use_f ? f0 : r0, use_f ? f1 : r1), w1 = make_u64(use_f ? f2 : r2, use_f ? f3 : r3);
+            const u64 h = seed == 0 ? murmur3_h1_16<true>(w0, w1, 0) : murmur3_h1_16<false>(w0, w1, seed);
             if (!append(in && clean >= 16u, h)) return;
         }
     } else {
