@@ -132,7 +132,8 @@ class SumOfSharedHashes:
         return idx, sm
 
     def set_profiling(self, on=True):
-        _lib.check(_lib.load().skx_stream_set_profiling(self._h, 1 if on else 0))
+        """False/0: off; True/1: every stage; 2: only the reference scan (cheapest way to time the roofline kernel)."""
+        _lib.check(_lib.load().skx_stream_set_profiling(self._h, int(on)))
 
     def profile(self):
         ms = (C.c_double * _lib.N_STAGES)()

@@ -379,7 +379,7 @@ struct skx_stream {
     bool have_hint = false;  // false until one dictionary size has been seen
     LongWork lw;
     // profiling
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 every stage, 2 only the reference scan (the roofline kernel)
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> ev_pool;
     double ms[SKX_N_STAGES] = {0, 0, 0, 0, 0};
@@ -566,12 +566,13 @@ static hipEvent_t get_event(skx_stream* st) {
     return ev;
 }
 struct Span {
-    skx_stream* st; int stage; hipStream_t on; hipEvent_t a = nullptr;
+    skx_stream* st; int stage; hipStream_t on; hipEvent_t a = nullptr; bool active = false;
     Span(skx_stream* s, int stg, hipStream_t on_ = nullptr) : st(s), stage(stg), on(on_ ? on_ : s->hs0) {
-        if (st->profiling) { a = get_event(st); (void)hipEventRecord(a, on); }
+        active = st->profiling == 1 || (st->profiling == 2 && stage == 2);
+        if (active) { a = get_event(st); (void)hipEventRecord(a, on); }
     }
     ~Span() {
-        if (st->profiling) { hipEvent_t b = get_event(st); (void)hipEventRecord(b, on); st->spans.push_back({stage, a, b}); }
+        if (active) { hipEvent_t b = get_event(st); (void)hipEventRecord(b, on); st->spans.push_back({stage, a, b}); }
     }
 };
 static void collect_spans(skx_stream* st) {
@@ -584,7 +585,7 @@ static void collect_spans(skx_stream* st) {
 }
 SKX_API int skx_stream_set_profiling(skx_stream* st, int enabled) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
-    st->profiling = enabled != 0;
+    st->profiling = enabled < 0 ? 0 : enabled > 2 ? 1 : enabled;
     return SKX_OK;
 }
 SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
