@@ -212,26 +212,6 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
             if (!append(valid, h)) return;
         }
     }
-    // INRANGE: of the candidates only those some genome holds can score (membership bitmap of the reference, see
-    // "membership filter" below): drop the others here, in LDS, before they are sorted and written out
-    if (INRANGE && filt != nullptr) {
-        wave_sync();
-        u32 kept = 0;
-        for (u32 base = 0; base < m; base += 64u) {
-            const u32 i = base + lane;
-            u64 h = 0;
-            bool keep = false;
-            if (i < m) {
-                h = hashes[i];
-                const u64 idx = h >> filt_shift;
-                keep = (filt[idx >> 5] >> (u32)(idx & 31u)) & 1u;
-            }
-            const u64 b = __ballot(keep);
-            if (keep) hashes[kept + __popcll(b & lt)] = h;  // (a hash only moves towards the front)
-            kept += __popcll(b);
-        }
-        m = kept;
-    }
     // pad to a power of two (>= 64) for the bitonic network
     u32 p2 = 64;
     while (p2 < m) p2 <<= 1;
@@ -254,8 +234,11 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         }
     }
 
-    // 4. distinct, truncate to s, count the part that can meet the reference at all
-    u32 outn = 0, cin = 0;
+    // 4. distinct, truncate to s, count the part that can meet the reference at all.
+    // INRANGE with a membership bitmap (production): of the hashes that made it into the bottom-s only those some genome
+    // holds are written -- strictly AFTER the truncation: a hash ranked beyond s is not part of the sketch even if
+    // everything before it is dropped (reads with more distinct in-range hashes than s, e.g. small s).
+    u32 outn = 0, cin = 0, wrote = 0;
     u64* out = out_sk + (size_t)r * sk_stride;
     for (u32 base = 0; base < m && outn < s; base += 64u) {
         const u32 i = base + lane;
@@ -265,13 +248,24 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         const u64 mask = __ballot(head);
         const u32 pos = outn + __popcll(mask & lt);
         const bool take = head && pos < s;
-        if (take) out[pos] = h;
-        cin += __popcll(__ballot(take && h <= max_ref));
+        if (INRANGE && filt != nullptr) {
+            bool keep = false;
+            if (take) {
+                const u64 idx = h >> filt_shift;
+                keep = (filt[idx >> 5] >> (u32)(idx & 31u)) & 1u;
+            }
+            const u64 km = __ballot(keep);
+            if (keep) out[wrote + __popcll(km & lt)] = h;
+            wrote += __popcll(km);
+        } else {
+            if (take) out[pos] = h;
+            cin += __popcll(__ballot(take && h <= max_ref));
+        }
         outn += __popcll(mask);
     }
     if (lane == 0) {
         out_len[r] = min(outn, s);
-        out_cnt_in[r] = cin;
+        out_cnt_in[r] = (INRANGE && filt != nullptr) ? wrote : cin;
     }
 }
 // from_list = 0: wave w of the grid sketches read w.  from_list = 1 (HCAP = CAP): a small fixed grid walks the reads

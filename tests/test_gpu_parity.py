@@ -425,3 +425,51 @@ def test_common_hashes_extreme_query_values(gpu):
     q2 = np.tile(np.array([[0, 5, 9, top - 1, top]], np.uint64), (300, 1))
     got2 = R.common_hashes(q2)
     assert (got2 == np.array([5, 2, 1, 1], np.uint32)).all()
+
+
+def test_randomized_workloads(gpu):
+    """40 random small workloads against the oracle: reference shape, ragged and duplicated columns, reads with
+    ambiguity codes / lower case / white space / lengths around k, random `top` and batch cuts, host and device pushes."""
+    from sketchy_amd import synth
+    rng = np.random.default_rng(2024)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNRYKM-\n ", np.uint8)
+    for case in range(40):
+        n = int(rng.integers(1, 700))
+        s = int(rng.choice([1, 7, 64, 200, 513]))
+        k = int(rng.choice([16, 16, 16, 11, 21, 32]))
+        seed = int(rng.choice([0, 0, 42, 7]))
+        ref = synth.make_reference(n, s, k=k, hash_seed=seed, genome_len=max(3000, 40 * s), rng_seed=1000 + case, device="numpy")
+        hashes = ref["ref"].copy()
+        col_len = np.full(n, s, np.uint32)
+        if n > 3 and rng.random() < 0.5:
+            hashes[rng.integers(0, n)] = hashes[rng.integers(0, n)]          # exact ties
+        if rng.random() < 0.5:
+            col_len = rng.integers(0, s + 1, size=n).astype(np.uint32)        # ragged, possibly empty columns
+        n_reads = int(rng.integers(1, 200))
+        bases, offsets = synth.make_reads(ref["genome"], n_reads, int(rng.choice([30, 150, 600])), err=0.03, rng_seed=5000 + case,
+                                          lognormal_sigma=0.7, min_len=0, max_len=4000)
+        reads = [bytearray(bases[int(offsets[i]):int(offsets[i + 1])].tobytes()) for i in range(n_reads)]
+        for r in reads:                                                       # dirty some reads
+            if len(r) and rng.random() < 0.3:
+                for _ in range(int(rng.integers(1, 6))):
+                    r[int(rng.integers(0, len(r)))] = int(alphabet[rng.integers(0, len(alphabet))])
+        if rng.random() < 0.3:
+            reads[int(rng.integers(0, n_reads))] = bytearray(b"")
+        bases, offsets = pack_reads([bytes(r) for r in reads])
+        top = int(rng.integers(0, min(n, 20) + 1))
+        check(hashes, bases, offsets, top=top, k=k, seed=seed, col_len=col_len, batches=int(rng.integers(1, 4)),
+              want_shared=bool(rng.random() < 0.3), want_sketches=bool(rng.random() < 0.3))
+
+
+def test_truncation_comes_before_the_membership_filter(gpu):
+    """Regression (found by test_randomized_workloads): a read hash that some genome holds but that ranks beyond the
+    read's bottom-s must not count, even though every smaller non-member hash is dropped by the filter."""
+    ref, bases, offsets = workload(4, 8, 6, read_len=700, genome_len=30000, rng_seed=33)
+    read0 = bases[int(offsets[0]):int(offsets[1])].tobytes()
+    H = orc.sketch(read0, 16, 0, 10 ** 6)  # all distinct hashes of the read, ascending
+    assert len(H) > 40
+    top = np.uint64(0xFFFFFFFFFFFFFFF0)
+    hashes = np.array([[H[0], H[7]], [H[3], H[9]], [H[1], top], [H[2], H[30]]], np.uint64)
+    got, exp, _, _ = check(hashes, bases, offsets, top=2, want_sketches=False)   # production sketch path, s = 2
+    assert exp["shared"][0].tolist() == [1, 0, 1, 0]
+    check(hashes, bases, offsets, top=1, want_shared=False, want_sketches=False)
