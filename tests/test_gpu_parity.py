@@ -429,16 +429,18 @@ def test_common_hashes_extreme_query_values(gpu):
 
 def test_randomized_workloads(gpu):
     """40 random small workloads against the oracle: reference shape, ragged and duplicated columns, reads with
-    ambiguity codes / lower case / white space / lengths around k, random `top` and batch cuts, host and device pushes."""
+    ambiguity codes / lower case / white space / lengths around k, random `top` and batch cuts.
+    SKX_TEST_SEED selects another stream of cases (sweeps beyond the committed one)."""
+    import os
     from sketchy_amd import synth
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(int(os.environ.get("SKX_TEST_SEED", "2024")))
     alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNRYKM-\n ", np.uint8)
     for case in range(40):
         n = int(rng.integers(1, 700))
         s = int(rng.choice([1, 7, 64, 200, 513]))
         k = int(rng.choice([16, 16, 16, 11, 21, 32]))
         seed = int(rng.choice([0, 0, 42, 7]))
-        ref = synth.make_reference(n, s, k=k, hash_seed=seed, genome_len=max(3000, 40 * s), rng_seed=1000 + case, device="numpy")
+        ref = synth.make_reference(n, s, k=k, hash_seed=seed, genome_len=max(3000, 40 * s), rng_seed=int(rng.integers(1, 10 ** 6)), device="numpy")
         hashes = ref["ref"].copy()
         col_len = np.full(n, s, np.uint32)
         if n > 3 and rng.random() < 0.5:
@@ -446,7 +448,7 @@ def test_randomized_workloads(gpu):
         if rng.random() < 0.5:
             col_len = rng.integers(0, s + 1, size=n).astype(np.uint32)        # ragged, possibly empty columns
         n_reads = int(rng.integers(1, 200))
-        bases, offsets = synth.make_reads(ref["genome"], n_reads, int(rng.choice([30, 150, 600])), err=0.03, rng_seed=5000 + case,
+        bases, offsets = synth.make_reads(ref["genome"], n_reads, int(rng.choice([30, 150, 600])), err=0.03, rng_seed=int(rng.integers(1, 10 ** 6)),
                                           lognormal_sigma=0.7, min_len=0, max_len=4000)
         reads = [bytearray(bases[int(offsets[i]):int(offsets[i + 1])].tobytes()) for i in range(n_reads)]
         for r in reads:                                                       # dirty some reads
@@ -473,3 +475,35 @@ def test_truncation_comes_before_the_membership_filter(gpu):
     got, exp, _, _ = check(hashes, bases, offsets, top=2, want_sketches=False)   # production sketch path, s = 2
     assert exp["shared"][0].tolist() == [1, 0, 1, 0]
     check(hashes, bases, offsets, top=1, want_shared=False, want_sketches=False)
+
+
+def test_randomized_families_leader_switching(gpu):
+    """Larger random cases for the pruned ranking: 2-4 clone families (different ancestors) shuffled over tiles and rank
+    groups, reads arriving in family blocks of random length (the leader changes inside segments, across segments and
+    across 1024-read chunks), top in {1, 2, 5}, random batch cuts.  SKX_TEST_SEED selects another stream of cases."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SKX_TEST_SEED", "77")))
+    for case in range(3):
+        n_fam = int(rng.integers(2, 5))
+        s = int(rng.choice([64, 200]))
+        fams = [workload(int(rng.integers(150, 700)), s, 900, read_len=int(rng.choice([300, 800])), rng_seed=int(rng.integers(1, 10 ** 6)))
+                for _ in range(n_fam)]
+        hashes = np.concatenate([f[0]["ref"] for f in fams])
+        n = len(hashes)
+        for _ in range(3):  # exact ties, possibly across families' positions
+            hashes[rng.integers(0, n)] = hashes[rng.integers(0, n)]
+        hashes = np.ascontiguousarray(hashes[rng.permutation(n)])
+        pools = [[f[1][int(f[2][i]):int(f[2][i + 1])].tobytes() for i in range(900)] for f in fams]
+        used = [0] * n_fam
+        reads = []
+        while len(reads) < 2300:
+            f = int(rng.integers(0, n_fam))
+            blk = int(rng.choice([1, 3, 20, 64, 150, 700]))
+            take = pools[f][used[f]:used[f] + blk]
+            used[f] += len(take)
+            reads += take
+            if all(u >= 900 for u in used):
+                break
+        bases, offsets = pack_reads(reads)
+        for top in (1, int(rng.choice([2, 5]))):
+            check(hashes, bases, offsets, top=top, batches=int(rng.integers(1, 4)), want_shared=False, want_sketches=False)
