@@ -699,7 +699,11 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
                                st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
-        if (st->top_k == 1 && d_topk_idx && d_topk_sum) {
+        // the top-1 kernel keeps (value relative to the leader) in 23 bits of a 32-bit key: at most 2 x 64 x s + 1 per
+        // segment, so sketch sizes from 2^15 on take the 64-bit-key kernel (with k = 1) instead
+        static const bool top1_wide_env = getenv("SKX_TOP1_WIDE") != nullptr;  // test knob: force the 64-bit-key kernel
+        const bool top1_fast = st->top_k == 1 && ref->s < (1u << 15) && !top1_wide_env;
+        if (top1_fast && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
                                       ref->n_genomes, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_inc,
                                       st->d_leader, st->d_gmax, st->d_lead_val);
