@@ -459,8 +459,15 @@ def test_randomized_workloads(gpu):
             reads[int(rng.integers(0, n_reads))] = bytearray(b"")
         bases, offsets = pack_reads([bytes(r) for r in reads])
         top = int(rng.integers(0, min(n, 20) + 1))
-        check(hashes, bases, offsets, top=top, k=k, seed=seed, col_len=col_len, batches=int(rng.integers(1, 4)),
-              want_shared=bool(rng.random() < 0.3), want_sketches=bool(rng.random() < 0.3))
+        got, exp, R, S = check(hashes, bases, offsets, top=top, k=k, seed=seed, col_len=col_len, batches=int(rng.integers(1, 4)),
+                               want_shared=bool(rng.random() < 0.3), want_sketches=bool(rng.random() < 0.3))
+        if top:  # the same batch through the device-resident entry point (offsets checked on the device)
+            from sketchy_amd import api
+            Sd = api.SumOfSharedHashes(R, top=top, max_batch_reads=n_reads, max_batch_bases=max(1, len(bases)))
+            gd = _push_device(Sd, bases, offsets, top)
+            np.testing.assert_array_equal(gd["topk_idx"], exp["topk_idx"], err_msg=f"case {case} device push idx")
+            np.testing.assert_array_equal(gd["topk_sum"], exp["topk_sum"], err_msg=f"case {case} device push sum")
+            np.testing.assert_array_equal(Sd.table(), exp["cum"], err_msg=f"case {case} device push table")
 
 
 def test_truncation_comes_before_the_membership_filter(gpu):
