@@ -142,6 +142,8 @@ int skx_common_hashes(const skx_ref *ref, const uint64_t *query, const uint32_t 
 #define SKX_COMM_ID_BYTES 128
 int skx_comm_unique_id(uint8_t id[SKX_COMM_ID_BYTES]);                 /* rank 0; broadcast it out of band */
 int skx_comm_create(skx_comm **out, int device, int rank, int n_ranks, const uint8_t id[SKX_COMM_ID_BYTES]);
+/* ranks of the communicator as RCCL reports them (ncclCommCount) */
+int skx_comm_n_ranks(const skx_comm *comm, int *n_ranks);
 /* in-place sum of the running tables of all ranks' streams (u64, exact) */
 int skx_stream_allreduce(skx_stream *st, skx_comm *comm);
 void skx_comm_destroy(skx_comm *comm);

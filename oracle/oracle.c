@@ -345,3 +345,35 @@ ORC_EXPORT int orc_stream(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_geno
     free(sk); free(idx); free(tmp);
     return 0;
 }
+
+/*
+ * The same driver with the N intersections of a read (src/sketchy.rs:337-347) spread over host threads (OpenMP over
+ * genomes).  The reference itself is single-threaded on this path; this is the generous "all host cores" upper bound
+ * of SURVEY.md 8(d)(ii) for bench.py's cpu_baseline_all_cores leg.  Same results (integer sums per genome).
+ */
+ORC_EXPORT int orc_stream_mt(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
+                             const uint64_t *ref_hashes, const uint32_t *col_len,
+                             const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                             uint32_t top_k, uint64_t *cum, uint32_t *topk_idx, uint64_t *topk_sum, int n_threads) {
+    if (top_k > n_genomes) return -1;
+    if (n_threads < 1) n_threads = 1;
+    uint64_t *sk = (uint64_t *)malloc(((uint64_t)s + 1) * sizeof(uint64_t));
+    uint32_t *idx = (uint32_t *)malloc(((uint64_t)n_genomes + 1) * sizeof(uint32_t));
+    uint32_t *tmp = (uint32_t *)malloc(((uint64_t)n_genomes + 1) * sizeof(uint32_t));
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        uint64_t len = orc_sketch_heap(bases + offsets[r], offsets[r + 1] - offsets[r], k, seed, s, sk);
+        int64_t g;
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+        for (g = 0; g < (int64_t)n_genomes; ++g)
+            cum[g] += orc_common_hashes(ref_hashes + (uint64_t)g * s, col_len[g], sk, len);
+        if (top_k > 0) {
+            stable_rank(cum, n_genomes, idx, tmp);
+            for (uint32_t t = 0; t < top_k; ++t) {
+                if (topk_idx) topk_idx[(uint64_t)r * top_k + t] = idx[t];
+                if (topk_sum) topk_sum[(uint64_t)r * top_k + t] = cum[idx[t]];
+            }
+        }
+    }
+    free(sk); free(idx); free(tmp);
+    return 0;
+}

@@ -56,6 +56,10 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_stream.restype = C.c_int
+        L.orc_stream_mt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_stream_mt.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -132,6 +136,27 @@ def stream(k, seed, s, ref_hashes, col_len, bases, offsets, top_k=1, cum=None,
     if rc != 0:
         raise ValueError("orc_stream failed (top_k > n_genomes?)")
     return dict(cum=cum, topk_idx=tk_i, topk_sum=tk_s, shared=shared, sketches=sk, sketch_len=sl)
+
+
+def stream_mt(k, seed, s, ref_hashes, col_len, bases, offsets, top_k=1, cum=None, n_threads=0):
+    """orc_stream with the per-read intersections spread over host threads (OpenMP over genomes): the
+    all-host-cores upper bound of the CPU baseline.  n_threads 0 = os.cpu_count()."""
+    ref_hashes = np.ascontiguousarray(ref_hashes, np.uint64)
+    n_genomes = ref_hashes.shape[0]
+    assert ref_hashes.shape[1] == s
+    col_len = np.ascontiguousarray(col_len, np.uint32)
+    bases = np.ascontiguousarray(bases, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    n_reads = len(offsets) - 1
+    cum = np.zeros(n_genomes, np.uint64) if cum is None else np.ascontiguousarray(cum, np.uint64).copy()
+    tk_i = np.zeros((n_reads, top_k), np.uint32)
+    tk_s = np.zeros((n_reads, top_k), np.uint64)
+    bases_p = bases if len(bases) else np.zeros(1, np.uint8)
+    rc = lib().orc_stream_mt(k, seed, s, n_genomes, _ptr(ref_hashes), _ptr(col_len), _ptr(bases_p), _ptr(offsets),
+                             n_reads, top_k, _ptr(cum), _ptr(tk_i), _ptr(tk_s), n_threads or (os.cpu_count() or 1))
+    if rc != 0:
+        raise ValueError("orc_stream_mt failed (top_k > n_genomes?)")
+    return dict(cum=cum, topk_idx=tk_i, topk_sum=tk_s)
 
 
 # ----------------------------------------------------------------------------- pure Python

@@ -45,6 +45,7 @@ SYMBOLS = [
     ("skx_common_hashes", _i, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("skx_comm_unique_id", _i, [_vp]),
     ("skx_comm_create", _i, [_pp, _i, _i, _i, _vp]),
+    ("skx_comm_n_ranks", _i, [_vp, C.POINTER(_i)]),
     ("skx_stream_allreduce", _i, [_vp, _vp]),
     ("skx_comm_destroy", None, [_vp]),
     ("skx_dev_malloc", _i, [_i, _pp, _sz]),

@@ -29,19 +29,33 @@ def device_info(device=0):
 
 
 class ReferenceSketch:
-    """Reference sketch collection resident in HBM.  hashes: [n_genomes, s] uint64, row g =
-    genome g's ascending distinct hashes, first col_len[g] valid."""
+    """Reference sketch collection(s) resident in HBM.  hashes: [n_genomes, s] uint64, row g = genome g's ascending
+    distinct hashes, first col_len[g] valid -- or a LIST of such matrices, one per species (same s, k, seed): they are
+    scanned together in one pass per batch, every species keeps its own table and ranking (one `sketchy predict` run
+    per species over the same reads, src/sketchy.rs:81-82)."""
 
     def __init__(self, hashes, col_len=None, k=16, seed=0, device=0):
         L = _lib.load()
-        hashes = np.ascontiguousarray(hashes, np.uint64)
-        if hashes.ndim != 2:
-            raise ValueError("hashes must be [n_genomes, s]")
-        self.n_genomes, self.s = int(hashes.shape[0]), int(hashes.shape[1])
-        col_len = np.full(self.n_genomes, self.s, np.uint32) if col_len is None else np.ascontiguousarray(col_len, np.uint32)
+        many = isinstance(hashes, (list, tuple))
+        mats = [np.ascontiguousarray(h, np.uint64) for h in (hashes if many else [hashes])]
+        if any(m.ndim != 2 for m in mats) or len({m.shape[1] for m in mats}) != 1:
+            raise ValueError("hashes must be [n_genomes, s] (one matrix per species, all with the same s)")
+        lens = col_len if many else [col_len]
+        lens = [None] * len(mats) if lens is None else list(lens)
+        lens = [np.full(m.shape[0], m.shape[1], np.uint32) if c is None else np.ascontiguousarray(c, np.uint32)
+                for m, c in zip(mats, lens)]
+        self.species = [int(m.shape[0]) for m in mats]
+        self.n_species = len(mats)
+        self.n_genomes, self.s = sum(self.species), int(mats[0].shape[1])
         self.k, self.seed, self.device = int(k), int(seed), int(device)
         h = C.c_void_p()
-        _lib.check(L.skx_ref_create(C.byref(h), device, self.k, self.seed, self.s, self.n_genomes, _p(hashes), _p(col_len)))
+        if self.n_species == 1:
+            _lib.check(L.skx_ref_create(C.byref(h), device, self.k, self.seed, self.s, self.n_genomes, _p(mats[0]), _p(lens[0])))
+        else:
+            ng = (C.c_uint32 * self.n_species)(*self.species)
+            hp = (C.c_void_p * self.n_species)(*[m.ctypes.data for m in mats])
+            cp = (C.c_void_p * self.n_species)(*[c.ctypes.data for c in lens])
+            _lib.check(L.skx_ref_create_multi(C.byref(h), device, self.k, self.seed, self.s, self.n_species, ng, hp, cp))
         self._h = h
 
     @property
@@ -170,6 +184,12 @@ class Comm:
         h = C.c_void_p()
         _lib.check(_lib.load().skx_comm_create(C.byref(h), device, rank, n_ranks, buf))
         self._h = h
+
+    @property
+    def n_ranks(self) -> int:
+        n = C.c_int(0)
+        _lib.check(_lib.load().skx_comm_n_ranks(self._h, C.byref(n)))
+        return n.value
 
     def close(self):
         if getattr(self, "_h", None):

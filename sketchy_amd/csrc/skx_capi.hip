@@ -303,9 +303,8 @@ static int sketch_long(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_read
 static int sketch_all(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
                       const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
                       bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
-    skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len, d_cnt,
-                            nullptr, 0, nullptr);
-    HIPCHK(hipGetLastError());
+    HIPCHK(skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len,
+                                   d_cnt, nullptr, 0, nullptr, h_offsets[n_reads] - h_offsets[0], nullptr));
     return sketch_long(hs, lw, cap_bases, cap_reads, d_bases, d_offsets, h_offsets, n_reads, k, seed, s, max_ref,
                        inrange_only, d_sk, sk_stride, d_len, d_cnt);
 }
@@ -359,6 +358,9 @@ struct skx_stream {
     u64* d_topk_sum = nullptr;
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0;
+    u64* d_tab_tmp = nullptr;   // [n_pad] staging of skx_stream_table_add
+    u32* d_rank_idx = nullptr;  // [SKX_MAX_TOP] / [SKX_MAX_TOP] outputs of skx_stream_rank
+    u64* d_rank_sum = nullptr;
     u32* h_poff = nullptr;   // pinned
     u64* h_offsets = nullptr;  // pinned
     // |Q| / pairs of the most recent pass whose dictionary has finished: the host only knows the pair count of a
@@ -396,7 +398,7 @@ static void stream_free(skx_stream* st) {
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
                     st->d_csum, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
-                    st->d_topk_sum, st->d_tmp};
+                    st->d_topk_sum, st->d_tmp, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum};
     for (void* p : ptrs) (void)hipFree(p);
     long_free(st->lw);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
@@ -435,6 +437,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     const u64 pass_mb = pass_mb_env ? pass_mb_env : std::min<u64>(8192, std::max<u64>(256, (u64)(mem_free >> 20) / 32));
     u64 pc = (pass_mb << 20) * 8 / n_pad;
     pc = std::min<u64>(pc, max_reads > 65536 ? (1u << 22) : (1u << 20));
+    pc = std::min<u64>(pc, (u64)max_reads * sk_stride);  // a read contributes at most sk_stride pairs
     pc = std::max<u64>(pc, sk_stride);
     pc = (pc + 63) / 64 * 64;
     st->pcap = (u32)pc;
@@ -488,9 +491,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipMalloc(&st->d_win[i], (size_t)n_bt * 8));
     }
     SCHK(hipMalloc(&st->d_m, (size_t)(st->pcap / 64) * n_pad * 8));
-    SCHK(hipMalloc(&st->d_mint, (size_t)(st->pcap / 64) * n_pad * 8));
     SCHK(hipMemset(st->d_m, 0, (size_t)(st->pcap / 64) * n_pad * 8));      // kept all-zero between passes
-    SCHK(hipMemset(st->d_mint, 0, (size_t)(st->pcap / 64) * n_pad * 8));   // (the transpose re-zeroes what it reads)
+    // (d_mint, the second word array of the split scan variant, is allocated by the first pass that wants it)
     for (int i = 0; i < 2; ++i)
         SCHK(hipMalloc(&st->d_mq[i], (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
@@ -514,6 +516,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     st->tmp_bytes = std::max({skx::prim_scan_tmp_bytes(max_reads + 1), skx::prim_sort_tmp_bytes(st->pcap),
                               skx::prim_unique_tmp_bytes(st->pcap)}) + 256;
     SCHK(hipMalloc(&st->d_tmp, st->tmp_bytes));
+    SCHK(hipMalloc(&st->d_tab_tmp, (size_t)n_pad * 8));
+    SCHK(hipMalloc(&st->d_rank_idx, (size_t)ref->n_genomes * 4));  // skx_stream_rank takes any top_k up to n_genomes
+    SCHK(hipMalloc(&st->d_rank_sum, (size_t)ref->n_genomes * 8));
     SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
     st->ht_slots = 1024;
@@ -665,7 +670,17 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         const u32 n_words = (P + 63) / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
         static const int split_env = getenv("SKX_SCAN_SPLIT") ? atoi(getenv("SKX_SCAN_SPLIT")) : -1;
-        const bool split = split_env >= 0 ? split_env != 0 : (nq_est * ref->rb / ref->s >= 192);
+        bool split = split_env >= 0 ? split_env != 0 : (nq_est * ref->rb / ref->s >= 192);
+        if (split && !st->d_mint) {  // dense dictionaries only: most streams never get here
+            const size_t bytes = (size_t)(st->pcap / 64) * n_pad * 8;
+            if (hipMalloc(&st->d_mint, bytes) == hipSuccess) {
+                HIPCHK(hipMemsetAsync(st->d_mint, 0, bytes, hs));  // (the transpose re-zeroes what it reads)
+            } else {
+                (void)hipGetLastError();
+                st->d_mint = nullptr;
+                split = false;  // no room: the plain variant gives the same bits
+            }
+        }
         static const int big_env = getenv("SKX_SCAN_BIG") ? atoi(getenv("SKX_SCAN_BIG")) : -1;
         const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
         {
@@ -751,7 +766,7 @@ static int for_each_pass(skx_stream* st, u32 n_reads, u32 max_pass_reads, F fn) 
 // kernel looks at them on the device and the host reads back 24 bytes instead of every offset.
 // h_shared / h_sketches / h_sketch_len: optional HOST outputs (parity/debug).
 static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, const u64* h_off, u32 n_reads,
-                         u32* d_topk_idx, u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
+                         u64 n_bases, u32* d_topk_idx, u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
     const skx_ref* ref = st->ref;
     hipStream_t hs = st->hs0;  // sketching and everything the host reads back run on the first pipeline stream
     if (n_reads == 0) return SKX_OK;
@@ -803,9 +818,9 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         // offsets are looked at on the device in any case (cheap); it also zeroes entry n_reads of the pair counts
         skx::launch_batch_check(hs, d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk, st->d_cnt + n_reads);
         if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
-        skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
-                                st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, inrange_only ? st->d_retry : nullptr);
-        HIPCHK(hipGetLastError());
+        HIPCHK(skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
+                                       st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift,
+                                       inrange_only ? st->d_retry : nullptr, n_bases, st->d_chk));
         if (h_off) {
             SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, h_off, n_reads, ref->k,
                                ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt,
@@ -829,6 +844,8 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         u32 c[8];
         for (int i = 0; i < 8; ++i) c[i] = st->h_chk[i];
         if (c[0]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
+        if (c[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases=%llu bytes given from offsets[0] on",
+                              (unsigned long long)n_bases);
         const u64 o_first = ((u64)c[3] << 32) | c[2], o_last = ((u64)c[5] << 32) | c[4];
         if (o_last - o_first > st->max_bases)
             return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu", (unsigned long long)(o_last - o_first),
@@ -898,7 +915,7 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     for (u32 r = 0; r <= n_reads; ++r) st->h_offsets[r] = offsets[r] - base0;
     HIPCHK(hipMemcpyAsync(st->d_offsets, st->h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, hs));
     if (n_bases) HIPCHK(hipMemcpyAsync(st->d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, hs));
-    SKXCHK(process_batch(st, st->d_bases, st->d_offsets, st->h_offsets, n_reads, st->d_topk_idx, st->d_topk_sum,
+    SKXCHK(process_batch(st, st->d_bases, st->d_offsets, st->h_offsets, n_reads, n_bases, st->d_topk_idx, st->d_topk_sum,
                          per_read_shared, reinterpret_cast<u64*>(sketches), sketch_len));
     HIPCHK(hipStreamSynchronize(hs));  // sketch copies (first stream)
     if (topk_idx) HIPCHK(hipMemcpyAsync(topk_idx, st->d_topk_idx, (size_t)n_reads * st->top_k * 4, hipMemcpyDeviceToHost, st->hs2));
@@ -918,7 +935,10 @@ SKX_API int skx_stream_push_device(skx_stream* st, const uint8_t* d_bases, const
     SKXCHK(use_device(st->device));
     u32* ti = d_topk_idx ? d_topk_idx : st->d_topk_idx;
     u64* ts = d_topk_sum ? reinterpret_cast<u64*>(d_topk_sum) : st->d_topk_sum;
-    return process_batch(st, d_bases, reinterpret_cast<const u64*>(d_offsets), nullptr, n_reads, ti, ts, nullptr, nullptr, nullptr);
+    if (n_bases > st->max_bases) return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu",
+                                             (unsigned long long)n_bases, (unsigned long long)st->max_bases);
+    return process_batch(st, d_bases, reinterpret_cast<const u64*>(d_offsets), nullptr, n_reads, n_bases, ti, ts, nullptr, nullptr,
+                         nullptr);
 }
 
 SKX_API int skx_stream_sync(skx_stream* st) {
@@ -942,13 +962,11 @@ SKX_API int skx_stream_table(skx_stream* st, uint64_t* cum) {
 SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
     if (!st || !add) return fail(SKX_ERR_INVALID, "NULL argument");
     SKXCHK(use_device(st->device));
-    u64* d_add = nullptr;
     const u32 n = st->ref->n_genomes;
-    HIPCHK(hipMalloc(&d_add, (size_t)n * 8));
-    hipError_t e = hipMemcpyAsync(d_add, add, (size_t)n * 8, hipMemcpyHostToDevice, st->hs2);
-    if (e == hipSuccess) { skx::launch_add_table(st->hs2, st->d_cum, d_add, n); e = hipStreamSynchronize(st->hs2); }
-    (void)hipFree(d_add);
-    if (e != hipSuccess) return fail(SKX_ERR_HIP, "table_add failed: %s", hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(st->d_tab_tmp, add, (size_t)n * 8, hipMemcpyHostToDevice, st->hs2));
+    skx::launch_add_table(st->hs2, st->d_cum, st->d_tab_tmp, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st->hs2));  // `add` is only borrowed for the call
     return SKX_OK;
 }
 SKX_API int skx_stream_reset(skx_stream* st) {
@@ -970,17 +988,11 @@ SKX_API int skx_stream_rank(skx_stream* st, uint32_t top_k, uint32_t* idx, uint6
     if (!st || !idx || !sum) return fail(SKX_ERR_INVALID, "NULL argument");
     if (top_k < 1 || top_k > st->ref->n_genomes) return fail(SKX_ERR_INVALID, "top_k=%u outside 1..n_genomes", top_k);
     SKXCHK(use_device(st->device));
-    u32* d_i = nullptr; u64* d_s = nullptr;
-    HIPCHK(hipMalloc(&d_i, (size_t)top_k * 4));
-    hipError_t e = hipMalloc(&d_s, (size_t)top_k * 8);
-    if (e == hipSuccess) {
-        skx::launch_rank_table(st->hs2, st->d_cum, st->ref->n_genomes, top_k, d_i, d_s);
-        e = hipMemcpyAsync(idx, d_i, (size_t)top_k * 4, hipMemcpyDeviceToHost, st->hs2);
-        if (e == hipSuccess) e = hipMemcpyAsync(sum, d_s, (size_t)top_k * 8, hipMemcpyDeviceToHost, st->hs2);
-        if (e == hipSuccess) e = hipStreamSynchronize(st->hs2);
-    }
-    (void)hipFree(d_i); (void)hipFree(d_s);
-    if (e != hipSuccess) return fail(SKX_ERR_HIP, "rank failed: %s", hipGetErrorString(e));
+    skx::launch_rank_table(st->hs2, st->d_cum, st->ref->n_genomes, top_k, st->d_rank_idx, st->d_rank_sum);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(idx, st->d_rank_idx, (size_t)top_k * 4, hipMemcpyDeviceToHost, st->hs2));
+    HIPCHK(hipMemcpyAsync(sum, st->d_rank_sum, (size_t)top_k * 8, hipMemcpyDeviceToHost, st->hs2));
+    HIPCHK(hipStreamSynchronize(st->hs2));
     return SKX_OK;
 }
 
@@ -1081,6 +1093,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -1096,6 +1109,7 @@ static int rccl_load() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
         return fail(SKX_ERR_COMM, "librccl lacks the expected symbols");
     g_rccl.h = h;
@@ -1125,6 +1139,17 @@ SKX_API int skx_comm_create(skx_comm** out, int device, int rank, int n_ranks, c
     ncclResult_t r = g_rccl.CommInitRank(&c, n_ranks, u, rank);
     if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     *out = new skx_comm{device, rank, n_ranks, c};
+    return SKX_OK;
+}
+SKX_API int skx_comm_n_ranks(const skx_comm* comm, int* n_ranks) {
+    if (!comm || !n_ranks) return fail(SKX_ERR_INVALID, "NULL argument");
+    *n_ranks = comm->n_ranks;
+    if (g_rccl.CommCount) {
+        int n = 0;
+        ncclResult_t r = g_rccl.CommCount(comm->comm, &n);
+        if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclCommCount: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        *n_ranks = n;
+    }
     return SKX_OK;
 }
 SKX_API int skx_stream_allreduce(skx_stream* st, skx_comm* comm) {

@@ -18,6 +18,7 @@
 // Integer work throughout (u64 hash compares, bit counts): no MFMA.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "skx_common.hpp"
 #include "skx_kernels.hpp"
@@ -107,15 +108,23 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                                                 const u64* __restrict__ offsets, u32 k_rt, u64 seed, u32 s, u64 max_ref,
                                                 u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                 u32* __restrict__ out_cnt_in, u32* __restrict__ retry,
-                                                const u32* __restrict__ filt, u32 filt_shift) {
+                                                const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
+                                                u32* __restrict__ chk) {
     constexpr u32 kPerWave = HCAP * 8 + CAP + 64;
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     u64* hashes = reinterpret_cast<u64*>(smem + (size_t)wv * kPerWave);
     uint8_t* codes = smem + (size_t)wv * kPerWave + HCAP * 8;
     const u32 k = KT > 0 ? (u32)KT : k_rt;
     const u64 o0 = offsets[r], o1 = offsets[r + 1];
-    if (o1 - o0 > (u64)CAP + k - 1u) {  // long read (or garbage offsets): sketched by the long_read_* kernels instead
-        if (lane == 0) { out_len[r] = 0; out_cnt_in[r] = 0; }
+    // the caller vouches for n_bases bytes from offsets[0] on: a read reaching outside is never touched (flagged in
+    // chk[6]; the push then fails with SKX_ERR_INVALID instead of faulting)
+    const u64 lo = offsets[0];
+    const bool outside = o0 < lo || o1 < o0 || o1 - lo > n_bases;
+    if (outside || o1 - o0 > (u64)CAP + k - 1u) {  // (long reads are sketched by the long_read_* kernels instead)
+        if (lane == 0) {
+            out_len[r] = 0; out_cnt_in[r] = 0;
+            if (outside && chk) atomicOr(&chk[6], 1u);
+        }
         return;
     }
     const u32 lraw = (u32)(o1 - o0);
@@ -278,19 +287,19 @@ __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restr
                                                           u32 sk_stride, u32* __restrict__ out_len,
                                                           u32* __restrict__ out_cnt_in, u32 from_list,
                                                           u32* __restrict__ retry, const u32* __restrict__ filt,
-                                                          u32 filt_shift) {
+                                                          u32 filt_shift, u64 n_bases, u32* __restrict__ chk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 w = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (!from_list) {
         if (w < n_reads)
             sketch_one_read<KT, CAP, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
-                                                    out_cnt_in, retry, filt, filt_shift);
+                                                    out_cnt_in, retry, filt, filt_shift, n_bases, chk);
         return;
     }
     const u32 n = retry[0];
     for (u32 i = w; i < n; i += gridDim.x * 4u) {
         sketch_one_read<KT, CAP, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
-                                                out_len, out_cnt_in, nullptr, filt, filt_shift);
+                                                out_len, out_cnt_in, nullptr, filt, filt_shift, n_bases, chk);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
 }
@@ -1588,26 +1597,38 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
 size_t sketch_wave_lds_bytes() { return 4 * (size_t)(kSketchCap * 8 + kSketchCap + 64); }
 constexpr int kSketchSmallHashes = 256;  // hash slots per read of the in-range fast variant
 
-void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
-                        u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                        const u32* filt, u32 filt_shift, u32* retry) {
-    if (n_reads == 0) return;
+hipError_t launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
+                              u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
+                              const u32* filt, u32 filt_shift, u32* retry, u64 n_bases, u32* chk) {
+    if (n_reads == 0) return hipSuccess;
     const size_t lds = sketch_wave_lds_bytes();
     const size_t lds_small = 4 * (size_t)(kSketchSmallHashes * 8 + kSketchCap + 64);
     dim3 grid(cdiv(n_reads, 4));
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
 #define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, kSketchCap, IR>
 #define SKX_SK_SMALL(KT) sketch_wave_kernel<KT, kSketchCap, kSketchSmallHashes, true>
-    if (!attr_set) {
-        const void* fns[] = {(const void*)&SKX_SK(16, false), (const void*)&SKX_SK(16, true),
-                             (const void*)&SKX_SK(0, false), (const void*)&SKX_SK(0, true)};
-        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU).  The attribute belongs to the (function,
+    // device) pair and handles on different devices may be driven from different threads: one latch per device.
+    {
+        static std::mutex mu;
+        static unsigned long long done[4] = {0, 0, 0, 0};  // devices 0..255
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= 256 || !((done[dev >> 6] >> (dev & 63)) & 1ull)) {
+            const void* fns[] = {(const void*)&SKX_SK(16, false), (const void*)&SKX_SK(16, true),
+                                 (const void*)&SKX_SK(0, false), (const void*)&SKX_SK(0, true)};
+            for (const void* f : fns) {
+                e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            if (dev >= 0 && dev < 256) done[dev >> 6] |= 1ull << (dev & 63);
+        }
     }
 #define SKX_SK_LAUNCH(KERNEL, LDS, FLAGGED)                                                                      \
     hipLaunchKernelGGL((KERNEL), (FLAGGED) ? dim3(std::min<u32>(cdiv(n_reads, 4), 256u)) : grid, dim3(256), LDS, st, bases, \
                        offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, FLAGGED, retry, filt,    \
-                       filt_shift)
+                       filt_shift, n_bases, chk)
     if (inrange_only && !retry) {  // no retry list: everything through the full-size variant
         if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, true), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, true), lds, 0u);
     } else if (inrange_only) {
@@ -1620,6 +1641,7 @@ void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets
 #undef SKX_SK_LAUNCH
 #undef SKX_SK_SMALL
 #undef SKX_SK
+    return hipGetLastError();
 }
 
 void launch_long_read_hash(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* long_idx, u32 n_long, u32 k,

@@ -20,10 +20,13 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
 
 // sketching
 size_t sketch_wave_lds_bytes();
-void launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
-                        u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                        const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
-                        u32* retry /* [1 + n_reads], [0] zero on entry: reads the fast variant hands to the full one; or NULL */);
+// n_bases: bytes the caller vouches for from offsets[0] on; a read reaching outside is skipped and flagged in chk[6]
+// (chk may be NULL).  Returns the launch status (it also opts the big-LDS variants in, once per device).
+hipError_t launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
+                              u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
+                              const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
+                              u32* retry /* [1 + n_reads], [0] zero on entry: reads the fast variant hands to the full one; or NULL */,
+                              u64 n_bases, u32* chk);
 
 // long reads: hash + append (phase 1), [segmented sort], distinct/truncate (phase 3)
 void launch_long_read_hash(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* long_idx, u32 n_long, u32 k,

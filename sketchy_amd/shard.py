@@ -113,10 +113,12 @@ class TableReducer:
         from . import api
         self.how = "single"
         self.comm = None
+        self.n_ranks = 1  # ranks the table is summed over (RCCL: ncclCommCount of the communicator)
         if not (dist.is_initialized() and dist.get_world_size() > 1):
             return
         rank, world = dist.get_rank(), dist.get_world_size()
         self.how = "gloo-host"
+        self.n_ranks = world
         # every rank first proves it can load RCCL (making an id does; only rank 0's is used): a rank that cannot
         # would otherwise leave the others blocked inside ncclCommInitRank
         uid = b"\0" * 128
@@ -134,6 +136,7 @@ class TableReducer:
             try:
                 self.comm = api.Comm(device, rank, world, uid)
                 self.how = "rccl"
+                self.n_ranks = self.comm.n_ranks
             except Exception as e:  # noqa: BLE001  (RCCL unavailable: stay on the host path)
                 self.err = repr(e)
                 self.comm = None
@@ -142,7 +145,12 @@ class TableReducer:
         if ok != world:
             if self.comm is not None:
                 self.comm.close()
-            self.comm, self.how = None, "gloo-host"
+            self.comm, self.how, self.n_ranks = None, "gloo-host", world
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     def allreduce(self, stream):
         if self.how == "single":

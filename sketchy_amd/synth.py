@@ -216,3 +216,52 @@ def make_reads(genome: np.ndarray, n_reads: int, read_len=1500, err: float = 0.0
         bases = bases.copy()
         bases[hit] = alphabet[(code + rng.integers(1, 4, size=nh)) % 4]
     return np.ascontiguousarray(bases, np.uint8), offsets
+
+
+def make_reads_torch(genome, n_reads: int, read_len=1500, err: float = 0.05, rng_seed: int = 2,
+                     lognormal_sigma: float = 0.0, min_len: int = 200, max_len: int = 50000, device="cuda"):
+    """make_reads with torch on ``device`` (bench.py: batches are generated straight into HBM, one call per batch, so
+    a run can hold many distinct batches without the host ever materialising them).  ``genome``: uint8 numpy array or
+    torch tensor.  Returns (bases uint8 tensor, offsets int64 tensor [n_reads + 1]) on ``device``.  Same construction
+    as make_reads (random start and strand, substitution errors) but a different random stream."""
+    import torch
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(rng_seed))
+    g = genome if isinstance(genome, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(genome, np.uint8))
+    g = g.to(dev)
+    G = int(g.numel())
+    if lognormal_sigma > 0:
+        z = torch.randn(n_reads, generator=gen, device=dev, dtype=torch.float64)
+        lens = torch.exp(z * lognormal_sigma + float(np.log(read_len)))
+        lens = lens.clamp(min_len, min(max_len, G)).to(torch.int64)
+    else:
+        lens = torch.full((n_reads,), min(int(read_len), G), dtype=torch.int64, device=dev)
+    offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(lens, 0)
+    total = int(offsets[-1].item())
+    starts = (torch.rand(n_reads, generator=gen, device=dev, dtype=torch.float64) * (G - lens + 1).to(torch.float64)).to(torch.int64)
+    rev_read = torch.randint(0, 2, (n_reads,), generator=gen, device=dev, dtype=torch.int64).bool()
+    read_id = torch.repeat_interleave(torch.arange(n_reads, device=dev), lens, output_size=total)
+    within = torch.arange(total, device=dev, dtype=torch.int64) - offsets[:-1][read_id]
+    rev = rev_read[read_id]
+    pos = torch.where(rev, (starts + lens - 1)[read_id] - within, starts[read_id] + within)
+    del within, read_id
+    bases = g[pos]
+    del pos
+    comp = torch.arange(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    bases = torch.where(rev, comp[bases.long()], bases)
+    del rev
+    if err > 0:
+        hit = torch.rand(total, generator=gen, device=dev) < err
+        idx = hit.nonzero(as_tuple=True)[0]
+        del hit
+        code = torch.zeros(256, dtype=torch.int64, device=dev)
+        for i, a in enumerate(b"ACGT"):
+            code[a] = i
+        alphabet = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        shift = torch.randint(1, 4, (idx.numel(),), generator=gen, device=dev, dtype=torch.int64)
+        bases[idx] = alphabet[(code[bases[idx].long()] + shift) % 4]
+    return bases.contiguous(), offsets

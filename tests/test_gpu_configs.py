@@ -1,0 +1,139 @@
+"""BASELINE.json configs on the GPU box beyond the small parity cases: C1 (5 000 genomes x s=1000) against the
+oracle and through size-independent properties at 100k reads; a plain `python bench.py --gpus 2` (self-launching,
+both ranks on the one GPU of the box); RCCL through the C ABI on a one-rank communicator.
+
+C2 at full batch size lives in test_gpu_fullsize.py (it shares that module's 3.2 GB reference)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import workload
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rank_np(table, k):
+    order = np.lexsort((np.arange(len(table)), -table.astype(np.int64)))  # sum desc, index asc
+    return order[:k].astype(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def c1(gpu):
+    from sketchy_amd import api
+    n_reads = 98304 + 8192
+    ref, bases, offsets = workload(5000, 1000, n_reads, rng_seed=101)
+    R = api.ReferenceSketch(ref["ref"], ref["col_len"])
+    yield dict(ref=ref, bases=bases, offsets=offsets, R=R)
+    R.close()
+
+
+def test_c1_8k_reads_vs_oracle(c1):
+    """BASELINE configs[1] (N=5 000, s=1 000, k=16): 8 192 reads, every row and the table against the oracle
+    (src/sketchy.rs:337-349), in one push and in uneven cuts."""
+    from sketchy_amd import api
+    ref, bases, offsets, R = c1["ref"], c1["bases"], c1["offsets"], c1["R"]
+    n = 8192
+    exp = orc.stream(16, 0, 1000, ref["ref"], ref["col_len"], bases, offsets[:n + 1], top_k=3)
+    S = api.SumOfSharedHashes(R, top=3, max_batch_reads=n, max_batch_bases=int(offsets[n]))
+    got = S.push(bases, offsets[:n + 1])
+    np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"])
+    np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    S1 = api.SumOfSharedHashes(R, top=1, max_batch_reads=3000, max_batch_bases=3000 * 1500)
+    parts = [S1.push(bases, offsets[a:b + 1]) for a, b in ((0, 1), (1, 3000), (3000, 5001), (5001, 8000), (8000, 8192))]
+    np.testing.assert_array_equal(np.concatenate([p["topk_idx"][:, 0] for p in parts]), exp["topk_idx"][:, 0])
+    np.testing.assert_array_equal(np.concatenate([p["topk_sum"][:, 0] for p in parts]), exp["topk_sum"][:, 0])
+    np.testing.assert_array_equal(S1.table(), exp["cum"])
+
+
+def test_c1_100k_reads_properties(c1):
+    """The whole ~100k-read C1 stream as ONE pass (B = 98 304, the geometry bench.py times) against the same reads in
+    4 096-read pushes, continuing the table the 8 192 oracle-checked reads left; plus the properties any size offers."""
+    from sketchy_amd import api
+    bases, offsets, R = c1["bases"], c1["offsets"], c1["R"]
+    n0, B = 8192, 98304
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=B, max_batch_bases=int(offsets[n0 + B] - offsets[n0]))
+    S.push(bases, offsets[:n0 + 1])
+    t0 = S.table()
+    big = S.push(bases, offsets[n0:])
+    t_big = S.table()
+    assert S.reads == n0 + B
+    C = api.SumOfSharedHashes(R, top=1, max_batch_reads=4096, max_batch_bases=4096 * 1500)
+    C.table_add(t0)
+    cuts = [C.push(bases, offsets[a:a + 4097]) for a in range(n0, n0 + B, 4096)]
+    np.testing.assert_array_equal(np.concatenate([c["topk_idx"] for c in cuts]), big["topk_idx"])
+    np.testing.assert_array_equal(np.concatenate([c["topk_sum"] for c in cuts]), big["topk_sum"])
+    np.testing.assert_array_equal(C.table(), t_big)
+    sums = big["topk_sum"][:, 0].astype(np.int64)
+    assert (np.diff(sums) >= 0).all() and sums[-1] == t_big.max()
+    assert big["topk_idx"][-1, 0] == _rank_np(t_big, 1)[0]
+    idx, sm = S.rank(10)
+    np.testing.assert_array_equal(idx, _rank_np(t_big, 10))
+    np.testing.assert_array_equal(sm, t_big[idx])
+    # shards add up: table(second part alone) = table(all) - table(first part)
+    S.reset()
+    S.push(bases, offsets[n0:])
+    np.testing.assert_array_equal(S.table(), t_big - t0)
+
+
+def test_rccl_one_rank_communicator_through_the_c_abi(gpu):
+    """skx_comm_* / skx_stream_allreduce on a 1-rank RCCL communicator: ncclCommInitRank + ncclAllReduce(u64, sum, in
+    place) run for real (a second rank needs a second GPU); the sum over one rank is the table itself."""
+    from sketchy_amd import api
+    ref, bases, offsets = workload(300, 256, 200, read_len=600, rng_seed=111)
+    R = api.ReferenceSketch(ref["ref"], ref["col_len"])
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=200, max_batch_bases=len(bases))
+    S.push(bases, offsets)
+    before = S.table()
+    assert before.any()
+    comm = api.Comm(0, 0, 1, api.Comm.unique_id())
+    assert comm.n_ranks == 1
+    S.allreduce(comm)
+    S.allreduce(comm)
+    np.testing.assert_array_equal(S.table(), before)
+    comm.close()
+
+
+def _run(cmd, timeout=600, **env):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+
+
+def test_bench_self_launches_two_ranks(gpu):
+    """`python bench.py --gpus 2` from a plain invocation (no torchrun, no WORLD_SIZE): the parent starts the ranks
+    itself; both share the box's one GPU.  The JSON line must come back with n_gpus = 2 and green parity."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--share-gpu", "--config", "c1", "--batch", "8192",
+                          "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900,
+                         env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and "parity_error" not in j
+    assert j["parity"]["last_timed_step_vs_4096_read_cuts"] is True
+    assert j["config"]["rccl_ranks"] == 2
+    assert j["value"] > 0
+
+
+def test_two_ranks_score_their_shards_on_the_hip_path(gpu, tmp_path):
+    """World-size-2 run where every rank scores its shard of the reads through libsketchy_hip (not a stand-in), the
+    tables are reduced through shard.TableReducer and the exactness extension (earlier shards' totals via
+    skx_stream_table_add) reproduces the single-stream rows: compared with the oracle's single stream."""
+    port = 29000 + os.getpid() % 2000
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), os.path.join(ROOT, "tests", "dist_hip_worker.py"), str(tmp_path)])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    ref, bases, offsets = workload(700, 300, 900, read_len=700, rng_seed=123)
+    single = orc.stream(16, 0, 300, ref["ref"], ref["col_len"], bases, offsets, top_k=2)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    for p in parts:
+        np.testing.assert_array_equal(p["reduced"], single["cum"])
+    np.testing.assert_array_equal(np.concatenate([p["idx"] for p in parts]), single["topk_idx"])
+    np.testing.assert_array_equal(np.concatenate([p["sums"] for p in parts]), single["topk_sum"])

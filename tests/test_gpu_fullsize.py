@@ -13,6 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N, S_, B = 40000, 10000, 4096
+B_FULL = 98304  # the batch bench.py times: the whole ~100k-read C2 stream as one pass
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +26,7 @@ def c2(gpu):
         "ref = synth.make_reference(%d, %d, rng_seed=1, device='cuda' if torch.cuda.is_available() else 'numpy')\n"
         "bases, offsets = synth.make_reads(ref['genome'], %d, 1500, rng_seed=4242)\n"
         "np.save(%r + '/ref.npy', ref['ref']); np.save(%r + '/bases.npy', bases); np.save(%r + '/offsets.npy', offsets)\n"
-    ) % (ROOT, N, S_, 2 * B, d, d, d)
+    ) % (ROOT, N, S_, 2 * B + B_FULL, d, d, d)
     subprocess.check_call([sys.executable, "-c", code])
     ref = np.load(d + "/ref.npy", mmap_mode="r")
     out = dict(ref=np.ascontiguousarray(ref), bases=np.load(d + "/bases.npy"), offsets=np.load(d + "/offsets.npy"))
@@ -49,7 +50,7 @@ def test_shard_invariance_determinism_and_rank(c2):
     S = api.SumOfSharedHashes(R, top=1, max_batch_reads=B, max_batch_bases=B * 1500)
     a = S.push(bases, offsets[:B + 1])
     ta = S.table()
-    b = S.push(bases, offsets[B:])
+    b = S.push(bases, offsets[B:2 * B + 1])
     tab = S.table()
     assert S.reads == 2 * B
     # running sums only grow, and the emitted top row is the table's leader at that read
@@ -62,17 +63,17 @@ def test_shard_invariance_determinism_and_rank(c2):
     np.testing.assert_array_equal(sm, tab[idx])
     # shards add up exactly (integer sums): table(second half alone) == table(all) - table(first half)
     S.reset()
-    b2 = S.push(bases, offsets[B:])
+    b2 = S.push(bases, offsets[B:2 * B + 1])
     np.testing.assert_array_equal(S.table(), tab - ta)
     # determinism: same input, same bytes
     S.reset()
-    b3 = S.push(bases, offsets[B:])
+    b3 = S.push(bases, offsets[B:2 * B + 1])
     np.testing.assert_array_equal(b2["topk_idx"], b3["topk_idx"])
     np.testing.assert_array_equal(b2["topk_sum"], b3["topk_sum"])
     # seeding the second shard with the first shard's totals reproduces the single-stream rows
     S.reset()
     S.table_add(ta)
-    b4 = S.push(bases, offsets[B:])
+    b4 = S.push(bases, offsets[B:2 * B + 1])
     np.testing.assert_array_equal(b4["topk_idx"], b["topk_idx"])
     np.testing.assert_array_equal(b4["topk_sum"], b["topk_sum"])
     # different batch cuts give the same stream (B=4096 vs 8 x 512)
@@ -81,6 +82,34 @@ def test_shard_invariance_determinism_and_rank(c2):
     np.testing.assert_array_equal(np.concatenate([p["topk_idx"] for p in parts]), a["topk_idx"])
     np.testing.assert_array_equal(np.concatenate([p["topk_sum"] for p in parts]), a["topk_sum"])
     np.testing.assert_array_equal(S2.table(), ta)
+
+
+def test_full_batch_one_pass_vs_4096_read_cuts_and_oracle_sample(c2):
+    """B = 98 304 reads in ONE push (96 chunks of 1024 reads, one scan, the chunk-level pruning at that scale -- what
+    bench.py times) gives the rows and the table of the same reads pushed 4 096 at a time, and its first rows are the
+    oracle's (src/sketchy.rs:337-349) -- checked through the very same stream."""
+    from oracle import oracle as orc
+    from sketchy_amd import api
+    R, ref, bases, offsets = c2["R"], c2["ref"], c2["bases"], c2["offsets"]
+    n0 = 2 * B
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=B_FULL, max_batch_bases=int(offsets[n0 + B_FULL] - offsets[n0]))
+    big = S.push(bases, offsets[n0:n0 + B_FULL + 1])
+    t_big = S.table()
+    n = 6
+    exp = orc.stream(16, 0, S_, ref, np.full(N, S_, np.uint32), bases, offsets[n0:n0 + n + 1], top_k=1)
+    np.testing.assert_array_equal(big["topk_idx"][:n], exp["topk_idx"])
+    np.testing.assert_array_equal(big["topk_sum"][:n], exp["topk_sum"])
+    C = api.SumOfSharedHashes(R, top=1, max_batch_reads=B, max_batch_bases=B * 1500)
+    cuts = [C.push(bases, offsets[a:a + B + 1]) for a in range(n0, n0 + B_FULL, B)]
+    np.testing.assert_array_equal(np.concatenate([c["topk_idx"] for c in cuts]), big["topk_idx"])
+    np.testing.assert_array_equal(np.concatenate([c["topk_sum"] for c in cuts]), big["topk_sum"])
+    np.testing.assert_array_equal(C.table(), t_big)
+    # a second full batch continues the table (steady state: pruned ranking against a clear leader)
+    big2 = S.push(bases, offsets[n0:n0 + B_FULL + 1])
+    cuts2 = [C.push(bases, offsets[a:a + B + 1]) for a in range(n0, n0 + B_FULL, B)]
+    np.testing.assert_array_equal(np.concatenate([c["topk_idx"] for c in cuts2]), big2["topk_idx"])
+    np.testing.assert_array_equal(np.concatenate([c["topk_sum"] for c in cuts2]), big2["topk_sum"])
+    np.testing.assert_array_equal(C.table(), S.table())
 
 
 def test_top5_rows_are_consistent_with_top1(c2):
