@@ -93,23 +93,47 @@ __global__ __launch_bounds__(256) void band_bounds_kernel(const u64* __restrict_
 }
 
 // =====================================================================================
-// read sketching: one wavefront per read
+// read sketching: one wavefront per read, any read length
 // =====================================================================================
-// LDS per wave: hashes[HCAP] u64, then codes[CAP + 64] bytes (CAP = most k-mers a read may have here).
+// LDS per wave: hashes[HCAP] u64, then codes[kSketchCap + 64] bytes.  The read is normalised and hashed in CHUNKS
+// of kSketchCap raw bytes; the last k-1 codes of a chunk are carried to the front of the next, so windows across a
+// chunk border are seen exactly once and a read of any length needs no scratch outside the wave's LDS.
 // INRANGE: keep only hashes <= max_ref before sorting.  Every such hash is smaller than every
 // dropped one, so the first min(s, #distinct kept) of them ARE the part of the bottom-s sketch that
 // can meet the reference (the only part scoring needs); out_len is then that count, not |sketch|.
-// HCAP < CAP (INRANGE only): small hash buffer for full occupancy; a read with more than HCAP kept hashes is
-// flagged (out_len = kSketchRetry, index appended to the retry list) and redone by a second launch with HCAP = CAP.
+// A read whose kept hashes overflow the buffer is handed on through a device-side list (never through the host):
+//   HCAP < kSketchCap  -> `retry` (redone by the HCAP = kSketchCap variant; out_len = kSketchRetry meanwhile)
+//   HCAP = kSketchCap  -> `big`   (redone by sketch_block_kernel, which holds 16 384 hashes and selects in passes)
+// !INRANGE (full sketches: debug outputs, skx_sketch_reads): reads with more than kSketchCap k-mers go to `big` at once.
 constexpr u32 kSketchRetry = 0xFFFFFFFFu;
-// retry: [0] = number of flagged reads, [1..] = their indices (appended by the HCAP < CAP variant)
-template <int KT, int CAP, int HCAP, bool INRANGE>
+// list layout: [0] = number of entries, [1..] = read indices
+__device__ __forceinline__ void list_append(u32* __restrict__ list, u32 r) { list[1u + atomicAdd(&list[0], 1u)] = r; }
+
+// 64 k-mers' worth of work shared by the wave and block sketchers lives in these two helpers --------------------
+// normalise raw bytes [from, to) of the read into codes[nb ...] (whitespace dropped, everything not ACGTU -> 4); returns
+// the new code count.  One wave.
+__device__ __forceinline__ u32 wave_normalise(const uint8_t* __restrict__ rd, u32 from, u32 to, uint8_t* codes, u32 nb,
+                                              u32 lane, u64 lt) {
+    for (u32 base = from; base < to; base += 64u) {
+        const u32 idx = base + lane;
+        const u32 ch = idx < to ? (u32)rd[idx] : (u32)' ';
+        const u32 code = classify_base(ch);
+        const bool keep = code != 5u;
+        const u64 mask = __ballot(keep);
+        if (keep) codes[nb + __popcll(mask & lt)] = (uint8_t)code;
+        nb += __popcll(mask);
+    }
+    return nb;
+}
+
+template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, const uint8_t* __restrict__ bases,
                                                 const u64* __restrict__ offsets, u32 k_rt, u64 seed, u32 s, u64 max_ref,
                                                 u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
-                                                u32* __restrict__ out_cnt_in, u32* __restrict__ retry,
+                                                u32* __restrict__ out_cnt_in, u32* __restrict__ retry, u32* __restrict__ big,
                                                 const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
                                                 u32* __restrict__ chk) {
+    constexpr u32 CAP = kSketchCap;
     constexpr u32 kPerWave = HCAP * 8 + CAP + 64;
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     u64* hashes = reinterpret_cast<u64*>(smem + (size_t)wv * kPerWave);
@@ -119,40 +143,29 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     // the caller vouches for n_bases bytes from offsets[0] on: a read reaching outside is never touched (flagged in
     // chk[6]; the push then fails with SKX_ERR_INVALID instead of faulting)
     const u64 lo = offsets[0];
-    const bool outside = o0 < lo || o1 < o0 || o1 - lo > n_bases;
-    if (outside || o1 - o0 > (u64)CAP + k - 1u) {  // (long reads are sketched by the long_read_* kernels instead)
+    if (o0 < lo || o1 < o0 || o1 - lo > n_bases) {
         if (lane == 0) {
             out_len[r] = 0; out_cnt_in[r] = 0;
-            if (outside && chk) atomicOr(&chk[6], 1u);
+            if (chk) atomicOr(&chk[6], 1u);
         }
         return;
     }
     const u32 lraw = (u32)(o1 - o0);
+    if (!INRANGE && lraw > CAP + k - 1u) {  // a full sketch of more k-mers than the buffer holds: the block sketcher
+        if (lane == 0) { out_len[r] = kSketchRetry; out_cnt_in[r] = 0; list_append(big, r); }
+        return;
+    }
+    const uint8_t* rd = bases + o0;
     const u64 lt = lanemask_lt();
 
-    // 1. normalise into 2-bit codes (whitespace dropped, everything not ACGTU -> 4)
-    u32 nb = 0;
-    for (u32 base = 0; base < lraw; base += 64u) {
-        const u32 idx = base + lane;
-        const u32 ch = idx < lraw ? (u32)bases[o0 + idx] : (u32)' ';
-        const u32 code = classify_base(ch);
-        const bool keep = code != 5u;
-        const u64 mask = __ballot(keep);
-        if (keep) codes[nb + __popcll(mask & lt)] = (uint8_t)code;
-        nb += __popcll(mask);
-    }
-    wave_sync();
-
-    // 2. canonical k-mer hashes, compacted (any order: they are sorted next)
-    u32 m = 0;
-    const u32 nk = nb >= k ? nb - k + 1u : 0u;
-    auto append = [&](bool valid, u64 h) -> bool {  // false: the small hash buffer overflowed (read flagged)
+    u32 m = 0;  // hashes collected so far (any order: they are sorted afterwards)
+    auto append = [&](bool valid, u64 h) -> bool {  // false: the hash buffer overflowed (read handed on)
         if (INRANGE) valid = valid && (h <= max_ref);
         const u64 mask = __ballot(valid);
-        if (HCAP < CAP && m + (u32)__popcll(mask) > (u32)HCAP) {  // uniform: hand the read to the big-buffer launch
+        if (m + (u32)__popcll(mask) > (u32)HCAP) {  // uniform
             if (lane == 0) {
                 out_len[r] = kSketchRetry; out_cnt_in[r] = 0;
-                if (retry) retry[1u + atomicAdd(&retry[0], 1u)] = r;
+                list_append(HCAP < (int)CAP ? retry : big, r);
             }
             return false;
         }
@@ -160,66 +173,85 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         m += __popcll(mask);
         return true;
     };
-    if constexpr (KT == 16) {
-        // Each lane walks a contiguous run of positions with ROLLING windows: the 2-bit forward / reverse-
-        // complement codes (for the canonical choice) and their 16 ASCII bytes as two little-endian words each
-        // (the murmur3 block) -- one LDS byte read and a few shifts per k-mer instead of rebuilding all 16 bases.
-        const u32 run = (nk + 63u) / 64u;
-        const u32 p0 = lane * run;
-        u32 fwd = 0, rc = 0;            // 16 bases x 2 bits: forward (first base highest) / reverse complement
-        u32 f0 = 0, f1 = 0, f2 = 0, f3 = 0;  // the 16 ASCII bytes of the forward k-mer, first base in the lowest byte
-        u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // ... of its reverse complement
-        u32 clean = 0;                  // consecutive valid bases ending at the newest one
-        auto push = [&](u32 c) {
-            clean = (c >> 2) ? 0u : clean + 1u;
-            c &= 3u;
-            fwd = (fwd << 2) | c;
-            rc = __builtin_amdgcn_alignbit(c ^ 3u, rc, 2);        // (rc >> 2) | (complement << 30)
-            const u32 a = (0x54474341u >> (8u * c)) & 0xFFu;   // "ACGT"[c]
-            const u32 ca = (0x41434754u >> (8u * c)) & 0xFFu;  // complement: "TGCA"[c]
-            // one byte per step: the forward window drops its lowest byte and takes the new base on top, the reverse
-            // complement shifts up and takes the complement at the bottom (v_alignbit_b32 each)
-            f0 = __builtin_amdgcn_alignbit(f1, f0, 8);
-            f1 = __builtin_amdgcn_alignbit(f2, f1, 8);
-            f2 = __builtin_amdgcn_alignbit(f3, f2, 8);
-            f3 = __builtin_amdgcn_alignbit(a, f3, 8);
-            r3 = __builtin_amdgcn_alignbit(r3, r2, 24);
-            r2 = __builtin_amdgcn_alignbit(r2, r1, 24);
-            r1 = __builtin_amdgcn_alignbit(r1, r0, 24);
-            r0 = (r0 << 8) | ca;
-        };
-        for (u32 j = 0; j < 15u; ++j) push(p0 + j < nb ? (u32)codes[p0 + j] : 4u);
-        for (u32 t = 0; t < run; ++t) {
-            const u32 p = p0 + t;
-            const bool in = p < nk;
-            push(in ? (u32)codes[p + 15u] : 4u);
-            const bool use_f = fwd < rc;
-            const u64 w0 = make_u64(use_f ? f0 : r0, use_f ? f1 : r1), w1 = make_u64(use_f ? f2 : r2, use_f ? f3 : r3);
-            const u64 h = seed == 0 ? murmur3_h1_16<true>(w0, w1, 0) : murmur3_h1_16<false>(w0, w1, seed);
-            if (!append(in && clean >= 16u, h)) return;
-        }
-    } else {
-        for (u32 base = 0; base < nk; base += 64u) {
-            const u32 p = base + lane;
-            bool valid = p < nk;
-            u64 fwd = 0, rc = 0;
-            u32 bad = 0;
-            if (valid) {
-#pragma unroll
-                for (u32 j = 0; j < 32u; ++j) {
-                    if (j < k) {
-                        u32 c = codes[p + j];
-                        bad |= c >> 2;
-                        c &= 3u;
-                        fwd = (fwd << 2) | c;
-                        rc |= (u64)(3u - c) << (2 * j);
-                    }
+
+    u32 carry = 0;  // codes kept from the previous chunk at codes[0 .. carry)
+    for (u32 cbase = 0;; cbase += CAP) {
+        const u32 cend = min(lraw, cbase + CAP);
+        // 1. normalise the chunk behind the carried codes
+        const u32 nb = wave_normalise(rd, cbase, cend, codes, carry, lane, lt);
+        wave_sync();
+        // 2. canonical k-mer hashes of the windows that END in this chunk, compacted
+        const u32 nk = nb >= k ? nb - k + 1u : 0u;
+        if constexpr (KT == 16) {
+            // Each lane walks a contiguous run of positions with ROLLING windows: the 2-bit forward / reverse-
+            // complement codes (for the canonical choice) and their 16 ASCII bytes as two little-endian words each
+            // (the murmur3 block) -- one LDS byte read and a few shifts per k-mer instead of rebuilding all 16 bases.
+            const u32 run = (nk + 63u) / 64u;
+            const u32 p0 = lane * run;
+            u32 fwd = 0, rc = 0;            // 16 bases x 2 bits: forward (first base highest) / reverse complement
+            u32 f0 = 0, f1 = 0, f2 = 0, f3 = 0;  // the 16 ASCII bytes of the forward k-mer, first base in the lowest byte
+            u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // ... of its reverse complement
+            u32 clean = 0;                  // consecutive valid bases ending at the newest one
+            auto push = [&](u32 c) {
+                clean = (c >> 2) ? 0u : clean + 1u;
+                c &= 3u;
+                fwd = (fwd << 2) | c;
+                rc = __builtin_amdgcn_alignbit(c ^ 3u, rc, 2);        // (rc >> 2) | (complement << 30)
+                const u32 a = (0x54474341u >> (8u * c)) & 0xFFu;   // "ACGT"[c]
+                const u32 ca = (0x41434754u >> (8u * c)) & 0xFFu;  // complement: "TGCA"[c]
+                // one byte per step: the forward window drops its lowest byte and takes the new base on top, the reverse
+                // complement shifts up and takes the complement at the bottom (v_alignbit_b32 each)
+                f0 = __builtin_amdgcn_alignbit(f1, f0, 8);
+                f1 = __builtin_amdgcn_alignbit(f2, f1, 8);
+                f2 = __builtin_amdgcn_alignbit(f3, f2, 8);
+                f3 = __builtin_amdgcn_alignbit(a, f3, 8);
+                r3 = __builtin_amdgcn_alignbit(r3, r2, 24);
+                r2 = __builtin_amdgcn_alignbit(r2, r1, 24);
+                r1 = __builtin_amdgcn_alignbit(r1, r0, 24);
+                r0 = (r0 << 8) | ca;
+            };
+            if (nk) {
+                for (u32 j = 0; j < 15u; ++j) push(p0 + j < nb ? (u32)codes[p0 + j] : 4u);
+                for (u32 t = 0; t < run; ++t) {
+                    const u32 p = p0 + t;
+                    const bool in = p < nk;
+                    push(in ? (u32)codes[p + 15u] : 4u);
+                    const bool use_f = fwd < rc;
+                    const u64 w0 = make_u64(use_f ? f0 : r0, use_f ? f1 : r1), w1 = make_u64(use_f ? f2 : r2, use_f ? f3 : r3);
+                    const u64 h = seed == 0 ? murmur3_h1_16<true>(w0, w1, 0) : murmur3_h1_16<false>(w0, w1, seed);
+                    if (!append(in && clean >= 16u, h)) return;
                 }
             }
-            valid = valid && (bad == 0);
-            const u64 h = hash_canonical_packed<KT>(fwd < rc ? fwd : rc, k, seed);
-            if (!append(valid, h)) return;
+        } else {
+            for (u32 base = 0; base < nk; base += 64u) {
+                const u32 p = base + lane;
+                bool valid = p < nk;
+                u64 fwd = 0, rc = 0;
+                u32 bad = 0;
+                if (valid) {
+#pragma unroll
+                    for (u32 j = 0; j < 32u; ++j) {
+                        if (j < k) {
+                            u32 c = codes[p + j];
+                            bad |= c >> 2;
+                            c &= 3u;
+                            fwd = (fwd << 2) | c;
+                            rc |= (u64)(3u - c) << (2 * j);
+                        }
+                    }
+                }
+                valid = valid && (bad == 0);
+                const u64 h = hash_canonical_packed<KT>(fwd < rc ? fwd : rc, k, seed);
+                if (!append(valid, h)) return;
+            }
         }
+        if (cend >= lraw) break;
+        // 3. the last k-1 codes open the next chunk
+        const u32 keep = min(nb, k - 1u);
+        const u32 cv = lane < keep ? (u32)codes[nb - keep + lane] : 0u;
+        wave_sync();
+        if (lane < keep) codes[lane] = (uint8_t)cv;
+        carry = keep;
     }
     // pad to a power of two (>= 64) for the bitonic network
     u32 p2 = 64;
@@ -227,7 +259,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     for (u32 i = m + lane; i < p2; i += 64u) hashes[i] = kPad;
     wave_sync();
 
-    // 3. bitonic sort ascending
+    // bitonic sort ascending
     if (m > 1) {
         for (u32 size = 2; size <= p2; size <<= 1) {
             for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
@@ -243,7 +275,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         }
     }
 
-    // 4. distinct, truncate to s, count the part that can meet the reference at all.
+    // distinct, truncate to s, count the part that can meet the reference at all.
     // INRANGE with a membership bitmap (production): of the hashes that made it into the bottom-s only those some genome
     // holds are written -- strictly AFTER the truncation: a hash ranked beyond s is not part of the sketch even if
     // everything before it is dropped (reads with more distinct in-range hashes than s, e.g. small s).
@@ -277,135 +309,231 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         out_cnt_in[r] = (INRANGE && filt != nullptr) ? wrote : cin;
     }
 }
-// from_list = 0: wave w of the grid sketches read w.  from_list = 1 (HCAP = CAP): a small fixed grid walks the reads
-// the fast variant appended to `retry` -- usually none, and then the launch costs a few microseconds instead of one
-// nearly empty wave per read of the batch.
-template <int KT, int CAP, int HCAP, bool INRANGE>
+// from_list = 0: wave w of the grid sketches read w.  from_list = 1: a small fixed grid walks the reads an earlier
+// variant appended to `retry` -- usually none, and then the launch costs a few microseconds instead of one nearly
+// empty wave per read of the batch.
+template <int KT, int HCAP, bool INRANGE>
 __global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
                                                           const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
                                                           u64 seed, u32 s, u64 max_ref, u64* __restrict__ out_sk,
                                                           u32 sk_stride, u32* __restrict__ out_len,
                                                           u32* __restrict__ out_cnt_in, u32 from_list,
-                                                          u32* __restrict__ retry, const u32* __restrict__ filt,
-                                                          u32 filt_shift, u64 n_bases, u32* __restrict__ chk) {
+                                                          u32* __restrict__ retry, u32* __restrict__ big,
+                                                          const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
+                                                          u32* __restrict__ chk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 w = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (!from_list) {
         if (w < n_reads)
-            sketch_one_read<KT, CAP, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
-                                                    out_cnt_in, retry, filt, filt_shift, n_bases, chk);
+            sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
+                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk);
         return;
     }
     const u32 n = retry[0];
     for (u32 i = w; i < n; i += gridDim.x * 4u) {
-        sketch_one_read<KT, CAP, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
-                                                out_len, out_cnt_in, nullptr, filt, filt_shift, n_bases, chk);
+        sketch_one_read<KT, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
+                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
 }
 
 // =====================================================================================
-// long reads (more k-mers than the one-wave sketcher holds): one block per read
+// the block sketcher: reads whose hashes do not fit one wave's LDS (and full sketches of long sequences)
 // =====================================================================================
-// Phase 1 (long_read_hash_kernel): normalise into codes[] (global scratch, whitespace removed), hash every
-// valid canonical k-mer and append the hashes that matter (all of them, or with INRANGE only those <= max_ref)
-// to the read's segment of hbuf[] in arbitrary order.  Phase 2: rocPRIM segmented radix sort of the
-// segments.  Phase 3 (long_read_finish_kernel): distinct, truncate to s, count the in-range prefix.
-// Segment of read r: hbuf[offsets[r] .. offsets[r] + seg_cnt[i]) (a read has fewer k-mers than bases).
-template <int KT, bool INRANGE>
-__global__ __launch_bounds__(1024) void long_read_hash_kernel(const uint8_t* __restrict__ bases,
-                                                              const u64* __restrict__ offsets,
-                                                              const u32* __restrict__ long_idx, u32 k_rt, u64 seed,
-                                                              u64 max_ref, uint8_t* __restrict__ codes,
-                                                              u64* __restrict__ hbuf, u32* __restrict__ seg_begin,
-                                                              u32* __restrict__ seg_end, u64 off0) {
-    __shared__ u32 wsum[16];
-    __shared__ u32 s_base, s_cnt;
-    const u32 i = blockIdx.x, r = long_idx[i], tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const u32 k = KT > 0 ? (u32)KT : k_rt;
-    const u64 o0 = offsets[r], o1 = offsets[r + 1];
-    const u32 lraw = (u32)(o1 - o0);
-    uint8_t* cd = codes + (o0 - off0);  // scratch is indexed relative to the batch's first base
-    if (tid == 0) { s_base = 0; s_cnt = 0; }
+// One 1024-thread block per read of the `big` list, 16 384 hash slots in LDS (128 KB), nothing in global memory.
+// The read is streamed in chunks like above; accepted hashes are appended to the buffer, and whenever it cannot take
+// another 1024 the block sorts it, drops duplicates and keeps the `keep` smallest -- from then on only hashes <= the
+// largest kept one are accepted (finch's "h <= heap.max", mash.rs push) -- so the buffer ends up holding the
+// min(keep, #distinct) smallest distinct hashes above `floor`.  A sketch larger than kBigKeep takes further passes over
+// the read, each starting above the previous pass's largest hash.  Exact for any read length and any s.
+constexpr u32 kBigHashes = 16384;
+constexpr u32 kBigKeep = 12288;
+constexpr u32 kBigChunk = 4096;  // raw bytes normalised per chunk
+constexpr size_t kBigLds = (size_t)kBigHashes * 8 + kBigChunk + 64;
+
+struct BlockScratch {
+    u32 wsum[16];
+    u32 n;      // hashes in the buffer
+    u32 nb;     // codes in the chunk buffer
+    u32 out;    // running count of a block-wide compaction
+    u32 cnt;    // a second running count (in-range / member hashes)
+};
+
+// block-wide: position of this thread's flag among all set flags (in thread order) + total; 1024 threads
+__device__ __forceinline__ u32 block_rank(bool flag, BlockScratch& sh, u32& total) {
+    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
+    const u64 mask = __ballot(flag);
+    if (lane == 0) sh.wsum[wv] = (u32)__popcll(mask);
     __syncthreads();
-    // 1. normalise + compact, 1024 bytes per step
-    for (u32 base = 0; base < lraw; base += 1024u) {
-        const u32 idx = base + tid;
-        const u32 code = classify_base(idx < lraw ? (u32)bases[o0 + idx] : (u32)' ');
-        const bool keep = code != 5u;
-        const u64 mask = __ballot(keep);
-        if (lane == 0) wsum[wv] = __popcll(mask);
-        __syncthreads();
-        u32 before = s_base;
-        for (u32 w = 0; w < wv; ++w) before += wsum[w];
-        if (keep) cd[before + __popcll(mask & lanemask_lt())] = (uint8_t)code;
-        __syncthreads();
-        if (tid == 0) { u32 t = 0; for (u32 w = 0; w < 16u; ++w) t += wsum[w]; s_base += t; }
-        __syncthreads();
-    }
-    const u32 nb = s_base;
-    const u32 nk = nb >= k ? nb - k + 1u : 0u;
-    u64* seg = hbuf + (o0 - off0);
-    // 2. hash every valid k-mer; append in arbitrary order (the segment is sorted afterwards)
-    for (u32 p = tid; p < nk; p += 1024u) {
-        u64 fwd = 0, rc = 0;
-        u32 bad = 0;
+    u32 before = 0, tot = 0;
 #pragma unroll
-        for (u32 j = 0; j < (KT > 0 ? (u32)KT : 32u); ++j) {
-            if (j < k) {
-                u32 c = cd[p + j];
-                bad |= c >> 2;
-                c &= 3u;
-                fwd = (fwd << 2) | c;
-                rc |= (u64)(3u - c) << (2 * j);
-            }
-        }
-        if (bad) continue;
-        const u64 h = hash_canonical_packed<KT>(fwd < rc ? fwd : rc, k, seed);
-        if (INRANGE && h > max_ref) continue;
-        seg[atomicAdd(&s_cnt, 1u)] = h;
-    }
-    __syncthreads();
-    if (tid == 0) { seg_begin[i] = (u32)(o0 - off0); seg_end[i] = (u32)(o0 - off0) + s_cnt; }
+    for (u32 w = 0; w < 16u; ++w) { const u32 c = sh.wsum[w]; before += w < wv ? c : 0u; tot += c; }
+    __syncthreads();  // wsum is reused by the next call
+    total = tot;
+    return before + (u32)__popcll(mask & lanemask_lt());
 }
 
-// sorted segment -> distinct, truncate to s, in-range count.  One block (256) per long read.
-__global__ __launch_bounds__(256) void long_read_finish_kernel(const u64* __restrict__ sorted,
-                                                               const u32* __restrict__ long_idx,
-                                                               const u32* __restrict__ seg_begin,
-                                                               const u32* __restrict__ seg_end, u32 s, u64 max_ref,
-                                                               u64* __restrict__ out_sk, u32 sk_stride,
-                                                               u32* __restrict__ out_len, u32* __restrict__ out_cnt_in) {
-    __shared__ u32 wsum[4];
-    __shared__ u32 s_out, s_in;
-    const u32 i = blockIdx.x, r = long_idx[i], tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const u64* seg = sorted + seg_begin[i];
-    const u32 m = seg_end[i] - seg_begin[i];
-    u64* out = out_sk + (size_t)r * sk_stride;
-    if (tid == 0) { s_out = 0; s_in = 0; }
-    __syncthreads();
-    for (u32 base = 0; base < m; base += 256u) {
-        if (s_out >= s) break;  // uniform: s_out is only updated between barriers
-        const u32 idx = base + tid;
-        const bool v = idx < m;
-        const u64 h = v ? seg[idx] : 0;
-        const bool head = v && (idx == 0 || seg[idx - 1] != h);
-        const u64 mask = __ballot(head);
-        if (lane == 0) wsum[wv] = __popcll(mask);
-        __syncthreads();
-        u32 pos = s_out;
-        for (u32 w = 0; w < wv; ++w) pos += wsum[w];
-        pos += __popcll(mask & lanemask_lt());
-        const bool take = head && pos < s;
-        if (take) out[pos] = h;
-        const u32 n_in = __popcll(__ballot(take && h <= max_ref));
-        if (lane == 0 && n_in) atomicAdd(&s_in, n_in);
-        __syncthreads();
-        if (tid == 0) s_out += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+template <int KT, bool INRANGE>
+__global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __restrict__ bases, const u64* __restrict__ offsets,
+                                                            const u32* __restrict__ big, u32 k_rt, u64 seed, u32 s,
+                                                            u64 max_ref, u64* __restrict__ out_sk, u32 sk_stride,
+                                                            u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
+                                                            const u32* __restrict__ filt, u32 filt_shift) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ BlockScratch sh;
+    u64* hashes = reinterpret_cast<u64*>(smem);
+    uint8_t* codes = smem + (size_t)kBigHashes * 8;
+    const u32 tid = threadIdx.x, lane = lane_id();
+    const u32 k = KT > 0 ? (u32)KT : k_rt;
+    const u32 n_big = big[0];
+
+    for (u32 bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+        const u32 r = big[1u + bi];
+        const u64 o0 = offsets[r];
+        const u32 lraw = (u32)(offsets[r + 1] - o0);
+        const uint8_t* rd = bases + o0;
+        u64* out = out_sk + (size_t)r * sk_stride;
+        u64 floor_v = 0;
+        bool have_floor = false;
+        u32 outn = 0;         // sketch entries emitted so far (distinct hashes, ascending)
+        u32 wrote = 0, cin = 0;
+
+        for (;;) {  // one pass over the read per kBigKeep sketch entries
+            const u32 keep = min(s - outn, kBigKeep);
+            u64 thr = INRANGE ? max_ref : ~0ull;
+            bool truncated = false;
+            if (tid == 0) { sh.n = 0; sh.nb = 0; }
+            __syncthreads();
+
+            // sort + distinct + keep the `keep` smallest; leaves sh.n = entries kept (all threads return with it in sync)
+            auto compact = [&]() {
+                const u32 n = sh.n;
+                u32 p2 = 2;
+                while (p2 < n) p2 <<= 1;
+                for (u32 i = n + tid; i < p2; i += 1024u) hashes[i] = kPad;
+                __syncthreads();
+                for (u32 size = 2; size <= p2; size <<= 1) {
+                    for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+                        for (u32 t = tid; t < (p2 >> 1); t += 1024u) {
+                            const u32 i = 2u * t - (t & (stride - 1u));
+                            const u32 j = i + stride;
+                            const bool up = (i & size) == 0u;
+                            const u64 a = hashes[i], b = hashes[j];
+                            if ((a > b) == up) { hashes[i] = b; hashes[j] = a; }
+                        }
+                        __syncthreads();
+                    }
+                }
+                // distinct, in place: an element only ever moves towards the front, one round of 1024 at a time
+                u32 nd = 0;
+                for (u32 base = 0; base < n; base += 1024u) {
+                    const u32 i = base + tid;
+                    const bool v = i < n;
+                    const u64 h = v ? hashes[i] : 0;
+                    const bool head = v && (i == 0 || hashes[i - 1] != h);
+                    u32 tot;
+                    const u32 pos = nd + block_rank(head, sh, tot);  // (its barriers order the reads above before the writes)
+                    if (head) hashes[pos] = h;
+                    nd += tot;
+                    __syncthreads();
+                }
+                if (nd > keep) { nd = keep; thr = hashes[keep - 1u]; truncated = true; }
+                __syncthreads();
+                if (tid == 0) sh.n = nd;
+                __syncthreads();
+            };
+
+            for (u32 cbase = 0;; cbase += kBigChunk) {
+                const u32 cend = min(lraw, cbase + kBigChunk);
+                // 1. normalise the chunk behind the carried codes (sh.nb holds the carry)
+                for (u32 base = cbase; base < cend; base += 1024u) {
+                    const u32 idx = base + tid;
+                    const u32 code = classify_base(idx < cend ? (u32)rd[idx] : (u32)' ');
+                    const bool kp = code != 5u;
+                    u32 tot;
+                    const u32 pos = sh.nb + block_rank(kp, sh, tot);
+                    if (kp) codes[pos] = (uint8_t)code;
+                    __syncthreads();
+                    if (tid == 0) sh.nb += tot;
+                    __syncthreads();
+                }
+                const u32 nb = sh.nb;
+                const u32 nk = nb >= k ? nb - k + 1u : 0u;
+                // 2. hash the windows ending in this chunk, 1024 at a time
+                for (u32 p0 = 0; p0 < nk; p0 += 1024u) {
+                    if (sh.n + 1024u > kBigHashes) compact();  // (uniform: sh.n only changes between barriers)
+                    const u32 p = p0 + tid;
+                    bool valid = p < nk;
+                    u64 fwd = 0, rc = 0;
+                    u32 bad = 0;
+                    if (valid) {
+#pragma unroll
+                        for (u32 j = 0; j < (KT > 0 ? (u32)KT : 32u); ++j) {
+                            if (j < k) {
+                                u32 c = codes[p + j];
+                                bad |= c >> 2;
+                                c &= 3u;
+                                fwd = (fwd << 2) | c;
+                                rc |= (u64)(3u - c) << (2 * j);
+                            }
+                        }
+                    }
+                    const u64 h = hash_canonical_packed<KT>(fwd < rc ? fwd : rc, k, seed);
+                    valid = valid && bad == 0 && h <= thr && (!have_floor || h > floor_v);
+                    u32 tot;
+                    const u32 pos = sh.n + block_rank(valid, sh, tot);
+                    if (valid) hashes[pos] = h;
+                    __syncthreads();
+                    if (tid == 0) sh.n += tot;
+                    __syncthreads();
+                }
+                if (cend >= lraw) break;
+                // 3. the last k-1 codes open the next chunk
+                const u32 kc = min(nb, k - 1u);
+                const u32 cv = tid < kc ? (u32)codes[nb - kc + tid] : 0u;
+                __syncthreads();
+                if (tid < kc) codes[tid] = (uint8_t)cv;
+                if (tid == 0) sh.nb = kc;
+                __syncthreads();
+            }
+            compact();
+            const u32 n = sh.n;  // the next `n` sketch entries, ascending and distinct, in hashes[0 .. n)
+
+            // emit (production: only the hashes some genome holds are written, AFTER the truncation to s)
+            for (u32 base = 0; base < n; base += 1024u) {
+                const u32 i = base + tid;
+                const bool v = i < n;
+                const u64 h = v ? hashes[i] : 0;
+                if (INRANGE && filt != nullptr) {
+                    bool kp = false;
+                    if (v) {
+                        const u64 idx = h >> filt_shift;
+                        kp = (filt[idx >> 5] >> (u32)(idx & 31u)) & 1u;
+                    }
+                    u32 tot;
+                    const u32 pos = wrote + block_rank(kp, sh, tot);
+                    if (kp) out[pos] = h;
+                    wrote += tot;
+                } else {
+                    if (v) out[outn + i] = h;
+                    u32 tot;
+                    (void)block_rank(v && h <= max_ref, sh, tot);
+                    cin += tot;
+                }
+            }
+            outn += n;
+            if (!truncated || outn >= s) break;   // exhausted, or the sketch is complete
+            floor_v = hashes[n - 1u];
+            have_floor = true;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            out_len[r] = min(outn, s);
+            out_cnt_in[r] = (INRANGE && filt != nullptr) ? wrote : cin;
+        }
         __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0) { out_len[r] = min(s_out, s); out_cnt_in[r] = s_in; }
+    (void)lane;
 }
 
 // =====================================================================================
@@ -431,15 +559,59 @@ __global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads,
 // raises a sequence number there; the host spins on it.  A blit copy + stream synchronisation for the same 36 bytes
 // cost ~100 us of idle front stream per push (kernel timeline), this costs a launch.  Also re-arms the device-side
 // counters (chk, the retry list) for the next push.
-__global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, const u32* __restrict__ total_pairs,
-                               volatile u32* __restrict__ h_pub, u32 seq) {
+__global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, u32* __restrict__ big,
+                               const u32* __restrict__ total_pairs, volatile u32* __restrict__ h_pub, u32 seq) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (big) { chk[7] = big[0]; big[0] = 0; }  // (reads that needed the block sketcher: a statistic for the host)
     for (int i = 0; i < 8; ++i) { h_pub[i] = chk[i]; chk[i] = 0; }
     if (retry) retry[0] = 0;
     h_pub[8] = *total_pairs;
     __threadfence_system();
     h_pub[15] = seq;
     __threadfence_system();
+}
+
+// =====================================================================================
+// exclusive scan of the per-read pair counts (n_reads + 1 entries) -> pair offsets
+// =====================================================================================
+// Two small launches: (a) every block scans its 1024 entries and leaves its total, (b) every block adds the totals of
+// the blocks before it.  (Replaces a library scan: two launches on the push's critical path instead of three.)
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = (u32)__shfl_up((int)v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+__global__ __launch_bounds__(1024) void count_scan_a_kernel(const u32* __restrict__ in, u32* __restrict__ out, u32 n,
+                                                            u32* __restrict__ bsum) {
+    __shared__ u32 wtot[16];
+    const u32 i = blockIdx.x * 1024u + threadIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
+    const u32 c = i < n ? in[i] : 0u;
+    const u32 incl = wave_incl_scan(c);
+    if (lane == 63u) wtot[wv] = incl;
+    __syncthreads();
+    u32 before = 0;
+#pragma unroll
+    for (u32 w = 0; w < 16u; ++w) before += w < wv ? wtot[w] : 0u;
+    if (i < n) out[i] = before + incl - c;
+    if (threadIdx.x == 1023u) bsum[blockIdx.x] = before + incl;
+}
+__global__ __launch_bounds__(1024) void count_scan_b_kernel(u32* __restrict__ out, u32 n, const u32* __restrict__ bsum) {
+    __shared__ u32 part[16];
+    __shared__ u32 s_before;
+    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
+    u32 t = 0;
+    for (u32 b = threadIdx.x; b < blockIdx.x; b += 1024u) t += bsum[b];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += (u32)__shfl_xor((int)t, d, 64);
+    if (lane == 0) part[wv] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 a = 0; for (u32 w = 0; w < 16u; ++w) a += part[w]; s_before = a; }
+    __syncthreads();
+    const u32 i = blockIdx.x * 1024u + threadIdx.x;
+    if (i < n && blockIdx.x) out[i] += s_before;
 }
 
 // =====================================================================================
@@ -1594,18 +1766,18 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
     hipLaunchKernelGGL(band_bounds_kernel, dim3(n_tiles * n_bands), dim3(256), 0, st, mat, s, n_tiles, rb, lo, hi);
 }
 
-size_t sketch_wave_lds_bytes() { return 4 * (size_t)(kSketchCap * 8 + kSketchCap + 64); }
 constexpr int kSketchSmallHashes = 256;  // hash slots per read of the in-range fast variant
+static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketchCap + 64); }
 
-hipError_t launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
-                              u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                              const u32* filt, u32 filt_shift, u32* retry, u64 n_bases, u32* chk) {
+hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
+                         u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
+                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk) {
     if (n_reads == 0) return hipSuccess;
-    const size_t lds = sketch_wave_lds_bytes();
-    const size_t lds_small = 4 * (size_t)(kSketchSmallHashes * 8 + kSketchCap + 64);
+    const size_t lds = sketch_wave_lds(kSketchCap), lds_small = sketch_wave_lds(kSketchSmallHashes);
     dim3 grid(cdiv(n_reads, 4));
-#define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, kSketchCap, IR>
-#define SKX_SK_SMALL(KT) sketch_wave_kernel<KT, kSketchCap, kSketchSmallHashes, true>
+#define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, IR>
+#define SKX_SK_SMALL(KT) sketch_wave_kernel<KT, kSketchSmallHashes, true>
+#define SKX_BLK(KT, IR) sketch_block_kernel<KT, IR>
     // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU).  The attribute belongs to the (function,
     // device) pair and handles on different devices may be driven from different threads: one latch per device.
     {
@@ -1616,51 +1788,52 @@ hipError_t launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* o
         if (e != hipSuccess) return e;
         std::lock_guard<std::mutex> lock(mu);
         if (dev < 0 || dev >= 256 || !((done[dev >> 6] >> (dev & 63)) & 1ull)) {
-            const void* fns[] = {(const void*)&SKX_SK(16, false), (const void*)&SKX_SK(16, true),
-                                 (const void*)&SKX_SK(0, false), (const void*)&SKX_SK(0, true)};
-            for (const void* f : fns) {
+            const void* wave_fns[] = {(const void*)&SKX_SK(16, false), (const void*)&SKX_SK(16, true),
+                                      (const void*)&SKX_SK(0, false), (const void*)&SKX_SK(0, true)};
+            for (const void* f : wave_fns) {
                 e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            const void* blk_fns[] = {(const void*)&SKX_BLK(16, false), (const void*)&SKX_BLK(16, true),
+                                     (const void*)&SKX_BLK(0, false), (const void*)&SKX_BLK(0, true)};
+            for (const void* f : blk_fns) {
+                e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLds);
                 if (e != hipSuccess) return e;
             }
             if (dev >= 0 && dev < 256) done[dev >> 6] |= 1ull << (dev & 63);
         }
     }
-#define SKX_SK_LAUNCH(KERNEL, LDS, FLAGGED)                                                                      \
-    hipLaunchKernelGGL((KERNEL), (FLAGGED) ? dim3(std::min<u32>(cdiv(n_reads, 4), 256u)) : grid, dim3(256), LDS, st, bases, \
-                       offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, FLAGGED, retry, filt,    \
-                       filt_shift, n_bases, chk)
-    if (inrange_only && !retry) {  // no retry list: everything through the full-size variant
-        if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, true), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, true), lds, 0u);
-    } else if (inrange_only) {
-        // fast variant first (full occupancy); reads it flags are redone with the full-size hash buffer
-        if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); }
-        else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); }
+    const dim3 list_grid(std::min<u32>(cdiv(n_reads, 4), 256u)), blk_grid(std::min<u32>(n_reads, 256u));
+#define SKX_SK_LAUNCH(KERNEL, LDS, FROM_LIST)                                                                              \
+    hipLaunchKernelGGL((KERNEL), (FROM_LIST) ? list_grid : grid, dim3(256), LDS, st, bases, offsets, n_reads, k, seed, s, \
+                       max_ref, out_sk, sk_stride, out_len, out_cnt_in, FROM_LIST, retry, big, filt, filt_shift, n_bases, chk)
+#define SKX_BLK_LAUNCH(KERNEL)                                                                                         \
+    hipLaunchKernelGGL((KERNEL), blk_grid, dim3(1024), kBigLds, st, bases, offsets, big, k, seed, s, max_ref, out_sk, \
+                       sk_stride, out_len, out_cnt_in, filt, filt_shift)
+    if (inrange_only) {
+        // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
+        // does not fit goes to the block sketcher -- both through device-side lists, usually empty
+        if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); SKX_BLK_LAUNCH(SKX_BLK(16, true)); }
+        else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); SKX_BLK_LAUNCH(SKX_BLK(0, true)); }
     } else {
-        if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u);
+        if (k == 16) { SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); SKX_BLK_LAUNCH(SKX_BLK(16, false)); }
+        else { SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u); SKX_BLK_LAUNCH(SKX_BLK(0, false)); }
     }
+#undef SKX_BLK_LAUNCH
 #undef SKX_SK_LAUNCH
+#undef SKX_BLK
 #undef SKX_SK_SMALL
 #undef SKX_SK
     return hipGetLastError();
 }
 
-void launch_long_read_hash(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* long_idx, u32 n_long, u32 k,
-                           u64 seed, u64 max_ref, bool inrange_only, uint8_t* codes, u64* hbuf, u32* seg_begin,
-                           u32* seg_end, u64 off0) {
-    if (n_long == 0) return;
-#define SKX_LR(KT, IR) hipLaunchKernelGGL((long_read_hash_kernel<KT, IR>), dim3(n_long), dim3(1024), 0, st, bases, offsets, \
-                                          long_idx, k, seed, max_ref, codes, hbuf, seg_begin, seg_end, off0)
-    if (k == 16) { if (inrange_only) SKX_LR(16, true); else SKX_LR(16, false); }
-    else { if (inrange_only) SKX_LR(0, true); else SKX_LR(0, false); }
-#undef SKX_LR
+void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum) {
+    if (n == 0) return;
+    const u32 nb = cdiv(n, 1024);
+    hipLaunchKernelGGL(count_scan_a_kernel, dim3(nb), dim3(1024), 0, st, in, out, n, bsum);
+    if (nb > 1) hipLaunchKernelGGL(count_scan_b_kernel, dim3(nb), dim3(1024), 0, st, out, n, bsum);
 }
-void launch_long_read_finish(hipStream_t st, const u64* sorted, const u32* long_idx, u32 n_long, const u32* seg_begin,
-                             const u32* seg_end, u32 s, u64 max_ref, u64* out_sk, u32 sk_stride, u32* out_len,
-                             u32* out_cnt_in) {
-    if (n_long == 0) return;
-    hipLaunchKernelGGL(long_read_finish_kernel, dim3(n_long), dim3(256), 0, st, sorted, long_idx, seg_begin, seg_end, s,
-                       max_ref, out_sk, sk_stride, out_len, out_cnt_in);
-}
+
 void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
                          u32 p_base, u64* pair_h, u32* pair_r) {
     if (r_end <= r_begin) return;
@@ -1737,8 +1910,8 @@ void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim
     hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk,
                        cnt_tail);
 }
-void launch_publish(hipStream_t st, u32* chk, u32* retry, const u32* total_pairs, u32* h_pub, u32 seq) {
-    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, st, chk, retry, total_pairs, h_pub, seq);
+void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, st, chk, retry, big, total_pairs, h_pub, seq);
 }
 void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values) {
     if (n == 0) return;

@@ -387,6 +387,13 @@ def test_push_device_errors_leave_the_table_alone(gpu):
         _push_device(S_small, bases, offsets, 1)
     assert e.value.code == _lib.ERR_CAPACITY
     assert S.reads == 0 and not S.table().any()
+    # n_bases is what the caller vouches for from offsets[0] on: offsets reaching past it are refused, not followed
+    d_b, d_o = api.DeviceBuffer.from_numpy(bases), api.DeviceBuffer.from_numpy(offsets)
+    with pytest.raises(_lib.SketchyHipError) as e:
+        S.push_device(d_b.ptr, d_o.ptr, 20, int(offsets[10]), None, None)
+    assert e.value.code == _lib.ERR_INVALID
+    d_b.free(); d_o.free()
+    assert S.reads == 0 and not S.table().any()
     _push_device(S, bases, offsets, 1)  # the stream is still usable
     assert S.reads == 20
 
