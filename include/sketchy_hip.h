@@ -50,6 +50,7 @@ extern "C" {
 
 #define SKX_MAX_K 32u             /* k-mer length 1..32 (sketchy default 16, src/cli.rs:39-41) */
 #define SKX_MAX_TOP 64u           /* rows ranked per read (sketchy default 1, src/cli.rs:118-119) */
+#define SKX_MAX_SPECIES 64u       /* reference collections resident together in one skx_ref */
 
 typedef struct skx_ref skx_ref;
 typedef struct skx_stream skx_stream;
@@ -71,23 +72,38 @@ int skx_device_info(int device, char *name, size_t name_cap, int *compute_units,
  */
 int skx_ref_create(skx_ref **out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
                    const uint64_t *hashes, const uint32_t *col_len);
+/*
+ * Several reference collections ("species": one sketch file each, src/sketchy.rs:81-82) resident together and scored
+ * in ONE pass per batch.  The reference binary takes one sketch file per `predict` run, so a multi-species deployment
+ * runs one predict per species over the same reads; here every read is sketched once and scanned against all of them,
+ * and every species keeps its own running table and its own (sum desc, index asc) ranking.  All collections share
+ * k, seed and s (the read sketch depends on them).  hashes[sp] / col_len[sp] are laid out as for skx_ref_create.
+ * Everywhere below, "n_genomes" of such a reference is the total over its species and genome-indexed arrays
+ * (running table, per_read_shared, skx_common_hashes) hold the species one after the other; ranked rows come per
+ * species, with genome indices local to the species.
+ */
+int skx_ref_create_multi(skx_ref **out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_species,
+                         const uint32_t *n_genomes, const uint64_t *const *hashes, const uint32_t *const *col_len);
 int skx_ref_n_genomes(const skx_ref *ref, uint32_t *n_genomes);
+int skx_ref_n_species(const skx_ref *ref, uint32_t *n_species);
+int skx_ref_species_genomes(const skx_ref *ref, uint32_t species, uint32_t *n_genomes);
 /* bytes of reference hashes one scoring pass streams from HBM (8*s*n_genomes) */
 int skx_ref_pass_bytes(const skx_ref *ref, uint64_t *bytes);
 void skx_ref_destroy(skx_ref *ref);
 
 /* ---- streaming predictor ----------------------------------------------------------- */
 /*
- * top_k: rows ranked after every read, 0..min(n_genomes, SKX_MAX_TOP) (0 = no per-read ranking,
- * table only).  max_batch_reads / max_batch_bases bound one skx_stream_push call.
+ * top_k: rows ranked after every read (per species), 0..min(genomes of the smallest species, SKX_MAX_TOP)
+ * (0 = no per-read ranking, table only).  max_batch_reads / max_batch_bases bound one skx_stream_push call.
  */
 int skx_stream_create(skx_stream **out, const skx_ref *ref, uint32_t top_k, uint32_t max_batch_reads,
                       uint64_t max_batch_bases);
 /*
  * Consume n_reads reads: read r is the raw (un-normalised) ASCII bytes bases[offsets[r] .. offsets[r+1]).
  * Outputs are optional (NULL to skip), caller-allocated host arrays:
- *   topk_idx [n_reads][top_k]  genome indices after that read, order = (cumulative sum desc, index asc)
- *   topk_sum [n_reads][top_k]  the cumulative sums of those genomes after that read
+ *   topk_idx [n_reads][n_species][top_k]  genome indices (within the species) after that read, order =
+ *                                         (cumulative sum desc, index asc); n_species = 1 for skx_ref_create
+ *   topk_sum [n_reads][n_species][top_k]  the cumulative sums of those genomes after that read
  *   per_read_shared [n_reads][n_genomes]  this read's shared-hash count per genome (parity/debug)
  *   sketches [n_reads][s], sketch_len [n_reads]  the read's bottom-s sketch, ascending (parity/debug)
  * Synchronous: on return the running table includes these reads.
@@ -112,7 +128,7 @@ int skx_stream_table_add(skx_stream *st, const uint64_t *add);
 int skx_stream_reset(skx_stream *st);
 /* reads consumed so far (the reference's `read` counter minus one, src/sketchy.rs:327/:350) */
 int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
-/* rank the CURRENT table: first top_k of (sum desc, index asc); idx/sum are host arrays [top_k] */
+/* rank the CURRENT table: first top_k of (sum desc, index asc) per species; idx/sum are host arrays [n_species][top_k] */
 int skx_stream_rank(skx_stream *st, uint32_t top_k, uint32_t *idx, uint64_t *sum);
 void skx_stream_destroy(skx_stream *st);
 

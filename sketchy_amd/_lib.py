@@ -16,6 +16,7 @@ STAGE_NAMES = ("sketch", "dictionary", "scan", "transpose", "rank")
 COMM_ID_BYTES = 128
 MAX_K = 32
 MAX_TOP = 64
+MAX_SPECIES = 64
 
 # every symbol include/sketchy_hip.h declares: (name, restype, argtypes)
 _vp, _u32, _u64, _i, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_size_t
@@ -26,7 +27,10 @@ SYMBOLS = [
     ("skx_device_count", _i, []),
     ("skx_device_info", _i, [_i, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_u64)]),
     ("skx_ref_create", _i, [_pp, _i, _u32, _u64, _u32, _u32, _vp, _vp]),
+    ("skx_ref_create_multi", _i, [_pp, _i, _u32, _u64, _u32, _u32, _vp, _vp, _vp]),
     ("skx_ref_n_genomes", _i, [_vp, C.POINTER(_u32)]),
+    ("skx_ref_n_species", _i, [_vp, C.POINTER(_u32)]),
+    ("skx_ref_species_genomes", _i, [_vp, _u32, C.POINTER(_u32)]),
     ("skx_ref_pass_bytes", _i, [_vp, C.POINTER(_u64)]),
     ("skx_ref_destroy", None, [_vp]),
     ("skx_stream_create", _i, [_pp, _vp, _u32, _u32, _u64]),

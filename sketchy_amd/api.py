@@ -98,14 +98,17 @@ class SumOfSharedHashes:
         self._h = h
 
     def push(self, bases, offsets, want_shared=False, want_sketches=False):
-        """Consume a packed batch; returns dict(topk_idx, topk_sum[, shared, sketches, sketch_len])."""
+        """Consume a packed batch; returns dict(topk_idx, topk_sum[, shared, sketches, sketch_len]).  Rows are
+        [n_reads, top] for a single reference and [n_reads, n_species, top] (genome indices local to the species)
+        for a multi-species one; shared / table() hold the species one after the other."""
         L = _lib.load()
         bases = np.ascontiguousarray(bases, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         n = len(offsets) - 1
         out = {}
-        ti = np.zeros((n, self.top), np.uint32) if self.top else None
-        ts = np.zeros((n, self.top), np.uint64) if self.top else None
+        shape = (n, self.top) if self.ref.n_species == 1 else (n, self.ref.n_species, self.top)  # rows per species
+        ti = np.zeros(shape, np.uint32) if self.top else None
+        ts = np.zeros(shape, np.uint64) if self.top else None
         sh = np.zeros((n, self.ref.n_genomes), np.uint32) if want_shared else None
         sk = np.zeros((n, self.ref.s), np.uint64) if want_sketches else None
         sl = np.zeros(n, np.uint32) if want_sketches else None
@@ -141,7 +144,8 @@ class SumOfSharedHashes:
 
     def rank(self, top=None):
         top = self.top if top is None else int(top)
-        idx, sm = np.zeros(top, np.uint32), np.zeros(top, np.uint64)
+        shape = (top,) if self.ref.n_species == 1 else (self.ref.n_species, top)
+        idx, sm = np.zeros(shape, np.uint32), np.zeros(shape, np.uint64)
         _lib.check(_lib.load().skx_stream_rank(self._h, top, _p(idx), _p(sm)))
         return idx, sm
 

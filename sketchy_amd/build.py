@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsketchy_hip.so")
-SOURCES = ["skx_kernels.hip", "skx_prim.hip", "skx_capi.hip"]
+SOURCES = ["skx_kernels.hip", "skx_capi.hip"]
 ARCH = "gfx950"
 
 

@@ -117,8 +117,14 @@ SKX_API int skx_dev_synchronize(int device) {
 // ------------------------------------------------------------------ reference
 struct skx_ref {
     int device = 0;
-    u32 k = 0, s = 0, n_genomes = 0, n_tiles = 0, n_pad = 0, rb = 0, n_bands = 0;
+    u32 k = 0, s = 0, n_genomes = 0 /* real genomes, all species */, n_tiles = 0, n_pad = 0, rb = 0, n_bands = 0;
     u64 seed = 0;
+    // species (reference collections scanned together); each padded to whole rank groups of 512 genomes
+    u32 n_species = 0;
+    std::vector<u32> sp_n, sp_g0, sp_real0;  // real genomes / first padded index / first index in the caller's order
+    u32 min_species = 0;                     // smallest species (bounds top_k)
+    u32 *d_sp_g0 = nullptr, *d_sp_n = nullptr, *d_grp_sp = nullptr;
+    u32* d_real2pad = nullptr;               // [n_genomes] caller's genome index -> padded index
     u64* d_mat = nullptr;  // [n_tiles][s][256]
     u64 *d_lo = nullptr, *d_hi = nullptr;  // [n_bands * n_tiles]
     u64 max_ref = 0;       // largest hash in the matrix (queries above it cannot match)
@@ -130,6 +136,7 @@ struct skx_ref {
     u32* d_filt = nullptr;
     u32 filt_shift = 0;
     u64 filt_bits = 0;
+    skx::Species species() const { return skx::Species{d_sp_g0, d_sp_n, d_grp_sp, n_species}; }
 };
 
 static void ref_free(skx_ref* r) {
@@ -137,71 +144,115 @@ static void ref_free(skx_ref* r) {
     (void)hipSetDevice(r->device);
     (void)hipFree(r->d_mat); (void)hipFree(r->d_lo); (void)hipFree(r->d_hi);
     (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h); (void)hipFree(r->d_filt);
+    (void)hipFree(r->d_sp_g0); (void)hipFree(r->d_sp_n); (void)hipFree(r->d_grp_sp); (void)hipFree(r->d_real2pad);
     delete r;
 }
 
-SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
-                           const uint64_t* hashes, const uint32_t* col_len) {
-    if (!out || !hashes || !col_len) return fail(SKX_ERR_INVALID, "NULL argument");
+static const u32 kGroupGenomes = skx::kRankWords * 64u;  // 512: a species starts on a rank-group boundary
+
+SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_species,
+                                 const uint32_t* n_genomes, const uint64_t* const* hashes, const uint32_t* const* col_len) {
+    if (!out || !n_genomes || !hashes || !col_len) return fail(SKX_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (k < 1 || k > SKX_MAX_K) return fail(SKX_ERR_INVALID, "k=%u outside 1..%u", k, SKX_MAX_K);
-    if (s < 1 || n_genomes < 1) return fail(SKX_ERR_INVALID, "empty reference (s=%u, n_genomes=%u)", s, n_genomes);
+    if (n_species < 1 || n_species > SKX_MAX_SPECIES) return fail(SKX_ERR_INVALID, "n_species=%u outside 1..%u", n_species, SKX_MAX_SPECIES);
+    if (s < 1) return fail(SKX_ERR_INVALID, "empty reference (s=0)");
+    u64 total = 0, total_pad = 0;
+    for (u32 sp = 0; sp < n_species; ++sp) {
+        if (!hashes[sp] || !col_len[sp]) return fail(SKX_ERR_INVALID, "NULL argument (species %u)", sp);
+        if (n_genomes[sp] < 1) return fail(SKX_ERR_INVALID, "empty reference (species %u has no genomes)", sp);
+        total += n_genomes[sp];
+        total_pad += ((u64)n_genomes[sp] + kGroupGenomes - 1) / kGroupGenomes * kGroupGenomes;
+    }
+    if (total_pad >= (1ull << 31)) return fail(SKX_ERR_CAPACITY, "%llu genomes exceed what the kernels index", (unsigned long long)total);
     SKXCHK(use_device(device));
 
+    skx_ref* r = new skx_ref;
+    r->device = device; r->k = k; r->seed = seed; r->s = s; r->n_genomes = (u32)total; r->n_species = n_species;
+    r->n_pad = (u32)total_pad;
+    r->n_tiles = r->n_pad / skx::kTileGenomes;
+    r->rb = 64;  // rows per band (measured best of 64/128/256/512 on MI355X)
+    r->n_bands = (s + r->rb - 1) / r->rb;
+    r->min_species = 0xFFFFFFFFu;
+    {
+        u32 g0 = 0, real0 = 0;
+        for (u32 sp = 0; sp < n_species; ++sp) {
+            r->sp_n.push_back(n_genomes[sp]); r->sp_g0.push_back(g0); r->sp_real0.push_back(real0);
+            r->min_species = std::min(r->min_species, n_genomes[sp]);
+            g0 += (n_genomes[sp] + kGroupGenomes - 1) / kGroupGenomes * kGroupGenomes;
+            real0 += n_genomes[sp];
+        }
+    }
+
     // validate (the reference assumes ascending columns, src/sketchy.rs:416-418; here it is checked)
-    std::vector<u32> eff(n_genomes);
+    std::vector<u32> eff(total);
     std::vector<u32> exc_g;
     std::vector<u64> exc_h;
     u64 max_ref = 0;
     bool any = false;
-    for (u32 g = 0; g < n_genomes; ++g) {
-        const u32 len = col_len[g];
-        if (len > s) return fail(SKX_ERR_INVALID, "col_len[%u]=%u exceeds s=%u", g, len, s);
-        const uint64_t* col = hashes + (size_t)g * s;
-        for (u32 i = 1; i < len; ++i)
-            if (col[i] <= col[i - 1]) return fail(SKX_ERR_UNSORTED, "genome %u: hashes not strictly ascending at %u", g, i);
-        u32 e = len;
-        while (e > 0 && col[e - 1] >= skx::kEmpty) {  // would alias table markers: handled as exceptions
-            exc_g.push_back(g); exc_h.push_back(col[e - 1]); --e;
+    for (u32 sp = 0; sp < n_species; ++sp) {
+        for (u32 g = 0; g < n_genomes[sp]; ++g) {
+            const u32 len = col_len[sp][g];
+            if (len > s) { delete r; return fail(SKX_ERR_INVALID, "species %u: col_len[%u]=%u exceeds s=%u", sp, g, len, s); }
+            const uint64_t* col = hashes[sp] + (size_t)g * s;
+            for (u32 i = 1; i < len; ++i)
+                if (col[i] <= col[i - 1]) { delete r; return fail(SKX_ERR_UNSORTED, "species %u genome %u: hashes not strictly ascending at %u", sp, g, i); }
+            u32 e = len;
+            while (e > 0 && col[e - 1] >= skx::kEmpty) {  // would alias table markers: handled as exceptions
+                exc_g.push_back(r->sp_g0[sp] + g); exc_h.push_back(col[e - 1]); --e;
+            }
+            eff[r->sp_real0[sp] + g] = e;
+            if (e > 0) { any = true; max_ref = std::max<u64>(max_ref, col[e - 1]); }
         }
-        eff[g] = e;
-        if (e > 0) { any = true; max_ref = std::max<u64>(max_ref, col[e - 1]); }
     }
     if (!exc_h.empty()) { any = true; max_ref = std::max<u64>(max_ref, *std::max_element(exc_h.begin(), exc_h.end())); }
-
-    skx_ref* r = new skx_ref;
-    r->device = device; r->k = k; r->seed = seed; r->s = s; r->n_genomes = n_genomes;
-    r->n_tiles = (n_genomes + skx::kTileGenomes - 1) / skx::kTileGenomes;
-    r->n_pad = r->n_tiles * skx::kTileGenomes;
-    r->rb = 64;  // rows per band (measured best of 64/128/256/512 on MI355X)
-    r->n_bands = (s + r->rb - 1) / r->rb;
     r->max_ref = max_ref; r->any = any;
     r->n_exc = (u32)exc_h.size();
 
     hipError_t e;
-#define RCHK(expr) do { e = (expr); if (e != hipSuccess) { ref_free(r); return fail(SKX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
+    u32* d_eff = nullptr;
+    u64* d_stage = nullptr;
+#define RCHK(expr) do { e = (expr); if (e != hipSuccess) { (void)hipFree(d_eff); (void)hipFree(d_stage); ref_free(r); return fail(SKX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
     const size_t mat_elems = (size_t)r->n_tiles * s * skx::kTileGenomes;
     RCHK(hipMalloc(&r->d_mat, mat_elems * 8));
+    RCHK(hipMemset(r->d_mat, 0xFF, mat_elems * 8));  // kPad everywhere: short columns, padding genomes
     RCHK(hipMalloc(&r->d_lo, (size_t)r->n_bands * r->n_tiles * 8));
     RCHK(hipMalloc(&r->d_hi, (size_t)r->n_bands * r->n_tiles * 8));
-    u32* d_eff = nullptr;
-    RCHK(hipMalloc(&d_eff, (size_t)n_genomes * 4));
-    RCHK(hipMemcpy(d_eff, eff.data(), (size_t)n_genomes * 4, hipMemcpyHostToDevice));
+    RCHK(hipMalloc(&d_eff, (size_t)total * 4));
+    RCHK(hipMemcpy(d_eff, eff.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+    // species tables
+    {
+        const u32 n_grp = r->n_pad / kGroupGenomes;
+        std::vector<u32> grp_sp(n_grp), real2pad(total);
+        for (u32 sp = 0; sp < n_species; ++sp) {
+            const u32 g_end = sp + 1 < n_species ? r->sp_g0[sp + 1] : r->n_pad;
+            for (u32 grp = r->sp_g0[sp] / kGroupGenomes; grp < g_end / kGroupGenomes; ++grp) grp_sp[grp] = sp;
+            for (u32 g = 0; g < n_genomes[sp]; ++g) real2pad[r->sp_real0[sp] + g] = r->sp_g0[sp] + g;
+        }
+        RCHK(hipMalloc(&r->d_sp_g0, (size_t)n_species * 4));
+        RCHK(hipMalloc(&r->d_sp_n, (size_t)n_species * 4));
+        RCHK(hipMalloc(&r->d_grp_sp, (size_t)n_grp * 4));
+        RCHK(hipMalloc(&r->d_real2pad, (size_t)total * 4));
+        RCHK(hipMemcpy(r->d_sp_g0, r->sp_g0.data(), (size_t)n_species * 4, hipMemcpyHostToDevice));
+        RCHK(hipMemcpy(r->d_sp_n, r->sp_n.data(), (size_t)n_species * 4, hipMemcpyHostToDevice));
+        RCHK(hipMemcpy(r->d_grp_sp, grp_sp.data(), (size_t)n_grp * 4, hipMemcpyHostToDevice));
+        RCHK(hipMemcpy(r->d_real2pad, real2pad.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+    }
     // upload in chunks of whole tiles (bounded staging), re-tiling on the device
     const u32 chunk_tiles = std::max<u32>(1u, (u32)((256ull << 20) / ((size_t)skx::kTileGenomes * s * 8)));
     const u32 chunk_g = chunk_tiles * skx::kTileGenomes;
-    u64* d_stage = nullptr;
-    RCHK(hipMalloc(&d_stage, (size_t)std::min<u32>(chunk_g, r->n_pad) * s * 8));
-    for (u32 g0 = 0; g0 < n_genomes; g0 += chunk_g) {
-        const u32 cnt = std::min<u32>(chunk_g, n_genomes - g0);
-        RCHK(hipMemcpy(d_stage, hashes + (size_t)g0 * s, (size_t)cnt * s * 8, hipMemcpyHostToDevice));
-        const u32 cnt_pad = ((cnt + skx::kTileGenomes - 1) / skx::kTileGenomes) * skx::kTileGenomes;
-        skx::launch_ref_tile(nullptr, d_stage, d_eff, r->d_mat, s, g0, n_genomes, cnt_pad);
-        RCHK(hipGetLastError());
-        RCHK(hipDeviceSynchronize());
+    RCHK(hipMalloc(&d_stage, (size_t)chunk_g * s * 8));
+    for (u32 sp = 0; sp < n_species; ++sp) {
+        for (u32 g0 = 0; g0 < n_genomes[sp]; g0 += chunk_g) {  // (chunks start on tile boundaries of the padded order)
+            const u32 cnt = std::min<u32>(chunk_g, n_genomes[sp] - g0);
+            RCHK(hipMemcpy(d_stage, hashes[sp] + (size_t)g0 * s, (size_t)cnt * s * 8, hipMemcpyHostToDevice));
+            skx::launch_ref_tile(nullptr, d_stage, d_eff + r->sp_real0[sp] + g0, r->d_mat, s, r->sp_g0[sp] + g0, cnt);
+            RCHK(hipGetLastError());
+            RCHK(hipDeviceSynchronize());
+        }
     }
-    (void)hipFree(d_stage);
-    (void)hipFree(d_eff);
+    (void)hipFree(d_stage); d_stage = nullptr;
+    (void)hipFree(d_eff); d_eff = nullptr;
     skx::launch_band_bounds(nullptr, r->d_mat, s, r->n_tiles, r->rb, r->n_bands, r->d_lo, r->d_hi);
     RCHK(hipGetLastError());
     if (r->n_exc) {
@@ -212,7 +263,7 @@ SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed,
     }
     {
         // bitmap size: 64 bits per reference hash, between 2^16 and 2^33 bits (1 GB); shift so that max_ref fits
-        const u64 want = 64ull * s * n_genomes;
+        const u64 want = 64ull * s * total;
         u32 lg = 16;
         while (lg < 33 && (1ull << lg) < want) ++lg;
         const u32 max_bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
@@ -229,9 +280,27 @@ SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed,
     *out = r;
     return SKX_OK;
 }
+SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
+                           const uint64_t* hashes, const uint32_t* col_len) {
+    if (!out || !hashes || !col_len) return fail(SKX_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (s < 1 || n_genomes < 1) return fail(SKX_ERR_INVALID, "empty reference (s=%u, n_genomes=%u)", s, n_genomes);
+    return skx_ref_create_multi(out, device, k, seed, s, 1, &n_genomes, &hashes, &col_len);
+}
 SKX_API int skx_ref_n_genomes(const skx_ref* ref, uint32_t* n_genomes) {
     if (!ref || !n_genomes) return fail(SKX_ERR_INVALID, "NULL argument");
     *n_genomes = ref->n_genomes;
+    return SKX_OK;
+}
+SKX_API int skx_ref_n_species(const skx_ref* ref, uint32_t* n_species) {
+    if (!ref || !n_species) return fail(SKX_ERR_INVALID, "NULL argument");
+    *n_species = ref->n_species;
+    return SKX_OK;
+}
+SKX_API int skx_ref_species_genomes(const skx_ref* ref, uint32_t species, uint32_t* n_genomes) {
+    if (!ref || !n_genomes) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (species >= ref->n_species) return fail(SKX_ERR_INVALID, "species %u outside 0..%u", species, ref->n_species - 1);
+    *n_genomes = ref->sp_n[species];
     return SKX_OK;
 }
 SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
@@ -240,74 +309,6 @@ SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
     return SKX_OK;
 }
 SKX_API void skx_ref_destroy(skx_ref* ref) { ref_free(ref); }
-
-// ------------------------------------------------------------------ sketching (short + long reads)
-// scratch of the long-read path, allocated on first use
-struct LongWork {
-    uint8_t* d_codes = nullptr;
-    u64 *d_hbuf = nullptr, *d_hsorted = nullptr;
-    u32 *d_idx = nullptr, *d_sb = nullptr, *d_se = nullptr;
-    void* d_tmp = nullptr;
-    size_t tmp_bytes = 0;
-    u64 cap_bases = 0;
-    u32 cap_reads = 0;
-};
-static void long_free(LongWork& w) {
-    (void)hipFree(w.d_codes); (void)hipFree(w.d_hbuf); (void)hipFree(w.d_hsorted);
-    (void)hipFree(w.d_idx); (void)hipFree(w.d_sb); (void)hipFree(w.d_se); (void)hipFree(w.d_tmp);
-    w = LongWork();
-}
-static int long_ensure(LongWork& w, u64 bases, u32 reads) {
-    if (bases <= w.cap_bases && reads <= w.cap_reads) return SKX_OK;
-    long_free(w);
-    if (bases >= (1ull << 32)) return fail(SKX_ERR_CAPACITY, "a batch with long reads must hold fewer than 2^32 bases");
-    HIPCHK(hipMalloc(&w.d_codes, bases));
-    HIPCHK(hipMalloc(&w.d_hbuf, bases * 8));
-    HIPCHK(hipMalloc(&w.d_hsorted, bases * 8));
-    HIPCHK(hipMalloc(&w.d_idx, (size_t)reads * 4));
-    HIPCHK(hipMalloc(&w.d_sb, (size_t)reads * 4));
-    HIPCHK(hipMalloc(&w.d_se, (size_t)reads * 4));
-    w.tmp_bytes = skx::prim_segsort_tmp_bytes((u32)bases, reads) + 256;
-    HIPCHK(hipMalloc(&w.d_tmp, w.tmp_bytes));
-    w.cap_bases = bases; w.cap_reads = reads;
-    return SKX_OK;
-}
-
-// Sketch the reads of a device-resident batch that have more than kSketchCap k-mers (h_offsets = host copy of
-// d_offsets): block-per-read hashing into global segments, segmented sort, distinct / truncate.  The one-wave-per-read
-// kernel (launch_sketch_wave) skips exactly these reads.
-static int sketch_long(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
-                       const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
-                       bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt, bool* any_long = nullptr) {
-    const u64 lim = (u64)skx::kSketchCap + k - 1;
-    std::vector<u32> longs;
-    for (u32 r = 0; r < n_reads; ++r)
-        if (h_offsets[r + 1] - h_offsets[r] > lim) longs.push_back(r);
-    if (any_long) *any_long = !longs.empty();
-    if (longs.empty()) return SKX_OK;
-    const u64 n_bases = h_offsets[n_reads] - h_offsets[0];
-    SKXCHK(long_ensure(lw, std::max<u64>(cap_bases, n_bases), std::max<u32>(cap_reads, n_reads)));
-    const u32 nl = (u32)longs.size();
-    HIPCHK(hipMemcpyAsync(lw.d_idx, longs.data(), (size_t)nl * 4, hipMemcpyHostToDevice, hs));
-    HIPCHK(hipStreamSynchronize(hs));  // `longs` is a local
-    const u64 off0 = h_offsets[0];
-    skx::launch_long_read_hash(hs, d_bases, d_offsets, lw.d_idx, nl, k, seed, max_ref, inrange_only, lw.d_codes, lw.d_hbuf,
-                               lw.d_sb, lw.d_se, off0);
-    HIPCHK(hipGetLastError());
-    HIPCHK(skx::prim_segsort_u64(hs, lw.d_tmp, lw.tmp_bytes, lw.d_hbuf, lw.d_hsorted, (u32)n_bases, nl, lw.d_sb, lw.d_se));
-    skx::launch_long_read_finish(hs, lw.d_hsorted, lw.d_idx, nl, lw.d_sb, lw.d_se, s, max_ref, d_sk, sk_stride, d_len, d_cnt);
-    HIPCHK(hipGetLastError());
-    return SKX_OK;
-}
-// every read of the batch: short ones by the wave kernel, long ones as above
-static int sketch_all(hipStream_t hs, LongWork& lw, u64 cap_bases, u32 cap_reads, const uint8_t* d_bases,
-                      const u64* d_offsets, const u64* h_offsets, u32 n_reads, u32 k, u64 seed, u32 s, u64 max_ref,
-                      bool inrange_only, u64* d_sk, u32 sk_stride, u32* d_len, u32* d_cnt) {
-    HIPCHK(skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, k, seed, s, max_ref, inrange_only, d_sk, sk_stride, d_len,
-                                   d_cnt, nullptr, 0, nullptr, h_offsets[n_reads] - h_offsets[0], nullptr));
-    return sketch_long(hs, lw, cap_bases, cap_reads, d_bases, d_offsets, h_offsets, n_reads, k, seed, s, max_ref,
-                       inrange_only, d_sk, sk_stride, d_len, d_cnt);
-}
 
 // ------------------------------------------------------------------ stream
 struct TimedSpan { int stage; hipEvent_t a, b; };
@@ -339,7 +340,7 @@ struct skx_stream {
     u64* d_sk = nullptr;
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
     // pass workspace
-    u64 *d_pair_h = nullptr, *d_sorted = nullptr, *d_q[2] = {nullptr, nullptr};
+    u64 *d_pair_h = nullptr, *d_q[2] = {nullptr, nullptr};
     u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
     u32 *d_pair_r[2] = {nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[2] = {nullptr, nullptr};
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
@@ -356,11 +357,10 @@ struct skx_stream {
     u64 *d_cum = nullptr, *d_cum2 = nullptr;  // running table (current) and the buffer the next pass writes
     u32* d_topk_idx = nullptr;
     u64* d_topk_sum = nullptr;
-    void* d_tmp = nullptr;
-    size_t tmp_bytes = 0;
-    u64* d_tab_tmp = nullptr;   // [n_pad] staging of skx_stream_table_add
-    u32* d_rank_idx = nullptr;  // [SKX_MAX_TOP] / [SKX_MAX_TOP] outputs of skx_stream_rank
+    u64* d_tab_tmp = nullptr;   // [n_genomes] staging of skx_stream_table / skx_stream_table_add
+    u32* d_rank_idx = nullptr;  // [n_species][top] outputs of skx_stream_rank
     u64* d_rank_sum = nullptr;
+    u32 rank_cap = 0;
     u32* h_poff = nullptr;   // pinned
     u64* h_offsets = nullptr;  // pinned
     // |Q| / pairs of the most recent pass whose dictionary has finished: the host only knows the pair count of a
@@ -375,11 +375,13 @@ struct skx_stream {
     u32 pub_seq = 0;         // sequence number of the latest publish
     bool chk_dirty = false;  // a push failed between arming and publishing: re-zero the device-side counters first
     u32* d_retry = nullptr;  // [1 + max_reads] reads the fast sketch variant hands to the full-size one ([0] = count)
+    u32* d_big = nullptr;    // [1 + max_reads] reads the wave sketchers hand to the block sketcher ([0] = count)
+    u32* d_bsum = nullptr;   // block totals of the pair-count scan
+    u64 reads_big = 0;       // reads that went through the block sketcher so far (statistic)
     u32* h_nq = nullptr;     // pinned [2]
     u32 hint_pairs[2] = {0, 0};
     double nq_per_pair = 1.0;
     bool have_hint = false;  // false until one dictionary size has been seen
-    LongWork lw;
     // profiling
     int profiling = 0;  // 0 off, 1 every stage, 2 only the reference scan (the roofline kernel)
     std::vector<TimedSpan> spans;
@@ -394,13 +396,12 @@ static void stream_free(skx_stream* st) {
     if (st->hs0) (void)hipStreamSynchronize(st->hs0);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     if (st->hs2) (void)hipStreamSynchronize(st->hs2);
-    void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h, st->d_sorted,
+    void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h,
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
                     st->d_csum, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
-                    st->d_topk_sum, st->d_tmp, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum};
+                    st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_big, st->d_bsum};
     for (void* p : ptrs) (void)hipFree(p);
-    long_free(st->lw);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
@@ -444,6 +445,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     static const u64 pass_reads = getenv("SKX_PASS_READS") ? (u64)atoll(getenv("SKX_PASS_READS")) : 131072;
     u64 rp = std::min<u64>(max_reads, pass_reads);
     // candidate arrays of the ranking: per (read, rank group, row) for top_k <= 16, per (read, genome word, row) beyond
+    const u32 n_sp = ref->n_species;
     const u32 n_cand_units = (top_k >= 1 && top_k <= skx::rank_topk_fast_max()) ? (n_gw + skx::kRankWords - 1) / skx::kRankWords : n_gw;
     if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (4ull << 30) / ((u64)n_cand_units * top_k * 12)));
     rp = std::max<u64>(rp, 1);
@@ -479,7 +481,6 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_cnt, ((size_t)max_reads + 1) * 4));
     SCHK(hipMalloc(&st->d_poff, ((size_t)max_reads + 2) * 4));
     SCHK(hipMalloc(&st->d_pair_h, (size_t)st->pcap * 8));
-    SCHK(hipMalloc(&st->d_sorted, (size_t)st->pcap * 8));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_q[i], (size_t)st->pcap * 8));
     for (int i = 0; i < 2; ++i) {
         SCHK(hipMalloc(&st->d_pair_r[i], (size_t)st->pcap * 4));
@@ -498,27 +499,26 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
-    SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * std::max<u32>(top_k, 1) * 4 + 64));
-    SCHK(hipMalloc(&st->d_lead_val, (size_t)((n_seg_max + 15) / 16) * 8 + 64));
-    SCHK(hipMalloc(&st->d_lpart_sum, (size_t)((n_seg_max + 15) / 16) * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 8 + 64));
-    SCHK(hipMalloc(&st->d_lpart_idx, (size_t)((n_seg_max + 15) / 16) * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 4 + 64));
+    SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * n_sp * std::max<u32>(top_k, 1) * 4 + 64));
+    SCHK(hipMalloc(&st->d_lead_val, (size_t)((n_seg_max + 15) / 16) * n_sp * 8 + 64));
+    SCHK(hipMalloc(&st->d_lpart_sum, (size_t)((n_seg_max + 15) / 16) * n_sp * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 8 + 64));
+    SCHK(hipMalloc(&st->d_lpart_idx, (size_t)((n_seg_max + 15) / 16) * n_sp * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 4 + 64));
     SCHK(hipMalloc(&st->d_gmax, (size_t)((n_seg_max + 15) / 16 + 1) * (n_pad / 256) * 8 + 64));
     if (top_k) {
         SCHK(hipMalloc(&st->d_cand_sum, (size_t)st->rpass * n_cand_units * top_k * 8));
         SCHK(hipMalloc(&st->d_cand_idx, (size_t)st->rpass * n_cand_units * top_k * 4));
-        SCHK(hipMalloc(&st->d_topk_idx, (size_t)max_reads * top_k * 4));
-        SCHK(hipMalloc(&st->d_topk_sum, (size_t)max_reads * top_k * 8));
+        SCHK(hipMalloc(&st->d_topk_idx, (size_t)max_reads * n_sp * top_k * 4));
+        SCHK(hipMalloc(&st->d_topk_sum, (size_t)max_reads * n_sp * top_k * 8));
     }
     SCHK(hipMalloc(&st->d_cum, (size_t)n_pad * 8));
     SCHK(hipMemset(st->d_cum, 0, (size_t)n_pad * 8));
     SCHK(hipMalloc(&st->d_cum2, (size_t)n_pad * 8));
     SCHK(hipMemset(st->d_cum2, 0, (size_t)n_pad * 8));
-    st->tmp_bytes = std::max({skx::prim_scan_tmp_bytes(max_reads + 1), skx::prim_sort_tmp_bytes(st->pcap),
-                              skx::prim_unique_tmp_bytes(st->pcap)}) + 256;
-    SCHK(hipMalloc(&st->d_tmp, st->tmp_bytes));
-    SCHK(hipMalloc(&st->d_tab_tmp, (size_t)n_pad * 8));
-    SCHK(hipMalloc(&st->d_rank_idx, (size_t)ref->n_genomes * 4));  // skx_stream_rank takes any top_k up to n_genomes
-    SCHK(hipMalloc(&st->d_rank_sum, (size_t)ref->n_genomes * 8));
+    SCHK(hipMalloc(&st->d_tab_tmp, (size_t)ref->n_genomes * 8));
+    st->rank_cap = n_sp * std::max<u32>(SKX_MAX_TOP, top_k);
+    SCHK(hipMalloc(&st->d_rank_idx, (size_t)st->rank_cap * 4));
+    SCHK(hipMalloc(&st->d_rank_sum, (size_t)st->rank_cap * 8));
+    SCHK(hipMalloc(&st->d_bsum, ((size_t)max_reads / 1024 + 2) * 4));
     SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
     st->ht_slots = 1024;
@@ -538,6 +538,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMemset(st->d_chk, 0, 64));
     SCHK(hipMalloc(&st->d_retry, ((size_t)max_reads + 1) * 4));
     SCHK(hipMemset(st->d_retry, 0, 4));
+    SCHK(hipMalloc(&st->d_big, ((size_t)max_reads + 1) * 4));
+    SCHK(hipMemset(st->d_big, 0, 4));
     SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocCoherent));
     st->h_nq[0] = st->h_nq[1] = 0;
     // the zero-fills above ran on the null stream, which the (non-blocking) pipeline streams do not wait for
@@ -552,7 +554,7 @@ SKX_API int skx_stream_create(skx_stream** out, const skx_ref* ref, uint32_t top
     if (!out || !ref) return fail(SKX_ERR_INVALID, "NULL argument");
     *out = nullptr;
     // the reference slices result_vec[..top] and panics when top > N (src/sketchy.rs:391)
-    if (top_k > ref->n_genomes) return fail(SKX_ERR_INVALID, "top_k=%u exceeds n_genomes=%u", top_k, ref->n_genomes);
+    if (top_k > ref->min_species) return fail(SKX_ERR_INVALID, "top_k=%u exceeds n_genomes=%u", top_k, ref->min_species);
     if (top_k > SKX_MAX_TOP) return fail(SKX_ERR_INVALID, "top_k=%u exceeds SKX_MAX_TOP=%u", top_k, SKX_MAX_TOP);
     if (max_batch_reads < 1) return fail(SKX_ERR_INVALID, "max_batch_reads must be >= 1");
     // a read contributes at most min(s, #k-mers) hashes; short reads (<= kSketchCap k-mers) are the floor
@@ -613,6 +615,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
                     u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table) {
     const skx_ref* ref = st->ref;
     hipStream_t hs0 = st->hs0, hs = st->hs, hs2 = st->hs2;
+    const skx::Species spc = ref->species();
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64, n_reads = rb - ra;
     const u32 n_bt = ref->n_bands * ref->n_tiles;
     const u32 nq_rows = ((P + 63) / 64) * 64;  // rows per group of the group-major bit matrix of this pass
@@ -638,16 +641,9 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs0));
     if (P > 0) {
         Span sp(st, 1, hs0);
-        static const bool own_dict = !(getenv("SKX_DICT") && atoi(getenv("SKX_DICT")) == 0);
-        if (own_dict) {
-            skx::launch_dictionary(hs0, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r, st->d_ht,
-                                   st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
-                                   st->d_dict_ctr, d_q, d_nq);
-        } else {  // general-purpose path: radix sort of all pair hashes + unique
-            skx::launch_gather_pairs(hs0, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r);
-            HIPCHK(skx::prim_sort_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_pair_h, st->d_sorted, P));
-            HIPCHK(skx::prim_unique_u64(hs0, st->d_tmp, st->tmp_bytes, st->d_sorted, d_q, d_nq, P));
-        }
+        skx::launch_dictionary(hs0, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r, st->d_ht,
+                               st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
+                               st->d_dict_ctr, d_q, d_nq);
         skx::launch_pair_q(hs0, st->d_pair_h, P, d_q, d_nq, d_pair_q);
         skx::launch_window(hs0, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);  // (also hands |Q| to the host)
         st->hint_pairs[b] = P;
@@ -710,7 +706,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         skx::launch_seg_sum(hs2, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, st->d_inc);
         const bool ranked = st->top_k && d_topk_idx && d_topk_sum;
         const u32 prune_k = (ranked && st->top_k <= skx::rank_topk_fast_max()) ? st->top_k : 0u;
-        skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, ref->n_genomes, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, prune_k,
+        skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, prune_k,
                                st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
@@ -720,25 +716,24 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         const bool top1_fast = st->top_k == 1 && ref->s < (1u << 15) && !top1_wide_env;
         if (top1_fast && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
-                                      ref->n_genomes, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_inc,
+                                      spc, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_inc,
                                       st->d_leader, st->d_gmax, st->d_lead_val);
-            skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, d_topk_idx, d_topk_sum, ra);
+            skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, d_topk_idx, d_topk_sum, ra, spc);
         } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
             const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
-            skx::launch_rank_seg_topk(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, ref->n_genomes,
+            skx::launch_rank_seg_topk(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
                                       cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, st->d_inc, st->d_leader,
                                       st->d_gmax, st->d_lead_val);
-            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp * st->top_k, st->top_k, d_topk_idx,
-                                   d_topk_sum, ra);
+            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, ra, spc);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
-                                 ref->n_genomes, cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx);
-            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw * st->top_k, st->top_k, d_topk_idx,
-                                   d_topk_sum, ra);
+                                 spc, cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx);
+            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, skx::kRankWords, st->top_k, d_topk_idx,
+                                   d_topk_sum, ra, spc);
         }
     }
     if (d_shared)
-        skx::launch_shared_debug(hs2, d_pair_q, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, ref->n_genomes, d_shared, 0);
+        skx::launch_shared_debug(hs2, d_pair_q, d_poff, p_base, 0, n_reads, d_mq, nq_rows, ref->n_genomes, ref->d_real2pad, d_shared, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->ev_back[b], hs2));
     st->back_pending[b] = true;
@@ -769,6 +764,7 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
                          u64 n_bases, u32* d_topk_idx, u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
     const skx_ref* ref = st->ref;
     hipStream_t hs = st->hs0;  // sketching and everything the host reads back run on the first pipeline stream
+    (void)h_off;
     if (n_reads == 0) return SKX_OK;
     const bool inrange_only = !(h_sketches || h_sketch_len);  // production: only what can meet the reference is built
     const u64 max_ref = ref->any ? ref->max_ref : 0;
@@ -780,16 +776,6 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     // debug outputs) get the separate pass.
     // ... and the few words the host needs (offsets check, total pairs) are published to page-locked memory
     u32 seq = 0;
-    auto finish_counts = [&](bool filter_pass) -> int {
-        if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
-        if (filt && filter_pass)
-            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
-        HIPCHK(skx::prim_exclusive_scan_u32(hs, st->d_tmp, st->tmp_bytes, st->d_cnt, st->d_poff, n_reads + 1));
-        seq = ++st->pub_seq;
-        skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_poff + n_reads, st->h_chk, seq);
-        HIPCHK(hipGetLastError());
-        return SKX_OK;
-    };
     // spin on the published sequence number (looking at the stream now and then so a fault cannot hang the caller)
     auto wait_published = [&]() -> int {
         volatile u32* pub = st->h_chk;
@@ -810,24 +796,18 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     if (st->chk_dirty) {  // an earlier push failed half-way
         HIPCHK(hipMemsetAsync(st->d_chk, 0, 64, hs));
         HIPCHK(hipMemsetAsync(st->d_retry, 0, 4, hs));
+        HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
     }
     st->chk_dirty = true;
-    bool have_long = false;
     {
         Span sp(st, 0);
-        // offsets are looked at on the device in any case (cheap); it also zeroes entry n_reads of the pair counts
+        // offsets are looked at on the device (cheap); it also zeroes entry n_reads of the pair counts
         skx::launch_batch_check(hs, d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk, st->d_cnt + n_reads);
         if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
-        HIPCHK(skx::launch_sketch_wave(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
-                                       st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift,
-                                       inrange_only ? st->d_retry : nullptr, n_bases, st->d_chk));
-        if (h_off) {
-            SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, h_off, n_reads, ref->k,
-                               ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt,
-                               &have_long));
-        } else if (h_sketches || h_sketch_len) {
-            return fail(SKX_ERR_INVALID, "sketch outputs need host offsets");  // (not reachable through the ABI)
-        }
+        // every read, any length: wave sketchers, then the block sketcher for what overflowed (device-side lists)
+        HIPCHK(skx::launch_sketch(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
+                                  st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big, n_bases,
+                                  st->d_chk));
         // optional sketch outputs leave now: the filter compacts the rows in place
         if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
         if (h_sketches) {
@@ -835,34 +815,26 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             HIPCHK(hipMemcpy2DAsync(h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
                                     (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
         }
-        SKXCHK(finish_counts(have_long || !inrange_only));
+        // counts -> (filter, for rows the sketchers did not filter themselves) -> pair offsets; poff[n_reads] = total pairs
+        if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
+        if (filt && !inrange_only)
+            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
+        skx::launch_count_scan(hs, st->d_cnt, st->d_poff, n_reads + 1, st->d_bsum);
+        // ... and the few words the host needs (offsets check, total pairs) are published to page-locked memory
+        seq = ++st->pub_seq;
+        skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, seq);
+        HIPCHK(hipGetLastError());
     }
-    SKXCHK(wait_published());  // the one wait of a push without long reads: 36 bytes, no copy, no stream synchronisation
+    SKXCHK(wait_published());  // the one wait of a push: 36 bytes, no copy, no stream synchronisation
     if (h_sketches || h_sketch_len) HIPCHK(hipStreamSynchronize(hs));  // (debug outputs: their copies must have landed)
     st->chk_dirty = false;
-    if (!h_off) {
+    {
         u32 c[8];
         for (int i = 0; i < 8; ++i) c[i] = st->h_chk[i];
         if (c[0]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
         if (c[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases=%llu bytes given from offsets[0] on",
                               (unsigned long long)n_bases);
-        const u64 o_first = ((u64)c[3] << 32) | c[2], o_last = ((u64)c[5] << 32) | c[4];
-        if (o_last - o_first > st->max_bases)
-            return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu", (unsigned long long)(o_last - o_first),
-                        (unsigned long long)st->max_bases);
-        have_long = c[1] != 0;
-        if (have_long) {
-            // rare for short-read streams: fetch the offsets after all, sketch the long reads, redo the counts
-            HIPCHK(hipMemcpyAsync(st->h_offsets, d_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, hs));
-            HIPCHK(hipStreamSynchronize(hs));
-            Span sp(st, 0);
-            st->chk_dirty = true;
-            SKXCHK(sketch_long(hs, st->lw, st->max_bases, st->max_reads, d_bases, d_offsets, st->h_offsets, n_reads, ref->k,
-                               ref->seed, ref->s, max_ref, inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt));
-            SKXCHK(finish_counts(true));  // (the filter is idempotent on the rows that are already compacted)
-            SKXCHK(wait_published());
-            st->chk_dirty = false;
-        }
+        st->reads_big += c[7];
     }
     const u32 total_pairs = st->h_chk[8];
 
@@ -918,8 +890,9 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     SKXCHK(process_batch(st, st->d_bases, st->d_offsets, st->h_offsets, n_reads, n_bases, st->d_topk_idx, st->d_topk_sum,
                          per_read_shared, reinterpret_cast<u64*>(sketches), sketch_len));
     HIPCHK(hipStreamSynchronize(hs));  // sketch copies (first stream)
-    if (topk_idx) HIPCHK(hipMemcpyAsync(topk_idx, st->d_topk_idx, (size_t)n_reads * st->top_k * 4, hipMemcpyDeviceToHost, st->hs2));
-    if (topk_sum) HIPCHK(hipMemcpyAsync(topk_sum, st->d_topk_sum, (size_t)n_reads * st->top_k * 8, hipMemcpyDeviceToHost, st->hs2));
+    const size_t rows = (size_t)n_reads * st->ref->n_species * st->top_k;
+    if (topk_idx) HIPCHK(hipMemcpyAsync(topk_idx, st->d_topk_idx, rows * 4, hipMemcpyDeviceToHost, st->hs2));
+    if (topk_sum) HIPCHK(hipMemcpyAsync(topk_sum, st->d_topk_sum, rows * 8, hipMemcpyDeviceToHost, st->hs2));
     HIPCHK(hipStreamSynchronize(st->hs2));  // the rows are written by the back half
     if (st->profiling) collect_spans(st);
     return SKX_OK;
@@ -954,8 +927,11 @@ SKX_API int skx_stream_sync(skx_stream* st) {
 SKX_API int skx_stream_table(skx_stream* st, uint64_t* cum) {
     if (!st || !cum) return fail(SKX_ERR_INVALID, "NULL argument");
     SKXCHK(use_device(st->device));
-    // the running table belongs to the back stream
-    HIPCHK(hipMemcpyAsync(cum, st->d_cum, (size_t)st->ref->n_genomes * 8, hipMemcpyDeviceToHost, st->hs2));
+    // the running table belongs to the back stream; the caller sees the real genomes, species concatenated
+    const u32 n = st->ref->n_genomes;
+    skx::launch_gather_table(st->hs2, st->d_cum, st->d_tab_tmp, n, st->ref->d_real2pad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(cum, st->d_tab_tmp, (size_t)n * 8, hipMemcpyDeviceToHost, st->hs2));
     HIPCHK(hipStreamSynchronize(st->hs2));
     return SKX_OK;
 }
@@ -964,7 +940,7 @@ SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
     SKXCHK(use_device(st->device));
     const u32 n = st->ref->n_genomes;
     HIPCHK(hipMemcpyAsync(st->d_tab_tmp, add, (size_t)n * 8, hipMemcpyHostToDevice, st->hs2));
-    skx::launch_add_table(st->hs2, st->d_cum, st->d_tab_tmp, n);
+    skx::launch_add_table(st->hs2, st->d_cum, st->d_tab_tmp, n, st->ref->d_real2pad);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st->hs2));  // `add` is only borrowed for the call
     return SKX_OK;
@@ -986,12 +962,22 @@ SKX_API int skx_stream_reads(const skx_stream* st, uint64_t* n_reads) {
 }
 SKX_API int skx_stream_rank(skx_stream* st, uint32_t top_k, uint32_t* idx, uint64_t* sum) {
     if (!st || !idx || !sum) return fail(SKX_ERR_INVALID, "NULL argument");
-    if (top_k < 1 || top_k > st->ref->n_genomes) return fail(SKX_ERR_INVALID, "top_k=%u outside 1..n_genomes", top_k);
+    const skx_ref* ref = st->ref;
+    if (top_k < 1 || top_k > ref->min_species) return fail(SKX_ERR_INVALID, "top_k=%u outside 1..n_genomes", top_k);
     SKXCHK(use_device(st->device));
-    skx::launch_rank_table(st->hs2, st->d_cum, st->ref->n_genomes, top_k, st->d_rank_idx, st->d_rank_sum);
+    const size_t rows = (size_t)ref->n_species * top_k;
+    if (rows > st->rank_cap) {  // (beyond SKX_MAX_TOP rows per species: grow the scratch once)
+        HIPCHK(hipStreamSynchronize(st->hs2));
+        (void)hipFree(st->d_rank_idx); (void)hipFree(st->d_rank_sum);
+        st->d_rank_idx = nullptr; st->d_rank_sum = nullptr; st->rank_cap = 0;
+        HIPCHK(hipMalloc(&st->d_rank_idx, rows * 4));
+        HIPCHK(hipMalloc(&st->d_rank_sum, rows * 8));
+        st->rank_cap = (u32)rows;
+    }
+    skx::launch_rank_table(st->hs2, st->d_cum, ref->species(), top_k, st->d_rank_idx, st->d_rank_sum);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(idx, st->d_rank_idx, (size_t)top_k * 4, hipMemcpyDeviceToHost, st->hs2));
-    HIPCHK(hipMemcpyAsync(sum, st->d_rank_sum, (size_t)top_k * 8, hipMemcpyDeviceToHost, st->hs2));
+    HIPCHK(hipMemcpyAsync(idx, st->d_rank_idx, rows * 4, hipMemcpyDeviceToHost, st->hs2));
+    HIPCHK(hipMemcpyAsync(sum, st->d_rank_sum, rows * 8, hipMemcpyDeviceToHost, st->hs2));
     HIPCHK(hipStreamSynchronize(st->hs2));
     return SKX_OK;
 }
@@ -1013,8 +999,7 @@ SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, 
         if (r) longest = std::max<u64>(longest, offsets[r] - offsets[r - 1]);
     }
     const u32 stride = (u32)std::min<u64>(s, std::max<u64>(longest, 1));
-    uint8_t* d_b = nullptr; u64 *d_o = nullptr, *d_sk = nullptr; u32 *d_len = nullptr, *d_cnt = nullptr;
-    LongWork lw;
+    uint8_t* d_b = nullptr; u64 *d_o = nullptr, *d_sk = nullptr; u32 *d_len = nullptr, *d_cnt = nullptr, *d_lists = nullptr;
     int rc = SKX_OK;
     hipError_t e = hipSuccess;
     do {
@@ -1023,18 +1008,19 @@ SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, 
         if ((e = hipMalloc(&d_sk, (size_t)n_reads * stride * 8)) != hipSuccess) break;
         if ((e = hipMalloc(&d_len, (size_t)n_reads * 4)) != hipSuccess) break;
         if ((e = hipMalloc(&d_cnt, (size_t)n_reads * 4)) != hipSuccess) break;
+        if ((e = hipMalloc(&d_lists, 2 * ((size_t)n_reads + 1) * 4)) != hipSuccess) break;  // retry / big lists
         if (n_bases && (e = hipMemcpy(d_b, bases + base0, n_bases, hipMemcpyHostToDevice)) != hipSuccess) break;
         if ((e = hipMemcpy(d_o, off.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) break;
         if ((e = hipMemset(d_sk, 0, (size_t)n_reads * stride * 8)) != hipSuccess) break;
-        rc = sketch_all(nullptr, lw, n_bases, n_reads, d_b, d_o, off.data(), n_reads, k, seed, s, 0, false, d_sk, stride, d_len, d_cnt);
-        if (rc != SKX_OK) break;
+        if ((e = hipMemset(d_lists, 0, 2 * ((size_t)n_reads + 1) * 4)) != hipSuccess) break;
+        if ((e = skx::launch_sketch(nullptr, d_b, d_o, n_reads, k, seed, s, 0, false, d_sk, stride, d_len, d_cnt, nullptr, 0,
+                                    d_lists, d_lists + n_reads + 1, n_bases, nullptr)) != hipSuccess) break;
         memset(sketches, 0, (size_t)n_reads * s * 8);
         if ((e = hipMemcpy2D(sketches, (size_t)s * 8, d_sk, (size_t)stride * 8, (size_t)stride * 8, n_reads, hipMemcpyDeviceToHost)) != hipSuccess) break;
         if ((e = hipMemcpy(sketch_len, d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
     } while (0);
     if (e != hipSuccess) rc = fail(SKX_ERR_HIP, "skx_sketch_reads: %s", hipGetErrorString(e));
-    long_free(lw);
-    (void)hipFree(d_b); (void)hipFree(d_o); (void)hipFree(d_sk); (void)hipFree(d_len); (void)hipFree(d_cnt);
+    (void)hipFree(d_b); (void)hipFree(d_o); (void)hipFree(d_sk); (void)hipFree(d_len); (void)hipFree(d_cnt); (void)hipFree(d_lists);
     return rc;
 }
 
@@ -1157,7 +1143,8 @@ SKX_API int skx_stream_allreduce(skx_stream* st, skx_comm* comm) {
     if (comm->device != st->device) return fail(SKX_ERR_INVALID, "communicator and stream are on different devices");
     SKXCHK(use_device(st->device));
     // one sum all-reduce of the u64 table (8*N bytes: latency-bound); in place
-    ncclResult_t r = g_rccl.AllReduce(st->d_cum, st->d_cum, st->ref->n_genomes, ncclUint64, ncclSum, comm->comm, st->hs2);
+    // (the padded table: padding entries are 0 on every rank)
+    ncclResult_t r = g_rccl.AllReduce(st->d_cum, st->d_cum, st->ref->n_pad, ncclUint64, ncclSum, comm->comm, st->hs2);
     if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     HIPCHK(hipStreamSynchronize(st->hs2));
     return SKX_OK;

@@ -5,7 +5,9 @@
 //   sketch_wave_kernel     one wavefront per read: normalise, canonical k-mers, murmur3; of the hashes that can
 //                          match at all (<= largest reference hash) those some genome holds (membership bitmap)
 //                          are kept, sorted in LDS, deduplicated, truncated to s       (A3-A6 of SURVEY 8(a))
-//   long_read_* kernels    the same for reads with more k-mers than one wave's LDS holds
+//                          (reads of any length: chunked through the wave's LDS)
+//   sketch_block_kernel    one block per read whose hashes overflow a wave's buffer; full sketches of long sequences
+//   count_scan_a/b         exclusive scan of the per-read pair counts
 //   dict_* kernels         (read, hash) pairs + Q: the pass's sorted distinct query hashes (hash set + bucket sort)
 //   pair_q_kernel          pair -> index of its hash in Q
 //   window_kernel          per reference tile-band: the slice [qa,qb) of Q its hashes can meet
@@ -35,21 +37,22 @@ __host__ __device__ __forceinline__ size_t mq_index(u32 gw, u32 q, u32 nq_rows) 
 // =====================================================================================
 // dst[t][i][c] = (i < eff_len[g]) ? src[g*s + i] : kPad   with g = t*256 + c.
 // 32x32 LDS transpose so both sides are coalesced.  grid: (ceil(s/32), n_tile_genomes/32)
+// src / eff_len start at the chunk's first genome; that genome sits at padded index pad_base (species are padded to
+// whole rank groups; the matrix was filled with kPad beforehand, so only real genomes are written)
 __global__ __launch_bounds__(256) void ref_tile_kernel(const u64* __restrict__ src, const u32* __restrict__ eff_len,
-                                                       u64* __restrict__ dst, u32 s, u32 g_base, u32 n_genomes,
-                                                       u32 g_count) {
+                                                       u64* __restrict__ dst, u32 s, u32 pad_base, u32 g_count) {
     __shared__ u64 tile[32][33];
     const u32 tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;  // 32 x 8
     const u32 i0 = blockIdx.x * 32u, gl0 = blockIdx.y * 32u;  // gl: genome index local to this chunk
     for (u32 yy = ty; yy < 32u; yy += 8u) {
-        const u32 gl = gl0 + yy, g = g_base + gl, i = i0 + tx;
+        const u32 gl = gl0 + yy, i = i0 + tx;
         u64 v = kPad;
-        if (gl < g_count && g < n_genomes && i < s && i < eff_len[g]) v = src[(size_t)gl * s + i];
+        if (gl < g_count && i < s && i < eff_len[gl]) v = src[(size_t)gl * s + i];
         tile[yy][tx] = v;
     }
     __syncthreads();
     for (u32 yy = ty; yy < 32u; yy += 8u) {
-        const u32 i = i0 + yy, gl = gl0 + tx, g = g_base + gl;
+        const u32 i = i0 + yy, gl = gl0 + tx, g = pad_base + gl;
         if (i < s && gl < g_count) {
             const u32 t = g / kTileGenomes, c = g % kTileGenomes;
             dst[((size_t)t * s + i) * kTileGenomes + c] = tile[tx][yy];
@@ -661,22 +664,7 @@ __global__ __launch_bounds__(256) void filter_apply_kernel(u64* __restrict__ sk,
 // =====================================================================================
 // dictionary of the batch's query hashes
 // =====================================================================================
-// pair_h[p], pair_r[p] for p in [poff[r]-p_base, ...): the first cnt_in[r] hashes of read r's sketch
-__global__ void gather_pairs_kernel(const u64* __restrict__ sk, u32 sk_stride, const u32* __restrict__ poff,
-                                    u32 r_begin, u32 r_end, u32 p_base, u64* __restrict__ pair_h,
-                                    u32* __restrict__ pair_r) {
-    // one wave per read
-    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();
-    const u32 r = r_begin + wave;
-    if (r >= r_end) return;
-    const u32 a = poff[r], b = poff[r + 1];
-    for (u32 j = lane; j < b - a; j += 64u) {
-        pair_h[a - p_base + j] = sk[(size_t)r * sk_stride + j];
-        pair_r[a - p_base + j] = r - r_begin;
-    }
-}
-
-// ---- purpose-built dictionary (default; the rocPRIM sort + unique path remains behind SKX_DICT=0) ---------------
+// ---- purpose-built dictionary ----------------------------------------------------------------------------------
 // The surviving pairs of a pass repeat a few distinct hashes many times (C2 / B=98304: ~450 k pairs, ~11 k distinct),
 // and a general radix sort of all of them costs 16 launches on the front stream's critical path.  Instead:
 //   dict_insert   (fused with the pair gather) every pair hash goes into an open-addressing hash SET in HBM
@@ -1178,22 +1166,25 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
 // (row n_chunks: as the pass ends), lead_val[c] = the value of the k-th ranked genome as chunk c begins.  No genome of
 // the half group can be among the first k at any read of chunk c unless the best value at the END of the chunk reaches
 // lead_val[c] (sums never decrease; the k-th best never decreases either).
-__device__ __forceinline__ bool chunk_half_live(const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
-                                                u32 n_half, u32 c, u32 h) {
-    return h < n_half && gmax[(size_t)(c + 1u) * n_half + h] >= lead_val[c];
-}
+// Species: several reference collections share the matrix, each padded to whole rank groups; every species has its own
+// ranking, so the leaders / bounds are per (chunk, species): lead_val[c * n_sp + sp], leader[(c * n_sp + sp) * k + j].
+// sp.g0[sp] = first (padded) genome index, sp.n[sp] = real genomes, sp.of_grp[grp] = species of a rank group.
+// (struct Species: skx_kernels.hpp)
 __device__ __forceinline__ bool chunk_group_live(const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
-                                                 u32 n_half, u32 c, u32 grp) {
-    return chunk_half_live(gmax, lead_val, n_half, c, 2u * grp) || chunk_half_live(gmax, lead_val, n_half, c, 2u * grp + 1u);
+                                                 u32 n_half, u32 c, u32 grp, const Species& sp) {
+    const u64 lv = lead_val[c * sp.n_sp + sp.of_grp[grp]];
+    const u64* gm = gmax + (size_t)(c + 1u) * n_half + 2u * grp;  // (n_half = 2 x rank groups: n_pad is a multiple of 512)
+    return gm[0] >= lv || gm[1] >= lv;
 }
 // grid: (n_half, n_chunks + 1), 256 threads = 256 genomes (small blocks: they must find wave slots next to the front half)
 __global__ __launch_bounds__(256) void chunk_gmax_kernel(const u64* __restrict__ cum_in, const u64* __restrict__ cum_out,
                                                          const u32* __restrict__ csum, u32 n_chunks, u32 n_pad,
-                                                         u32 n_genomes, u32 n_half, u64* __restrict__ gmax) {
+                                                         u32 n_half, u64* __restrict__ gmax) {
     __shared__ u64 part[4];
     const u32 h = blockIdx.x, c = blockIdx.y, g = h * 256u + threadIdx.x;
-    u64 v = 0;
-    if (g < n_genomes) v = c < n_chunks ? cum_in[g] + csum[(size_t)c * n_pad + g] : cum_out[g];
+    // (padding genomes never score: their table entries and chunk sums are 0, which cannot raise a maximum)
+    const u64 v0 = c < n_chunks ? cum_in[g] + csum[(size_t)c * n_pad + g] : cum_out[g];
+    u64 v = v0;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v = max(v, shfl_xor64(v, d));
     if (lane_id() == 0) part[threadIdx.x >> 6] = v;
@@ -1234,12 +1225,12 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(u32* __restrict__ csu
 __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, const u32* __restrict__ csum,
                                                          u32 n_seg, u32 n_pad, u32* __restrict__ rel,
                                                          const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
-                                                         u32 n_half) {
+                                                         u32 n_half, Species sp) {
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
     // a (chunk, rank group) without any possible candidate is never looked at by the ranking: skip its start values
     // (both halves of a live group are written: the ranking reads the whole group)
-    if (gmax && !chunk_group_live(gmax, lead_val, n_half, c, blockIdx.x >> 1)) return;
+    if (gmax && !chunk_group_live(gmax, lead_val, n_half, c, blockIdx.x >> 1, sp)) return;
     const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
     u32 run = csum[(size_t)c * n_pad + g];
 #pragma unroll 16
@@ -1275,14 +1266,16 @@ __device__ __forceinline__ void wave_best(u64& sum, u32& idx, bool ok) {
 // kLeaderParts x top_k candidates.
 constexpr u32 kLeaderParts = 32;
 __global__ __launch_bounds__(256) void chunk_leader_part_kernel(const u64* __restrict__ cum_in, const u32* __restrict__ csum,
-                                                                 u32 n_pad, u32 n_genomes, u32 top_k,
+                                                                 u32 n_pad, Species sp, u32 top_k,
                                                                  u64* __restrict__ part_sum, u32* __restrict__ part_idx) {
     __shared__ u64 ssum[4];
     __shared__ u32 sidx[4];
     __shared__ u64 wsum;
     __shared__ u32 widx;
-    const u32 c = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const u32 per = (n_genomes + kLeaderParts - 1) / kLeaderParts, g_lo = part * per, g_hi = min(n_genomes, g_lo + per);
+    // blockIdx.x = chunk * n_sp + species: the arrays below are indexed by it directly
+    const u32 cs = blockIdx.x, c = cs / sp.n_sp, spi = cs % sp.n_sp, part = blockIdx.y, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 sp_lo = sp.g0[spi], sp_hi = sp_lo + sp.n[spi];
+    const u32 per = (sp.n[spi] + kLeaderParts - 1) / kLeaderParts, g_lo = min(sp_hi, sp_lo + part * per), g_hi = min(sp_hi, g_lo + per);
     u64 ps = 0; u32 pi = 0; bool first = true;
     for (u32 j = 0; j < top_k; ++j) {
         u64 bs = 0; u32 bi = 0xFFFFFFFFu;
@@ -1299,14 +1292,14 @@ __global__ __launch_bounds__(256) void chunk_leader_part_kernel(const u64* __res
             wave_best(s2, i2, i2 != 0xFFFFFFFFu);
             if (lane == 0) {
                 wsum = s2; widx = i2;
-                part_sum[((size_t)c * kLeaderParts + part) * top_k + j] = s2;
-                part_idx[((size_t)c * kLeaderParts + part) * top_k + j] = i2;  // 0xFFFFFFFF: the slice is exhausted
+                part_sum[((size_t)cs * kLeaderParts + part) * top_k + j] = s2;
+                part_idx[((size_t)cs * kLeaderParts + part) * top_k + j] = i2;  // 0xFFFFFFFF: the slice is exhausted
             }
         }
         __syncthreads();
         ps = wsum; pi = widx; first = widx == 0xFFFFFFFFu ? first : false;
         if (widx == 0xFFFFFFFFu) {  // nothing left in this slice: the remaining rounds are empty too
-            for (u32 jj = j + 1; jj < top_k && tid == 0; ++jj) part_idx[((size_t)c * kLeaderParts + part) * top_k + jj] = 0xFFFFFFFFu;
+            for (u32 jj = j + 1; jj < top_k && tid == 0; ++jj) part_idx[((size_t)cs * kLeaderParts + part) * top_k + jj] = 0xFFFFFFFFu;
             break;
         }
         __syncthreads();
@@ -1338,7 +1331,7 @@ __global__ __launch_bounds__(64) void chunk_leader_merge_kernel(const u64* __res
 __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ pair_r,
                                                        const u32* __restrict__ poff, u32 p_base, u32 r_begin,
                                                        u32 n_reads, u32 seg_len, const u64* __restrict__ mq,
-                                                       u32 n_gw, u32 n_pad, u32 n_genomes,
+                                                       u32 n_gw, u32 n_pad, Species sp,
                                                        const u64* __restrict__ cum_in, const u32* __restrict__ rel,
                                                        u32 top_k, u64* __restrict__ cand_sum,
                                                        u32* __restrict__ cand_idx, u32 nq_rows) {
@@ -1349,7 +1342,8 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g = gw * 64u + lane;
-    const bool real = g < n_genomes;
+    const u32 spi = sp.of_grp[gw / kRankWords];
+    const bool real = g < sp.g0[spi] + sp.n[spi];  // (padding genomes of the species' last groups never rank)
     u64 state = cum_in[g] + rel[(size_t)seg * n_pad + g];
     u32 cur = ra;  // next read to emit
 
@@ -1390,15 +1384,21 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
     while (cur < rz) { emit(cur); ++cur; }
 }
 
-// topk_merge: per read, merge the n_gw*top_k candidates into the final top_k.  One wave per read.
+// topk_merge: per (read, species), merge the species' candidates into the final top_k.  One wave per (read, species).
+// Candidates of read r: cand[(r * n_units + u) * top_k + j], u = rank group (pruned path, per_grp = 1) or genome word
+// (generic path, per_grp = kRankWords); a species owns the units of its rank groups.  Output rows hold genome indices
+// LOCAL to the species: out[((out_r0 + r) * n_sp + sp) * top_k + j].
 __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__ cand_sum,
-                                                         const u32* __restrict__ cand_idx, u32 n_reads, u32 n_cand,
-                                                         u32 top_k, u32* __restrict__ out_idx,
-                                                         u64* __restrict__ out_sum, u32 out_r0) {
-    const u32 r = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
+                                                         const u32* __restrict__ cand_idx, u32 n_reads, u32 n_units,
+                                                         u32 per_grp, u32 top_k, u32* __restrict__ out_idx,
+                                                         u64* __restrict__ out_sum, u32 out_r0, Species sp) {
+    const u32 w = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
+    const u32 r = w / sp.n_sp, spi = w % sp.n_sp;
     if (r >= n_reads) return;
-    const u64* cs = cand_sum + (size_t)r * n_cand;
-    const u32* ci = cand_idx + (size_t)r * n_cand;
+    const u32 g_lo = sp.g0[spi], grp0 = g_lo / (kRankWords * 64u), grp1 = (g_lo + sp.n[spi] + kRankWords * 64u - 1u) / (kRankWords * 64u);
+    const u32 n_cand = (grp1 - grp0) * per_grp * top_k;
+    const u64* cs = cand_sum + ((size_t)r * n_units + (size_t)grp0 * per_grp) * top_k;
+    const u32* ci = cand_idx + ((size_t)r * n_units + (size_t)grp0 * per_grp) * top_k;
     u64 ps = 0; u32 pi = 0; bool first = true;
     for (u32 j = 0; j < top_k; ++j) {
         u64 bs = 0; u32 bi = 0xFFFFFFFFu;
@@ -1410,8 +1410,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__
         }
         wave_best(bs, bi, bi != 0xFFFFFFFFu);
         if (lane == 0) {
-            out_idx[(size_t)(out_r0 + r) * top_k + j] = bi;
-            out_sum[(size_t)(out_r0 + r) * top_k + j] = bs;
+            out_idx[((size_t)(out_r0 + r) * sp.n_sp + spi) * top_k + j] = bi - g_lo;
+            out_sum[((size_t)(out_r0 + r) * sp.n_sp + spi) * top_k + j] = bs;
         }
         ps = bs; pi = bi; first = false;
     }
@@ -1440,7 +1440,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             const u32* __restrict__ poff, u32 p_base, u32 r_begin,
                                                             u32 n_reads, u32 seg_len /* == 64 */,
                                                             const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
-                                                            u32 n_genomes, const u64* __restrict__ cum_in,
+                                                            Species sp, const u64* __restrict__ cum_in,
                                                             const u32* __restrict__ rel,
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
                                                             u32 nq_rows, const u32* __restrict__ inc,
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     if (seg >= n_seg) return;
     const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
-    if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp)) {  // (its start values were not even written)
+    if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp, sp)) {  // (its start values were not even written)
         if (lane < rz - ra) {
             const size_t o = (size_t)grp * n_reads + ra + lane;
             best_sum[o] = 0;
@@ -1464,6 +1464,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         }
         return;
     }
+    const u32 spi = sp.of_grp[grp], sp_end = sp.g0[spi] + sp.n[spi];
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
     // Pruning (exact).  Sums never decrease and a genome ends the segment at start + inc, so with ANY lower bound
@@ -1474,7 +1475,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     // (the latter also keeps every start of the group <= lead, which the 32-bit keys need).  Once a sample has a
     // clear best match a handful of genomes are left: a group without any reports "none" straight away, and inside
     // a live group words without any are neither loaded nor counted.  Non-candidates (and padding) get value 0.
-    const u32 gl = leader[seg >> 4];  // (top_k == 1: one leader per chunk)
+    const u32 gl = leader[(seg >> 4) * sp.n_sp + spi];  // (top_k == 1: one leader per chunk and species)
     u64 lead = cum_in[gl] + rel[(size_t)seg * n_pad + gl];
     const u32 gain = pz - pa;
     u64 st0[NW];
@@ -1484,7 +1485,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const u32 g = g0 + (u32)j * 64u;
-        real[j] = g < n_genomes;  // also false for words past n_gw (n_genomes <= n_pad)
+        real[j] = g < sp_end;  // (padding genomes of the species' last group never rank)
         st0[j] = real[j] ? cum_in[g] + rel[(size_t)seg * n_pad + g] : 0;
         ic[j] = real[j] ? inc[(size_t)seg * n_pad + g] : 0;
         grp_best = max(grp_best, st0[j]);
@@ -1580,7 +1581,7 @@ constexpr u32 kTopkFast = 16;
 __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ pair_r,
                                                             const u32* __restrict__ poff, u32 p_base, u32 r_begin,
                                                             u32 n_reads, const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
-                                                            u32 n_genomes, const u64* __restrict__ cum_in,
+                                                            Species sp, const u64* __restrict__ cum_in,
                                                             const u32* __restrict__ rel, u32 top_k,
                                                             u64* __restrict__ cand_sum, u32* __restrict__ cand_idx,
                                                             u32 nq_rows, const u32* __restrict__ inc,
@@ -1593,7 +1594,7 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
     if (seg >= n_seg) return;
     const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
     const u32 ra = seg * 64u, rz = min(n_reads, ra + 64u);
-    if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp)) {  // (its start values were not even written)
+    if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp, sp)) {  // (its start values were not even written)
         if (lane < rz - ra) {
             const size_t o = ((size_t)(ra + lane) * n_grp + grp) * top_k;
             for (u32 j = 0; j < top_k; ++j) { cand_sum[o + j] = 0; cand_idx[o + j] = 0xFFFFFFFFu; }
@@ -1602,10 +1603,11 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
     }
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
-    // lower bound of the k-th best sum over the segment
+    // lower bound of the k-th best sum (of this group's species) over the segment
+    const u32 spi = sp.of_grp[grp], sp_end = sp.g0[spi] + sp.n[spi];
     u64 lead = ~0ull;
     for (u32 j = 0; j < top_k; ++j) {
-        const u32 gl = leader[(seg >> 4) * top_k + j];
+        const u32 gl = leader[((seg >> 4) * sp.n_sp + spi) * top_k + j];
         lead = min(lead, cum_in[gl] + rel[(size_t)seg * n_pad + gl]);
     }
     u64 sum[NW];
@@ -1614,7 +1616,7 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const u32 g = g0 + (u32)j * 64u;
-        const bool real = g < n_genomes;
+        const bool real = g < sp_end;
         sum[j] = real ? cum_in[g] + rel[(size_t)seg * n_pad + g] : 0;
         const u32 ic = real ? inc[(size_t)seg * n_pad + g] : 0;
         cand[j] = real && sum[j] + ic >= lead;
@@ -1683,37 +1685,42 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
     }
 }
 
-// merge for top_k == 1: one lane per read, walking the rank groups in index order.  grid: reads/256
+// merge for top_k == 1: one lane per (read, species), walking the species' rank groups in index order.
+// out[(out_r0 + r) * n_sp + sp] = (genome index local to the species, sum)
 __global__ __launch_bounds__(256) void top1_merge_kernel(const u64* __restrict__ best_sum,
-                                                         const u32* __restrict__ best_idx, u32 n_reads, u32 n_grp,
+                                                         const u32* __restrict__ best_idx, u32 n_reads,
                                                          u32* __restrict__ out_idx, u64* __restrict__ out_sum,
-                                                         u32 out_r0) {
-    const u32 r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n_reads) return;
+                                                         u32 out_r0, Species sp) {
+    const u32 t = blockIdx.x * 256u + threadIdx.x;
+    const u32 spi = t / n_reads, r = t % n_reads;  // (reads innermost: coalesced candidate loads)
+    if (spi >= sp.n_sp) return;
+    const u32 g_lo = sp.g0[spi], grp0 = g_lo / (kRankWords * 64u), grp1 = (g_lo + sp.n[spi] + kRankWords * 64u - 1u) / (kRankWords * 64u);
     u64 bs = 0; u32 bi = 0xFFFFFFFFu;
 #pragma unroll 8
-    for (u32 t = 0; t < n_grp; ++t) {
-        const u64 s_ = best_sum[(size_t)t * n_reads + r];
-        const u32 i_ = best_idx[(size_t)t * n_reads + r];
+    for (u32 grp = grp0; grp < grp1; ++grp) {
+        const u64 s_ = best_sum[(size_t)grp * n_reads + r];
+        const u32 i_ = best_idx[(size_t)grp * n_reads + r];
         // groups come in ascending index order: a later group wins only with a strictly larger sum
         if (i_ != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || s_ > bs)) { bs = s_; bi = i_; }
     }
-    out_idx[out_r0 + r] = bi;
-    out_sum[out_r0 + r] = bs;
+    out_idx[(size_t)(out_r0 + r) * sp.n_sp + spi] = bi - g_lo;
+    out_sum[(size_t)(out_r0 + r) * sp.n_sp + spi] = bs;
 }
 
-// rank the table itself: one block, top_k rounds.  (skx_stream_rank; also the all-reduced table)
-__global__ __launch_bounds__(1024) void rank_table_kernel(const u64* __restrict__ cum, u32 n_genomes, u32 top_k,
+// rank the table itself: one block per species, top_k rounds.  (skx_stream_rank; also the all-reduced table)
+// out[sp * top_k + j] = (genome index local to the species, sum)
+__global__ __launch_bounds__(1024) void rank_table_kernel(const u64* __restrict__ cum, Species sp, u32 top_k,
                                                           u32* __restrict__ out_idx, u64* __restrict__ out_sum) {
     __shared__ u64 ssum[16];
     __shared__ u32 sidx[16];
     __shared__ u64 wsum;
     __shared__ u32 widx;
-    const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6, spi = blockIdx.x;
+    const u32 g_lo = sp.g0[spi], g_hi = g_lo + sp.n[spi];
     u64 ps = 0; u32 pi = 0; bool first = true;
     for (u32 j = 0; j < top_k; ++j) {
         u64 bs = 0; u32 bi = 0xFFFFFFFFu;
-        for (u32 g = tid; g < n_genomes; g += 1024u) {
+        for (u32 g = g_lo + tid; g < g_hi; g += 1024u) {
             const u64 s_ = cum[g];
             if (!first && !ranks_before(ps, pi, s_, g)) continue;
             if (bi == 0xFFFFFFFFu || ranks_before(s_, g, bs, bi)) { bs = s_; bi = g; }
@@ -1724,7 +1731,7 @@ __global__ __launch_bounds__(1024) void rank_table_kernel(const u64* __restrict_
         if (wv == 0) {
             u64 s2 = lane < 16 ? ssum[lane] : 0; u32 i2 = lane < 16 ? sidx[lane] : 0xFFFFFFFFu;
             wave_best(s2, i2, i2 != 0xFFFFFFFFu);
-            if (lane == 0) { wsum = s2; widx = i2; out_idx[j] = i2; out_sum[j] = s2; }
+            if (lane == 0) { wsum = s2; widx = i2; out_idx[spi * top_k + j] = i2 - g_lo; out_sum[spi * top_k + j] = s2; }
         }
         __syncthreads();
         ps = wsum; pi = widx; first = false;
@@ -1733,23 +1740,30 @@ __global__ __launch_bounds__(1024) void rank_table_kernel(const u64* __restrict_
 }
 
 // parity/debug: shared[r][g] = sum over read r's pairs of bit(Mq[q][g]).  One block per read.
+// g runs over the n_real real genomes (species concatenated, no padding); real2pad maps it into the padded order.
 __global__ __launch_bounds__(256) void shared_debug_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                            u32 p_base, u32 r_begin, const u64* __restrict__ mq,
-                                                           u32 n_gw, u32 n_genomes, u32* __restrict__ shared,
-                                                           u32 out_r0, u32 nq_rows) {
+                                                           u32 n_real, const u32* __restrict__ real2pad,
+                                                           u32* __restrict__ shared, u32 out_r0, u32 nq_rows) {
     const u32 r = blockIdx.x;
     const u32 pa = poff[r_begin + r] - p_base, pz = poff[r_begin + r + 1] - p_base;
-    for (u32 g = threadIdx.x; g < n_genomes; g += 256u) {
+    for (u32 g = threadIdx.x; g < n_real; g += 256u) {
+        const u32 gp = real2pad[g];
         u32 acc = 0;
         for (u32 p = pa; p < pz; ++p)
-            acc += (u32)((mq[mq_index(g >> 6, pair_q[p], nq_rows)] >> (g & 63u)) & 1ull);
-        shared[(size_t)(out_r0 + r) * n_genomes + g] = acc;
+            acc += (u32)((mq[mq_index(gp >> 6, pair_q[p], nq_rows)] >> (gp & 63u)) & 1ull);
+        shared[(size_t)(out_r0 + r) * n_real + g] = acc;
     }
 }
 
-__global__ void add_table_kernel(u64* __restrict__ cum, const u64* __restrict__ add, u32 n) {
+// the table as the caller sees it (real genomes, species concatenated) <-> the padded table of the kernels
+__global__ void add_table_kernel(u64* __restrict__ cum, const u64* __restrict__ add, u32 n_real, const u32* __restrict__ real2pad) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n) cum[g] += add[g];
+    if (g < n_real) cum[real2pad[g]] += add[g];
+}
+__global__ void gather_table_kernel(const u64* __restrict__ cum, u64* __restrict__ out, u32 n_real, const u32* __restrict__ real2pad) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_real) out[g] = cum[real2pad[g]];
 }
 
 // =====================================================================================
@@ -1757,10 +1771,9 @@ __global__ void add_table_kernel(u64* __restrict__ cum, const u64* __restrict__ 
 // =====================================================================================
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
-void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 g_base, u32 n_genomes,
-                     u32 g_count) {
+void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 pad_base, u32 g_count) {
     dim3 grid(cdiv(s, 32), cdiv(g_count, 32));
-    hipLaunchKernelGGL(ref_tile_kernel, grid, dim3(256), 0, st, src, eff_len, dst, s, g_base, n_genomes, g_count);
+    hipLaunchKernelGGL(ref_tile_kernel, grid, dim3(256), 0, st, src, eff_len, dst, s, pad_base, g_count);
 }
 void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, u64* lo, u64* hi) {
     hipLaunchKernelGGL(band_bounds_kernel, dim3(n_tiles * n_bands), dim3(256), 0, st, mat, s, n_tiles, rb, lo, hi);
@@ -1834,12 +1847,6 @@ void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum
     if (nb > 1) hipLaunchKernelGGL(count_scan_b_kernel, dim3(nb), dim3(1024), 0, st, out, n, bsum);
 }
 
-void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
-                         u32 p_base, u64* pair_h, u32* pair_r) {
-    if (r_end <= r_begin) return;
-    hipLaunchKernelGGL(gather_pairs_kernel, dim3(cdiv(r_end - r_begin, 4)), dim3(256), 0, st, sk, sk_stride, poff,
-                       r_begin, r_end, p_base, pair_h, pair_r);
-}
 void launch_dictionary(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase,
                        u32* btot, u32* ctr, u64* q, u32* n_q) {
@@ -1930,7 +1937,7 @@ void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_ba
     hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv((u64)cdiv(n_grp, 8) * n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
                        r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
 }
-void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u32 n_genomes, const u64* cum_in, u64* cum_out,
+void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32 prune_top_k, u32* leader,
                        u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx) {
     const u32 n_chunks = cdiv(n_seg, 16);
@@ -1938,68 +1945,71 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u32
     hipLaunchKernelGGL(chunk_sum_kernel, grid, dim3(256), 0, st, inc, n_seg, n_pad, csum);
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, csum, n_chunks, n_pad, cum_in, cum_out);
     if (prune_top_k) {
-        // who leads as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
-        hipLaunchKernelGGL(chunk_leader_part_kernel, dim3(n_chunks, kLeaderParts), dim3(256), 0, st, cum_in, csum, n_pad,
-                           n_genomes, prune_top_k, part_sum, part_idx);
-        hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
+        // who leads (per species) as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
+        hipLaunchKernelGGL(chunk_leader_part_kernel, dim3(n_chunks * sp.n_sp, kLeaderParts), dim3(256), 0, st, cum_in, csum, n_pad,
+                           sp, prune_top_k, part_sum, part_idx);
+        hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
                            lead_val);
         hipLaunchKernelGGL(chunk_gmax_kernel, dim3(n_pad / 256, n_chunks + 1), dim3(256), 0, st, cum_in, cum_out, csum, n_chunks,
-                           n_pad, n_genomes, n_pad / 256, gmax);
+                           n_pad, n_pad / 256, gmax);
     }
     hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
-                       lead_val, n_pad / 256);
+                       lead_val, n_pad / 256, sp);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                      const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     hipLaunchKernelGGL(rank_seg_kernel, dim3(cdiv((u64)n_seg * n_gw, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, seg_len, mq, n_gw, n_pad, n_genomes, cum_in, rel, top_k, cand_sum,
+                       p_base, r_begin, n_reads, seg_len, mq, n_gw, n_pad, sp, cum_in, rel, top_k, cand_sum,
                        cand_idx, nq_rows);
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
                           const u64* lead_val) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, n_genomes, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader,
+                       p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, sp, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader,
                        gmax, lead_val);
 }
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
                           const u64* gmax, const u64* lead_val) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_topk_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
-                       p_base, r_begin, n_reads, mq, n_gw, n_pad, n_genomes, cum_in, rel, top_k, cand_sum, cand_idx, nq_rows,
+                       p_base, r_begin, n_reads, mq, n_gw, n_pad, sp, cum_in, rel, top_k, cand_sum, cand_idx, nq_rows,
                        inc, leader, gmax, lead_val);
 }
 u32 rank_topk_fast_max() { return kTopkFast; }
 u32 rank_leader_parts() { return kLeaderParts; }
-void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
-                       u64* out_sum, u32 out_r0) {
+void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32* out_idx, u64* out_sum,
+                       u32 out_r0, const Species& sp) {
     if (n_reads == 0) return;
-    hipLaunchKernelGGL(top1_merge_kernel, dim3(cdiv(n_reads, 256)), dim3(256), 0, st, best_sum, best_idx, n_reads,
-                       cdiv(n_gw, kRankWords), out_idx, out_sum, out_r0);
+    hipLaunchKernelGGL(top1_merge_kernel, dim3(cdiv((u64)n_reads * sp.n_sp, 256)), dim3(256), 0, st, best_sum, best_idx, n_reads,
+                       out_idx, out_sum, out_r0, sp);
 }
-void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_cand, u32 top_k,
-                       u32* out_idx, u64* out_sum, u32 out_r0) {
+void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_units, u32 per_grp,
+                       u32 top_k, u32* out_idx, u64* out_sum, u32 out_r0, const Species& sp) {
     if (n_reads == 0) return;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, cand_sum, cand_idx, n_reads,
-                       n_cand, top_k, out_idx, out_sum, out_r0);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(cdiv((u64)n_reads * sp.n_sp, 4)), dim3(256), 0, st, cand_sum, cand_idx, n_reads,
+                       n_units, per_grp, top_k, out_idx, out_sum, out_r0, sp);
 }
-void launch_rank_table(hipStream_t st, const u64* cum, u32 n_genomes, u32 top_k, u32* out_idx, u64* out_sum) {
-    hipLaunchKernelGGL(rank_table_kernel, dim3(1), dim3(1024), 0, st, cum, n_genomes, top_k, out_idx, out_sum);
+void launch_rank_table(hipStream_t st, const u64* cum, const Species& sp, u32 top_k, u32* out_idx, u64* out_sum) {
+    hipLaunchKernelGGL(rank_table_kernel, dim3(sp.n_sp), dim3(1024), 0, st, cum, sp, top_k, out_idx, out_sum);
 }
 void launch_shared_debug(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                         const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, u32* shared, u32 out_r0) {
+                         const u64* mq, u32 nq_rows, u32 n_real, const u32* real2pad, u32* shared, u32 out_r0) {
     if (n_reads == 0) return;
-    hipLaunchKernelGGL(shared_debug_kernel, dim3(n_reads), dim3(256), 0, st, pair_q, poff, p_base, r_begin, mq,
-                       n_pad / 64, n_genomes, shared, out_r0, nq_rows);
+    hipLaunchKernelGGL(shared_debug_kernel, dim3(n_reads), dim3(256), 0, st, pair_q, poff, p_base, r_begin, mq, n_real, real2pad,
+                       shared, out_r0, nq_rows);
 }
-void launch_add_table(hipStream_t st, u64* cum, const u64* add, u32 n) {
-    hipLaunchKernelGGL(add_table_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, cum, add, n);
+void launch_add_table(hipStream_t st, u64* cum, const u64* add, u32 n_real, const u32* real2pad) {
+    hipLaunchKernelGGL(add_table_kernel, dim3(cdiv(n_real, 256)), dim3(256), 0, st, cum, add, n_real, real2pad);
+}
+void launch_gather_table(hipStream_t st, const u64* cum, u64* out, u32 n_real, const u32* real2pad) {
+    hipLaunchKernelGGL(gather_table_kernel, dim3(cdiv(n_real, 256)), dim3(256), 0, st, cum, out, n_real, real2pad);
 }
 
 }  // namespace skx

@@ -1,5 +1,4 @@
-// skx_kernels.hpp -- launch wrappers of the gfx950 kernels (skx_kernels.hip) and of the
-// rocPRIM-backed dictionary primitives (skx_prim.hip).  Internal to libsketchy_hip.so.
+// skx_kernels.hpp -- launch wrappers of the gfx950 kernels (skx_kernels.hip).  Internal to libsketchy_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -13,32 +12,27 @@ constexpr int kSketchCap = 2048;   // k-mers per read the one-wave-per-read sket
 constexpr u32 kSegLen = 64;        // reads per ranking segment
 constexpr int kRankWords = 8;      // genome words (x64 genomes) per ranking wave = one 64-byte sector of Mq per pair
 
-// reference upload
-void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 g_base, u32 n_genomes,
-                     u32 g_count);
+// Species: several reference collections share one matrix, each padded to whole rank groups (512 genomes); every species
+// has its own ranking.  Device arrays: g0[sp] first padded genome index, n[sp] real genomes, of_grp[rank group] species.
+struct Species { const u32* g0; const u32* n; const u32* of_grp; u32 n_sp; };
+
+// reference upload: src / eff_len start at the chunk's first genome, which sits at padded index pad_base
+void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 pad_base, u32 g_count);
 void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, u64* lo, u64* hi);
 
-// sketching
-size_t sketch_wave_lds_bytes();
+// sketching: every read of the batch, any length -- one wave per read (256 hash slots, then 2048 for the reads that
+// overflow), then one block per read of what still does not fit (and, for full sketches, of every read with more than
+// kSketchCap k-mers); the hand-over runs through the device-side lists `retry` / `big` ([0] = count, zero on entry).
 // n_bases: bytes the caller vouches for from offsets[0] on; a read reaching outside is skipped and flagged in chk[6]
-// (chk may be NULL).  Returns the launch status (it also opts the big-LDS variants in, once per device).
-hipError_t launch_sketch_wave(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
-                              u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                              const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
-                              u32* retry /* [1 + n_reads], [0] zero on entry: reads the fast variant hands to the full one; or NULL */,
-                              u64 n_bases, u32* chk);
-
-// long reads: hash + append (phase 1), [segmented sort], distinct/truncate (phase 3)
-void launch_long_read_hash(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* long_idx, u32 n_long, u32 k,
-                           u64 seed, u64 max_ref, bool inrange_only, uint8_t* codes, u64* hbuf, u32* seg_begin,
-                           u32* seg_end, u64 off0);
-void launch_long_read_finish(hipStream_t st, const u64* sorted, const u32* long_idx, u32 n_long, const u32* seg_begin,
-                             const u32* seg_end, u32 s, u64 max_ref, u64* out_sk, u32 sk_stride, u32* out_len,
-                             u32* out_cnt_in);
+// (chk may be NULL).  Returns the launch status (it also opts the big-LDS kernels in, once per device).
+hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
+                         u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
+                         const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
+                         u32* retry /* [1 + n_reads] */, u32* big /* [1 + n_reads] */, u64 n_bases, u32* chk);
+// exclusive scan of n counts (out[i] = sum of in[0..i)); bsum: [ceil(n / 1024)] scratch
+void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum);
 
 // dictionary
-void launch_gather_pairs(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end,
-                         u32 p_base, u64* pair_h, u32* pair_r);
 void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q);
 // gather the pairs of reads [r_begin, r_end) AND build the sorted distinct dictionary q / n_q of their hashes.
 // ht: hash set of ht_slots (power of two, >= 2 x pairs) u64, all-ones between passes; slot_off: [ht_slots] scratch;
@@ -60,7 +54,8 @@ void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u
 // chk[0..5] (zeroed by the caller): non-monotonic marker, long-read count, offsets[0], offsets[n_reads]
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail /* zeroed */);
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
-void launch_publish(hipStream_t st, u32* chk, u32* retry, const u32* total_pairs, u32* h_pub, u32 seq);
+// ([7] = number of reads the block sketcher took; `big` is re-armed like `retry`)
+void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq);
 // membership filter over the union of the reference hashes (bitmap over hash >> shift)
 void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values);
 void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n_reads, const u32* bits, u32 shift);
@@ -71,44 +66,36 @@ void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_ba
 // prune_top_k > 0 (1..rank_topk_fast_max()): also find the first prune_top_k genomes as each chunk of 16 segments begins
 // (leader [n_chunks * k], lead_val [n_chunks]) and every half rank group's best value per chunk boundary (gmax
 // [(n_chunks + 1) * n_pad / 256]); start values are then only written for (chunk, group)s that can hold a candidate.
-void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u32 n_genomes, const u64* cum_in, u64* cum_out,
+void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel /* [n_seg][n_pad]: segment start values minus cum_in */, u32* csum, u32 prune_top_k,
-                       u32* leader, u64* lead_val, u64* gmax,
-                       u64* part_sum, u32* part_idx /* [n_chunks * rank_leader_parts() * k] scratch */);
+                       u32* leader /* [n_chunks * n_sp * k] */, u64* lead_val /* [n_chunks * n_sp] */, u64* gmax,
+                       u64* part_sum, u32* part_idx /* [n_chunks * n_sp * rank_leader_parts() * k] scratch */);
 u32 rank_leader_parts();
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                     u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                      const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx);
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
                           const u64* lead_val);
 // 2 <= top_k <= rank_topk_fast_max(): pruned, one wave per (rank group, segment);
 // cand_sum / cand_idx[(r * n_grp + grp) * top_k + j]
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
-                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, const u64* cum_in,
+                          u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
                           const u64* gmax, const u64* lead_val);
 u32 rank_topk_fast_max();
-void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32 n_gw, u32* out_idx,
-                       u64* out_sum, u32 out_r0);
-void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_cand, u32 top_k,
-                       u32* out_idx, u64* out_sum, u32 out_r0);
-void launch_rank_table(hipStream_t st, const u64* cum, u32 n_genomes, u32 top_k, u32* out_idx, u64* out_sum);
+// rows come out per (read, species) with genome indices local to the species: out[((out_r0 + r) * n_sp + sp) * top_k + j]
+void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32* out_idx, u64* out_sum,
+                       u32 out_r0, const Species& sp);
+// n_units candidates-units per read (rank groups: per_grp = 1; genome words: per_grp = kRankWords)
+void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_units, u32 per_grp,
+                       u32 top_k, u32* out_idx, u64* out_sum, u32 out_r0, const Species& sp);
+void launch_rank_table(hipStream_t st, const u64* cum, const Species& sp, u32 top_k, u32* out_idx /* [n_sp][top_k] */, u64* out_sum);
+// n_real real genomes (species concatenated); real2pad[g] = padded index
 void launch_shared_debug(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                         const u64* mq, u32 n_pad, u32 nq_rows, u32 n_genomes, u32* shared, u32 out_r0);
-void launch_add_table(hipStream_t st, u64* cum, const u64* add, u32 n);
-
-// rocPRIM-backed primitives (skx_prim.hip).  `tmp`/`tmp_bytes`: caller-provided scratch; each
-// *_tmp_bytes() returns what the matching call needs for up to `n` items.
-size_t prim_scan_tmp_bytes(u32 n);
-hipError_t prim_exclusive_scan_u32(hipStream_t st, void* tmp, size_t tmp_bytes, const u32* in, u32* out, u32 n);
-size_t prim_sort_tmp_bytes(u32 n);
-hipError_t prim_sort_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32 n);
-size_t prim_unique_tmp_bytes(u32 n);
-hipError_t prim_unique_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32* n_out, u32 n);
-size_t prim_segsort_tmp_bytes(u32 n, u32 n_seg);
-hipError_t prim_segsort_u64(hipStream_t st, void* tmp, size_t tmp_bytes, const u64* in, u64* out, u32 n, u32 n_seg,
-                            const u32* seg_begin, const u32* seg_end);
+                         const u64* mq, u32 nq_rows, u32 n_real, const u32* real2pad, u32* shared, u32 out_r0);
+void launch_add_table(hipStream_t st, u64* cum, const u64* add, u32 n_real, const u32* real2pad);
+void launch_gather_table(hipStream_t st, const u64* cum, u64* out, u32 n_real, const u32* real2pad);
 
 }  // namespace skx

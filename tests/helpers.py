@@ -33,3 +33,20 @@ def assert_stream_equal(got, exp, top, what=""):
     if got.get("sketches") is not None and exp.get("sketches") is not None:
         np.testing.assert_array_equal(got["sketch_len"], exp["sketch_len"], err_msg=f"{what} sketch_len")
         np.testing.assert_array_equal(got["sketches"], exp["sketches"], err_msg=f"{what} sketches")
+
+
+def workload_species(sizes, s, n_reads, read_len=1500, k=16, seed=0, genome_len=0, rng_seed=1, err=0.05, lognormal_sigma=0.0,
+                     max_len=50000):
+    """Several species (reference collections with unrelated ancestors) and ONE read stream sampled from all of their
+    ancestors, shuffled: (refs [list of make_reference dicts], bases, offsets)."""
+    refs = [synth.make_reference(n, s, k=k, hash_seed=seed, genome_len=genome_len, rng_seed=rng_seed + 17 * i, device="numpy")
+            for i, n in enumerate(sizes)]
+    per = [n_reads // len(sizes) + (1 if i < n_reads % len(sizes) else 0) for i in range(len(sizes))]
+    reads = []
+    for i, (r, m) in enumerate(zip(refs, per)):
+        b, o = synth.make_reads(r["genome"], m, read_len, err=err, rng_seed=rng_seed + 1000 + i, lognormal_sigma=lognormal_sigma,
+                                max_len=max_len)
+        reads += unpack_reads(b, o)
+    order = np.random.default_rng(rng_seed).permutation(len(reads))
+    bases, offsets = pack_reads([reads[i] for i in order])
+    return refs, bases, offsets

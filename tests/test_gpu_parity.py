@@ -304,6 +304,19 @@ def test_dense_reference_most_read_hashes_in_range(gpu):
     check(ref, bases, offsets, top=1)
 
 
+def test_dense_reference_long_reads_take_the_block_sketcher(gpu):
+    """Long reads against a reference that covers most of the hash space: thousands of in-range hashes per read, more
+    than a wave's 2048 slots -- the production (in-range) sketch path hands them to the block sketcher, which must
+    compact mid-read (16 384 slots) and, with s = 20 000 > 12 288, select in two passes."""
+    from sketchy_amd import synth
+    ref = synth.make_reference(12, 20000, genome_len=30000, rng_seed=181, device="numpy")
+    bases, offsets = synth.make_reads(ref["genome"], 12, 9000, err=0.02, rng_seed=182, lognormal_sigma=0.8, min_len=300, max_len=29000)
+    assert np.diff(offsets.astype(np.int64)).max() > 18000
+    got, exp, _, _ = check(ref, bases, offsets, top=1, want_sketches=False, want_shared=True)
+    assert exp["shared"].max() > 2048
+    check(ref, bases, offsets, top=2)
+
+
 def test_leader_changes_mid_pass_and_ties(gpu):
     """The per-read top-1 replay prunes genomes that cannot lead within a 64-read segment, against a bound taken
     from the genome that led when the pass began.  Here the leader moves from one clone family to another in the
