@@ -316,7 +316,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
 // variant appended to `retry` -- usually none, and then the launch costs a few microseconds instead of one nearly
 // empty wave per read of the batch.
 template <int KT, int HCAP, bool INRANGE>
-__global__ __launch_bounds__(256) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
                                                           const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
                                                           u64 seed, u32 s, u64 max_ref, u64* __restrict__ out_sk,
                                                           u32 sk_stride, u32* __restrict__ out_len,

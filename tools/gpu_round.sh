@@ -1,8 +1,10 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/gpu_round.sh <tag> [pytest args...]  -- the GPU test suite, then the default bench
+# usage (GPU box, repo root): tools/gpu_round.sh <tag> [pytest args...]  -- the GPU test suite, then the default bench (+ c4)
 TAG=$1; shift
 mkdir -p gpurun_out
-timeout 1500 python3 -m pytest tests -m gpu -x -q "$@" > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log
-tail -15 gpurun_out/${TAG}_pytest.log
+timeout 2400 python3 -m pytest tests -m gpu -x -q "$@" > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log
+tail -25 gpurun_out/${TAG}_pytest.log
 timeout 600 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 cat gpurun_out/${TAG}_bench.json; tail -5 gpurun_out/${TAG}_bench.err
+timeout 900 python3 bench.py --config c4 --steps 8 --warmup 2 > gpurun_out/${TAG}_bench_c4.json 2> gpurun_out/${TAG}_bench_c4.err; echo "bench c4 rc=$?"
+cat gpurun_out/${TAG}_bench_c4.json; tail -5 gpurun_out/${TAG}_bench_c4.err
