@@ -422,8 +422,10 @@ static void stream_free(skx_stream* st) {
     delete st;
 }
 
+// pair_hint: pairs (read, hash some genome holds) a read is expected to contribute at most; sizes the pass workspace
+// (a batch with more than it can hold is cut into several passes -- correct at any size)
 static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_k, u32 max_reads, u64 max_bases,
-                                  u32 sk_stride) {
+                                  u32 sk_stride, u32 pair_hint) {
     SKXCHK(use_device(ref->device));
     skx_stream* st = new skx_stream;
     st->ref = ref; st->device = ref->device; st->top_k = top_k; st->max_reads = max_reads; st->max_bases = max_bases;
@@ -435,10 +437,10 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     size_t mem_free = 0, mem_total = 0;
     (void)hipMemGetInfo(&mem_free, &mem_total);
     static const u64 pass_mb_env = getenv("SKX_PASS_MB") ? (u64)atoll(getenv("SKX_PASS_MB")) : 0;
-    const u64 pass_mb = pass_mb_env ? pass_mb_env : std::min<u64>(8192, std::max<u64>(256, (u64)(mem_free >> 20) / 32));
+    const u64 pass_mb = pass_mb_env ? pass_mb_env : std::min<u64>(16384, std::max<u64>(256, (u64)(mem_free >> 20) / 16));
     u64 pc = (pass_mb << 20) * 8 / n_pad;
     pc = std::min<u64>(pc, max_reads > 65536 ? (1u << 22) : (1u << 20));
-    pc = std::min<u64>(pc, (u64)max_reads * sk_stride);  // a read contributes at most sk_stride pairs
+    pc = std::min<u64>(pc, (u64)max_reads * std::min<u32>(sk_stride, pair_hint));  // (a read contributes at most sk_stride pairs)
     pc = std::max<u64>(pc, sk_stride);
     pc = (pc + 63) / 64 * 64;
     st->pcap = (u32)pc;
@@ -561,7 +563,9 @@ SKX_API int skx_stream_create(skx_stream** out, const skx_ref* ref, uint32_t top
     const u64 longest = std::max<u64>(max_batch_bases, (u64)skx::kSketchCap);
     const u32 sk_stride = (u32)std::min<u64>(ref->s, longest);
     if (max_batch_bases >= (1ull << 32)) return fail(SKX_ERR_CAPACITY, "max_batch_bases must be below 2^32");
-    return stream_create_internal(out, ref, top_k, max_batch_reads, max_batch_bases, sk_stride);
+    // real reads leave a handful of pairs each (C2: ~5 of ~1500 hashes are in range and held by some genome); 64 per read
+    // keeps small streams small, and denser batches simply take more passes
+    return stream_create_internal(out, ref, top_k, max_batch_reads, max_batch_bases, sk_stride, 64);
 }
 SKX_API void skx_stream_destroy(skx_stream* st) { stream_free(st); }
 
@@ -1037,7 +1041,7 @@ SKX_API int skx_common_hashes(const skx_ref* ref, const uint64_t* query, const u
         max_len = std::max(max_len, query_len[i]);
     }
     skx_stream* st = nullptr;
-    SKXCHK(stream_create_internal(&st, ref, 0, n_query, 1, max_len));
+    SKXCHK(stream_create_internal(&st, ref, 0, n_query, 1, max_len, max_len));  // (whole sketches: every hash is a pair)
     int rc = SKX_OK;
     do {
         // candidate prefix of every query: hashes <= max_ref (ascending rows)

@@ -839,13 +839,22 @@ __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __re
 // SPLIT those go (atomically) to m_bits and every word in between -- complete, owned by the lane -- is stored
 // plainly into m_int; the transpose ORs the two arrays.  Atomics cost a memory-side transaction each (~90 G/s),
 // plain stores into exclusively owned words a fraction of that; the two kinds never share a cache line.
+// FAST PROBE.  The general probe above is ~30 instructions per 8-byte element with two dependent LDS round trips and
+// a data-dependent walk loop, one element after the other -- at the HBM rate that is well over half of the chip's
+// VALU issue slots.  When no directory bucket of the slice holds more than two entries (checked while the directory
+// is built: at C2 a slice has ~70 entries in 2048 buckets, 1-2 % of the slices fail and take the general probe), an
+// element's match, if any, is slice[dir[bucket]] or its successor, so the probe is branch-free up to the hit and
+// eight elements go through it together: 8 bucket computations, 8 directory reads in flight, 8 pairs of entry reads in
+// flight, 16 compares.  Out-of-range elements (and the matrix padding) clamp to the last bucket, whose entries are the
+// end sentinels (kEmpty: no matrix cell holds it -- real hashes >= kEmpty live in the exception list, padding is kPad).
 template <int CAP, int ABLATE, bool SPLIT>
-__global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
+__global__ __launch_bounds__(256, 6) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                    const u64* __restrict__ q, const u32* __restrict__ win,
                                                    u64* __restrict__ m_bits, u64* __restrict__ m_int, u32 n_pad) {
     constexpr u32 kBuckets = CAP > 2048 ? 4096 : 2048;  // directory entries (power of two); CAP = 2040 -> 20 KB of LDS
-    __shared__ u64 slice[CAP + 1];
+    __shared__ u64 slice[CAP + 2];
     __shared__ unsigned short dir[kBuckets + 1];
+    __shared__ u32 deep;  // some bucket holds more than two entries: general probe
     const u32 bt = blockIdx.x;
     const u32 t = bt % n_tiles, b = bt / n_tiles, c = threadIdx.x;
     const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
@@ -863,15 +872,17 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
         const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
         const u32 shift = span_bits > (u32)__builtin_ctz(kBuckets) ? span_bits - (u32)__builtin_ctz(kBuckets) : 0u;
         for (u32 j = c; j < n; j += 256u) slice[j] = q[sub + j];
-        if (c == 0) slice[n] = kPad;
+        if (c == 0) { slice[n] = kEmpty; slice[n + 1] = kEmpty; deep = 0; }
         __syncthreads();
         for (u32 j = c; j <= n; j += 256u) {
             // entry j opens every bucket in (bucket(j-1), bucket(j)]; the sentinel closes the rest
             const u32 bj = j < n ? (u32)((slice[j] - lo) >> shift) : kBuckets;
             const u32 bp = j == 0 ? 0xFFFFFFFFu : (u32)((slice[j - 1] - lo) >> shift);
             for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned short)j;
+            if (j >= 2u && j < n && (u32)((slice[j - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
         }
         __syncthreads();
+        const bool fast = deep == 0u && ABLATE == 0;
 
         u32 cur_w = 0xFFFFFFFFu;  // absolute word index (q >> 6)
         u64 cur_bits = 0;
@@ -894,9 +905,33 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
             if (hv < lo || hv > hi) return;  // also drops the padding value
             u32 j = dir[(u32)((hv - lo) >> shift)];
             u64 e = slice[j];
-            while (e < hv) e = slice[++j];   // the sentinel (all ones) ends every walk
+            while (e < hv) e = slice[++j];   // the sentinel ends every walk (hv <= hi < kEmpty)
             if (ABLATE == 3) { cur_bits ^= e; return; }
             if (e == hv) hit(sub + j);
+        };
+        // eight elements at once, branch-free up to the hit (see FAST PROBE above)
+        auto probe8 = [&](const u64 (&h)[8]) {
+#pragma unroll
+            for (u32 v = 0; v < 8u; v += 4u) {  // (four at a time: the entry pairs of eight would cost two waves of occupancy)
+                u32 j[4];
+                u64 e0[4], e1[4];
+#pragma unroll
+                for (u32 u = 0; u < 4u; ++u) {
+                    const u64 d = h[v + u] - lo;
+                    // (shift >= 32 whenever the slice spans more than 2^43: one 32-bit shift of the high word)
+                    const u64 tq = d >> shift;
+                    j[u] = (u32)(tq >> 32) ? kBuckets : min((u32)tq, kBuckets);
+                }
+#pragma unroll
+                for (u32 u = 0; u < 4u; ++u) j[u] = dir[j[u]];
+#pragma unroll
+                for (u32 u = 0; u < 4u; ++u) { e0[u] = slice[j[u]]; e1[u] = slice[j[u] + 1u]; }
+#pragma unroll
+                for (u32 u = 0; u < 4u; ++u) {
+                    const bool h0 = e0[u] == h[v + u], h1 = e1[u] == h[v + u];
+                    if (h0 || h1) hit(sub + j[u] + (h1 ? 1u : 0u));
+                }
+            }
         };
         // software-pipelined: the next 8 rows are in flight while the current 8 are probed
         u32 i = 0;
@@ -908,13 +943,19 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
                 u64 hn[8];
 #pragma unroll
                 for (u32 u = 0; u < 8u; ++u) hn[u] = col[(size_t)(i + u) * kTileGenomes];
+                if (fast) probe8(h);
+                else {
 #pragma unroll
-                for (u32 u = 0; u < 8u; ++u) probe(h[u]);
+                    for (u32 u = 0; u < 8u; ++u) probe(h[u]);
+                }
 #pragma unroll
                 for (u32 u = 0; u < 8u; ++u) h[u] = hn[u];
             }
+            if (fast) probe8(h);
+            else {
 #pragma unroll
-            for (u32 u = 0; u < 8u; ++u) probe(h[u]);
+                for (u32 u = 0; u < 8u; ++u) probe(h[u]);
+            }
         }
         for (; i < rows; ++i) probe(col[(size_t)i * kTileGenomes]);
 
