@@ -374,6 +374,7 @@ struct skx_stream {
     u32* h_chk = nullptr;    // page-locked, coherent [16]: written by publish_kernel: d_chk, [8] = total pairs, [15] = sequence
     u32 pub_seq = 0;         // sequence number of the latest publish
     bool chk_dirty = false;  // a push failed between arming and publishing: re-zero the device-side counters first
+    u32* d_grp_any[2] = {nullptr, nullptr};  // [rank groups] per buffer set: the group's slice of the bit matrix holds any bit
     u32* d_retry = nullptr;  // [1 + max_reads] reads the fast sketch variant hands to the full-size one ([0] = count)
     u32* d_big = nullptr;    // [1 + max_reads] reads the wave sketchers hand to the block sketcher ([0] = count)
     u32* d_bsum = nullptr;   // block totals of the pair-count scan
@@ -400,7 +401,8 @@ static void stream_free(skx_stream* st) {
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
                     st->d_csum, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
-                    st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_big, st->d_bsum};
+                    st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_big, st->d_bsum, st->d_grp_any[0],
+                    st->d_grp_any[1]};
     for (void* p : ptrs) (void)hipFree(p);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
@@ -521,6 +523,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_rank_idx, (size_t)st->rank_cap * 4));
     SCHK(hipMalloc(&st->d_rank_sum, (size_t)st->rank_cap * 8));
     SCHK(hipMalloc(&st->d_bsum, ((size_t)max_reads / 1024 + 2) * 4));
+    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64)) * 4));
     SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
     st->ht_slots = 1024;
@@ -628,6 +631,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     u32 *d_pair_r = st->d_pair_r[b], *d_pair_q = st->d_pair_q[b], *d_poff = st->d_poff_pass[b];
     u32 *d_nq = st->d_nq[b], *d_win = st->d_win[b];
     u64 *d_mq = st->d_mq[b], *d_q = st->d_q[b];
+    u32* d_grp_any = st->d_grp_any[b];
 
     // |Q| per pair from the latest pass whose dictionary is known to be complete
     for (int i = 0; i < 2; ++i)
@@ -666,6 +670,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
 
     // ---- scan + transpose (stream hs, HBM-bound)
     HIPCHK(hipStreamWaitEvent(hs, st->ev_dict[b], 0));
+    HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)(n_pad / (skx::kRankWords * 64)) * 4, hs));  // raised by the transpose
     if (P > 0) {
         const u32 n_words = (P + 63) / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
@@ -695,7 +700,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         }
         {
             Span sp(st, 3, hs);
-            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq);
+            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq, d_grp_any);
         }
     }
     HIPCHK(hipGetLastError());
@@ -707,11 +712,11 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     if (update_table) {
         Span sp(st, 4, hs2);
         const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
-        skx::launch_seg_sum(hs2, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, st->d_inc);
+        skx::launch_seg_sum(hs2, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, st->d_inc, d_grp_any);
         const bool ranked = st->top_k && d_topk_idx && d_topk_sum;
         const u32 prune_k = (ranked && st->top_k <= skx::rank_topk_fast_max()) ? st->top_k : 0u;
         skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, prune_k,
-                               st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx);
+                               st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
         // the top-1 kernel keeps (value relative to the leader) in 23 bits of a 32-bit key: at most 2 x 64 x s + 1 per
@@ -721,17 +726,17 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         if (top1_fast && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
                                       spc, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_inc,
-                                      st->d_leader, st->d_gmax, st->d_lead_val);
+                                      st->d_leader, st->d_gmax, st->d_lead_val, d_grp_any);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, d_topk_idx, d_topk_sum, ra, spc);
         } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
             const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
             skx::launch_rank_seg_topk(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
                                       cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, st->d_inc, st->d_leader,
-                                      st->d_gmax, st->d_lead_val);
+                                      st->d_gmax, st->d_lead_val, d_grp_any);
             skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, ra, spc);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
-                                 spc, cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx);
+                                 spc, cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, d_grp_any);
             skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, skx::kRankWords, st->top_k, d_topk_idx,
                                    d_topk_sum, ra, spc);
         }

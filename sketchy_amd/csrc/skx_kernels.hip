@@ -160,6 +160,9 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     }
     const uint8_t* rd = bases + o0;
     const u64 lt = lanemask_lt();
+    // a long read is one wave's work for a long time (50 kb next to seven other waves on the SIMD: ~2 ms, longer than the
+    // rest of the batch takes): it goes first (two-phase launch below) and its wave gets issue priority
+    if (lraw > 4u * CAP) __builtin_amdgcn_s_setprio(2);
 
     u32 m = 0;  // hashes collected so far (any order: they are sorted afterwards)
     auto append = [&](bool valid, u64 h) -> bool {  // false: the hash buffer overflowed (read handed on)
@@ -311,10 +314,14 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         out_len[r] = min(outn, s);
         out_cnt_in[r] = (INRANGE && filt != nullptr) ? wrote : cin;
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 // from_list = 0: wave w of the grid sketches read w.  from_list = 1: a small fixed grid walks the reads an earlier
 // variant appended to `retry` -- usually none, and then the launch costs a few microseconds instead of one nearly
-// empty wave per read of the batch.
+// empty wave per read of the batch.  from_list = 2: like 0 with a grid twice as large, in two phases -- the first
+// half of the blocks (dispatched first) takes the reads with more than kSketchCap k-mers, the second half the others,
+// so that the long reads of a mixed-length batch start before the bulk instead of somewhere inside it (chk[1] =
+// number of such reads, counted by batch_check_kernel: without any the first half returns at once).
 template <int KT, int HCAP, bool INRANGE>
 __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
                                                           const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
@@ -325,8 +332,19 @@ __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_ke
                                                           const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
                                                           u32* __restrict__ chk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 w = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (!from_list) {
+    u32 w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (from_list == 2u) {
+        const u32 half = gridDim.x >> 1;
+        const bool long_phase = blockIdx.x < half;
+        if (!long_phase) w -= half * 4u;
+        if (long_phase && chk[1] == 0u) return;
+        if (w >= n_reads) return;
+        const u32 k = KT > 0 ? (u32)KT : k_rt;
+        const u64 o0 = offsets[w], o1 = offsets[w + 1];
+        const bool is_long = o1 >= o0 && o1 - o0 > (u64)kSketchCap + k - 1u;  // (the same test as batch_check_kernel's count)
+        if (is_long != long_phase) return;
+    }
+    if (from_list != 1u) {
         if (w < n_reads)
             sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
                                                out_cnt_in, retry, big, filt, filt_shift, n_bases, chk);
@@ -847,8 +865,8 @@ __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __re
 // eight elements go through it together: 8 bucket computations, 8 directory reads in flight, 8 pairs of entry reads in
 // flight, 16 compares.  Out-of-range elements (and the matrix padding) clamp to the last bucket, whose entries are the
 // end sentinels (kEmpty: no matrix cell holds it -- real hashes >= kEmpty live in the exception list, padding is kPad).
-template <int CAP, int ABLATE, bool SPLIT>
-__global__ __launch_bounds__(256, 6) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
+template <int CAP, int ABLATE, bool SPLIT, bool FAST = false>
+__global__ __launch_bounds__(256, FAST ? 6 : 1) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                    const u64* __restrict__ q, const u32* __restrict__ win,
                                                    u64* __restrict__ m_bits, u64* __restrict__ m_int, u32 n_pad) {
     constexpr u32 kBuckets = CAP > 2048 ? 4096 : 2048;  // directory entries (power of two); CAP = 2040 -> 20 KB of LDS
@@ -879,10 +897,10 @@ __global__ __launch_bounds__(256, 6) void scan_kernel(const u64* __restrict__ ma
             const u32 bj = j < n ? (u32)((slice[j] - lo) >> shift) : kBuckets;
             const u32 bp = j == 0 ? 0xFFFFFFFFu : (u32)((slice[j - 1] - lo) >> shift);
             for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned short)j;
-            if (j >= 2u && j < n && (u32)((slice[j - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
+            if (FAST && j >= 2u && j < n && (u32)((slice[j - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
         }
         __syncthreads();
-        const bool fast = deep == 0u && ABLATE == 0;
+        const bool fast = FAST && deep == 0u && ABLATE == 0;
 
         u32 cur_w = 0xFFFFFFFFu;  // absolute word index (q >> 6)
         u64 cur_bits = 0;
@@ -943,7 +961,7 @@ __global__ __launch_bounds__(256, 6) void scan_kernel(const u64* __restrict__ ma
                 u64 hn[8];
 #pragma unroll
                 for (u32 u = 0; u < 8u; ++u) hn[u] = col[(size_t)(i + u) * kTileGenomes];
-                if (fast) probe8(h);
+                if (FAST && fast) probe8(h);
                 else {
 #pragma unroll
                     for (u32 u = 0; u < 8u; ++u) probe(h[u]);
@@ -951,7 +969,7 @@ __global__ __launch_bounds__(256, 6) void scan_kernel(const u64* __restrict__ ma
 #pragma unroll
                 for (u32 u = 0; u < 8u; ++u) h[u] = hn[u];
             }
-            if (fast) probe8(h);
+            if (FAST && fast) probe8(h);
             else {
 #pragma unroll
                 for (u32 u = 0; u < 8u; ++u) probe(h[u]);
@@ -965,6 +983,160 @@ __global__ __launch_bounds__(256, 6) void scan_kernel(const u64* __restrict__ ma
             atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
         }
         __syncthreads();  // slice and directory are rebuilt by the next sub-window
+    }
+}
+
+// =====================================================================================
+// the reference scan, persistent form (default for sparse dictionaries)
+// =====================================================================================
+// scan_kernel above spends one short-lived block on every (band, tile): each pays the dependent loads of its window and
+// slice, the directory build and two barriers before its first matrix load is even requested, and its load pipeline
+// fills and drains inside 64 rows -- measured, 58 % of the wave cycles are waits and the pure stream in that geometry
+// runs at 0.57 ms against 0.515 ms for a flat copy.  Here a fixed grid of resident blocks walks the (band, tile) items
+// with stride gridDim.x and keeps ONE load pipeline running across them:
+//   * the unit of work is (item, sub-window of <= kStreamCap query hashes of its slice) -- one sub-window for the usual
+//     ~70-entry slice, several (the band re-streamed) for denser ones: any slice size is handled, just slower;
+//   * the next unit's slice is requested from Q when the current unit starts and its first 8 rows are requested before
+//     the current unit's last 8 are probed; at the unit border the block stores that slice into the OTHER table buffer,
+//     builds its (small: 1024 buckets) directory and flips buffers -- two barriers with the matrix loads in flight;
+//   * probing, hit bits and the atomicOr write-back of M are those of scan_kernel.
+constexpr u32 kStreamCap = 510;       // slice entries per table buffer (two per thread)
+constexpr u32 kStreamBuckets = 1024;  // directory entries per table buffer
+
+struct StreamUnit {
+    u32 bt;    // item = band * n_tiles + tile (>= n_bt: none left)
+    u32 sub;   // first query index of the sub-window
+    u32 n;     // entries of the sub-window
+    u32 qb;    // end of the item's slice
+};
+
+template <int ABLATE>
+__global__ __launch_bounds__(256) void scan_stream_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb, u32 n_bt,
+                                                          const u64* __restrict__ q, const u32* __restrict__ win,
+                                                          u64* __restrict__ m_bits, u32 n_pad) {
+    __shared__ u64 slice[2][kStreamCap + 2];
+    __shared__ unsigned short dir[2][kStreamBuckets + 1];
+    const u32 c = threadIdx.x;
+
+    // the unit after `u` (wave-uniform: scalar loads of the windows)
+    auto next_unit = [&](const StreamUnit& u) -> StreamUnit {
+        StreamUnit v = u;
+        if (u.bt < n_bt && u.sub + kStreamCap < u.qb) {  // next sub-window of the same item
+            v.sub = u.sub + kStreamCap;
+            v.n = min(kStreamCap, u.qb - v.sub);
+            return v;
+        }
+        u32 bt = u.bt < n_bt ? u.bt + gridDim.x : u.bt;
+        while (bt < n_bt) {
+            const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
+            if (qa < qb) { v.bt = bt; v.sub = qa; v.qb = qb; v.n = min(kStreamCap, qb - qa); return v; }
+            bt += gridDim.x;
+        }
+        v.bt = 0xFFFFFFFFu; v.n = 0;
+        return v;
+    };
+    // requests this thread's (up to two) entries of a unit's slice
+    auto fetch_slice = [&](const StreamUnit& u, u64& a, u64& b) {
+        a = (u.bt < n_bt && c < u.n) ? q[u.sub + c] : kEmpty;
+        b = (u.bt < n_bt && c + 256u < u.n) ? q[u.sub + 256u + c] : kEmpty;
+    };
+    // stores them and builds the directory of table buffer `tb` (both barriers inside)
+    auto build = [&](const StreamUnit& u, u32 tb, u64 a, u64 b, u64& lo, u64& hi, u32& shift) {
+        if (c < u.n) slice[tb][c] = a;
+        if (c + 256u < u.n) slice[tb][c + 256u] = b;
+        if (c == 0) { slice[tb][u.n] = kEmpty; slice[tb][u.n + 1u] = kEmpty; }
+        __syncthreads();
+        lo = slice[tb][0]; hi = slice[tb][u.n - 1u];
+        const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
+        shift = span_bits > (u32)__builtin_ctz(kStreamBuckets) ? span_bits - (u32)__builtin_ctz(kStreamBuckets) : 0u;
+        for (u32 j = c; j <= u.n; j += 256u) {
+            // entry j opens every bucket in (bucket(j-1), bucket(j)]; the sentinel closes the rest
+            const u32 bj = j < u.n ? (u32)((slice[tb][j] - lo) >> shift) : kStreamBuckets;
+            const u32 bp = j == 0 ? 0xFFFFFFFFu : (u32)((slice[tb][j - 1] - lo) >> shift);
+            for (u32 x = bp + 1u; x <= bj; ++x) dir[tb][x] = (unsigned short)j;
+        }
+        __syncthreads();
+    };
+    // rows [i, i + 8) of a unit's band for this lane's genome (rows past the band's end read as padding)
+    auto load8 = [&](const StreamUnit& u, u32 i, u64 (&h)[8]) {
+        const u32 t = u.bt % n_tiles, bnd = u.bt / n_tiles;
+        const u32 i0 = bnd * rb, rows = min(s, i0 + rb) - i0;
+        const u64* col = mat + ((size_t)t * s + i0) * kTileGenomes + c;
+#pragma unroll
+        for (u32 x = 0; x < 8u; ++x) h[x] = (i + x < rows) ? col[(size_t)(i + x) * kTileGenomes] : kPad;
+    };
+
+    StreamUnit cur;
+    cur.bt = 0xFFFFFFFFu; cur.sub = 0; cur.n = 0; cur.qb = 0;
+    {   // first unit of this block
+        u32 bt = blockIdx.x;
+        while (bt < n_bt) {
+            const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
+            if (qa < qb) { cur.bt = bt; cur.sub = qa; cur.qb = qb; cur.n = min(kStreamCap, qb - qa); break; }
+            bt += gridDim.x;
+        }
+    }
+    if (cur.bt >= n_bt) return;
+    u32 tb = 0;
+    u64 lo, hi;
+    u32 shift;
+    {
+        u64 a, b;
+        fetch_slice(cur, a, b);
+        build(cur, 0, a, b, lo, hi, shift);
+    }
+    u64 h[8];
+    load8(cur, 0, h);
+
+    while (cur.bt < n_bt) {
+        const StreamUnit nxt = next_unit(cur);
+        u64 na, nb;
+        fetch_slice(nxt, na, nb);  // lands while this unit streams
+        const u32 rows = min(s, (cur.bt / n_tiles) * rb + rb) - (cur.bt / n_tiles) * rb;
+        const u32 g = (cur.bt % n_tiles) * kTileGenomes + c;
+
+        u32 cur_w = 0xFFFFFFFFu;  // absolute word index (q >> 6)
+        u64 cur_bits = 0;
+        auto hit = [&](u32 qi) {
+            const u32 w = qi >> 6;
+            if (w != cur_w) {
+                if (ABLATE != 1 && cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
+                cur_w = w; cur_bits = 0;
+            }
+            cur_bits |= 1ull << (qi & 63u);
+        };
+        auto probe = [&](u64 hv) {
+            if (ABLATE == 2) { cur_bits ^= hv; return; }
+            if (hv < lo || hv > hi) return;  // also drops the padding value
+            u32 j = dir[tb][(u32)((hv - lo) >> shift)];
+            u64 e = slice[tb][j];
+            while (e < hv) e = slice[tb][++j];   // the sentinel ends every walk (hv <= hi < kEmpty)
+            if (ABLATE == 3) { cur_bits ^= e; return; }
+            if (e == hv) hit(cur.sub + j);
+        };
+        for (u32 i = 0; i < rows; i += 8u) {
+            u64 hn[8];
+            if (i + 8u < rows) load8(cur, i + 8u, hn);
+            else if (nxt.bt < n_bt) load8(nxt, 0, hn);  // the next unit's first rows are in flight across the border
+            else {
+#pragma unroll
+                for (u32 x = 0; x < 8u; ++x) hn[x] = kPad;
+            }
+#pragma unroll
+            for (u32 x = 0; x < 8u; ++x) probe(h[x]);
+#pragma unroll
+            for (u32 x = 0; x < 8u; ++x) h[x] = hn[x];
+        }
+        if (ABLATE >= 1) {
+            if (cur_bits == 0x123456789ull) m_bits[g] = cur_bits;  // keep the work alive
+        } else if (cur_bits) {
+            atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
+        }
+        if (nxt.bt < n_bt) {
+            build(nxt, tb ^ 1u, na, nb, lo, hi, shift);  // (its first barrier also ends every wave's use of buffer tb)
+            tb ^= 1u;
+        }
+        cur = nxt;
     }
 }
 
@@ -1019,9 +1191,11 @@ __device__ __forceinline__ u64 transpose64(u64 x, u32 lane) {
 constexpr u32 kWordsPerBlock = 4;
 // The kernel also restores the "all zero between passes" state of the word arrays (only words that were set are
 // written back): no memset of 2 x |M| bytes per pass.
+// grp_any[grp] (zero on entry) is raised when the group's slice of the matrix holds any bit at all: rank groups without
+// one -- a whole species the sample does not belong to, for instance -- are skipped by every kernel of the back half.
 __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m_bits, u64* __restrict__ m_int,
                                                              u32 n_pad, u32 n_words, u64* __restrict__ mq, u32 n_gw,
-                                                             const u32* __restrict__ n_q) {
+                                                             const u32* __restrict__ n_q, u32* __restrict__ grp_any) {
     __shared__ u64 tile[2][64][kRankWords + 1];
     // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
     // index Q, so rows of Mq beyond nq are never read
@@ -1044,14 +1218,17 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
     };
     const u32 row = threadIdx.x >> 3, cw = threadIdx.x & 7u;
     u64 nxt = load(w0);
+    u64 seen = 0;
     for (u32 w = w0; w < w1; ++w) {
         const u64 cur = nxt;
+        seen |= cur;
         nxt = load(w + 1u);
         const u32 bsel = (w - w0) & 1u;
         tile[bsel][lane][wv] = transpose64(cur, lane);
         __syncthreads();  // (double-buffered tile: one barrier per word is enough)
         if (grp * kRankWords + cw < n_gw) mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = tile[bsel][row][cw];
     }
+    if (__ballot(seen != 0) && lane == 0) grp_any[grp] = 1u;  // (plain store of the same value from several waves)
 }
 
 // =====================================================================================
@@ -1116,7 +1293,7 @@ __device__ __forceinline__ void add_planes(u32 (&x)[10], const u32 (&y)[10]) {
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
-                                                      u32 nq_rows, u32* __restrict__ inc) {
+                                                      u32 nq_rows, u32* __restrict__ inc, const u32* __restrict__ grp_any) {
     static_assert(kRankWords == 8, "lane = (sub, word) layout assumes 8 words per rank group");
     const u32 lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + kRankWords - 1) / kRankWords;
@@ -1126,7 +1303,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     const u32 xcd = blockIdx.x & 7u;
     const u32 task = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6));
     const u32 grp = (task / n_seg) * 8u + xcd, seg = task % n_seg;
-    if (grp >= n_grp) return;
+    if (grp >= n_grp || !grp_any[grp]) return;  // (a group without any bit: nobody reads its increments)
     const u32 sub = lane >> 3, j = lane & 7u;
     const u64* mq_gj = mq + (size_t)grp * nq_rows * kRankWords + j;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
@@ -1241,9 +1418,10 @@ __global__ __launch_bounds__(256) void chunk_gmax_kernel(const u64* __restrict__
 // so that the running sum of genome g before the first read of segment seg is cum_in[g] + rel[seg][g].
 // grids: (n_pad/256, n_chunks), (n_pad/256), (n_pad/256, n_chunks)
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad,
-                                                        u32* __restrict__ csum) {
+                                                        u32* __restrict__ csum, const u32* __restrict__ grp_any) {
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
+    if (!grp_any[blockIdx.x >> 1]) { csum[(size_t)c * n_pad + g] = 0; return; }  // (its increments were never written)
     const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
     u32 t = 0;
 #pragma unroll 16
@@ -1266,9 +1444,9 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(u32* __restrict__ csu
 __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, const u32* __restrict__ csum,
                                                          u32 n_seg, u32 n_pad, u32* __restrict__ rel,
                                                          const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
-                                                         u32 n_half, Species sp) {
+                                                         u32 n_half, Species sp, const u32* __restrict__ grp_any) {
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
-    if (g >= n_pad) return;
+    if (g >= n_pad || !grp_any[blockIdx.x >> 1]) return;  // (a group without any bit starts every segment at the pass-start table)
     // a (chunk, rank group) without any possible candidate is never looked at by the ranking: skip its start values
     // (both halves of a live group are written: the ranking reads the whole group)
     if (gmax && !chunk_group_live(gmax, lead_val, n_half, c, blockIdx.x >> 1, sp)) return;
@@ -1375,17 +1553,18 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
                                                        u32 n_gw, u32 n_pad, Species sp,
                                                        const u64* __restrict__ cum_in, const u32* __restrict__ rel,
                                                        u32 top_k, u64* __restrict__ cand_sum,
-                                                       u32* __restrict__ cand_idx, u32 nq_rows) {
+                                                       u32* __restrict__ cand_idx, u32 nq_rows, const u32* __restrict__ grp_any) {
     const u32 wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len;
     const u32 gw = wave % n_gw, seg = wave / n_gw;
     if (seg >= n_seg) return;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
-    const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
+    const bool dead = !grp_any[gw / kRankWords];  // no bit in the whole group: the table does not move, nothing to replay
+    const u32 pa = poff[r_begin + ra] - p_base, pz = dead ? pa : poff[r_begin + rz] - p_base;
     const u32 g = gw * 64u + lane;
     const u32 spi = sp.of_grp[gw / kRankWords];
     const bool real = g < sp.g0[spi] + sp.n[spi];  // (padding genomes of the species' last groups never rank)
-    u64 state = cum_in[g] + rel[(size_t)seg * n_pad + g];
+    u64 state = cum_in[g] + (dead ? 0u : rel[(size_t)seg * n_pad + g]);
     u32 cur = ra;  // next read to emit
 
     auto emit = [&](u32 r) {
@@ -1486,7 +1665,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
-                                                            const u64* __restrict__ lead_val) {
+                                                            const u64* __restrict__ lead_val, const u32* __restrict__ grp_any) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
@@ -1506,7 +1685,10 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         return;
     }
     const u32 spi = sp.of_grp[grp], sp_end = sp.g0[spi] + sp.n[spi];
-    const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
+    // a group without any bit in the pass (e.g. a species the sample does not belong to): its sums do not move -- no
+    // start values / increments were written for it, no pairs are replayed, one key serves the whole segment
+    const bool dead = !grp_any[grp];
+    const u32 pa = poff[r_begin + ra] - p_base, pz = dead ? pa : poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
     // Pruning (exact).  Sums never decrease and a genome ends the segment at start + inc, so with ANY lower bound
     // `lead` of the leading sum over the segment, only genomes with start + inc >= lead can lead at one of its
@@ -1517,7 +1699,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     // clear best match a handful of genomes are left: a group without any reports "none" straight away, and inside
     // a live group words without any are neither loaded nor counted.  Non-candidates (and padding) get value 0.
     const u32 gl = leader[(seg >> 4) * sp.n_sp + spi];  // (top_k == 1: one leader per chunk and species)
-    u64 lead = cum_in[gl] + rel[(size_t)seg * n_pad + gl];
+    u64 lead = cum_in[gl] + (grp_any[gl / (NW * 64u)] ? rel[(size_t)seg * n_pad + gl] : 0u);
     const u32 gain = pz - pa;
     u64 st0[NW];
     u32 ic[NW];
@@ -1527,8 +1709,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     for (int j = 0; j < NW; ++j) {
         const u32 g = g0 + (u32)j * 64u;
         real[j] = g < sp_end;  // (padding genomes of the species' last group never rank)
-        st0[j] = real[j] ? cum_in[g] + rel[(size_t)seg * n_pad + g] : 0;
-        ic[j] = real[j] ? inc[(size_t)seg * n_pad + g] : 0;
+        st0[j] = real[j] ? cum_in[g] + (dead ? 0u : rel[(size_t)seg * n_pad + g]) : 0;
+        ic[j] = (real[j] && !dead) ? inc[(size_t)seg * n_pad + g] : 0;
         grp_best = max(grp_best, st0[j]);
     }
 #pragma unroll
@@ -1627,7 +1809,7 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
                                                             u64* __restrict__ cand_sum, u32* __restrict__ cand_idx,
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
-                                                            const u64* __restrict__ lead_val) {
+                                                            const u64* __restrict__ lead_val, const u32* __restrict__ grp_any) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + 63u) / 64u, n_grp = (n_gw + NW - 1) / NW;
@@ -1642,14 +1824,15 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
         }
         return;
     }
-    const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
+    const bool dead = !grp_any[grp];  // no bit in the whole group: nothing was written for it, nothing to replay
+    const u32 pa = poff[r_begin + ra] - p_base, pz = dead ? pa : poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
     // lower bound of the k-th best sum (of this group's species) over the segment
     const u32 spi = sp.of_grp[grp], sp_end = sp.g0[spi] + sp.n[spi];
     u64 lead = ~0ull;
     for (u32 j = 0; j < top_k; ++j) {
         const u32 gl = leader[((seg >> 4) * sp.n_sp + spi) * top_k + j];
-        lead = min(lead, cum_in[gl] + rel[(size_t)seg * n_pad + gl]);
+        lead = min(lead, cum_in[gl] + (grp_any[gl / (NW * 64u)] ? rel[(size_t)seg * n_pad + gl] : 0u));
     }
     u64 sum[NW];
     bool cand[NW];
@@ -1658,8 +1841,8 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
     for (int j = 0; j < NW; ++j) {
         const u32 g = g0 + (u32)j * 64u;
         const bool real = g < sp_end;
-        sum[j] = real ? cum_in[g] + rel[(size_t)seg * n_pad + g] : 0;
-        const u32 ic = real ? inc[(size_t)seg * n_pad + g] : 0;
+        sum[j] = real ? cum_in[g] + (dead ? 0u : rel[(size_t)seg * n_pad + g]) : 0;
+        const u32 ic = (real && !dead) ? inc[(size_t)seg * n_pad + g] : 0;
         cand[j] = real && sum[j] + ic >= lead;
         if (__ballot(cand[j])) wmask |= 1u << j;
     }
@@ -1858,17 +2041,20 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
         }
     }
     const dim3 list_grid(std::min<u32>(cdiv(n_reads, 4), 256u)), blk_grid(std::min<u32>(n_reads, 256u));
+    const dim3 grid2(2u * cdiv(n_reads, 4));  // two-phase (long reads first); needs chk[1] from batch_check_kernel
 #define SKX_SK_LAUNCH(KERNEL, LDS, FROM_LIST)                                                                              \
-    hipLaunchKernelGGL((KERNEL), (FROM_LIST) ? list_grid : grid, dim3(256), LDS, st, bases, offsets, n_reads, k, seed, s, \
-                       max_ref, out_sk, sk_stride, out_len, out_cnt_in, FROM_LIST, retry, big, filt, filt_shift, n_bases, chk)
+    hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid, dim3(256), LDS, st, bases, \
+                       offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, FROM_LIST, retry, big,   \
+                       filt, filt_shift, n_bases, chk)
 #define SKX_BLK_LAUNCH(KERNEL)                                                                                         \
     hipLaunchKernelGGL((KERNEL), blk_grid, dim3(1024), kBigLds, st, bases, offsets, big, k, seed, s, max_ref, out_sk, \
                        sk_stride, out_len, out_cnt_in, filt, filt_shift)
     if (inrange_only) {
         // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
         // does not fit goes to the block sketcher -- both through device-side lists, usually empty
-        if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); SKX_BLK_LAUNCH(SKX_BLK(16, true)); }
-        else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, 0u); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); SKX_BLK_LAUNCH(SKX_BLK(0, true)); }
+        const u32 first = chk ? 2u : 0u;
+        if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, first); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); SKX_BLK_LAUNCH(SKX_BLK(16, true)); }
+        else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, first); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); SKX_BLK_LAUNCH(SKX_BLK(0, true)); }
     } else {
         if (k == 16) { SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); SKX_BLK_LAUNCH(SKX_BLK(16, false)); }
         else { SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u); SKX_BLK_LAUNCH(SKX_BLK(0, false)); }
@@ -1919,10 +2105,43 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
+// resident blocks of scan_stream_kernel on the current device (occupancy x CUs; once per device)
+static u32 scan_stream_grid() {
+    static std::mutex mu;
+    static u32 cached[256] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cached[dev]) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_stream_kernel<0>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        static const int per_cu_env = env_int("SKX_SCAN_BLOCKS_PER_CU", 0);  // experiment
+        if (per_cu_env > 0) per_cu = per_cu_env;
+        cached[dev] = (u32)per_cu * (u32)cus;
+    }
+    return cached[dev];
+}
+
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table) {
     static const int ablate = env_int("SKX_SCAN_ABLATE", 0);  // profiling aid only
     dim3 grid(n_tiles * n_bands), block(256);
+    // sparse dictionaries (the host asked for neither the split nor the big-table variant): the persistent kernel
+    static const int stream_env = env_int("SKX_SCAN_STREAM", 1);
+    if (stream_env && !m_int && !big_table) {
+        const u32 n_bt = n_tiles * n_bands;
+        dim3 sgrid(std::min<u32>(scan_stream_grid(), n_bt));
+#define SKX_SCAN_S(A) hipLaunchKernelGGL((scan_stream_kernel<A>), sgrid, block, 0, st, mat, s, n_tiles, rb, n_bt, q, win, m_bits, n_pad)
+        switch (ablate) {
+            case 1: SKX_SCAN_S(1); break;
+            case 2: SKX_SCAN_S(2); break;
+            case 3: SKX_SCAN_S(3); break;
+            default: SKX_SCAN_S(0); break;
+        }
+#undef SKX_SCAN_S
+        return;
+    }
 #define SKX_SCAN(A, SP) \
     hipLaunchKernelGGL((scan_kernel<2040, A, SP>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
     if (big_table && ablate == 0 && m_int) {
@@ -1944,15 +2163,21 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
         case 1: SKX_SCAN(1, false); break;
         case 2: SKX_SCAN(2, false); break;
         case 3: SKX_SCAN(3, false); break;
-        default: if (m_int) SKX_SCAN(0, true); else SKX_SCAN(0, false); break;
+        default: {
+            static const int fast = env_int("SKX_SCAN_FAST", 0);  // experiment: the branch-free four-at-a-time probe
+            if (m_int) SKX_SCAN(0, true);
+            else if (fast) hipLaunchKernelGGL((scan_kernel<2040, 0, false, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
+            else SKX_SCAN(0, false);
+            break;
+        }
     }
 #undef SKX_SCAN
 }
-void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q) {
+void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
-                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q);
+                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any);
 }
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail) {
     hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk,
@@ -1971,19 +2196,19 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
     hipLaunchKernelGGL(filter_apply_kernel, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, sk, sk_stride, cnt, n_reads, bits, shift);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc) {
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     const u32 n_grp = cdiv(n_gw, kRankWords);
     // 8 XCDs x ceil(groups / 8) groups each x n_seg segments, 4 waves (segments) per workgroup
     hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv((u64)cdiv(n_grp, 8) * n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
-                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc);
+                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32 prune_top_k, u32* leader,
-                       u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx) {
+                       u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx, const u32* grp_any) {
     const u32 n_chunks = cdiv(n_seg, 16);
     dim3 grid(cdiv(n_pad, 256), n_chunks);
-    hipLaunchKernelGGL(chunk_sum_kernel, grid, dim3(256), 0, st, inc, n_seg, n_pad, csum);
+    hipLaunchKernelGGL(chunk_sum_kernel, grid, dim3(256), 0, st, inc, n_seg, n_pad, csum, grp_any);
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, csum, n_chunks, n_pad, cum_in, cum_out);
     if (prune_top_k) {
         // who leads (per species) as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
@@ -1995,33 +2220,33 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
                            n_pad, n_pad / 256, gmax);
     }
     hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
-                       lead_val, n_pad / 256, sp);
+                       lead_val, n_pad / 256, sp, grp_any);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
-                     const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx) {
+                     const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* grp_any) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     hipLaunchKernelGGL(rank_seg_kernel, dim3(cdiv((u64)n_seg * n_gw, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, seg_len, mq, n_gw, n_pad, sp, cum_in, rel, top_k, cand_sum,
-                       cand_idx, nq_rows);
+                       cand_idx, nq_rows, grp_any);
 }
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
-                          const u64* lead_val) {
+                          const u64* lead_val, const u32* grp_any) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, sp, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader,
-                       gmax, lead_val);
+                       gmax, lead_val, grp_any);
 }
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
-                          const u64* gmax, const u64* lead_val) {
+                          const u64* gmax, const u64* lead_val, const u32* grp_any) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_topk_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, mq, n_gw, n_pad, sp, cum_in, rel, top_k, cand_sum, cand_idx, nq_rows,
-                       inc, leader, gmax, lead_val);
+                       inc, leader, gmax, lead_val, grp_any);
 }
 u32 rank_topk_fast_max() { return kTopkFast; }
 u32 rank_leader_parts() { return kLeaderParts; }

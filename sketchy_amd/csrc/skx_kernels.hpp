@@ -49,8 +49,10 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
 // scan + transpose
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u64* m_int, u32 n_pad, bool big_table);
+// also re-zeroes m_bits / m_int; words beyond *n_q are skipped; raises grp_any[rank group] (zero on entry) for every
+// rank group whose slice of the matrix holds any bit -- the ranking kernels skip the others (grp_any arguments below)
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
-                           const u32* n_q);  // also re-zeroes m_bits / m_int; words beyond *n_q are skipped
+                           const u32* n_q, u32* grp_any);
 // chk[0..5] (zeroed by the caller): non-monotonic marker, long-read count, offsets[0], offsets[n_reads]
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail /* zeroed */);
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
@@ -62,28 +64,29 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc);
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any);
 // prune_top_k > 0 (1..rank_topk_fast_max()): also find the first prune_top_k genomes as each chunk of 16 segments begins
 // (leader [n_chunks * k], lead_val [n_chunks]) and every half rank group's best value per chunk boundary (gmax
 // [(n_chunks + 1) * n_pad / 256]); start values are then only written for (chunk, group)s that can hold a candidate.
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel /* [n_seg][n_pad]: segment start values minus cum_in */, u32* csum, u32 prune_top_k,
                        u32* leader /* [n_chunks * n_sp * k] */, u64* lead_val /* [n_chunks * n_sp] */, u64* gmax,
-                       u64* part_sum, u32* part_idx /* [n_chunks * n_sp * rank_leader_parts() * k] scratch */);
+                       u64* part_sum, u32* part_idx /* [n_chunks * n_sp * rank_leader_parts() * k] scratch */,
+                       const u32* grp_any);
 u32 rank_leader_parts();
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
-                     const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx);
+                     const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* grp_any);
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
-                          const u64* lead_val);
+                          const u64* lead_val, const u32* grp_any);
 // 2 <= top_k <= rank_topk_fast_max(): pruned, one wave per (rank group, segment);
 // cand_sum / cand_idx[(r * n_grp + grp) * top_k + j]
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
-                          const u64* gmax, const u64* lead_val);
+                          const u64* gmax, const u64* lead_val, const u32* grp_any);
 u32 rank_topk_fast_max();
 // rows come out per (read, species) with genome indices local to the species: out[((out_r0 + r) * n_sp + sp) * top_k + j]
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32* out_idx, u64* out_sum,

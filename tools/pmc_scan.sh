@@ -7,7 +7,7 @@ KPAT=${KPAT:-scan_kernel}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 P=gpurun_out/prof; mkdir -p $P
 PASSES=(
- "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
+ "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_WR"
  "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum"
  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_32B_sum"
@@ -19,7 +19,7 @@ i=0
 : > $P/${TAG}_pmc.csv
 for C in "${PASSES[@]}"; do
   i=$((i+1))
-  timeout 120 env "$@" rocprofv3 --pmc $C --output-format csv -d $P/pmc_${TAG}_$i -o pmc -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > /dev/null 2> $P/${TAG}_pmc_$i.err || true
+  timeout 120 env "$@" rocprofv3 --pmc $C --output-format csv -d $P/pmc_${TAG}_$i -o pmc -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-extra-legs --no-check > /dev/null 2> $P/${TAG}_pmc_$i.err || true
   F=$(find $P/pmc_${TAG}_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$F" ]; then python3 profiles/summarize_pmc.py $F | grep -E "$KPAT" >> $P/${TAG}_pmc.csv || true; fi
   rm -rf $P/pmc_${TAG}_$i
