@@ -470,9 +470,25 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
     static const int prio_env = getenv("SKX_PRIO") ? atoi(getenv("SKX_PRIO")) : 1;
     if (!prio_env) prio_hi = prio_lo;
+    // Experiment (env SKX_CU_SCAN = n, with SKX_PIPELINE = 3): partition the chip -- the scan stream may only use n of the
+    // CUs (spread evenly over the XCDs: mask bit i is CU i / 8 of XCD i % 8), the sketch / dictionary and ranking
+    // streams only the others, so the HBM-bound scan of batch i and the VALU-bound sketch of batch i + 1 run side by
+    // side without sharing a CU.  Results in DESIGN.md; off by default.
+    static const int cu_scan_env = getenv("SKX_CU_SCAN") ? atoi(getenv("SKX_CU_SCAN")) : 0;
+    int n_cus = 0;
+    (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, st->device);
+    if (cu_scan_env > 0 && cu_scan_env < n_cus && st->depth >= 3) {
+        const u32 words = (u32)(n_cus + 31) / 32;
+        std::vector<uint32_t> m_scan(words, 0u), m_rest(words, 0u);
+        for (int i = 0; i < n_cus; ++i) (i < cu_scan_env ? m_scan : m_rest)[i / 32] |= 1u << (i % 32);
+        SCHK(hipExtStreamCreateWithCUMask(&st->hs, words, m_scan.data()));
+        SCHK(hipExtStreamCreateWithCUMask(&st->hs0, words, m_rest.data()));
+        SCHK(hipExtStreamCreateWithCUMask(&st->hs2, words, m_rest.data()));
+    } else {
     SCHK(hipStreamCreateWithPriority(&st->hs, hipStreamNonBlocking, prio_hi));
     if (st->depth >= 3) SCHK(hipStreamCreateWithPriority(&st->hs0, hipStreamNonBlocking, prio_lo)); else st->hs0 = st->hs;
     if (st->depth >= 2) SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, prio_lo)); else st->hs2 = st->hs;
+    }
     for (int i = 0; i < 2; ++i) {
         SCHK(hipEventCreateWithFlags(&st->ev_dict[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
@@ -689,14 +705,15 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         static const int big_env = getenv("SKX_SCAN_BIG") ? atoi(getenv("SKX_SCAN_BIG")) : -1;
         const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
         {
-            Span sp(st, 1, hs);
-            // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
-            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad);
-        }
-        {
             Span sp(st, 2, hs);
+            // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
             skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, d_q, d_win, st->d_m,
                              split ? st->d_mint : nullptr, n_pad, big);
+        }
+        {
+            Span sp(st, 1, hs);
+            // (after the scan: its persistent form writes complete words with plain stores, these OR single bits in)
+            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad);
         }
         {
             Span sp(st, 3, hs);

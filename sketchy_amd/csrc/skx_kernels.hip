@@ -987,160 +987,6 @@ __global__ __launch_bounds__(256, FAST ? 6 : 1) void scan_kernel(const u64* __re
 }
 
 // =====================================================================================
-// the reference scan, persistent form (default for sparse dictionaries)
-// =====================================================================================
-// scan_kernel above spends one short-lived block on every (band, tile): each pays the dependent loads of its window and
-// slice, the directory build and two barriers before its first matrix load is even requested, and its load pipeline
-// fills and drains inside 64 rows -- measured, 58 % of the wave cycles are waits and the pure stream in that geometry
-// runs at 0.57 ms against 0.515 ms for a flat copy.  Here a fixed grid of resident blocks walks the (band, tile) items
-// with stride gridDim.x and keeps ONE load pipeline running across them:
-//   * the unit of work is (item, sub-window of <= kStreamCap query hashes of its slice) -- one sub-window for the usual
-//     ~70-entry slice, several (the band re-streamed) for denser ones: any slice size is handled, just slower;
-//   * the next unit's slice is requested from Q when the current unit starts and its first 8 rows are requested before
-//     the current unit's last 8 are probed; at the unit border the block stores that slice into the OTHER table buffer,
-//     builds its (small: 1024 buckets) directory and flips buffers -- two barriers with the matrix loads in flight;
-//   * probing, hit bits and the atomicOr write-back of M are those of scan_kernel.
-constexpr u32 kStreamCap = 510;       // slice entries per table buffer (two per thread)
-constexpr u32 kStreamBuckets = 1024;  // directory entries per table buffer
-
-struct StreamUnit {
-    u32 bt;    // item = band * n_tiles + tile (>= n_bt: none left)
-    u32 sub;   // first query index of the sub-window
-    u32 n;     // entries of the sub-window
-    u32 qb;    // end of the item's slice
-};
-
-template <int ABLATE>
-__global__ __launch_bounds__(256) void scan_stream_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb, u32 n_bt,
-                                                          const u64* __restrict__ q, const u32* __restrict__ win,
-                                                          u64* __restrict__ m_bits, u32 n_pad) {
-    __shared__ u64 slice[2][kStreamCap + 2];
-    __shared__ unsigned short dir[2][kStreamBuckets + 1];
-    const u32 c = threadIdx.x;
-
-    // the unit after `u` (wave-uniform: scalar loads of the windows)
-    auto next_unit = [&](const StreamUnit& u) -> StreamUnit {
-        StreamUnit v = u;
-        if (u.bt < n_bt && u.sub + kStreamCap < u.qb) {  // next sub-window of the same item
-            v.sub = u.sub + kStreamCap;
-            v.n = min(kStreamCap, u.qb - v.sub);
-            return v;
-        }
-        u32 bt = u.bt < n_bt ? u.bt + gridDim.x : u.bt;
-        while (bt < n_bt) {
-            const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
-            if (qa < qb) { v.bt = bt; v.sub = qa; v.qb = qb; v.n = min(kStreamCap, qb - qa); return v; }
-            bt += gridDim.x;
-        }
-        v.bt = 0xFFFFFFFFu; v.n = 0;
-        return v;
-    };
-    // requests this thread's (up to two) entries of a unit's slice
-    auto fetch_slice = [&](const StreamUnit& u, u64& a, u64& b) {
-        a = (u.bt < n_bt && c < u.n) ? q[u.sub + c] : kEmpty;
-        b = (u.bt < n_bt && c + 256u < u.n) ? q[u.sub + 256u + c] : kEmpty;
-    };
-    // stores them and builds the directory of table buffer `tb` (both barriers inside)
-    auto build = [&](const StreamUnit& u, u32 tb, u64 a, u64 b, u64& lo, u64& hi, u32& shift) {
-        if (c < u.n) slice[tb][c] = a;
-        if (c + 256u < u.n) slice[tb][c + 256u] = b;
-        if (c == 0) { slice[tb][u.n] = kEmpty; slice[tb][u.n + 1u] = kEmpty; }
-        __syncthreads();
-        lo = slice[tb][0]; hi = slice[tb][u.n - 1u];
-        const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
-        shift = span_bits > (u32)__builtin_ctz(kStreamBuckets) ? span_bits - (u32)__builtin_ctz(kStreamBuckets) : 0u;
-        for (u32 j = c; j <= u.n; j += 256u) {
-            // entry j opens every bucket in (bucket(j-1), bucket(j)]; the sentinel closes the rest
-            const u32 bj = j < u.n ? (u32)((slice[tb][j] - lo) >> shift) : kStreamBuckets;
-            const u32 bp = j == 0 ? 0xFFFFFFFFu : (u32)((slice[tb][j - 1] - lo) >> shift);
-            for (u32 x = bp + 1u; x <= bj; ++x) dir[tb][x] = (unsigned short)j;
-        }
-        __syncthreads();
-    };
-    // rows [i, i + 8) of a unit's band for this lane's genome (rows past the band's end read as padding)
-    auto load8 = [&](const StreamUnit& u, u32 i, u64 (&h)[8]) {
-        const u32 t = u.bt % n_tiles, bnd = u.bt / n_tiles;
-        const u32 i0 = bnd * rb, rows = min(s, i0 + rb) - i0;
-        const u64* col = mat + ((size_t)t * s + i0) * kTileGenomes + c;
-#pragma unroll
-        for (u32 x = 0; x < 8u; ++x) h[x] = (i + x < rows) ? col[(size_t)(i + x) * kTileGenomes] : kPad;
-    };
-
-    StreamUnit cur;
-    cur.bt = 0xFFFFFFFFu; cur.sub = 0; cur.n = 0; cur.qb = 0;
-    {   // first unit of this block
-        u32 bt = blockIdx.x;
-        while (bt < n_bt) {
-            const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
-            if (qa < qb) { cur.bt = bt; cur.sub = qa; cur.qb = qb; cur.n = min(kStreamCap, qb - qa); break; }
-            bt += gridDim.x;
-        }
-    }
-    if (cur.bt >= n_bt) return;
-    u32 tb = 0;
-    u64 lo, hi;
-    u32 shift;
-    {
-        u64 a, b;
-        fetch_slice(cur, a, b);
-        build(cur, 0, a, b, lo, hi, shift);
-    }
-    u64 h[8];
-    load8(cur, 0, h);
-
-    while (cur.bt < n_bt) {
-        const StreamUnit nxt = next_unit(cur);
-        u64 na, nb;
-        fetch_slice(nxt, na, nb);  // lands while this unit streams
-        const u32 rows = min(s, (cur.bt / n_tiles) * rb + rb) - (cur.bt / n_tiles) * rb;
-        const u32 g = (cur.bt % n_tiles) * kTileGenomes + c;
-
-        u32 cur_w = 0xFFFFFFFFu;  // absolute word index (q >> 6)
-        u64 cur_bits = 0;
-        auto hit = [&](u32 qi) {
-            const u32 w = qi >> 6;
-            if (w != cur_w) {
-                if (ABLATE != 1 && cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
-                cur_w = w; cur_bits = 0;
-            }
-            cur_bits |= 1ull << (qi & 63u);
-        };
-        auto probe = [&](u64 hv) {
-            if (ABLATE == 2) { cur_bits ^= hv; return; }
-            if (hv < lo || hv > hi) return;  // also drops the padding value
-            u32 j = dir[tb][(u32)((hv - lo) >> shift)];
-            u64 e = slice[tb][j];
-            while (e < hv) e = slice[tb][++j];   // the sentinel ends every walk (hv <= hi < kEmpty)
-            if (ABLATE == 3) { cur_bits ^= e; return; }
-            if (e == hv) hit(cur.sub + j);
-        };
-        for (u32 i = 0; i < rows; i += 8u) {
-            u64 hn[8];
-            if (i + 8u < rows) load8(cur, i + 8u, hn);
-            else if (nxt.bt < n_bt) load8(nxt, 0, hn);  // the next unit's first rows are in flight across the border
-            else {
-#pragma unroll
-                for (u32 x = 0; x < 8u; ++x) hn[x] = kPad;
-            }
-#pragma unroll
-            for (u32 x = 0; x < 8u; ++x) probe(h[x]);
-#pragma unroll
-            for (u32 x = 0; x < 8u; ++x) h[x] = hn[x];
-        }
-        if (ABLATE >= 1) {
-            if (cur_bits == 0x123456789ull) m_bits[g] = cur_bits;  // keep the work alive
-        } else if (cur_bits) {
-            atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
-        }
-        if (nxt.bt < n_bt) {
-            build(nxt, tb ^ 1u, na, nb, lo, hi, shift);  // (its first barrier also ends every wave's use of buffer tb)
-            tb ^= 1u;
-        }
-        cur = nxt;
-    }
-}
-
-// =====================================================================================
 // M[word][genome] (bit j of the word = query 64*word + j)  ->  Mq[query][genome word]
 // =====================================================================================
 // Partner exchange x[lane ^ D] for the butterfly, without the LDS crossbar (one LDS pipe per CU is shared by
@@ -2105,43 +1951,10 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-// resident blocks of scan_stream_kernel on the current device (occupancy x CUs; once per device)
-static u32 scan_stream_grid() {
-    static std::mutex mu;
-    static u32 cached[256] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) dev = 0;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!cached[dev]) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_stream_kernel<0>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        static const int per_cu_env = env_int("SKX_SCAN_BLOCKS_PER_CU", 0);  // experiment
-        if (per_cu_env > 0) per_cu = per_cu_env;
-        cached[dev] = (u32)per_cu * (u32)cus;
-    }
-    return cached[dev];
-}
-
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table) {
     static const int ablate = env_int("SKX_SCAN_ABLATE", 0);  // profiling aid only
     dim3 grid(n_tiles * n_bands), block(256);
-    // sparse dictionaries (the host asked for neither the split nor the big-table variant): the persistent kernel
-    static const int stream_env = env_int("SKX_SCAN_STREAM", 1);
-    if (stream_env && !m_int && !big_table) {
-        const u32 n_bt = n_tiles * n_bands;
-        dim3 sgrid(std::min<u32>(scan_stream_grid(), n_bt));
-#define SKX_SCAN_S(A) hipLaunchKernelGGL((scan_stream_kernel<A>), sgrid, block, 0, st, mat, s, n_tiles, rb, n_bt, q, win, m_bits, n_pad)
-        switch (ablate) {
-            case 1: SKX_SCAN_S(1); break;
-            case 2: SKX_SCAN_S(2); break;
-            case 3: SKX_SCAN_S(3); break;
-            default: SKX_SCAN_S(0); break;
-        }
-#undef SKX_SCAN_S
-        return;
-    }
 #define SKX_SCAN(A, SP) \
     hipLaunchKernelGGL((scan_kernel<2040, A, SP>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
     if (big_table && ablate == 0 && m_int) {

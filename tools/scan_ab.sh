@@ -8,10 +8,10 @@ run() { L=$1; shift; env "$@" timeout 300 python3 bench.py --cpu-seconds 0 2>/de
 run legacy SKX_SCAN_STREAM=0
 run stream SKX_SCAN_STREAM=1
 run stream SKX_SCAN_STREAM=1
-run stream_bpc4 SKX_SCAN_BLOCKS_PER_CU=4
+run stream_run2 SKX_SCAN_RUN=2
+run stream_run4 SKX_SCAN_RUN=4
+run stream_run8 SKX_SCAN_RUN=8
+run stream_run16 SKX_SCAN_RUN=16
 run stream_bpc5 SKX_SCAN_BLOCKS_PER_CU=5
-run stream_bpc8 SKX_SCAN_BLOCKS_PER_CU=8
-run stream_abl2 SKX_SCAN_ABLATE=2
-run stream_abl3 SKX_SCAN_ABLATE=3
+run stream_bpc7 SKX_SCAN_BLOCKS_PER_CU=7
 run stream_abl1 SKX_SCAN_ABLATE=1
-run legacy_abl2 SKX_SCAN_STREAM=0 SKX_SCAN_ABLATE=2
