@@ -209,6 +209,7 @@ def main():
     prof = S.profile() if not args.no_profile else None
     S.set_profiling(False)
     table_final = S.table()
+    stats = S.stats()
 
     total_reads = K * B * world
     value = total_reads / elapsed
@@ -274,6 +275,7 @@ def main():
                                        "measured while the other stages of neighbouring steps run on the other streams",
                                "whole_step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                                               "note": "the same bytes over the whole step time (sketch, dictionary, ranking included)"}}
+        out["pass_stats"] = stats  # (read, hash) pairs / passes of the last timed push, dictionary size, ...
         out["setup_s"] = {"reference": round(t_ref, 2), "reads": round(t_gen - t_ref, 2), "total": round(t_setup, 2)}
 
     # ---- extra legs, outside the contract's timed region
@@ -309,6 +311,38 @@ def main():
             out["value_steady_state"] = {"value": n_long * B * world / float(np.median(steady)), "unit": "reads/s", "steps": n_long,
                                          "median_of": 3, "all": [n_long * B * world / t for t in steady],
                                          "what": f"the stream continued past {(W + K) * B} reads per GPU without reset (batches cycled)"}
+        # value_host_fed: the same stream with every batch coming from PAGE-LOCKED HOST memory through
+        # skx_stream_submit (copy of batch i+1 over PCIe while batch i is in the kernels) and the rows going back
+        if top:
+            n_h = min(n_distinct, 4)
+            h_b, h_o = [], []
+            for j in range(n_h):
+                hb, ho = api.HostBuffer(batch_bases[j], dev), api.HostBuffer((B + 1) * 8, dev)
+                hb.view(np.uint8, batch_bases[j])[:] = batches[j][0].cpu().numpy()
+                ho.view(np.int64, B + 1)[:] = batches[j][1].cpu().numpy()
+                h_b.append(hb); h_o.append(ho)
+            h_ti = [api.HostBuffer(B * rows * 4, dev) for _ in range(2)]
+            h_ts = [api.HostBuffer(B * rows * 8, dev) for _ in range(2)]
+            S.reset()
+            for i in range(2):
+                S.submit(h_b[i % n_h].ptr, h_o[i % n_h].ptr, B, h_ti[i & 1].ptr, h_ts[i & 1].ptr)
+            S.drain()
+            n_sub = max(16, int(0.5 / (elapsed / K) / 2))
+            shard.barrier()
+            tc = time.perf_counter()
+            for i in range(n_sub):
+                S.submit(h_b[i % n_h].ptr, h_o[i % n_h].ptr, B, h_ti[i & 1].ptr, h_ts[i & 1].ptr)
+            S.drain()
+            t_host = shard.max_over_ranks(time.perf_counter() - tc)
+            if rank == 0:
+                bytes_in = float(np.mean(batch_bases[:n_h])) + 8.0 * (B + 1)
+                out["value_host_fed"] = {"value": n_sub * B * world / t_host, "unit": "reads/s", "steps": n_sub,
+                                         "h2d_GBps_per_gpu": n_sub * bytes_in / t_host / 1e9,
+                                         "what": "batches in page-locked host memory, skx_stream_submit (H2D of batch i+1 overlaps the "
+                                                 "kernels of batch i), rows copied back to the host; PCIe-bound when the GPU step is "
+                                                 "shorter than the copy"}
+            for h in h_b + h_o + h_ti + h_ts:
+                h.free()
         if not args.no_profile:
             # per-stage breakdown from a few extra, untimed steps with every stage bracketed by events
             S.set_profiling(1)

@@ -120,6 +120,22 @@ int skx_stream_push(skx_stream *st, const uint8_t *bases, const uint64_t *offset
 int skx_stream_push_device(skx_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
                            uint64_t n_bases, uint32_t *d_topk_idx, uint64_t *d_topk_sum);
 int skx_stream_sync(skx_stream *st);
+/*
+ * Host-fed pipeline.  skx_stream_submit() queues a batch from PAGE-LOCKED host buffers (skx_host_alloc; bases, offsets
+ * and the optional row arrays) and returns without waiting for it: the host-to-device copy of batch i+1 runs on its
+ * own stream into the second staging slot while batch i is sketched, scanned and ranked.  Processing lags one call
+ * behind submission (submit(i) starts the copy of batch i, then runs batch i-1 through the kernels), so a single host
+ * thread keeps the copy engine and the kernels busy at the same time -- what needletail's reader plus the loop of
+ * src/sketchy.rs:328-354 would look like with the device in between.  Rows of batch `ticket` ([n_reads][n_species]
+ * [top_k], as skx_stream_push) are in its arrays once skx_stream_wait(st, ticket) or skx_stream_drain(st) has returned;
+ * the input buffers may be reused after the NEXT submit has returned (or after wait / drain).  Results are those of
+ * the same batches pushed with skx_stream_push in the same order.  Do not interleave with skx_stream_push[_device]
+ * without a drain in between.
+ */
+int skx_stream_submit(skx_stream *st, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                      uint32_t *topk_idx, uint64_t *topk_sum, uint64_t *ticket);
+int skx_stream_wait(skx_stream *st, uint64_t ticket);
+int skx_stream_drain(skx_stream *st);
 /* running sum-of-shared-hashes table, u64[n_genomes] (host) */
 int skx_stream_table(skx_stream *st, uint64_t *cum);
 /* cum[g] += add[g]: resume from a checkpoint, or offset a shard by the totals of earlier shards */
@@ -128,6 +144,14 @@ int skx_stream_table_add(skx_stream *st, const uint64_t *add);
 int skx_stream_reset(skx_stream *st);
 /* reads consumed so far (the reference's `read` counter minus one, src/sketchy.rs:327/:350) */
 int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
+/*
+ * Counters for tuning / reporting (no effect on results): out[0] (read, hash) pairs of the last push, [1] scoring
+ * passes it took, [2] distinct query hashes of the most recent dictionary, [3] reads sketched by the block sketcher so
+ * far, [4] passes so far, [5] of those with the lean scan kernel, [6] pair capacity of a pass, [7] rank groups (512 genomes)
+ * that received any bit in the most recent pass.  Waits for the stream's queued work.
+ */
+#define SKX_N_STATS 8
+int skx_stream_stats(skx_stream *st, uint64_t *out, uint32_t n_out);
 /* rank the CURRENT table: first top_k of (sum desc, index asc) per species; idx/sum are host arrays [n_species][top_k] */
 int skx_stream_rank(skx_stream *st, uint32_t top_k, uint32_t *idx, uint64_t *sum);
 void skx_stream_destroy(skx_stream *st);

@@ -37,10 +37,14 @@ SYMBOLS = [
     ("skx_stream_push", _i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     ("skx_stream_push_device", _i, [_vp, _vp, _vp, _u32, _u64, _vp, _vp]),
     ("skx_stream_sync", _i, [_vp]),
+    ("skx_stream_submit", _i, [_vp, _vp, _vp, _u32, _vp, _vp, C.POINTER(_u64)]),
+    ("skx_stream_wait", _i, [_vp, _u64]),
+    ("skx_stream_drain", _i, [_vp]),
     ("skx_stream_table", _i, [_vp, _vp]),
     ("skx_stream_table_add", _i, [_vp, _vp]),
     ("skx_stream_reset", _i, [_vp]),
     ("skx_stream_reads", _i, [_vp, C.POINTER(_u64)]),
+    ("skx_stream_stats", _i, [_vp, C.POINTER(_u64), _u32]),
     ("skx_stream_rank", _i, [_vp, _u32, _vp, _vp]),
     ("skx_stream_destroy", None, [_vp]),
     ("skx_stream_set_profiling", _i, [_vp, _i]),

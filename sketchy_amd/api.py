@@ -123,6 +123,19 @@ class SumOfSharedHashes:
     def sync(self):
         _lib.check(_lib.load().skx_stream_sync(self._h))
 
+    def submit(self, h_bases, h_offsets, n_reads, h_topk_idx=None, h_topk_sum=None) -> int:
+        """Queue a batch held in page-locked host memory (HostBuffer pointers / addresses); returns its ticket.  The
+        copy overlaps the previous batch's kernels; rows are valid after wait(ticket) or drain()."""
+        t = C.c_uint64(0)
+        _lib.check(_lib.load().skx_stream_submit(self._h, h_bases, h_offsets, n_reads, h_topk_idx, h_topk_sum, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        _lib.check(_lib.load().skx_stream_wait(self._h, ticket))
+
+    def drain(self):
+        _lib.check(_lib.load().skx_stream_drain(self._h))
+
     def table(self) -> np.ndarray:
         cum = np.zeros(self.ref.n_genomes, np.uint64)
         _lib.check(_lib.load().skx_stream_table(self._h, _p(cum)))
@@ -148,6 +161,14 @@ class SumOfSharedHashes:
         idx, sm = np.zeros(shape, np.uint32), np.zeros(shape, np.uint64)
         _lib.check(_lib.load().skx_stream_rank(self._h, top, _p(idx), _p(sm)))
         return idx, sm
+
+    def stats(self):
+        """Counters of the stream (skx_stream_stats): pairs / passes of the last push, dictionary size, ..."""
+        v = (C.c_uint64 * 8)()
+        _lib.check(_lib.load().skx_stream_stats(self._h, v, 8))
+        names = ("last_pairs", "last_passes", "dictionary_size", "reads_block_sketcher", "passes", "passes_lean_scan",
+                 "pair_capacity", "live_rank_groups")
+        return dict(zip(names, [int(x) for x in v]))
 
     def set_profiling(self, on=True):
         """False/0: off; True/1: every stage; 2: only the reference scan (cheapest way to time the roofline kernel)."""
@@ -238,4 +259,25 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             _lib.load().skx_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+
+class HostBuffer:
+    """Page-locked host memory (skx_host_alloc) with a numpy view: batch buffers for SumOfSharedHashes.submit."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        _lib.check(_lib.load().skx_host_alloc(device, C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p
+
+    def view(self, dtype, count=None, offset=0):
+        dt = np.dtype(dtype)
+        count = (self.nbytes - offset) // dt.itemsize if count is None else count
+        buf = (C.c_uint8 * (count * dt.itemsize)).from_address(self.ptr.value + offset)
+        return np.frombuffer(buf, dtype=dt, count=count)
+
+    def free(self):
+        if self.ptr:
+            _lib.load().skx_host_free(self.device, self.ptr)
             self.ptr = None

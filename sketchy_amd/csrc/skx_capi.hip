@@ -262,10 +262,13 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipMemcpy(r->d_exc_h, exc_h.data(), (size_t)r->n_exc * 8, hipMemcpyHostToDevice));
     }
     {
-        // bitmap size: 64 bits per reference hash, between 2^16 and 2^33 bits (1 GB); shift so that max_ref fits
+        // bitmap size: 64 bits per reference hash (1.6 % false positives -- each one is an all-zero row of the bit matrices
+        // and an entry of every slice it falls into), between 2^16 and 2^36 bits (8 GB; env SKX_FILTER_LG caps it lower:
+        // at 2^33 bits C2 has 21 bits per hash and half of its dictionary is false positives); shift so that max_ref fits
+        static const u32 lg_cap = getenv("SKX_FILTER_LG") ? (u32)std::min(36, std::max(16, atoi(getenv("SKX_FILTER_LG")))) : 36u;
         const u64 want = 64ull * s * total;
         u32 lg = 16;
-        while (lg < 33 && (1ull << lg) < want) ++lg;
+        while (lg < lg_cap && (1ull << lg) < want) ++lg;
         const u32 max_bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
         r->filt_shift = max_bits > lg ? max_bits - lg : 0u;
         r->filt_bits = 1ull << lg;
@@ -374,11 +377,29 @@ struct skx_stream {
     u32* h_chk = nullptr;    // page-locked, coherent [16]: written by publish_kernel: d_chk, [8] = total pairs, [15] = sequence
     u32 pub_seq = 0;         // sequence number of the latest publish
     bool chk_dirty = false;  // a push failed between arming and publishing: re-zero the device-side counters first
-    u32* d_grp_any[2] = {nullptr, nullptr};  // [rank groups] per buffer set: the group's slice of the bit matrix holds any bit
+    u32* d_grp_any[2] = {nullptr, nullptr};  // [rank groups + 1] per buffer set: the group's slice of the bit matrix holds any
+                                             // bit; last word = "M itself was written this pass" (m_dirty)
+    u64* d_hbuf = nullptr;                   // slabs of the lean scan kernel, [bands * tiles][scan_lean_words()][256]
+    u32* d_wb[2] = {nullptr, nullptr};       // [query words][tiles] bands that can reach a word (launch_word_bands)
     u32* d_retry = nullptr;  // [1 + max_reads] reads the fast sketch variant hands to the full-size one ([0] = count)
     u32* d_big = nullptr;    // [1 + max_reads] reads the wave sketchers hand to the block sketcher ([0] = count)
     u32* d_bsum = nullptr;   // block totals of the pair-count scan
     u64 reads_big = 0;       // reads that went through the block sketcher so far (statistic)
+    u64 last_pairs = 0, last_passes = 0, total_passes = 0, lean_passes = 0;  // statistics (skx_stream_stats)
+    // host-fed pipeline (skx_stream_submit): two staging slots, a copy stream, one batch of lag
+    struct Staged {
+        bool pending = false;   // copied (or being copied) to the device, not yet processed
+        bool in_flight = false; // processed, rows possibly still on their way to the host
+        u32 n_reads = 0;
+        u64 n_bases = 0, ticket = 0;
+        u32* out_idx = nullptr;
+        u64* out_sum = nullptr;
+        uint8_t* d_bases = nullptr;
+        u64 *d_offsets = nullptr, *h_offsets = nullptr;
+        hipEvent_t ev_copy = nullptr, ev_done = nullptr;
+    } slot[2];
+    hipStream_t hs_copy = nullptr;
+    u64 next_ticket = 0;
     u32* h_nq = nullptr;     // pinned [2]
     u32 hint_pairs[2] = {0, 0};
     double nq_per_pair = 1.0;
@@ -402,7 +423,7 @@ static void stream_free(skx_stream* st) {
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
                     st->d_csum, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_big, st->d_bsum, st->d_grp_any[0],
-                    st->d_grp_any[1]};
+                    st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1]};
     for (void* p : ptrs) (void)hipFree(p);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
@@ -411,6 +432,13 @@ static void stream_free(skx_stream* st) {
     (void)hipFree(st->d_chk); (void)hipFree(st->d_retry);
     (void)hipFree(st->d_ht); (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
     (void)hipFree(st->d_btot); (void)hipFree(st->d_dict_ctr);
+    for (auto& sl : st->slot) {
+        (void)hipFree(sl.d_bases); (void)hipFree(sl.d_offsets);
+        if (sl.h_offsets) (void)hipHostFree(sl.h_offsets);
+        if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (st->hs_copy) (void)hipStreamDestroy(st->hs_copy);
     for (auto& sp : st->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : st->ev_pool) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; ++i) {
@@ -539,7 +567,11 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_rank_idx, (size_t)st->rank_cap * 4));
     SCHK(hipMalloc(&st->d_rank_sum, (size_t)st->rank_cap * 8));
     SCHK(hipMalloc(&st->d_bsum, ((size_t)max_reads / 1024 + 2) * 4));
-    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64)) * 4));
+    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64) + 1) * 4));
+    if (skx::scan_lean_applies(ref->n_bands, false, false)) {
+        SCHK(hipMalloc(&st->d_hbuf, (size_t)n_bt * skx::scan_lean_words() * skx::kTileGenomes * 8));
+        for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_wb[i], ((size_t)st->pcap / 64 + 1) * ref->n_tiles * 4));
+    }
     SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
     st->ht_slots = 1024;
@@ -670,6 +702,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
                                st->d_dict_ctr, d_q, d_nq);
         skx::launch_pair_q(hs0, st->d_pair_h, P, d_q, d_nq, d_pair_q);
         skx::launch_window(hs0, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);  // (also hands |Q| to the host)
+        if (st->d_hbuf) skx::launch_word_bands(hs0, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b]);
         st->hint_pairs[b] = P;
     }
     HIPCHK(hipGetLastError());
@@ -686,7 +719,9 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
 
     // ---- scan + transpose (stream hs, HBM-bound)
     HIPCHK(hipStreamWaitEvent(hs, st->ev_dict[b], 0));
-    HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)(n_pad / (skx::kRankWords * 64)) * 4, hs));  // raised by the transpose
+    const u32 n_grp_all = n_pad / (skx::kRankWords * 64);
+    u32* d_mdirty = d_grp_any + n_grp_all;
+    HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)(n_grp_all + 1) * 4, hs));  // raised by the transpose / by writers of M
     if (P > 0) {
         const u32 n_words = (P + 63) / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
@@ -704,20 +739,24 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         }
         static const int big_env = getenv("SKX_SCAN_BIG") ? atoi(getenv("SKX_SCAN_BIG")) : -1;
         const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
+        const bool lean = st->d_hbuf && skx::scan_lean_applies(ref->n_bands, split, big);
+        st->total_passes += 1; st->lean_passes += lean ? 1 : 0;
         {
             Span sp(st, 2, hs);
+            // sparse dictionaries: the lean kernel with its single-owner slabs; dense ones: scan_kernel's variants into M
             // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
             skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, d_q, d_win, st->d_m,
-                             split ? st->d_mint : nullptr, n_pad, big);
+                             split ? st->d_mint : nullptr, n_pad, big, lean ? st->d_hbuf : nullptr, d_mdirty);
         }
         {
             Span sp(st, 1, hs);
             // (after the scan: its persistent form writes complete words with plain stores, these OR single bits in)
-            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad);
+            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad, d_mdirty);
         }
         {
             Span sp(st, 3, hs);
-            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq, d_grp_any);
+            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq, d_grp_any,
+                                       lean ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty);
         }
     }
     HIPCHK(hipGetLastError());
@@ -863,6 +902,7 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         st->reads_big += c[7];
     }
     const u32 total_pairs = st->h_chk[8];
+    st->last_pairs = total_pairs; st->last_passes = 0;
 
     u32* d_shared = nullptr;
     // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
@@ -873,6 +913,7 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
         }
         SKXCHK(run_pass(st, ra, rb, p_base, P, d_topk_idx, d_topk_sum, d_shared, true));
+        st->last_passes += 1;
         if (h_shared) {
             HIPCHK(hipMemcpyAsync(h_shared + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
                                   hipMemcpyDeviceToHost, st->hs2));
@@ -940,6 +981,85 @@ SKX_API int skx_stream_push_device(skx_stream* st, const uint8_t* d_bases, const
                          nullptr);
 }
 
+// ---- host-fed pipeline
+static int staged_process(skx_stream* st, skx_stream::Staged& sl) {
+    if (!sl.pending) return SKX_OK;
+    sl.pending = false;
+    HIPCHK(hipStreamWaitEvent(st->hs0, sl.ev_copy, 0));  // the batch must have landed before the sketcher reads it
+    SKXCHK(process_batch(st, sl.d_bases, sl.d_offsets, nullptr, sl.n_reads, sl.n_bases, st->d_topk_idx, st->d_topk_sum, nullptr,
+                         nullptr, nullptr));
+    // rows travel back behind the pass's ranking (same stream), before the next batch's ranking overwrites them
+    const size_t rows = (size_t)sl.n_reads * st->ref->n_species * st->top_k;
+    if (sl.out_idx) HIPCHK(hipMemcpyAsync(sl.out_idx, st->d_topk_idx, rows * 4, hipMemcpyDeviceToHost, st->hs2));
+    if (sl.out_sum) HIPCHK(hipMemcpyAsync(sl.out_sum, st->d_topk_sum, rows * 8, hipMemcpyDeviceToHost, st->hs2));
+    HIPCHK(hipEventRecord(sl.ev_done, st->hs2));
+    sl.in_flight = true;
+    return SKX_OK;
+}
+SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                              uint32_t* topk_idx, uint64_t* topk_sum, uint64_t* ticket) {
+    if (!st || !offsets) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (n_reads == 0) return fail(SKX_ERR_INVALID, "empty batch");
+    if (n_reads > st->max_reads) return fail(SKX_ERR_CAPACITY, "n_reads=%u exceeds max_batch_reads=%u", n_reads, st->max_reads);
+    for (u32 r = 0; r < n_reads; ++r)
+        if (offsets[r + 1] < offsets[r]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", r);
+    const u64 base0 = offsets[0], n_bases = offsets[n_reads] - base0;
+    if (n_bases > st->max_bases) return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu",
+                                             (unsigned long long)n_bases, (unsigned long long)st->max_bases);
+    if (n_bases && !bases) return fail(SKX_ERR_INVALID, "bases is NULL");
+    if ((topk_idx || topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
+    SKXCHK(use_device(st->device));
+    if (!st->hs_copy) {  // first use: copy stream + two staging slots
+        HIPCHK(hipStreamCreateWithFlags(&st->hs_copy, hipStreamNonBlocking));
+        for (auto& sl : st->slot) {
+            HIPCHK(hipMalloc(&sl.d_bases, std::max<u64>(st->max_bases, 1)));
+            HIPCHK(hipMalloc(&sl.d_offsets, ((size_t)st->max_reads + 1) * 8));
+            HIPCHK(hipHostMalloc((void**)&sl.h_offsets, ((size_t)st->max_reads + 1) * 8, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&sl.ev_copy, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        }
+    }
+    skx_stream::Staged& sl = st->slot[st->next_ticket & 1u];
+    skx_stream::Staged& other = st->slot[(st->next_ticket & 1u) ^ 1u];
+    // the slot's previous batch (two tickets ago) must be through: processed, rows on the host
+    SKXCHK(staged_process(st, sl));
+    if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
+    for (u32 r = 0; r <= n_reads; ++r) sl.h_offsets[r] = offsets[r] - base0;
+    HIPCHK(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st->hs_copy));
+    if (n_bases) HIPCHK(hipMemcpyAsync(sl.d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, st->hs_copy));
+    HIPCHK(hipEventRecord(sl.ev_copy, st->hs_copy));
+    sl.pending = true; sl.n_reads = n_reads; sl.n_bases = n_bases; sl.out_idx = topk_idx; sl.out_sum = topk_sum;
+    sl.ticket = st->next_ticket;
+    if (ticket) *ticket = st->next_ticket;
+    st->next_ticket += 1;
+    // ... and while that copy runs, the previous batch goes through the kernels (its blocking part: the sketch)
+    return staged_process(st, other);
+}
+SKX_API int skx_stream_wait(skx_stream* st, uint64_t ticket) {
+    if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
+    if (ticket >= st->next_ticket) return fail(SKX_ERR_INVALID, "ticket %llu was never issued", (unsigned long long)ticket);
+    SKXCHK(use_device(st->device));
+    skx_stream::Staged& sl = st->slot[ticket & 1u];
+    if (sl.ticket != ticket) return SKX_OK;  // the slot has moved on: that batch completed before it was reused
+    SKXCHK(staged_process(st, sl));
+    if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
+    if (st->profiling) collect_spans(st);
+    return SKX_OK;
+}
+SKX_API int skx_stream_drain(skx_stream* st) {
+    if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
+    SKXCHK(use_device(st->device));
+    // oldest first
+    const u32 first = (u32)(st->next_ticket & 1u);
+    for (u32 i = 0; i < 2; ++i) {
+        skx_stream::Staged& sl = st->slot[(first + i) & 1u];
+        SKXCHK(staged_process(st, sl));
+    }
+    for (auto& sl : st->slot)
+        if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
+    return skx_stream_sync(st);
+}
+
 SKX_API int skx_stream_sync(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
@@ -984,6 +1104,21 @@ SKX_API int skx_stream_reset(skx_stream* st) {
 SKX_API int skx_stream_reads(const skx_stream* st, uint64_t* n_reads) {
     if (!st || !n_reads) return fail(SKX_ERR_INVALID, "NULL argument");
     *n_reads = st->reads_total;
+    return SKX_OK;
+}
+SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
+    if (!st || !out) return fail(SKX_ERR_INVALID, "NULL argument");
+    // rank groups that received any bit in the most recent pass (waits for the stream)
+    uint64_t live = 0;
+    if (use_device(st->device) == SKX_OK && skx_stream_sync(st) == SKX_OK) {
+        const u32 n_grp = st->ref->n_pad / (skx::kRankWords * 64);
+        std::vector<u32> flags(n_grp, 0);
+        if (hipMemcpy(flags.data(), st->d_grp_any[st->buf ^ 1], (size_t)n_grp * 4, hipMemcpyDeviceToHost) == hipSuccess)
+            for (u32 f : flags) live += f ? 1 : 0;
+    }
+    const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)std::max(st->h_nq[0], st->h_nq[1]), st->reads_big,
+                                     st->total_passes, st->lean_passes, st->pcap, live};
+    for (uint32_t i = 0; i < n_out; ++i) out[i] = i < SKX_N_STATS ? v[i] : 0;
     return SKX_OK;
 }
 SKX_API int skx_stream_rank(skx_stream* st, uint32_t top_k, uint32_t* idx, uint64_t* sum) {

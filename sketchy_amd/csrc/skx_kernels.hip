@@ -817,7 +817,9 @@ __global__ void window_kernel(const u64* __restrict__ lo, const u64* __restrict_
     if (bt == 0 && h_nq) { *h_nq = *n_q; __threadfence_system(); }  // |Q| for the host (page-locked memory), a hint only
     if (bt >= n_bt) return;
     const u32 nq = *n_q;
-    u32 qa = 0, qb = 0;
+    // (a band without any real hash -- only possible at the end of a tile's columns -- gets the empty window [nq, nq): the
+    // first index of the windows of a tile then never decreases from band to band, which word_bands_kernel relies on)
+    u32 qa = nq, qb = nq;
     if (lo[bt] <= hi[bt]) { qa = lower_bound_u64(q, nq, lo[bt]); qb = upper_bound_u64(q, nq, hi[bt]); }
     win[2 * bt] = qa;
     win[2 * bt + 1] = qb;
@@ -827,13 +829,15 @@ __global__ void window_kernel(const u64* __restrict__ lo, const u64* __restrict_
 // markers); set their bits here.  exc_g / exc_h: (genome, hash) pairs.
 __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __restrict__ exc_h, u32 n_exc,
                                   const u64* __restrict__ q, const u32* __restrict__ n_q, u64* __restrict__ m_bits,
-                                  u32 n_pad) {
+                                  u32 n_pad, u32* __restrict__ m_dirty) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_exc) return;
     const u32 nq = *n_q;
     const u32 pos = lower_bound_u64(q, nq, exc_h[e]);
-    if (pos < nq && q[pos] == exc_h[e])
+    if (pos < nq && q[pos] == exc_h[e]) {
         atomicOr(&m_bits[(size_t)(pos >> 6) * n_pad + exc_g[e]], 1ull << (pos & 63u));
+        if (m_dirty) *m_dirty = 1u;  // (the transpose must look at M)
+    }
 }
 
 // =====================================================================================
@@ -857,22 +861,13 @@ __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __re
 // SPLIT those go (atomically) to m_bits and every word in between -- complete, owned by the lane -- is stored
 // plainly into m_int; the transpose ORs the two arrays.  Atomics cost a memory-side transaction each (~90 G/s),
 // plain stores into exclusively owned words a fraction of that; the two kinds never share a cache line.
-// FAST PROBE.  The general probe above is ~30 instructions per 8-byte element with two dependent LDS round trips and
-// a data-dependent walk loop, one element after the other -- at the HBM rate that is well over half of the chip's
-// VALU issue slots.  When no directory bucket of the slice holds more than two entries (checked while the directory
-// is built: at C2 a slice has ~70 entries in 2048 buckets, 1-2 % of the slices fail and take the general probe), an
-// element's match, if any, is slice[dir[bucket]] or its successor, so the probe is branch-free up to the hit and
-// eight elements go through it together: 8 bucket computations, 8 directory reads in flight, 8 pairs of entry reads in
-// flight, 16 compares.  Out-of-range elements (and the matrix padding) clamp to the last bucket, whose entries are the
-// end sentinels (kEmpty: no matrix cell holds it -- real hashes >= kEmpty live in the exception list, padding is kPad).
-template <int CAP, int ABLATE, bool SPLIT, bool FAST = false>
-__global__ __launch_bounds__(256, FAST ? 6 : 1) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
+template <int CAP, int ABLATE, bool SPLIT>
+__global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                    const u64* __restrict__ q, const u32* __restrict__ win,
                                                    u64* __restrict__ m_bits, u64* __restrict__ m_int, u32 n_pad) {
     constexpr u32 kBuckets = CAP > 2048 ? 4096 : 2048;  // directory entries (power of two); CAP = 2040 -> 20 KB of LDS
-    __shared__ u64 slice[CAP + 2];
+    __shared__ u64 slice[CAP + 1];
     __shared__ unsigned short dir[kBuckets + 1];
-    __shared__ u32 deep;  // some bucket holds more than two entries: general probe
     const u32 bt = blockIdx.x;
     const u32 t = bt % n_tiles, b = bt / n_tiles, c = threadIdx.x;
     const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
@@ -890,17 +885,15 @@ __global__ __launch_bounds__(256, FAST ? 6 : 1) void scan_kernel(const u64* __re
         const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
         const u32 shift = span_bits > (u32)__builtin_ctz(kBuckets) ? span_bits - (u32)__builtin_ctz(kBuckets) : 0u;
         for (u32 j = c; j < n; j += 256u) slice[j] = q[sub + j];
-        if (c == 0) { slice[n] = kEmpty; slice[n + 1] = kEmpty; deep = 0; }
+        if (c == 0) slice[n] = kPad;
         __syncthreads();
         for (u32 j = c; j <= n; j += 256u) {
             // entry j opens every bucket in (bucket(j-1), bucket(j)]; the sentinel closes the rest
             const u32 bj = j < n ? (u32)((slice[j] - lo) >> shift) : kBuckets;
             const u32 bp = j == 0 ? 0xFFFFFFFFu : (u32)((slice[j - 1] - lo) >> shift);
             for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned short)j;
-            if (FAST && j >= 2u && j < n && (u32)((slice[j - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
         }
         __syncthreads();
-        const bool fast = FAST && deep == 0u && ABLATE == 0;
 
         u32 cur_w = 0xFFFFFFFFu;  // absolute word index (q >> 6)
         u64 cur_bits = 0;
@@ -923,31 +916,156 @@ __global__ __launch_bounds__(256, FAST ? 6 : 1) void scan_kernel(const u64* __re
             if (hv < lo || hv > hi) return;  // also drops the padding value
             u32 j = dir[(u32)((hv - lo) >> shift)];
             u64 e = slice[j];
-            while (e < hv) e = slice[++j];   // the sentinel ends every walk (hv <= hi < kEmpty)
+            while (e < hv) e = slice[++j];   // the sentinel (all ones) ends every walk
             if (ABLATE == 3) { cur_bits ^= e; return; }
             if (e == hv) hit(sub + j);
         };
-        // eight elements at once, branch-free up to the hit (see FAST PROBE above)
-        auto probe8 = [&](const u64 (&h)[8]) {
+        // software-pipelined: the next 8 rows are in flight while the current 8 are probed
+        u32 i = 0;
+        if (rows >= 8u) {
+            u64 h[8];
 #pragma unroll
-            for (u32 v = 0; v < 8u; v += 4u) {  // (four at a time: the entry pairs of eight would cost two waves of occupancy)
-                u32 j[4];
-                u64 e0[4], e1[4];
+            for (u32 u = 0; u < 8u; ++u) h[u] = col[(size_t)u * kTileGenomes];
+            for (i = 8u; i + 8u <= rows; i += 8u) {
+                u64 hn[8];
 #pragma unroll
-                for (u32 u = 0; u < 4u; ++u) {
-                    const u64 d = h[v + u] - lo;
-                    // (shift >= 32 whenever the slice spans more than 2^43: one 32-bit shift of the high word)
-                    const u64 tq = d >> shift;
-                    j[u] = (u32)(tq >> 32) ? kBuckets : min((u32)tq, kBuckets);
-                }
+                for (u32 u = 0; u < 8u; ++u) hn[u] = col[(size_t)(i + u) * kTileGenomes];
 #pragma unroll
-                for (u32 u = 0; u < 4u; ++u) j[u] = dir[j[u]];
+                for (u32 u = 0; u < 8u; ++u) probe(h[u]);
 #pragma unroll
-                for (u32 u = 0; u < 4u; ++u) { e0[u] = slice[j[u]]; e1[u] = slice[j[u] + 1u]; }
+                for (u32 u = 0; u < 8u; ++u) h[u] = hn[u];
+            }
 #pragma unroll
-                for (u32 u = 0; u < 4u; ++u) {
-                    const bool h0 = e0[u] == h[v + u], h1 = e1[u] == h[v + u];
-                    if (h0 || h1) hit(sub + j[u] + (h1 ? 1u : 0u));
+            for (u32 u = 0; u < 8u; ++u) probe(h[u]);
+        }
+        for (; i < rows; ++i) probe(col[(size_t)i * kTileGenomes]);
+
+        if (ABLATE >= 1) {
+            if (cur_bits == 0x123456789ull) m_bits[g] = cur_bits;  // keep the work alive
+        } else if (cur_bits) {
+            atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
+        }
+        __syncthreads();  // slice and directory are rebuilt by the next sub-window
+    }
+}
+
+// =====================================================================================
+// the reference scan, lean probe (default for sparse dictionaries)
+// =====================================================================================
+// scan_kernel's probe costs ~55 issued instructions per 64-lane element (31 VALU, 20 SALU for the exec-mask juggling of
+// its branches and walk loop, 4 LDS): measured, that -- not HBM and not latency -- is what bounds it: 352 M wave
+// instructions per launch over 1024 SIMDs at ~4 cycles each = the kernel's duration.  And once the probe is lean the
+// write-back shows: every lane flushing its 8-byte word by atomicOr at its own moment costs 0.10 of 0.64 ms (plain
+// stores at the same moments still 0.06: partial lines).  Same geometry here (one block per (band, tile), the best
+// memory behaviour of everything tried), with
+//   * a probe of ~20 instructions without branches: slices of at most kLeanCap = 254 entries, one-byte directory of
+//     2048 buckets; while it is built the block checks that no bucket holds more than two entries (C2: a ~70-entry
+//     slice fails with probability ~1.4 % and the block takes the walk-loop probe over the same tables); then an
+//     element's match, if any, is slice[dir[bucket]] or its successor: one ds_read_u8, one ds_read2_b64, two 64-bit
+//     compares.  The bucket is (high word of (h - lo)) >> (shift - 32) clamped to the last bucket, whose entries are
+//     the end sentinels (kEmpty: no matrix cell holds it -- real hashes >= kEmpty live in the exception list, padding
+//     is kPad), so out-of-range elements and padding need no test of their own;
+//   * single-owner output: the block ORs its hit bits into an LDS tile acc[word of the slice][genome] (one ds_or_b64
+//     per hit, no word tracking) and, when the band is done, stores the <= kLeanWords words of its slice for all 256
+//     genomes with plain, fully coalesced stores into ITS OWN slab of `hbuf` -- written exactly once, zero words
+//     included, so nothing has to be cleared.  Bands of a tile overlap in q, so a word of M is the OR of the slabs of the
+//     2-3 bands that reach it: transpose_bits_kernel does that OR (word_bands_kernel tells it which bands).
+// A band whose slice has more than kLeanCap entries (dense dictionaries; the host normally sends those to scan_kernel's
+// split / big-table variants) is streamed once per sub-window with the walk probe and atomicOr into M, and raises
+// *m_dirty so that the transpose also reads M.
+constexpr u32 kLeanCap = 254;
+constexpr u32 kLeanBuckets = 2048;
+constexpr u32 kLeanWords = 5;  // query words a slice of <= kLeanCap entries can touch
+
+template <int ABLATE, bool NT = false>
+__global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
+                                                        const u64* __restrict__ q, const u32* __restrict__ win,
+                                                        u64* __restrict__ m_bits, u32 n_pad, u64* __restrict__ hbuf,
+                                                        u32* __restrict__ m_dirty) {
+    __shared__ u64 slice[kLeanCap + 2];
+    __shared__ unsigned char dir[kLeanBuckets + 8];
+    __shared__ u64 acc[kLeanWords][kTileGenomes];
+    __shared__ u32 deep;  // some bucket holds more than two entries (or the slice spans < 2^43): walk probe
+    const u32 bt = blockIdx.x;
+    const u32 t = bt % n_tiles, b = bt / n_tiles, c = threadIdx.x;
+    const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
+    if (qa >= qb) return;
+    const u32 i0 = b * rb, rows = min(s, i0 + rb) - i0;
+    const u64* col = mat + ((size_t)t * s + i0) * kTileGenomes + c;
+    const u32 g = t * kTileGenomes + c;
+    const bool multi = qb - qa > kLeanCap;  // several sub-window passes: the atomic path into M
+    if (multi && c == 0) *m_dirty = 1u;
+    const u32 w0 = qa >> 6, n_w = ((qb - 1u) >> 6) - w0 + 1u;  // (single window: n_w <= kLeanWords)
+    if (!multi) {
+#pragma unroll
+        for (u32 k = 0; k < kLeanWords; ++k) acc[k][c] = 0;  // (only this lane ever touches column c: no barrier needed)
+    }
+
+    for (u32 sub = qa; sub < qb; sub += kLeanCap) {
+        const u32 n = min(kLeanCap, qb - sub);
+        const u64 lo = q[sub], hi = q[sub + n - 1];
+        // bucket(h) = (h - lo) >> shift, with (hi - lo) >> shift < kLeanBuckets
+        const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
+        const u32 shift = span_bits > (u32)__builtin_ctz(kLeanBuckets) ? span_bits - (u32)__builtin_ctz(kLeanBuckets) : 0u;
+        if (c < n) slice[c] = q[sub + c];
+        if (c == 0) { slice[n] = kEmpty; slice[n + 1] = kEmpty; deep = shift < 32u ? 1u : 0u; }
+        __syncthreads();
+        if (c <= n) {
+            // entry c opens every bucket in (bucket(c-1), bucket(c)]; the sentinel closes the rest
+            const u32 bj = c < n ? (u32)((slice[c] - lo) >> shift) : kLeanBuckets;
+            const u32 bp = c == 0 ? 0xFFFFFFFFu : (u32)((slice[c - 1] - lo) >> shift);
+            for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned char)c;
+            if (c >= 2u && c < n && (u32)((slice[c - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
+        }
+        __syncthreads();
+        const bool lean = deep == 0u && !multi;
+        const u32 sh_hi = shift - 32u;  // (lean only: shift >= 32)
+
+        // ---- multi-window path: word in a register, atomicOr when it moves on (as scan_kernel)
+        u32 cur_w = 0xFFFFFFFFu;
+        u64 cur_bits = 0;
+        auto hit_atomic = [&](u32 qi) {
+            const u32 w = qi >> 6;
+            if (w != cur_w) {
+                if (ABLATE != 1 && cur_bits) atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
+                cur_w = w; cur_bits = 0;
+            }
+            cur_bits |= 1ull << (qi & 63u);
+        };
+        // ---- single-window path: bit (qi - 64 * w0) of this lane's column of the LDS tile
+        const u32 lo_lo = (u32)lo;
+        // (kept in vector registers on purpose: as scalar operands they would be re-moved for every element -- one
+        // scalar operand per VALU instruction on this ISA, and the borrow / the mask already is one)
+        u32 lo_hi = (u32)(lo >> 32), one = 1, zero = 0, rel = sub - (w0 << 6);
+        asm volatile("" : "+v"(lo_hi), "+v"(one), "+v"(zero), "+v"(rel));
+        u64* my_acc = &acc[0][c];
+        auto probe_lean = [&](u64 hv) {
+            if (ABLATE == 2) { cur_bits ^= hv; return; }
+            // high word of (hv - lo), from the halves
+            const u32 dh = (u32)(hv >> 32) - lo_hi - ((u32)hv < lo_lo ? 1u : 0u);
+            const u32 bk = min(dh >> sh_hi, kLeanBuckets);
+            const u32 j = dir[bk];
+            const u64 e0 = slice[j], e1 = slice[j + 1u];
+            if (ABLATE == 3) { cur_bits ^= e0 ^ e1; return; }
+            const bool m1 = e1 == hv;
+            if ((e0 == hv) || m1) {
+                const u32 qr = rel + j + (m1 ? 1u : 0u);
+                __hip_atomic_fetch_or(&my_acc[(size_t)(qr >> 6) * kTileGenomes], make_u64(one, zero) << (qr & 63u),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        auto probe_walk = [&](u64 hv) {
+            if (ABLATE == 2) { cur_bits ^= hv; return; }
+            if (hv < lo || hv > hi) return;  // also drops the padding value
+            u32 j = dir[(u32)((hv - lo) >> shift)];
+            u64 e = slice[j];
+            while (e < hv) e = slice[++j];   // the sentinel ends every walk (hv <= hi < kEmpty)
+            if (ABLATE == 3) { cur_bits ^= e; return; }
+            if (e == hv) {
+                if (multi) hit_atomic(sub + j);
+                else {
+                    const u32 qr = rel + j;
+                    my_acc[(size_t)(qr >> 6) * kTileGenomes] |= 1ull << (qr & 63u);
                 }
             }
         };
@@ -961,28 +1079,91 @@ __global__ __launch_bounds__(256, FAST ? 6 : 1) void scan_kernel(const u64* __re
                 u64 hn[8];
 #pragma unroll
                 for (u32 u = 0; u < 8u; ++u) hn[u] = col[(size_t)(i + u) * kTileGenomes];
-                if (FAST && fast) probe8(h);
-                else {
+                if (lean) {
 #pragma unroll
-                    for (u32 u = 0; u < 8u; ++u) probe(h[u]);
+                    for (u32 u = 0; u < 8u; ++u) probe_lean(h[u]);
+                } else {
+#pragma unroll
+                    for (u32 u = 0; u < 8u; ++u) probe_walk(h[u]);
                 }
 #pragma unroll
                 for (u32 u = 0; u < 8u; ++u) h[u] = hn[u];
             }
-            if (FAST && fast) probe8(h);
-            else {
+            if (lean) {
 #pragma unroll
-                for (u32 u = 0; u < 8u; ++u) probe(h[u]);
+                for (u32 u = 0; u < 8u; ++u) probe_lean(h[u]);
+            } else {
+#pragma unroll
+                for (u32 u = 0; u < 8u; ++u) probe_walk(h[u]);
             }
         }
-        for (; i < rows; ++i) probe(col[(size_t)i * kTileGenomes]);
+        for (; i < rows; ++i) probe_walk(col[(size_t)i * kTileGenomes]);
 
         if (ABLATE >= 1) {
             if (cur_bits == 0x123456789ull) m_bits[g] = cur_bits;  // keep the work alive
-        } else if (cur_bits) {
+        } else if (multi && cur_bits) {
             atomicOr(&m_bits[(size_t)cur_w * n_pad + g], cur_bits);
         }
         __syncthreads();  // slice and directory are rebuilt by the next sub-window
+    }
+    if (!multi && ABLATE != 1) {
+        // this block's slab: [kLeanWords][256] words, the first n_w of them are read by the transpose
+        u64* out = hbuf + (size_t)bt * kLeanWords * kTileGenomes + c;
+        for (u32 k = 0; k < n_w; ++k) {
+            if (NT) __builtin_nontemporal_store(acc[k][c], &out[(size_t)k * kTileGenomes]);
+            else out[(size_t)k * kTileGenomes] = acc[k][c];
+        }
+    }
+}
+
+// Which bands of a tile reach query word w?  A band's slice [qa, qb) covers the words qa >> 6 .. (qb - 1) >> 6; qa grows
+// with the band (the smallest hash of a band does), qb need not (ragged columns), so the answer is the candidate range
+// [first band whose PREFIX MAXIMUM of last words reaches w, last band whose first word is <= w] -- the transpose tests
+// each band of the range.  One block per tile; wb[w * n_tiles + t] = lo | hi << 16 (lo > hi: none).
+constexpr u32 kWordBandsMax = 2048;  // bands per tile the LDS tables hold (s <= 131 072 at 64 rows per band)
+__global__ __launch_bounds__(256) void word_bands_kernel(const u32* __restrict__ win, u32 n_tiles, u32 n_bands,
+                                                         const u32* __restrict__ n_q, u32* __restrict__ wb) {
+    __shared__ u32 first_w[kWordBandsMax], pmax_w[kWordBandsMax];
+    __shared__ u32 wtot[4];
+    const u32 t = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 n_words = (*n_q + 63u) >> 6;
+    // first word / (last word + 1) per band; empty bands reach nothing
+    u32 carry = 0;  // prefix maximum of (last word + 1) so far
+    for (u32 b0 = 0; b0 < n_bands; b0 += 256u) {
+        const u32 b = b0 + tid;
+        u32 fw = 0xFFFFFFFFu, lw1 = 0;
+        if (b < n_bands) {
+            const u32 qa = win[2 * (b * n_tiles + t)], qb = win[2 * (b * n_tiles + t) + 1];
+            fw = qa >> 6;  // (monotone in b, also for empty bands: window_kernel)
+            if (qa < qb) lw1 = ((qb - 1u) >> 6) + 1u;
+        }
+        // inclusive prefix maximum over the block
+        u32 v = lw1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 o = (u32)__shfl_up((int)v, d, 64);
+            if ((int)lane >= d) v = max(v, o);
+        }
+        if (lane == 63u) wtot[wv] = v;
+        __syncthreads();
+        u32 before = carry;
+        for (u32 x = 0; x < wv; ++x) before = max(before, wtot[x]);
+        v = max(v, before);
+        if (b < n_bands) { first_w[b] = fw; pmax_w[b] = v; }
+        const u32 tot = max(max(max(wtot[0], wtot[1]), max(wtot[2], wtot[3])), carry);
+        __syncthreads();
+        carry = tot;
+    }
+    __syncthreads();
+    for (u32 w = tid; w < n_words; w += 256u) {
+        // hi = last band with first_w <= w  (upper bound - 1);  lo = first band with pmax_w >= w + 1
+        u32 a = 0, z = n_bands;
+        while (a < z) { const u32 m = (a + z) >> 1; if (first_w[m] <= w) a = m + 1; else z = m; }
+        const u32 hi = a;  // (one past)
+        a = 0; z = n_bands;
+        while (a < z) { const u32 m = (a + z) >> 1; if (pmax_w[m] < w + 1u) a = m + 1; else z = m; }
+        const u32 lo = a;
+        wb[(size_t)w * n_tiles + t] = (lo < hi) ? (lo | ((hi - 1u) << 16)) : (1u | (0u << 16));
     }
 }
 
@@ -1039,9 +1220,14 @@ constexpr u32 kWordsPerBlock = 4;
 // written back): no memset of 2 x |M| bytes per pass.
 // grp_any[grp] (zero on entry) is raised when the group's slice of the matrix holds any bit at all: rank groups without
 // one -- a whole species the sample does not belong to, for instance -- are skipped by every kernel of the back half.
+// hbuf != NULL: scan_lean_kernel's per-(band, tile) slabs are OR-ed in (the bands word_bands_kernel lists in wb, each
+// tested against its window), and M itself is only read when *m_dirty says somebody wrote it.
 __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m_bits, u64* __restrict__ m_int,
                                                              u32 n_pad, u32 n_words, u64* __restrict__ mq, u32 n_gw,
-                                                             const u32* __restrict__ n_q, u32* __restrict__ grp_any) {
+                                                             const u32* __restrict__ n_q, u32* __restrict__ grp_any,
+                                                             const u64* __restrict__ hbuf, const u32* __restrict__ wb,
+                                                             const u32* __restrict__ win, u32 n_tiles,
+                                                             const u32* __restrict__ m_dirty) {
     __shared__ u64 tile[2][64][kRankWords + 1];
     // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
     // index Q, so rows of Mq beyond nq are never read
@@ -1052,13 +1238,27 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
     const u32 gw = grp * kRankWords + wv;
     const bool on = gw < n_gw;
     const size_t col = (size_t)gw * 64u + lane;
+    const bool read_m = hbuf == nullptr || *m_dirty != 0u;
+    const u32 ref_tile = gw / (kTileGenomes / 64u), tc = (gw % (kTileGenomes / 64u)) * 64u + lane;  // this lane's genome in its tile
     auto load = [&](u32 w) -> u64 {
         if (!on || w >= w1) return 0;
-        u64 x = m_bits[(size_t)w * n_pad + col];
-        if (x) m_bits[(size_t)w * n_pad + col] = 0;
-        if (m_int) {
-            const u64 y = m_int[(size_t)w * n_pad + col];
-            if (y) { m_int[(size_t)w * n_pad + col] = 0; x |= y; }
+        u64 x = 0;
+        if (read_m) {
+            x = m_bits[(size_t)w * n_pad + col];
+            if (x) m_bits[(size_t)w * n_pad + col] = 0;
+            if (m_int) {
+                const u64 y = m_int[(size_t)w * n_pad + col];
+                if (y) { m_int[(size_t)w * n_pad + col] = 0; x |= y; }
+            }
+        }
+        if (hbuf) {
+            const u32 range = wb[(size_t)w * n_tiles + ref_tile];  // (wave-uniform: scalar loads below)
+            for (u32 b = range & 0xFFFFu; b <= (range >> 16); ++b) {
+                const u32 bt = b * n_tiles + ref_tile;
+                const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
+                if (qa < qb && qb - qa <= kLeanCap && (qa >> 6) <= w && w <= ((qb - 1u) >> 6))
+                    x |= hbuf[((size_t)bt * kLeanWords + (w - (qa >> 6))) * kTileGenomes + tc];
+            }
         }
         return x;
     };
@@ -1944,17 +2144,44 @@ void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const
     hipLaunchKernelGGL(window_kernel, dim3(cdiv(n_bt, 256)), dim3(256), 0, st, lo, hi, n_bt, q, n_q, win, h_nq);
 }
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
-                       u64* m_bits, u32 n_pad) {
+                       u64* m_bits, u32 n_pad, u32* m_dirty) {
     if (n_exc == 0) return;
     hipLaunchKernelGGL(exceptions_kernel, dim3(cdiv(n_exc, 256)), dim3(256), 0, st, exc_g, exc_h, n_exc, q, n_q,
-                       m_bits, n_pad);
+                       m_bits, n_pad, m_dirty);
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
+bool scan_lean_applies(u32 n_bands, bool split, bool big_table) {
+    static const int lean_env = env_int("SKX_SCAN_LEAN", 1);
+    return lean_env && !split && !big_table && n_bands <= kWordBandsMax;
+}
+u32 scan_lean_words() { return kLeanWords; }
+void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb) {
+    hipLaunchKernelGGL(word_bands_kernel, dim3(n_tiles), dim3(256), 0, st, win, n_tiles, n_bands, n_q, wb);
+}
+
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
-                 u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table) {
+                 u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table,
+                 u64* hbuf /* slabs of the lean kernel, or NULL: legacy kernels */, u32* m_dirty) {
     static const int ablate = env_int("SKX_SCAN_ABLATE", 0);  // profiling aid only
     dim3 grid(n_tiles * n_bands), block(256);
+    // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe
+    if (hbuf) {
+#define SKX_SCAN_L(A) hipLaunchKernelGGL((scan_lean_kernel<A>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty)
+        switch (ablate) {
+            case 1: SKX_SCAN_L(1); break;
+            case 2: SKX_SCAN_L(2); break;
+            case 3: SKX_SCAN_L(3); break;
+            default: {
+                static const int nt = env_int("SKX_SCAN_NT", 0);  // experiment: non-temporal slab stores
+                if (nt) hipLaunchKernelGGL((scan_lean_kernel<0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty);
+                else SKX_SCAN_L(0);
+                break;
+            }
+        }
+#undef SKX_SCAN_L
+        return;
+    }
 #define SKX_SCAN(A, SP) \
     hipLaunchKernelGGL((scan_kernel<2040, A, SP>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
     if (big_table && ablate == 0 && m_int) {
@@ -1976,21 +2203,16 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
         case 1: SKX_SCAN(1, false); break;
         case 2: SKX_SCAN(2, false); break;
         case 3: SKX_SCAN(3, false); break;
-        default: {
-            static const int fast = env_int("SKX_SCAN_FAST", 0);  // experiment: the branch-free four-at-a-time probe
-            if (m_int) SKX_SCAN(0, true);
-            else if (fast) hipLaunchKernelGGL((scan_kernel<2040, 0, false, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
-            else SKX_SCAN(0, false);
-            break;
-        }
+        default: if (m_int) SKX_SCAN(0, true); else SKX_SCAN(0, false); break;
     }
 #undef SKX_SCAN
 }
-void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any) {
+void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any,
+                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
-                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any);
+                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty);
 }
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail) {
     hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk,

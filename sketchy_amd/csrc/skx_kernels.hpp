@@ -44,15 +44,25 @@ u32 dict_buckets();
 void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win,
                    u32* h_nq /* page-locked host word that receives *n_q, or NULL */);
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
-                       u64* m_bits, u32 n_pad);
+                       u64* m_bits, u32 n_pad, u32* m_dirty /* raised when a bit was set, or NULL */);
 
 // scan + transpose
+// hbuf != NULL: the lean kernel (sparse dictionaries): every (band, tile) block stores the words of its slice into its own
+// slab hbuf[(band * n_tiles + tile) * scan_lean_words() * 256 ...] (plain stores, nothing to clear); only bands with
+// dense slices go through atomicOr into m_bits and raise *m_dirty.  hbuf == NULL: scan_kernel variants into m_bits / m_int.
+bool scan_lean_applies(u32 n_bands, bool split, bool big_table);
+u32 scan_lean_words();
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
-                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table);
+                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table, u64* hbuf, u32* m_dirty);
+// wb[w * n_tiles + t] = (first | last << 16) band of tile t whose slice can reach query word w (first > last: none)
+void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb);
 // also re-zeroes m_bits / m_int; words beyond *n_q are skipped; raises grp_any[rank group] (zero on entry) for every
 // rank group whose slice of the matrix holds any bit -- the ranking kernels skip the others (grp_any arguments below)
+// hbuf != NULL: also ORs the lean kernel's slabs in (wb from launch_word_bands, win = the windows) and reads m_bits only
+// when *m_dirty != 0
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
-                           const u32* n_q, u32* grp_any);
+                           const u32* n_q, u32* grp_any, const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles,
+                           const u32* m_dirty);
 // chk[0..5] (zeroed by the caller): non-monotonic marker, long-read count, offsets[0], offsets[n_reads]
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail /* zeroed */);
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last

@@ -411,6 +411,45 @@ def test_push_device_errors_leave_the_table_alone(gpu):
     assert S.reads == 20
 
 
+def test_submit_pipeline_matches_push(gpu):
+    """skx_stream_submit / wait / drain (page-locked buffers, copy of batch i+1 overlapping batch i, processing one
+    call behind submission): rows and table of the same batches pushed synchronously; uneven batches, a wait in the
+    middle, reuse of the stream afterwards."""
+    import ctypes as C
+    from sketchy_amd import api
+    ref, bases, offsets = workload(300, 400, 930, read_len=700, rng_seed=191)
+    exp = orc.stream(16, 0, 400, ref["ref"], ref["col_len"], bases, offsets, top_k=2)
+    n = len(offsets) - 1
+    R = api.ReferenceSketch(ref["ref"], ref["col_len"])
+    S = api.SumOfSharedHashes(R, top=2, max_batch_reads=256, max_batch_bases=256 * 700)
+    hb, ho = api.HostBuffer(len(bases)), api.HostBuffer((n + 1) * 8)
+    hi, hs = api.HostBuffer(n * 2 * 4), api.HostBuffer(n * 2 * 8)
+    hb.view(np.uint8)[:] = bases
+    ho.view(np.uint64)[:] = offsets
+    hi.view(np.uint32)[:] = 0xFFFFFFFF
+    at = lambda buf, off: C.c_void_p(buf.ptr.value + off)
+    cuts = [0, 256, 300, 301, 557, 800, 930]
+    tickets = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        tickets.append(S.submit(hb.ptr, at(ho, a * 8), b - a, at(hi, a * 8), at(hs, a * 16)))
+        if len(tickets) == 3:
+            S.wait(tickets[0])  # the first batch is complete although two more are queued behind it
+            np.testing.assert_array_equal(hi.view(np.uint32).reshape(n, 2)[:256], exp["topk_idx"][:256])
+    S.wait(tickets[3])
+    np.testing.assert_array_equal(hs.view(np.uint64).reshape(n, 2)[:557], exp["topk_sum"][:557])
+    S.drain()
+    np.testing.assert_array_equal(hi.view(np.uint32).reshape(n, 2), exp["topk_idx"])
+    np.testing.assert_array_equal(hs.view(np.uint64).reshape(n, 2), exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    assert S.reads == n
+    # the synchronous entry point still works on the same stream after a drain
+    S.reset()
+    got = S.push(bases, offsets[:201])
+    np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"][:200])
+    for h in (hb, ho, hi, hs):
+        h.free()
+
+
 @pytest.mark.parametrize("top", [2, 16, 17, 40])
 def test_topk_fast_and_generic_paths(gpu, top):
     """2..16 rows: pruned per-group kernel; 17..64: generic per-word kernel.  Duplicated genomes give ties that span

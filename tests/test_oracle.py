@@ -154,3 +154,75 @@ def test_stream_rejects_top_above_n():
     ref, bases, offsets = workload(3, 16, 2, read_len=200, genome_len=30000, rng_seed=29)
     with pytest.raises(ValueError):
         orc.stream(16, 0, 16, ref["ref"], ref["col_len"], bases, offsets, top_k=4)
+
+
+def test_sanitizer_build_of_the_oracle_runs_clean(tmp_path):
+    """oracle/Makefile's ASan + UBSan target (CPU only: GPU sanitizers are unavailable on the pool): the streaming driver,
+    both sketchers and the OpenMP variant on a small workload, in a child process with the sanitizer runtime preloaded."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(here, "oracle"), "liboracle_asan.so"], stdout=subprocess.DEVNULL)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan not installed")
+    code = (
+        "import ctypes as C, numpy as np, sys\n"
+        f"sys.path.insert(0, {here!r}); sys.path.insert(0, {os.path.join(here, 'tests')!r})\n"
+        "from helpers import workload\n"
+        f"L = C.CDLL({os.path.join(here, 'oracle', 'liboracle_asan.so')!r})\n"
+        "ref, bases, offsets = workload(30, 64, 25, read_len=300, genome_len=20000, rng_seed=5)\n"
+        "p = lambda a: a.ctypes.data_as(C.c_void_p)\n"
+        "n = 25; cum = np.zeros(30, np.uint64); ti = np.zeros((n, 2), np.uint32); ts = np.zeros((n, 2), np.uint64)\n"
+        "sh = np.zeros((n, 30), np.uint32); sk = np.zeros((n, 64), np.uint64); sl = np.zeros(n, np.uint32)\n"
+        "L.orc_stream.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.c_int]\n"
+        "rc = L.orc_stream(16, 0, 64, 30, p(ref['ref']), p(ref['col_len']), p(bases), p(offsets), n, 2, p(cum), p(ti), p(ts), p(sh), p(sk), p(sl), 1)\n"
+        "assert rc == 0 and cum.sum() == sh.sum()\n"
+        "cum2 = np.zeros(30, np.uint64)\n"
+        "L.orc_stream_mt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32] + [C.c_void_p] * 3 + [C.c_int]\n"
+        "rc = L.orc_stream_mt(16, 0, 64, 30, p(ref['ref']), p(ref['col_len']), p(bases), p(offsets), n, 2, p(cum2), p(ti), p(ts), 3)\n"
+        "assert rc == 0 and np.array_equal(cum, cum2)\n"
+        "out = np.zeros(65, np.uint64)\n"
+        "for f in (L.orc_sketch_sort, L.orc_sketch_heap):\n"
+        "    f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]; f.restype = C.c_uint64\n"
+        "    assert f(p(bases), int(offsets[1]), 16, 0, 64, p(out)) <= 64\n"
+        "print('asan ok')\n"
+    )
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="3")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "asan ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_reference_pinned_vectors():
+    """Outputs of the REAL reference binary, frozen by tools/pin_from_reference.sh on a machine with a Rust toolchain
+    (this image has none: the directory is absent and the test skips -- parity stays 'unpinned').  Once
+    present: the oracle must reproduce `sketchy predict -s -t 5 -H` row for row on the frozen inputs."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = os.path.join(here, "golden", "ref_pinned")
+    if not os.path.isdir(d):
+        pytest.skip("no reference outputs pinned yet (tools/pin_from_reference.sh needs cargo + the reference's crates)")
+    from mshio import read_msh
+    for tag in ("s1000_e0", "s1000_e42"):
+        k, seed, recs = read_msh(os.path.join(d, f"ref_{tag}.msh"))
+        names, hashes = [r["name"] for r in recs], [r["hashes"] for r in recs]
+        s = max(len(h) for h in hashes)
+        ref = np.zeros((len(names), s), np.uint64)
+        col_len = np.zeros(len(names), np.uint32)
+        for i, h in enumerate(hashes):
+            ref[i, :len(h)] = h
+            col_len[i] = len(h)
+        geno = {ln.split("\t")[0]: ln.rstrip("\n").split("\t")[1:] for ln in open(os.path.join(d, "genotypes.tsv")).readlines()[1:]}
+        for fq in ("reads", "reads_edge"):
+            lines = open(os.path.join(d, f"{fq}.fq"), "rb").read().split(b"\n")
+            reads = [lines[i] for i in range(1, len(lines), 4)]
+            offsets = np.zeros(len(reads) + 1, np.uint64)
+            offsets[1:] = np.cumsum([len(r) for r in reads])
+            bases = np.frombuffer(b"".join(reads), np.uint8)
+            exp = orc.stream(k, seed, s, ref, col_len, bases, offsets, top_k=5)
+            want = open(os.path.join(d, f"pred_ref.{tag}.{fq}.5.tsv")).read().split("\n")
+            rows = [ln for ln in want if ln and not ln.startswith("reads\t")]
+            assert len(rows) == 5 * len(reads)
+            for r in range(len(reads)):
+                for j in range(5):
+                    nm = names[exp["topk_idx"][r, j]]
+                    assert rows[5 * r + j] == f"{r + 1}\t{nm}\t{exp['topk_sum'][r, j]}\t" + "\t".join(geno[nm])
