@@ -1028,7 +1028,7 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     HIPCHK(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st->hs_copy));
     if (n_bases) HIPCHK(hipMemcpyAsync(sl.d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, st->hs_copy));
     HIPCHK(hipEventRecord(sl.ev_copy, st->hs_copy));
-    sl.pending = true; sl.n_reads = n_reads; sl.n_bases = n_bases; sl.out_idx = topk_idx; sl.out_sum = topk_sum;
+    sl.pending = true; sl.n_reads = n_reads; sl.n_bases = n_bases; sl.out_idx = topk_idx; sl.out_sum = reinterpret_cast<u64*>(topk_sum);
     sl.ticket = st->next_ticket;
     if (ticket) *ticket = st->next_ticket;
     st->next_ticket += 1;
