@@ -1119,8 +1119,10 @@ __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ 
 // Which bands of a tile reach query word w?  A band's slice [qa, qb) covers the words qa >> 6 .. (qb - 1) >> 6; qa grows
 // with the band (the smallest hash of a band does), qb need not (ragged columns), so the answer is the candidate range
 // [first band whose PREFIX MAXIMUM of last words reaches w, last band whose first word is <= w] -- the transpose tests
-// each band of the range.  One block per tile; wb[w * n_tiles + t] = lo | hi << 16 (lo > hi: none).
+// each band of the range -- here, once per (word, tile), so that transpose_bits_kernel only follows ready-made slab
+// indices.  One block per tile; wb[w * n_tiles + t] = four slab word indices (kWbNone = unused).
 constexpr u32 kWordBandsMax = 2048;  // bands per tile the LDS tables hold (s <= 131 072 at 64 rows per band)
+constexpr u32 kWbNone = 0xFFFFFFFFu, kWbRange = 0xFFFFFFFEu;
 __global__ __launch_bounds__(256) void word_bands_kernel(const u32* __restrict__ win, u32 n_tiles, u32 n_bands,
                                                          const u32* __restrict__ n_q, u32* __restrict__ wb) {
     __shared__ u32 first_w[kWordBandsMax], pmax_w[kWordBandsMax];
@@ -1163,7 +1165,21 @@ __global__ __launch_bounds__(256) void word_bands_kernel(const u32* __restrict__
         a = 0; z = n_bands;
         while (a < z) { const u32 m = (a + z) >> 1; if (pmax_w[m] < w + 1u) a = m + 1; else z = m; }
         const u32 lo = a;
-        wb[(size_t)w * n_tiles + t] = (lo < hi) ? (lo | ((hi - 1u) << 16)) : (1u | (0u << 16));
+        // up to four slab words (index into hbuf in units of 256 u64) that hold bits of query word w for this tile;
+        // more than four bands reaching one word (ragged / dense references): e[3] = kWbRange, e[0] = lo | last << 16
+        uint4 e = make_uint4(kWbNone, kWbNone, kWbNone, kWbNone);
+        u32 cnt = 0;
+        for (u32 b = lo; b < hi; ++b) {
+            const u32 bt = b * n_tiles + t;
+            const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
+            if (qa < qb && qb - qa <= kLeanCap && (qa >> 6) <= w && w <= ((qb - 1u) >> 6)) {
+                const u32 word = bt * kLeanWords + (w - (qa >> 6));
+                if (cnt == 0) e.x = word; else if (cnt == 1) e.y = word; else if (cnt == 2) e.z = word; else if (cnt == 3) e.w = word;
+                ++cnt;
+            }
+        }
+        if (cnt > 4u) e = make_uint4(lo | ((hi - 1u) << 16), kWbNone, kWbNone, kWbRange);
+        reinterpret_cast<uint4*>(wb)[(size_t)w * n_tiles + t] = e;
     }
 }
 
@@ -1227,7 +1243,8 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
                                                              const u32* __restrict__ n_q, u32* __restrict__ grp_any,
                                                              const u64* __restrict__ hbuf, const u32* __restrict__ wb,
                                                              const u32* __restrict__ win, u32 n_tiles,
-                                                             const u32* __restrict__ m_dirty) {
+                                                             const u32* __restrict__ m_dirty,
+                                                             unsigned char* __restrict__ rowmask) {
     __shared__ u64 tile[2][64][kRankWords + 1];
     // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
     // index Q, so rows of Mq beyond nq are never read
@@ -1252,12 +1269,19 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
             }
         }
         if (hbuf) {
-            const u32 range = wb[(size_t)w * n_tiles + ref_tile];  // (wave-uniform: scalar loads below)
-            for (u32 b = range & 0xFFFFu; b <= (range >> 16); ++b) {
-                const u32 bt = b * n_tiles + ref_tile;
-                const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
-                if (qa < qb && qb - qa <= kLeanCap && (qa >> 6) <= w && w <= ((qb - 1u) >> 6))
-                    x |= hbuf[((size_t)bt * kLeanWords + (w - (qa >> 6))) * kTileGenomes + tc];
+            const uint4 e = reinterpret_cast<const uint4*>(wb)[(size_t)w * n_tiles + ref_tile];  // (wave-uniform)
+            if (e.w != kWbRange) {
+                if (e.x != kWbNone) x |= hbuf[(size_t)e.x * kTileGenomes + tc];
+                if (e.y != kWbNone) x |= hbuf[(size_t)e.y * kTileGenomes + tc];
+                if (e.z != kWbNone) x |= hbuf[(size_t)e.z * kTileGenomes + tc];
+                if (e.w != kWbNone) x |= hbuf[(size_t)e.w * kTileGenomes + tc];
+            } else {  // more than four bands reach this word: walk the candidate range
+                for (u32 b = e.x & 0xFFFFu; b <= (e.x >> 16); ++b) {
+                    const u32 bt = b * n_tiles + ref_tile;
+                    const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
+                    if (qa < qb && qb - qa <= kLeanCap && (qa >> 6) <= w && w <= ((qb - 1u) >> 6))
+                        x |= hbuf[((size_t)bt * kLeanWords + (w - (qa >> 6))) * kTileGenomes + tc];
+                }
             }
         }
         return x;
@@ -1272,7 +1296,14 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
         const u32 bsel = (w - w0) & 1u;
         tile[bsel][lane][wv] = transpose64(cur, lane);
         __syncthreads();  // (double-buffered tile: one barrier per word is enough)
-        if (grp * kRankWords + cw < n_gw) mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = tile[bsel][row][cw];
+        const u64 v = tile[bsel][row][cw];
+        if (grp * kRankWords + cw < n_gw) mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = v;
+        // rowmask: bit (query row) of word [grp][w] = the row holds a bit for some genome of the group (seg_sum skips the
+        // others).  This wave wrote rows 8 wv .. 8 wv + 7, eight lanes each: byte wv of the little-endian word.
+        u64 nzb = __ballot(v != 0);
+        nzb |= nzb >> 4; nzb |= nzb >> 2; nzb |= nzb >> 1;
+        nzb &= 0x0101010101010101ull;
+        if (lane == 0) rowmask[((size_t)grp * n_words + w) * 8u + wv] = (unsigned char)((nzb * 0x0102040810204080ull) >> 56);
     }
     if (__ballot(seen != 0) && lane == 0) grp_any[grp] = 1u;  // (plain store of the same value from several waves)
 }
@@ -1339,7 +1370,8 @@ __device__ __forceinline__ void add_planes(u32 (&x)[10], const u32 (&y)[10]) {
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
-                                                      u32 nq_rows, u32* __restrict__ inc, const u32* __restrict__ grp_any) {
+                                                      u32 nq_rows, u32* __restrict__ inc, const u32* __restrict__ grp_any,
+                                                      const u64* __restrict__ rowmask) {
     static_assert(kRankWords == 8, "lane = (sub, word) layout assumes 8 words per rank group");
     const u32 lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + kRankWords - 1) / kRankWords;
@@ -1352,6 +1384,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     if (grp >= n_grp || !grp_any[grp]) return;  // (a group without any bit: nobody reads its increments)
     const u32 sub = lane >> 3, j = lane & 7u;
     const u64* mq_gj = mq + (size_t)grp * nq_rows * kRankWords + j;
+    const u64* rm_g = rowmask + (size_t)grp * (nq_rows >> 6);  // which query rows hold a bit for this group at all
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     u32 acc[8];
@@ -1366,7 +1399,14 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
 #pragma unroll
             for (u32 u = 0; u < 8u; ++u) {
                 const u32 p = p0 + 8u * u + sub;
-                x[u] = p < bz ? mq_gj[(size_t)pair_q[p] * kRankWords] : 0ull;
+                u64 v = 0;
+                if (p < bz) {
+                    // (a species that only shares a stray k-mer with the sample: nearly all of its rows are empty -- one
+                    // bit of a cached mask instead of a 64-byte gather)
+                    const u32 qq = pair_q[p];
+                    if ((rm_g[qq >> 6] >> (qq & 63u)) & 1ull) v = mq_gj[(size_t)qq * kRankWords];
+                }
+                x[u] = v;
             }
             u64 twos_a, twos_b, fours_a, fours_b, eights_a;
             SKX_CSA(twos_a, ones, ones, x[0], x[1])
@@ -1734,7 +1774,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     // a group without any bit in the pass (e.g. a species the sample does not belong to): its sums do not move -- no
     // start values / increments were written for it, no pairs are replayed, one key serves the whole segment
     const bool dead = !grp_any[grp];
-    const u32 pa = poff[r_begin + ra] - p_base, pz = dead ? pa : poff[r_begin + rz] - p_base;
+    const u32 pa = poff[r_begin + ra] - p_base;
+    u32 pz = dead ? pa : poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
     // Pruning (exact).  Sums never decrease and a genome ends the segment at start + inc, so with ANY lower bound
     // `lead` of the leading sum over the segment, only genomes with start + inc >= lead can lead at one of its
@@ -1758,6 +1799,14 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         st0[j] = real[j] ? cum_in[g] + (dead ? 0u : rel[(size_t)seg * n_pad + g]) : 0;
         ic[j] = (real[j] && !dead) ? inc[(size_t)seg * n_pad + g] : 0;
         grp_best = max(grp_best, st0[j]);
+    }
+    // Nobody in this group gains anything in this segment (a species that shares a k-mer with the sample now and then:
+    // most of its (group, segment)s): the sums stand still, one key serves every read -- nothing to gather or replay.
+    {
+        u32 any_inc = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) any_inc |= ic[j];
+        if (__ballot(any_inc != 0u) == 0ull) pz = pa;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) grp_best = max(grp_best, shfl_xor64(grp_best, d));
@@ -2208,11 +2257,12 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 #undef SKX_SCAN
 }
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any,
-                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty) {
+                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64* rowmask) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
-                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty);
+                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty,
+                       reinterpret_cast<unsigned char*>(rowmask));
 }
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail) {
     hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk,
@@ -2231,12 +2281,12 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
     hipLaunchKernelGGL(filter_apply_kernel, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, sk, sk_stride, cnt, n_reads, bits, shift);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any) {
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any, const u64* rowmask) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     const u32 n_grp = cdiv(n_gw, kRankWords);
     // 8 XCDs x ceil(groups / 8) groups each x n_seg segments, 4 waves (segments) per workgroup
     hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv((u64)cdiv(n_grp, 8) * n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
-                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any);
+                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any, rowmask);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32 prune_top_k, u32* leader,

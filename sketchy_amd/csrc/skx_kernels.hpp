@@ -62,7 +62,7 @@ void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands,
 // when *m_dirty != 0
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
                            const u32* n_q, u32* grp_any, const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles,
-                           const u32* m_dirty);
+                           const u32* m_dirty, u64* rowmask /* [rank groups][n_words]: bit = the query row holds a bit */);
 // chk[0..5] (zeroed by the caller): non-monotonic marker, long-read count, offsets[0], offsets[n_reads]
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail /* zeroed */);
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
@@ -74,7 +74,7 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any);
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any, const u64* rowmask);
 // prune_top_k > 0 (1..rank_topk_fast_max()): also find the first prune_top_k genomes as each chunk of 16 segments begins
 // (leader [n_chunks * k], lead_val [n_chunks]) and every half rank group's best value per chunk boundary (gmax
 // [(n_chunks + 1) * n_pad / 256]); start values are then only written for (chunk, group)s that can hold a candidate.
