@@ -488,11 +488,13 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
 
     hipError_t e;
 #define SCHK(expr) do { e = (expr); if (e != hipSuccess) { stream_free(st); return fail(SKX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
-    // pipeline depth (env SKX_PIPELINE, default 2): 1 = one stream (strictly serial), 2 = {sketch, dictionary, scan,
-    // transpose} | {ranking}, 3 = {sketch, dictionary} | {scan, transpose} | {ranking}.  Measured on MI355X (C2,
-    // B=49152): 9.9 / 10.3 / 10.0 M reads/s -- with three streams the HBM-bound scan loses more from sharing the
-    // CUs (1.55 -> 2.4 ms) than the overlap returns.
-    static const int depth_env = getenv("SKX_PIPELINE") ? atoi(getenv("SKX_PIPELINE")) : 2;
+    // pipeline depth (env SKX_PIPELINE, default 3): 1 = one stream (strictly serial), 2 = {sketch, dictionary, scan,
+    // transpose} | {ranking}, 3 = {sketch, dictionary} | {scan, transpose} | {ranking}.  With round 1's scan kernel
+    // (issue-bound itself) three streams gained nothing; with the lean scan kernel, its waves at raised priority and the
+    // sketch kernel leaving room on every CU (launch_sketch, leave_room) the VALU-bound sketch of batch i+1 and the
+    // HBM-bound scan of batch i overlap for real: C2, same box: 54.5 -> 59.7 M reads/s from a fresh table, 56.8 -> 63.6 M
+    // steady, the scan itself 0.62 -> 0.78 ms.
+    static const int depth_env = getenv("SKX_PIPELINE") ? atoi(getenv("SKX_PIPELINE")) : 3;
     st->depth = depth_env < 1 ? 1 : depth_env > 3 ? 3 : depth_env;
     // the HBM-bound scan stream gets the higher priority (it needs its full occupancy); the others fill what is left
     int prio_lo = 0, prio_hi = 0;
@@ -873,9 +875,15 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         skx::launch_batch_check(hs, d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk, st->d_cnt + n_reads);
         if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
         // every read, any length: wave sketchers, then the block sketcher for what overflowed (device-side lists)
+        // (three-stream pipeline: is the previous pass's scan still in flight?  then this sketch shares the CUs with it)
+        bool leave_room = false;
+        if (st->depth >= 3)
+            for (int i = 0; i < 2; ++i)
+                if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = true;
+        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
         HIPCHK(skx::launch_sketch(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
                                   st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big, n_bases,
-                                  st->d_chk));
+                                  st->d_chk, leave_room));
         // optional sketch outputs leave now: the filter compacts the rows in place
         if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
         if (h_sketches) {
@@ -1178,7 +1186,7 @@ SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, 
         if ((e = hipMemset(d_sk, 0, (size_t)n_reads * stride * 8)) != hipSuccess) break;
         if ((e = hipMemset(d_lists, 0, 2 * ((size_t)n_reads + 1) * 4)) != hipSuccess) break;
         if ((e = skx::launch_sketch(nullptr, d_b, d_o, n_reads, k, seed, s, 0, false, d_sk, stride, d_len, d_cnt, nullptr, 0,
-                                    d_lists, d_lists + n_reads + 1, n_bases, nullptr)) != hipSuccess) break;
+                                    d_lists, d_lists + n_reads + 1, n_bases, nullptr, false)) != hipSuccess) break;
         memset(sketches, 0, (size_t)n_reads * s * 8);
         if ((e = hipMemcpy2D(sketches, (size_t)s * 8, d_sk, (size_t)stride * 8, (size_t)stride * 8, n_reads, hipMemcpyDeviceToHost)) != hipSuccess) break;
         if ((e = hipMemcpy(sketch_len, d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;

@@ -981,7 +981,10 @@ template <int ABLATE, bool NT = false>
 __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                         const u64* __restrict__ q, const u32* __restrict__ win,
                                                         u64* __restrict__ m_bits, u32 n_pad, u64* __restrict__ hbuf,
-                                                        u32* __restrict__ m_dirty) {
+                                                        u32* __restrict__ m_dirty, u32 prio) {
+    // next to the VALU-bound sketch / ranking kernels (three-stream pipeline) the scan's few instructions should not
+    // queue behind theirs: its loads are what keeps HBM busy
+    if (prio) __builtin_amdgcn_s_setprio(3);
     __shared__ u64 slice[kLeanCap + 2];
     __shared__ unsigned char dir[kLeanBuckets + 8];
     __shared__ u64 acc[kLeanWords][kTileGenomes];
@@ -1298,12 +1301,7 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
         __syncthreads();  // (double-buffered tile: one barrier per word is enough)
         const u64 v = tile[bsel][row][cw];
         if (grp * kRankWords + cw < n_gw) mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = v;
-        // rowmask: bit (query row) of word [grp][w] = the row holds a bit for some genome of the group (seg_sum skips the
-        // others).  This wave wrote rows 8 wv .. 8 wv + 7, eight lanes each: byte wv of the little-endian word.
-        u64 nzb = __ballot(v != 0);
-        nzb |= nzb >> 4; nzb |= nzb >> 2; nzb |= nzb >> 1;
-        nzb &= 0x0101010101010101ull;
-        if (lane == 0) rowmask[((size_t)grp * n_words + w) * 8u + wv] = (unsigned char)((nzb * 0x0102040810204080ull) >> 56);
+        (void)rowmask;
     }
     if (__ballot(seen != 0) && lane == 0) grp_any[grp] = 1u;  // (plain store of the same value from several waves)
 }
@@ -1384,7 +1382,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     if (grp >= n_grp || !grp_any[grp]) return;  // (a group without any bit: nobody reads its increments)
     const u32 sub = lane >> 3, j = lane & 7u;
     const u64* mq_gj = mq + (size_t)grp * nq_rows * kRankWords + j;
-    const u64* rm_g = rowmask + (size_t)grp * (nq_rows >> 6);  // which query rows hold a bit for this group at all
+    (void)rowmask;  // (skipping empty rows by a per-row mask was measured: the dependent lookup cost more than the gathers saved)
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
     u32 acc[8];
@@ -1399,14 +1397,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
 #pragma unroll
             for (u32 u = 0; u < 8u; ++u) {
                 const u32 p = p0 + 8u * u + sub;
-                u64 v = 0;
-                if (p < bz) {
-                    // (a species that only shares a stray k-mer with the sample: nearly all of its rows are empty -- one
-                    // bit of a cached mask instead of a 64-byte gather)
-                    const u32 qq = pair_q[p];
-                    if ((rm_g[qq >> 6] >> (qq & 63u)) & 1ull) v = mq_gj[(size_t)qq * kRankWords];
-                }
-                x[u] = v;
+                x[u] = p < bz ? mq_gj[(size_t)pair_q[p] * kRankWords] : 0ull;
             }
             u64 twos_a, twos_b, fours_a, fours_b, eights_a;
             SKX_CSA(twos_a, ones, ones, x[0], x[1])
@@ -2089,6 +2080,7 @@ __global__ void gather_table_kernel(const u64* __restrict__ cum, u64* __restrict
 // launchers
 // =====================================================================================
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 pad_base, u32 g_count) {
     dim3 grid(cdiv(s, 32), cdiv(g_count, 32));
@@ -2103,9 +2095,15 @@ static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketch
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk) {
+                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, bool leave_room) {
     if (n_reads == 0) return hipSuccess;
-    const size_t lds = sketch_wave_lds(kSketchCap), lds_small = sketch_wave_lds(kSketchSmallHashes);
+    // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
+    // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 11 KB: 5 instead of 8 of its blocks fit a CU), which leaves
+    // wave slots, registers and LDS for the scan's blocks: the VALU-bound sketch and the HBM-bound scan share every CU
+    // instead of taking turns (measured at C2: +9 % reads/s, the scan stretched from 0.62 to 0.78 ms).
+    static const size_t lds_pad_env = (size_t)env_int("SKX_SKETCH_LDS_PAD", 11264);
+    const size_t lds_pad = leave_room ? lds_pad_env : 0;
+    const size_t lds = sketch_wave_lds(kSketchCap), lds_small = sketch_wave_lds(kSketchSmallHashes) + lds_pad;
     dim3 grid(cdiv(n_reads, 4));
 #define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, IR>
 #define SKX_SK_SMALL(KT) sketch_wave_kernel<KT, kSketchSmallHashes, true>
@@ -2198,7 +2196,6 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
     hipLaunchKernelGGL(exceptions_kernel, dim3(cdiv(n_exc, 256)), dim3(256), 0, st, exc_g, exc_h, n_exc, q, n_q,
                        m_bits, n_pad, m_dirty);
 }
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 bool scan_lean_applies(u32 n_bands, bool split, bool big_table) {
     static const int lean_env = env_int("SKX_SCAN_LEAN", 1);
@@ -2216,14 +2213,15 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
     dim3 grid(n_tiles * n_bands), block(256);
     // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe
     if (hbuf) {
-#define SKX_SCAN_L(A) hipLaunchKernelGGL((scan_lean_kernel<A>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty)
+        static const u32 prio = (u32)env_int("SKX_SCAN_PRIO", 1);
+#define SKX_SCAN_L(A) hipLaunchKernelGGL((scan_lean_kernel<A>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio)
         switch (ablate) {
             case 1: SKX_SCAN_L(1); break;
             case 2: SKX_SCAN_L(2); break;
             case 3: SKX_SCAN_L(3); break;
             default: {
                 static const int nt = env_int("SKX_SCAN_NT", 0);  // experiment: non-temporal slab stores
-                if (nt) hipLaunchKernelGGL((scan_lean_kernel<0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty);
+                if (nt) hipLaunchKernelGGL((scan_lean_kernel<0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
                 else SKX_SCAN_L(0);
                 break;
             }

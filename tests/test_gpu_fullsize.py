@@ -161,7 +161,7 @@ def test_forced_scan_kernel_variants(gpu, split, big):
 
 
 @pytest.mark.parametrize("knobs", [{"SKX_PASS_READS": "64"}, {"SKX_PASS_READS": "100", "SKX_PIPELINE": "1"},
-                                   {"SKX_PASS_READS": "37", "SKX_PIPELINE": "3"}, {"SKX_NO_FILTER": "1"},
+                                   {"SKX_PASS_READS": "37", "SKX_PIPELINE": "2"}, {"SKX_NO_FILTER": "1"},
                                    {"SKX_TOP1_WIDE": "1"}])
 def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     """Several passes per push (the path that needs the per-read pair offsets on the host), the three pipeline depths
