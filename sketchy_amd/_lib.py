@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsketchy_hip.so")
+# (SKX_LIB_PATH: load another build of the same ABI instead -- A/B measurements of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("SKX_LIB_PATH") or os.path.join(_HERE, "libsketchy_hip.so")
 
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSORTED, ERR_CAPACITY, ERR_COMM, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7

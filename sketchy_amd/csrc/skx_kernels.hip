@@ -137,7 +137,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                                                 const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
                                                 u32* __restrict__ chk) {
     constexpr u32 CAP = kSketchCap;
-    constexpr u32 kPerWave = HCAP * 8 + CAP + 64;
+    constexpr u32 kPerWave = HCAP * 8 + CAP + 128;  // (carry of k-1 codes + a chunk + 64 codes of padding behind it)
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     u64* hashes = reinterpret_cast<u64*>(smem + (size_t)wv * kPerWave);
     uint8_t* codes = smem + (size_t)wv * kPerWave + HCAP * 8;
@@ -164,27 +164,28 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     // rest of the batch takes): it goes first (two-phase launch below) and its wave gets issue priority
     if (lraw > 4u * CAP) __builtin_amdgcn_s_setprio(2);
 
-    u32 m = 0;  // hashes collected so far (any order: they are sorted afterwards)
-    auto append = [&](bool valid, u64 h) -> bool {  // false: the hash buffer overflowed (read handed on)
+    u32 m = 0;    // hashes collected so far (any order: they are sorted afterwards); wave-uniform (kept scalar)
+    u32 ovf = 0;  // the hash buffer overflowed: the read is handed on after the loop (wave-uniform, scalar)
+    // (in production mode 99.5 % of the hashes are out of range: three iterations in four keep nothing at all and skip
+    // everything below the ballot)
+    auto append = [&](bool valid, u64 h) {
         if (INRANGE) valid = valid && (h <= max_ref);
         const u64 mask = __ballot(valid);
-        if (m + (u32)__popcll(mask) > (u32)HCAP) {  // uniform
-            if (lane == 0) {
-                out_len[r] = kSketchRetry; out_cnt_in[r] = 0;
-                list_append(HCAP < (int)CAP ? retry : big, r);
-            }
-            return false;
+        if (mask) {
+            const u32 cnt = (u32)__popcll(mask);
+            const u32 over = __builtin_amdgcn_readfirstlane(m + cnt > (u32)HCAP ? 1u : 0u);
+            ovf |= over;
+            if (!over && valid) hashes[m + __popcll(mask & lt)] = h;
+            m = __builtin_amdgcn_readfirstlane(m + cnt);
         }
-        if (valid) hashes[m + __popcll(mask & lt)] = h;
-        m += __popcll(mask);
-        return true;
     };
 
     u32 carry = 0;  // codes kept from the previous chunk at codes[0 .. carry)
     for (u32 cbase = 0;; cbase += CAP) {
         const u32 cend = min(lraw, cbase + CAP);
         // 1. normalise the chunk behind the carried codes
-        const u32 nb = wave_normalise(rd, cbase, cend, codes, carry, lane, lt);
+        const u32 nb = __builtin_amdgcn_readfirstlane(wave_normalise(rd, cbase, cend, codes, carry, lane, lt));
+        codes[nb + lane] = 4;  // 64 invalid codes behind the chunk: lanes past the last window read them unconditionally
         wave_sync();
         // 2. canonical k-mer hashes of the windows that END in this chunk, compacted
         const u32 nk = nb >= k ? nb - k + 1u : 0u;
@@ -192,7 +193,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
             // Each lane walks a contiguous run of positions with ROLLING windows: the 2-bit forward / reverse-
             // complement codes (for the canonical choice) and their 16 ASCII bytes as two little-endian words each
             // (the murmur3 block) -- one LDS byte read and a few shifts per k-mer instead of rebuilding all 16 bases.
-            const u32 run = (nk + 63u) / 64u;
+            const u32 run = __builtin_amdgcn_readfirstlane((nk + 63u) / 64u);
             const u32 p0 = lane * run;
             u32 fwd = 0, rc = 0;            // 16 bases x 2 bits: forward (first base highest) / reverse complement
             u32 f0 = 0, f1 = 0, f2 = 0, f3 = 0;  // the 16 ASCII bytes of the forward k-mer, first base in the lowest byte
@@ -217,15 +218,19 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                 r0 = (r0 << 8) | ca;
             };
             if (nk) {
-                for (u32 j = 0; j < 15u; ++j) push(p0 + j < nb ? (u32)codes[p0 + j] : 4u);
+                // (a window that reaches past the chunk takes in padding codes, which reset `clean`: no bounds tests --
+                // positions are clamped into the padded buffer, p0 + t + 15 <= nb + 63 whenever the window can be valid)
+                const u32 lim = nb + 63u;
+                for (u32 j = 0; j < 15u; ++j) push((u32)codes[min(p0 + j, lim)]);
+                u32 cnext = codes[min(p0 + 15u, lim)];  // (the next code is requested one iteration ahead of its use)
                 for (u32 t = 0; t < run; ++t) {
-                    const u32 p = p0 + t;
-                    const bool in = p < nk;
-                    push(in ? (u32)codes[p + 15u] : 4u);
+                    const u32 ccur = cnext;
+                    cnext = codes[min(p0 + t + 16u, lim)];
+                    push(ccur);
                     const bool use_f = fwd < rc;
                     const u64 w0 = make_u64(use_f ? f0 : r0, use_f ? f1 : r1), w1 = make_u64(use_f ? f2 : r2, use_f ? f3 : r3);
                     const u64 h = seed == 0 ? murmur3_h1_16<true>(w0, w1, 0) : murmur3_h1_16<false>(w0, w1, seed);
-                    if (!append(in && clean >= 16u, h)) return;
+                    append(clean >= 16u, h);
                 }
             }
         } else {
@@ -248,8 +253,16 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                 }
                 valid = valid && (bad == 0);
                 const u64 h = hash_canonical_packed<KT>(fwd < rc ? fwd : rc, k, seed);
-                if (!append(valid, h)) return;
+                append(valid, h);
             }
+        }
+        if (ovf) {  // hand the read on (fast variant -> 2048-slot variant -> block sketcher)
+            if (lane == 0) {
+                out_len[r] = kSketchRetry; out_cnt_in[r] = 0;
+                list_append(HCAP < (int)CAP ? retry : big, r);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            return;
         }
         if (cend >= lraw) break;
         // 3. the last k-1 codes open the next chunk
@@ -2091,7 +2104,7 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
 }
 
 constexpr int kSketchSmallHashes = 256;  // hash slots per read of the in-range fast variant
-static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketchCap + 64); }
+static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketchCap + 128); }
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,

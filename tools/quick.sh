@@ -1,3 +1,6 @@
 #!/bin/bash
-tools/ubench/mul_rates
-tools/prof_kt.sh quick_c2 --steps 12 --warmup 2 | grep -E "seg_sum|rank_seg|sketch_wave|scan_lean|transpose"
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+P=gpurun_out/prof; mkdir -p $P
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $P/pmc_all -o pmc -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-extra-legs --no-check > /dev/null 2> $P/pmc_all.err
+python3 profiles/summarize_pmc.py $(find $P/pmc_all -name "*counter_collection.csv") | grep -E "skx::" | grep -E "SQ_INSTS_VALU|SQ_INSTS_SALU" | sed 's/"[a-z ]*skx::\([a-z_0-9]*\)[^"]*"/\1/' | awk -F, '{printf "%-28s %-16s %4s %14s %16s\n",$1,$2,$3,$4,$5}' | sort -k2,2 -k5,5nr | head -60
+rm -rf $P/pmc_all
