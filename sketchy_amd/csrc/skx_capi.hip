@@ -329,6 +329,10 @@ struct skx_stream {
     int depth = 2;
     int buf = 0;
     hipEvent_t ev_dict[2] = {nullptr, nullptr}, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
+    hipEvent_t ev_sketch = nullptr;    // sketch stream: this batch's sketches, pair offsets (and speculative pair gather) are done
+    hipEvent_t ev_dictrest = nullptr;  // scan stream: the hash set / pair hashes of the latest pass have been consumed
+    bool dictrest_pending = false;
+    bool sk_reader_pending = false;    // a pass gathered its pairs on the scan stream: the sketch buffers are still being read
     bool front_pending[2] = {false, false};
     bool back_pending[2] = {false, false};
     u32 top_k = 0, max_reads = 0, sk_stride = 0;
@@ -447,6 +451,8 @@ static void stream_free(skx_stream* st) {
         if (st->ev_front[i]) (void)hipEventDestroy(st->ev_front[i]);
         if (st->ev_back[i]) (void)hipEventDestroy(st->ev_back[i]);
     }
+    if (st->ev_sketch) (void)hipEventDestroy(st->ev_sketch);
+    if (st->ev_dictrest) (void)hipEventDestroy(st->ev_dictrest);
     if (st->hs0 && st->hs0 != st->hs) (void)hipStreamDestroy(st->hs0);
     if (st->hs2 && st->hs2 != st->hs) (void)hipStreamDestroy(st->hs2);
     if (st->hs) (void)hipStreamDestroy(st->hs);
@@ -525,6 +531,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_back[i], hipEventDisableTiming));
     }
+    SCHK(hipEventCreateWithFlags(&st->ev_sketch, hipEventDisableTiming));
+    SCHK(hipEventCreateWithFlags(&st->ev_dictrest, hipEventDisableTiming));
     SCHK(hipMalloc(&st->d_bases, std::max<u64>(max_bases, 1)));
     SCHK(hipMalloc(&st->d_offsets, ((size_t)max_reads + 1) * 8));
     SCHK(hipMalloc(&st->d_sk, (size_t)max_reads * sk_stride * 8));
@@ -670,8 +678,10 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 }
 
 // ---- one pass: reads [ra, rb) of the batch, pairs [p_base, p_base + P)
+// inserted: the pairs of this pass were already gathered / inserted into the hash set on the sketch stream (the usual
+// case: the whole batch is one pass and process_batch queued launch_dict_insert right behind the sketcher)
 static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_topk_idx, u64* d_topk_sum,
-                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table) {
+                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table, bool inserted = false) {
     const skx_ref* ref = st->ref;
     hipStream_t hs0 = st->hs0, hs = st->hs, hs2 = st->hs2;
     const skx::Species spc = ref->species();
@@ -694,35 +704,46 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         }
     u64 nq_est = std::max<u64>(1, (u64)(P * st->nq_per_pair));
 
-    // ---- dictionary (stream hs0): set b was last used two passes ago -- by that pass's scan (Q, windows) and
-    // ranking (pair lists, offsets, Mq); wait for both before overwriting it
-    if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs0, st->ev_front[b], 0)); st->front_pending[b] = false; }
-    if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs0, st->ev_back[b], 0)); st->back_pending[b] = false; }
-    HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs0));
+    // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already): set b was last used
+    // two passes ago -- by that pass's scan (Q, windows) and ranking (pair lists, offsets, Mq)
+    (void)hs0;
+    HIPCHK(hipStreamWaitEvent(hs, st->ev_sketch, 0));  // this batch's sketches and pair offsets
+    if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_front[b], 0)); st->front_pending[b] = false; }
+    if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
+    // (inserted: the sketch stream also copied the pass's pair offsets -- this stream then never touches the sketch buffers,
+    // which the next batch's sketch is free to overwrite)
+    if (!inserted) {
+        HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
+        st->sk_reader_pending = true;
+    }
     if (P > 0) {
-        Span sp(st, 1, hs0);
-        skx::launch_dictionary(hs0, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r, st->d_ht,
-                               st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
-                               st->d_dict_ctr, d_q, d_nq);
-        skx::launch_pair_q(hs0, st->d_pair_h, P, d_q, d_nq, d_pair_q);
-        skx::launch_window(hs0, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);  // (also hands |Q| to the host)
-        if (st->d_hbuf) skx::launch_word_bands(hs0, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b]);
+        Span sp(st, 1, hs);
+        if (!inserted)
+            skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r, st->d_ht,
+                                    st->ht_slots, st->d_dict_ctr, st->pcap);
+        skx::launch_dict_rest(hs, st->d_ht, st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
+                              st->d_dict_ctr, d_q, d_nq);
+        skx::launch_pair_q(hs, st->d_pair_h, P, d_q, d_nq, d_pair_q);
+        skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);  // (also hands |Q| to the host)
+        if (st->d_hbuf) skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b]);
         st->hint_pairs[b] = P;
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(st->ev_dict[b], hs0));
+    // hash set and pair hashes may be refilled (by the next batch's gather), the sketch buffers overwritten
+    HIPCHK(hipEventRecord(st->ev_dictrest, hs));
+    st->dictrest_pending = true;
+    HIPCHK(hipEventRecord(st->ev_dict[b], hs));
 
     // the very first pass of a stream has no hint: wait for its dictionary once rather than run the heaviest variant
     if (!st->have_hint && P > 0) {
-        HIPCHK(hipStreamSynchronize(hs0));
+        HIPCHK(hipStreamSynchronize(hs));
         st->nq_per_pair = std::min(1.0, (double)st->h_nq[b] / P);
         st->hint_pairs[b] = 0;
         st->have_hint = true;
         nq_est = std::max<u64>(1, st->h_nq[b]);
     }
 
-    // ---- scan + transpose (stream hs, HBM-bound)
-    HIPCHK(hipStreamWaitEvent(hs, st->ev_dict[b], 0));
+    // ---- scan + transpose (same stream, HBM-bound)
     const u32 n_grp_all = n_pad / (skx::kRankWords * 64);
     u32* d_mdirty = d_grp_any + n_grp_all;
     HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)(n_grp_all + 1) * 4, hs));  // raised by the transpose / by writers of M
@@ -845,6 +866,9 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     // applies the filter itself in production mode; rows it did not filter (long reads, full sketches for the
     // debug outputs) get the separate pass.
     // ... and the few words the host needs (offsets check, total pairs) are published to page-locked memory
+    // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
+    const u32 dbg_cap = h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
+    const bool spec_insert = n_reads <= std::min(st->rpass, dbg_cap);  // one pass unless the pairs turn out too many
     u32 seq = 0;
     // spin on the published sequence number (looking at the stream now and then so a fault cannot hang the caller)
     auto wait_published = [&]() -> int {
@@ -863,12 +887,42 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         }
         return SKX_OK;
     };
+    // counts -> (filter, for rows the sketchers did not filter themselves) -> pair offsets (poff[n_reads] = total pairs)
+    // -> speculative pair gather -> the few words the host needs, published to page-locked memory
+    auto finish_counts = [&]() -> int {
+        if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
+        if (filt && !inrange_only)
+            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
+        skx::launch_count_scan(hs, st->d_cnt, st->d_poff, n_reads + 1, st->d_bsum);
+        // the whole batch is normally ONE pass: gather its pairs into the next buffer set and fill the hash set right
+        // here, behind the sketcher -- the rest of the dictionary then runs on the scan stream and this stream is free
+        // for the next batch's sketch (the kernel does nothing if the pairs do not fit one pass: the host finds out
+        // after the wait and cuts the batch into passes)
+        if (spec_insert) {
+            const int b = st->buf;
+            if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_front[b], 0)); st->front_pending[b] = false; }
+            if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
+            if (st->dictrest_pending) { HIPCHK(hipStreamWaitEvent(hs, st->ev_dictrest, 0)); st->dictrest_pending = false; }
+            skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h, st->d_pair_r[b], st->d_ht,
+                                    st->ht_slots, st->d_dict_ctr, st->pcap);
+            HIPCHK(hipMemcpyAsync(st->d_poff_pass[b], st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
+        }
+        seq = ++st->pub_seq;
+        skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, seq);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(st->ev_sketch, hs));
+        return SKX_OK;
+    };
     if (st->chk_dirty) {  // an earlier push failed half-way
         HIPCHK(hipMemsetAsync(st->d_chk, 0, 64, hs));
         HIPCHK(hipMemsetAsync(st->d_retry, 0, 4, hs));
         HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
     }
     st->chk_dirty = true;
+    if (st->sk_reader_pending) {  // (rare: the previous batch was cut into passes that read the sketch buffers on the scan stream)
+        HIPCHK(hipStreamWaitEvent(hs, st->ev_dictrest, 0));
+        st->sk_reader_pending = false;
+    }
     {
         Span sp(st, 0);
         // offsets are looked at on the device (cheap); it also zeroes entry n_reads of the pair counts
@@ -884,6 +938,17 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         HIPCHK(skx::launch_sketch(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
                                   st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big, n_bases,
                                   st->d_chk, leave_room));
+        if (!inrange_only) {
+            // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
+            // not the fast one -- read the count back and run the block sketcher before the rows are copied out
+            u32 n_big = 0;
+            HIPCHK(hipMemcpyAsync(&n_big, st->d_big, 4, hipMemcpyDeviceToHost, hs));
+            HIPCHK(hipStreamSynchronize(hs));
+            HIPCHK(skx::launch_sketch_block(hs, d_bases, d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s, max_ref, false,
+                                            st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift));
+            st->reads_big += n_big;
+            HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
+        }
         // optional sketch outputs leave now: the filter compacts the rows in place
         if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
         if (h_sketches) {
@@ -891,15 +956,7 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             HIPCHK(hipMemcpy2DAsync(h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
                                     (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
         }
-        // counts -> (filter, for rows the sketchers did not filter themselves) -> pair offsets; poff[n_reads] = total pairs
-        if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
-        if (filt && !inrange_only)
-            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
-        skx::launch_count_scan(hs, st->d_cnt, st->d_poff, n_reads + 1, st->d_bsum);
-        // ... and the few words the host needs (offsets check, total pairs) are published to page-locked memory
-        seq = ++st->pub_seq;
-        skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, seq);
-        HIPCHK(hipGetLastError());
+        SKXCHK(finish_counts());
     }
     SKXCHK(wait_published());  // the one wait of a push: 36 bytes, no copy, no stream synchronisation
     if (h_sketches || h_sketch_len) HIPCHK(hipStreamSynchronize(hs));  // (debug outputs: their copies must have landed)
@@ -910,20 +967,32 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
         if (c[0]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
         if (c[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases=%llu bytes given from offsets[0] on",
                               (unsigned long long)n_bases);
-        st->reads_big += c[7];
+        if (c[7]) {
+            // production mode, rare: reads whose in-range hashes overflowed a wave's 2048 slots wait on the `big` list.
+            // The block sketcher was not queued blindly (it needs a drained CU even to find the list empty): run it now,
+            // then counts, pair gather and the published summary once more.
+            st->reads_big += c[7];
+            st->chk_dirty = true;
+            HIPCHK(skx::launch_sketch_block(hs, d_bases, d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s, max_ref, inrange_only,
+                                            st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift));
+            SKXCHK(finish_counts());
+            SKXCHK(wait_published());
+            st->chk_dirty = false;
+            if (st->h_chk[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases given from offsets[0] on");
+        }
     }
     const u32 total_pairs = st->h_chk[8];
     st->last_pairs = total_pairs; st->last_passes = 0;
 
     u32* d_shared = nullptr;
-    // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
-    const u32 dbg_cap = h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
+    bool inserted = spec_insert && total_pairs <= st->pcap;  // the gather queued above did its work
     auto one_pass = [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
         if (h_shared) {
             if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
         }
-        SKXCHK(run_pass(st, ra, rb, p_base, P, d_topk_idx, d_topk_sum, d_shared, true));
+        SKXCHK(run_pass(st, ra, rb, p_base, P, d_topk_idx, d_topk_sum, d_shared, true, inserted));
+        inserted = false;
         st->last_passes += 1;
         if (h_shared) {
             HIPCHK(hipMemcpyAsync(h_shared + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
@@ -1187,6 +1256,11 @@ SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, 
         if ((e = hipMemset(d_lists, 0, 2 * ((size_t)n_reads + 1) * 4)) != hipSuccess) break;
         if ((e = skx::launch_sketch(nullptr, d_b, d_o, n_reads, k, seed, s, 0, false, d_sk, stride, d_len, d_cnt, nullptr, 0,
                                     d_lists, d_lists + n_reads + 1, n_bases, nullptr, false)) != hipSuccess) break;
+        // sequences with more k-mers than a wave holds wait on the second list: the block sketcher
+        u32 n_big = 0;
+        if ((e = hipMemcpy(&n_big, d_lists + n_reads + 1, 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = skx::launch_sketch_block(nullptr, d_b, d_o, d_lists + n_reads + 1, n_big, k, seed, s, 0, false, d_sk, stride, d_len,
+                                          d_cnt, nullptr, 0)) != hipSuccess) break;
         memset(sketches, 0, (size_t)n_reads * s * 8);
         if ((e = hipMemcpy2D(sketches, (size_t)s * 8, d_sk, (size_t)stride * 8, (size_t)stride * 8, n_reads, hipMemcpyDeviceToHost)) != hipSuccess) break;
         if ((e = hipMemcpy(sketch_len, d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;

@@ -409,7 +409,7 @@ __device__ __forceinline__ u32 block_rank(bool flag, BlockScratch& sh, u32& tota
 
 template <int KT, bool INRANGE>
 __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __restrict__ bases, const u64* __restrict__ offsets,
-                                                            const u32* __restrict__ big, u32 k_rt, u64 seed, u32 s,
+                                                            const u32* __restrict__ big, u32 n_big, u32 k_rt, u64 seed, u32 s,
                                                             u64 max_ref, u64* __restrict__ out_sk, u32 sk_stride,
                                                             u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
                                                             const u32* __restrict__ filt, u32 filt_shift) {
@@ -419,7 +419,6 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
     uint8_t* codes = smem + (size_t)kBigHashes * 8;
     const u32 tid = threadIdx.x, lane = lane_id();
     const u32 k = KT > 0 ? (u32)KT : k_rt;
-    const u32 n_big = big[0];
 
     for (u32 bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
         const u32 r = big[1u + bi];
@@ -618,34 +617,53 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
     }
     return v;
 }
-__global__ __launch_bounds__(1024) void count_scan_a_kernel(const u32* __restrict__ in, u32* __restrict__ out, u32 n,
-                                                            u32* __restrict__ bsum) {
-    __shared__ u32 wtot[16];
-    const u32 i = blockIdx.x * 1024u + threadIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
-    const u32 c = i < n ? in[i] : 0u;
-    const u32 incl = wave_incl_scan(c);
+// (256-thread blocks, four entries per thread: a 1024-thread block needs 16 free wave slots on ONE CU and waits tens of
+// microseconds for them next to the other streams' kernels -- measured; 4-wave blocks slip in)
+__device__ __forceinline__ u32 block256_excl_scan4(const u32 (&c)[4], u32 (&excl)[4], u32* wtot /* [4] shared */) {
+    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
+    const u32 mine = c[0] + c[1] + c[2] + c[3];
+    const u32 incl = wave_incl_scan(mine);
     if (lane == 63u) wtot[wv] = incl;
     __syncthreads();
-    u32 before = 0;
+    u32 before = 0, total = 0;
 #pragma unroll
-    for (u32 w = 0; w < 16u; ++w) before += w < wv ? wtot[w] : 0u;
-    if (i < n) out[i] = before + incl - c;
-    if (threadIdx.x == 1023u) bsum[blockIdx.x] = before + incl;
+    for (u32 w = 0; w < 4u; ++w) { before += w < wv ? wtot[w] : 0u; total += wtot[w]; }
+    u32 run = before + incl - mine;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { excl[j] = run; run += c[j]; }
+    return total;
 }
-__global__ __launch_bounds__(1024) void count_scan_b_kernel(u32* __restrict__ out, u32 n, const u32* __restrict__ bsum) {
-    __shared__ u32 part[16];
+__global__ __launch_bounds__(256) void count_scan_a_kernel(const u32* __restrict__ in, u32* __restrict__ out, u32 n,
+                                                           u32* __restrict__ bsum) {
+    __shared__ u32 wtot[4];
+    const u32 i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+    u32 c[4], e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = i0 + j < n ? in[i0 + j] : 0u;
+    const u32 total = block256_excl_scan4(c, e, wtot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (i0 + j < n) out[i0 + j] = e[j];
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void count_scan_b_kernel(u32* __restrict__ out, u32 n, const u32* __restrict__ bsum) {
+    __shared__ u32 part[4];
     __shared__ u32 s_before;
     const u32 lane = lane_id(), wv = threadIdx.x >> 6;
     u32 t = 0;
-    for (u32 b = threadIdx.x; b < blockIdx.x; b += 1024u) t += bsum[b];
+    for (u32 b = threadIdx.x; b < blockIdx.x; b += 256u) t += bsum[b];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) t += (u32)__shfl_xor((int)t, d, 64);
     if (lane == 0) part[wv] = t;
     __syncthreads();
-    if (threadIdx.x == 0) { u32 a = 0; for (u32 w = 0; w < 16u; ++w) a += part[w]; s_before = a; }
+    if (threadIdx.x == 0) s_before = part[0] + part[1] + part[2] + part[3];
     __syncthreads();
-    const u32 i = blockIdx.x * 1024u + threadIdx.x;
-    if (i < n && blockIdx.x) out[i] += s_before;
+    if (blockIdx.x) {
+        const u32 i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) out[i0 + j] += s_before;
+    }
 }
 
 // =====================================================================================
@@ -706,12 +724,16 @@ __global__ __launch_bounds__(256) void filter_apply_kernel(u64* __restrict__ sk,
 constexpr u32 kDictBuckets = 1u << 17;
 __device__ __forceinline__ u32 dict_bucket(u64 key, u32 bshift) { return (u32)min((u64)(kDictBuckets - 1u), key >> bshift); }
 
+// pair_cap: the pair arrays' capacity.  The kernel can be queued before the host knows how many pairs the reads have
+// (right behind the sketcher, on its stream); when they do not fit one pass it does nothing and the host, which learns
+// the count a moment later, cuts the batch into passes and inserts per pass.
 __global__ void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, const u32* __restrict__ poff, u32 r_begin,
                                    u32 r_end, u32 p_base, u64* __restrict__ pair_h, u32* __restrict__ pair_r,
-                                   u64* __restrict__ ht, u32 ht_mask, u32* __restrict__ ctr) {
+                                   u64* __restrict__ ht, u32 ht_mask, u32* __restrict__ ctr, u32 pair_cap) {
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();  // one wave per read
     const u32 r = r_begin + wave;
     if (r >= r_end) return;
+    if (poff[r_end] - p_base > pair_cap) return;
     const u32 a = poff[r], b = poff[r + 1];
     for (u32 j = lane; j < b - a; j += 64u) {
         const u64 key = sk[(size_t)r * sk_stride + j];
@@ -735,22 +757,17 @@ __global__ __launch_bounds__(256) void dict_count_kernel(const u64* __restrict__
     }
 }
 // exclusive scan of the bucket counts, two levels: (a) inside every block of 1024 buckets, (b) over the block totals
-__global__ __launch_bounds__(1024) void dict_scan_a_kernel(u32* __restrict__ bcount, u32* __restrict__ bbase,
-                                                           u32* __restrict__ btot) {
-    __shared__ u32 part[1024];
-    const u32 t = threadIdx.x, b = blockIdx.x * 1024u + t;
-    const u32 c = bcount[b];
-    bcount[b] = 0;  // zero again for the next pass
-    part[t] = c;
-    __syncthreads();
-    for (u32 d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele inclusive scan
-        const u32 v = t >= d ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    bbase[b] = part[t] - c;
-    if (t == 1023u) btot[blockIdx.x] = part[t];
+__global__ __launch_bounds__(256) void dict_scan_a_kernel(u32* __restrict__ bcount, u32* __restrict__ bbase,
+                                                          u32* __restrict__ btot) {
+    __shared__ u32 wtot[4];
+    const u32 b0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+    u32 c[4], e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = bcount[b0 + j]; bcount[b0 + j] = 0; }  // zero again for the next pass
+    const u32 total = block256_excl_scan4(c, e, wtot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bbase[b0 + j] = e[j];
+    if (threadIdx.x == 0) btot[blockIdx.x] = total;
 }
 __global__ __launch_bounds__(128) void dict_scan_b_kernel(u32* __restrict__ btot, const u32* __restrict__ ctr,
                                                           u32* __restrict__ n_q) {
@@ -2152,20 +2169,16 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid, dim3(256), LDS, st, bases, \
                        offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, FROM_LIST, retry, big,   \
                        filt, filt_shift, n_bases, chk)
-#define SKX_BLK_LAUNCH(KERNEL)                                                                                         \
-    hipLaunchKernelGGL((KERNEL), blk_grid, dim3(1024), kBigLds, st, bases, offsets, big, k, seed, s, max_ref, out_sk, \
-                       sk_stride, out_len, out_cnt_in, filt, filt_shift)
+    (void)blk_grid;
     if (inrange_only) {
         // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
-        // does not fit goes to the block sketcher -- both through device-side lists, usually empty
+        // does not fit is left on the `big` list for launch_sketch_block -- both lists live on the device, usually empty
         const u32 first = chk ? 2u : 0u;
-        if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, first); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); SKX_BLK_LAUNCH(SKX_BLK(16, true)); }
-        else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, first); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); SKX_BLK_LAUNCH(SKX_BLK(0, true)); }
+        if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, first); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); }
+        else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, first); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); }
     } else {
-        if (k == 16) { SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); SKX_BLK_LAUNCH(SKX_BLK(16, false)); }
-        else { SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u); SKX_BLK_LAUNCH(SKX_BLK(0, false)); }
+        if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u);
     }
-#undef SKX_BLK_LAUNCH
 #undef SKX_SK_LAUNCH
 #undef SKX_BLK
 #undef SKX_SK_SMALL
@@ -2173,24 +2186,43 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     return hipGetLastError();
 }
 
+// The reads launch_sketch left on the `big` list (n_big of them; the caller read the count back).  A separate call because
+// the kernel needs 135 KB of LDS per block: queued unconditionally it waits for a drained CU even when the list is empty
+// (40-80 us on the sketch stream per push, measured) -- and it almost always is.
+hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
+                               u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
+                               const u32* filt, u32 filt_shift) {
+    if (n_big == 0) return hipSuccess;
+    const dim3 blk_grid(std::min<u32>(n_big, 256u));
+#define SKX_BLK_LAUNCH(KERNEL)                                                                                              \
+    hipLaunchKernelGGL((KERNEL), blk_grid, dim3(1024), kBigLds, st, bases, offsets, big, n_big, k, seed, s, max_ref, out_sk, \
+                       sk_stride, out_len, out_cnt_in, filt, filt_shift)
+    if (k == 16) { if (inrange_only) SKX_BLK_LAUNCH((sketch_block_kernel<16, true>)); else SKX_BLK_LAUNCH((sketch_block_kernel<16, false>)); }
+    else { if (inrange_only) SKX_BLK_LAUNCH((sketch_block_kernel<0, true>)); else SKX_BLK_LAUNCH((sketch_block_kernel<0, false>)); }
+#undef SKX_BLK_LAUNCH
+    return hipGetLastError();
+}
+
 void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum) {
     if (n == 0) return;
     const u32 nb = cdiv(n, 1024);
-    hipLaunchKernelGGL(count_scan_a_kernel, dim3(nb), dim3(1024), 0, st, in, out, n, bsum);
-    if (nb > 1) hipLaunchKernelGGL(count_scan_b_kernel, dim3(nb), dim3(1024), 0, st, out, n, bsum);
+    hipLaunchKernelGGL(count_scan_a_kernel, dim3(nb), dim3(256), 0, st, in, out, n, bsum);
+    if (nb > 1) hipLaunchKernelGGL(count_scan_b_kernel, dim3(nb), dim3(256), 0, st, out, n, bsum);
 }
 
-void launch_dictionary(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
-                       u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase,
-                       u32* btot, u32* ctr, u64* q, u32* n_q) {
+void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
+                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap) {
     if (r_end <= r_begin) return;
+    hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 4)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
+                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap);
+}
+void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
+                      u32* ctr, u64* q, u32* n_q) {
     const u32 bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
     const u32 bshift = bits > 17u ? bits - 17u : 0u;  // hashes <= max_ref  =>  hash >> bshift < 2^17
     const u32 walk = std::min<u32>(cdiv(ht_slots, 256), 8192u);
-    hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 4)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
-                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr);
     hipLaunchKernelGGL(dict_count_kernel, dim3(walk), dim3(256), 0, st, ht, ht_slots, bshift, slot_off, bcount);
-    hipLaunchKernelGGL(dict_scan_a_kernel, dim3(kDictBuckets / 1024u), dim3(1024), 0, st, bcount, bbase, btot);
+    hipLaunchKernelGGL(dict_scan_a_kernel, dim3(kDictBuckets / 1024u), dim3(256), 0, st, bcount, bbase, btot);
     hipLaunchKernelGGL(dict_scan_b_kernel, dim3(1), dim3(128), 0, st, btot, ctr, n_q);
     hipLaunchKernelGGL(dict_scatter_kernel, dim3(walk), dim3(256), 0, st, ht, ht_slots, bshift, slot_off, bbase, btot, ctr, q);
     hipLaunchKernelGGL(dict_bucket_sort_kernel, dim3(kDictBuckets / 256), dim3(256), 0, st, q, bbase, btot, ctr);

@@ -21,8 +21,8 @@ void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* ds
 void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, u64* lo, u64* hi);
 
 // sketching: every read of the batch, any length -- one wave per read (256 hash slots, then 2048 for the reads that
-// overflow), then one block per read of what still does not fit (and, for full sketches, of every read with more than
-// kSketchCap k-mers); the hand-over runs through the device-side lists `retry` / `big` ([0] = count, zero on entry).
+// overflow); what still does not fit (and, for full sketches, every read with more than kSketchCap k-mers) is left on the
+// device-side list `big` for launch_sketch_block (one block per read).  `retry` / `big`: [0] = count, zero on entry.
 // n_bases: bytes the caller vouches for from offsets[0] on; a read reaching outside is skipped and flagged in chk[6]
 // (chk may be NULL).  Returns the launch status (it also opts the big-LDS kernels in, once per device).
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
@@ -30,17 +30,25 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
                          const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
                          u32* retry /* [1 + n_reads] */, u32* big /* [1 + n_reads] */, u64 n_bases, u32* chk,
                          bool leave_room /* a scan is running next to this launch: cap the blocks per CU */);
+// the block sketcher for the n_big reads launch_sketch left on `big` (big[1 ..]); the caller reads the count back first
+hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
+                               u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
+                               const u32* filt, u32 filt_shift);
 // exclusive scan of n counts (out[i] = sum of in[0..i)); bsum: [ceil(n / 1024)] scratch
 void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum);
 
 // dictionary
 void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q);
-// gather the pairs of reads [r_begin, r_end) AND build the sorted distinct dictionary q / n_q of their hashes.
+// Dictionary of a pass, in two steps.  (1) launch_dict_insert gathers the pairs of reads [r_begin, r_end) (pair_h, pair_r)
+// and inserts every pair hash into the hash set -- one wave per read, no knowledge of the pair count needed: it can be
+// queued right behind the sketcher; if the reads have more than pair_cap pairs it does nothing.  (2) launch_dict_rest
+// turns the set into q / n_q, the sorted distinct dictionary, and empties it.
 // ht: hash set of ht_slots (power of two, >= 2 x pairs) u64, all-ones between passes; slot_off: [ht_slots] scratch;
 // bcount: [dict_buckets()] zero between passes; bbase: [dict_buckets()]; btot: [129]; ctr: [4] zero between passes
-void launch_dictionary(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
-                       u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase,
-                       u32* btot, u32* ctr, u64* q, u32* n_q);
+void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
+                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap);
+void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
+                      u32* ctr, u64* q, u32* n_q);
 u32 dict_buckets();
 void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win,
                    u32* h_nq /* page-locked host word that receives *n_q, or NULL */);

@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 P=gpurun_out/prof; mkdir -p $P
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $P/pmc_all -o pmc -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-extra-legs --no-check > /dev/null 2> $P/pmc_all.err
-python3 profiles/summarize_pmc.py $(find $P/pmc_all -name "*counter_collection.csv") | grep -E "skx::" | grep -E "SQ_INSTS_VALU|SQ_INSTS_SALU" | sed 's/"[a-z ]*skx::\([a-z_0-9]*\)[^"]*"/\1/' | awk -F, '{printf "%-28s %-16s %4s %14s %16s\n",$1,$2,$3,$4,$5}' | sort -k2,2 -k5,5nr | head -60
-rm -rf $P/pmc_all
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $P/kt_tl -o kt -- python3 bench.py --cpu-seconds 0 --no-extra-legs --no-check --steps 10 --warmup 3 > /dev/null 2>&1
+F=$(find $P/kt_tl -name "*kernel_trace.csv" | head -1)
+python3 tools/timeline.py $F > $P/timeline_p3.txt; tail -120 $P/timeline_p3.txt | cut -c1-150
+rm -rf $P/kt_tl

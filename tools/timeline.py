@@ -5,8 +5,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows if "skx::" in r["Kernel_Name"] or "rocprim" in r["Kernel_Name"]]
 ks.sort()
-starts = [i for i, k in enumerate(ks) if "sketch_wave_kernel<16, 2048, 256" in k[2]]
-a, b = starts[-3], starts[-2]
+starts = [i for i, k in enumerate(ks) if "sketch_wave_kernel<16, 256" in k[2]]
+a, b = starts[-4], starts[-2]  # two steps
 t0 = ks[a][0]
 print(f"step length {(ks[b][0] - t0) / 1e3:.1f} us")
 for s, e, n, q in ks[a:b + 1]:
