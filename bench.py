@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=98304, help="reads per step (one reference scan is amortised over this many reads)")
+    ap.add_argument("--api", default="enqueue", choices=["enqueue", "push"],
+                    help="device-resident entry point of the timed stream: skx_stream_enqueue_device (halves of consecutive "
+                         "batches interleaved) or skx_stream_push_device (one batch per call, round 1's)")
     ap.add_argument("--top", type=int, default=1, help="rows ranked after every read (sketchy default 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
@@ -176,12 +179,15 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.time() - t0
 
-    def step(i, slot=None):
+    # skx_stream_enqueue_device (default): the sketch of batch i + 1 is queued before the host waits for batch i's summary;
+    # --api push: skx_stream_push_device, both halves of a batch per call (round 1's entry point).  Same rows, same table.
+    def step(i, slot=None, call=None):
         j = i % n_distinct
         slot = i if slot is None else slot
         bases, offs = batches[j]
-        S.push_device(bases.data_ptr(), offs.data_ptr(), B, batch_bases[j], d_ti[slot].data_ptr() if top else None,
-                      d_ts[slot].data_ptr() if top else None)
+        call = call or (S.enqueue_device if args.api == "enqueue" else S.push_device)
+        call(bases.data_ptr(), offs.data_ptr(), B, batch_bases[j], d_ti[slot].data_ptr() if top else None,
+             d_ts[slot].data_ptr() if top else None)
 
     # ---- warmup (untimed), then a fresh table: the timed stream starts like a new sample
     for i in range(W):
@@ -222,6 +228,7 @@ def main():
                    "reads_per_step": B, "read_len": read_len, "read_len_lognormal_sigma": sigma,
                    "mean_read_len": round(float(np.mean(batch_bases)) / B, 1), "n_species": n_sp, "n_genomes": species, "s": s, "k": k,
                    "top": top, "rccl_ranks": reducer.n_ranks,
+                   "api": "skx_stream_enqueue_device + final sync" if args.api == "enqueue" else "skx_stream_push_device + final sync",
                    "parallelism": f"reads sharded x{world}, reference replicated, final table all-reduce via {reducer.how}"},
     }
     err = None
@@ -303,6 +310,19 @@ def main():
             ach = R.pass_bytes / (ms_alone * 1e-3) / 1e9
             out["roofline"]["isolated"] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_alone,
                                            "note": "scan kernel alone on the GPU (the synchronised pushes of value_cold)"}
+        # value_push_device: the timed stream once more through the other entry point (whichever --api did not select)
+        other_call, other_name = (S.push_device, "skx_stream_push_device") if args.api == "enqueue" else (S.enqueue_device, "skx_stream_enqueue_device")
+        S.reset()
+        shard.barrier()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for i in range(W, W + K):
+            step(i, slot=0, call=other_call)
+        S.sync()
+        other_s = shard.max_over_ranks(time.perf_counter() - tc)
+        if rank == 0:
+            out["value_other_api"] = {"value": K * B * world / other_s, "unit": "reads/s", "api": other_name,
+                                      "what": "the same K batches from a fresh table through the other device-resident entry point"}
         # value_steady_state: the same stream far from its start (no reset, batches cycled), three regions of >= 0.5 s
         n_long = max(32, int(0.5 / (elapsed / K)))
         S.reset()

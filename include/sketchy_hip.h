@@ -119,6 +119,21 @@ int skx_stream_push(skx_stream *st, const uint8_t *bases, const uint64_t *offset
  */
 int skx_stream_push_device(skx_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
                            uint64_t n_bases, uint32_t *d_topk_idx, uint64_t *d_topk_sum);
+/*
+ * skx_stream_push_device in two halves, so that consecutive batches overlap on the device without the host in between:
+ * the call queues the sketch of THIS batch first, then waits for the published summary of the batch enqueued one call
+ * earlier and queues that batch's scan / ranking passes.  (skx_stream_push_device does both halves of one batch in one
+ * call: the sketch stream then idles while the host queues the passes -- ~0.25 ms per 98,304-read batch, measured.)
+ * Consequences: rows of batch i are written by work queued during call i + 1; an error found in batch i (offsets not
+ * monotonic, a read outside n_bases) is returned by call i + 1 or by the flush, and the batch of call i + 1 is then
+ * dropped as well.  d_bases / d_offsets of batch i must stay untouched until call i + 1 has returned AND the stream has
+ * been synchronised, or -- simpler -- until skx_stream_sync().  skx_stream_flush() queues the outstanding half; every
+ * other entry point of the stream (sync, table, rank, push, reset, stats ...) flushes first.  Rows and table are those
+ * of skx_stream_push_device on the same batches in the same order (src/sketchy.rs:328-354 is sequential over reads).
+ */
+int skx_stream_enqueue_device(skx_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                              uint64_t n_bases, uint32_t *d_topk_idx, uint64_t *d_topk_sum);
+int skx_stream_flush(skx_stream *st);
 int skx_stream_sync(skx_stream *st);
 /*
  * Host-fed pipeline.  skx_stream_submit() queues a batch from PAGE-LOCKED host buffers (skx_host_alloc; bases, offsets

@@ -120,6 +120,14 @@ class SumOfSharedHashes:
     def push_device(self, d_bases, d_offsets, n_reads, n_bases, d_topk_idx=None, d_topk_sum=None):
         _lib.check(_lib.load().skx_stream_push_device(self._h, d_bases, d_offsets, n_reads, n_bases, d_topk_idx, d_topk_sum))
 
+    def enqueue_device(self, d_bases, d_offsets, n_reads, n_bases, d_topk_idx=None, d_topk_sum=None):
+        """push_device with the host wait of batch i overlapped by the sketch of batch i + 1: the passes (and any
+        error) of a batch are queued by the NEXT enqueue / flush / sync.  Same rows, same table."""
+        _lib.check(_lib.load().skx_stream_enqueue_device(self._h, d_bases, d_offsets, n_reads, n_bases, d_topk_idx, d_topk_sum))
+
+    def flush(self):
+        _lib.check(_lib.load().skx_stream_flush(self._h))
+
     def sync(self):
         _lib.check(_lib.load().skx_stream_sync(self._h))
 

@@ -316,6 +316,30 @@ SKX_API void skx_ref_destroy(skx_ref* ref) { ref_free(ref); }
 // ------------------------------------------------------------------ stream
 struct TimedSpan { int stage; hipEvent_t a, b; };
 
+// A batch between its two halves.  batch_front queues the sketcher, the pair counts, the speculative pair gather and the
+// published summary on the sketch stream; batch_back waits for the summary (the one host wait of a batch) and queues the
+// passes.  skx_stream_push* run both halves in one call; skx_stream_enqueue_device runs the front half of batch i + 1
+// BEFORE the back half of batch i, so the sketch stream never waits for the host between two batches.
+struct PendingBatch {
+    bool valid = false;
+    int side = 0;  // which copy of the sketch buffers holds it
+    const uint8_t* d_bases = nullptr;
+    const u64* d_offsets = nullptr;
+    u32 n_reads = 0;
+    u64 n_bases = 0;
+    u32* d_topk_idx = nullptr;
+    u64* d_topk_sum = nullptr;
+    u32 seq = 0;               // sequence number its summary is published under
+    bool spec_insert = false;  // its pairs were gathered into buffer set spec_set right behind the sketcher
+    int spec_set = 0;
+    bool inrange_only = true;
+    u32 dbg_cap = 0xFFFFFFFFu;
+    u32* h_shared = nullptr;   // host outputs of the synchronous parity / debug path
+    u64* h_sketches = nullptr;
+    u32* h_sketch_len = nullptr;
+    void* slot = nullptr;      // skx_stream::Staged of a host-fed batch: its rows travel to the host behind the ranking
+};
+
 struct skx_stream {
     const skx_ref* ref = nullptr;
     int device = 0;
@@ -329,10 +353,12 @@ struct skx_stream {
     int depth = 2;
     int buf = 0;
     hipEvent_t ev_dict[2] = {nullptr, nullptr}, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
-    hipEvent_t ev_sketch = nullptr;    // sketch stream: this batch's sketches, pair offsets (and speculative pair gather) are done
-    hipEvent_t ev_dictrest = nullptr;  // scan stream: the hash set / pair hashes of the latest pass have been consumed
-    bool dictrest_pending = false;
-    bool sk_reader_pending = false;    // a pass gathered its pairs on the scan stream: the sketch buffers are still being read
+    // per side of the sketch buffers (see d_sk below):
+    hipEvent_t ev_sketch[2] = {nullptr, nullptr};  // sketch stream: the batch's sketches, pair offsets (and speculative pair gather) are done
+    hipEvent_t ev_skread[2] = {nullptr, nullptr};  // scan stream: a pass that gathered its own pairs has read the sketch buffers
+    bool sk_reader_pending[2] = {false, false};
+    int side = 0;                                  // the side d_sk ... h_chk currently name
+    PendingBatch pend;                             // skx_stream_enqueue_device: the batch whose back half is still to come
     bool front_pending[2] = {false, false};
     bool back_pending[2] = {false, false};
     u32 top_k = 0, max_reads = 0, sk_stride = 0;
@@ -343,11 +369,15 @@ struct skx_stream {
     // staging for host pushes
     uint8_t* d_bases = nullptr;
     u64* d_offsets = nullptr;
-    // sketch outputs for the whole batch
+    // sketch outputs for the whole batch.  Two copies ("sides"): a batch queued with skx_stream_enqueue_device keeps its
+    // side until its passes are queued, while the next batch is sketched into the other.  d_sk ... d_big / h_chk name the
+    // side in use (use_side); side 1 is allocated by the first call that needs it.
     u64* d_sk = nullptr;
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
-    // pass workspace
-    u64 *d_pair_h = nullptr, *d_q[2] = {nullptr, nullptr};
+    u64* sd_sk[2] = {nullptr, nullptr};
+    u32 *sd_len[2] = {nullptr, nullptr}, *sd_cnt[2] = {nullptr, nullptr}, *sd_poff[2] = {nullptr, nullptr}, *sd_big[2] = {nullptr, nullptr};
+    // pass workspace (per buffer set: pair hashes, hash set and its counters, Q, windows, pair lists, Mq)
+    u64 *d_pair_h[2] = {nullptr, nullptr}, *d_q[2] = {nullptr, nullptr};
     u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
     u32 *d_pair_r[2] = {nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[2] = {nullptr, nullptr};
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
@@ -374,11 +404,12 @@ struct skx_stream {
     // pass when it picks the scan variant; reads of one sample share most of their matching hashes, so |Q| can be
     // far below it.  A hint only -- every variant gives the same bits.
     // dictionary builder scratch (launch_dictionary): hash set, per-key bucket offsets, bucket counts / bases, counters
-    u64* d_ht = nullptr;
+    u64* d_ht[2] = {nullptr, nullptr};
     u32 ht_slots = 0;
-    u32 *d_slot_off = nullptr, *d_bcount = nullptr, *d_bbase = nullptr, *d_btot = nullptr, *d_dict_ctr = nullptr;
+    u32 *d_slot_off = nullptr, *d_bcount = nullptr, *d_bbase = nullptr, *d_btot = nullptr, *d_dict_ctr[2] = {nullptr, nullptr};
     u32* d_chk = nullptr;    // [8] device-side look at a batch's offsets (batch_check_kernel)
-    u32* h_chk = nullptr;    // page-locked, coherent [16]: written by publish_kernel: d_chk, [8] = total pairs, [15] = sequence
+    u32* h_chk = nullptr;    // page-locked, coherent [16] per side: written by publish_kernel: d_chk, [8] = total pairs, [15] = sequence
+    u32* h_chk_base = nullptr;
     u32 pub_seq = 0;         // sequence number of the latest publish
     bool chk_dirty = false;  // a push failed between arming and publishing: re-zero the device-side counters first
     u32* d_grp_any[2] = {nullptr, nullptr};  // [rank groups + 1] per buffer set: the group's slice of the bit matrix holds any
@@ -423,20 +454,22 @@ static void stream_free(skx_stream* st) {
     if (st->hs0) (void)hipStreamSynchronize(st->hs0);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     if (st->hs2) (void)hipStreamSynchronize(st->hs2);
-    void* ptrs[] = {st->d_bases, st->d_offsets, st->d_sk, st->d_len, st->d_cnt, st->d_poff, st->d_pair_h,
+    void* ptrs[] = {st->d_bases, st->d_offsets, st->sd_sk[0], st->sd_len[0], st->sd_cnt[0], st->sd_poff[0], st->sd_big[0],
+                    st->sd_sk[1], st->sd_len[1], st->sd_cnt[1], st->sd_poff[1], st->sd_big[1], st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
                     st->d_csum, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
-                    st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_big, st->d_bsum, st->d_grp_any[0],
+                    st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowmask[0], st->d_rowmask[1]};
     for (void* p : ptrs) (void)hipFree(p);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
-    if (st->h_chk) (void)hipHostFree(st->h_chk);
+    if (st->h_chk_base) (void)hipHostFree(st->h_chk_base);
     (void)hipFree(st->d_chk); (void)hipFree(st->d_retry);
-    (void)hipFree(st->d_ht); (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
-    (void)hipFree(st->d_btot); (void)hipFree(st->d_dict_ctr);
+    (void)hipFree(st->d_ht[0]); (void)hipFree(st->d_ht[1]); (void)hipFree(st->d_dict_ctr[0]); (void)hipFree(st->d_dict_ctr[1]);
+    (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
+    (void)hipFree(st->d_btot);
     for (auto& sl : st->slot) {
         (void)hipFree(sl.d_bases); (void)hipFree(sl.d_offsets);
         if (sl.h_offsets) (void)hipHostFree(sl.h_offsets);
@@ -450,13 +483,36 @@ static void stream_free(skx_stream* st) {
         if (st->ev_dict[i]) (void)hipEventDestroy(st->ev_dict[i]);
         if (st->ev_front[i]) (void)hipEventDestroy(st->ev_front[i]);
         if (st->ev_back[i]) (void)hipEventDestroy(st->ev_back[i]);
+        if (st->ev_sketch[i]) (void)hipEventDestroy(st->ev_sketch[i]);
+        if (st->ev_skread[i]) (void)hipEventDestroy(st->ev_skread[i]);
     }
-    if (st->ev_sketch) (void)hipEventDestroy(st->ev_sketch);
-    if (st->ev_dictrest) (void)hipEventDestroy(st->ev_dictrest);
+    if (st->hs2 && st->hs2 != st->hs && st->hs2 != st->hs0) (void)hipStreamDestroy(st->hs2);
     if (st->hs0 && st->hs0 != st->hs) (void)hipStreamDestroy(st->hs0);
-    if (st->hs2 && st->hs2 != st->hs) (void)hipStreamDestroy(st->hs2);
     if (st->hs) (void)hipStreamDestroy(st->hs);
     delete st;
+}
+
+// one copy of the per-batch sketch buffers
+static hipError_t alloc_side(skx_stream* st, int i) {
+    hipError_t e;
+    if ((e = hipMalloc(&st->sd_sk[i], (size_t)st->max_reads * st->sk_stride * 8)) != hipSuccess) return e;
+    if ((e = hipMalloc(&st->sd_len[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&st->sd_cnt[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&st->sd_poff[i], ((size_t)st->max_reads + 2) * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&st->sd_big[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
+    return hipMemset(st->sd_big[i], 0, 4);  // (null stream; callers on the pipeline streams synchronise the device once)
+}
+static hipError_t use_side(skx_stream* st, int i) {
+    if (!st->sd_sk[i]) {
+        hipError_t e = alloc_side(st, i);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+    }
+    st->side = i;
+    st->d_sk = st->sd_sk[i]; st->d_len = st->sd_len[i]; st->d_cnt = st->sd_cnt[i]; st->d_poff = st->sd_poff[i];
+    st->d_big = st->sd_big[i];
+    st->h_chk = st->h_chk_base + 16 * i;
+    return hipSuccess;
 }
 
 // pair_hint: pairs (read, hash some genome holds) a read is expected to contribute at most; sizes the pass workspace
@@ -501,7 +557,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // HBM-bound scan of batch i overlap for real: C2, same box: 54.5 -> 59.7 M reads/s from a fresh table, 56.8 -> 63.6 M
     // steady, the scan itself 0.62 -> 0.78 ms.
     static const int depth_env = getenv("SKX_PIPELINE") ? atoi(getenv("SKX_PIPELINE")) : 3;
-    st->depth = depth_env < 1 ? 1 : depth_env > 3 ? 3 : depth_env;
+    st->depth = depth_env < 1 ? 1 : depth_env > 4 ? 4 : depth_env;
     // the HBM-bound scan stream gets the higher priority (it needs its full occupancy); the others fill what is left
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
@@ -524,22 +580,22 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     } else {
     SCHK(hipStreamCreateWithPriority(&st->hs, hipStreamNonBlocking, prio_hi));
     if (st->depth >= 3) SCHK(hipStreamCreateWithPriority(&st->hs0, hipStreamNonBlocking, prio_lo)); else st->hs0 = st->hs;
-    if (st->depth >= 2) SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, prio_lo)); else st->hs2 = st->hs;
+    // (4: the ranking shares the SKETCH stream -- {sketch, ranking} | {dictionary, scan, transpose}: the two VALU-bound stages
+    // take turns and only the HBM-bound scan runs beside them)
+    if (st->depth == 4) st->hs2 = st->hs0;
+    else if (st->depth >= 2) SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, prio_lo)); else st->hs2 = st->hs;
     }
     for (int i = 0; i < 2; ++i) {
         SCHK(hipEventCreateWithFlags(&st->ev_dict[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_back[i], hipEventDisableTiming));
+        SCHK(hipEventCreateWithFlags(&st->ev_sketch[i], hipEventDisableTiming));
+        SCHK(hipEventCreateWithFlags(&st->ev_skread[i], hipEventDisableTiming));
     }
-    SCHK(hipEventCreateWithFlags(&st->ev_sketch, hipEventDisableTiming));
-    SCHK(hipEventCreateWithFlags(&st->ev_dictrest, hipEventDisableTiming));
     SCHK(hipMalloc(&st->d_bases, std::max<u64>(max_bases, 1)));
     SCHK(hipMalloc(&st->d_offsets, ((size_t)max_reads + 1) * 8));
-    SCHK(hipMalloc(&st->d_sk, (size_t)max_reads * sk_stride * 8));
-    SCHK(hipMalloc(&st->d_len, ((size_t)max_reads + 1) * 4));
-    SCHK(hipMalloc(&st->d_cnt, ((size_t)max_reads + 1) * 4));
-    SCHK(hipMalloc(&st->d_poff, ((size_t)max_reads + 2) * 4));
-    SCHK(hipMalloc(&st->d_pair_h, (size_t)st->pcap * 8));
+    SCHK(alloc_side(st, 0));
+    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_pair_h[i], (size_t)st->pcap * 8));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_q[i], (size_t)st->pcap * 8));
     for (int i = 0; i < 2; ++i) {
         SCHK(hipMalloc(&st->d_pair_r[i], (size_t)st->pcap * 4));
@@ -588,23 +644,24 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
     st->ht_slots = 1024;
     while (st->ht_slots < 2ull * st->pcap) st->ht_slots <<= 1;
-    SCHK(hipMalloc(&st->d_ht, (size_t)st->ht_slots * 8));
-    SCHK(hipMemset(st->d_ht, 0xFF, (size_t)st->ht_slots * 8));  // all-ones = empty; the compaction empties it again
+    for (int i = 0; i < 2; ++i) {
+        SCHK(hipMalloc(&st->d_ht[i], (size_t)st->ht_slots * 8));
+        SCHK(hipMemset(st->d_ht[i], 0xFF, (size_t)st->ht_slots * 8));  // all-ones = empty; the compaction empties it again
+        SCHK(hipMalloc(&st->d_dict_ctr[i], 64));
+        SCHK(hipMemset(st->d_dict_ctr[i], 0, 64));
+    }
     SCHK(hipMalloc(&st->d_slot_off, (size_t)st->ht_slots * 4));
     SCHK(hipMalloc(&st->d_btot, 256 * 4));
     SCHK(hipMalloc(&st->d_bcount, (size_t)skx::dict_buckets() * 4));
     SCHK(hipMemset(st->d_bcount, 0, (size_t)skx::dict_buckets() * 4));
     SCHK(hipMalloc(&st->d_bbase, (size_t)skx::dict_buckets() * 4));
-    SCHK(hipMalloc(&st->d_dict_ctr, 64));
-    SCHK(hipMemset(st->d_dict_ctr, 0, 64));
-    SCHK(hipHostMalloc((void**)&st->h_chk, 16 * 4, hipHostMallocCoherent));  // kernels write it, the host polls it
-    memset(st->h_chk, 0, 16 * 4);
+    SCHK(hipHostMalloc((void**)&st->h_chk_base, 2 * 16 * 4, hipHostMallocCoherent));  // kernels write it, the host polls it
+    memset(st->h_chk_base, 0, 2 * 16 * 4);
     SCHK(hipMalloc(&st->d_chk, 64));
     SCHK(hipMemset(st->d_chk, 0, 64));
     SCHK(hipMalloc(&st->d_retry, ((size_t)max_reads + 1) * 4));
     SCHK(hipMemset(st->d_retry, 0, 4));
-    SCHK(hipMalloc(&st->d_big, ((size_t)max_reads + 1) * 4));
-    SCHK(hipMemset(st->d_big, 0, 4));
+    SCHK(use_side(st, 0));
     SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocCoherent));
     st->h_nq[0] = st->h_nq[1] = 0;
     // the zero-fills above ran on the null stream, which the (non-blocking) pipeline streams do not wait for
@@ -633,6 +690,7 @@ SKX_API int skx_stream_create(skx_stream** out, const skx_ref* ref, uint32_t top
 SKX_API void skx_stream_destroy(skx_stream* st) { stream_free(st); }
 
 // ---- profiling spans
+static int flush_pending(skx_stream* st);
 static hipEvent_t get_event(skx_stream* st) {
     if (!st->ev_pool.empty()) { hipEvent_t ev = st->ev_pool.back(); st->ev_pool.pop_back(); return ev; }
     hipEvent_t ev = nullptr;
@@ -665,6 +723,7 @@ SKX_API int skx_stream_set_profiling(skx_stream* st, int enabled) {
 SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));
     HIPCHK(hipStreamSynchronize(st->hs0));
     HIPCHK(hipStreamSynchronize(st->hs));
     HIPCHK(hipStreamSynchronize(st->hs2));
@@ -707,31 +766,29 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already): set b was last used
     // two passes ago -- by that pass's scan (Q, windows) and ranking (pair lists, offsets, Mq)
     (void)hs0;
-    HIPCHK(hipStreamWaitEvent(hs, st->ev_sketch, 0));  // this batch's sketches and pair offsets
+    HIPCHK(hipStreamWaitEvent(hs, st->ev_sketch[st->side], 0));  // this batch's sketches and pair offsets
     if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_front[b], 0)); st->front_pending[b] = false; }
     if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
     // (inserted: the sketch stream also copied the pass's pair offsets -- this stream then never touches the sketch buffers,
     // which the next batch's sketch is free to overwrite)
-    if (!inserted) {
-        HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
-        st->sk_reader_pending = true;
-    }
+    if (!inserted) HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
     if (P > 0) {
         Span sp(st, 1, hs);
         if (!inserted)
-            skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h, d_pair_r, st->d_ht,
-                                    st->ht_slots, st->d_dict_ctr, st->pcap);
-        skx::launch_dict_rest(hs, st->d_ht, st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
-                              st->d_dict_ctr, d_q, d_nq);
-        skx::launch_pair_q(hs, st->d_pair_h, P, d_q, d_nq, d_pair_q);
+            skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h[b], d_pair_r, st->d_ht[b],
+                                    st->ht_slots, st->d_dict_ctr[b], st->pcap);
+        skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
+                              st->d_dict_ctr[b], d_q, d_nq);
+        skx::launch_pair_q(hs, st->d_pair_h[b], P, d_q, d_nq, d_pair_q);
         skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);  // (also hands |Q| to the host)
         if (st->d_hbuf) skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b]);
         st->hint_pairs[b] = P;
     }
     HIPCHK(hipGetLastError());
-    // hash set and pair hashes may be refilled (by the next batch's gather), the sketch buffers overwritten
-    HIPCHK(hipEventRecord(st->ev_dictrest, hs));
-    st->dictrest_pending = true;
+    if (!inserted) {  // this side of the sketch buffers may be overwritten once the gather above has run
+        HIPCHK(hipEventRecord(st->ev_skread[st->side], hs));
+        st->sk_reader_pending[st->side] = true;
+    }
     HIPCHK(hipEventRecord(st->ev_dict[b], hs));
 
     // the very first pass of a stream has no hint: wait for its dictionary once rather than run the heaviest variant
@@ -847,171 +904,249 @@ static int for_each_pass(skx_stream* st, u32 n_reads, u32 max_pass_reads, F fn) 
     return SKX_OK;
 }
 
-// sketch + score + rank a batch already resident on the device.
-// h_off: host copy of the offsets when the caller has one (validated, st->h_offsets), else NULL -- then a small
-// kernel looks at them on the device and the host reads back 24 bytes instead of every offset.
-// h_shared / h_sketches / h_sketch_len: optional HOST outputs (parity/debug).
-static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, const u64* h_off, u32 n_reads,
-                         u64 n_bases, u32* d_topk_idx, u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
-    const skx_ref* ref = st->ref;
-    hipStream_t hs = st->hs0;  // sketching and everything the host reads back run on the first pipeline stream
-    (void)h_off;
-    if (n_reads == 0) return SKX_OK;
-    const bool inrange_only = !(h_sketches || h_sketch_len);  // production: only what can meet the reference is built
-    const u64 max_ref = ref->any ? ref->max_ref : 0;
-    static const bool no_filter = getenv("SKX_NO_FILTER") != nullptr;  // measurement aid
-    // counts -> (filter) -> pair offsets; poff[n_reads] = total pairs
-    const u32* filt = (ref->any && !no_filter) ? ref->d_filt : nullptr;
-    // Only hashes some genome holds become pairs (exact: the others share nothing with anyone).  The wave kernel
-    // applies the filter itself in production mode; rows it did not filter (long reads, full sketches for the
-    // debug outputs) get the separate pass.
-    // ... and the few words the host needs (offsets check, total pairs) are published to page-locked memory
-    // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
-    const u32 dbg_cap = h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
-    const bool spec_insert = n_reads <= std::min(st->rpass, dbg_cap);  // one pass unless the pairs turn out too many
-    u32 seq = 0;
-    // spin on the published sequence number (looking at the stream now and then so a fault cannot hang the caller)
-    auto wait_published = [&]() -> int {
-        volatile u32* pub = st->h_chk;
-        for (u64 spins = 1; pub[15] != seq; ++spins) {
-            if ((spins & 0xFFF) == 0) {
-                const hipError_t e = hipStreamQuery(hs);
-                if (e == hipSuccess) {
-                    if (pub[15] == seq) break;
-                    HIPCHK(hipStreamSynchronize(hs));
-                    if (pub[15] != seq) return fail(SKX_ERR_HIP, "publish kernel finished without raising its sequence number");
-                } else if (e != hipErrorNotReady) {
-                    return fail(SKX_ERR_HIP, "stream failed while waiting for the batch summary: %s", hipGetErrorString(e));
-                }
+// spin on the published sequence number (looking at the stream now and then so a fault cannot hang the caller)
+static int wait_published(skx_stream* st, const PendingBatch& pb) {
+    volatile u32* pub = st->h_chk_base + 16 * pb.side;
+    hipStream_t hs = st->hs0;
+    for (u64 spins = 1; pub[15] != pb.seq; ++spins) {
+        if ((spins & 0xFFF) == 0) {
+            const hipError_t e = hipStreamQuery(hs);
+            if (e == hipSuccess) {
+                if (pub[15] == pb.seq) break;
+                HIPCHK(hipStreamSynchronize(hs));
+                if (pub[15] != pb.seq) return fail(SKX_ERR_HIP, "publish kernel finished without raising its sequence number");
+            } else if (e != hipErrorNotReady) {
+                return fail(SKX_ERR_HIP, "stream failed while waiting for the batch summary: %s", hipGetErrorString(e));
             }
         }
-        return SKX_OK;
-    };
-    // counts -> (filter, for rows the sketchers did not filter themselves) -> pair offsets (poff[n_reads] = total pairs)
-    // -> speculative pair gather -> the few words the host needs, published to page-locked memory
-    auto finish_counts = [&]() -> int {
-        if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
-        if (filt && !inrange_only)
-            skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
-        skx::launch_count_scan(hs, st->d_cnt, st->d_poff, n_reads + 1, st->d_bsum);
-        // the whole batch is normally ONE pass: gather its pairs into the next buffer set and fill the hash set right
-        // here, behind the sketcher -- the rest of the dictionary then runs on the scan stream and this stream is free
-        // for the next batch's sketch (the kernel does nothing if the pairs do not fit one pass: the host finds out
-        // after the wait and cuts the batch into passes)
-        if (spec_insert) {
-            const int b = st->buf;
-            if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_front[b], 0)); st->front_pending[b] = false; }
-            if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
-            if (st->dictrest_pending) { HIPCHK(hipStreamWaitEvent(hs, st->ev_dictrest, 0)); st->dictrest_pending = false; }
-            skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h, st->d_pair_r[b], st->d_ht,
-                                    st->ht_slots, st->d_dict_ctr, st->pcap);
-            HIPCHK(hipMemcpyAsync(st->d_poff_pass[b], st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
-        }
-        seq = ++st->pub_seq;
-        skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, seq);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(st->ev_sketch, hs));
-        return SKX_OK;
-    };
-    if (st->chk_dirty) {  // an earlier push failed half-way
+    }
+    return SKX_OK;
+}
+static const u32* batch_filter(const skx_ref* ref) {
+    static const bool no_filter = getenv("SKX_NO_FILTER") != nullptr;  // measurement aid
+    return (ref->any && !no_filter) ? ref->d_filt : nullptr;
+}
+// counts -> (filter, for rows the sketchers did not filter themselves) -> pair offsets (poff[n_reads] = total pairs)
+// -> speculative pair gather -> the few words the host needs, published to page-locked memory
+// (the stream's d_sk ... names must be on the batch's side)
+static int finish_counts(skx_stream* st, PendingBatch& pb) {
+    const skx_ref* ref = st->ref;
+    hipStream_t hs = st->hs0;
+    const u32 n_reads = pb.n_reads;
+    const u32* filt = batch_filter(ref);
+    if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
+    if (filt && !pb.inrange_only)
+        skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
+    skx::launch_count_scan(hs, st->d_cnt, st->d_poff, n_reads + 1, st->d_bsum);
+    // the whole batch is normally ONE pass: gather its pairs into the buffer set that pass will use and fill the set's
+    // hash set right here, behind the sketcher -- the rest of the dictionary then runs on the scan stream and this
+    // stream is free for the next batch's sketch (the kernel does nothing if the pairs do not fit one pass: the host
+    // finds out after the wait and cuts the batch into passes)
+    if (pb.spec_insert) {
+        const int b = pb.spec_set;
+        if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_front[b], 0)); st->front_pending[b] = false; }
+        if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
+        skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h[b], st->d_pair_r[b],
+                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap);
+        HIPCHK(hipMemcpyAsync(st->d_poff_pass[b], st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
+    }
+    pb.seq = ++st->pub_seq;
+    skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, pb.seq);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(st->ev_sketch[pb.side], hs));
+    return SKX_OK;
+}
+
+// front half of a batch already resident on the device: everything up to the published summary, on the sketch stream.
+// Only hashes some genome holds become pairs (exact: the others share nothing with anyone).  The wave kernel applies the
+// filter itself in production mode; rows it did not filter (full sketches for the debug outputs) get the separate pass.
+static int batch_front(skx_stream* st, PendingBatch& pb) {
+    const skx_ref* ref = st->ref;
+    hipStream_t hs = st->hs0;  // sketching and everything the host reads back run on the first pipeline stream
+    const u32 n_reads = pb.n_reads;
+    // the other side while an enqueued batch still owns one; likewise the buffer set that batch's pass will take
+    pb.side = st->pend.valid ? st->pend.side ^ 1 : 0;
+    HIPCHK(use_side(st, pb.side));
+    pb.inrange_only = !(pb.h_sketches || pb.h_sketch_len);  // production: only what can meet the reference is built
+    const u64 max_ref = ref->any ? ref->max_ref : 0;
+    const u32* filt = batch_filter(ref);
+    // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
+    pb.dbg_cap = pb.h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
+    static const bool spec_env = !getenv("SKX_SPEC_INSERT") || atoi(getenv("SKX_SPEC_INSERT")) != 0;  // test knob
+    pb.spec_insert = spec_env && n_reads <= std::min(st->rpass, pb.dbg_cap);  // one pass unless the pairs turn out too many
+    pb.spec_set = st->buf ^ (st->pend.valid ? 1 : 0);
+    if (st->chk_dirty) {  // an earlier batch failed half-way through this function
         HIPCHK(hipMemsetAsync(st->d_chk, 0, 64, hs));
         HIPCHK(hipMemsetAsync(st->d_retry, 0, 4, hs));
         HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
     }
     st->chk_dirty = true;
-    if (st->sk_reader_pending) {  // (rare: the previous batch was cut into passes that read the sketch buffers on the scan stream)
-        HIPCHK(hipStreamWaitEvent(hs, st->ev_dictrest, 0));
-        st->sk_reader_pending = false;
+    if (st->sk_reader_pending[pb.side]) {  // (rare: this side's previous batch was cut into passes that read it on the scan stream)
+        HIPCHK(hipStreamWaitEvent(hs, st->ev_skread[pb.side], 0));
+        st->sk_reader_pending[pb.side] = false;
     }
     {
         Span sp(st, 0);
         // offsets are looked at on the device (cheap); it also zeroes entry n_reads of the pair counts
-        skx::launch_batch_check(hs, d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk, st->d_cnt + n_reads);
-        if (h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
-        // every read, any length: wave sketchers, then the block sketcher for what overflowed (device-side lists)
-        // (three-stream pipeline: is the previous pass's scan still in flight?  then this sketch shares the CUs with it)
-        bool leave_room = false;
+        skx::launch_batch_check(hs, pb.d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk, st->d_cnt + n_reads);
+        if (pb.h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
+        // every read, any length: wave sketchers (then the block sketcher for what overflowed: device-side lists)
+        // (three-stream pipeline: will the previous pass's scan be in flight?  then this sketch shares the CUs with it)
+        bool leave_room = st->depth >= 3 && st->pend.valid;
         if (st->depth >= 3)
             for (int i = 0; i < 2; ++i)
                 if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = true;
         (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-        HIPCHK(skx::launch_sketch(hs, d_bases, d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, inrange_only, st->d_sk,
-                                  st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big, n_bases,
-                                  st->d_chk, leave_room));
-        if (!inrange_only) {
+        HIPCHK(skx::launch_sketch(hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, pb.inrange_only,
+                                  st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big,
+                                  pb.n_bases, st->d_chk, leave_room));
+        if (!pb.inrange_only) {
             // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
             // not the fast one -- read the count back and run the block sketcher before the rows are copied out
             u32 n_big = 0;
             HIPCHK(hipMemcpyAsync(&n_big, st->d_big, 4, hipMemcpyDeviceToHost, hs));
             HIPCHK(hipStreamSynchronize(hs));
-            HIPCHK(skx::launch_sketch_block(hs, d_bases, d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s, max_ref, false,
-                                            st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift));
+            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s, max_ref,
+                                            false, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift));
             st->reads_big += n_big;
             HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
         }
         // optional sketch outputs leave now: the filter compacts the rows in place
-        if (h_sketch_len) HIPCHK(hipMemcpyAsync(h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
-        if (h_sketches) {
-            memset(h_sketches, 0, (size_t)n_reads * ref->s * 8);
-            HIPCHK(hipMemcpy2DAsync(h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
+        if (pb.h_sketch_len) HIPCHK(hipMemcpyAsync(pb.h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
+        if (pb.h_sketches) {
+            memset(pb.h_sketches, 0, (size_t)n_reads * ref->s * 8);
+            HIPCHK(hipMemcpy2DAsync(pb.h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
                                     (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
         }
-        SKXCHK(finish_counts());
+        SKXCHK(finish_counts(st, pb));
     }
-    SKXCHK(wait_published());  // the one wait of a push: 36 bytes, no copy, no stream synchronisation
-    if (h_sketches || h_sketch_len) HIPCHK(hipStreamSynchronize(hs));  // (debug outputs: their copies must have landed)
-    st->chk_dirty = false;
+    st->chk_dirty = false;  // the publish kernel is queued: it re-arms the device-side counters
+    pb.valid = true;
+    return SKX_OK;
+}
+
+// a younger batch's speculative pair gather has to be undone: the batch before it needs more than one pass, so the
+// buffer sets no longer alternate the way the gather assumed (rare)
+static int cancel_speculation(skx_stream* st, PendingBatch& y) {
+    if (!y.spec_insert) return SKX_OK;
+    HIPCHK(hipMemsetAsync(st->d_ht[y.spec_set], 0xFF, (size_t)st->ht_slots * 8, st->hs0));
+    HIPCHK(hipMemsetAsync(st->d_dict_ctr[y.spec_set], 0, 64, st->hs0));
+    HIPCHK(hipStreamSynchronize(st->hs0));
+    y.spec_insert = false;
+    return SKX_OK;
+}
+
+// back half: wait for the summary, then queue the passes.  `younger`: a batch whose front half is already queued.
+static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
+    const skx_ref* ref = st->ref;
+    hipStream_t hs = st->hs0;
+    const u32 n_reads = pb.n_reads;
+    const u64 max_ref = ref->any ? ref->max_ref : 0;
+    const u32* filt = batch_filter(ref);
+    pb.valid = false;
+    HIPCHK(use_side(st, pb.side));
+    SKXCHK(wait_published(st, pb));  // the one wait of a batch: 36 bytes, no copy, no stream synchronisation
+    if (pb.h_sketches || pb.h_sketch_len) HIPCHK(hipStreamSynchronize(hs));  // (debug outputs: their copies must have landed)
     {
         u32 c[8];
         for (int i = 0; i < 8; ++i) c[i] = st->h_chk[i];
         if (c[0]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
         if (c[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases=%llu bytes given from offsets[0] on",
-                              (unsigned long long)n_bases);
+                              (unsigned long long)pb.n_bases);
         if (c[7]) {
             // production mode, rare: reads whose in-range hashes overflowed a wave's 2048 slots wait on the `big` list.
             // The block sketcher was not queued blindly (it needs a drained CU even to find the list empty): run it now,
-            // then counts, pair gather and the published summary once more.
+            // then counts, pair gather (into the same buffer set: the keys already there are a subset) and the
+            // published summary once more.
             st->reads_big += c[7];
-            st->chk_dirty = true;
-            HIPCHK(skx::launch_sketch_block(hs, d_bases, d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s, max_ref, inrange_only,
-                                            st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift));
-            SKXCHK(finish_counts());
-            SKXCHK(wait_published());
-            st->chk_dirty = false;
+            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s, max_ref,
+                                            pb.inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift));
+            SKXCHK(finish_counts(st, pb));
+            SKXCHK(wait_published(st, pb));
             if (st->h_chk[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases given from offsets[0] on");
         }
     }
     const u32 total_pairs = st->h_chk[8];
     st->last_pairs = total_pairs; st->last_passes = 0;
 
+    const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap;
+    bool inserted = pb.spec_insert && single;  // the gather queued by the front half did its work
+    if (!single && younger) SKXCHK(cancel_speculation(st, *younger));
+    if (inserted && st->buf != pb.spec_set) return fail(SKX_ERR_HIP, "internal: buffer sets out of step");
     u32* d_shared = nullptr;
-    bool inserted = spec_insert && total_pairs <= st->pcap;  // the gather queued above did its work
     auto one_pass = [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
-        if (h_shared) {
+        if (pb.h_shared) {
             if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
         }
-        SKXCHK(run_pass(st, ra, rb, p_base, P, d_topk_idx, d_topk_sum, d_shared, true, inserted));
+        SKXCHK(run_pass(st, ra, rb, p_base, P, pb.d_topk_idx, pb.d_topk_sum, d_shared, true, inserted));
         inserted = false;
         st->last_passes += 1;
-        if (h_shared) {
-            HIPCHK(hipMemcpyAsync(h_shared + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
+        if (pb.h_shared) {
+            HIPCHK(hipMemcpyAsync(pb.h_shared + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
                                   hipMemcpyDeviceToHost, st->hs2));
             HIPCHK(hipStreamSynchronize(st->hs2));
         }
         return SKX_OK;
     };
     int pass_rc;
-    if (n_reads <= std::min(st->rpass, dbg_cap) && total_pairs <= st->pcap) {
+    if (single) {
         pass_rc = one_pass(0, n_reads, 0, total_pairs);  // the whole batch is one pass: no per-read offsets needed
     } else {
         HIPCHK(hipMemcpyAsync(st->h_poff, st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, hs));
         HIPCHK(hipStreamSynchronize(hs));
-        pass_rc = for_each_pass(st, n_reads, dbg_cap, one_pass);
+        pass_rc = for_each_pass(st, n_reads, pb.dbg_cap, one_pass);
     }
     if (d_shared) (void)hipFree(d_shared);
     SKXCHK(pass_rc);
     st->reads_total += n_reads;
+    return SKX_OK;
+}
+
+// the back half of the enqueued batch, if there is one (every entry point that looks at the stream's state starts here)
+static int staged_rows(skx_stream* st, void* slot);
+static int flush_pending(skx_stream* st) {
+    if (!st->pend.valid) return SKX_OK;
+    PendingBatch pb = st->pend;
+    st->pend.valid = false;
+    SKXCHK(batch_back(st, pb, nullptr));
+    return staged_rows(st, pb.slot);
+}
+// sketch + score + rank a batch already resident on the device, both halves (synchronous entry points).
+// h_shared / h_sketches / h_sketch_len: optional HOST outputs (parity/debug).
+static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u64 n_bases, u32* d_topk_idx,
+                         u64* d_topk_sum, u32* h_shared, u64* h_sketches, u32* h_sketch_len) {
+    if (n_reads == 0) return SKX_OK;
+    SKXCHK(flush_pending(st));
+    PendingBatch pb;
+    pb.d_bases = d_bases; pb.d_offsets = d_offsets; pb.n_reads = n_reads; pb.n_bases = n_bases;
+    pb.d_topk_idx = d_topk_idx; pb.d_topk_sum = d_topk_sum;
+    pb.h_shared = h_shared; pb.h_sketches = h_sketches; pb.h_sketch_len = h_sketch_len;
+    SKXCHK(batch_front(st, pb));
+    return batch_back(st, pb, nullptr);
+}
+// ... and with the halves of consecutive batches interleaved: front(i + 1), then back(i).  Errors of batch i surface here
+// (or in the flush); the younger batch is then dropped too.
+static int enqueue_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u64 n_bases, u32* d_topk_idx,
+                         u64* d_topk_sum, void* slot) {
+    PendingBatch nw;
+    nw.d_bases = d_bases; nw.d_offsets = d_offsets; nw.n_reads = n_reads; nw.n_bases = n_bases;
+    nw.d_topk_idx = d_topk_idx; nw.d_topk_sum = d_topk_sum; nw.slot = slot;
+    SKXCHK(batch_front(st, nw));
+    if (st->pend.valid) {
+        PendingBatch old = st->pend;
+        st->pend.valid = false;
+        int rc = batch_back(st, old, &nw);
+        if (rc == SKX_OK) rc = staged_rows(st, old.slot);
+        if (rc != SKX_OK) {
+            const std::string msg = g_err;
+            (void)cancel_speculation(st, nw);
+            (void)hipStreamSynchronize(st->hs0);
+            g_err = msg + " (batch enqueued one call earlier; the batch of this call was dropped too)";
+            return rc;
+        }
+    }
+    st->pend = nw;
     return SKX_OK;
 }
 
@@ -1029,12 +1164,13 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     if (n_bases && !bases) return fail(SKX_ERR_INVALID, "bases is NULL");
     if ((topk_idx || topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
     SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));
     hipStream_t hs = st->hs0;
     // rebase offsets to 0 on the way in
     for (u32 r = 0; r <= n_reads; ++r) st->h_offsets[r] = offsets[r] - base0;
     HIPCHK(hipMemcpyAsync(st->d_offsets, st->h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, hs));
     if (n_bases) HIPCHK(hipMemcpyAsync(st->d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, hs));
-    SKXCHK(process_batch(st, st->d_bases, st->d_offsets, st->h_offsets, n_reads, n_bases, st->d_topk_idx, st->d_topk_sum,
+    SKXCHK(process_batch(st, st->d_bases, st->d_offsets, n_reads, n_bases, st->d_topk_idx, st->d_topk_sum,
                          per_read_shared, reinterpret_cast<u64*>(sketches), sketch_len));
     HIPCHK(hipStreamSynchronize(hs));  // sketch copies (first stream)
     const size_t rows = (size_t)n_reads * st->ref->n_species * st->top_k;
@@ -1045,35 +1181,64 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     return SKX_OK;
 }
 
+static int check_device_batch(skx_stream* st, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads, uint64_t n_bases,
+                              const uint32_t* d_topk_idx, const uint64_t* d_topk_sum) {
+    if (!st || !d_offsets) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (n_reads > st->max_reads) return fail(SKX_ERR_CAPACITY, "n_reads=%u exceeds max_batch_reads=%u", n_reads, st->max_reads);
+    if (n_reads && n_bases && !d_bases) return fail(SKX_ERR_INVALID, "d_bases is NULL");
+    if ((d_topk_idx || d_topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
+    if (n_bases > st->max_bases) return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu",
+                                             (unsigned long long)n_bases, (unsigned long long)st->max_bases);
+    return SKX_OK;
+}
 SKX_API int skx_stream_push_device(skx_stream* st, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads,
                                    uint64_t n_bases, uint32_t* d_topk_idx, uint64_t* d_topk_sum) {
-    if (!st || !d_offsets) return fail(SKX_ERR_INVALID, "NULL argument");
+    SKXCHK(check_device_batch(st, d_bases, d_offsets, n_reads, n_bases, d_topk_idx, d_topk_sum));
+    SKXCHK(use_device(st->device));
+    if (n_reads == 0) return flush_pending(st);
+    u32* ti = d_topk_idx ? d_topk_idx : st->d_topk_idx;
+    u64* ts = d_topk_sum ? reinterpret_cast<u64*>(d_topk_sum) : st->d_topk_sum;
+    return process_batch(st, d_bases, reinterpret_cast<const u64*>(d_offsets), n_reads, n_bases, ti, ts, nullptr, nullptr, nullptr);
+}
+SKX_API int skx_stream_enqueue_device(skx_stream* st, const uint8_t* d_bases, const uint64_t* d_offsets, uint32_t n_reads,
+                                      uint64_t n_bases, uint32_t* d_topk_idx, uint64_t* d_topk_sum) {
+    SKXCHK(check_device_batch(st, d_bases, d_offsets, n_reads, n_bases, d_topk_idx, d_topk_sum));
     if (n_reads == 0) return SKX_OK;
-    if (n_reads > st->max_reads) return fail(SKX_ERR_CAPACITY, "n_reads=%u exceeds max_batch_reads=%u", n_reads, st->max_reads);
-    if (n_bases && !d_bases) return fail(SKX_ERR_INVALID, "d_bases is NULL");
-    if ((d_topk_idx || d_topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
     SKXCHK(use_device(st->device));
     u32* ti = d_topk_idx ? d_topk_idx : st->d_topk_idx;
     u64* ts = d_topk_sum ? reinterpret_cast<u64*>(d_topk_sum) : st->d_topk_sum;
-    if (n_bases > st->max_bases) return fail(SKX_ERR_CAPACITY, "batch has %llu bases > max_batch_bases=%llu",
-                                             (unsigned long long)n_bases, (unsigned long long)st->max_bases);
-    return process_batch(st, d_bases, reinterpret_cast<const u64*>(d_offsets), nullptr, n_reads, n_bases, ti, ts, nullptr, nullptr,
-                         nullptr);
+    return enqueue_batch(st, d_bases, reinterpret_cast<const u64*>(d_offsets), n_reads, n_bases, ti, ts, nullptr);
+}
+SKX_API int skx_stream_flush(skx_stream* st) {
+    if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
+    SKXCHK(use_device(st->device));
+    return flush_pending(st);
 }
 
 // ---- host-fed pipeline
-static int staged_process(skx_stream* st, skx_stream::Staged& sl) {
-    if (!sl.pending) return SKX_OK;
-    sl.pending = false;
-    HIPCHK(hipStreamWaitEvent(st->hs0, sl.ev_copy, 0));  // the batch must have landed before the sketcher reads it
-    SKXCHK(process_batch(st, sl.d_bases, sl.d_offsets, nullptr, sl.n_reads, sl.n_bases, st->d_topk_idx, st->d_topk_sum, nullptr,
-                         nullptr, nullptr));
-    // rows travel back behind the pass's ranking (same stream), before the next batch's ranking overwrites them
+// rows travel back behind the pass's ranking (same stream), before the next batch's ranking overwrites them
+static int staged_rows(skx_stream* st, void* slot) {
+    if (!slot) return SKX_OK;
+    skx_stream::Staged& sl = *static_cast<skx_stream::Staged*>(slot);
     const size_t rows = (size_t)sl.n_reads * st->ref->n_species * st->top_k;
     if (sl.out_idx) HIPCHK(hipMemcpyAsync(sl.out_idx, st->d_topk_idx, rows * 4, hipMemcpyDeviceToHost, st->hs2));
     if (sl.out_sum) HIPCHK(hipMemcpyAsync(sl.out_sum, st->d_topk_sum, rows * 8, hipMemcpyDeviceToHost, st->hs2));
     HIPCHK(hipEventRecord(sl.ev_done, st->hs2));
     sl.in_flight = true;
+    return SKX_OK;
+}
+// front half of the slot's batch (and the back half of the one before it)
+static int staged_process(skx_stream* st, skx_stream::Staged& sl) {
+    if (!sl.pending) return SKX_OK;
+    sl.pending = false;
+    HIPCHK(hipStreamWaitEvent(st->hs0, sl.ev_copy, 0));  // the batch must have landed before the sketcher reads it
+    return enqueue_batch(st, sl.d_bases, sl.d_offsets, sl.n_reads, sl.n_bases, st->d_topk_idx, st->d_topk_sum, &sl);
+}
+// ... until its rows are on the host
+static int staged_finish(skx_stream* st, skx_stream::Staged& sl) {
+    SKXCHK(staged_process(st, sl));
+    if (st->pend.valid && st->pend.slot == &sl) SKXCHK(flush_pending(st));
+    if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
     return SKX_OK;
 }
 SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
@@ -1101,9 +1266,12 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     }
     skx_stream::Staged& sl = st->slot[st->next_ticket & 1u];
     skx_stream::Staged& other = st->slot[(st->next_ticket & 1u) ^ 1u];
-    // the slot's previous batch (two tickets ago) must be through: processed, rows on the host
-    SKXCHK(staged_process(st, sl));
-    if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
+    // the previous batch goes to the kernels first (its sketch is queued, and the passes of the batch before it) ...
+    SKXCHK(staged_process(st, other));
+    if (other.ev_copy && other.ticket + 1 == st->next_ticket) HIPCHK(hipEventSynchronize(other.ev_copy));  // its host buffers are free again
+    // ... then this slot's previous batch (two tickets ago) must be through -- passes queued, rows on the host -- while
+    // the device works on
+    SKXCHK(staged_finish(st, sl));
     for (u32 r = 0; r <= n_reads; ++r) sl.h_offsets[r] = offsets[r] - base0;
     HIPCHK(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st->hs_copy));
     if (n_bases) HIPCHK(hipMemcpyAsync(sl.d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, st->hs_copy));
@@ -1112,8 +1280,7 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     sl.ticket = st->next_ticket;
     if (ticket) *ticket = st->next_ticket;
     st->next_ticket += 1;
-    // ... and while that copy runs, the previous batch goes through the kernels (its blocking part: the sketch)
-    return staged_process(st, other);
+    return SKX_OK;
 }
 SKX_API int skx_stream_wait(skx_stream* st, uint64_t ticket) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
@@ -1121,8 +1288,9 @@ SKX_API int skx_stream_wait(skx_stream* st, uint64_t ticket) {
     SKXCHK(use_device(st->device));
     skx_stream::Staged& sl = st->slot[ticket & 1u];
     if (sl.ticket != ticket) return SKX_OK;  // the slot has moved on: that batch completed before it was reused
-    SKXCHK(staged_process(st, sl));
-    if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
+    skx_stream::Staged& older = st->slot[(ticket & 1u) ^ 1u];
+    if (older.pending && older.ticket < ticket) SKXCHK(staged_process(st, older));  // (in submission order)
+    SKXCHK(staged_finish(st, sl));
     if (st->profiling) collect_spans(st);
     return SKX_OK;
 }
@@ -1135,6 +1303,7 @@ SKX_API int skx_stream_drain(skx_stream* st) {
         skx_stream::Staged& sl = st->slot[(first + i) & 1u];
         SKXCHK(staged_process(st, sl));
     }
+    SKXCHK(flush_pending(st));
     for (auto& sl : st->slot)
         if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
     return skx_stream_sync(st);
@@ -1143,6 +1312,7 @@ SKX_API int skx_stream_drain(skx_stream* st) {
 SKX_API int skx_stream_sync(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));
     HIPCHK(hipStreamSynchronize(st->hs0));
     HIPCHK(hipStreamSynchronize(st->hs));
     HIPCHK(hipStreamSynchronize(st->hs2));
@@ -1153,6 +1323,7 @@ SKX_API int skx_stream_sync(skx_stream* st) {
 SKX_API int skx_stream_table(skx_stream* st, uint64_t* cum) {
     if (!st || !cum) return fail(SKX_ERR_INVALID, "NULL argument");
     SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));
     // the running table belongs to the back stream; the caller sees the real genomes, species concatenated
     const u32 n = st->ref->n_genomes;
     skx::launch_gather_table(st->hs2, st->d_cum, st->d_tab_tmp, n, st->ref->d_real2pad);
@@ -1164,6 +1335,7 @@ SKX_API int skx_stream_table(skx_stream* st, uint64_t* cum) {
 SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
     if (!st || !add) return fail(SKX_ERR_INVALID, "NULL argument");
     SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));
     const u32 n = st->ref->n_genomes;
     HIPCHK(hipMemcpyAsync(st->d_tab_tmp, add, (size_t)n * 8, hipMemcpyHostToDevice, st->hs2));
     skx::launch_add_table(st->hs2, st->d_cum, st->d_tab_tmp, n, st->ref->d_real2pad);
@@ -1174,6 +1346,7 @@ SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
 SKX_API int skx_stream_reset(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));
     HIPCHK(hipStreamSynchronize(st->hs0));
     HIPCHK(hipStreamSynchronize(st->hs));
     HIPCHK(hipMemsetAsync(st->d_cum, 0, (size_t)st->ref->n_pad * 8, st->hs2));
@@ -1206,6 +1379,7 @@ SKX_API int skx_stream_rank(skx_stream* st, uint32_t top_k, uint32_t* idx, uint6
     const skx_ref* ref = st->ref;
     if (top_k < 1 || top_k > ref->min_species) return fail(SKX_ERR_INVALID, "top_k=%u outside 1..n_genomes", top_k);
     SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));
     const size_t rows = (size_t)ref->n_species * top_k;
     if (rows > st->rank_cap) {  // (beyond SKX_MAX_TOP rows per species: grow the scratch once)
         HIPCHK(hipStreamSynchronize(st->hs2));

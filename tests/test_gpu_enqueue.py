@@ -1,0 +1,169 @@
+"""GPU parity of skx_stream_enqueue_device: the device-resident entry point whose halves of consecutive batches are
+interleaved (sketch of batch i + 1 queued before the host waits for batch i's summary).  Rows and table must be those of
+the oracle (oracle/oracle.c, the restatement of src/sketchy.rs:317-356) on the same reads in the same order -- through
+the usual one-pass case, batches cut into several passes (the younger batch's speculative pair gather is undone), the
+block-sketcher slow path, errors surfacing one call late, and the non-speculative dictionary placement."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import pack_reads, workload
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _enqueue_stream(S, bases, offsets, cuts, top, poke=None):
+    """every batch [cuts[i], cuts[i+1]) through enqueue_device with its own device rows; poke(i) runs after batch i"""
+    from sketchy_amd import api
+    d_b = api.DeviceBuffer.from_numpy(bases if len(bases) else np.zeros(1, np.uint8))
+    bufs, rows = [], []
+    try:
+        for i in range(len(cuts) - 1):
+            a, b = cuts[i], cuts[i + 1]
+            n = b - a
+            d_o = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[a:b + 1], np.uint64))
+            d_i = api.DeviceBuffer(max(1, n * top) * 4)
+            d_s = api.DeviceBuffer(max(1, n * top) * 8)
+            bufs += [d_o, d_i, d_s]
+            rows.append((n, d_i, d_s))
+            S.enqueue_device(d_b.ptr, d_o.ptr, n, int(offsets[b] - offsets[a]), d_i.ptr if top else None, d_s.ptr if top else None)
+            if poke:
+                poke(i)
+        S.sync()
+        idx = np.concatenate([d_i.to_numpy(np.uint32, (n, top)) for n, d_i, _ in rows]) if top else None
+        val = np.concatenate([d_s.to_numpy(np.uint64, (n, top)) for n, _, d_s in rows]) if top else None
+        return idx, val
+    finally:
+        d_b.free()
+        for d in bufs:
+            d.free()
+
+
+def _expect(ref, s, bases, offsets, top, k=16, seed=0):
+    n = len(ref)
+    return orc.stream(k, seed, s, ref, np.full(n, s, np.uint32), bases, offsets, top_k=top)
+
+
+def test_enqueue_matches_oracle_uneven_batches(gpu):
+    from sketchy_amd import api
+    ref, bases, offsets = workload(700, 400, 1500, read_len=300, rng_seed=301)
+    exp = _expect(ref["ref"], 400, bases, offsets, 2)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=2, max_batch_reads=600, max_batch_bases=len(bases))
+    cuts = [0, 1, 400, 401, 1000, 1000 + 37, 1500]
+    idx, val = _enqueue_stream(S, bases, offsets, cuts, 2)
+    np.testing.assert_array_equal(idx, exp["topk_idx"])
+    np.testing.assert_array_equal(val, exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    assert S.reads == 1500
+    # entry points that look at the stream flush the outstanding half first: table / rank / push_device in between
+    S2 = api.SumOfSharedHashes(R, top=2, max_batch_reads=600, max_batch_bases=len(bases))
+    seen = {}
+
+    def poke(i):
+        if i == 1:
+            seen["table"] = S2.table()
+        if i == 3:
+            seen["rank"] = S2.rank(3)
+    idx, val = _enqueue_stream(S2, bases, offsets, cuts, 2, poke)
+    np.testing.assert_array_equal(idx, exp["topk_idx"])
+    np.testing.assert_array_equal(val, exp["topk_sum"])
+    np.testing.assert_array_equal(S2.table(), exp["cum"])
+    part = _expect(ref["ref"], 400, bases, offsets[:401], 1)
+    np.testing.assert_array_equal(seen["table"], part["cum"])
+    part = _expect(ref["ref"], 400, bases, offsets[:1001], 3)
+    np.testing.assert_array_equal(seen["rank"][0].reshape(-1), part["topk_idx"][-1])
+    np.testing.assert_array_equal(seen["rank"][1].reshape(-1), part["topk_sum"][-1])
+
+
+def test_enqueue_batches_that_need_several_passes(gpu):
+    """Dense batches (reads sharing hundreds of hashes with the reference: more pairs than one pass holds) between sparse
+    ones: the dense batch finds out it needs several passes AFTER the next batch's pairs were gathered speculatively
+    into the buffer set it now needs itself -- the gather is undone and redone on the scan stream."""
+    from sketchy_amd import api, synth
+    ref = synth.make_reference(40, 3000, genome_len=24000, rng_seed=311, device="numpy")
+    dense_b, dense_o = synth.make_reads(ref["genome"], 120, 4000, err=0.01, rng_seed=312)
+    sparse_b, sparse_o = synth.make_reads(ref["genome"], 300, 120, err=0.05, rng_seed=313)
+    d = [dense_b[int(dense_o[i]):int(dense_o[i + 1])].tobytes() for i in range(120)]
+    sp = [sparse_b[int(sparse_o[i]):int(sparse_o[i + 1])].tobytes() for i in range(300)]
+    reads = sp[:100] + d[:40] + sp[100:200] + d[40:80] + d[80:120] + sp[200:300]
+    cuts = [0, 100, 140, 240, 280, 320, 420]
+    bases, offsets = pack_reads(reads)
+    exp = _expect(ref["ref"], 3000, bases, offsets, 1)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=100, max_batch_bases=int(np.diff(offsets[cuts].astype(np.int64)).max()))
+    passes = []
+    idx, val = _enqueue_stream(S, bases, offsets, cuts, 1, poke=None)
+    np.testing.assert_array_equal(idx, exp["topk_idx"])
+    np.testing.assert_array_equal(val, exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    # the dense batches really were cut: one of them alone, synchronously
+    S1 = api.SumOfSharedHashes(R, top=1, max_batch_reads=100, max_batch_bases=int(np.diff(offsets[cuts].astype(np.int64)).max()))
+    d_b, d_o = api.DeviceBuffer.from_numpy(bases), api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[100:141]))
+    S1.push_device(d_b.ptr, d_o.ptr, 40, int(offsets[140] - offsets[100]), None, None)
+    passes.append(S1.stats()["last_passes"])
+    d_b.free(); d_o.free()
+    assert passes[0] > 1, passes
+
+
+def test_enqueue_block_sketcher_slow_path(gpu):
+    """A production-mode batch with reads whose in-range hashes overflow a wave's slots (the `big` list) is finished by
+    the block sketcher in its back half -- queued behind the NEXT batch's sketch, on that batch's other side."""
+    from sketchy_amd import api, synth
+    ref = synth.make_reference(12, 20000, genome_len=30000, rng_seed=181, device="numpy")
+    bases, offsets = synth.make_reads(ref["genome"], 24, 9000, err=0.02, rng_seed=182, lognormal_sigma=0.8, min_len=300, max_len=29000)
+    assert np.diff(offsets.astype(np.int64)).max() > 18000
+    exp = _expect(ref["ref"], 20000, bases, offsets, 1)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=8, max_batch_bases=int(np.diff(offsets[::8].astype(np.int64)).max()))
+    idx, val = _enqueue_stream(S, bases, offsets, [0, 8, 16, 24], 1)
+    np.testing.assert_array_equal(idx, exp["topk_idx"])
+    np.testing.assert_array_equal(val, exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    assert S.stats()["reads_block_sketcher"] > 0
+
+
+def test_enqueue_errors_surface_one_call_late(gpu):
+    from sketchy_amd import api, _lib
+    ref, bases, offsets = workload(40, 200, 60, rng_seed=75)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=20, max_batch_bases=len(bases))
+    bad = offsets[:21].copy()
+    bad[7], bad[8] = bad[8], bad[7]  # not monotonic
+    d_b = api.DeviceBuffer.from_numpy(bases)
+    d_bad = api.DeviceBuffer.from_numpy(np.ascontiguousarray(bad))
+    d_o1 = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[20:41]))
+    d_o0 = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[:21]))
+    S.enqueue_device(d_b.ptr, d_bad.ptr, 20, int(bad[20]), None, None)   # accepted: nothing has looked at it yet
+    with pytest.raises(_lib.SketchyHipError) as e:
+        S.enqueue_device(d_b.ptr, d_o1.ptr, 20, int(offsets[40] - offsets[20]), None, None)
+    assert e.value.code == _lib.ERR_INVALID and "one call earlier" in str(e.value)
+    assert S.reads == 0 and not S.table().any()     # both batches dropped
+    S.enqueue_device(d_b.ptr, d_bad.ptr, 20, int(bad[20]), None, None)
+    with pytest.raises(_lib.SketchyHipError):
+        S.flush()
+    assert S.reads == 0 and not S.table().any()
+    # the stream is still usable, and gives what it should
+    S.enqueue_device(d_b.ptr, d_o0.ptr, 20, int(offsets[20]), None, None)
+    S.enqueue_device(d_b.ptr, d_o1.ptr, 20, int(offsets[40] - offsets[20]), None, None)
+    exp = _expect(ref["ref"], 200, bases, offsets[:41], 1)
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    assert S.reads == 40
+    for d in (d_b, d_bad, d_o1, d_o0):
+        d.free()
+
+
+@pytest.mark.parametrize("env", [{"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "2"}, {"SKX_PIPELINE": "1"}, {"SKX_PASS_READS": "128"}])
+def test_enqueue_under_other_placements(gpu, env):
+    """the same stream with the pair gather on the scan stream (never speculative), with fewer pipeline streams, and with
+    every batch cut into passes of 128 reads (each enqueue undoes the younger batch's speculation) -- separate
+    processes: the knobs are read once"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, os.path.join(here, "enqueue_check.py")], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "enqueue_check ok" in r.stdout
