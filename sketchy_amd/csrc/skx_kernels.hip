@@ -112,6 +112,61 @@ constexpr u32 kSketchRetry = 0xFFFFFFFFu;
 // list layout: [0] = number of entries, [1..] = read indices
 __device__ __forceinline__ void list_append(u32* __restrict__ list, u32 r) { list[1u + atomicAdd(&list[0], 1u)] = r; }
 
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = (u32)__shfl_up((int)v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+// normalisation table of the wave sketchers (one per block, in LDS): 0..3 = A C G T/U (either case), 4 = any other retained
+// byte, 0x80 = removed (whitespace) -- classify_base() with the "removed" class moved to a flag bit
+__device__ __forceinline__ void fill_base_lut(unsigned char* lut) {
+    const u32 c = classify_base(threadIdx.x & 0xFFu);
+    if (threadIdx.x < 256u) lut[threadIdx.x] = (unsigned char)(c == 5u ? 0x80u : c);
+}
+// normalise raw bytes [from, to) of the read into codes[nb ...]; returns the new end.  Four bytes per lane: one dword
+// load, four table reads, and -- as long as nothing has been removed and the end is word-aligned (the usual case: reads
+// hold no whitespace) -- one word store: ~4 VALU instructions per 64 bases instead of ~22 for the byte-at-a-time
+// classification (measured: the sketch kernel is VALU-bound and a third of its instructions were outside the hash loop).
+// A group of 256 bytes with a removed byte in it, and everything behind it in this call, is compacted byte by byte.
+__device__ __forceinline__ u32 wave_normalise4(const uint8_t* __restrict__ rd, u32 from, u32 to, uint8_t* codes, u32 nb,
+                                               u32 lane, const unsigned char* lut) {
+    bool packed = (nb & 3u) == 0u;  // wave-uniform
+    for (u32 base = from; base < to; base += 256u) {
+        const u32 idx = base + 4u * lane;
+        const u32 have = idx < to ? min(4u, to - idx) : 0u;
+        u32 x = 0x41414141u;  // (absent bytes: a plain base, never written)
+        if (have == 4u) {
+            __builtin_memcpy(&x, rd + idx, 4);
+        } else {
+            for (u32 b = 0; b < have; ++b) x = (x & ~(0xFFu << (8u * b))) | ((u32)rd[idx + b] << (8u * b));
+        }
+        const u32 w = (u32)lut[x & 0xFFu] | ((u32)lut[(x >> 8) & 0xFFu] << 8) | ((u32)lut[(x >> 16) & 0xFFu] << 16) |
+                      ((u32)lut[x >> 24] << 24);
+        if (packed && __ballot((w & 0x80808080u) != 0u) == 0ull) {
+            uint8_t* dst = codes + nb + 4u * lane;
+            if (have == 4u) *reinterpret_cast<u32*>(dst) = w;
+            else for (u32 b = 0; b < have; ++b) dst[b] = (uint8_t)(w >> (8u * b));
+            nb += min(256u, to - base);
+        } else {
+            packed = false;
+            u32 cnt = 0;
+#pragma unroll
+            for (u32 b = 0; b < 4u; ++b) cnt += (b < have && !((w >> (8u * b)) & 0x80u)) ? 1u : 0u;
+            const u32 incl = wave_incl_scan(cnt);
+            u32 pos = nb + incl - cnt;
+#pragma unroll
+            for (u32 b = 0; b < 4u; ++b)
+                if (b < have && !((w >> (8u * b)) & 0x80u)) codes[pos++] = (uint8_t)(w >> (8u * b));
+            nb += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    return nb;
+}
+
 // 64 k-mers' worth of work shared by the wave and block sketchers lives in these two helpers --------------------
 // normalise raw bytes [from, to) of the read into codes[nb ...] (whitespace dropped, everything not ACGTU -> 4); returns
 // the new code count.  One wave.
@@ -135,9 +190,10 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                                                 u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                 u32* __restrict__ out_cnt_in, u32* __restrict__ retry, u32* __restrict__ big,
                                                 const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
-                                                u32* __restrict__ chk) {
+                                                u32* __restrict__ chk, const unsigned char* lut) {
     constexpr u32 CAP = kSketchCap;
-    constexpr u32 kPerWave = HCAP * 8 + CAP + 128;  // (carry of k-1 codes + a chunk + 64 codes of padding behind it)
+    constexpr u32 kPerWave = HCAP * 8 + CAP + 128;  // (32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding)
+    constexpr u32 kChunkAt = 32;                    // a chunk's codes start here; the carried k-1 end here
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     u64* hashes = reinterpret_cast<u64*>(smem + (size_t)wv * kPerWave);
     uint8_t* codes = smem + (size_t)wv * kPerWave + HCAP * 8;
@@ -180,21 +236,23 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         }
     };
 
-    u32 carry = 0;  // codes kept from the previous chunk at codes[0 .. carry)
+    u32 carry = 0;  // codes kept from the previous chunk at codes[kChunkAt - carry .. kChunkAt)
     for (u32 cbase = 0;; cbase += CAP) {
         const u32 cend = min(lraw, cbase + CAP);
         // 1. normalise the chunk behind the carried codes
-        const u32 nb = __builtin_amdgcn_readfirstlane(wave_normalise(rd, cbase, cend, codes, carry, lane, lt));
-        codes[nb + lane] = 4;  // 64 invalid codes behind the chunk: lanes past the last window read them unconditionally
+        const u32 cs = kChunkAt - carry;  // first code of the buffer
+        const u32 ne = __builtin_amdgcn_readfirstlane(wave_normalise4(rd, cbase, cend, codes, kChunkAt, lane, lut));  // one past the last
+        codes[ne + lane] = 4;  // 64 invalid codes behind the chunk: lanes past the last window read them unconditionally
         wave_sync();
         // 2. canonical k-mer hashes of the windows that END in this chunk, compacted
+        const u32 nb = ne - cs;
         const u32 nk = nb >= k ? nb - k + 1u : 0u;
         if constexpr (KT == 16) {
             // Each lane walks a contiguous run of positions with ROLLING windows: the 2-bit forward / reverse-
             // complement codes (for the canonical choice) and their 16 ASCII bytes as two little-endian words each
             // (the murmur3 block) -- one LDS byte read and a few shifts per k-mer instead of rebuilding all 16 bases.
             const u32 run = __builtin_amdgcn_readfirstlane((nk + 63u) / 64u);
-            const u32 p0 = lane * run;
+            const u32 p0 = cs + lane * run;
             u32 fwd = 0, rc = 0;            // 16 bases x 2 bits: forward (first base highest) / reverse complement
             u32 f0 = 0, f1 = 0, f2 = 0, f3 = 0;  // the 16 ASCII bytes of the forward k-mer, first base in the lowest byte
             u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // ... of its reverse complement
@@ -220,7 +278,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
             if (nk) {
                 // (a window that reaches past the chunk takes in padding codes, which reset `clean`: no bounds tests --
                 // positions are clamped into the padded buffer, p0 + t + 15 <= nb + 63 whenever the window can be valid)
-                const u32 lim = nb + 63u;
+                const u32 lim = ne + 63u;
                 for (u32 j = 0; j < 15u; ++j) push((u32)codes[min(p0 + j, lim)]);
                 u32 cnext = codes[min(p0 + 15u, lim)];  // (the next code is requested one iteration ahead of its use)
                 for (u32 t = 0; t < run; ++t) {
@@ -243,7 +301,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
 #pragma unroll
                     for (u32 j = 0; j < 32u; ++j) {
                         if (j < k) {
-                            u32 c = codes[p + j];
+                            u32 c = codes[cs + p + j];
                             bad |= c >> 2;
                             c &= 3u;
                             fwd = (fwd << 2) | c;
@@ -267,19 +325,43 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         if (cend >= lraw) break;
         // 3. the last k-1 codes open the next chunk
         const u32 keep = min(nb, k - 1u);
-        const u32 cv = lane < keep ? (u32)codes[nb - keep + lane] : 0u;
+        const u32 cv = lane < keep ? (u32)codes[ne - keep + lane] : 0u;
         wave_sync();
-        if (lane < keep) codes[lane] = (uint8_t)cv;
+        if (lane < keep) codes[kChunkAt - keep + lane] = (uint8_t)cv;
         carry = keep;
+    }
+    // At most one hash per lane (production: a 1.5 kb read keeps ~8): sort by counting.  Lane l holds hash l; for every j the
+    // wave sees hash j as a scalar, finds the lanes holding the same value (ballot) -- j counts only if it is the first of
+    // them -- and every lane holding something larger moves up one place: ~5 VALU instructions per hash instead of the
+    // ~300 of a 64-element bitonic network through LDS.  Leaves the DISTINCT hashes, ascending, at hashes[0 .. m).
+    if (m <= 64u) {
+        const u64 h = lane < m ? hashes[lane] : kPad;
+        u32 rank = 0;
+        u64 heads = 0;
+        for (u32 j = 0; j < m; ++j) {
+            const u64 hj = make_u64((u32)__builtin_amdgcn_readlane((int)(u32)h, (int)j),
+                                    (u32)__builtin_amdgcn_readlane((int)(u32)(h >> 32), (int)j));
+            const u64 eq = __ballot(h == hj);
+            if ((u32)__builtin_ctzll(eq) == j) {  // (lane j itself is in eq: never zero)
+                heads |= 1ull << j;
+                rank += hj < h ? 1u : 0u;
+            }
+        }
+        wave_sync();
+        if ((heads >> lane) & 1ull) hashes[rank] = h;
+        m = (u32)__popcll(heads);
+        wave_sync();
     }
     // pad to a power of two (>= 64) for the bitonic network
     u32 p2 = 64;
     while (p2 < m) p2 <<= 1;
-    for (u32 i = m + lane; i < p2; i += 64u) hashes[i] = kPad;
-    wave_sync();
+    if (m > 64u) {
+        for (u32 i = m + lane; i < p2; i += 64u) hashes[i] = kPad;
+        wave_sync();
+    }
 
     // bitonic sort ascending
-    if (m > 1) {
+    if (m > 64u) {
         for (u32 size = 2; size <= p2; size <<= 1) {
             for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
                 for (u32 t = lane; t < (p2 >> 1); t += 64u) {
@@ -345,6 +427,9 @@ __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_ke
                                                           const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
                                                           u32* __restrict__ chk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned char lut[256];
+    fill_base_lut(lut);
+    __syncthreads();
     u32 w = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (from_list == 2u) {
         const u32 half = gridDim.x >> 1;
@@ -360,13 +445,13 @@ __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_ke
     if (from_list != 1u) {
         if (w < n_reads)
             sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
-                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk);
+                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut);
         return;
     }
     const u32 n = retry[0];
     for (u32 i = w; i < n; i += gridDim.x * 4u) {
         sketch_one_read<KT, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
-                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk);
+                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
 }
@@ -609,14 +694,6 @@ __global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, u
 // =====================================================================================
 // Two small launches: (a) every block scans its 1024 entries and leaves its total, (b) every block adds the totals of
 // the blocks before it.  (Replaces a library scan: two launches on the push's critical path instead of three.)
-__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 o = (u32)__shfl_up((int)v, d, 64);
-        if ((int)lane_id() >= d) v += o;
-    }
-    return v;
-}
 // (256-thread blocks, four entries per thread: a 1024-thread block needs 16 free wave slots on ONE CU and waits tens of
 // microseconds for them next to the other streams' kernels -- measured; 4-wave blocks slip in)
 __device__ __forceinline__ u32 block256_excl_scan4(const u32 (&c)[4], u32 (&excl)[4], u32* wtot /* [4] shared */) {
