@@ -171,7 +171,8 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
     r->device = device; r->k = k; r->seed = seed; r->s = s; r->n_genomes = (u32)total; r->n_species = n_species;
     r->n_pad = (u32)total_pad;
     r->n_tiles = r->n_pad / skx::kTileGenomes;
-    r->rb = 64;  // rows per band (measured best of 64/128/256/512 on MI355X)
+    static const int rb_env = getenv("SKX_RB") ? atoi(getenv("SKX_RB")) : 0;  // experiment knob
+    r->rb = rb_env >= 8 ? (u32)rb_env : 64;  // rows per band (measured best of 64/128/256/512 on MI355X)
     r->n_bands = (s + r->rb - 1) / r->rb;
     r->min_species = 0xFFFFFFFFu;
     {
@@ -583,7 +584,10 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // (4: the ranking shares the SKETCH stream -- {sketch, ranking} | {dictionary, scan, transpose}: the two VALU-bound stages
     // take turns and only the HBM-bound scan runs beside them)
     if (st->depth == 4) st->hs2 = st->hs0;
-    else if (st->depth >= 2) SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, prio_lo)); else st->hs2 = st->hs;
+    else if (st->depth >= 2) {
+        static const int rank_hi = getenv("SKX_PRIO_RANK") ? atoi(getenv("SKX_PRIO_RANK")) : 0;  // experiment knob
+        SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, rank_hi ? prio_hi : prio_lo));
+    } else st->hs2 = st->hs;
     }
     for (int i = 0; i < 2; ++i) {
         SCHK(hipEventCreateWithFlags(&st->ev_dict[i], hipEventDisableTiming));

@@ -124,8 +124,10 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
 // normalisation table of the wave sketchers (one per block, in LDS): 0..3 = A C G T/U (either case), 4 = any other retained
 // byte, 0x80 = removed (whitespace) -- classify_base() with the "removed" class moved to a flag bit
 __device__ __forceinline__ void fill_base_lut(unsigned char* lut) {
-    const u32 c = classify_base(threadIdx.x & 0xFFu);
-    if (threadIdx.x < 256u) lut[threadIdx.x] = (unsigned char)(c == 5u ? 0x80u : c);
+    for (u32 i = threadIdx.x; i < 256u; i += blockDim.x) {  // (blocks of 64 or 256 threads)
+        const u32 c = classify_base(i);
+        lut[i] = (unsigned char)(c == 5u ? 0x80u : c);
+    }
 }
 // normalise raw bytes [from, to) of the read into codes[nb ...]; returns the new end.  Four bytes per lane: one dword
 // load, four table reads, and -- as long as nothing has been removed and the end is word-aligned (the usual case: reads
@@ -279,7 +281,49 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                 // (a window that reaches past the chunk takes in padding codes, which reset `clean`: no bounds tests --
                 // positions are clamped into the padded buffer, p0 + t + 15 <= nb + 63 whenever the window can be valid)
                 const u32 lim = ne + 63u;
-                for (u32 j = 0; j < 15u; ++j) push((u32)codes[min(p0 + j, lim)]);
+                // Window state after the first 15 codes of the run, straight from the code bytes (15 push() calls cost
+                // ~285 instructions per chunk, this ~85): five aligned words funnel-shifted to the run's start; ASCII
+                // blocks by v_perm_b32 table lookups (4 codes per instruction), the reverse complement through a byte
+                // swap of the selectors; the 2-bit packings and the validity bits by multiplications that gather one
+                // field per byte into the top byte (fields never overlap: no carries).  A run that starts in the padding
+                // is clamped into it (every window it sees is invalid either way).
+                {
+                    const u32 al = min(p0 & ~3u, (ne + 44u) & ~3u);
+                    const u32* cw = reinterpret_cast<const u32*>(codes + al);
+                    const u32 w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3], w4 = cw[4];
+                    const u32 sh = p0 & 3u;  // (clamped lanes: any shift reads padding)
+                    const u32 b0 = __builtin_amdgcn_alignbyte(w1, w0, sh), b1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                    const u32 b2 = __builtin_amdgcn_alignbyte(w3, w2, sh), b3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+                    const u32 x0 = b0 & 0x03030303u, x1 = b1 & 0x03030303u, x2 = b2 & 0x03030303u, x3 = b3 & 0x03030303u;
+                    // forward: bytes 1..15 = "ACGT"[c_0 .. c_14]
+                    const u32 a0 = __builtin_amdgcn_perm(0u, 0x54474341u, x0), a1 = __builtin_amdgcn_perm(0u, 0x54474341u, x1);
+                    const u32 a2 = __builtin_amdgcn_perm(0u, 0x54474341u, x2), a3 = __builtin_amdgcn_perm(0u, 0x54474341u, x3);
+                    f0 = a0 << 8;
+                    f1 = __builtin_amdgcn_alignbit(a1, a0, 24);
+                    f2 = __builtin_amdgcn_alignbit(a2, a1, 24);
+                    f3 = __builtin_amdgcn_alignbit(a3, a2, 24);
+                    // reverse complement: byte 14 - j = "TGCA"[c_j]
+                    const u32 m0 = __builtin_amdgcn_perm(0u, 0x41434754u, __builtin_amdgcn_perm(x0, x0, 0x00010203u));
+                    const u32 m1 = __builtin_amdgcn_perm(0u, 0x41434754u, __builtin_amdgcn_perm(x1, x1, 0x00010203u));
+                    const u32 m2 = __builtin_amdgcn_perm(0u, 0x41434754u, __builtin_amdgcn_perm(x2, x2, 0x00010203u));
+                    const u32 m3 = __builtin_amdgcn_perm(0u, 0x41434754u, __builtin_amdgcn_perm(x3, x3, 0x00010203u));
+                    r0 = __builtin_amdgcn_alignbit(m2, m3, 8);
+                    r1 = __builtin_amdgcn_alignbit(m1, m2, 8);
+                    r2 = __builtin_amdgcn_alignbit(m0, m1, 8);
+                    r3 = m0 >> 8;
+                    // 2-bit packings: fwd = sum c_j << 2 (14 - j), rc = sum (3 - c_j) << (2 + 2 j), j = 0..14
+                    constexpr u32 kF = 0x40100401u, kR = 0x01041040u;
+                    const u32 fw16 = (((x0 * kF) >> 24) << 24) | (((x1 * kF) >> 24) << 16) | (((x2 * kF) >> 24) << 8) | ((x3 * kF) >> 24);
+                    fwd = fw16 >> 2;
+                    const u32 rc16 = (((x0 ^ 0x03030303u) * kR) >> 24) | ((((x1 ^ 0x03030303u) * kR) >> 24) << 8) |
+                                     ((((x2 ^ 0x03030303u) * kR) >> 24) << 16) | ((((x3 ^ 0x03030303u) * kR) >> 24) << 24);
+                    rc = rc16 << 2;
+                    // clean = valid codes in a row ending at c_14 (an invalid code has bit 2 set)
+                    constexpr u32 kV = 0x04081020u;
+                    const u32 inv = (((b0 & 0x04040404u) * kV) >> 28) | ((((b1 & 0x04040404u) * kV) >> 28) << 4) |
+                                    ((((b2 & 0x04040404u) * kV) >> 28) << 8) | ((((b3 & 0x04040404u) * kV) >> 28) << 12);
+                    clean = (u32)__builtin_clz(((inv & 0x7FFFu) << 17) | 0x10000u);
+                }
                 u32 cnext = codes[min(p0 + 15u, lim)];  // (the next code is requested one iteration ahead of its use)
                 for (u32 t = 0; t < run; ++t) {
                     const u32 ccur = cnext;
@@ -430,7 +474,8 @@ __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_ke
     __shared__ unsigned char lut[256];
     fill_base_lut(lut);
     __syncthreads();
-    u32 w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const u32 wpb = blockDim.x >> 6;  // waves per block: 4, or 1 for the list walk (see launch_sketch)
+    u32 w = blockIdx.x * wpb + (threadIdx.x >> 6);
     if (from_list == 2u) {
         const u32 half = gridDim.x >> 1;
         const bool long_phase = blockIdx.x < half;
@@ -449,7 +494,7 @@ __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_ke
         return;
     }
     const u32 n = retry[0];
-    for (u32 i = w; i < n; i += gridDim.x * 4u) {
+    for (u32 i = w; i < n; i += gridDim.x * wpb) {
         sketch_one_read<KT, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
                                            out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut);
         wave_sync();  // the wave's LDS region is reused by its next read
@@ -1084,7 +1129,9 @@ constexpr u32 kLeanCap = 254;
 constexpr u32 kLeanBuckets = 2048;
 constexpr u32 kLeanWords = 5;  // query words a slice of <= kLeanCap entries can touch
 
-template <int ABLATE, bool NT = false>
+// NT: bit 0 = non-temporal slab stores, bit 1 = non-temporal loads of the matrix (it is streamed once per pass: marking its
+// lines evict-first keeps them from flushing what the kernels running beside the scan gather from -- Mq, the pair lists)
+template <int ABLATE, int NT = 0>
 __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                         const u64* __restrict__ q, const u32* __restrict__ win,
                                                         u64* __restrict__ m_bits, u32 n_pad, u64* __restrict__ hbuf,
@@ -1184,11 +1231,12 @@ __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ 
         if (rows >= 8u) {
             u64 h[8];
 #pragma unroll
-            for (u32 u = 0; u < 8u; ++u) h[u] = col[(size_t)u * kTileGenomes];
+            for (u32 u = 0; u < 8u; ++u) h[u] = (NT & 2) ? __builtin_nontemporal_load(&col[(size_t)u * kTileGenomes]) : col[(size_t)u * kTileGenomes];
             for (i = 8u; i + 8u <= rows; i += 8u) {
                 u64 hn[8];
 #pragma unroll
-                for (u32 u = 0; u < 8u; ++u) hn[u] = col[(size_t)(i + u) * kTileGenomes];
+                for (u32 u = 0; u < 8u; ++u)
+                    hn[u] = (NT & 2) ? __builtin_nontemporal_load(&col[(size_t)(i + u) * kTileGenomes]) : col[(size_t)(i + u) * kTileGenomes];
                 if (lean) {
 #pragma unroll
                     for (u32 u = 0; u < 8u; ++u) probe_lean(h[u]);
@@ -1220,7 +1268,7 @@ __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ 
         // this block's slab: [kLeanWords][256] words, the first n_w of them are read by the transpose
         u64* out = hbuf + (size_t)bt * kLeanWords * kTileGenomes + c;
         for (u32 k = 0; k < n_w; ++k) {
-            if (NT) __builtin_nontemporal_store(acc[k][c], &out[(size_t)k * kTileGenomes]);
+            if (NT & 1) __builtin_nontemporal_store(acc[k][c], &out[(size_t)k * kTileGenomes]);
             else out[(size_t)k * kTileGenomes] = acc[k][c];
         }
     }
@@ -2240,10 +2288,14 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
             if (dev >= 0 && dev < 256) done[dev >> 6] |= 1ull << (dev & 63);
         }
     }
-    const dim3 list_grid(std::min<u32>(cdiv(n_reads, 4), 256u)), blk_grid(std::min<u32>(n_reads, 256u));
+    const dim3 list_grid(std::min<u32>(n_reads, 1024u)), blk_grid(std::min<u32>(n_reads, 256u));
     const dim3 grid2(2u * cdiv(n_reads, 4));  // two-phase (long reads first); needs chk[1] from batch_check_kernel
+    // (the list walk -- usually over an empty list -- goes out as ONE-wave blocks with a quarter of the LDS, 18.6 KB: a
+    // 74 KB block would wait for a CU the scan's blocks have left, i.e. for the end of the scan running beside it:
+    // 140-180 us on the sketch stream, measured)
 #define SKX_SK_LAUNCH(KERNEL, LDS, FROM_LIST)                                                                              \
-    hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid, dim3(256), LDS, st, bases, \
+    hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid,                        \
+                       dim3((FROM_LIST) == 1u ? 64 : 256), (FROM_LIST) == 1u ? (LDS) / 4 : (LDS), st, bases,                \
                        offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, FROM_LIST, retry, big,   \
                        filt, filt_shift, n_bases, chk)
     (void)blk_grid;
@@ -2342,8 +2394,10 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
             case 2: SKX_SCAN_L(2); break;
             case 3: SKX_SCAN_L(3); break;
             default: {
-                static const int nt = env_int("SKX_SCAN_NT", 0);  // experiment: non-temporal slab stores
-                if (nt) hipLaunchKernelGGL((scan_lean_kernel<0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+                static const int nt = env_int("SKX_SCAN_NT", 0);  // experiment: 1 = non-temporal slab stores, 2 = matrix loads, 3 = both
+                if (nt == 1) hipLaunchKernelGGL((scan_lean_kernel<0, 1>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+                else if (nt == 2) hipLaunchKernelGGL((scan_lean_kernel<0, 2>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+                else if (nt == 3) hipLaunchKernelGGL((scan_lean_kernel<0, 3>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
                 else SKX_SCAN_L(0);
                 break;
             }
