@@ -1127,6 +1127,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
 // *m_dirty so that the transpose also reads M.
 constexpr u32 kLeanCap = 254;
 constexpr u32 kLeanBuckets = 2048;
+constexpr u32 kLeanBucketsMax = 4096;  // directory of a slice with more than kLeanBigFrom entries
+constexpr u32 kLeanBigFrom = 96;
 constexpr u32 kLeanWords = 5;  // query words a slice of <= kLeanCap entries can touch
 
 // NT: bit 0 = non-temporal slab stores, bit 1 = non-temporal loads of the matrix (it is streamed once per pass: marking its
@@ -1140,7 +1142,7 @@ __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ 
     // queue behind theirs: its loads are what keeps HBM busy
     if (prio) __builtin_amdgcn_s_setprio(3);
     __shared__ u64 slice[kLeanCap + 2];
-    __shared__ unsigned char dir[kLeanBuckets + 8];
+    __shared__ unsigned char dir[kLeanBucketsMax + 8];
     __shared__ u64 acc[kLeanWords][kTileGenomes];
     __shared__ u32 deep;  // some bucket holds more than two entries (or the slice spans < 2^43): walk probe
     const u32 bt = blockIdx.x;
@@ -1161,15 +1163,19 @@ __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ 
     for (u32 sub = qa; sub < qb; sub += kLeanCap) {
         const u32 n = min(kLeanCap, qb - sub);
         const u64 lo = q[sub], hi = q[sub + n - 1];
-        // bucket(h) = (h - lo) >> shift, with (hi - lo) >> shift < kLeanBuckets
+        // bucket(h) = (h - lo) >> shift, with (hi - lo) >> shift < n_bk; longer slices get the larger directory (the chance
+        // of three entries in one bucket grows with n^3 / n_bk^2: 1 % at n = 64 / 2048 buckets, 13 % at n = 150, and a
+        // block that fails the test pays the walk probe for its whole band)
+        const u32 bk_bits = n > kLeanBigFrom ? (u32)__builtin_ctz(kLeanBucketsMax) : (u32)__builtin_ctz(kLeanBuckets);
+        const u32 n_bk = 1u << bk_bits;
         const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
-        const u32 shift = span_bits > (u32)__builtin_ctz(kLeanBuckets) ? span_bits - (u32)__builtin_ctz(kLeanBuckets) : 0u;
+        const u32 shift = span_bits > bk_bits ? span_bits - bk_bits : 0u;
         if (c < n) slice[c] = q[sub + c];
         if (c == 0) { slice[n] = kEmpty; slice[n + 1] = kEmpty; deep = shift < 32u ? 1u : 0u; }
         __syncthreads();
         if (c <= n) {
             // entry c opens every bucket in (bucket(c-1), bucket(c)]; the sentinel closes the rest
-            const u32 bj = c < n ? (u32)((slice[c] - lo) >> shift) : kLeanBuckets;
+            const u32 bj = c < n ? (u32)((slice[c] - lo) >> shift) : n_bk;
             const u32 bp = c == 0 ? 0xFFFFFFFFu : (u32)((slice[c - 1] - lo) >> shift);
             for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned char)c;
             if (c >= 2u && c < n && (u32)((slice[c - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
@@ -1200,7 +1206,7 @@ __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ 
             if (ABLATE == 2) { cur_bits ^= hv; return; }
             // high word of (hv - lo), from the halves
             const u32 dh = (u32)(hv >> 32) - lo_hi - ((u32)hv < lo_lo ? 1u : 0u);
-            const u32 bk = min(dh >> sh_hi, kLeanBuckets);
+            const u32 bk = min(dh >> sh_hi, n_bk);
             const u32 j = dir[bk];
             const u64 e0 = slice[j], e1 = slice[j + 1u];
             if (ABLATE == 3) { cur_bits ^= e0 ^ e1; return; }

@@ -573,3 +573,52 @@ def test_randomized_families_leader_switching(gpu):
         bases, offsets = pack_reads(reads)
         for top in (1, int(rng.choice([2, 5]))):
             check(hashes, bases, offsets, top=top, batches=int(rng.integers(1, 4)), want_shared=False, want_sketches=False)
+
+
+def test_sketch_normalisation_stress(gpu):
+    """The wave sketcher classifies four bytes per lane through an LDS table and stores whole words while nothing has
+    been removed; a removed byte (whitespace) switches the rest of the chunk to byte-wise compaction, and the window
+    state of every lane's run is rebuilt from the code bytes.  Random reads of every small length (partial words at the
+    end, runs starting at every alignment), whitespace / N / lower case / U / IUPAC at random places, lengths straddling
+    the 256-byte groups and the 2048-byte chunks, whitespace right at a chunk border -- sketches (full, k = 16 and the
+    generic k path) and production rows against the oracle."""
+    from sketchy_amd import api
+    rng = np.random.default_rng(2025)
+    ref, _, _ = workload(24, 300, 1, read_len=300, genome_len=60000, rng_seed=401)
+    g = ref["genome"].tobytes()
+    reads = []
+    for n in list(range(0, 70)) + [255, 256, 257, 258, 259, 511, 512, 513, 1023, 1025, 2047, 2048, 2049, 2062, 2063]:
+        a = int(rng.integers(0, len(g) - n - 1))
+        reads.append(bytearray(g[a:a + n]))
+    for n in (300, 700, 2100, 4096 + 15, 4097, 6000, 9000):
+        for _ in range(3):
+            a = int(rng.integers(0, len(g) - n - 1))
+            reads.append(bytearray(g[a:a + n]))
+    dirt = [b"\n", b" ", b"\t", b"\r", b"N", b"n", b"R", b"-", b"u", b"U", b"a", b"c", b"g", b"t"]
+    out = []
+    for i, r in enumerate(reads):
+        r = bytes(r)
+        if i % 3 and len(r):
+            pieces, pos = [], 0
+            for cut in sorted(set(int(x) for x in rng.integers(0, len(r) + 1, size=int(rng.integers(1, 6))))):
+                pieces.append(r[pos:cut])
+                pieces.append(dirt[int(rng.integers(0, len(dirt)))] * int(rng.integers(1, 4)))
+                pos = cut
+            pieces.append(r[pos:])
+            r = b"".join(pieces)
+        out.append(r)
+    # whitespace exactly around the 2048-byte chunk border and the 256-byte group borders of a long read
+    base = g[100:100 + 5000]
+    out.append(base[:2047] + b"\n" + base[2047:])
+    out.append(base[:2048] + b"\n" + base[2048:])
+    out.append(base[:255] + b" " + base[255:256] + b"\t" + base[256:4000])
+    out.append(b"\n" * 300 + base[:600] + b"\n" * 2100 + base[600:900])
+    bases, offsets = pack_reads(out)
+    for k, seed in ((16, 0), (16, 42), (21, 0), (11, 7)):
+        sk, sl = api.sketch_reads(bases, offsets, k=k, seed=seed, s=200)
+        for r in range(len(out)):
+            e = orc.sketch(out[r], k, seed, 200)
+            assert sl[r] == len(e), (k, seed, r, len(out[r]))
+            np.testing.assert_array_equal(sk[r, :len(e)], e, err_msg=f"k={k} seed={seed} read {r}")
+    check(ref, bases, offsets, top=2)                                              # debug outputs: full sketches
+    check(ref, bases, offsets, top=1, want_sketches=False, want_shared=False)      # production (in-range) sketch path
