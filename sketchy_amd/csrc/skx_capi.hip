@@ -331,8 +331,8 @@ struct PendingBatch {
     u32* d_topk_idx = nullptr;
     u64* d_topk_sum = nullptr;
     u32 seq = 0;               // sequence number its summary is published under
-    bool spec_insert = false;  // its pairs were gathered into buffer set spec_set right behind the sketcher
-    int spec_set = 0;
+    bool spec_insert = false;  // its pairs were gathered into buffer set spec_set / pair slot spec_slot right behind the sketcher
+    int spec_set = 0, spec_slot = 0;
     bool inrange_only = true;
     u32 dbg_cap = 0xFFFFFFFFu;
     u32* h_shared = nullptr;   // host outputs of the synchronous parity / debug path
@@ -362,6 +362,15 @@ struct skx_stream {
     PendingBatch pend;                             // skx_stream_enqueue_device: the batch whose back half is still to come
     bool front_pending[2] = {false, false};
     bool back_pending[2] = {false, false};
+    // The per-pass pair lists the ranking reads (read of every pair, the pass's pair offsets) rotate over THREE slots, and a
+    // pass only waits for the ranking two passes back right before it overwrites what that ranking reads (pair -> query
+    // index, Mq, group flags: after its scan).  So the gather / dictionary / scan of batch i + 1 never wait for the
+    // ranking of batch i - 1, which is the longest chain of a step.
+    hipEvent_t ev_pslot[3] = {nullptr, nullptr, nullptr};   // back stream: the pass using the slot has been ranked
+    bool pslot_pending[3] = {false, false, false};
+    int pslot = 0;                                          // slot of the next pass
+    hipEvent_t ev_pairq[2] = {nullptr, nullptr};            // scan stream: the set's hash set / pair hashes have been consumed
+    bool pairq_pending[2] = {false, false};
     u32 top_k = 0, max_reads = 0, sk_stride = 0;
     u64 max_bases = 0;
     u32 pcap = 0;        // pairs per pass
@@ -380,7 +389,7 @@ struct skx_stream {
     // pass workspace (per buffer set: pair hashes, hash set and its counters, Q, windows, pair lists, Mq)
     u64 *d_pair_h[2] = {nullptr, nullptr}, *d_q[2] = {nullptr, nullptr};
     u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
-    u32 *d_pair_r[2] = {nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[2] = {nullptr, nullptr};
+    u32 *d_pair_r[3] = {nullptr, nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[3] = {nullptr, nullptr, nullptr};
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
     u32* d_inc = nullptr;
     u32* d_csum = nullptr;
@@ -458,7 +467,7 @@ static void stream_free(skx_stream* st) {
     void* ptrs[] = {st->d_bases, st->d_offsets, st->sd_sk[0], st->sd_len[0], st->sd_cnt[0], st->sd_poff[0], st->sd_big[0],
                     st->sd_sk[1], st->sd_len[1], st->sd_cnt[1], st->sd_poff[1], st->sd_big[1], st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
-                    st->d_poff_pass[0], st->d_poff_pass[1], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
+                    st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
                     st->d_csum, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowmask[0], st->d_rowmask[1]};
@@ -482,11 +491,14 @@ static void stream_free(skx_stream* st) {
     for (auto ev : st->ev_pool) (void)hipEventDestroy(ev);
     for (int i = 0; i < 2; ++i) {
         if (st->ev_dict[i]) (void)hipEventDestroy(st->ev_dict[i]);
+        if (st->ev_pairq[i]) (void)hipEventDestroy(st->ev_pairq[i]);
         if (st->ev_front[i]) (void)hipEventDestroy(st->ev_front[i]);
         if (st->ev_back[i]) (void)hipEventDestroy(st->ev_back[i]);
         if (st->ev_sketch[i]) (void)hipEventDestroy(st->ev_sketch[i]);
         if (st->ev_skread[i]) (void)hipEventDestroy(st->ev_skread[i]);
     }
+    for (auto ev : st->ev_pslot)
+        if (ev) (void)hipEventDestroy(ev);
     if (st->hs2 && st->hs2 != st->hs && st->hs2 != st->hs0) (void)hipStreamDestroy(st->hs2);
     if (st->hs0 && st->hs0 != st->hs) (void)hipStreamDestroy(st->hs0);
     if (st->hs) (void)hipStreamDestroy(st->hs);
@@ -591,6 +603,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     }
     for (int i = 0; i < 2; ++i) {
         SCHK(hipEventCreateWithFlags(&st->ev_dict[i], hipEventDisableTiming));
+        SCHK(hipEventCreateWithFlags(&st->ev_pairq[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_back[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_sketch[i], hipEventDisableTiming));
@@ -601,10 +614,11 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(alloc_side(st, 0));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_pair_h[i], (size_t)st->pcap * 8));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_q[i], (size_t)st->pcap * 8));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_pair_q[i], (size_t)st->pcap * 4));
+    for (int i = 0; i < 3; ++i) {
         SCHK(hipMalloc(&st->d_pair_r[i], (size_t)st->pcap * 4));
-        SCHK(hipMalloc(&st->d_pair_q[i], (size_t)st->pcap * 4));
         SCHK(hipMalloc(&st->d_poff_pass[i], ((size_t)st->rpass + 2) * 4));
+        SCHK(hipEventCreateWithFlags(&st->ev_pslot[i], hipEventDisableTiming));
     }
     for (int i = 0; i < 2; ++i) {
         SCHK(hipMalloc(&st->d_nq[i], 64));
@@ -753,7 +767,9 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     const u32 nq_rows = ((P + 63) / 64) * 64;  // rows per group of the group-major bit matrix of this pass
     const int b = st->buf;                      // buffer set handed from stage to stage for this pass
     st->buf ^= 1;
-    u32 *d_pair_r = st->d_pair_r[b], *d_pair_q = st->d_pair_q[b], *d_poff = st->d_poff_pass[b];
+    const int slot = st->pslot;                 // ... and its slot of the pair lists
+    st->pslot = (st->pslot + 1) % 3;
+    u32 *d_pair_r = st->d_pair_r[slot], *d_pair_q = st->d_pair_q[b], *d_poff = st->d_poff_pass[slot];
     u32 *d_nq = st->d_nq[b], *d_win = st->d_win[b];
     u64 *d_mq = st->d_mq[b], *d_q = st->d_q[b];
     u32* d_grp_any = st->d_grp_any[b];
@@ -767,15 +783,19 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         }
     u64 nq_est = std::max<u64>(1, (u64)(P * st->nq_per_pair));
 
-    // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already): set b was last used
-    // two passes ago -- by that pass's scan (Q, windows) and ranking (pair lists, offsets, Mq)
+    // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already).  Set b was last used two
+    // passes ago: by that pass's dictionary / scan / transpose on THIS stream (Q, windows, hash set: ordered by the stream)
+    // and by its ranking on the back stream (pair -> query index, Mq, group flags) -- the wait for that ranking sits
+    // further down, right before those are overwritten.
     (void)hs0;
     HIPCHK(hipStreamWaitEvent(hs, st->ev_sketch[st->side], 0));  // this batch's sketches and pair offsets
-    if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_front[b], 0)); st->front_pending[b] = false; }
-    if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
+    st->front_pending[b] = false;  // (this stream recorded it)
     // (inserted: the sketch stream also copied the pass's pair offsets -- this stream then never touches the sketch buffers,
     // which the next batch's sketch is free to overwrite)
-    if (!inserted) HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
+    if (!inserted) {
+        if (st->pslot_pending[slot]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pslot[slot], 0)); st->pslot_pending[slot] = false; }
+        HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
+    }
     if (P > 0) {
         Span sp(st, 1, hs);
         if (!inserted)
@@ -783,7 +803,6 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
                                     st->ht_slots, st->d_dict_ctr[b], st->pcap);
         skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
                               st->d_dict_ctr[b], d_q, d_nq);
-        skx::launch_pair_q(hs, st->d_pair_h[b], P, d_q, d_nq, d_pair_q);
         skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);  // (also hands |Q| to the host)
         if (st->d_hbuf) skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b]);
         st->hint_pairs[b] = P;
@@ -807,7 +826,19 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     // ---- scan + transpose (same stream, HBM-bound)
     const u32 n_grp_all = n_pad / (skx::kRankWords * 64);
     u32* d_mdirty = d_grp_any + n_grp_all;
-    HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)(n_grp_all + 1) * 4, hs));  // raised by the transpose / by writers of M
+    HIPCHK(hipMemsetAsync(d_mdirty, 0, 4, hs));  // raised by writers of M (read by the transpose, this stream)
+    // the ranking two passes back reads this set's pair -> query index, Mq and group flags: from here on they are rewritten
+    auto wait_back = [&]() -> int {
+        if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
+        HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)n_grp_all * 4, hs));  // raised by the transpose
+        if (P > 0) {
+            skx::launch_pair_q(hs, st->d_pair_h[b], P, d_q, d_nq, d_pair_q);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(st->ev_pairq[b], hs));  // the set's hash set and pair hashes may be refilled
+        st->pairq_pending[b] = true;
+        return SKX_OK;
+    };
     if (P > 0) {
         const u32 n_words = (P + 63) / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
@@ -839,12 +870,14 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
             // (after the scan: its persistent form writes complete words with plain stores, these OR single bits in)
             skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad, d_mdirty);
         }
+        SKXCHK(wait_back());
         {
             Span sp(st, 3, hs);
             skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq, d_grp_any,
                                        lean ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, st->d_rowmask[b]);
         }
     }
+    if (P == 0) SKXCHK(wait_back());
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->ev_front[b], hs));
     st->front_pending[b] = true;
@@ -889,6 +922,8 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->ev_back[b], hs2));
     st->back_pending[b] = true;
+    HIPCHK(hipEventRecord(st->ev_pslot[slot], hs2));
+    st->pslot_pending[slot] = true;
     return SKX_OK;
 }
 
@@ -947,12 +982,14 @@ static int finish_counts(skx_stream* st, PendingBatch& pb) {
     // stream is free for the next batch's sketch (the kernel does nothing if the pairs do not fit one pass: the host
     // finds out after the wait and cuts the batch into passes)
     if (pb.spec_insert) {
-        const int b = pb.spec_set;
-        if (st->front_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_front[b], 0)); st->front_pending[b] = false; }
-        if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
-        skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h[b], st->d_pair_r[b],
+        const int b = pb.spec_set, slot = pb.spec_slot;
+        // the set's hash set / pair hashes were last read by the dictionary of the pass two back (scan stream), the slot's
+        // pair lists by the ranking three passes back
+        if (st->pairq_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pairq[b], 0)); st->pairq_pending[b] = false; }
+        if (st->pslot_pending[slot]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pslot[slot], 0)); st->pslot_pending[slot] = false; }
+        skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h[b], st->d_pair_r[slot],
                                 st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap);
-        HIPCHK(hipMemcpyAsync(st->d_poff_pass[b], st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
+        HIPCHK(hipMemcpyAsync(st->d_poff_pass[slot], st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
     }
     pb.seq = ++st->pub_seq;
     skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, pb.seq);
@@ -979,6 +1016,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     static const bool spec_env = !getenv("SKX_SPEC_INSERT") || atoi(getenv("SKX_SPEC_INSERT")) != 0;  // test knob
     pb.spec_insert = spec_env && n_reads <= std::min(st->rpass, pb.dbg_cap);  // one pass unless the pairs turn out too many
     pb.spec_set = st->buf ^ (st->pend.valid ? 1 : 0);
+    pb.spec_slot = (st->pslot + (st->pend.valid ? 1 : 0)) % 3;
     if (st->chk_dirty) {  // an earlier batch failed half-way through this function
         HIPCHK(hipMemsetAsync(st->d_chk, 0, 64, hs));
         HIPCHK(hipMemsetAsync(st->d_retry, 0, 4, hs));
@@ -1076,7 +1114,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap;
     bool inserted = pb.spec_insert && single;  // the gather queued by the front half did its work
     if (!single && younger) SKXCHK(cancel_speculation(st, *younger));
-    if (inserted && st->buf != pb.spec_set) return fail(SKX_ERR_HIP, "internal: buffer sets out of step");
+    if (inserted && (st->buf != pb.spec_set || st->pslot != pb.spec_slot)) return fail(SKX_ERR_HIP, "internal: buffer sets out of step");
     u32* d_shared = nullptr;
     auto one_pass = [&](u32 ra, u32 rb, u32 p_base, u32 P) -> int {
         if (pb.h_shared) {

@@ -707,6 +707,7 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
 // chk[2..3] = offsets[0], chk[4..5] = offsets[n_reads]               (chk zeroed by the caller)
 __global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads, u64 lim, u32* __restrict__ chk,
                                    u32* __restrict__ cnt_tail) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
         const u64 o0 = offsets[r], o1 = offsets[r + 1];
         if (o1 < o0) atomicMax(&chk[0], 0xFFFFFFFFu - r);
@@ -724,6 +725,7 @@ __global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads,
 // counters (chk, the retry list) for the next push.
 __global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, u32* __restrict__ big,
                                const u32* __restrict__ total_pairs, volatile u32* __restrict__ h_pub, u32 seq) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (big) { chk[7] = big[0]; big[0] = 0; }  // (reads that needed the block sketcher: a statistic for the host)
     for (int i = 0; i < 8; ++i) { h_pub[i] = chk[i]; chk[i] = 0; }
@@ -757,6 +759,7 @@ __device__ __forceinline__ u32 block256_excl_scan4(const u32 (&c)[4], u32 (&excl
 }
 __global__ __launch_bounds__(256) void count_scan_a_kernel(const u32* __restrict__ in, u32* __restrict__ out, u32 n,
                                                            u32* __restrict__ bsum) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u32 wtot[4];
     const u32 i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
     u32 c[4], e[4];
@@ -769,6 +772,7 @@ __global__ __launch_bounds__(256) void count_scan_a_kernel(const u32* __restrict
     if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
 __global__ __launch_bounds__(256) void count_scan_b_kernel(u32* __restrict__ out, u32 n, const u32* __restrict__ bsum) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u32 part[4];
     __shared__ u32 s_before;
     const u32 lane = lane_id(), wv = threadIdx.x >> 6;
@@ -852,6 +856,7 @@ __device__ __forceinline__ u32 dict_bucket(u64 key, u32 bshift) { return (u32)mi
 __global__ void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, const u32* __restrict__ poff, u32 r_begin,
                                    u32 r_end, u32 p_base, u64* __restrict__ pair_h, u32* __restrict__ pair_r,
                                    u64* __restrict__ ht, u32 ht_mask, u32* __restrict__ ctr, u32 pair_cap) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();  // one wave per read
     const u32 r = r_begin + wave;
     if (r >= r_end) return;
@@ -873,6 +878,7 @@ __global__ void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, co
 // used slots: count per bucket; the slot remembers its place inside the bucket (atomics spread over 2^17 addresses)
 __global__ __launch_bounds__(256) void dict_count_kernel(const u64* __restrict__ ht, u32 ht_slots, u32 bshift,
                                                          u32* __restrict__ slot_off, u32* __restrict__ bcount) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     for (u32 slot = blockIdx.x * 256u + threadIdx.x; slot < ht_slots; slot += gridDim.x * 256u) {
         const u64 key = ht[slot];
         if (key != kPad) slot_off[slot] = atomicAdd(&bcount[dict_bucket(key, bshift)], 1u);
@@ -881,6 +887,7 @@ __global__ __launch_bounds__(256) void dict_count_kernel(const u64* __restrict__
 // exclusive scan of the bucket counts, two levels: (a) inside every block of 1024 buckets, (b) over the block totals
 __global__ __launch_bounds__(256) void dict_scan_a_kernel(u32* __restrict__ bcount, u32* __restrict__ bbase,
                                                           u32* __restrict__ btot) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u32 wtot[4];
     const u32 b0 = blockIdx.x * 1024u + threadIdx.x * 4u;
     u32 c[4], e[4];
@@ -893,6 +900,7 @@ __global__ __launch_bounds__(256) void dict_scan_a_kernel(u32* __restrict__ bcou
 }
 __global__ __launch_bounds__(128) void dict_scan_b_kernel(u32* __restrict__ btot, const u32* __restrict__ ctr,
                                                           u32* __restrict__ n_q) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     static_assert(kDictBuckets / 1024u == 128u, "one thread per block of buckets");
     __shared__ u32 part[128];
     const u32 t = threadIdx.x;
@@ -913,6 +921,7 @@ __global__ __launch_bounds__(256) void dict_scatter_kernel(u64* __restrict__ ht,
                                                            const u32* __restrict__ slot_off, const u32* __restrict__ bbase,
                                                            const u32* __restrict__ btot, const u32* __restrict__ ctr,
                                                            u64* __restrict__ q) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     if (blockIdx.x == 0 && threadIdx.x == 0 && (ctr[1] & 1u)) q[btot[128]] = kPad;  // the largest possible hash goes last
     for (u32 slot = blockIdx.x * 256u + threadIdx.x; slot < ht_slots; slot += gridDim.x * 256u) {
         const u64 key = ht[slot];
@@ -925,6 +934,7 @@ __global__ __launch_bounds__(256) void dict_scatter_kernel(u64* __restrict__ ht,
 }
 __global__ void dict_bucket_sort_kernel(u64* __restrict__ q, const u32* __restrict__ bbase, const u32* __restrict__ btot,
                                         u32* __restrict__ ctr) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= kDictBuckets) return;
     const u32 a = btot[b >> 10] + bbase[b];
@@ -957,6 +967,7 @@ __device__ __forceinline__ u32 upper_bound_u64(const u64* __restrict__ a, u32 n,
 
 __global__ void pair_q_kernel(const u64* __restrict__ pair_h, u32 n_pairs, const u64* __restrict__ q,
                               const u32* __restrict__ n_q, u32* __restrict__ pair_q) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n_pairs) pair_q[p] = lower_bound_u64(q, *n_q, pair_h[p]);
 }
@@ -965,6 +976,7 @@ __global__ void pair_q_kernel(const u64* __restrict__ pair_h, u32 n_pairs, const
 __global__ void window_kernel(const u64* __restrict__ lo, const u64* __restrict__ hi, u32 n_bt,
                               const u64* __restrict__ q, const u32* __restrict__ n_q, u32* __restrict__ win,
                               volatile u32* __restrict__ h_nq) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 bt = blockIdx.x * blockDim.x + threadIdx.x;
     if (bt == 0 && h_nq) { *h_nq = *n_q; __threadfence_system(); }  // |Q| for the host (page-locked memory), a hint only
     if (bt >= n_bt) return;
@@ -1289,6 +1301,7 @@ constexpr u32 kWordBandsMax = 2048;  // bands per tile the LDS tables hold (s <=
 constexpr u32 kWbNone = 0xFFFFFFFFu, kWbRange = 0xFFFFFFFEu;
 __global__ __launch_bounds__(256) void word_bands_kernel(const u32* __restrict__ win, u32 n_tiles, u32 n_bands,
                                                          const u32* __restrict__ n_q, u32* __restrict__ wb) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u32 first_w[kWordBandsMax], pmax_w[kWordBandsMax];
     __shared__ u32 wtot[4];
     const u32 t = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
@@ -1409,6 +1422,7 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
                                                              const u32* __restrict__ win, u32 n_tiles,
                                                              const u32* __restrict__ m_dirty,
                                                              unsigned char* __restrict__ rowmask) {
+    __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u64 tile[2][64][kRankWords + 1];
     // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
     // index Q, so rows of Mq beyond nq are never read
@@ -1531,6 +1545,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                       u32 nq_rows, u32* __restrict__ inc, const u32* __restrict__ grp_any,
                                                       const u64* __restrict__ rowmask) {
+    __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     static_assert(kRankWords == 8, "lane = (sub, word) layout assumes 8 words per rank group");
     const u32 lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + kRankWords - 1) / kRankWords;
@@ -1657,6 +1672,7 @@ __global__ __launch_bounds__(256) void chunk_gmax_kernel(const u64* __restrict__
 // grids: (n_pad/256, n_chunks), (n_pad/256), (n_pad/256, n_chunks)
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad,
                                                         u32* __restrict__ csum, const u32* __restrict__ grp_any) {
+    __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
     if (!grp_any[blockIdx.x >> 1]) { csum[(size_t)c * n_pad + g] = 0; return; }  // (its increments were never written)
@@ -1666,23 +1682,55 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const u32* __restrict__ 
     for (u32 sgi = s0; sgi < s1; ++sgi) t += inc[(size_t)sgi * n_pad + g];
     csum[(size_t)c * n_pad + g] = t;
 }
+// One block per 256 genomes (half a rank group; n_pad is a multiple of 512).  The chunk sums are fetched sixteen at a time
+// (independent loads: the in-place update otherwise makes every load wait for the store before it -- 96 memory round
+// trips in a row, 200+ us next to the other streams' kernels, measured).  gmax != NULL: the best value of the block's
+// genomes at every chunk boundary (gmax[c][half], row n_chunks = as the pass ends) comes out of the same registers
+// (chunk_group_live's bound) instead of a separate 30 000-block launch.
 __global__ __launch_bounds__(256) void chunk_prefix_kernel(u32* __restrict__ csum, u32 n_chunks, u32 n_pad,
-                                                           const u64* __restrict__ cum_in, u64* __restrict__ cum_out) {
-    const u32 g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= n_pad) return;
+                                                           const u64* __restrict__ cum_in, u64* __restrict__ cum_out,
+                                                           u64* __restrict__ gmax, u32 n_half) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
+    __shared__ u64 part[4][17];
+    const u32 g = blockIdx.x * 256u + threadIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
+    const u64 base = cum_in[g];  // (padding genomes: 0, and their sums stay 0)
     u32 run = 0;
-#pragma unroll 8
-    for (u32 c = 0; c < n_chunks; ++c) {
-        const u32 t = csum[(size_t)c * n_pad + g];
-        csum[(size_t)c * n_pad + g] = run;
-        run += t;
+    for (u32 c0 = 0; c0 <= n_chunks; c0 += 16u) {
+        const u32 nc = min(16u, n_chunks - c0);  // (the last round may have none: only the closing row)
+        u32 t[16];
+#pragma unroll
+        for (u32 i = 0; i < 16u; ++i) t[i] = i < nc ? csum[(size_t)(c0 + i) * n_pad + g] : 0u;
+        const u32 rows = min(17u, n_chunks + 1u - c0);  // boundaries handled this round (row n_chunks closes the pass)
+#pragma unroll
+        for (u32 i = 0; i < 16u; ++i) {
+            if (i < rows) {
+                if (i < nc) csum[(size_t)(c0 + i) * n_pad + g] = run;
+                if (gmax) {
+                    u64 v = base + run;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) v = max(v, shfl_xor64(v, d));
+                    if (lane == 0) part[wv][i] = v;
+                }
+                run += t[i];
+            }
+        }
+        if (gmax) {
+            const u32 rows16 = min(16u, rows);
+            __syncthreads();
+            if (threadIdx.x < rows16)
+                gmax[(size_t)(c0 + threadIdx.x) * n_half + blockIdx.x] =
+                    max(max(part[0][threadIdx.x], part[1][threadIdx.x]), max(part[2][threadIdx.x], part[3][threadIdx.x]));
+            __syncthreads();
+        }
+        if (nc < 16u) break;
     }
-    cum_out[g] = cum_in[g] + run;
+    cum_out[g] = base + run;
 }
 __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, const u32* __restrict__ csum,
                                                          u32 n_seg, u32 n_pad, u32* __restrict__ rel,
                                                          const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
                                                          u32 n_half, Species sp, const u32* __restrict__ grp_any) {
+    __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad || !grp_any[blockIdx.x >> 1]) return;  // (a group without any bit starts every segment at the pass-start table)
     // a (chunk, rank group) without any possible candidate is never looked at by the ranking: skip its start values
@@ -1725,6 +1773,7 @@ constexpr u32 kLeaderParts = 32;
 __global__ __launch_bounds__(256) void chunk_leader_part_kernel(const u64* __restrict__ cum_in, const u32* __restrict__ csum,
                                                                  u32 n_pad, Species sp, u32 top_k,
                                                                  u64* __restrict__ part_sum, u32* __restrict__ part_idx) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u64 ssum[4];
     __shared__ u32 sidx[4];
     __shared__ u64 wsum;
@@ -1765,6 +1814,7 @@ __global__ __launch_bounds__(256) void chunk_leader_part_kernel(const u64* __res
 // one wave per chunk
 __global__ __launch_bounds__(64) void chunk_leader_merge_kernel(const u64* __restrict__ part_sum, const u32* __restrict__ part_idx,
                                                                 u32 top_k, u32* __restrict__ leader, u64* __restrict__ lead_val) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 c = blockIdx.x, lane = lane_id(), n_cand = kLeaderParts * top_k;
     u64 ps = 0; u32 pi = 0; bool first = true;
     for (u32 j = 0; j < top_k; ++j) {
@@ -1904,6 +1954,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
                                                             const u64* __restrict__ lead_val, const u32* __restrict__ grp_any) {
+    __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
@@ -2162,6 +2213,7 @@ __global__ __launch_bounds__(256) void top1_merge_kernel(const u64* __restrict__
                                                          const u32* __restrict__ best_idx, u32 n_reads,
                                                          u32* __restrict__ out_idx, u64* __restrict__ out_sum,
                                                          u32 out_r0, Species sp) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 t = blockIdx.x * 256u + threadIdx.x;
     const u32 spi = t / n_reads, r = t % n_reads;  // (reads innermost: coalesced candidate loads)
     if (spi >= sp.n_sp) return;
@@ -2474,15 +2526,14 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
     const u32 n_chunks = cdiv(n_seg, 16);
     dim3 grid(cdiv(n_pad, 256), n_chunks);
     hipLaunchKernelGGL(chunk_sum_kernel, grid, dim3(256), 0, st, inc, n_seg, n_pad, csum, grp_any);
-    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, csum, n_chunks, n_pad, cum_in, cum_out);
+    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(n_pad / 256), dim3(256), 0, st, csum, n_chunks, n_pad, cum_in, cum_out,
+                       prune_top_k ? gmax : nullptr, n_pad / 256);
     if (prune_top_k) {
         // who leads (per species) as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
         hipLaunchKernelGGL(chunk_leader_part_kernel, dim3(n_chunks * sp.n_sp, kLeaderParts), dim3(256), 0, st, cum_in, csum, n_pad,
                            sp, prune_top_k, part_sum, part_idx);
         hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
                            lead_val);
-        hipLaunchKernelGGL(chunk_gmax_kernel, dim3(n_pad / 256, n_chunks + 1), dim3(256), 0, st, cum_in, cum_out, csum, n_chunks,
-                           n_pad, n_pad / 256, gmax);
     }
     hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
                        lead_val, n_pad / 256, sp, grp_any);
