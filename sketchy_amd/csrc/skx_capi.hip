@@ -874,7 +874,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         {
             Span sp(st, 3, hs);
             skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq, d_grp_any,
-                                       lean ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, st->d_rowmask[b]);
+                                       lean ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, st->d_rowmask[b], nq_est);
         }
     }
     if (P == 0) SKXCHK(wait_back());

@@ -1426,10 +1426,15 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
     __shared__ u64 tile[2][64][kRankWords + 1];
     // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
     // index Q, so rows of Mq beyond nq are never read
+    // (... and the grid's y extent comes from the host's ESTIMATE of nq -- tens of thousands of 512-thread blocks that
+    // only find out they have nothing to do cost the scan stream 0.3-0.4 ms next to the other streams' kernels -- so a
+    // block strides over the word groups: any estimate is correct, a good one is fast)
     const u32 live_words = min(n_words, (*n_q + 63u) >> 6);
-    const u32 grp = blockIdx.x, w0 = blockIdx.y * kWordsPerBlock, w1 = min(live_words, w0 + kWordsPerBlock);
-    if (w0 >= w1) return;
+    const u32 grp = blockIdx.x;
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
+    u64 seen = 0;
+    for (u32 w0 = blockIdx.y * kWordsPerBlock; w0 < live_words; w0 += gridDim.y * kWordsPerBlock) {
+    const u32 w1 = min(live_words, w0 + kWordsPerBlock);
     const u32 gw = grp * kRankWords + wv;
     const bool on = gw < n_gw;
     const size_t col = (size_t)gw * 64u + lane;
@@ -1465,18 +1470,25 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
         return x;
     };
     const u32 row = threadIdx.x >> 3, cw = threadIdx.x & 7u;
-    u64 nxt = load(w0);
-    u64 seen = 0;
-    for (u32 w = w0; w < w1; ++w) {
-        const u64 cur = nxt;
+    // all of the group's words are requested before the first is used: next to the other streams' kernels a memory round
+    // trip takes several microseconds, and one per word in a row was most of this kernel's time
+    u64 xs[kWordsPerBlock];
+#pragma unroll
+    for (u32 i = 0; i < kWordsPerBlock; ++i) xs[i] = load(w0 + i);
+#pragma unroll
+    for (u32 i = 0; i < kWordsPerBlock; ++i) {
+        const u32 w = w0 + i;
+        if (w >= w1) break;
+        const u64 cur = xs[i];
         seen |= cur;
-        nxt = load(w + 1u);
-        const u32 bsel = (w - w0) & 1u;
+        const u32 bsel = i & 1u;
         tile[bsel][lane][wv] = transpose64(cur, lane);
         __syncthreads();  // (double-buffered tile: one barrier per word is enough)
         const u64 v = tile[bsel][row][cw];
         if (grp * kRankWords + cw < n_gw) mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = v;
         (void)rowmask;
+    }
+    __syncthreads();  // (the tile buffers are reused by the block's next word group)
     }
     if (__ballot(seen != 0) && lane == 0) grp_any[grp] = 1u;  // (plain store of the same value from several waves)
 }
@@ -1568,13 +1580,25 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     for (u32 b0 = pa; b0 < pz; b0 += kBlockPairs) {
         const u32 bz = min(pz, b0 + kBlockPairs);
         u64 ones = 0, twos = 0, fours = 0, eights = 0, sixteens = 0, thirtytwos = 0;
-        for (u32 p0 = b0; p0 < bz; p0 += 64u) {
-            u64 x[8];
+        // the query indices of the next 64 pairs are requested before the current rows are counted (one memory round trip
+        // per step instead of two in a row; requesting the rows ahead as well needs 82 VGPRs and lost: 417 -> 725 us)
+        auto load_q = [&](u32 p0, u32 (&qv)[8]) {
 #pragma unroll
             for (u32 u = 0; u < 8u; ++u) {
                 const u32 p = p0 + 8u * u + sub;
-                x[u] = p < bz ? mq_gj[(size_t)pair_q[p] * kRankWords] : 0ull;
+                qv[u] = p < bz ? pair_q[p] : 0xFFFFFFFFu;
             }
+        };
+        auto gather = [&](const u32 (&qv)[8], u64 (&xv)[8]) {
+#pragma unroll
+            for (u32 u = 0; u < 8u; ++u) xv[u] = qv[u] != 0xFFFFFFFFu ? mq_gj[(size_t)qv[u] * kRankWords] : 0ull;
+        };
+        u32 qn[8];
+        load_q(b0, qn);
+        for (u32 p0 = b0; p0 < bz; p0 += 64u) {
+            u64 x[8];
+            gather(qn, x);
+            load_q(p0 + 64u, qn);
             u64 twos_a, twos_b, fours_a, fours_b, eights_a;
             SKX_CSA(twos_a, ones, ones, x[0], x[1])
             SKX_CSA(twos_b, ones, ones, x[2], x[3])
@@ -2489,10 +2513,14 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 #undef SKX_SCAN
 }
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any,
-                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64* rowmask) {
+                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64* rowmask,
+                           u64 nq_est) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
-    hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), cdiv(n_words, kWordsPerBlock)), dim3(512), 0, st,
+    // y extent: twice the estimated dictionary size (the blocks stride, see the kernel), at most what the pairs allow
+    const u32 y_all = cdiv(n_words, kWordsPerBlock);
+    const u32 y_est = (u32)std::min<u64>(y_all, std::max<u64>(16, cdiv((u32)std::min<u64>(2 * nq_est / 64 + 1, 0xFFFFFFF0u), kWordsPerBlock)));
+    hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), std::min(y_est, 65535u)), dim3(512), 0, st,
                        m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty,
                        reinterpret_cast<unsigned char*>(rowmask));
 }
