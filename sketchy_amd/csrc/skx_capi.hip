@@ -391,8 +391,13 @@ struct skx_stream {
     u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
     u32 *d_pair_r[3] = {nullptr, nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[3] = {nullptr, nullptr, nullptr};
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
-    u32* d_inc = nullptr;
-    u32* d_csum = nullptr;
+    // per-segment increments and their chunk sums (before the prefix), per buffer set: they depend on the pass's bit matrix
+    // only, not on the running table, so seg_sum / chunk_sum of pass i + 1 run (stream hs3) while pass i is still ranked (hs2)
+    u32* d_inc2[2] = {nullptr, nullptr};
+    u32* d_csum_raw2[2] = {nullptr, nullptr};
+    u32* d_csum = nullptr;        // exclusive prefix of the chunk sums (chunk_prefix)
+    hipStream_t hs3 = nullptr;    // aliases hs2 below pipeline depth 3
+    hipEvent_t ev_inc[2] = {nullptr, nullptr};
     u32* d_leader = nullptr;      // [chunks of 16 segments][top_k] genomes ranked first as the chunk begins
     u64* d_lead_val = nullptr;    // [chunks] value of the top_k-th of them
     u64* d_gmax = nullptr;        // [chunks + 1][half rank groups] best value inside 256 genomes at every chunk boundary
@@ -467,8 +472,8 @@ static void stream_free(skx_stream* st) {
     void* ptrs[] = {st->d_bases, st->d_offsets, st->sd_sk[0], st->sd_len[0], st->sd_cnt[0], st->sd_poff[0], st->sd_big[0],
                     st->sd_sk[1], st->sd_len[1], st->sd_cnt[1], st->sd_poff[1], st->sd_big[1], st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
-                    st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc,
-                    st->d_csum, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc2[0], st->d_inc2[1] != st->d_inc2[0] ? st->d_inc2[1] : nullptr,
+                    st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowmask[0], st->d_rowmask[1]};
     for (void* p : ptrs) (void)hipFree(p);
@@ -492,6 +497,7 @@ static void stream_free(skx_stream* st) {
     for (int i = 0; i < 2; ++i) {
         if (st->ev_dict[i]) (void)hipEventDestroy(st->ev_dict[i]);
         if (st->ev_pairq[i]) (void)hipEventDestroy(st->ev_pairq[i]);
+        if (st->ev_inc[i]) (void)hipEventDestroy(st->ev_inc[i]);
         if (st->ev_front[i]) (void)hipEventDestroy(st->ev_front[i]);
         if (st->ev_back[i]) (void)hipEventDestroy(st->ev_back[i]);
         if (st->ev_sketch[i]) (void)hipEventDestroy(st->ev_sketch[i]);
@@ -499,6 +505,7 @@ static void stream_free(skx_stream* st) {
     }
     for (auto ev : st->ev_pslot)
         if (ev) (void)hipEventDestroy(ev);
+    if (st->hs3 && st->hs3 != st->hs2) (void)hipStreamDestroy(st->hs3);
     if (st->hs2 && st->hs2 != st->hs && st->hs2 != st->hs0) (void)hipStreamDestroy(st->hs2);
     if (st->hs0 && st->hs0 != st->hs) (void)hipStreamDestroy(st->hs0);
     if (st->hs) (void)hipStreamDestroy(st->hs);
@@ -601,9 +608,17 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, rank_hi ? prio_hi : prio_lo));
     } else st->hs2 = st->hs;
     }
+    {
+        // (measured at C2: with the split the stream far from its start gains 5 % (78.6 -> 83 M reads/s), the first 2 M reads
+        // of a sample -- heavy ranking, nothing pruned yet -- lose 10 % (72.5 -> 64.5 M): off by default)
+        static const int split_env = getenv("SKX_RANK_SPLIT") ? atoi(getenv("SKX_RANK_SPLIT")) : 0;
+        if (st->depth == 3 && split_env && cu_scan_env <= 0) SCHK(hipStreamCreateWithPriority(&st->hs3, hipStreamNonBlocking, prio_lo));
+        else st->hs3 = st->hs2;
+    }
     for (int i = 0; i < 2; ++i) {
         SCHK(hipEventCreateWithFlags(&st->ev_dict[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_pairq[i], hipEventDisableTiming));
+        SCHK(hipEventCreateWithFlags(&st->ev_inc[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_back[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_sketch[i], hipEventDisableTiming));
@@ -629,9 +644,12 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // (d_mint, the second word array of the split scan variant, is allocated by the first pass that wants it)
     for (int i = 0; i < 2; ++i)
         SCHK(hipMalloc(&st->d_mq[i], (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
-    SCHK(hipMalloc(&st->d_inc, (size_t)n_seg_max * n_pad * 4));
+    SCHK(hipMalloc(&st->d_inc2[0], (size_t)n_seg_max * n_pad * 4));
+    if (st->hs3 != st->hs2) SCHK(hipMalloc(&st->d_inc2[1], (size_t)n_seg_max * n_pad * 4)); else st->d_inc2[1] = st->d_inc2[0];
     SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
+    SCHK(hipMalloc(&st->d_csum_raw2[0], (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
+    if (st->hs3 != st->hs2) SCHK(hipMalloc(&st->d_csum_raw2[1], (size_t)((n_seg_max + 15) / 16) * n_pad * 4)); else st->d_csum_raw2[1] = st->d_csum_raw2[0];
     SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * n_sp * std::max<u32>(top_k, 1) * 4 + 64));
     SCHK(hipMalloc(&st->d_lead_val, (size_t)((n_seg_max + 15) / 16) * n_sp * 8 + 64));
     SCHK(hipMalloc(&st->d_lpart_sum, (size_t)((n_seg_max + 15) / 16) * n_sp * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 8 + 64));
@@ -882,16 +900,26 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     HIPCHK(hipEventRecord(st->ev_front[b], hs));
     st->front_pending[b] = true;
 
-    // ---- back half (stream hs2): running table, per-read rows; overlaps the next pass's front half
-    HIPCHK(hipStreamWaitEvent(hs2, st->ev_front[b], 0));
+    // ---- back half: per-segment increments and their chunk sums (stream hs3: they need this pass's Mq only), then the
+    // running table and the per-read rows (stream hs2, in pass order); overlaps the next pass's front half
+    hipStream_t hs3 = st->hs3;
+    u32 *d_inc = st->d_inc2[b], *d_csum_raw = st->d_csum_raw2[b];
+    const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
+    HIPCHK(hipStreamWaitEvent(hs3, st->ev_front[b], 0));
+    if (update_table) {
+        Span sp(st, 4, hs3);
+        skx::launch_seg_sum(hs3, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
+                            st->d_rowmask[b]);
+        skx::launch_chunk_sum(hs3, d_inc, n_seg, n_pad, d_csum_raw, d_grp_any);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(st->ev_inc[b], hs3));
+    HIPCHK(hipStreamWaitEvent(hs2, st->ev_inc[b], 0));  // (implies ev_front[b])
     if (update_table) {
         Span sp(st, 4, hs2);
-        const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
-        skx::launch_seg_sum(hs2, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, st->d_inc, d_grp_any,
-                            st->d_rowmask[b]);
         const bool ranked = st->top_k && d_topk_idx && d_topk_sum;
         const u32 prune_k = (ranked && st->top_k <= skx::rank_topk_fast_max()) ? st->top_k : 0u;
-        skx::launch_seg_prefix(hs2, st->d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, prune_k,
+        skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
                                st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
@@ -901,13 +929,13 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         const bool top1_fast = st->top_k == 1 && ref->s < (1u << 15) && !top1_wide_env;
         if (top1_fast && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
-                                      spc, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, st->d_inc,
+                                      spc, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, d_inc,
                                       st->d_leader, st->d_gmax, st->d_lead_val, d_grp_any);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, d_topk_idx, d_topk_sum, ra, spc);
         } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
             const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
             skx::launch_rank_seg_topk(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
-                                      cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, st->d_inc, st->d_leader,
+                                      cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, d_inc, st->d_leader,
                                       st->d_gmax, st->d_lead_val, d_grp_any);
             skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, ra, spc);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {

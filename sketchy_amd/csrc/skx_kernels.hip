@@ -25,6 +25,12 @@
 #include "skx_common.hpp"
 #include "skx_kernels.hpp"
 
+#ifndef SKX_SEGSUM_PRIO
+#define SKX_SEGSUM_PRIO 2
+#endif
+#ifndef SKX_RANK1_PRIO
+#define SKX_RANK1_PRIO 3
+#endif
 namespace skx {
 
 // position of genome word gw of query row q in the group-major bit matrix Mq (nq_rows rows per group)
@@ -1415,7 +1421,7 @@ constexpr u32 kWordsPerBlock = 4;
 // one -- a whole species the sample does not belong to, for instance -- are skipped by every kernel of the back half.
 // hbuf != NULL: scan_lean_kernel's per-(band, tile) slabs are OR-ed in (the bands word_bands_kernel lists in wb, each
 // tested against its window), and M itself is only read when *m_dirty says somebody wrote it.
-__global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m_bits, u64* __restrict__ m_int,
+__global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m_bits, u64* __restrict__ m_int,
                                                              u32 n_pad, u32 n_words, u64* __restrict__ mq, u32 n_gw,
                                                              const u32* __restrict__ n_q, u32* __restrict__ grp_any,
                                                              const u64* __restrict__ hbuf, const u32* __restrict__ wb,
@@ -1435,12 +1441,14 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
     u64 seen = 0;
     for (u32 w0 = blockIdx.y * kWordsPerBlock; w0 < live_words; w0 += gridDim.y * kWordsPerBlock) {
     const u32 w1 = min(live_words, w0 + kWordsPerBlock);
-    const u32 gw = grp * kRankWords + wv;
-    const bool on = gw < n_gw;
-    const size_t col = (size_t)gw * 64u + lane;
     const bool read_m = hbuf == nullptr || *m_dirty != 0u;
-    const u32 ref_tile = gw / (kTileGenomes / 64u), tc = (gw % (kTileGenomes / 64u)) * 64u + lane;  // this lane's genome in its tile
-    auto load = [&](u32 w) -> u64 {
+    // (four waves, two genome words each: a 512-thread block needs eight free wave slots on one CU at once, which it
+    // waits for next to the other streams' 256-thread blocks)
+    auto load = [&](u32 w, u32 half) -> u64 {
+        const u32 gw = grp * kRankWords + wv + 4u * half;
+        const bool on = gw < n_gw;
+        const size_t col = (size_t)gw * 64u + lane;
+        const u32 ref_tile = gw / (kTileGenomes / 64u), tc = (gw % (kTileGenomes / 64u)) * 64u + lane;  // this lane's genome in its tile
         if (!on || w >= w1) return 0;
         u64 x = 0;
         if (read_m) {
@@ -1472,20 +1480,22 @@ __global__ __launch_bounds__(512) void transpose_bits_kernel(u64* __restrict__ m
     const u32 row = threadIdx.x >> 3, cw = threadIdx.x & 7u;
     // all of the group's words are requested before the first is used: next to the other streams' kernels a memory round
     // trip takes several microseconds, and one per word in a row was most of this kernel's time
-    u64 xs[kWordsPerBlock];
+    u64 xs[kWordsPerBlock][2];
 #pragma unroll
-    for (u32 i = 0; i < kWordsPerBlock; ++i) xs[i] = load(w0 + i);
+    for (u32 i = 0; i < kWordsPerBlock; ++i) { xs[i][0] = load(w0 + i, 0u); xs[i][1] = load(w0 + i, 1u); }
 #pragma unroll
     for (u32 i = 0; i < kWordsPerBlock; ++i) {
         const u32 w = w0 + i;
         if (w >= w1) break;
-        const u64 cur = xs[i];
-        seen |= cur;
+        seen |= xs[i][0] | xs[i][1];
         const u32 bsel = i & 1u;
-        tile[bsel][lane][wv] = transpose64(cur, lane);
+        tile[bsel][lane][wv] = transpose64(xs[i][0], lane);
+        tile[bsel][lane][wv + 4u] = transpose64(xs[i][1], lane);
         __syncthreads();  // (double-buffered tile: one barrier per word is enough)
-        const u64 v = tile[bsel][row][cw];
-        if (grp * kRankWords + cw < n_gw) mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = v;
+        if (grp * kRankWords + cw < n_gw) {
+            mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = tile[bsel][row][cw];
+            mq[mq_index(grp * kRankWords + cw, w * 64u + row + 32u, n_words * 64u)] = tile[bsel][row + 32u][cw];
+        }
         (void)rowmask;
     }
     __syncthreads();  // (the tile buffers are reused by the block's next word group)
@@ -1557,7 +1567,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                       u32 nq_rows, u32* __restrict__ inc, const u32* __restrict__ grp_any,
                                                       const u64* __restrict__ rowmask) {
-    __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
+    __builtin_amdgcn_s_setprio(SKX_SEGSUM_PRIO);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     static_assert(kRankWords == 8, "lane = (sub, word) layout assumes 8 words per rank group");
     const u32 lane = lane_id();
     const u32 n_seg = (n_reads + seg_len - 1) / seg_len, n_grp = (n_gw + kRankWords - 1) / kRankWords;
@@ -1711,8 +1721,8 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const u32* __restrict__ 
 // trips in a row, 200+ us next to the other streams' kernels, measured).  gmax != NULL: the best value of the block's
 // genomes at every chunk boundary (gmax[c][half], row n_chunks = as the pass ends) comes out of the same registers
 // (chunk_group_live's bound) instead of a separate 30 000-block launch.
-__global__ __launch_bounds__(256) void chunk_prefix_kernel(u32* __restrict__ csum, u32 n_chunks, u32 n_pad,
-                                                           const u64* __restrict__ cum_in, u64* __restrict__ cum_out,
+__global__ __launch_bounds__(256) void chunk_prefix_kernel(const u32* __restrict__ csum_raw, u32* __restrict__ csum, u32 n_chunks,
+                                                           u32 n_pad, const u64* __restrict__ cum_in, u64* __restrict__ cum_out,
                                                            u64* __restrict__ gmax, u32 n_half) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u64 part[4][17];
@@ -1723,7 +1733,7 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(u32* __restrict__ csu
         const u32 nc = min(16u, n_chunks - c0);  // (the last round may have none: only the closing row)
         u32 t[16];
 #pragma unroll
-        for (u32 i = 0; i < 16u; ++i) t[i] = i < nc ? csum[(size_t)(c0 + i) * n_pad + g] : 0u;
+        for (u32 i = 0; i < 16u; ++i) t[i] = i < nc ? csum_raw[(size_t)(c0 + i) * n_pad + g] : 0u;  // (not in place: no load waits for a store)
         const u32 rows = min(17u, n_chunks + 1u - c0);  // boundaries handled this round (row n_chunks closes the pass)
 #pragma unroll
         for (u32 i = 0; i < 16u; ++i) {
@@ -1978,7 +1988,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
                                                             const u64* __restrict__ lead_val, const u32* __restrict__ grp_any) {
-    __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
+    __builtin_amdgcn_s_setprio(SKX_RANK1_PRIO);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
@@ -2520,7 +2530,7 @@ void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u
     // y extent: twice the estimated dictionary size (the blocks stride, see the kernel), at most what the pairs allow
     const u32 y_all = cdiv(n_words, kWordsPerBlock);
     const u32 y_est = (u32)std::min<u64>(y_all, std::max<u64>(16, cdiv((u32)std::min<u64>(2 * nq_est / 64 + 1, 0xFFFFFFF0u), kWordsPerBlock)));
-    hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), std::min(y_est, 65535u)), dim3(512), 0, st,
+    hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), std::min(y_est, 65535u)), dim3(256), 0, st,
                        m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty,
                        reinterpret_cast<unsigned char*>(rowmask));
 }
@@ -2549,12 +2559,11 @@ void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_ba
                        r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any, rowmask);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
-                       u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32 prune_top_k, u32* leader,
+                       u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32* csum_raw /* same size */, u32 prune_top_k, u32* leader,
                        u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx, const u32* grp_any) {
     const u32 n_chunks = cdiv(n_seg, 16);
     dim3 grid(cdiv(n_pad, 256), n_chunks);
-    hipLaunchKernelGGL(chunk_sum_kernel, grid, dim3(256), 0, st, inc, n_seg, n_pad, csum, grp_any);
-    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(n_pad / 256), dim3(256), 0, st, csum, n_chunks, n_pad, cum_in, cum_out,
+    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(n_pad / 256), dim3(256), 0, st, csum_raw, csum, n_chunks, n_pad, cum_in, cum_out,
                        prune_top_k ? gmax : nullptr, n_pad / 256);
     if (prune_top_k) {
         // who leads (per species) as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
@@ -2565,6 +2574,10 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
     }
     hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
                        lead_val, n_pad / 256, sp, grp_any);
+}
+// (the first level of launch_seg_prefix's three: needs only the increments, not the running table -- queued with seg_sum)
+void launch_chunk_sum(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u32* csum_raw, const u32* grp_any) {
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(cdiv(n_pad, 256), cdiv(n_seg, 16)), dim3(256), 0, st, inc, n_seg, n_pad, csum_raw, grp_any);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
