@@ -1760,10 +1760,16 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(const u32* __restrict
     }
     cum_out[g] = base + run;
 }
+// live != NULL (top-1 ranking): live[seg][genome word] = some genome of the word ENDS segment seg at or above lead_val of
+// the segment's chunk (the leader's value as the chunk began -- the leader only grows, so that is a lower bound of
+// every bound the ranking uses inside the chunk).  Words that cannot are never looked at by rank_seg_top1_kernel, and
+// their start values are not even stored: once a sample has a clear best match that is nearly all of them, and the
+// 2 x 247 MB per batch that the ranking read only to find no candidate (measured: 119 000 of 121 000 waves) stay unread.
 __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__ inc, const u32* __restrict__ csum,
                                                          u32 n_seg, u32 n_pad, u32* __restrict__ rel,
                                                          const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
-                                                         u32 n_half, Species sp, const u32* __restrict__ grp_any) {
+                                                         u32 n_half, Species sp, const u32* __restrict__ grp_any,
+                                                         const u64* __restrict__ cum_in, unsigned char* __restrict__ live) {
     __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad || !grp_any[blockIdx.x >> 1]) return;  // (a group without any bit starts every segment at the pass-start table)
@@ -1772,10 +1778,29 @@ __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__
     if (gmax && !chunk_group_live(gmax, lead_val, n_half, c, blockIdx.x >> 1, sp)) return;
     const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
     u32 run = csum[(size_t)c * n_pad + g];
+    if (!live) {
 #pragma unroll 16
-    for (u32 sgi = s0; sgi < s1; ++sgi) {
-        rel[(size_t)sgi * n_pad + g] = run;
-        run += inc[(size_t)sgi * n_pad + g];
+        for (u32 sgi = s0; sgi < s1; ++sgi) {
+            rel[(size_t)sgi * n_pad + g] = run;
+            run += inc[(size_t)sgi * n_pad + g];
+        }
+        return;
+    }
+    const u64 lv = lead_val[c * sp.n_sp + sp.of_grp[blockIdx.x >> 1]];
+    const u64 base = cum_in[g];
+    const u32 gw = g >> 6, n_gw = n_pad >> 6;
+    u32 t[16];
+#pragma unroll
+    for (u32 i = 0; i < 16u; ++i) t[i] = s0 + i < s1 ? inc[(size_t)(s0 + i) * n_pad + g] : 0u;
+#pragma unroll
+    for (u32 i = 0; i < 16u; ++i) {
+        if (s0 + i < s1) {
+            const u32 start = run;
+            run += t[i];
+            const bool any = __ballot(base + run >= lv) != 0ull;  // (padding genomes: base 0, never gain)
+            if (any) rel[(size_t)(s0 + i) * n_pad + g] = start;
+            if (lane_id() == 0) live[(size_t)(s0 + i) * n_gw + gw] = any ? 1 : 0;
+        }
     }
 }
 
@@ -1987,7 +2012,8 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u64* __restrict__ best_sum, u32* __restrict__ best_idx,
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
-                                                            const u64* __restrict__ lead_val, const u32* __restrict__ grp_any) {
+                                                            const u64* __restrict__ lead_val, const u32* __restrict__ grp_any,
+                                                            const unsigned char* __restrict__ live) {
     __builtin_amdgcn_s_setprio(SKX_RANK1_PRIO);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
@@ -2025,6 +2051,21 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     const u32 gl = leader[(seg >> 4) * sp.n_sp + spi];  // (top_k == 1: one leader per chunk and species)
     u64 lead = cum_in[gl] + (grp_any[gl / (NW * 64u)] ? rel[(size_t)seg * n_pad + gl] : 0u);
     const u32 gain = pz - pa;
+    // words none of whose genomes can reach even the chunk's leader bound by the end of the segment (seg_prefix_kernel):
+    // no start values were stored for them, nothing of theirs is loaded -- usually that is the whole group
+    u32 livew = 0xFFu;
+    if (!dead && live) {
+        const u32 gwl = grp * NW + (lane & (NW - 1));
+        livew = (u32)__ballot(lane < (u32)NW && gwl < n_gw && live[(size_t)seg * n_gw + gwl] != 0) & 0xFFu;
+        if (livew == 0u) {
+            if (lane < rz - ra) {
+                const size_t o = (size_t)grp * n_reads + ra + lane;
+                best_sum[o] = 0;
+                best_idx[o] = 0xFFFFFFFFu;
+            }
+            return;
+        }
+    }
     u64 st0[NW];
     u32 ic[NW];
     bool real[NW];
@@ -2032,7 +2073,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const u32 g = g0 + (u32)j * 64u;
-        real[j] = g < sp_end;  // (padding genomes of the species' last group never rank)
+        real[j] = g < sp_end && ((livew >> j) & 1u);  // (padding genomes of the species' last group never rank)
         st0[j] = real[j] ? cum_in[g] + (dead ? 0u : rel[(size_t)seg * n_pad + g]) : 0;
         ic[j] = (real[j] && !dead) ? inc[(size_t)seg * n_pad + g] : 0;
         grp_best = max(grp_best, st0[j]);
@@ -2560,7 +2601,8 @@ void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_ba
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32* csum_raw /* same size */, u32 prune_top_k, u32* leader,
-                       u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx, const u32* grp_any) {
+                       u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx, const u32* grp_any,
+                       unsigned char* live /* [n_seg][n_pad / 64] or NULL: every start value is stored */) {
     const u32 n_chunks = cdiv(n_seg, 16);
     dim3 grid(cdiv(n_pad, 256), n_chunks);
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3(n_pad / 256), dim3(256), 0, st, csum_raw, csum, n_chunks, n_pad, cum_in, cum_out,
@@ -2573,7 +2615,7 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
                            lead_val);
     }
     hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
-                       lead_val, n_pad / 256, sp, grp_any);
+                       lead_val, n_pad / 256, sp, grp_any, cum_in, prune_top_k ? live : nullptr);  // (live: the caller's choice, top-1 path only)
 }
 // (the first level of launch_seg_prefix's three: needs only the increments, not the running table -- queued with seg_sum)
 void launch_chunk_sum(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u32* csum_raw, const u32* grp_any) {
@@ -2590,11 +2632,11 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
-                          const u64* lead_val, const u32* grp_any) {
+                          const u64* lead_val, const u32* grp_any, const unsigned char* live) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, sp, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader,
-                       gmax, lead_val, grp_any);
+                       gmax, lead_val, grp_any, live);
 }
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
