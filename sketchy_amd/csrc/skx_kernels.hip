@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                       u32 nq_rows, u32* __restrict__ inc, const u32* __restrict__ grp_any,
-                                                      const u64* __restrict__ rowmask) {
+                                                      u32* __restrict__ qsum) {
     __builtin_amdgcn_s_setprio(SKX_SEGSUM_PRIO);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     static_assert(kRankWords == 8, "lane = (sub, word) layout assumes 8 words per rank group");
     const u32 lane = lane_id();
@@ -1574,15 +1574,19 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     // XCD-aware task order: workgroups go round-robin to the 8 XCDs, each with its own 4 MB L2.  XCD x takes the
     // groups x, x+8, ... and walks them one after the other (all segments of a group before the next group), so the
     // rows being gathered -- one group's slice of Mq, 64 B x |Q| -- stay in that XCD's L2.
-    const u32 xcd = blockIdx.x & 7u;
-    const u32 task = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * 4u + (threadIdx.x >> 6));
-    const u32 grp = (task / n_seg) * 8u + xcd, seg = task % n_seg;
-    if (grp >= n_grp || !grp_any[grp]) return;  // (a group without any bit: nobody reads its increments)
+    // A workgroup = four consecutive segments of one group; their sum (qsum[quarter chunk][g]) leaves with the increments,
+    // so that the chunk sums are built from 4 rows per chunk instead of re-reading all 16 segment rows (247 MB per batch).
+    __shared__ u32 red[4][kRankWords * 64];
+    const u32 xcd = blockIdx.x & 7u, wv = threadIdx.x >> 6;
+    const u32 n_q4 = (n_seg + 3u) / 4u, blk = blockIdx.x >> 3;
+    const u32 grp = (blk / n_q4) * 8u + xcd, seg4 = blk % n_q4;
+    const u32 seg = __builtin_amdgcn_readfirstlane(seg4 * 4u + wv);
+    if (grp >= n_grp || !grp_any[grp]) return;  // (a group without any bit: nobody reads its increments; the whole block leaves)
+    const bool on = seg < n_seg;
     const u32 sub = lane >> 3, j = lane & 7u;
     const u64* mq_gj = mq + (size_t)grp * nq_rows * kRankWords + j;
-    (void)rowmask;  // (skipping empty rows by a per-row mask was measured: the dependent lookup cost more than the gathers saved)
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
-    const u32 pa = poff[r_begin + ra] - p_base, pz = poff[r_begin + rz] - p_base;
+    const u32 pa = on ? poff[r_begin + ra] - p_base : 0u, pz = on ? poff[r_begin + rz] - p_base : 0u;
     u32 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0;
@@ -1659,10 +1663,22 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
         }
     }
     const u32 gw = grp * kRankWords + j;
-    if (gw < n_gw) {  // words past n_gw hold no genomes
+    if (on && gw < n_gw) {  // words past n_gw hold no genomes
         u32* out = inc + (size_t)seg * n_pad + gw * 64u + sub * 8u;
         *reinterpret_cast<uint4*>(out) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
         *reinterpret_cast<uint4*>(out + 4) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    if (qsum) {
+        u32* mine = &red[wv][j * 64u + sub * 8u];
+        *reinterpret_cast<uint4*>(mine) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<uint4*>(mine + 4) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+        __syncthreads();
+#pragma unroll
+        for (u32 h = 0; h < 2u; ++h) {
+            const u32 t = threadIdx.x + 256u * h;
+            if (grp * kRankWords * 64u + t < n_pad)
+                qsum[(size_t)seg4 * n_pad + grp * kRankWords * 64u + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        }
     }
 }
 #undef SKX_CSA
@@ -1704,15 +1720,16 @@ __global__ __launch_bounds__(256) void chunk_gmax_kernel(const u64* __restrict__
 //   seg_prefix_kernel  : rel[seg][g] = csum[chunk of seg][g] + inc of the chunk's earlier segments
 // so that the running sum of genome g before the first read of segment seg is cum_in[g] + rel[seg][g].
 // grids: (n_pad/256, n_chunks), (n_pad/256), (n_pad/256, n_chunks)
+// (inc_is_q4: `inc` holds seg_sum's sums over 4 segments, n_seg counts those rows, 4 of them make a chunk)
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad,
-                                                        u32* __restrict__ csum, const u32* __restrict__ grp_any) {
+                                                        u32* __restrict__ csum, const u32* __restrict__ grp_any, u32 per_chunk) {
     __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad) return;
     if (!grp_any[blockIdx.x >> 1]) { csum[(size_t)c * n_pad + g] = 0; return; }  // (its increments were never written)
-    const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
+    const u32 s0 = c * per_chunk, s1 = min(n_seg, s0 + per_chunk);
     u32 t = 0;
-#pragma unroll 16
+#pragma unroll 4
     for (u32 sgi = s0; sgi < s1; ++sgi) t += inc[(size_t)sgi * n_pad + g];
     csum[(size_t)c * n_pad + g] = t;
 }
@@ -1725,18 +1742,19 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(const u32* __restrict
                                                            u32 n_pad, const u64* __restrict__ cum_in, u64* __restrict__ cum_out,
                                                            u64* __restrict__ gmax, u32 n_half) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
-    __shared__ u64 part[4][17];
+    constexpr u32 kR = 32;  // chunk sums requested per round trip
+    __shared__ u64 part[4][kR + 1];
     const u32 g = blockIdx.x * 256u + threadIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
     const u64 base = cum_in[g];  // (padding genomes: 0, and their sums stay 0)
     u32 run = 0;
-    for (u32 c0 = 0; c0 <= n_chunks; c0 += 16u) {
-        const u32 nc = min(16u, n_chunks - c0);  // (the last round may have none: only the closing row)
-        u32 t[16];
+    for (u32 c0 = 0; c0 <= n_chunks; c0 += kR) {
+        const u32 nc = min(kR, n_chunks - c0);  // (the last round may have none: only the closing row)
+        u32 t[kR];
 #pragma unroll
-        for (u32 i = 0; i < 16u; ++i) t[i] = i < nc ? csum_raw[(size_t)(c0 + i) * n_pad + g] : 0u;  // (not in place: no load waits for a store)
-        const u32 rows = min(17u, n_chunks + 1u - c0);  // boundaries handled this round (row n_chunks closes the pass)
+        for (u32 i = 0; i < kR; ++i) t[i] = i < nc ? csum_raw[(size_t)(c0 + i) * n_pad + g] : 0u;  // (not in place: no load waits for a store)
+        const u32 rows = min(kR + 1u, n_chunks + 1u - c0);  // boundaries handled this round (row n_chunks closes the pass)
 #pragma unroll
-        for (u32 i = 0; i < 16u; ++i) {
+        for (u32 i = 0; i < kR; ++i) {
             if (i < rows) {
                 if (i < nc) csum[(size_t)(c0 + i) * n_pad + g] = run;
                 if (gmax) {
@@ -1749,14 +1767,14 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(const u32* __restrict
             }
         }
         if (gmax) {
-            const u32 rows16 = min(16u, rows);
+            const u32 rows16 = min(kR, rows);
             __syncthreads();
             if (threadIdx.x < rows16)
                 gmax[(size_t)(c0 + threadIdx.x) * n_half + blockIdx.x] =
                     max(max(part[0][threadIdx.x], part[1][threadIdx.x]), max(part[2][threadIdx.x], part[3][threadIdx.x]));
             __syncthreads();
         }
-        if (nc < 16u) break;
+        if (nc < kR) break;
     }
     cum_out[g] = base + run;
 }
@@ -2592,12 +2610,13 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
     hipLaunchKernelGGL(filter_apply_kernel, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, sk, sk_stride, cnt, n_reads, bits, shift);
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any, const u64* rowmask) {
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any,
+                    u32* qsum /* [ceil(n_seg / 4)][n_pad]: sums over 4 segments */) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     const u32 n_grp = cdiv(n_gw, kRankWords);
-    // 8 XCDs x ceil(groups / 8) groups each x n_seg segments, 4 waves (segments) per workgroup
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv((u64)cdiv(n_grp, 8) * n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
-                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any, rowmask);
+    // 8 XCDs x ceil(groups / 8) groups each x ceil(n_seg / 4) workgroups of 4 waves (= 4 consecutive segments)
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv(n_grp, 8) * cdiv(n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
+                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any, qsum);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32* csum_raw /* same size */, u32 prune_top_k, u32* leader,
@@ -2618,8 +2637,10 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
                        lead_val, n_pad / 256, sp, grp_any, cum_in, prune_top_k ? live : nullptr);  // (live: the caller's choice, top-1 path only)
 }
 // (the first level of launch_seg_prefix's three: needs only the increments, not the running table -- queued with seg_sum)
-void launch_chunk_sum(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, u32* csum_raw, const u32* grp_any) {
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3(cdiv(n_pad, 256), cdiv(n_seg, 16)), dim3(256), 0, st, inc, n_seg, n_pad, csum_raw, grp_any);
+// qsum: seg_sum's sums over 4 segments ([ceil(n_seg / 4)][n_pad])
+void launch_chunk_sum(hipStream_t st, const u32* qsum, u32 n_seg, u32 n_pad, u32* csum_raw, const u32* grp_any) {
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(cdiv(n_pad, 256), cdiv(n_seg, 16)), dim3(256), 0, st, qsum, cdiv(n_seg, 4), n_pad, csum_raw,
+                       grp_any, 4u);
 }
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
