@@ -467,17 +467,15 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
 // half of the blocks (dispatched first) takes the reads with more than kSketchCap k-mers, the second half the others,
 // so that the long reads of a mixed-length batch start before the bulk instead of somewhere inside it (chk[1] =
 // number of such reads, counted by batch_check_kernel: without any the first half returns at once).
+#define SKX_SKETCH_PARAMS                                                                                              \
+    const uint8_t *__restrict__ bases, const u64 *__restrict__ offsets, u32 n_reads, u32 k_rt, u64 seed, u32 s, u64 max_ref,  \
+        u64 *__restrict__ out_sk, u32 sk_stride, u32 *__restrict__ out_len, u32 *__restrict__ out_cnt_in, u32 from_list,      \
+        u32 *__restrict__ retry, u32 *__restrict__ big, const u32 *__restrict__ filt, u32 filt_shift, u64 n_bases,            \
+        u32 *__restrict__ chk
+#define SKX_SKETCH_ARGS \
+    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk
 template <int KT, int HCAP, bool INRANGE>
-__global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_kernel(const uint8_t* __restrict__ bases,
-                                                          const u64* __restrict__ offsets, u32 n_reads, u32 k_rt,
-                                                          u64 seed, u32 s, u64 max_ref, u64* __restrict__ out_sk,
-                                                          u32 sk_stride, u32* __restrict__ out_len,
-                                                          u32* __restrict__ out_cnt_in, u32 from_list,
-                                                          u32* __restrict__ retry, u32* __restrict__ big,
-                                                          const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
-                                                          u32* __restrict__ chk) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned char lut[256];
+__device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, unsigned char* lut) {
     fill_base_lut(lut);
     __syncthreads();
     const u32 wpb = blockDim.x >> 6;  // waves per block: 4, or 1 for the list walk (see launch_sketch)
@@ -505,6 +503,21 @@ __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_ke
                                            out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
+}
+template <int KT, int HCAP, bool INRANGE>
+__global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_kernel(SKX_SKETCH_PARAMS) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned char lut[256];
+    sketch_wave_body<KT, HCAP, INRANGE>(SKX_SKETCH_ARGS, smem, lut);
+}
+// Experiment (SKX_SKETCH_ROOM=1): the fast in-range variant held to 5 waves per SIMD by its register allocation instead of
+// by unused dynamic LDS.  It gives the scan its stand-alone speed inside the pipeline and costs the step 12 %: the
+// 102-register waves leave no room in the register file for the other kernels' waves on the SIMDs they occupy.
+template <int KT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 5))) void sketch_wave_kernel_capped(SKX_SKETCH_PARAMS) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned char lut[256];
+    sketch_wave_body<KT, 256, true>(SKX_SKETCH_ARGS, smem, lut);
 }
 
 // =====================================================================================
@@ -2407,8 +2420,14 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 11 KB: 5 instead of 8 of its blocks fit a CU), which leaves
     // wave slots, registers and LDS for the scan's blocks: the VALU-bound sketch and the HBM-bound scan share every CU
     // instead of taking turns (measured at C2: +9 % reads/s, the scan stretched from 0.62 to 0.78 ms).
+    // SKX_SKETCH_ROOM: 2 (default) = unused dynamic LDS per block (SKX_SKETCH_LDS_PAD bytes), 1 = the register-capped
+    // variant (5 waves per SIMD; measured: the scan then runs at its stand-alone speed inside the pipeline, 0.61-0.63 ms =
+    // 0.64-0.66 of peak, but the step takes 1.48-1.50 ms instead of 1.32-1.33: 66 M reads/s instead of 74 M), 0 = never
+    static const int room_mode = env_int("SKX_SKETCH_ROOM", 2);
     static const size_t lds_pad_env = (size_t)env_int("SKX_SKETCH_LDS_PAD", 11264);
-    const size_t lds_pad = leave_room ? lds_pad_env : 0;
+    static const size_t lds_pad_capped = (size_t)env_int("SKX_SKETCH_LDS_PAD_CAPPED", 0);
+    const size_t lds_pad = !leave_room ? 0 : room_mode == 2 ? lds_pad_env : room_mode == 1 ? lds_pad_capped : 0;
+    const bool capped = leave_room && room_mode == 1;
     const size_t lds = sketch_wave_lds(kSketchCap), lds_small = sketch_wave_lds(kSketchSmallHashes) + lds_pad;
     dim3 grid(cdiv(n_reads, 4));
 #define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, IR>
@@ -2454,8 +2473,13 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
         // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
         // does not fit is left on the `big` list for launch_sketch_block -- both lists live on the device, usually empty
         const u32 first = chk ? 2u : 0u;
-        if (k == 16) { SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, first); SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); }
-        else { SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, first); SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u); }
+        if (k == 16) {
+            if (capped) SKX_SK_LAUNCH(sketch_wave_kernel_capped<16>, lds_small, first); else SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, first);
+            SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u);
+        } else {
+            if (capped) SKX_SK_LAUNCH(sketch_wave_kernel_capped<0>, lds_small, first); else SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, first);
+            SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u);
+        }
     } else {
         if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u);
     }
