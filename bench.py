@@ -276,7 +276,7 @@ def main():
             step_gbs = pass_bytes * (prof["scan"]["launches"] / K) / (elapsed / K) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "scan_kernel", "avg_launch_ms": scan_ms, "launches_per_step": prof["scan"]["launches"] / K,
+                               "kernel": "scan_lean_kernel", "avg_launch_ms": scan_ms, "launches_per_step": prof["scan"]["launches"] / K,
                                "algorithmic_bytes_per_launch": pass_bytes,
                                "note": "achieved = algorithmic bytes (8*s*N) / HIP-event time of the kernel on its own stream in the timed "
                                        "region, where the sketch of the next batch and the ranking of the previous one run beside it "

@@ -1160,6 +1160,8 @@ constexpr u32 kLeanCap = 254;
 constexpr u32 kLeanBuckets = 2048;
 constexpr u32 kLeanBucketsMax = 4096;  // directory of a slice with more than kLeanBigFrom entries
 constexpr u32 kLeanBigFrom = 96;
+constexpr u32 kLeanMultiCap = 1022;    // entries per sub-window of a slice beyond kLeanCap (tables in the result tile's LDS)
+static_assert((kLeanMultiCap + 2) * 8 <= 5 * 256 * 8 && (2048 + 2) * 2 <= kLeanBucketsMax + 8, "multi-window tables alias the lean ones");
 constexpr u32 kLeanWords = 5;  // query words a slice of <= kLeanCap entries can touch
 
 // NT: bit 0 = non-temporal slab stores, bit 1 = non-temporal loads of the matrix (it is streamed once per pass: marking its
@@ -1191,25 +1193,33 @@ __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ 
         for (u32 k = 0; k < kLeanWords; ++k) acc[k][c] = 0;  // (only this lane ever touches column c: no barrier needed)
     }
 
-    for (u32 sub = qa; sub < qb; sub += kLeanCap) {
-        const u32 n = min(kLeanCap, qb - sub);
+    // A slice of more than kLeanCap entries (C4: nearly half of the blocks -- the order statistics of 256 genomes spread a
+    // band's hash range to three times one genome's) used to stream its band once per 254 entries: 1.5 x the matrix in HBM
+    // reads at C4 (PMC).  Those blocks need no result tile (their hits go to M), so its 10 KB hold a slice of up to
+    // kLeanMultiCap entries and the directory's 4 KB become 2048 two-byte entries: one pass for slices up to 1022.
+    u64* const sl = multi ? reinterpret_cast<u64*>(&acc[0][0]) : slice;
+    unsigned short* const dir16 = reinterpret_cast<unsigned short*>(dir);
+    const u32 cap = multi ? kLeanMultiCap : kLeanCap;
+    for (u32 sub = qa; sub < qb; sub += cap) {
+        const u32 n = min(cap, qb - sub);
         const u64 lo = q[sub], hi = q[sub + n - 1];
         // bucket(h) = (h - lo) >> shift, with (hi - lo) >> shift < n_bk; longer slices get the larger directory (the chance
         // of three entries in one bucket grows with n^3 / n_bk^2: 1 % at n = 64 / 2048 buckets, 13 % at n = 150, and a
         // block that fails the test pays the walk probe for its whole band)
-        const u32 bk_bits = n > kLeanBigFrom ? (u32)__builtin_ctz(kLeanBucketsMax) : (u32)__builtin_ctz(kLeanBuckets);
+        const u32 bk_bits = (!multi && n > kLeanBigFrom) ? (u32)__builtin_ctz(kLeanBucketsMax) : (u32)__builtin_ctz(kLeanBuckets);
         const u32 n_bk = 1u << bk_bits;
         const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
         const u32 shift = span_bits > bk_bits ? span_bits - bk_bits : 0u;
-        if (c < n) slice[c] = q[sub + c];
-        if (c == 0) { slice[n] = kEmpty; slice[n + 1] = kEmpty; deep = shift < 32u ? 1u : 0u; }
+        for (u32 i = c; i < n; i += kTileGenomes) sl[i] = q[sub + i];
+        if (c == 0) { sl[n] = kEmpty; sl[n + 1] = kEmpty; deep = shift < 32u ? 1u : 0u; }
         __syncthreads();
-        if (c <= n) {
-            // entry c opens every bucket in (bucket(c-1), bucket(c)]; the sentinel closes the rest
-            const u32 bj = c < n ? (u32)((slice[c] - lo) >> shift) : n_bk;
-            const u32 bp = c == 0 ? 0xFFFFFFFFu : (u32)((slice[c - 1] - lo) >> shift);
-            for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned char)c;
-            if (c >= 2u && c < n && (u32)((slice[c - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
+        for (u32 i = c; i <= n; i += kTileGenomes) {
+            // entry i opens every bucket in (bucket(i-1), bucket(i)]; the sentinel closes the rest
+            const u32 bj = i < n ? (u32)((sl[i] - lo) >> shift) : n_bk;
+            const u32 bp = i == 0 ? 0xFFFFFFFFu : (u32)((sl[i - 1] - lo) >> shift);
+            if (multi) { for (u32 x = bp + 1u; x <= bj; ++x) dir16[x] = (unsigned short)i; }
+            else { for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned char)i; }
+            if (i >= 2u && i < n && (u32)((sl[i - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
         }
         __syncthreads();
         const bool lean = deep == 0u && !multi;
@@ -1251,9 +1261,10 @@ __global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ 
         auto probe_walk = [&](u64 hv) {
             if (ABLATE == 2) { cur_bits ^= hv; return; }
             if (hv < lo || hv > hi) return;  // also drops the padding value
-            u32 j = dir[(u32)((hv - lo) >> shift)];
-            u64 e = slice[j];
-            while (e < hv) e = slice[++j];   // the sentinel ends every walk (hv <= hi < kEmpty)
+            const u32 bk = (u32)((hv - lo) >> shift);
+            u32 j = multi ? (u32)dir16[bk] : (u32)dir[bk];
+            u64 e = sl[j];
+            while (e < hv) e = sl[++j];   // the sentinel ends every walk (hv <= hi < kEmpty)
             if (ABLATE == 3) { cur_bits ^= e; return; }
             if (e == hv) {
                 if (multi) hit_atomic(sub + j);
