@@ -1142,8 +1142,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const u64* __restrict__ mat, 
 // stores at the same moments still 0.06: partial lines).  Same geometry here (one block per (band, tile), the best
 // memory behaviour of everything tried), with
 //   * a probe of ~20 instructions without branches: slices of at most kLeanCap = 254 entries, one-byte directory of
-//     2048 buckets; while it is built the block checks that no bucket holds more than two entries (C2: a ~70-entry
-//     slice fails with probability ~1.4 % and the block takes the walk-loop probe over the same tables); then an
+//     2048 buckets; while it is built the block checks that no bucket holds more than two entries (measured at C2, slices of
+//     ~200 entries in 4096 buckets: 13 % of the blocks fail and take the walk-loop probe over the same tables); then an
 //     element's match, if any, is slice[dir[bucket]] or its successor: one ds_read_u8, one ds_read2_b64, two 64-bit
 //     compares.  The bucket is (high word of (h - lo)) >> (shift - 32) clamped to the last bucket, whose entries are
 //     the end sentinels (kEmpty: no matrix cell holds it -- real hashes >= kEmpty live in the exception list, padding
