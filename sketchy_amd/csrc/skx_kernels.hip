@@ -175,23 +175,6 @@ __device__ __forceinline__ u32 wave_normalise4(const uint8_t* __restrict__ rd, u
     return nb;
 }
 
-// 64 k-mers' worth of work shared by the wave and block sketchers lives in these two helpers --------------------
-// normalise raw bytes [from, to) of the read into codes[nb ...] (whitespace dropped, everything not ACGTU -> 4); returns
-// the new code count.  One wave.
-__device__ __forceinline__ u32 wave_normalise(const uint8_t* __restrict__ rd, u32 from, u32 to, uint8_t* codes, u32 nb,
-                                              u32 lane, u64 lt) {
-    for (u32 base = from; base < to; base += 64u) {
-        const u32 idx = base + lane;
-        const u32 ch = idx < to ? (u32)rd[idx] : (u32)' ';
-        const u32 code = classify_base(ch);
-        const bool keep = code != 5u;
-        const u64 mask = __ballot(keep);
-        if (keep) codes[nb + __popcll(mask & lt)] = (uint8_t)code;
-        nb += __popcll(mask);
-    }
-    return nb;
-}
-
 template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, const uint8_t* __restrict__ bases,
                                                 const u64* __restrict__ offsets, u32 k_rt, u64 seed, u32 s, u64 max_ref,
@@ -1434,10 +1417,10 @@ __device__ __forceinline__ u64 transpose64(u64 x, u32 lane) {
     return x;
 }
 
-// One block = 8 waves = one rank group (8 genome words = 512 genomes) x kWordsPerBlock consecutive query words.
-// Per word: every wave loads its 64 genomes' words (512 contiguous bytes), transposes the 64x64 bit block with the
-// butterfly, and the block stages [64 queries][8 words] in LDS and writes 64 x 64 B = 4 KB contiguous of the
-// group-major Mq.  The next word's load is in flight while the current one is transposed and written.
+// One block = 4 waves = one rank group (8 genome words = 512 genomes, two per wave) x kWordsPerBlock consecutive query
+// words, strided over the word groups of the dictionary.  All words of a group are requested first; per word every wave
+// transposes its two 64x64 bit blocks with the butterfly, and the block stages [64 queries][8 words] in LDS and writes
+// 64 x 64 B = 4 KB contiguous of the group-major Mq.
 constexpr u32 kWordsPerBlock = 4;
 // The kernel also restores the "all zero between passes" state of the word arrays (only words that were set are
 // written back): no memset of 2 x |M| bytes per pass.
@@ -1450,8 +1433,7 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
                                                              const u32* __restrict__ n_q, u32* __restrict__ grp_any,
                                                              const u64* __restrict__ hbuf, const u32* __restrict__ wb,
                                                              const u32* __restrict__ win, u32 n_tiles,
-                                                             const u32* __restrict__ m_dirty,
-                                                             unsigned char* __restrict__ rowmask) {
+                                                             const u32* __restrict__ m_dirty) {
     __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u64 tile[2][64][kRankWords + 1];
     // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
@@ -1520,7 +1502,6 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
             mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = tile[bsel][row][cw];
             mq[mq_index(grp * kRankWords + cw, w * 64u + row + 32u, n_words * 64u)] = tile[bsel][row + 32u][cw];
         }
-        (void)rowmask;
     }
     __syncthreads();  // (the tile buffers are reused by the block's next word group)
     }
@@ -1720,21 +1701,6 @@ __device__ __forceinline__ bool chunk_group_live(const u64* __restrict__ gmax, c
     const u64 lv = lead_val[c * sp.n_sp + sp.of_grp[grp]];
     const u64* gm = gmax + (size_t)(c + 1u) * n_half + 2u * grp;  // (n_half = 2 x rank groups: n_pad is a multiple of 512)
     return gm[0] >= lv || gm[1] >= lv;
-}
-// grid: (n_half, n_chunks + 1), 256 threads = 256 genomes (small blocks: they must find wave slots next to the front half)
-__global__ __launch_bounds__(256) void chunk_gmax_kernel(const u64* __restrict__ cum_in, const u64* __restrict__ cum_out,
-                                                         const u32* __restrict__ csum, u32 n_chunks, u32 n_pad,
-                                                         u32 n_half, u64* __restrict__ gmax) {
-    __shared__ u64 part[4];
-    const u32 h = blockIdx.x, c = blockIdx.y, g = h * 256u + threadIdx.x;
-    // (padding genomes never score: their table entries and chunk sums are 0, which cannot raise a maximum)
-    const u64 v0 = c < n_chunks ? cum_in[g] + csum[(size_t)c * n_pad + g] : cum_out[g];
-    u64 v = v0;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, shfl_xor64(v, d));
-    if (lane_id() == 0) part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) gmax[(size_t)c * n_half + h] = max(max(part[0], part[1]), max(part[2], part[3]));
 }
 
 // Segment start values, relative to the table at the start of the pass (32 bits: a pass gains at most its pair
@@ -2617,16 +2583,14 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 #undef SKX_SCAN
 }
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any,
-                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64* rowmask,
-                           u64 nq_est) {
+                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64 nq_est) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     // y extent: twice the estimated dictionary size (the blocks stride, see the kernel), at most what the pairs allow
     const u32 y_all = cdiv(n_words, kWordsPerBlock);
     const u32 y_est = (u32)std::min<u64>(y_all, std::max<u64>(16, cdiv((u32)std::min<u64>(2 * nq_est / 64 + 1, 0xFFFFFFF0u), kWordsPerBlock)));
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), std::min(y_est, 65535u)), dim3(256), 0, st,
-                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty,
-                       reinterpret_cast<unsigned char*>(rowmask));
+                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty);
 }
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail) {
     hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk,

@@ -71,8 +71,7 @@ void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands,
 // when *m_dirty != 0
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
                            const u32* n_q, u32* grp_any, const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles,
-                           const u32* m_dirty, u64* rowmask /* [rank groups][n_words]: bit = the query row holds a bit */,
-                           u64 nq_est);
+                           const u32* m_dirty, u64 nq_est /* the host's estimate of the dictionary size: sizes the grid */);
 // chk[0..5] (zeroed by the caller): non-monotonic marker, long-read count, offsets[0], offsets[n_reads]
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail /* zeroed */);
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
