@@ -392,11 +392,10 @@ struct skx_stream {
     u32 *d_pair_r[3] = {nullptr, nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[3] = {nullptr, nullptr, nullptr};
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
     // per-segment increments and their chunk sums (before the prefix), per buffer set: they depend on the pass's bit matrix
-    // only, not on the running table, so seg_sum / chunk_sum of pass i + 1 run (stream hs3) while pass i is still ranked (hs2)
+    // only, not on the running table, so seg_sum of pass i + 1 can run (stream hs3, SKX_RANK_SPLIT) while pass i is still ranked (hs2)
     u32* d_inc2[2] = {nullptr, nullptr};
     u32* d_csum_raw2[2] = {nullptr, nullptr};
     u32* d_csum = nullptr;        // exclusive prefix of the chunk sums (chunk_prefix)
-    u32* d_qsum = nullptr;        // [segments / 4][n_pad] seg_sum's sums over four segments (consumed by chunk_sum right behind it)
     hipStream_t hs3 = nullptr;    // aliases hs2 below pipeline depth 3
     hipEvent_t ev_inc[2] = {nullptr, nullptr};
     u32* d_leader = nullptr;      // [chunks of 16 segments][top_k] genomes ranked first as the chunk begins
@@ -474,7 +473,7 @@ static void stream_free(skx_stream* st) {
                     st->sd_sk[1], st->sd_len[1], st->sd_cnt[1], st->sd_poff[1], st->sd_big[1], st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc2[0], st->d_inc2[1] != st->d_inc2[0] ? st->d_inc2[1] : nullptr,
-                    st->d_csum, st->d_qsum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1]};
     for (void* p : ptrs) (void)hipFree(p);
@@ -650,7 +649,6 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_live, (size_t)n_seg_max * (n_pad / 64)));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
-    SCHK(hipMalloc(&st->d_qsum, (size_t)((n_seg_max + 3) / 4) * n_pad * 4));
     SCHK(hipMalloc(&st->d_csum_raw2[0], (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
     if (st->hs3 != st->hs2) SCHK(hipMalloc(&st->d_csum_raw2[1], (size_t)((n_seg_max + 15) / 16) * n_pad * 4)); else st->d_csum_raw2[1] = st->d_csum_raw2[0];
     SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * n_sp * std::max<u32>(top_k, 1) * 4 + 64));
@@ -910,9 +908,10 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     HIPCHK(hipStreamWaitEvent(hs3, st->ev_front[b], 0));
     if (update_table) {
         Span sp(st, 4, hs3);
+        // (the chunk sums are accumulated by seg_sum's workgroups: four atomic adds per chunk and genome)
+        HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * n_pad * 4, hs3));
         skx::launch_seg_sum(hs3, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
-                            st->d_qsum);
-        skx::launch_chunk_sum(hs3, st->d_qsum, n_seg, n_pad, d_csum_raw, d_grp_any);
+                            d_csum_raw);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(st->ev_inc[b], hs3));

@@ -1579,8 +1579,9 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     // XCD-aware task order: workgroups go round-robin to the 8 XCDs, each with its own 4 MB L2.  XCD x takes the
     // groups x, x+8, ... and walks them one after the other (all segments of a group before the next group), so the
     // rows being gathered -- one group's slice of Mq, 64 B x |Q| -- stay in that XCD's L2.
-    // A workgroup = four consecutive segments of one group; their sum (qsum[quarter chunk][g]) leaves with the increments,
-    // so that the chunk sums are built from 4 rows per chunk instead of re-reading all 16 segment rows (247 MB per batch).
+    // A workgroup = four consecutive segments of one group; their sum is added to the chunk's row of `qsum` (= the chunk
+    // sums csum_raw[chunk][g], zeroed by the caller: four workgroups per chunk, one coalesced atomic add each) as the
+    // increments leave -- no separate pass that re-reads all 16 segment rows of every chunk (247 MB per batch).
     __shared__ u32 red[4][kRankWords * 64];
     const u32 xcd = blockIdx.x & 7u, wv = threadIdx.x >> 6;
     const u32 n_q4 = (n_seg + 3u) / 4u, blk = blockIdx.x >> 3;
@@ -1681,8 +1682,8 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
 #pragma unroll
         for (u32 h = 0; h < 2u; ++h) {
             const u32 t = threadIdx.x + 256u * h;
-            if (grp * kRankWords * 64u + t < n_pad)
-                qsum[(size_t)seg4 * n_pad + grp * kRankWords * 64u + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+            const u32 v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+            if (grp * kRankWords * 64u + t < n_pad && v) atomicAdd(&qsum[(size_t)(seg4 >> 2) * n_pad + grp * kRankWords * 64u + t], v);
         }
     }
 }
@@ -1705,29 +1706,15 @@ __device__ __forceinline__ bool chunk_group_live(const u64* __restrict__ gmax, c
 
 // Segment start values, relative to the table at the start of the pass (32 bits: a pass gains at most its pair
 // count), in three levels so no thread walks a long chain and nothing is read twice:
-//   chunk_sum_kernel   : csum[c][g] = sum of inc over the 16 segments of chunk c
-//   chunk_prefix_kernel: csum[.][g] -> exclusive prefix over the chunks (in place);  cum_out[g] = cum_in[g] + total
+//   seg_sum_kernel     : csum_raw[c][g] = sum of inc over the 16 segments of chunk c (atomic adds of its workgroups' sums)
+//   chunk_prefix_kernel: csum[.][g] = exclusive prefix of csum_raw over the chunks;  cum_out[g] = cum_in[g] + total
 //   seg_prefix_kernel  : rel[seg][g] = csum[chunk of seg][g] + inc of the chunk's earlier segments
 // so that the running sum of genome g before the first read of segment seg is cum_in[g] + rel[seg][g].
-// grids: (n_pad/256, n_chunks), (n_pad/256), (n_pad/256, n_chunks)
-// (inc_is_q4: `inc` holds seg_sum's sums over 4 segments, n_seg counts those rows, 4 of them make a chunk)
-__global__ __launch_bounds__(256) void chunk_sum_kernel(const u32* __restrict__ inc, u32 n_seg, u32 n_pad,
-                                                        u32* __restrict__ csum, const u32* __restrict__ grp_any, u32 per_chunk) {
-    __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
-    const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
-    if (g >= n_pad) return;
-    if (!grp_any[blockIdx.x >> 1]) { csum[(size_t)c * n_pad + g] = 0; return; }  // (its increments were never written)
-    const u32 s0 = c * per_chunk, s1 = min(n_seg, s0 + per_chunk);
-    u32 t = 0;
-#pragma unroll 4
-    for (u32 sgi = s0; sgi < s1; ++sgi) t += inc[(size_t)sgi * n_pad + g];
-    csum[(size_t)c * n_pad + g] = t;
-}
-// One block per 256 genomes (half a rank group; n_pad is a multiple of 512).  The chunk sums are fetched sixteen at a time
-// (independent loads: the in-place update otherwise makes every load wait for the store before it -- 96 memory round
-// trips in a row, 200+ us next to the other streams' kernels, measured).  gmax != NULL: the best value of the block's
-// genomes at every chunk boundary (gmax[c][half], row n_chunks = as the pass ends) comes out of the same registers
-// (chunk_group_live's bound) instead of a separate 30 000-block launch.
+// chunk_prefix: one block per 256 genomes (half a rank group; n_pad is a multiple of 512).  The chunk sums are fetched 32
+// at a time into registers and the prefixes written elsewhere (in place every load waited for the store before it: 96
+// memory round trips in a row, 200+ us next to the other streams' kernels, measured).  gmax != NULL: the best value of
+// the block's genomes at every chunk boundary (gmax[c][half], row n_chunks = as the pass ends) comes out of the same
+// registers (chunk_group_live's bound) instead of a separate 30 000-block launch.
 __global__ __launch_bounds__(256) void chunk_prefix_kernel(const u32* __restrict__ csum_raw, u32* __restrict__ csum, u32 n_chunks,
                                                            u32 n_pad, const u64* __restrict__ cum_in, u64* __restrict__ cum_out,
                                                            u64* __restrict__ gmax, u32 n_half) {
@@ -2610,7 +2597,7 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any,
-                    u32* qsum /* [ceil(n_seg / 4)][n_pad]: sums over 4 segments */) {
+                    u32* qsum /* [ceil(n_seg / 16)][n_pad]: the chunk sums, zero on entry */) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     const u32 n_grp = cdiv(n_gw, kRankWords);
     // 8 XCDs x ceil(groups / 8) groups each x ceil(n_seg / 4) workgroups of 4 waves (= 4 consecutive segments)
@@ -2636,11 +2623,6 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
                        lead_val, n_pad / 256, sp, grp_any, cum_in, prune_top_k ? live : nullptr);  // (live: the caller's choice, top-1 path only)
 }
 // (the first level of launch_seg_prefix's three: needs only the increments, not the running table -- queued with seg_sum)
-// qsum: seg_sum's sums over 4 segments ([ceil(n_seg / 4)][n_pad])
-void launch_chunk_sum(hipStream_t st, const u32* qsum, u32 n_seg, u32 n_pad, u32* csum_raw, const u32* grp_any) {
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3(cdiv(n_pad, 256), cdiv(n_seg, 16)), dim3(256), 0, st, qsum, cdiv(n_seg, 4), n_pad, csum_raw,
-                       grp_any, 4u);
-}
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                      const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* grp_any) {
