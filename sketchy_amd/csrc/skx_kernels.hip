@@ -25,6 +25,9 @@
 #include "skx_common.hpp"
 #include "skx_kernels.hpp"
 
+#ifndef SKX_SCAN_OCC
+#define SKX_SCAN_OCC 1
+#endif
 #ifndef SKX_SEGSUM_PRIO
 #define SKX_SEGSUM_PRIO 2
 #endif
@@ -1150,7 +1153,7 @@ constexpr u32 kLeanWords = 5;  // query words a slice of <= kLeanCap entries can
 // NT: bit 0 = non-temporal slab stores, bit 1 = non-temporal loads of the matrix (it is streamed once per pass: marking its
 // lines evict-first keeps them from flushing what the kernels running beside the scan gather from -- Mq, the pair lists)
 template <int ABLATE, int NT = 0>
-__global__ __launch_bounds__(256) void scan_lean_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
+__global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                         const u64* __restrict__ q, const u32* __restrict__ win,
                                                         u64* __restrict__ m_bits, u32 n_pad, u64* __restrict__ hbuf,
                                                         u32* __restrict__ m_dirty, u32 prio) {
