@@ -925,7 +925,8 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         static const bool top1_wide_env = getenv("SKX_TOP1_WIDE") != nullptr;  // test knob: force the 64-bit-key kernel
         const bool top1_fast = st->top_k == 1 && ref->s < (1u << 15) && !top1_wide_env;
         static const bool live_env = !getenv("SKX_RANK_LIVE") || atoi(getenv("SKX_RANK_LIVE")) != 0;  // test knob
-        unsigned char* d_live = (top1_fast && ranked && live_env) ? st->d_live : nullptr;  // (only that kernel looks at the flags)
+        const bool topk_fast = !top1_fast && st->top_k && st->top_k <= skx::rank_topk_fast_max();
+        unsigned char* d_live = ((top1_fast || topk_fast) && ranked && live_env) ? st->d_live : nullptr;  // (the pruned kernels look at the flags)
         skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
                                st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
@@ -939,7 +940,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
             const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
             skx::launch_rank_seg_topk(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
                                       cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, d_inc, st->d_leader,
-                                      st->d_gmax, st->d_lead_val, d_grp_any);
+                                      st->d_gmax, st->d_lead_val, d_grp_any, d_live);
             skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, ra, spc);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,

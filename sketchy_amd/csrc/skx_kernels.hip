@@ -2180,7 +2180,8 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
                                                             u64* __restrict__ cand_sum, u32* __restrict__ cand_idx,
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
-                                                            const u64* __restrict__ lead_val, const u32* __restrict__ grp_any) {
+                                                            const u64* __restrict__ lead_val, const u32* __restrict__ grp_any,
+                                                            const unsigned char* __restrict__ live) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + 63u) / 64u, n_grp = (n_gw + NW - 1) / NW;
@@ -2198,6 +2199,20 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
     const bool dead = !grp_any[grp];  // no bit in the whole group: nothing was written for it, nothing to replay
     const u32 pa = poff[r_begin + ra] - p_base, pz = dead ? pa : poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
+    // words none of whose genomes can reach the chunk's k-th value by the end of the segment (seg_prefix_kernel's flags:
+    // no start values were stored for them): usually the whole group, which then reports "none" without loading anything
+    u32 livew = 0xFFu;
+    if (!dead && live) {
+        const u32 gwl = grp * NW + (lane & (NW - 1));
+        livew = (u32)__ballot(lane < (u32)NW && gwl < n_gw && live[(size_t)seg * n_gw + gwl] != 0) & 0xFFu;
+        if (livew == 0u) {
+            if (lane < rz - ra) {
+                const size_t o = ((size_t)(ra + lane) * n_grp + grp) * top_k;
+                for (u32 j = 0; j < top_k; ++j) { cand_sum[o + j] = 0; cand_idx[o + j] = 0xFFFFFFFFu; }
+            }
+            return;
+        }
+    }
     // lower bound of the k-th best sum (of this group's species) over the segment
     const u32 spi = sp.of_grp[grp], sp_end = sp.g0[spi] + sp.n[spi];
     u64 lead = ~0ull;
@@ -2211,7 +2226,7 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const u32 g = g0 + (u32)j * 64u;
-        const bool real = g < sp_end;
+        const bool real = g < sp_end && ((livew >> j) & 1u);
         sum[j] = real ? cum_in[g] + (dead ? 0u : rel[(size_t)seg * n_pad + g]) : 0;
         const u32 ic = (real && !dead) ? inc[(size_t)seg * n_pad + g] : 0;
         cand[j] = real && sum[j] + ic >= lead;
@@ -2646,11 +2661,11 @@ void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, 
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
-                          const u64* gmax, const u64* lead_val, const u32* grp_any) {
+                          const u64* gmax, const u64* lead_val, const u32* grp_any, const unsigned char* live) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_topk_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, mq, n_gw, n_pad, sp, cum_in, rel, top_k, cand_sum, cand_idx, nq_rows,
-                       inc, leader, gmax, lead_val, grp_any);
+                       inc, leader, gmax, lead_val, grp_any, live);
 }
 u32 rank_topk_fast_max() { return kTopkFast; }
 u32 rank_leader_parts() { return kLeaderParts; }

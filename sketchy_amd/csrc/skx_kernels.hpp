@@ -105,7 +105,7 @@ void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, 
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
-                          const u64* gmax, const u64* lead_val, const u32* grp_any);
+                          const u64* gmax, const u64* lead_val, const u32* grp_any, const unsigned char* live);
 u32 rank_topk_fast_max();
 // rows come out per (read, species) with genome indices local to the species: out[((out_r0 + r) * n_sp + sp) * top_k + j]
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32* out_idx, u64* out_sum,
