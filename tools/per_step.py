@@ -2,7 +2,7 @@
 """usage: per_step.py kernel_trace.csv -- duration (us) of the main kernels per launch, in launch order (one column per kernel)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-names = ["sketch_wave_kernel<16, 256", "scan_lean_kernel", "transpose_bits", "seg_sum", "chunk_sum", "chunk_prefix", "seg_prefix", "rank_seg_top1", "dict_insert"]
+names = ["sketch_wave_kernel<16, 256", "scan_lean_kernel", "transpose_bits", "seg_sum", "chunk_prefix", "seg_prefix", "rank_seg_top", "k_merge", "top1_merge", "chunk_leader_part", "dict_insert"]
 cols = {n: [] for n in names}
 for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
     for n in names:
