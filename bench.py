@@ -374,7 +374,44 @@ def main():
                                          "what": "batches in page-locked host memory, skx_stream_submit (H2D of batch i+1 overlaps the "
                                                  "kernels of batch i), rows copied back to the host; PCIe-bound when the GPU step is "
                                                  "shorter than the copy"}
-            for h in h_b + h_o + h_ti + h_ts:
+            # value_host_fed_packed: the same with the bases as 4 bits each (skx_pack_bases on the host, outside the timed
+            # loop -- a FASTQ parser would pack as it parses): half of the bytes over PCIe
+            from sketchy_amd import _lib
+            L = _lib.load()
+            h_p = []
+            for j in range(n_h):
+                hp = api.HostBuffer(batch_bases[j] // 2 + 2, dev)
+                pos = int(L.skx_pack_bases(h_b[j].ptr, batch_bases[j], hp.ptr, 0))
+                assert pos == batch_bases[j]  # (the synthetic reads hold no whitespace: offsets are the same in bases)
+                h_p.append(hp)
+            S.set_packed_input(True)
+            S.reset()
+            for i in range(2):
+                S.submit(h_p[i % n_h].ptr, h_o[i % n_h].ptr, B, h_ti[i & 1].ptr, h_ts[i & 1].ptr)
+            S.drain()
+            rows_packed = h_ti[1].view(np.uint32, B * rows).copy()
+            shard.barrier()
+            tc = time.perf_counter()
+            for i in range(n_sub):
+                S.submit(h_p[i % n_h].ptr, h_o[i % n_h].ptr, B, h_ti[i & 1].ptr, h_ts[i & 1].ptr)
+            S.drain()
+            t_pack = shard.max_over_ranks(time.perf_counter() - tc)
+            S.set_packed_input(False)
+            # (same reads, same table history as the ASCII warm-up above: the rows of its second batch must be identical)
+            S.reset()
+            for i in range(2):
+                S.submit(h_b[i % n_h].ptr, h_o[i % n_h].ptr, B, h_ti[i & 1].ptr, h_ts[i & 1].ptr)
+            S.drain()
+            packed_ok = bool(np.array_equal(rows_packed, h_ti[1].view(np.uint32, B * rows)))
+            if rank == 0:
+                out["value_host_fed_packed"] = {"value": n_sub * B * world / t_pack, "unit": "reads/s", "steps": n_sub,
+                                                "h2d_GBps_per_gpu": n_sub * (bytes_in - float(np.mean(batch_bases[:n_h])) / 2) / t_pack / 1e9,
+                                                "rows_match_ascii": packed_ok,
+                                                "what": "the same with 4-bit packed bases (skx_stream_set_packed_input; packed on the host "
+                                                        "before the timed loop): half the bytes over PCIe"}
+            if not packed_ok:
+                err = err or "rows of a 4-bit packed batch differ from the same batch as ASCII"
+            for h in h_b + h_o + h_ti + h_ts + h_p:
                 h.free()
         if not args.no_profile:
             # per-stage breakdown from a few extra, untimed steps with every stage bracketed by events

@@ -134,6 +134,19 @@ int skx_stream_push_device(skx_stream *st, const uint8_t *d_bases, const uint64_
 int skx_stream_enqueue_device(skx_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
                               uint64_t n_bases, uint32_t *d_topk_idx, uint64_t *d_topk_sum);
 int skx_stream_flush(skx_stream *st);
+/*
+ * 4-bit packed input (optional; the reference reads ASCII FASTX: src/sketchy.rs:328-333 -- this is a wire format for
+ * hosts that feed the device over PCIe, where a 98 304-read batch of 1.5 kb reads is 147 MB of ASCII and the copy,
+ * not the kernels, bounds a host-fed stream).  After skx_stream_set_packed_input(st, 1) every entry point of the stream
+ * takes `bases` as two bases per byte, low nibble first, codes 0..3 = A C G T(U), any other value = a retained
+ * non-ACGT byte (N, IUPAC, '-': breaks k-mers exactly as in the ASCII path); whitespace does not exist in this format.
+ * `offsets` (and n_bases / max_batch_bases) count BASES, i.e. nibbles of the stream; a read may start on an odd
+ * nibble.  skx_pack_bases() is the matching host-side packer: it appends the normalised bases of `ascii[0..n)`
+ * (whitespace dropped) at nibble position `nibble_pos` of `packed` and returns the new position.  Rows, tables and
+ * debug outputs are those of the same reads given as ASCII.
+ */
+int skx_stream_set_packed_input(skx_stream *st, int on);
+uint64_t skx_pack_bases(const uint8_t *ascii, uint64_t n, uint8_t *packed, uint64_t nibble_pos);
 int skx_stream_sync(skx_stream *st);
 /*
  * Host-fed pipeline.  skx_stream_submit() queues a batch from PAGE-LOCKED host buffers (skx_host_alloc; bases, offsets

@@ -39,6 +39,8 @@ SYMBOLS = [
     ("skx_stream_push_device", _i, [_vp, _vp, _vp, _u32, _u64, _vp, _vp]),
     ("skx_stream_enqueue_device", _i, [_vp, _vp, _vp, _u32, _u64, _vp, _vp]),
     ("skx_stream_flush", _i, [_vp]),
+    ("skx_stream_set_packed_input", _i, [_vp, _i]),
+    ("skx_pack_bases", _u64, [_vp, _u64, _vp, _u64]),
     ("skx_stream_sync", _i, [_vp]),
     ("skx_stream_submit", _i, [_vp, _vp, _vp, _u32, _vp, _vp, C.POINTER(_u64)]),
     ("skx_stream_wait", _i, [_vp, _u64]),

@@ -16,6 +16,26 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def pack_reads(bases, offsets, first_nibble=0):
+    """ASCII reads (bases, offsets as for push()) -> (packed uint8 array, uint64 offsets in bases): two bases per byte, low
+    nibble first, whitespace dropped, everything not ACGTU -> 4 (skx_pack_bases).  first_nibble: start the stream at that
+    nibble (tests: reads on odd nibbles)."""
+    L = _lib.load()
+    bases = np.ascontiguousarray(bases, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    n = len(offsets) - 1
+    packed = np.zeros((first_nibble + len(bases) + 1) // 2 + 1, np.uint8)
+    out = np.zeros(n + 1, np.uint64)
+    pos = int(first_nibble)
+    out[0] = pos
+    for r in range(n):
+        a, b = int(offsets[r]), int(offsets[r + 1])
+        if b > a:
+            pos = int(L.skx_pack_bases(bases[a:b].ctypes.data_as(C.c_void_p), b - a, _p(packed), pos))
+        out[r + 1] = pos
+    return packed[: (pos + 1) // 2 + 1], out
+
+
 def device_count() -> int:
     return _lib.load().skx_device_count()
 
@@ -127,6 +147,10 @@ class SumOfSharedHashes:
 
     def flush(self):
         _lib.check(_lib.load().skx_stream_flush(self._h))
+
+    def set_packed_input(self, on=True):
+        """From now on `bases` of every entry point are 4-bit packed (pack_reads()), offsets count bases."""
+        _lib.check(_lib.load().skx_stream_set_packed_input(self._h, int(bool(on))))
 
     def sync(self):
         _lib.check(_lib.load().skx_stream_sync(self._h))

@@ -371,6 +371,7 @@ struct skx_stream {
     int pslot = 0;                                          // slot of the next pass
     hipEvent_t ev_pairq[2] = {nullptr, nullptr};            // scan stream: the set's hash set / pair hashes have been consumed
     bool pairq_pending[2] = {false, false};
+    bool packed = false;  // the stream's input is 4 bits per base (skx_stream_set_packed_input): offsets count bases
     u32 top_k = 0, max_reads = 0, sk_stride = 0;
     u64 max_bases = 0;
     u32 pcap = 0;        // pairs per pass
@@ -1073,7 +1074,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         (void)hipGetLastError();  // (hipErrorNotReady is not an error)
         HIPCHK(skx::launch_sketch(hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, pb.inrange_only,
                                   st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big,
-                                  pb.n_bases, st->d_chk, leave_room));
+                                  pb.n_bases, st->d_chk, leave_room, st->packed));
         if (!pb.inrange_only) {
             // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
             // not the fast one -- read the count back and run the block sketcher before the rows are copied out
@@ -1081,7 +1082,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
             HIPCHK(hipMemcpyAsync(&n_big, st->d_big, 4, hipMemcpyDeviceToHost, hs));
             HIPCHK(hipStreamSynchronize(hs));
             HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s, max_ref,
-                                            false, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift));
+                                            false, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->packed));
             st->reads_big += n_big;
             HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
         }
@@ -1134,7 +1135,8 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
             // published summary once more.
             st->reads_big += c[7];
             HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s, max_ref,
-                                            pb.inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift));
+                                            pb.inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift,
+                                            st->packed));
             SKXCHK(finish_counts(st, pb));
             SKXCHK(wait_published(st, pb));
             if (st->h_chk[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases given from offsets[0] on");
@@ -1240,10 +1242,12 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     SKXCHK(use_device(st->device));
     SKXCHK(flush_pending(st));
     hipStream_t hs = st->hs0;
-    // rebase offsets to 0 on the way in
-    for (u32 r = 0; r <= n_reads; ++r) st->h_offsets[r] = offsets[r] - base0;
+    // rebase offsets to 0 on the way in (packed input: to the first byte that holds a base of the batch)
+    const u64 byte0 = st->packed ? base0 >> 1 : base0, rebase = st->packed ? byte0 * 2 : base0;
+    const u64 n_bytes = st->packed ? ((offsets[n_reads] + 1) >> 1) - byte0 : n_bases;
+    for (u32 r = 0; r <= n_reads; ++r) st->h_offsets[r] = offsets[r] - rebase;
     HIPCHK(hipMemcpyAsync(st->d_offsets, st->h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, hs));
-    if (n_bases) HIPCHK(hipMemcpyAsync(st->d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, hs));
+    if (n_bases) HIPCHK(hipMemcpyAsync(st->d_bases, bases + byte0, n_bytes, hipMemcpyHostToDevice, hs));
     SKXCHK(process_batch(st, st->d_bases, st->d_offsets, n_reads, n_bases, st->d_topk_idx, st->d_topk_sum,
                          per_read_shared, reinterpret_cast<u64*>(sketches), sketch_len));
     HIPCHK(hipStreamSynchronize(hs));  // sketch copies (first stream)
@@ -1346,9 +1350,11 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     // ... then this slot's previous batch (two tickets ago) must be through -- passes queued, rows on the host -- while
     // the device works on
     SKXCHK(staged_finish(st, sl));
-    for (u32 r = 0; r <= n_reads; ++r) sl.h_offsets[r] = offsets[r] - base0;
+    const u64 byte0 = st->packed ? base0 >> 1 : base0, rebase = st->packed ? byte0 * 2 : base0;
+    const u64 n_bytes = st->packed ? ((offsets[n_reads] + 1) >> 1) - byte0 : n_bases;
+    for (u32 r = 0; r <= n_reads; ++r) sl.h_offsets[r] = offsets[r] - rebase;
     HIPCHK(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st->hs_copy));
-    if (n_bases) HIPCHK(hipMemcpyAsync(sl.d_bases, bases + base0, n_bases, hipMemcpyHostToDevice, st->hs_copy));
+    if (n_bases) HIPCHK(hipMemcpyAsync(sl.d_bases, bases + byte0, n_bytes, hipMemcpyHostToDevice, st->hs_copy));
     HIPCHK(hipEventRecord(sl.ev_copy, st->hs_copy));
     sl.pending = true; sl.n_reads = n_reads; sl.n_bases = n_bases; sl.out_idx = topk_idx; sl.out_sum = reinterpret_cast<u64*>(topk_sum);
     sl.ticket = st->next_ticket;
@@ -1383,6 +1389,26 @@ SKX_API int skx_stream_drain(skx_stream* st) {
     return skx_stream_sync(st);
 }
 
+SKX_API int skx_stream_set_packed_input(skx_stream* st, int on) {
+    if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
+    SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));
+    for (auto& sl : st->slot)
+        if (sl.pending || sl.in_flight) return fail(SKX_ERR_INVALID, "drain the submitted batches before changing the input format");
+    st->packed = on != 0;
+    return SKX_OK;
+}
+// host helper (no device involved): ASCII -> 4-bit codes, appended at nibble position `nibble_pos` of `packed`
+SKX_API uint64_t skx_pack_bases(const uint8_t* ascii, uint64_t n, uint8_t* packed, uint64_t nibble_pos) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const u32 code = skx::classify_base(ascii[i]);
+        if (code == 5u) continue;  // whitespace does not exist in the packed format
+        uint8_t& b = packed[nibble_pos >> 1];
+        b = (nibble_pos & 1ull) ? (uint8_t)((b & 0x0Fu) | (code << 4)) : (uint8_t)code;  // (an even nibble starts its byte afresh)
+        ++nibble_pos;
+    }
+    return nibble_pos;
+}
 SKX_API int skx_stream_sync(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));

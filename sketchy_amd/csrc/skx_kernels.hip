@@ -178,13 +178,51 @@ __device__ __forceinline__ u32 wave_normalise4(const uint8_t* __restrict__ rd, u
     return nb;
 }
 
+// 4-bit packed input (skx_stream_set_packed_input): nibble i of the stream = base i, low nibble of a byte first; 0..3 = A C G T,
+// anything else = a retained non-ACGT byte (N).  Whitespace does not exist in this format (skx_pack_bases drops it).
+__device__ __forceinline__ u32 packed_code(const uint8_t* __restrict__ bases, u64 nib) {
+    const u32 v = ((u32)bases[nib >> 1] >> (4u * (u32)(nib & 1ull))) & 0xFu;
+    return v > 3u ? 4u : v;
+}
+// wave_normalise4 for packed input: bases [nib0 + from, nib0 + to) -> codes[nb ...] (nb a multiple of 4: whole words)
+__device__ __forceinline__ u32 wave_normalise_packed(const uint8_t* __restrict__ bases, u64 nib0, u32 from, u32 to, uint8_t* codes,
+                                                     u32 nb, u32 lane) {
+    for (u32 base = from; base < to; base += 256u) {
+        const u32 idx = base + 4u * lane;
+        const u32 have = idx < to ? min(4u, to - idx) : 0u;
+        u32 w = 0;
+        if (have) {
+            const u64 p = nib0 + idx;
+            u32 x = 0;
+            if (idx + 8u <= to) {  // (8 nibbles of the read from here on: one dword covers the 4 wanted at either parity)
+                __builtin_memcpy(&x, bases + (p >> 1), 4);
+                x >>= 4u * (u32)(p & 1ull);
+            } else if (have == 4u) {  // 4 nibbles from bit 4 * (p & 1) of two or three bytes
+                const uint8_t* src = bases + (p >> 1);
+                x = (u32)src[0] | ((u32)src[1] << 8) | ((p & 1ull) ? ((u32)src[2] << 16) : 0u);
+                x >>= 4u * (u32)(p & 1ull);
+            } else {
+                for (u32 b = 0; b < have; ++b) x |= (((u32)bases[(p + b) >> 1] >> (4u * (u32)((p + b) & 1ull))) & 0xFu) << (4u * b);
+            }
+            w = (x & 0xFu) | ((x & 0xF0u) << 4) | ((x & 0xF00u) << 8) | ((x & 0xF000u) << 12);
+            const u32 inv = ((w >> 1) | w) & 0x04040404u;  // nibble > 3
+            w = ((w & 0x03030303u) & ~((inv >> 2) * 3u)) | inv;
+        }
+        uint8_t* dst = codes + nb + 4u * lane;
+        if (have == 4u) *reinterpret_cast<u32*>(dst) = w;
+        else for (u32 b = 0; b < have; ++b) dst[b] = (uint8_t)(w >> (8u * b));
+        nb += min(256u, to - base);
+    }
+    return nb;
+}
+
 template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, const uint8_t* __restrict__ bases,
                                                 const u64* __restrict__ offsets, u32 k_rt, u64 seed, u32 s, u64 max_ref,
                                                 u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                 u32* __restrict__ out_cnt_in, u32* __restrict__ retry, u32* __restrict__ big,
                                                 const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
-                                                u32* __restrict__ chk, const unsigned char* lut) {
+                                                u32* __restrict__ chk, const unsigned char* lut, bool packed) {
     constexpr u32 CAP = kSketchCap;
     constexpr u32 kPerWave = HCAP * 8 + CAP + 128;  // (32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding)
     constexpr u32 kChunkAt = 32;                    // a chunk's codes start here; the carried k-1 end here
@@ -235,7 +273,8 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         const u32 cend = min(lraw, cbase + CAP);
         // 1. normalise the chunk behind the carried codes
         const u32 cs = kChunkAt - carry;  // first code of the buffer
-        const u32 ne = __builtin_amdgcn_readfirstlane(wave_normalise4(rd, cbase, cend, codes, kChunkAt, lane, lut));  // one past the last
+        const u32 ne = __builtin_amdgcn_readfirstlane(packed ? wave_normalise_packed(bases, o0, cbase, cend, codes, kChunkAt, lane)
+                                                             : wave_normalise4(rd, cbase, cend, codes, kChunkAt, lane, lut));  // one past the last
         codes[ne + lane] = 4;  // 64 invalid codes behind the chunk: lanes past the last window read them unconditionally
         wave_sync();
         // 2. canonical k-mer hashes of the windows that END in this chunk, compacted
@@ -464,6 +503,8 @@ template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, unsigned char* lut) {
     fill_base_lut(lut);
     __syncthreads();
+    const bool packed = (from_list & 0x100u) != 0u;  // (bit 8: 4-bit packed input)
+    from_list &= 0xFFu;
     const u32 wpb = blockDim.x >> 6;  // waves per block: 4, or 1 for the list walk (see launch_sketch)
     u32 w = blockIdx.x * wpb + (threadIdx.x >> 6);
     if (from_list == 2u) {
@@ -480,13 +521,13 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
     if (from_list != 1u) {
         if (w < n_reads)
             sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
-                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut);
+                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut, packed);
         return;
     }
     const u32 n = retry[0];
     for (u32 i = w; i < n; i += gridDim.x * wpb) {
         sketch_one_read<KT, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
-                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut);
+                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut, packed);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
 }
@@ -547,7 +588,7 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
                                                             const u32* __restrict__ big, u32 n_big, u32 k_rt, u64 seed, u32 s,
                                                             u64 max_ref, u64* __restrict__ out_sk, u32 sk_stride,
                                                             u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
-                                                            const u32* __restrict__ filt, u32 filt_shift) {
+                                                            const u32* __restrict__ filt, u32 filt_shift, u32 packed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ BlockScratch sh;
     u64* hashes = reinterpret_cast<u64*>(smem);
@@ -616,7 +657,7 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
                 // 1. normalise the chunk behind the carried codes (sh.nb holds the carry)
                 for (u32 base = cbase; base < cend; base += 1024u) {
                     const u32 idx = base + tid;
-                    const u32 code = classify_base(idx < cend ? (u32)rd[idx] : (u32)' ');
+                    const u32 code = idx >= cend ? 5u : packed ? packed_code(bases, o0 + idx) : classify_base((u32)rd[idx]);
                     const bool kp = code != 5u;
                     u32 tot;
                     const u32 pos = sh.nb + block_rank(kp, sh, tot);
@@ -2396,7 +2437,7 @@ static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketch
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, bool leave_room) {
+                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, bool leave_room, bool packed) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
     // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 11 KB: 5 instead of 8 of its blocks fit a CU), which leaves
@@ -2448,8 +2489,8 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
 #define SKX_SK_LAUNCH(KERNEL, LDS, FROM_LIST)                                                                              \
     hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid,                        \
                        dim3((FROM_LIST) == 1u ? 64 : 256), (FROM_LIST) == 1u ? (LDS) / 4 : (LDS), st, bases,                \
-                       offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, FROM_LIST, retry, big,   \
-                       filt, filt_shift, n_bases, chk)
+                       offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in,                          \
+                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk)
     (void)blk_grid;
     if (inrange_only) {
         // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
@@ -2477,12 +2518,12 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
 // (40-80 us on the sketch stream per push, measured) -- and it almost always is.
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                               const u32* filt, u32 filt_shift) {
+                               const u32* filt, u32 filt_shift, bool packed) {
     if (n_big == 0) return hipSuccess;
     const dim3 blk_grid(std::min<u32>(n_big, 256u));
 #define SKX_BLK_LAUNCH(KERNEL)                                                                                              \
     hipLaunchKernelGGL((KERNEL), blk_grid, dim3(1024), kBigLds, st, bases, offsets, big, n_big, k, seed, s, max_ref, out_sk, \
-                       sk_stride, out_len, out_cnt_in, filt, filt_shift)
+                       sk_stride, out_len, out_cnt_in, filt, filt_shift, packed ? 1u : 0u)
     if (k == 16) { if (inrange_only) SKX_BLK_LAUNCH((sketch_block_kernel<16, true>)); else SKX_BLK_LAUNCH((sketch_block_kernel<16, false>)); }
     else { if (inrange_only) SKX_BLK_LAUNCH((sketch_block_kernel<0, true>)); else SKX_BLK_LAUNCH((sketch_block_kernel<0, false>)); }
 #undef SKX_BLK_LAUNCH

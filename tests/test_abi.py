@@ -73,3 +73,23 @@ def test_product_package_never_touches_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|orc_", txt, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_pack_bases_helper_matches_the_normalisation_rules():
+    """skx_pack_bases (host-side, no device): ACGTU in either case -> 0..3, any other retained byte -> 4, whitespace dropped;
+    two bases per byte, low nibble first; appending at an odd nibble keeps the nibble already there."""
+    import ctypes as C
+    import numpy as np
+    from sketchy_amd import _lib
+    L = _lib.load()
+    text = b"ACGTUacgtuNnRy-.* \t\r\nXA"
+    src = np.frombuffer(text, np.uint8)
+    out = np.full(32, 0xEE, np.uint8)
+    out[0] = 0x07  # an earlier base in the low nibble of byte 0
+    pos = int(L.skx_pack_bases(src.ctypes.data_as(C.c_void_p), len(src), out.ctypes.data_as(C.c_void_p), 1))
+    kept = [c for c in text if c not in b" \t\r\n"]
+    assert pos == 1 + len(kept)
+    codes = [(int(out[i >> 1]) >> (4 * (i & 1))) & 0xF for i in range(pos)]
+    assert codes[0] == 7
+    want = [{65: 0, 67: 1, 71: 2, 84: 3, 85: 3}.get(c & 0xDF if chr(c).isalpha() else c, 4) for c in kept]
+    assert codes[1:] == want
