@@ -151,7 +151,7 @@ int skx_stream_sync(skx_stream *st);
 /*
  * Host-fed pipeline.  skx_stream_submit() queues a batch from PAGE-LOCKED host buffers (skx_host_alloc; bases, offsets
  * and the optional row arrays) and returns without waiting for it: the host-to-device copy of batch i+1 runs on its
- * own stream into the second staging slot while batch i is sketched, scanned and ranked.  Processing lags one call
+ * own stream into another staging slot (there are three) while batch i is sketched, scanned and ranked.  Processing lags one call
  * behind submission (submit(i) starts the copy of batch i, then runs batch i-1 through the kernels), so a single host
  * thread keeps the copy engine and the kernels busy at the same time -- what needletail's reader plus the loop of
  * src/sketchy.rs:328-354 would look like with the device in between.  Rows of batch `ticket` ([n_reads][n_species]

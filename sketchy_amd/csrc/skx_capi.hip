@@ -438,7 +438,7 @@ struct skx_stream {
     u32* d_bsum = nullptr;   // block totals of the pair-count scan
     u64 reads_big = 0;       // reads that went through the block sketcher so far (statistic)
     u64 last_pairs = 0, last_passes = 0, total_passes = 0, lean_passes = 0;  // statistics (skx_stream_stats)
-    // host-fed pipeline (skx_stream_submit): two staging slots, a copy stream, one batch of lag
+    // host-fed pipeline (skx_stream_submit): three staging slots, a copy stream, one batch of lag
     struct Staged {
         bool pending = false;   // copied (or being copied) to the device, not yet processed
         bool in_flight = false; // processed, rows possibly still on their way to the host
@@ -449,7 +449,7 @@ struct skx_stream {
         uint8_t* d_bases = nullptr;
         u64 *d_offsets = nullptr, *h_offsets = nullptr;
         hipEvent_t ev_copy = nullptr, ev_done = nullptr;
-    } slot[2];
+    } slot[3];  // (three: the copy of batch i starts once batch i - 3 is through, not i - 2)
     hipStream_t hs_copy = nullptr;
     u64 next_ticket = 0;
     u32* h_nq = nullptr;     // pinned [2]
@@ -1332,7 +1332,7 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     if (n_bases && !bases) return fail(SKX_ERR_INVALID, "bases is NULL");
     if ((topk_idx || topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
     SKXCHK(use_device(st->device));
-    if (!st->hs_copy) {  // first use: copy stream + two staging slots
+    if (!st->hs_copy) {  // first use: copy stream + three staging slots
         HIPCHK(hipStreamCreateWithFlags(&st->hs_copy, hipStreamNonBlocking));
         for (auto& sl : st->slot) {
             HIPCHK(hipMalloc(&sl.d_bases, std::max<u64>(st->max_bases, 1)));
@@ -1342,12 +1342,12 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
             HIPCHK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
         }
     }
-    skx_stream::Staged& sl = st->slot[st->next_ticket & 1u];
-    skx_stream::Staged& other = st->slot[(st->next_ticket & 1u) ^ 1u];
+    skx_stream::Staged& sl = st->slot[st->next_ticket % 3u];
+    skx_stream::Staged& other = st->slot[(st->next_ticket + 2u) % 3u];  // (the previous ticket's)
     // the previous batch goes to the kernels first (its sketch is queued, and the passes of the batch before it) ...
     SKXCHK(staged_process(st, other));
     if (other.ev_copy && other.ticket + 1 == st->next_ticket) HIPCHK(hipEventSynchronize(other.ev_copy));  // its host buffers are free again
-    // ... then this slot's previous batch (two tickets ago) must be through -- passes queued, rows on the host -- while
+    // ... then this slot's previous batch (three tickets ago) must be through -- passes queued, rows on the host -- while
     // the device works on
     SKXCHK(staged_finish(st, sl));
     const u64 byte0 = st->packed ? base0 >> 1 : base0, rebase = st->packed ? byte0 * 2 : base0;
@@ -1366,10 +1366,12 @@ SKX_API int skx_stream_wait(skx_stream* st, uint64_t ticket) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     if (ticket >= st->next_ticket) return fail(SKX_ERR_INVALID, "ticket %llu was never issued", (unsigned long long)ticket);
     SKXCHK(use_device(st->device));
-    skx_stream::Staged& sl = st->slot[ticket & 1u];
+    skx_stream::Staged& sl = st->slot[ticket % 3u];
     if (sl.ticket != ticket) return SKX_OK;  // the slot has moved on: that batch completed before it was reused
-    skx_stream::Staged& older = st->slot[(ticket & 1u) ^ 1u];
-    if (older.pending && older.ticket < ticket) SKXCHK(staged_process(st, older));  // (in submission order)
+    for (u64 t = ticket >= 2 ? ticket - 2 : 0; t < ticket; ++t) {  // (in submission order)
+        skx_stream::Staged& older = st->slot[t % 3u];
+        if (older.pending && older.ticket == t) SKXCHK(staged_process(st, older));
+    }
     SKXCHK(staged_finish(st, sl));
     if (st->profiling) collect_spans(st);
     return SKX_OK;
@@ -1378,10 +1380,9 @@ SKX_API int skx_stream_drain(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
     // oldest first
-    const u32 first = (u32)(st->next_ticket & 1u);
-    for (u32 i = 0; i < 2; ++i) {
-        skx_stream::Staged& sl = st->slot[(first + i) & 1u];
-        SKXCHK(staged_process(st, sl));
+    for (u64 t = st->next_ticket >= 3 ? st->next_ticket - 3 : 0; t < st->next_ticket; ++t) {
+        skx_stream::Staged& sl = st->slot[t % 3u];
+        if (sl.pending && sl.ticket == t) SKXCHK(staged_process(st, sl));
     }
     SKXCHK(flush_pending(st));
     for (auto& sl : st->slot)
