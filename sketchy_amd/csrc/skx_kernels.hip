@@ -2281,19 +2281,28 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
         auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
             if (cur >= r_stop) return;
             const bool mine = lane >= cur - ra && lane < r_stop - ra;
+            // keys of this lane's candidates, once per emit (words without any candidate -- usually seven of the eight -- are
+            // skipped: wave-uniform); then one wave-wide maximum per rank, stopping at the first rank nobody fills
+            u64 keys[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                keys[w] = ((wmask >> w) & 1u) && cand[w] ? (((sum[w] + 1ull) << SH) | ((u64)(NW - 1 - w) << 6) | (63u - lane)) : 0ull;
             u64 prev = ~0ull;
+            bool more = true;  // wave-uniform
 #pragma unroll
             for (u32 j = 0; j < kTopkFast; ++j) {
                 if (j < top_k) {
-                    u64 k = 0;
+                    u64 best = 0;
+                    if (more) {
+                        u64 k = 0;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const u64 key = cand[w] ? (((sum[w] + 1ull) << SH) | ((u64)(NW - 1 - w) << 6) | (63u - lane)) : 0ull;
-                        if (key < prev) k = max(k, key);
+                        for (int w = 0; w < NW; ++w)
+                            if ((wmask >> w) & 1u) { if (keys[w] < prev) k = max(k, keys[w]); }
+                        best = wave_max_u64(k);  // 0: fewer than j+1 candidates in this group
+                        more = best != 0ull;
                     }
-                    const u64 best = wave_max_u64(k);  // 0: fewer than j+1 candidates in this group
                     if (mine) res[j] = best;
-                    prev = best ? best : 0ull;         // (0 ends it: nothing is below 0)
+                    prev = best;                  // (0 ends it: nothing is below 0)
                 }
             }
             cur = r_stop;
