@@ -1997,7 +1997,8 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
 __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__ cand_sum,
                                                          const u32* __restrict__ cand_idx, u32 n_reads, u32 n_units,
                                                          u32 per_grp, u32 top_k, u32* __restrict__ out_idx,
-                                                         u64* __restrict__ out_sum, u32 out_r0, Species sp) {
+                                                         u64* __restrict__ out_sum, u32 out_r0, Species sp,
+                                                         const unsigned char* __restrict__ has /* [seg][n_units] or NULL */) {
     const u32 w = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
     const u32 r = w / sp.n_sp, spi = w % sp.n_sp;
     if (r >= n_reads) return;
@@ -2009,6 +2010,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__
     for (u32 j = 0; j < top_k; ++j) {
         u64 bs = 0; u32 bi = 0xFFFFFFFFu;
         for (u32 c = lane; c < n_cand; c += 64u) {
+            if (has && !has[(size_t)(r >> 6) * n_units + grp0 + c / top_k]) continue;  // (pruned path: unit = rank group)
             const u64 s_ = cs[c]; const u32 i_ = ci[c];
             if (i_ == 0xFFFFFFFFu) continue;
             if (!first && !ranks_before(ps, pi, s_, i_)) continue;
@@ -2052,7 +2054,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
                                                             const u64* __restrict__ lead_val, const u32* __restrict__ grp_any,
-                                                            const unsigned char* __restrict__ live) {
+                                                            const unsigned char* __restrict__ live, unsigned char* __restrict__ has) {
     __builtin_amdgcn_s_setprio(SKX_RANK1_PRIO);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
@@ -2065,11 +2067,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp, sp)) {  // (its start values were not even written)
-        if (lane < rz - ra) {
-            const size_t o = (size_t)grp * n_reads + ra + lane;
-            best_sum[o] = 0;
-            best_idx[o] = 0xFFFFFFFFu;
-        }
+        if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;  // nothing to report: the merge skips this (segment, group)
         return;
     }
     const u32 spi = sp.of_grp[grp], sp_end = sp.g0[spi] + sp.n[spi];
@@ -2097,11 +2095,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         const u32 gwl = grp * NW + (lane & (NW - 1));
         livew = (u32)__ballot(lane < (u32)NW && gwl < n_gw && live[(size_t)seg * n_gw + gwl] != 0) & 0xFFu;
         if (livew == 0u) {
-            if (lane < rz - ra) {
-                const size_t o = (size_t)grp * n_reads + ra + lane;
-                best_sum[o] = 0;
-                best_idx[o] = 0xFFFFFFFFu;
-            }
+            if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;
             return;
         }
     }
@@ -2137,11 +2131,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         if (__ballot(cand)) wmask |= 1u << j;
     }
     if (wmask == 0) {
-        if (lane < rz - ra) {
-            const size_t o = (size_t)grp * n_reads + ra + lane;
-            best_sum[o] = 0;
-            best_idx[o] = 0xFFFFFFFFu;
-        }
+        if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;  // nothing to report: the merge skips this (segment, group)
         return;
     }
     const u64 base = lead - gain - 1u;  // winner sum = base + (key >> SH)   (mod 2^64)
@@ -2186,6 +2176,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         replay(x, rv, n);
     }
     emit_upto(rz);
+    if (lane == 0) has[(size_t)seg * n_grp + grp] = 1;
     if (lane < rz - ra) {
         const size_t o = (size_t)grp * n_reads + ra + lane;
         // A non-candidate sitting in a live word counts up from 0 and can out-number this group's candidates; what
@@ -2222,7 +2213,7 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
                                                             const u64* __restrict__ lead_val, const u32* __restrict__ grp_any,
-                                                            const unsigned char* __restrict__ live) {
+                                                            const unsigned char* __restrict__ live, unsigned char* __restrict__ has) {
     constexpr int NW = kRankWords, SH = 6 + 3;
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), lane = lane_id();
     const u32 n_seg = (n_reads + 63u) / 64u, n_grp = (n_gw + NW - 1) / NW;
@@ -2231,10 +2222,7 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
     const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
     const u32 ra = seg * 64u, rz = min(n_reads, ra + 64u);
     if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp, sp)) {  // (its start values were not even written)
-        if (lane < rz - ra) {
-            const size_t o = ((size_t)(ra + lane) * n_grp + grp) * top_k;
-            for (u32 j = 0; j < top_k; ++j) { cand_sum[o + j] = 0; cand_idx[o + j] = 0xFFFFFFFFu; }
-        }
+        if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;  // nothing to report: the merge skips this (segment, group)
         return;
     }
     const bool dead = !grp_any[grp];  // no bit in the whole group: nothing was written for it, nothing to replay
@@ -2247,10 +2235,7 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
         const u32 gwl = grp * NW + (lane & (NW - 1));
         livew = (u32)__ballot(lane < (u32)NW && gwl < n_gw && live[(size_t)seg * n_gw + gwl] != 0) & 0xFFu;
         if (livew == 0u) {
-            if (lane < rz - ra) {
-                const size_t o = ((size_t)(ra + lane) * n_grp + grp) * top_k;
-                for (u32 j = 0; j < top_k; ++j) { cand_sum[o + j] = 0; cand_idx[o + j] = 0xFFFFFFFFu; }
-            }
+            if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;
             return;
         }
     }
@@ -2331,6 +2316,8 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
         }
         emit_upto(rz);
     }
+    if (lane == 0) has[(size_t)seg * n_grp + grp] = wmask != 0 ? 1 : 0;
+    if (wmask == 0) return;
     if (lane < rz - ra) {
         const size_t o = ((size_t)(ra + lane) * n_grp + grp) * top_k;
 #pragma unroll
@@ -2350,7 +2337,7 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
 __global__ __launch_bounds__(256) void top1_merge_kernel(const u64* __restrict__ best_sum,
                                                          const u32* __restrict__ best_idx, u32 n_reads,
                                                          u32* __restrict__ out_idx, u64* __restrict__ out_sum,
-                                                         u32 out_r0, Species sp) {
+                                                         u32 out_r0, Species sp, const unsigned char* __restrict__ has, u32 n_grp) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 t = blockIdx.x * 256u + threadIdx.x;
     const u32 spi = t / n_reads, r = t % n_reads;  // (reads innermost: coalesced candidate loads)
@@ -2359,6 +2346,7 @@ __global__ __launch_bounds__(256) void top1_merge_kernel(const u64* __restrict__
     u64 bs = 0; u32 bi = 0xFFFFFFFFu;
 #pragma unroll 8
     for (u32 grp = grp0; grp < grp1; ++grp) {
+        if (!has[(size_t)(r >> 6) * n_grp + grp]) continue;  // (the ranking had nothing to report for this segment and group)
         const u64 s_ = best_sum[(size_t)grp * n_reads + r];
         const u32 i_ = best_idx[(size_t)grp * n_reads + r];
         // groups come in ascending index order: a later group wins only with a strictly larger sum
@@ -2702,34 +2690,36 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
-                          const u64* lead_val, const u32* grp_any, const unsigned char* live) {
+                          const u64* lead_val, const u32* grp_any, const unsigned char* live,
+                          unsigned char* has /* [segments][rank groups]: the kernel reported something for it */) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, sp, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader,
-                       gmax, lead_val, grp_any, live);
+                       gmax, lead_val, grp_any, live, has);
 }
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
-                          const u64* gmax, const u64* lead_val, const u32* grp_any, const unsigned char* live) {
+                          const u64* gmax, const u64* lead_val, const u32* grp_any, const unsigned char* live,
+                          unsigned char* has) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_topk_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, mq, n_gw, n_pad, sp, cum_in, rel, top_k, cand_sum, cand_idx, nq_rows,
-                       inc, leader, gmax, lead_val, grp_any, live);
+                       inc, leader, gmax, lead_val, grp_any, live, has);
 }
 u32 rank_topk_fast_max() { return kTopkFast; }
 u32 rank_leader_parts() { return kLeaderParts; }
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32* out_idx, u64* out_sum,
-                       u32 out_r0, const Species& sp) {
+                       u32 out_r0, const Species& sp, const unsigned char* has, u32 n_grp) {
     if (n_reads == 0) return;
     hipLaunchKernelGGL(top1_merge_kernel, dim3(cdiv((u64)n_reads * sp.n_sp, 256)), dim3(256), 0, st, best_sum, best_idx, n_reads,
-                       out_idx, out_sum, out_r0, sp);
+                       out_idx, out_sum, out_r0, sp, has, n_grp);
 }
 void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_units, u32 per_grp,
-                       u32 top_k, u32* out_idx, u64* out_sum, u32 out_r0, const Species& sp) {
+                       u32 top_k, u32* out_idx, u64* out_sum, u32 out_r0, const Species& sp, const unsigned char* has) {
     if (n_reads == 0) return;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(cdiv((u64)n_reads * sp.n_sp, 4)), dim3(256), 0, st, cand_sum, cand_idx, n_reads,
-                       n_units, per_grp, top_k, out_idx, out_sum, out_r0, sp);
+                       n_units, per_grp, top_k, out_idx, out_sum, out_r0, sp, has);
 }
 void launch_rank_table(hipStream_t st, const u64* cum, const Species& sp, u32 top_k, u32* out_idx, u64* out_sum) {
     hipLaunchKernelGGL(rank_table_kernel, dim3(sp.n_sp), dim3(1024), 0, st, cum, sp, top_k, out_idx, out_sum);

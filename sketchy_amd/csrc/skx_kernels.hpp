@@ -99,20 +99,20 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
-                          const u64* lead_val, const u32* grp_any, const unsigned char* live);
+                          const u64* lead_val, const u32* grp_any, const unsigned char* live, unsigned char* has);
 // 2 <= top_k <= rank_topk_fast_max(): pruned, one wave per (rank group, segment);
 // cand_sum / cand_idx[(r * n_grp + grp) * top_k + j]
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u32 top_k, u64* cand_sum, u32* cand_idx, const u32* inc, const u32* leader,
-                          const u64* gmax, const u64* lead_val, const u32* grp_any, const unsigned char* live);
+                          const u64* gmax, const u64* lead_val, const u32* grp_any, const unsigned char* live, unsigned char* has);
 u32 rank_topk_fast_max();
 // rows come out per (read, species) with genome indices local to the species: out[((out_r0 + r) * n_sp + sp) * top_k + j]
 void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx, u32 n_reads, u32* out_idx, u64* out_sum,
-                       u32 out_r0, const Species& sp);
+                       u32 out_r0, const Species& sp, const unsigned char* has, u32 n_grp);
 // n_units candidates-units per read (rank groups: per_grp = 1; genome words: per_grp = kRankWords)
 void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_units, u32 per_grp,
-                       u32 top_k, u32* out_idx, u64* out_sum, u32 out_r0, const Species& sp);
+                       u32 top_k, u32* out_idx, u64* out_sum, u32 out_r0, const Species& sp, const unsigned char* has /* [segments][rank groups] of the pruned kernels, or NULL */);
 void launch_rank_table(hipStream_t st, const u64* cum, const Species& sp, u32 top_k, u32* out_idx /* [n_sp][top_k] */, u64* out_sum);
 // n_real real genomes (species concatenated); real2pad[g] = padded index
 void launch_shared_debug(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
