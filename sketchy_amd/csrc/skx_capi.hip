@@ -1667,6 +1667,7 @@ SKX_API int skx_stream_allreduce(skx_stream* st, skx_comm* comm) {
     if (!st || !comm) return fail(SKX_ERR_INVALID, "NULL argument");
     if (comm->device != st->device) return fail(SKX_ERR_INVALID, "communicator and stream are on different devices");
     SKXCHK(use_device(st->device));
+    SKXCHK(flush_pending(st));  // (an enqueued batch whose passes are still to be queued belongs to the table)
     // one sum all-reduce of the u64 table (8*N bytes: latency-bound); in place
     // (the padded table: padding entries are 0 on every rank)
     ncclResult_t r = g_rccl.AllReduce(st->d_cum, st->d_cum, st->ref->n_pad, ncclUint64, ncclSum, comm->comm, st->hs2);

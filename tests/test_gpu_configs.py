@@ -97,6 +97,14 @@ def test_rccl_one_rank_communicator_through_the_c_abi(gpu):
     S.allreduce(comm)
     S.allreduce(comm)
     np.testing.assert_array_equal(S.table(), before)
+    # a batch enqueued but not yet flushed belongs to the table the collective sums (regression: the all-reduce used to run
+    # before the batch's passes were queued, so the reduced table missed it and the batch was added on top afterwards)
+    S2 = api.SumOfSharedHashes(R, top=1, max_batch_reads=200, max_batch_bases=len(bases))
+    d_b, d_o = api.DeviceBuffer.from_numpy(bases), api.DeviceBuffer.from_numpy(offsets)
+    S2.enqueue_device(d_b.ptr, d_o.ptr, 200, int(offsets[-1]), None, None)
+    S2.allreduce(comm)
+    np.testing.assert_array_equal(S2.table(), before)
+    d_b.free(); d_o.free()
     comm.close()
 
 
