@@ -1461,7 +1461,7 @@ SKX_API int skx_stream_reset(skx_stream* st) {
 }
 SKX_API int skx_stream_reads(const skx_stream* st, uint64_t* n_reads) {
     if (!st || !n_reads) return fail(SKX_ERR_INVALID, "NULL argument");
-    *n_reads = st->reads_total;
+    *n_reads = st->reads_total + (st->pend.valid ? st->pend.n_reads : 0u);  // (an enqueued batch counts once it is accepted)
     return SKX_OK;
 }
 SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
