@@ -1,0 +1,10 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/ab.sh [-c CONFIG] [-s STEPS] "label ENV=val ENV=val" "label2 ..." ...
+# runs bench.py once per variant (same box, back to back) and prints one condensed line each -- how every A/B of
+# DESIGN.md was measured.  Boxes differ by a few per cent: compare inside one call only, and repeat the baseline.
+CFG=c2; STEPS=20
+while getopts "c:s:" o; do case $o in c) CFG=$OPTARG;; s) STEPS=$OPTARG;; esac; done; shift $((OPTIND - 1))
+for V in "$@"; do
+  set -- $V; L=$1; shift
+  env "$@" timeout 600 python3 bench.py --config $CFG --steps $STEPS --cpu-seconds 0 2>/dev/null | python3 tools/bench_line.py "$L" | cut -c1-220
+done
