@@ -25,6 +25,9 @@
 #include "skx_common.hpp"
 #include "skx_kernels.hpp"
 
+#ifndef SKX_SCAN_ROWS
+#define SKX_SCAN_ROWS 8
+#endif
 #ifndef SKX_SCAN_OCC
 #define SKX_SCAN_OCC 1
 #endif
@@ -1210,7 +1213,6 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
     const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
     if (qa >= qb) return;
     const u32 i0 = b * rb, rows = min(s, i0 + rb) - i0;
-    const u64* col = mat + ((size_t)t * s + i0) * kTileGenomes + c;
     const u32 g = t * kTileGenomes + c;
     const bool multi = qb - qa > kLeanCap;  // several sub-window passes: the atomic path into M
     if (multi && c == 0) *m_dirty = 1u;
@@ -1301,36 +1303,43 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
                 }
             }
         };
-        // software-pipelined: the next 8 rows are in flight while the current 8 are probed
+        // software-pipelined: the next kU rows are in flight while the current kU are probed (kU = 8: 16 loads in flight per
+        // lane.  Measured with -DSKX_SCAN_ROWS=16 / 32: more bytes in flight per wave at fewer resident waves loses --
+        // 75 -> 67 -> 52 M reads/s at C2, scan 0.90 -> 1.2 -> 1.6 ms in the pipeline)
+        constexpr u32 kU = SKX_SCAN_ROWS;
+        const u64* const band = mat + ((size_t)t * s + i0) * kTileGenomes;  // wave-uniform
+        auto row = [&](u32 r) -> u64 {
+            const u64* rp = band + (size_t)r * kTileGenomes;  // (uniform: scalar arithmetic)
+            return (NT & 2) ? __builtin_nontemporal_load(&rp[c]) : rp[c];
+        };
         u32 i = 0;
-        if (rows >= 8u) {
-            u64 h[8];
+        if (rows >= kU) {
+            u64 h[kU];
 #pragma unroll
-            for (u32 u = 0; u < 8u; ++u) h[u] = (NT & 2) ? __builtin_nontemporal_load(&col[(size_t)u * kTileGenomes]) : col[(size_t)u * kTileGenomes];
-            for (i = 8u; i + 8u <= rows; i += 8u) {
-                u64 hn[8];
+            for (u32 u = 0; u < kU; ++u) h[u] = row(u);
+            for (i = kU; i + kU <= rows; i += kU) {
+                u64 hn[kU];
 #pragma unroll
-                for (u32 u = 0; u < 8u; ++u)
-                    hn[u] = (NT & 2) ? __builtin_nontemporal_load(&col[(size_t)(i + u) * kTileGenomes]) : col[(size_t)(i + u) * kTileGenomes];
+                for (u32 u = 0; u < kU; ++u) hn[u] = row(i + u);
                 if (lean) {
 #pragma unroll
-                    for (u32 u = 0; u < 8u; ++u) probe_lean(h[u]);
+                    for (u32 u = 0; u < kU; ++u) probe_lean(h[u]);
                 } else {
 #pragma unroll
-                    for (u32 u = 0; u < 8u; ++u) probe_walk(h[u]);
+                    for (u32 u = 0; u < kU; ++u) probe_walk(h[u]);
                 }
 #pragma unroll
-                for (u32 u = 0; u < 8u; ++u) h[u] = hn[u];
+                for (u32 u = 0; u < kU; ++u) h[u] = hn[u];
             }
             if (lean) {
 #pragma unroll
-                for (u32 u = 0; u < 8u; ++u) probe_lean(h[u]);
+                for (u32 u = 0; u < kU; ++u) probe_lean(h[u]);
             } else {
 #pragma unroll
-                for (u32 u = 0; u < 8u; ++u) probe_walk(h[u]);
+                for (u32 u = 0; u < kU; ++u) probe_walk(h[u]);
             }
         }
-        for (; i < rows; ++i) probe_walk(col[(size_t)i * kTileGenomes]);
+        for (; i < rows; ++i) probe_walk(row(i));
 
         if (ABLATE >= 1) {
             if (cur_bits == 0x123456789ull) m_bits[g] = cur_bits;  // keep the work alive
