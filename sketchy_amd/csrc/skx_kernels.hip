@@ -2075,14 +2075,30 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     if (seg >= n_seg) return;
     const u64* mq_g = mq + (size_t)grp * nq_rows * NW;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
+    // Everything that can end this wave at once is requested together, before anything else is loaded: the chunk-level
+    // bound, the group's "any bit" flag and the eight `live` bytes of seg_prefix_kernel.  (119 000 of the 121 000 waves of
+    // a C2 batch leave here; with the leader lookups -- two dependent round trips -- in front of the test they held
+    // their wave slots three times as long.)
+    const u32 gwl = grp * NW + (lane & (NW - 1));
+    const bool live_byte = live && lane < (u32)NW && gwl < n_gw && live[(size_t)seg * n_gw + gwl] != 0;
+    // a group without any bit in the pass (e.g. a species the sample does not belong to): its sums do not move -- no
+    // start values / increments were written for it, no pairs are replayed, one key serves the whole segment
+    const bool dead = !grp_any[grp];
     if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp, sp)) {  // (its start values were not even written)
         if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;  // nothing to report: the merge skips this (segment, group)
         return;
     }
+    // words none of whose genomes can reach even the chunk's leader bound by the end of the segment (seg_prefix_kernel):
+    // no start values were stored for them, nothing of theirs is loaded -- usually that is the whole group
+    u32 livew = 0xFFu;
+    if (!dead && live) {
+        livew = (u32)__ballot(live_byte) & 0xFFu;
+        if (livew == 0u) {
+            if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;
+            return;
+        }
+    }
     const u32 spi = sp.of_grp[grp], sp_end = sp.g0[spi] + sp.n[spi];
-    // a group without any bit in the pass (e.g. a species the sample does not belong to): its sums do not move -- no
-    // start values / increments were written for it, no pairs are replayed, one key serves the whole segment
-    const bool dead = !grp_any[grp];
     const u32 pa = poff[r_begin + ra] - p_base;
     u32 pz = dead ? pa : poff[r_begin + rz] - p_base;
     const u32 g0 = grp * NW * 64u + lane;
@@ -2097,17 +2113,6 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     const u32 gl = leader[(seg >> 4) * sp.n_sp + spi];  // (top_k == 1: one leader per chunk and species)
     u64 lead = cum_in[gl] + (grp_any[gl / (NW * 64u)] ? rel[(size_t)seg * n_pad + gl] : 0u);
     const u32 gain = pz - pa;
-    // words none of whose genomes can reach even the chunk's leader bound by the end of the segment (seg_prefix_kernel):
-    // no start values were stored for them, nothing of theirs is loaded -- usually that is the whole group
-    u32 livew = 0xFFu;
-    if (!dead && live) {
-        const u32 gwl = grp * NW + (lane & (NW - 1));
-        livew = (u32)__ballot(lane < (u32)NW && gwl < n_gw && live[(size_t)seg * n_gw + gwl] != 0) & 0xFFu;
-        if (livew == 0u) {
-            if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;
-            return;
-        }
-    }
     u64 st0[NW];
     u32 ic[NW];
     bool real[NW];
