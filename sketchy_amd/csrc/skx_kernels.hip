@@ -504,10 +504,14 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk
 template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, unsigned char* lut) {
-    fill_base_lut(lut);
-    __syncthreads();
     const bool packed = (from_list & 0x100u) != 0u;  // (bit 8: 4-bit packed input)
     from_list &= 0xFFu;
+    // (whole workgroups that have nothing to do leave before the table is filled: the long-read half of a batch without
+    // long reads, the list walk over an empty list)
+    if (from_list == 2u && blockIdx.x < (gridDim.x >> 1) && chk[1] == 0u) return;
+    if (from_list == 1u && retry[0] == 0u) return;
+    fill_base_lut(lut);
+    __syncthreads();
     const u32 wpb = blockDim.x >> 6;  // waves per block: 4, or 1 for the list walk (see launch_sketch)
     u32 w = blockIdx.x * wpb + (threadIdx.x >> 6);
     if (from_list == 2u) {
