@@ -2362,13 +2362,23 @@ __global__ __launch_bounds__(256) void top1_merge_kernel(const u64* __restrict__
     if (spi >= sp.n_sp) return;
     const u32 g_lo = sp.g0[spi], grp0 = g_lo / (kRankWords * 64u), grp1 = (g_lo + sp.n[spi] + kRankWords * 64u - 1u) / (kRankWords * 64u);
     u64 bs = 0; u32 bi = 0xFFFFFFFFu;
+    // the groups the ranking reported anything for (this read's segment): their flags first, 64 independent byte loads at a
+    // time, then only those groups' entries -- usually one or two of 79 (a test per group in front of its loads made every
+    // load wait for the one before it)
+    const unsigned char* hs = has + (size_t)(r >> 6) * n_grp;
+    for (u32 base = grp0; base < grp1; base += 64u) {
+        u64 mask = 0;
 #pragma unroll 8
-    for (u32 grp = grp0; grp < grp1; ++grp) {
-        if (!has[(size_t)(r >> 6) * n_grp + grp]) continue;  // (the ranking had nothing to report for this segment and group)
-        const u64 s_ = best_sum[(size_t)grp * n_reads + r];
-        const u32 i_ = best_idx[(size_t)grp * n_reads + r];
-        // groups come in ascending index order: a later group wins only with a strictly larger sum
-        if (i_ != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || s_ > bs)) { bs = s_; bi = i_; }
+        for (u32 i = 0; i < 64u; ++i)
+            if (base + i < grp1) mask |= (u64)(hs[base + i] != 0) << i;
+        while (mask) {
+            const u32 grp = base + (u32)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const u64 s_ = best_sum[(size_t)grp * n_reads + r];
+            const u32 i_ = best_idx[(size_t)grp * n_reads + r];
+            // groups come in ascending index order: a later group wins only with a strictly larger sum
+            if (i_ != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || s_ > bs)) { bs = s_; bi = i_; }
+        }
     }
     out_idx[(size_t)(out_r0 + r) * sp.n_sp + spi] = bi - g_lo;
     out_sum[(size_t)(out_r0 + r) * sp.n_sp + spi] = bs;
