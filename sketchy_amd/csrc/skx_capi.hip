@@ -405,6 +405,7 @@ struct skx_stream {
     u64* d_lpart_sum = nullptr;   // per-slice leader candidates (chunk_leader_part_kernel)
     u32* d_lpart_idx = nullptr;
     u32* d_rel = nullptr;         // [segments of a pass][n_pad] segment start values relative to the pass-start table
+    u64* d_lead_seg = nullptr;        // [segments of a pass][species] the ranking's bound as every segment begins (seg_lead_kernel)
     unsigned char* d_has = nullptr;   // [segments of a pass][rank groups] the pruned ranking kernels reported something (the merges skip the rest)
     unsigned char* d_live = nullptr;  // [segments of a pass][n_pad / 64] top-1 ranking: the word can hold a candidate (seg_prefix_kernel)
     u64* d_cand_sum = nullptr;
@@ -475,7 +476,7 @@ static void stream_free(skx_stream* st) {
                     st->sd_sk[1], st->sd_len[1], st->sd_cnt[1], st->sd_poff[1], st->sd_big[1], st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc2[0], st->d_inc2[1] != st->d_inc2[0] ? st->d_inc2[1] : nullptr,
-                    st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_has, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_has, st->d_lead_seg, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1]};
     for (void* p : ptrs) (void)hipFree(p);
@@ -651,6 +652,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
     SCHK(hipMalloc(&st->d_live, (size_t)n_seg_max * (n_pad / 64)));
     SCHK(hipMalloc(&st->d_has, (size_t)n_seg_max * (n_pad / (skx::kRankWords * 64))));
+    SCHK(hipMalloc(&st->d_lead_seg, (size_t)n_seg_max * n_sp * 8 + 64));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
     SCHK(hipMalloc(&st->d_csum_raw2[0], (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
     if (st->hs3 != st->hs2) SCHK(hipMalloc(&st->d_csum_raw2[1], (size_t)((n_seg_max + 15) / 16) * n_pad * 4)); else st->d_csum_raw2[1] = st->d_csum_raw2[0];
@@ -931,7 +933,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         const bool topk_fast = !top1_fast && st->top_k && st->top_k <= skx::rank_topk_fast_max();
         unsigned char* d_live = ((top1_fast || topk_fast) && ranked && live_env) ? st->d_live : nullptr;  // (the pruned kernels look at the flags)
         skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
-                               st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live);
+                               st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live, st->d_lead_seg);
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
         if (top1_fast && d_topk_idx && d_topk_sum) {

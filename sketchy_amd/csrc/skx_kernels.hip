@@ -1812,6 +1812,29 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(const u32* __restrict
     }
     cum_out[g] = base + run;
 }
+// lead_seg[seg][species] = the smallest value, as segment seg begins, among the k genomes that ranked first when its chunk
+// began: the bound the pruned ranking kernels measure candidates against (they recompute it; here it lets seg_prefix_kernel
+// decide per word whether ANY genome of it can be a candidate).  One wave per (chunk, species); lane = segment of the chunk.
+__global__ __launch_bounds__(64) void seg_lead_kernel(const u32* __restrict__ inc, const u32* __restrict__ csum, u32 n_seg, u32 n_pad,
+                                                      const u64* __restrict__ cum_in, const u32* __restrict__ leader, u32 top_k,
+                                                      Species sp, const u32* __restrict__ grp_any, u64* __restrict__ lead_seg) {
+    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
+    const u32 cs = blockIdx.x, c = cs / sp.n_sp, spi = cs % sp.n_sp, lane = lane_id();
+    const u32 seg = c * 16u + lane;
+    if (lane >= 16u || seg >= n_seg) return;
+    u64 lead = ~0ull;
+    for (u32 j = 0; j < top_k; ++j) {
+        const u32 gl = leader[cs * top_k + j];
+        u64 v = cum_in[gl];
+        if (grp_any[gl / (kRankWords * 64u)]) {
+            u32 run = csum[(size_t)c * n_pad + gl];
+            for (u32 s2 = c * 16u; s2 < seg; ++s2) run += inc[(size_t)s2 * n_pad + gl];
+            v += run;
+        }
+        lead = min(lead, v);
+    }
+    lead_seg[(size_t)seg * sp.n_sp + spi] = lead;
+}
 // live != NULL (top-1 ranking): live[seg][genome word] = some genome of the word ENDS segment seg at or above lead_val of
 // the segment's chunk (the leader's value as the chunk began -- the leader only grows, so that is a lower bound of
 // every bound the ranking uses inside the chunk).  Words that cannot are never looked at by rank_seg_top1_kernel, and
@@ -1821,7 +1844,8 @@ __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__
                                                          u32 n_seg, u32 n_pad, u32* __restrict__ rel,
                                                          const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
                                                          u32 n_half, Species sp, const u32* __restrict__ grp_any,
-                                                         const u64* __restrict__ cum_in, unsigned char* __restrict__ live) {
+                                                         const u64* __restrict__ cum_in, unsigned char* __restrict__ live,
+                                                         const u64* __restrict__ lead_seg) {
     __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
     if (g >= n_pad || !grp_any[blockIdx.x >> 1]) return;  // (a group without any bit starts every segment at the pass-start table)
@@ -1838,7 +1862,7 @@ __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__
         }
         return;
     }
-    const u64 lv = lead_val[c * sp.n_sp + sp.of_grp[blockIdx.x >> 1]];
+    const u32 spi = sp.of_grp[blockIdx.x >> 1];
     const u64 base = cum_in[g];
     const u32 gw = g >> 6, n_gw = n_pad >> 6;
     u32 t[16];
@@ -1849,6 +1873,8 @@ __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__
         if (s0 + i < s1) {
             const u32 start = run;
             run += t[i];
+            // (the segment's own bound, seg_lead_kernel: exactly the candidate test of the ranking kernels, per word)
+            const u64 lv = lead_seg[(size_t)(s0 + i) * sp.n_sp + spi];
             const bool any = __ballot(base + run >= lv) != 0ull;  // (padding genomes: base 0, never gain)
             if (any) rel[(size_t)(s0 + i) * n_pad + g] = start;
             if (lane_id() == 0) live[(size_t)(s0 + i) * n_gw + gw] = any ? 1 : 0;
@@ -2691,7 +2717,8 @@ void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_ba
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32* csum_raw /* same size */, u32 prune_top_k, u32* leader,
                        u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx, const u32* grp_any,
-                       unsigned char* live /* [n_seg][n_pad / 64] or NULL: every start value is stored */) {
+                       unsigned char* live /* [n_seg][n_pad / 64] or NULL: every start value is stored */,
+                       u64* lead_seg /* [n_seg][n_sp] scratch (with live) */) {
     const u32 n_chunks = cdiv(n_seg, 16);
     dim3 grid(cdiv(n_pad, 256), n_chunks);
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3(n_pad / 256), dim3(256), 0, st, csum_raw, csum, n_chunks, n_pad, cum_in, cum_out,
@@ -2703,8 +2730,11 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
         hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
                            lead_val);
     }
+    if (prune_top_k && live)
+        hipLaunchKernelGGL(seg_lead_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, inc, csum, n_seg, n_pad, cum_in, leader, prune_top_k, sp,
+                           grp_any, lead_seg);
     hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
-                       lead_val, n_pad / 256, sp, grp_any, cum_in, prune_top_k ? live : nullptr);  // (live: the caller's choice, top-1 path only)
+                       lead_val, n_pad / 256, sp, grp_any, cum_in, prune_top_k ? live : nullptr, lead_seg);  // (live: the caller's choice, top-1 path only)
 }
 // (the first level of launch_seg_prefix's three: needs only the increments, not the running table -- queued with seg_sum)
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,

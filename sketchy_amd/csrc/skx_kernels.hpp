@@ -91,7 +91,8 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
                        u32* rel /* [n_seg][n_pad]: segment start values minus cum_in */, u32* csum, u32* csum_raw, u32 prune_top_k,
                        u32* leader /* [n_chunks * n_sp * k] */, u64* lead_val /* [n_chunks * n_sp] */, u64* gmax,
                        u64* part_sum, u32* part_idx /* [n_chunks * n_sp * rank_leader_parts() * k] scratch */,
-                       const u32* grp_any, unsigned char* live /* [n_seg][n_pad / 64], top-1 ranking only; else NULL */);
+                       const u32* grp_any, unsigned char* live /* [n_seg][n_pad / 64], pruned rankings only; else NULL */,
+                       u64* lead_seg /* [n_seg][n_sp] scratch */);
 u32 rank_leader_parts();
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
