@@ -2305,7 +2305,39 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
     u64 res[kTopkFast];  // lane l: the k winners (keys) of read ra + l
 #pragma unroll
     for (u32 j = 0; j < kTopkFast; ++j) res[j] = 0;
-    if (wmask != 0) {
+    // One candidate in the whole group (instrumented at C2, k = 5: every replaying wave): its value after read r is its
+    // start plus the hits among the pairs of reads <= r -- one row WORD per pair (not the group's 64 bytes), one ballot per
+    // 64 pairs, a prefix popcount per read.  No transposes, no read-by-read replay: ~70 instructions instead of ~3000.
+    u32 n_cands = 0;
+    u32 wc = 0;
+    u64 cbal = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const u64 b_ = __ballot(cand[w]);
+        n_cands += (u32)__popcll(b_);
+        if (b_) { wc = (u32)w; cbal = b_; }
+    }
+    if (n_cands == 1u) {
+        const u32 lc = (u32)__builtin_ctzll(cbal);
+        u64 sv = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            if ((u32)w == wc) sv = sum[w];
+        const u64 start = make_u64((u32)__builtin_amdgcn_readlane((int)(u32)sv, (int)lc), (u32)__builtin_amdgcn_readlane((int)(u32)(sv >> 32), (int)lc));
+        // pairs of the segment up to and including this lane's read
+        const u32 pe = lane < rz - ra ? poff[r_begin + ra + lane + 1u] - p_base - pa : 0u;
+        u32 cnt = 0;
+        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+            const u32 p = p0 + lane;
+            const bool v = p < pz;
+            const u64 word = v ? mq_g[(size_t)pair_q[p] * NW + wc] : 0ull;
+            const u64 hm = __ballot(v && ((word >> lc) & 1ull));
+            const u32 off = p0 - pa, nlow = pe > off ? min(64u, pe - off) : 0u;
+            const u64 lm = nlow >= 64u ? ~0ull : ((1ull << nlow) - 1ull);
+            cnt += (u32)__popcll(hm & lm);
+        }
+        if (lane < rz - ra) res[0] = ((start + cnt + 1ull) << SH) | ((u64)(NW - 1 - wc) << 6) | (u64)(63u - lc);
+    } else if (wmask != 0) {
         u32 cur = ra;
         auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
             if (cur >= r_stop) return;
