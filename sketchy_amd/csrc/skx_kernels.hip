@@ -2183,6 +2183,39 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
 #pragma unroll
     for (int j = 0; j < NW; ++j) tiec[j] = ((u32)(NW - 1 - j) << 6) | (63u - lane);
     u32 cur = ra, res_key = 0;
+    // One candidate in the whole group -- the usual case once a sample has a clear best match (the leader's group, every
+    // segment): its value after read r is its start plus the hits among the pairs of reads <= r.  One row WORD per pair
+    // (not the group's 64 bytes), one ballot per 64 pairs, a prefix popcount per read: no transposes, no read-by-read
+    // replay (~70 instructions instead of ~3000, and a wave that ends in microseconds instead of being the kernel's tail).
+    u32 n_cands = 0, wc = 0;
+    u64 cbal = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u64 b_ = __ballot(val[j] != 0u);
+        n_cands += (u32)__popcll(b_);
+        if (b_) { wc = (u32)j; cbal = b_; }
+    }
+    const bool single = n_cands == 1u;
+    if (single) {
+        const u32 lc = (u32)__builtin_ctzll(cbal);
+        u32 vsel = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+            if ((u32)j == wc) vsel = val[j];
+        const u32 v0 = (u32)__builtin_amdgcn_readlane((int)vsel, (int)lc);
+        const u32 pe = lane < rz - ra ? poff[r_begin + ra + lane + 1u] - p_base - pa : 0u;  // pairs of reads <= this lane's
+        u32 cnt = 0;
+        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+            const u32 p = p0 + lane;
+            const bool v = p < pz;
+            const u64 word = v ? mq_g[(size_t)pair_q[p] * NW + wc] : 0ull;
+            const u64 hm = __ballot(v && ((word >> lc) & 1ull));
+            const u32 off = p0 - pa, nlow = pe > off ? min(64u, pe - off) : 0u;
+            const u64 lm = nlow >= 64u ? ~0ull : ((1ull << nlow) - 1ull);
+            cnt += (u32)__popcll(hm & lm);
+        }
+        res_key = ((v0 + cnt) << SH) | ((u32)(NW - 1 - wc) << 6) | (63u - lc);
+    }
 
     auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
         if (cur >= r_stop) return;
@@ -2205,6 +2238,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
             j += __popcll(m);
         }
     };
+    if (!single) {
     MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
     u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
     for (u32 p0 = pa; p0 < pz; p0 += 64u) {
@@ -2220,6 +2254,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         replay(x, rv, n);
     }
     emit_upto(rz);
+    }
     if (lane == 0) has[(size_t)seg * n_grp + grp] = 1;
     if (lane < rz - ra) {
         const size_t o = (size_t)grp * n_reads + ra + lane;
