@@ -25,6 +25,9 @@
 #include "skx_common.hpp"
 #include "skx_kernels.hpp"
 
+#ifndef SKX_FEW_CANDS
+#define SKX_FEW_CANDS 1  /* measured at C2: 1 -> 77.0 M reads/s, 6 -> 76.2 M, 16 -> 76.8 M (cold batch: 49.1 / 50.1 / 48.5 M) */
+#endif
 #ifndef SKX_SCAN_ROWS
 #define SKX_SCAN_ROWS 8
 #endif
@@ -2183,38 +2186,42 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
 #pragma unroll
     for (int j = 0; j < NW; ++j) tiec[j] = ((u32)(NW - 1 - j) << 6) | (63u - lane);
     u32 cur = ra, res_key = 0;
-    // One candidate in the whole group -- the usual case once a sample has a clear best match (the leader's group, every
-    // segment): its value after read r is its start plus the hits among the pairs of reads <= r.  One row WORD per pair
-    // (not the group's 64 bytes), one ballot per 64 pairs, a prefix popcount per read: no transposes, no read-by-read
-    // replay (~70 instructions instead of ~3000, and a wave that ends in microseconds instead of being the kernel's tail).
-    u32 n_cands = 0, wc = 0;
-    u64 cbal = 0;
+    // Few candidates in the whole group -- one is the usual case once a sample has a clear best match (the leader's group,
+    // every segment): a candidate's value after read r is its start plus the hits among the pairs of reads <= r.  Per
+    // candidate: one row WORD per pair (not the group's 64 bytes), one ballot per 64 pairs, a prefix popcount per read; the
+    // read's best is the maximum over the candidates' keys.  No transposes, no read-by-read replay (~70 instructions per
+    // candidate instead of ~3000 per wave, and a wave that ends in microseconds instead of being the kernel's tail).
+    constexpr u32 kFewCands = SKX_FEW_CANDS;
+    u32 n_cands = 0;
+    u64 cbal[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-        const u64 b_ = __ballot(val[j] != 0u);
-        n_cands += (u32)__popcll(b_);
-        if (b_) { wc = (u32)j; cbal = b_; }
+        cbal[j] = __ballot(val[j] != 0u);
+        n_cands += (u32)__popcll(cbal[j]);
     }
-    const bool single = n_cands == 1u;
+    const bool single = n_cands <= kFewCands;  // (n_cands >= 1 here: wmask != 0)
     if (single) {
-        const u32 lc = (u32)__builtin_ctzll(cbal);
-        u32 vsel = 0;
-#pragma unroll
-        for (int j = 0; j < NW; ++j)
-            if ((u32)j == wc) vsel = val[j];
-        const u32 v0 = (u32)__builtin_amdgcn_readlane((int)vsel, (int)lc);
         const u32 pe = lane < rz - ra ? poff[r_begin + ra + lane + 1u] - p_base - pa : 0u;  // pairs of reads <= this lane's
-        u32 cnt = 0;
-        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
-            const u32 p = p0 + lane;
-            const bool v = p < pz;
-            const u64 word = v ? mq_g[(size_t)pair_q[p] * NW + wc] : 0ull;
-            const u64 hm = __ballot(v && ((word >> lc) & 1ull));
-            const u32 off = p0 - pa, nlow = pe > off ? min(64u, pe - off) : 0u;
-            const u64 lm = nlow >= 64u ? ~0ull : ((1ull << nlow) - 1ull);
-            cnt += (u32)__popcll(hm & lm);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            u64 bal = cbal[j];
+            while (bal) {  // (wave-uniform)
+                const u32 lc = (u32)__builtin_ctzll(bal);
+                bal &= bal - 1ull;
+                const u32 v0 = (u32)__builtin_amdgcn_readlane((int)val[j], (int)lc);
+                u32 cnt = 0;
+                for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+                    const u32 p = p0 + lane;
+                    const bool v = p < pz;
+                    const u64 word = v ? mq_g[(size_t)pair_q[p] * NW + (u32)j] : 0ull;
+                    const u64 hm = __ballot(v && ((word >> lc) & 1ull));
+                    const u32 off = p0 - pa, nlow = pe > off ? min(64u, pe - off) : 0u;
+                    const u64 lm = nlow >= 64u ? ~0ull : ((1ull << nlow) - 1ull);
+                    cnt += (u32)__popcll(hm & lm);
+                }
+                res_key = max(res_key, ((v0 + cnt) << SH) | ((u32)(NW - 1 - j) << 6) | (63u - lc));
+            }
         }
-        res_key = ((v0 + cnt) << SH) | ((u32)(NW - 1 - wc) << 6) | (63u - lc);
     }
 
     auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
