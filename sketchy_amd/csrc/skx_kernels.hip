@@ -2565,14 +2565,18 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
                          const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, bool leave_room, bool packed) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
-    // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 11 KB: 5 instead of 8 of its blocks fit a CU), which leaves
-    // wave slots, registers and LDS for the scan's blocks: the VALU-bound sketch and the HBM-bound scan share every CU
-    // instead of taking turns (measured at C2: +9 % reads/s, the scan stretched from 0.62 to 0.78 ms).
+    // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 19 KB: 4 instead of 8 of its blocks fit a CU, and when one
+    // leaves, the LDS it frees goes to the -- higher-priority -- scan's blocks first), which leaves wave slots, registers
+    // and LDS for the scan: the VALU-bound sketch and the HBM-bound scan share every CU instead of taking turns.
+    // End of round 2, C2, same box: pad 11 KB 76.1 M reads/s with the scan at 1.00 ms (0.40 of peak) in the pipeline; 18 KB
+    // sits on the threshold (either 0.41 or 0.50); **19-20 KB 76.3-77.5 M with the scan at 0.71-0.75 ms (0.53-0.56)**; 22 KB
+    // 75.5 M, 0.55; 23-28 KB 70-72 M with the scan at its stand-alone 0.61-0.65 ms (0.61-0.65).  C4: 21.3 M / 0.40 at
+    // 11 KB, 21.1 M / 0.53 at 18 KB, 20.6 M / 0.58 at 20 KB.
     // SKX_SKETCH_ROOM: 2 (default) = unused dynamic LDS per block (SKX_SKETCH_LDS_PAD bytes), 1 = the register-capped
     // variant (5 waves per SIMD; measured: the scan then runs at its stand-alone speed inside the pipeline, 0.61-0.63 ms =
     // 0.64-0.66 of peak, but the step takes 1.48-1.50 ms instead of 1.32-1.33: 66 M reads/s instead of 74 M), 0 = never
     static const int room_mode = env_int("SKX_SKETCH_ROOM", 2);
-    static const size_t lds_pad_env = (size_t)env_int("SKX_SKETCH_LDS_PAD", 11264);
+    static const size_t lds_pad_env = (size_t)env_int("SKX_SKETCH_LDS_PAD", 19456);
     static const size_t lds_pad_capped = (size_t)env_int("SKX_SKETCH_LDS_PAD_CAPPED", 0);
     const size_t lds_pad = !leave_room ? 0 : room_mode == 2 ? lds_pad_env : room_mode == 1 ? lds_pad_capped : 0;
     const bool capped = leave_room && room_mode == 1;
