@@ -1073,10 +1073,10 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         if (pb.h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
         // every read, any length: wave sketchers (then the block sketcher for what overflowed: device-side lists)
         // (three-stream pipeline: will the previous pass's scan be in flight?  then this sketch shares the CUs with it)
-        bool leave_room = st->depth >= 3 && st->pend.valid;
-        if (st->depth >= 3)
+        int leave_room = (st->depth >= 3 && st->pend.valid) ? 2 : 0;
+        if (st->depth >= 3 && !leave_room)
             for (int i = 0; i < 2; ++i)
-                if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = true;
+                if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
         (void)hipGetLastError();  // (hipErrorNotReady is not an error)
         HIPCHK(skx::launch_sketch(hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, pb.inrange_only,
                                   st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big,
@@ -1536,7 +1536,7 @@ SKX_API int skx_sketch_reads(int device, uint32_t k, uint64_t seed, uint32_t s, 
         if ((e = hipMemset(d_sk, 0, (size_t)n_reads * stride * 8)) != hipSuccess) break;
         if ((e = hipMemset(d_lists, 0, 2 * ((size_t)n_reads + 1) * 4)) != hipSuccess) break;
         if ((e = skx::launch_sketch(nullptr, d_b, d_o, n_reads, k, seed, s, 0, false, d_sk, stride, d_len, d_cnt, nullptr, 0,
-                                    d_lists, d_lists + n_reads + 1, n_bases, nullptr, false)) != hipSuccess) break;
+                                    d_lists, d_lists + n_reads + 1, n_bases, nullptr, 0)) != hipSuccess) break;
         // sequences with more k-mers than a wave holds wait on the second list: the block sketcher
         u32 n_big = 0;
         if ((e = hipMemcpy(&n_big, d_lists + n_reads + 1, 4, hipMemcpyDeviceToHost)) != hipSuccess) break;

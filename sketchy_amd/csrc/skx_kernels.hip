@@ -2562,7 +2562,7 @@ static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketch
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, bool leave_room, bool packed) {
+                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
     // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 19 KB: 4 instead of 8 of its blocks fit a CU, and when one
@@ -2576,7 +2576,12 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     // variant (5 waves per SIMD; measured: the scan then runs at its stand-alone speed inside the pipeline, 0.61-0.63 ms =
     // 0.64-0.66 of peak, but the step takes 1.48-1.50 ms instead of 1.32-1.33: 66 M reads/s instead of 74 M), 0 = never
     static const int room_mode = env_int("SKX_SKETCH_ROOM", 2);
-    static const size_t lds_pad_env = (size_t)env_int("SKX_SKETCH_LDS_PAD", 19456);
+    // (leave_room = 2: the batch was enqueued behind another one -- the scan of that one WILL run beside this sketch for
+    // most of its time: the larger pad; 1: a push found the previous scan still in flight -- it overlaps only the start of
+    // this sketch: 11 KB, SKX_SKETCH_LDS_PAD_PUSH (measured: 72-73 M reads/s through skx_stream_push_device, 64-65 M with 19 KB))
+    static const size_t lds_pad_enq = (size_t)env_int("SKX_SKETCH_LDS_PAD", 19456);
+    static const size_t lds_pad_push = (size_t)env_int("SKX_SKETCH_LDS_PAD_PUSH", 11264);
+    const size_t lds_pad_env = leave_room >= 2 ? lds_pad_enq : lds_pad_push;
     static const size_t lds_pad_capped = (size_t)env_int("SKX_SKETCH_LDS_PAD_CAPPED", 0);
     const size_t lds_pad = !leave_room ? 0 : room_mode == 2 ? lds_pad_env : room_mode == 1 ? lds_pad_capped : 0;
     const bool capped = leave_room && room_mode == 1;
