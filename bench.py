@@ -65,6 +65,26 @@ def _pmc_traffic(config, batch):
     return None, None
 
 
+N_SIMDS = 1024                 # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+VALU_CYCLES_PER_WAVE_INST = 4  # a wave64 VALU instruction occupies its SIMD (16 lanes wide) for 4 cycles
+CLOCK_GHZ = 2.4
+
+
+def _valu_insts(config, batch):
+    """VALU wave instructions one step issues, from the COMMITTED per-kernel SQ_INSTS_VALU profile (profiles/valu_insts.json,
+    written from tools/pmc_all.sh output) -- not measured in this run; None when no matching profile is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_insts.json")) as f:
+            e = json.load(f).get(f"{config}_b{batch}")
+        if e:
+            return {"wave_insts_per_step": e["wave_insts_per_step"], "per_kernel": e.get("per_kernel"),
+                    "source": f"profiles/valu_insts.json:{config}_b{batch} ({e.get('profile', 'committed rocprofv3 --pmc SQ_INSTS_VALU pass')}; "
+                              "not measured in this run)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def _usable_cores():
     """Host threads this process can really run at once: the affinity mask, capped by the container's CPU quota
     (cgroup v2 cpu.max / v1 cfs quota) -- os.cpu_count() reports the machine, not the container."""
@@ -110,6 +130,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed steps (batches of --batch reads)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the timed region (each: table reset, exactly --steps steps, the table all-reduce); "
+                         "`value` is their median, every repetition is listed in `values_all`")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=98304, help="reads per step (one reference scan is amortised over this many reads)")
     ap.add_argument("--api", default="enqueue", choices=["enqueue", "push"],
@@ -200,22 +223,35 @@ def main():
     if not args.no_profile:
         S.set_profiling(2)  # the timed region records HIP events around the roofline kernel only (every stage: -2 %)
 
-    # ---- timed region: exactly K steps + the final table all-reduce
-    shard.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    reducer.allreduce(S)
-    S.sync()
-    torch.cuda.synchronize()
-    shard.barrier()
-    elapsed = time.perf_counter() - t1
-    elapsed = shard.max_over_ranks(elapsed)
+    # ---- timed region: exactly K steps + the final table all-reduce, from a fresh table; repeated --reps times (a single
+    # 26 ms shot was the whole headline before) and reported as the median, every repetition listed
+    reps = max(1, args.reps)
+    rep_s, rep_ar_ms, rep_own_s = [], [], []
+    for rep in range(reps):
+        if rep:
+            S.reset()
+        shard.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(W, W + K):
+            step(i)
+        reducer.allreduce(S)  # (flushes the enqueued batch; its own wall time is kept in reducer.last_ms)
+        S.sync()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t1
+        shard.barrier()
+        e = time.perf_counter() - t1
+        rep_s.append(shard.max_over_ranks(e))
+        rep_own_s.append(own)
+        rep_ar_ms.append(shard.max_over_ranks(reducer.last_ms or 0.0))
+    order = sorted(range(reps), key=lambda i: rep_s[i])
+    med = order[(reps - 1) // 2]  # (lower median: an actual repetition, so ms_per_step * K is a measured time)
+    elapsed = rep_s[med]
     prof = S.profile() if not args.no_profile else None
     S.set_profiling(False)
     table_final = S.table()
     stats = S.stats()
+    per_rank_values = shard.gather_floats(K * B / rep_own_s[med])
 
     total_reads = K * B * world
     value = total_reads / elapsed
@@ -224,14 +260,25 @@ def main():
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "values_all": [total_reads / t for t in rep_s], "reps": reps,
+        "values_per_rank": per_rank_values,
         "config": {"workload": desc, "stream": f"{K} distinct batches = the first {K * B} reads of a sample per GPU, table fresh at the first timed step",
                    "reads_per_step": B, "read_len": read_len, "read_len_lognormal_sigma": sigma,
                    "mean_read_len": round(float(np.mean(batch_bases)) / B, 1), "n_species": n_sp, "n_genomes": species, "s": s, "k": k,
-                   "top": top, "rccl_ranks": reducer.n_ranks,
+                   "top": top, "rccl_ranks": reducer.rccl_ranks if reducer.how == "rccl" else 0,
+                   "allreduce": dict(reducer.report(), ms=rep_ar_ms[med],
+                                     what="final sum all-reduce of the u64 table, inside the timed region (max over ranks; includes "
+                                          "queueing the last batch's passes and waiting for them)"),
                    "api": "skx_stream_enqueue_device + final sync" if args.api == "enqueue" else "skx_stream_push_device + final sync",
                    "parallelism": f"reads sharded x{world}, reference replicated, final table all-reduce via {reducer.how}"},
     }
     err = None
+    # a multi-GPU line is only valid when RCCL really reduced the table over `world` ranks (a run that silently fell back to
+    # the host path would otherwise print a green line): --share-gpu (testing: all ranks on one device, which RCCL refuses)
+    # is the only way to run N > 1 without it
+    if world > 1 and not args.share_gpu and not (reducer.how == "rccl" and reducer.rccl_ranks == world):
+        err = (f"--gpus {world}: the table was not reduced by RCCL over {world} ranks (transport {reducer.how}, RCCL counted "
+               f"{reducer.rccl_ranks} ranks; {reducer.err})")
 
     # ---- parity of what was timed (every rank checks its own shard)
     if not args.no_check and top:
@@ -273,16 +320,27 @@ def main():
             scan_ms = prof["scan"]["ms"] / prof["scan"]["launches"]
             achieved = pass_bytes / (scan_ms * 1e-3) / 1e9
             traffic, traffic_src = _pmc_traffic(args.config, B)
-            step_gbs = pass_bytes * (prof["scan"]["launches"] / K) / (elapsed / K) / 1e9
+            launches_per_step = prof["scan"]["launches"] / (K * reps)
+            step_gbs = pass_bytes * launches_per_step / (elapsed / K) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "scan_lean_kernel", "avg_launch_ms": scan_ms, "launches_per_step": prof["scan"]["launches"] / K,
+                               "kernel": "scan_lean_kernel", "avg_launch_ms": scan_ms, "launches_per_step": launches_per_step,
                                "algorithmic_bytes_per_launch": pass_bytes,
                                "note": "achieved = algorithmic bytes (8*s*N) / HIP-event time of the kernel on its own stream in the timed "
                                        "region, where the sketch of the next batch and the ranking of the previous one run beside it "
                                        "(three-stream pipeline); `isolated` = the same kernel alone",
                                "whole_step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                                               "note": "the same bytes over the whole step time (sketch, dictionary, ranking included)"}}
+        vi = _valu_insts(args.config, B)
+        if vi:
+            floor_ms = vi["wave_insts_per_step"] * VALU_CYCLES_PER_WAVE_INST / (N_SIMDS * CLOCK_GHZ * 1e9) * 1e3
+            out["roofline_valu"] = {"bound": "valu_issue", "wave_insts_per_step": vi["wave_insts_per_step"],
+                                    "insts_source": vi["source"], "per_kernel": vi.get("per_kernel"),
+                                    "simds": N_SIMDS, "cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST, "clock_ghz": CLOCK_GHZ,
+                                    "floor_ms": floor_ms, "frac": floor_ms / (1e3 * elapsed / K),
+                                    "note": "VALU wave instructions one step issues (all kernels of the step; committed rocprofv3 "
+                                            "SQ_INSTS_VALU pass, not measured in this run) x 4 cycles per wave64 instruction / "
+                                            "(1024 SIMDs x clock): the issue floor of the step; frac = floor / measured step"}
         out["pass_stats"] = stats  # (read, hash) pairs / passes of the last timed push, dictionary size, ...
         out["setup_s"] = {"reference": round(t_ref, 2), "reads": round(t_gen - t_ref, 2), "total": round(t_setup, 2)}
 

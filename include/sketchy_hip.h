@@ -65,29 +65,35 @@ int skx_device_info(int device, char *name, size_t name_cap, int *compute_units,
 
 /* ---- reference sketch collection, resident in HBM --------------------------------- */
 /*
- * hashes: genome g's ascending distinct 64-bit hashes at [g*s, g*s + col_len[g]), col_len[g] <= s.
- * k, seed, s are the reference's sketch parameters (reads are sketched with the same ones,
- * src/sketchy.rs:82/:331).  The library keeps its own device copy (a tiled, rank-major
- * s x N matrix); `hashes` may be freed after the call.
+ * hashes: genome g's ascending distinct 64-bit hashes at [g*stride, g*stride + col_len[g]), col_len[g] <= stride.
+ * k, seed, s are the sketch parameters reads are sketched with (src/sketchy.rs:331): the reference takes them from the
+ * FIRST sketch of the collection -- s := number of hashes of sketch 0 (src/sketchy.rs:82, :520-527) -- while the other
+ * sketches of a collection may be longer or shorter and are still intersected in full (:425-438).  So `s` (read sketch
+ * size) and `stride` (capacity of a column = the longest sketch) are separate; a host mirroring the reference passes
+ * s = col_len[0].  The library keeps its own device copy (a tiled, rank-major stride x N matrix); `hashes` may be
+ * freed after the call.
  */
-int skx_ref_create(skx_ref **out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
+int skx_ref_create(skx_ref **out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, uint32_t n_genomes,
                    const uint64_t *hashes, const uint32_t *col_len);
 /*
  * Several reference collections ("species": one sketch file each, src/sketchy.rs:81-82) resident together and scored
  * in ONE pass per batch.  The reference binary takes one sketch file per `predict` run, so a multi-species deployment
  * runs one predict per species over the same reads; here every read is sketched once and scanned against all of them,
  * and every species keeps its own running table and its own (sum desc, index asc) ranking.  All collections share
- * k, seed and s (the read sketch depends on them).  hashes[sp] / col_len[sp] are laid out as for skx_ref_create.
+ * k, seed, s (the read sketch depends on them) and the column stride.  hashes[sp] / col_len[sp] are laid out as for
+ * skx_ref_create.
  * Everywhere below, "n_genomes" of such a reference is the total over its species and genome-indexed arrays
  * (running table, per_read_shared, skx_common_hashes) hold the species one after the other; ranked rows come per
  * species, with genome indices local to the species.
  */
-int skx_ref_create_multi(skx_ref **out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_species,
+int skx_ref_create_multi(skx_ref **out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, uint32_t n_species,
                          const uint32_t *n_genomes, const uint64_t *const *hashes, const uint32_t *const *col_len);
 int skx_ref_n_genomes(const skx_ref *ref, uint32_t *n_genomes);
 int skx_ref_n_species(const skx_ref *ref, uint32_t *n_species);
 int skx_ref_species_genomes(const skx_ref *ref, uint32_t species, uint32_t *n_genomes);
-/* bytes of reference hashes one scoring pass streams from HBM (8*s*n_genomes) */
+/* read sketch size and column stride the reference was created with */
+int skx_ref_sketch_size(const skx_ref *ref, uint32_t *s, uint32_t *stride);
+/* bytes of reference hashes one scoring pass streams from HBM (8*stride*n_genomes) */
 int skx_ref_pass_bytes(const skx_ref *ref, uint64_t *bytes);
 void skx_ref_destroy(skx_ref *ref);
 

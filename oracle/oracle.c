@@ -313,12 +313,15 @@ ORC_EXPORT void orc_stable_rank(const uint64_t *sum, uint32_t n, uint32_t *idx_o
  * [n_reads][n_genomes], sketches [n_reads][s] + sketch_len [n_reads].
  * rank_every_read = 0 skips the per-read sort (used only to time the scoring loop alone).
  */
-ORC_EXPORT int orc_stream(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
-                          const uint64_t *ref_hashes, const uint32_t *col_len,
-                          const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
-                          uint32_t top_k, uint64_t *cum,
-                          uint32_t *topk_idx, uint64_t *topk_sum, uint32_t *per_read_shared,
-                          uint64_t *sketches, uint32_t *sketch_len, int rank_every_read) {
+/* `stride`: genome g's hashes start at ref_hashes + g * stride (col_len[g] <= stride).  The reference keeps every sketch in
+ * its own Vec, of any length; the read sketch size s is the length of the FIRST one (src/sketchy.rs:82, :520-527), so a
+ * collection can hold columns longer (or shorter) than s and they are still walked in full by _common_hashes (:425-438). */
+ORC_EXPORT int orc_stream_strided(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, uint32_t n_genomes,
+                                  const uint64_t *ref_hashes, const uint32_t *col_len,
+                                  const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                                  uint32_t top_k, uint64_t *cum,
+                                  uint32_t *topk_idx, uint64_t *topk_sum, uint32_t *per_read_shared,
+                                  uint64_t *sketches, uint32_t *sketch_len, int rank_every_read) {
     if (top_k > n_genomes) return -1; /* the reference panics on [..top] (src/sketchy.rs:391) */
     uint64_t *sk = (uint64_t *)malloc(((uint64_t)s + 1) * sizeof(uint64_t));
     uint32_t *idx = (uint32_t *)malloc(((uint64_t)n_genomes + 1) * sizeof(uint32_t));
@@ -330,7 +333,7 @@ ORC_EXPORT int orc_stream(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_geno
         if (sketches) memcpy(sketches + (uint64_t)r * s, sk, len * sizeof(uint64_t));
         if (sketch_len) sketch_len[r] = (uint32_t)len;
         for (uint32_t g = 0; g < n_genomes; ++g) { /* :337-347 */
-            uint64_t sh = orc_common_hashes(ref_hashes + (uint64_t)g * s, col_len[g], sk, len);
+            uint64_t sh = orc_common_hashes(ref_hashes + (uint64_t)g * stride, col_len[g], sk, len);
             cum[g] += sh;
             if (per_read_shared) per_read_shared[(uint64_t)r * n_genomes + g] = (uint32_t)sh;
         }
@@ -344,6 +347,15 @@ ORC_EXPORT int orc_stream(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_geno
     }
     free(sk); free(idx); free(tmp);
     return 0;
+}
+ORC_EXPORT int orc_stream(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
+                          const uint64_t *ref_hashes, const uint32_t *col_len,
+                          const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                          uint32_t top_k, uint64_t *cum,
+                          uint32_t *topk_idx, uint64_t *topk_sum, uint32_t *per_read_shared,
+                          uint64_t *sketches, uint32_t *sketch_len, int rank_every_read) {
+    return orc_stream_strided(k, seed, s, s, n_genomes, ref_hashes, col_len, bases, offsets, n_reads, top_k, cum, topk_idx,
+                              topk_sum, per_read_shared, sketches, sketch_len, rank_every_read);
 }
 
 /*

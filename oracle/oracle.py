@@ -56,6 +56,10 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_stream.restype = C.c_int
+        L.orc_stream_strided.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_stream_strided.restype = C.c_int
         L.orc_stream_mt.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int]
@@ -114,11 +118,11 @@ def stable_rank(sums: np.ndarray) -> np.ndarray:
 
 def stream(k, seed, s, ref_hashes, col_len, bases, offsets, top_k=1, cum=None,
            want_shared=False, want_sketches=False, rank_every_read=True):
-    """Run the streaming driver over a packed batch.  ref_hashes: [n_genomes, s] uint64
-    (row g = genome g's ascending hashes, first col_len[g] valid)."""
+    """Run the streaming driver over a packed batch.  ref_hashes: [n_genomes, stride] uint64
+    (row g = genome g's ascending hashes, first col_len[g] valid); s = the size reads are sketched with -- the row
+    stride unless the collection's first sketch is shorter / longer than others (src/sketchy.rs:82, :520-527)."""
     ref_hashes = np.ascontiguousarray(ref_hashes, np.uint64)
-    n_genomes = ref_hashes.shape[0]
-    assert ref_hashes.shape[1] == s
+    n_genomes, stride = ref_hashes.shape
     col_len = np.ascontiguousarray(col_len, np.uint32)
     bases = np.ascontiguousarray(bases, np.uint8)
     offsets = np.ascontiguousarray(offsets, np.uint64)
@@ -130,9 +134,9 @@ def stream(k, seed, s, ref_hashes, col_len, bases, offsets, top_k=1, cum=None,
     sk = np.zeros((n_reads, s), np.uint64) if want_sketches else None
     sl = np.zeros(n_reads, np.uint32) if want_sketches else None
     bases_p = bases if len(bases) else np.zeros(1, np.uint8)
-    rc = lib().orc_stream(k, seed, s, n_genomes, _ptr(ref_hashes), _ptr(col_len), _ptr(bases_p), _ptr(offsets),
-                          n_reads, top_k, _ptr(cum), _ptr(tk_i), _ptr(tk_s), _ptr(shared), _ptr(sk), _ptr(sl),
-                          1 if rank_every_read else 0)
+    rc = lib().orc_stream_strided(k, seed, s, stride, n_genomes, _ptr(ref_hashes), _ptr(col_len), _ptr(bases_p), _ptr(offsets),
+                                  n_reads, top_k, _ptr(cum), _ptr(tk_i), _ptr(tk_s), _ptr(shared), _ptr(sk), _ptr(sl),
+                                  1 if rank_every_read else 0)
     if rc != 0:
         raise ValueError("orc_stream failed (top_k > n_genomes?)")
     return dict(cum=cum, topk_idx=tk_i, topk_sum=tk_s, shared=shared, sketches=sk, sketch_len=sl)

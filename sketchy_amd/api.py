@@ -52,9 +52,11 @@ class ReferenceSketch:
     """Reference sketch collection(s) resident in HBM.  hashes: [n_genomes, s] uint64, row g = genome g's ascending
     distinct hashes, first col_len[g] valid -- or a LIST of such matrices, one per species (same s, k, seed): they are
     scanned together in one pass per batch, every species keeps its own table and ranking (one `sketchy predict` run
-    per species over the same reads, src/sketchy.rs:81-82)."""
+    per species over the same reads, src/sketchy.rs:81-82).  s: the size reads are sketched with; default = the matrix
+    width.  The reference uses the length of the collection's FIRST sketch (src/sketchy.rs:82, :520-527) -- pass
+    s=col_len[0] to mirror a collection whose sketches differ in length."""
 
-    def __init__(self, hashes, col_len=None, k=16, seed=0, device=0):
+    def __init__(self, hashes, col_len=None, k=16, seed=0, device=0, s=None):
         L = _lib.load()
         many = isinstance(hashes, (list, tuple))
         mats = [np.ascontiguousarray(h, np.uint64) for h in (hashes if many else [hashes])]
@@ -66,16 +68,17 @@ class ReferenceSketch:
                 for m, c in zip(mats, lens)]
         self.species = [int(m.shape[0]) for m in mats]
         self.n_species = len(mats)
-        self.n_genomes, self.s = sum(self.species), int(mats[0].shape[1])
+        self.n_genomes, self.stride = sum(self.species), int(mats[0].shape[1])
+        self.s = self.stride if s is None else int(s)
         self.k, self.seed, self.device = int(k), int(seed), int(device)
         h = C.c_void_p()
         if self.n_species == 1:
-            _lib.check(L.skx_ref_create(C.byref(h), device, self.k, self.seed, self.s, self.n_genomes, _p(mats[0]), _p(lens[0])))
+            _lib.check(L.skx_ref_create(C.byref(h), device, self.k, self.seed, self.s, self.stride, self.n_genomes, _p(mats[0]), _p(lens[0])))
         else:
             ng = (C.c_uint32 * self.n_species)(*self.species)
             hp = (C.c_void_p * self.n_species)(*[m.ctypes.data for m in mats])
             cp = (C.c_void_p * self.n_species)(*[c.ctypes.data for c in lens])
-            _lib.check(L.skx_ref_create_multi(C.byref(h), device, self.k, self.seed, self.s, self.n_species, ng, hp, cp))
+            _lib.check(L.skx_ref_create_multi(C.byref(h), device, self.k, self.seed, self.s, self.stride, self.n_species, ng, hp, cp))
         self._h = h
 
     @property

@@ -11,6 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsketchy_hip.so")
+# the same sources with -DSKX_EXPERIMENTS: the environment knobs of tests/ and tools/ (kernel variants, pass sizes,
+# pipeline depths, ablations) exist only here; selected with SKX_LIB_PATH, never loaded by default
+LIB_EXP = os.path.join(HERE, "libsketchy_hip_exp.so")
 SOURCES = ["skx_kernels.hip", "skx_capi.hip"]
 ARCH = "gfx950"
 
@@ -26,15 +29,13 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 and link the shared library."""
+def _build_lib(lib, objdir, extra, force, verbose):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(ROOT, "include", "sketchy_hip.h"))
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-             "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-result"]
-    objs = []
+             "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-result", *extra]
+    objs, procs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -42,13 +43,23 @@ def build(force=False, verbose=False):
             cmd = [_hipcc(), *flags, "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
-    if force or _stale(LIB, objs):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-ldl"]
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if force or _stale(lib, objs):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib, "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    return lib
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 and link the shared library (and its experiments twin)."""
+    _build_lib(LIB, os.path.join(HERE, "build"), [], force, verbose)
+    _build_lib(LIB_EXP, os.path.join(HERE, "build", "exp"), ["-DSKX_EXPERIMENTS"], force, verbose)
     build_host(force=force, verbose=verbose)
     return LIB
 

@@ -51,7 +51,11 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 SKX_API const char* skx_last_error(void) { return g_err.c_str(); }
-SKX_API const char* skx_version(void) { return "sketchy-hip 0.1.0 (gfx950)"; }
+#ifdef SKX_EXPERIMENTS
+SKX_API const char* skx_version(void) { return "sketchy-hip 0.3.0 (gfx950, experiments build: reads SKX_* environment knobs)"; }
+#else
+SKX_API const char* skx_version(void) { return "sketchy-hip 0.3.0 (gfx950)"; }
+#endif
 
 SKX_API int skx_device_count(void) {
     int n = 0;
@@ -117,7 +121,8 @@ SKX_API int skx_dev_synchronize(int device) {
 // ------------------------------------------------------------------ reference
 struct skx_ref {
     int device = 0;
-    u32 k = 0, s = 0, n_genomes = 0 /* real genomes, all species */, n_tiles = 0, n_pad = 0, rb = 0, n_bands = 0;
+    u32 k = 0, s = 0 /* rows of the matrix = column stride */, s_read = 0 /* sketch size of the reads (|sketch 0| in the reference) */;
+    u32 n_genomes = 0 /* real genomes, all species */, n_tiles = 0, n_pad = 0, rb = 0, n_bands = 0;
     u64 seed = 0;
     // species (reference collections scanned together); each padded to whole rank groups of 512 genomes
     u32 n_species = 0;
@@ -150,13 +155,16 @@ static void ref_free(skx_ref* r) {
 
 static const u32 kGroupGenomes = skx::kRankWords * 64u;  // 512: a species starts on a rank-group boundary
 
-SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_species,
-                                 const uint32_t* n_genomes, const uint64_t* const* hashes, const uint32_t* const* col_len) {
+SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s_read, uint32_t stride,
+                                 uint32_t n_species, const uint32_t* n_genomes, const uint64_t* const* hashes,
+                                 const uint32_t* const* col_len) {
     if (!out || !n_genomes || !hashes || !col_len) return fail(SKX_ERR_INVALID, "NULL argument");
     *out = nullptr;
+    if (s_read < 1) return fail(SKX_ERR_INVALID, "read sketch size s must be >= 1");
+    const uint32_t s = stride;  // rows of the resident matrix
     if (k < 1 || k > SKX_MAX_K) return fail(SKX_ERR_INVALID, "k=%u outside 1..%u", k, SKX_MAX_K);
     if (n_species < 1 || n_species > SKX_MAX_SPECIES) return fail(SKX_ERR_INVALID, "n_species=%u outside 1..%u", n_species, SKX_MAX_SPECIES);
-    if (s < 1) return fail(SKX_ERR_INVALID, "empty reference (s=0)");
+    if (s < 1) return fail(SKX_ERR_INVALID, "empty reference (stride=0)");
     u64 total = 0, total_pad = 0;
     for (u32 sp = 0; sp < n_species; ++sp) {
         if (!hashes[sp] || !col_len[sp]) return fail(SKX_ERR_INVALID, "NULL argument (species %u)", sp);
@@ -168,10 +176,10 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
     SKXCHK(use_device(device));
 
     skx_ref* r = new skx_ref;
-    r->device = device; r->k = k; r->seed = seed; r->s = s; r->n_genomes = (u32)total; r->n_species = n_species;
+    r->device = device; r->k = k; r->seed = seed; r->s = s; r->s_read = s_read; r->n_genomes = (u32)total; r->n_species = n_species;
     r->n_pad = (u32)total_pad;
     r->n_tiles = r->n_pad / skx::kTileGenomes;
-    static const int rb_env = getenv("SKX_RB") ? atoi(getenv("SKX_RB")) : 0;  // experiment knob
+    static const int rb_env = skx::knob("SKX_RB") ? atoi(skx::knob("SKX_RB")) : 0;  // experiment knob
     r->rb = rb_env >= 8 ? (u32)rb_env : 64;  // rows per band (measured best of 64/128/256/512 on MI355X)
     r->n_bands = (s + r->rb - 1) / r->rb;
     r->min_species = 0xFFFFFFFFu;
@@ -194,7 +202,7 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
     for (u32 sp = 0; sp < n_species; ++sp) {
         for (u32 g = 0; g < n_genomes[sp]; ++g) {
             const u32 len = col_len[sp][g];
-            if (len > s) { delete r; return fail(SKX_ERR_INVALID, "species %u: col_len[%u]=%u exceeds s=%u", sp, g, len, s); }
+            if (len > s) { delete r; return fail(SKX_ERR_INVALID, "species %u: col_len[%u]=%u exceeds stride=%u", sp, g, len, s); }
             const uint64_t* col = hashes[sp] + (size_t)g * s;
             for (u32 i = 1; i < len; ++i)
                 if (col[i] <= col[i - 1]) { delete r; return fail(SKX_ERR_UNSORTED, "species %u genome %u: hashes not strictly ascending at %u", sp, g, i); }
@@ -266,7 +274,7 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         // bitmap size: 64 bits per reference hash (1.6 % false positives -- each one is an all-zero row of the bit matrices
         // and an entry of every slice it falls into), between 2^16 and 2^36 bits (8 GB; env SKX_FILTER_LG caps it lower:
         // at 2^33 bits C2 has 21 bits per hash and half of its dictionary is false positives); shift so that max_ref fits
-        static const u32 lg_cap = getenv("SKX_FILTER_LG") ? (u32)std::min(36, std::max(16, atoi(getenv("SKX_FILTER_LG")))) : 36u;
+        static const u32 lg_cap = skx::knob("SKX_FILTER_LG") ? (u32)std::min(36, std::max(16, atoi(skx::knob("SKX_FILTER_LG")))) : 36u;
         const u64 want = 64ull * s * total;
         u32 lg = 16;
         while (lg < lg_cap && (1ull << lg) < want) ++lg;
@@ -284,12 +292,19 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
     *out = r;
     return SKX_OK;
 }
-SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t n_genomes,
+SKX_API int skx_ref_create(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, uint32_t n_genomes,
                            const uint64_t* hashes, const uint32_t* col_len) {
     if (!out || !hashes || !col_len) return fail(SKX_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    if (s < 1 || n_genomes < 1) return fail(SKX_ERR_INVALID, "empty reference (s=%u, n_genomes=%u)", s, n_genomes);
-    return skx_ref_create_multi(out, device, k, seed, s, 1, &n_genomes, &hashes, &col_len);
+    if (s < 1 || stride < 1 || n_genomes < 1)
+        return fail(SKX_ERR_INVALID, "empty reference (s=%u, stride=%u, n_genomes=%u)", s, stride, n_genomes);
+    return skx_ref_create_multi(out, device, k, seed, s, stride, 1, &n_genomes, &hashes, &col_len);
+}
+SKX_API int skx_ref_sketch_size(const skx_ref* ref, uint32_t* s, uint32_t* stride) {
+    if (!ref) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (s) *s = ref->s_read;
+    if (stride) *stride = ref->s;
+    return SKX_OK;
 }
 SKX_API int skx_ref_n_genomes(const skx_ref* ref, uint32_t* n_genomes) {
     if (!ref || !n_genomes) return fail(SKX_ERR_INVALID, "NULL argument");
@@ -552,7 +567,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // 1/32 of the free device memory each, at most 8 GB -- env SKX_PASS_MB overrides)
     size_t mem_free = 0, mem_total = 0;
     (void)hipMemGetInfo(&mem_free, &mem_total);
-    static const u64 pass_mb_env = getenv("SKX_PASS_MB") ? (u64)atoll(getenv("SKX_PASS_MB")) : 0;
+    static const u64 pass_mb_env = skx::knob("SKX_PASS_MB") ? (u64)atoll(skx::knob("SKX_PASS_MB")) : 0;
     const u64 pass_mb = pass_mb_env ? pass_mb_env : std::min<u64>(16384, std::max<u64>(256, (u64)(mem_free >> 20) / 16));
     u64 pc = (pass_mb << 20) * 8 / n_pad;
     pc = std::min<u64>(pc, max_reads > 65536 ? (1u << 22) : (1u << 20));
@@ -560,7 +575,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     pc = std::max<u64>(pc, sk_stride);
     pc = (pc + 63) / 64 * 64;
     st->pcap = (u32)pc;
-    static const u64 pass_reads = getenv("SKX_PASS_READS") ? (u64)atoll(getenv("SKX_PASS_READS")) : 131072;
+    static const u64 pass_reads = skx::knob("SKX_PASS_READS") ? (u64)atoll(skx::knob("SKX_PASS_READS")) : 131072;
     u64 rp = std::min<u64>(max_reads, pass_reads);
     // candidate arrays of the ranking: per (read, rank group, row) for top_k <= 16, per (read, genome word, row) beyond
     const u32 n_sp = ref->n_species;
@@ -579,18 +594,18 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // sketch kernel leaving room on every CU (launch_sketch, leave_room) the VALU-bound sketch of batch i+1 and the
     // HBM-bound scan of batch i overlap for real: C2, same box: 54.5 -> 59.7 M reads/s from a fresh table, 56.8 -> 63.6 M
     // steady, the scan itself 0.62 -> 0.78 ms.
-    static const int depth_env = getenv("SKX_PIPELINE") ? atoi(getenv("SKX_PIPELINE")) : 3;
+    static const int depth_env = skx::knob("SKX_PIPELINE") ? atoi(skx::knob("SKX_PIPELINE")) : 3;
     st->depth = depth_env < 1 ? 1 : depth_env > 4 ? 4 : depth_env;
     // the HBM-bound scan stream gets the higher priority (it needs its full occupancy); the others fill what is left
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // numerically lower = higher priority
-    static const int prio_env = getenv("SKX_PRIO") ? atoi(getenv("SKX_PRIO")) : 1;
+    static const int prio_env = skx::knob("SKX_PRIO") ? atoi(skx::knob("SKX_PRIO")) : 1;
     if (!prio_env) prio_hi = prio_lo;
     // Experiment (env SKX_CU_SCAN = n, with SKX_PIPELINE = 3): partition the chip -- the scan stream may only use n of the
     // CUs (spread evenly over the XCDs: mask bit i is CU i / 8 of XCD i % 8), the sketch / dictionary and ranking
     // streams only the others, so the HBM-bound scan of batch i and the VALU-bound sketch of batch i + 1 run side by
     // side without sharing a CU.  Results in DESIGN.md; off by default.
-    static const int cu_scan_env = getenv("SKX_CU_SCAN") ? atoi(getenv("SKX_CU_SCAN")) : 0;
+    static const int cu_scan_env = skx::knob("SKX_CU_SCAN") ? atoi(skx::knob("SKX_CU_SCAN")) : 0;
     int n_cus = 0;
     (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, st->device);
     if (cu_scan_env > 0 && cu_scan_env < n_cus && st->depth >= 3) {
@@ -607,14 +622,14 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // take turns and only the HBM-bound scan runs beside them)
     if (st->depth == 4) st->hs2 = st->hs0;
     else if (st->depth >= 2) {
-        static const int rank_hi = getenv("SKX_PRIO_RANK") ? atoi(getenv("SKX_PRIO_RANK")) : 0;  // experiment knob
+        static const int rank_hi = skx::knob("SKX_PRIO_RANK") ? atoi(skx::knob("SKX_PRIO_RANK")) : 0;  // experiment knob
         SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, rank_hi ? prio_hi : prio_lo));
     } else st->hs2 = st->hs;
     }
     {
         // (measured at C2: with the split the stream far from its start gains 5 % (78.6 -> 83 M reads/s), the first 2 M reads
         // of a sample -- heavy ranking, nothing pruned yet -- lose 10 % (72.5 -> 64.5 M): off by default)
-        static const int split_env = getenv("SKX_RANK_SPLIT") ? atoi(getenv("SKX_RANK_SPLIT")) : 0;
+        static const int split_env = skx::knob("SKX_RANK_SPLIT") ? atoi(skx::knob("SKX_RANK_SPLIT")) : 0;
         if (st->depth == 3 && split_env && cu_scan_env <= 0) SCHK(hipStreamCreateWithPriority(&st->hs3, hipStreamNonBlocking, prio_lo));
         else st->hs3 = st->hs2;
     }
@@ -722,7 +737,7 @@ SKX_API int skx_stream_create(skx_stream** out, const skx_ref* ref, uint32_t top
     if (max_batch_reads < 1) return fail(SKX_ERR_INVALID, "max_batch_reads must be >= 1");
     // a read contributes at most min(s, #k-mers) hashes; short reads (<= kSketchCap k-mers) are the floor
     const u64 longest = std::max<u64>(max_batch_bases, (u64)skx::kSketchCap);
-    const u32 sk_stride = (u32)std::min<u64>(ref->s, longest);
+    const u32 sk_stride = (u32)std::min<u64>(ref->s_read, longest);
     if (max_batch_bases >= (1ull << 32)) return fail(SKX_ERR_CAPACITY, "max_batch_bases must be below 2^32");
     // real reads leave a handful of pairs each (C2: ~5 of ~1500 hashes are in range and held by some genome); 64 per read
     // keeps small streams small, and denser batches simply take more passes
@@ -865,7 +880,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     if (P > 0) {
         const u32 n_words = (P + 63) / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
-        static const int split_env = getenv("SKX_SCAN_SPLIT") ? atoi(getenv("SKX_SCAN_SPLIT")) : -1;
+        static const int split_env = skx::knob("SKX_SCAN_SPLIT") ? atoi(skx::knob("SKX_SCAN_SPLIT")) : -1;
         bool split = split_env >= 0 ? split_env != 0 : (nq_est * ref->rb / ref->s >= 192);
         if (split && !st->d_mint) {  // dense dictionaries only: most streams never get here
             const size_t bytes = (size_t)(st->pcap / 64) * n_pad * 8;
@@ -877,7 +892,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
                 split = false;  // no room: the plain variant gives the same bits
             }
         }
-        static const int big_env = getenv("SKX_SCAN_BIG") ? atoi(getenv("SKX_SCAN_BIG")) : -1;
+        static const int big_env = skx::knob("SKX_SCAN_BIG") ? atoi(skx::knob("SKX_SCAN_BIG")) : -1;
         const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
         const bool lean = st->d_hbuf && skx::scan_lean_applies(ref->n_bands, split, big);
         st->total_passes += 1; st->lean_passes += lean ? 1 : 0;
@@ -927,9 +942,9 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         const u32 prune_k = (ranked && st->top_k <= skx::rank_topk_fast_max()) ? st->top_k : 0u;
         // the top-1 kernel keeps (value relative to the leader) in 23 bits of a 32-bit key: at most 2 x 64 x s + 1 per
         // segment, so sketch sizes from 2^15 on take the 64-bit-key kernel (with k = 1) instead
-        static const bool top1_wide_env = getenv("SKX_TOP1_WIDE") != nullptr;  // test knob: force the 64-bit-key kernel
-        const bool top1_fast = st->top_k == 1 && ref->s < (1u << 15) && !top1_wide_env;
-        static const bool live_env = !getenv("SKX_RANK_LIVE") || atoi(getenv("SKX_RANK_LIVE")) != 0;  // test knob
+        static const bool top1_wide_env = skx::knob("SKX_TOP1_WIDE") != nullptr;  // test knob: force the 64-bit-key kernel
+        const bool top1_fast = st->top_k == 1 && ref->s_read < (1u << 15) && !top1_wide_env;
+        static const bool live_env = !skx::knob("SKX_RANK_LIVE") || atoi(skx::knob("SKX_RANK_LIVE")) != 0;  // test knob
         const bool topk_fast = !top1_fast && st->top_k && st->top_k <= skx::rank_topk_fast_max();
         unsigned char* d_live = ((top1_fast || topk_fast) && ranked && live_env) ? st->d_live : nullptr;  // (the pruned kernels look at the flags)
         skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
@@ -1001,13 +1016,13 @@ static int wait_published(skx_stream* st, const PendingBatch& pb) {
     return SKX_OK;
 }
 static const u32* batch_filter(const skx_ref* ref) {
-    static const bool no_filter = getenv("SKX_NO_FILTER") != nullptr;  // measurement aid
+    static const bool no_filter = skx::knob("SKX_NO_FILTER") != nullptr;  // measurement aid
     return (ref->any && !no_filter) ? ref->d_filt : nullptr;
 }
 // counts -> (filter, for rows the sketchers did not filter themselves) -> pair offsets (poff[n_reads] = total pairs)
 // -> speculative pair gather -> the few words the host needs, published to page-locked memory
 // (the stream's d_sk ... names must be on the batch's side)
-static int finish_counts(skx_stream* st, PendingBatch& pb) {
+static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
     const skx_ref* ref = st->ref;
     hipStream_t hs = st->hs0;
     const u32 n_reads = pb.n_reads;
@@ -1052,7 +1067,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     const u32* filt = batch_filter(ref);
     // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
     pb.dbg_cap = pb.h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
-    static const bool spec_env = !getenv("SKX_SPEC_INSERT") || atoi(getenv("SKX_SPEC_INSERT")) != 0;  // test knob
+    static const bool spec_env = !skx::knob("SKX_SPEC_INSERT") || atoi(skx::knob("SKX_SPEC_INSERT")) != 0;  // test knob
     pb.spec_insert = spec_env && n_reads <= std::min(st->rpass, pb.dbg_cap);  // one pass unless the pairs turn out too many
     pb.spec_set = st->buf ^ (st->pend.valid ? 1 : 0);
     pb.spec_slot = (st->pslot + (st->pend.valid ? 1 : 0)) % 3;
@@ -1078,7 +1093,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
             for (int i = 0; i < 2; ++i)
                 if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
         (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-        HIPCHK(skx::launch_sketch(hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s, max_ref, pb.inrange_only,
+        HIPCHK(skx::launch_sketch(hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s_read, max_ref, pb.inrange_only,
                                   st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big,
                                   pb.n_bases, st->d_chk, leave_room, st->packed));
         if (!pb.inrange_only) {
@@ -1087,7 +1102,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
             u32 n_big = 0;
             HIPCHK(hipMemcpyAsync(&n_big, st->d_big, 4, hipMemcpyDeviceToHost, hs));
             HIPCHK(hipStreamSynchronize(hs));
-            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s, max_ref,
+            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s_read, max_ref,
                                             false, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->packed));
             st->reads_big += n_big;
             HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
@@ -1095,11 +1110,11 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         // optional sketch outputs leave now: the filter compacts the rows in place
         if (pb.h_sketch_len) HIPCHK(hipMemcpyAsync(pb.h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
         if (pb.h_sketches) {
-            memset(pb.h_sketches, 0, (size_t)n_reads * ref->s * 8);
-            HIPCHK(hipMemcpy2DAsync(pb.h_sketches, (size_t)ref->s * 8, st->d_sk, (size_t)st->sk_stride * 8,
-                                    (size_t)std::min(ref->s, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
+            memset(pb.h_sketches, 0, (size_t)n_reads * ref->s_read * 8);
+            HIPCHK(hipMemcpy2DAsync(pb.h_sketches, (size_t)ref->s_read * 8, st->d_sk, (size_t)st->sk_stride * 8,
+                                    (size_t)std::min(ref->s_read, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
         }
-        SKXCHK(finish_counts(st, pb));
+        SKXCHK(queue_counts_and_summary(st, pb));
     }
     st->chk_dirty = false;  // the publish kernel is queued: it re-arms the device-side counters
     pb.valid = true;
@@ -1128,30 +1143,47 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     HIPCHK(use_side(st, pb.side));
     SKXCHK(wait_published(st, pb));  // the one wait of a batch: 36 bytes, no copy, no stream synchronisation
     if (pb.h_sketches || pb.h_sketch_len) HIPCHK(hipStreamSynchronize(hs));  // (debug outputs: their copies must have landed)
+    // A refused batch must not leave its pairs behind: the speculative gather queued by the front half has already put the
+    // batch's keys into the hash set of buffer set spec_set (it only looks at the pair capacity, not at the offsets), and
+    // every later pass on that set assumes |Q| <= its own pair count.  Empty the set again before returning the error.
+    auto refuse = [&](int code, const std::string& msg) -> int {
+        (void)cancel_speculation(st, pb);
+        return fail(code, "%s", msg.c_str());
+    };
     {
         u32 c[8];
         for (int i = 0; i < 8; ++i) c[i] = st->h_chk[i];
-        if (c[0]) return fail(SKX_ERR_INVALID, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
-        if (c[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases=%llu bytes given from offsets[0] on",
-                              (unsigned long long)pb.n_bases);
+        char buf[160];
+        if (c[0]) {
+            snprintf(buf, sizeof buf, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
+            return refuse(SKX_ERR_INVALID, buf);
+        }
+        if (c[6]) {
+            snprintf(buf, sizeof buf, "a read lies outside the n_bases=%llu bytes given from offsets[0] on", (unsigned long long)pb.n_bases);
+            return refuse(SKX_ERR_INVALID, buf);
+        }
         if (c[7]) {
             // production mode, rare: reads whose in-range hashes overflowed a wave's 2048 slots wait on the `big` list.
             // The block sketcher was not queued blindly (it needs a drained CU even to find the list empty): run it now,
             // then counts, pair gather (into the same buffer set: the keys already there are a subset) and the
             // published summary once more.
             st->reads_big += c[7];
-            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s, max_ref,
+            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s_read, max_ref,
                                             pb.inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift,
                                             st->packed));
-            SKXCHK(finish_counts(st, pb));
+            SKXCHK(queue_counts_and_summary(st, pb));
             SKXCHK(wait_published(st, pb));
-            if (st->h_chk[6]) return fail(SKX_ERR_INVALID, "a read lies outside the n_bases given from offsets[0] on");
+            if (st->h_chk[6]) return refuse(SKX_ERR_INVALID, "a read lies outside the n_bases given from offsets[0] on");
         }
     }
     const u32 total_pairs = st->h_chk[8];
     st->last_pairs = total_pairs; st->last_passes = 0;
 
     const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap;
+    // (the batch needs several passes although a speculative gather was queued for it: normally that gather did nothing -- it
+    // saw more pairs than a pass holds -- but after the block-sketcher redo above the FIRST gather may have fitted while the
+    // recount does not; either way the set must be empty before the passes insert their own pairs)
+    if (!single && pb.spec_insert) SKXCHK(cancel_speculation(st, pb));
     bool inserted = pb.spec_insert && single;  // the gather queued by the front half did its work
     if (!single && younger) SKXCHK(cancel_speculation(st, *younger));
     if (inserted && (st->buf != pb.spec_set || st->pslot != pb.spec_slot)) return fail(SKX_ERR_HIP, "internal: buffer sets out of step");
@@ -1469,12 +1501,15 @@ SKX_API int skx_stream_reads(const skx_stream* st, uint64_t* n_reads) {
 SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
     if (!st || !out) return fail(SKX_ERR_INVALID, "NULL argument");
     // rank groups that received any bit in the most recent pass (waits for the stream)
+    // (a deferred error of an enqueued batch surfaces here like in every other entry point that flushes)
     uint64_t live = 0;
-    if (use_device(st->device) == SKX_OK && skx_stream_sync(st) == SKX_OK) {
+    SKXCHK(use_device(st->device));
+    SKXCHK(skx_stream_sync(st));
+    {
         const u32 n_grp = st->ref->n_pad / (skx::kRankWords * 64);
         std::vector<u32> flags(n_grp, 0);
-        if (hipMemcpy(flags.data(), st->d_grp_any[st->buf ^ 1], (size_t)n_grp * 4, hipMemcpyDeviceToHost) == hipSuccess)
-            for (u32 f : flags) live += f ? 1 : 0;
+        HIPCHK(hipMemcpy(flags.data(), st->d_grp_any[st->buf ^ 1], (size_t)n_grp * 4, hipMemcpyDeviceToHost));
+        for (u32 f : flags) live += f ? 1 : 0;
     }
     const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)std::max(st->h_nq[0], st->h_nq[1]), st->reads_big,
                                      st->total_passes, st->lean_passes, st->pcap, live};

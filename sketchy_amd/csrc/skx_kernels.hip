@@ -2549,7 +2549,7 @@ __global__ void gather_table_kernel(const u64* __restrict__ cum, u64* __restrict
 // launchers
 // =====================================================================================
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int env_int(const char* name, int dflt) { const char* e = knob(name); return e ? atoi(e) : dflt; }
 
 void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 pad_base, u32 g_count) {
     dim3 grid(cdiv(s, 32), cdiv(g_count, 32));
@@ -2717,52 +2717,39 @@ void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands,
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table,
                  u64* hbuf /* slabs of the lean kernel, or NULL: legacy kernels */, u32* m_dirty) {
-    static const int ablate = env_int("SKX_SCAN_ABLATE", 0);  // profiling aid only
     dim3 grid(n_tiles * n_bands), block(256);
-    // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe
-    if (hbuf) {
-        static const u32 prio = (u32)env_int("SKX_SCAN_PRIO", 1);
-#define SKX_SCAN_L(A) hipLaunchKernelGGL((scan_lean_kernel<A>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio)
-        switch (ablate) {
-            case 1: SKX_SCAN_L(1); break;
-            case 2: SKX_SCAN_L(2); break;
-            case 3: SKX_SCAN_L(3); break;
-            default: {
-                static const int nt = env_int("SKX_SCAN_NT", 0);  // experiment: 1 = non-temporal slab stores, 2 = matrix loads, 3 = both
-                if (nt == 1) hipLaunchKernelGGL((scan_lean_kernel<0, 1>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
-                else if (nt == 2) hipLaunchKernelGGL((scan_lean_kernel<0, 2>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
-                else if (nt == 3) hipLaunchKernelGGL((scan_lean_kernel<0, 3>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
-                else SKX_SCAN_L(0);
-                break;
-            }
-        }
+#ifdef SKX_EXPERIMENTS
+    // profiling aids (results invalid unless 0): the ablated kernels are not even compiled into the product library
+    static const int ablate = env_int("SKX_SCAN_ABLATE", 0);
+    static const int nt = env_int("SKX_SCAN_NT", 0);  // 1 = non-temporal slab stores, 2 = matrix loads, 3 = both
+    static const u32 prio = (u32)env_int("SKX_SCAN_PRIO", 1);
+    if (hbuf && (ablate || nt)) {
+#define SKX_SCAN_L(A, N) hipLaunchKernelGGL((scan_lean_kernel<A, N>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio)
+        if (ablate == 1) SKX_SCAN_L(1, 0); else if (ablate == 2) SKX_SCAN_L(2, 0); else if (ablate == 3) SKX_SCAN_L(3, 0);
+        else if (nt == 1) SKX_SCAN_L(0, 1); else if (nt == 2) SKX_SCAN_L(0, 2); else SKX_SCAN_L(0, 3);
 #undef SKX_SCAN_L
         return;
     }
-#define SKX_SCAN(A, SP) \
-    hipLaunchKernelGGL((scan_kernel<2040, A, SP>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
-    if (big_table && ablate == 0 && m_int) {
-        // very dense passes: 4088-entry slices (40 KB of LDS, 3 blocks per CU) instead of re-streaming the band
-        hipLaunchKernelGGL((scan_kernel<4088, 0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
+    if (!hbuf && ablate) {
+#define SKX_SCAN_A(CAP, A, SP) hipLaunchKernelGGL((scan_kernel<CAP, A, SP>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
+        if (big_table && m_int) { if (ablate == 1) SKX_SCAN_A(4088, 1, true); else if (ablate == 2) SKX_SCAN_A(4088, 2, true); else SKX_SCAN_A(4088, 3, true); }
+        else if (ablate == 1) SKX_SCAN_A(2040, 1, false); else if (ablate == 2) SKX_SCAN_A(2040, 2, false); else SKX_SCAN_A(2040, 3, false);
+#undef SKX_SCAN_A
         return;
     }
-#define SKX_SCAN_BIG(A) \
-    hipLaunchKernelGGL((scan_kernel<4088, A, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
-    if (big_table && m_int) {
-        switch (ablate) {
-            case 1: SKX_SCAN_BIG(1); return;
-            case 2: SKX_SCAN_BIG(2); return;
-            default: SKX_SCAN_BIG(3); return;
-        }
+#else
+    const u32 prio = 1u;
+#endif
+    // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe
+    if (hbuf) {
+        hipLaunchKernelGGL((scan_lean_kernel<0, 0>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+        return;
     }
-#undef SKX_SCAN_BIG
-    switch (ablate) {
-        case 1: SKX_SCAN(1, false); break;
-        case 2: SKX_SCAN(2, false); break;
-        case 3: SKX_SCAN(3, false); break;
-        default: if (m_int) SKX_SCAN(0, true); else SKX_SCAN(0, false); break;
-    }
-#undef SKX_SCAN
+    // dense passes: 2040-entry slices, interior words by plain stores when the caller has the second array; very dense:
+    // 4088-entry slices (40 KB of LDS, 3 blocks per CU) instead of re-streaming the band
+    if (big_table && m_int) hipLaunchKernelGGL((scan_kernel<4088, 0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
+    else if (m_int) hipLaunchKernelGGL((scan_kernel<2040, 0, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
+    else hipLaunchKernelGGL((scan_kernel<2040, 0, false>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
 }
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any,
                            const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64 nq_est) {

@@ -4,9 +4,24 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 namespace skx {
 typedef unsigned long long u64;
 typedef unsigned int u32;
+
+// Experiment / test knobs: environment variables that pick a kernel variant, a stream arrangement, a pass size or -- the
+// profiling aids SKX_SCAN_ABLATE and SKX_NO_FILTER -- change what the kernels compute.  They exist only in the
+// -DSKX_EXPERIMENTS build (sketchy_amd/libsketchy_hip_exp.so, used by tests/ and tools/ through SKX_LIB_PATH); the
+// product library reads no environment variable at all.
+inline const char* knob(const char* name) {
+#ifdef SKX_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 constexpr int kSketchCap = 2048;   // k-mers per read the one-wave-per-read sketcher holds in LDS
 constexpr u32 kSegLen = 64;        // reads per ranking segment

@@ -182,7 +182,8 @@ class Sketchy {
             }
             stride_ = stride;
             // columns may be longer than sketch 0; the read sketch size stays s (reference behaviour)
-            hip_check(skx_ref_create(&h, device, k, seed, stride, (uint32_t)sk.size(), flat.data(), len.data()), "reference upload");
+            if (s == 0) throw SketchyError("the first reference sketch is empty (it defines the read sketch size)");
+            hip_check(skx_ref_create(&h, device, k, seed, s, stride, (uint32_t)sk.size(), flat.data(), len.data()), "reference upload");
         }
         ~Ref() { skx_ref_destroy(h); }
         uint32_t stride_ = 0;
@@ -220,7 +221,6 @@ class Sketchy {
     // streaming mode
     void sum_of_shared_hashes(FastxReader& reader, const std::vector<Sketch>& sketches, Ref& ref, const Genotypes& geno,
                               const PredictConfig& config, std::ostream& out) {
-        if (ref.stride_ != ref.s) throw SketchyError("reference sketches of unequal size are not supported in stream mode");
         const size_t cap = 256ull << 20;  // bases per batch buffer (a single record must fit)
         skx_stream* st = nullptr;
         hip_check(skx_stream_create(&st, ref.h, (uint32_t)config.top, (uint32_t)batch_, cap), "stream");

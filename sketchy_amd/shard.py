@@ -67,6 +67,18 @@ def sum_over_ranks_int(x: int) -> int:
     return int(t.item())
 
 
+def gather_floats(x: float):
+    """Every rank's x, in rank order (a one-element list for a single process)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(x)]
+    mine = torch.tensor([x], dtype=torch.float64)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]
+
+
 def broadcast_bytes(b: bytes, n: int, src=0) -> bytes:
     import torch
     import torch.distributed as dist
@@ -113,12 +125,15 @@ class TableReducer:
         from . import api
         self.how = "single"
         self.comm = None
-        self.n_ranks = 1  # ranks the table is summed over (RCCL: ncclCommCount of the communicator)
+        self.world = 1        # ranks of the job (torch.distributed)
+        self.rccl_ranks = 0   # ranks a LIVE RCCL communicator reports (ncclCommCount); 0 whenever RCCL is not the transport
+        self.err = None       # why RCCL was not used (fallback path only)
+        self.last_ms = None   # wall time of the most recent allreduce() on this rank (collective + its synchronisation)
         if not (dist.is_initialized() and dist.get_world_size() > 1):
             return
         rank, world = dist.get_rank(), dist.get_world_size()
+        self.world = world
         self.how = "gloo-host"
-        self.n_ranks = world
         # every rank first proves it can load RCCL (making an id does; only rank 0's is used): a rank that cannot
         # would otherwise leave the others blocked inside ncclCommInitRank
         uid = b"\0" * 128
@@ -136,7 +151,7 @@ class TableReducer:
             try:
                 self.comm = api.Comm(device, rank, world, uid)
                 self.how = "rccl"
-                self.n_ranks = self.comm.n_ranks
+                self.rccl_ranks = self.comm.n_ranks
             except Exception as e:  # noqa: BLE001  (RCCL unavailable: stay on the host path)
                 self.err = repr(e)
                 self.comm = None
@@ -145,19 +160,34 @@ class TableReducer:
         if ok != world:
             if self.comm is not None:
                 self.comm.close()
-            self.comm, self.how, self.n_ranks = None, "gloo-host", world
+            self.comm, self.how, self.rccl_ranks = None, "gloo-host", 0
 
     def close(self):
         if self.comm is not None:
             self.comm.close()
             self.comm = None
 
+    @property
+    def n_ranks(self) -> int:
+        """Ranks the table is summed over, whatever the transport (1 for a single process)."""
+        return self.world
+
+    def report(self) -> dict:
+        """What bench.py prints as config.allreduce: transport, ranks RCCL itself counted (0 unless how == "rccl"), and the
+        time of the last collective."""
+        return {"how": self.how, "ranks": self.rccl_ranks if self.how == "rccl" else 0, "world": self.world,
+                "ms": self.last_ms, "fallback_reason": self.err if self.how == "gloo-host" else None}
+
     def allreduce(self, stream):
+        import time
         if self.how == "single":
+            self.last_ms = 0.0
             return
+        t0 = time.perf_counter()
         if self.comm is not None:
-            stream.allreduce(self.comm)
-            return
-        mine = stream.table()
-        total = allreduce_table_host(mine)
-        stream.table_add(total - mine)  # u64 wrap-around arithmetic is exact here
+            stream.allreduce(self.comm)  # (flushes the stream's pending batch, then ncclAllReduce + stream synchronisation)
+        else:
+            mine = stream.table()
+            total = allreduce_table_host(mine)
+            stream.table_add(total - mine)  # u64 wrap-around arithmetic is exact here
+        self.last_ms = 1e3 * (time.perf_counter() - t0)

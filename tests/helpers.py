@@ -1,7 +1,19 @@
 """Shared builders for the parity tests: seeded workloads handed to BOTH the oracle and the HIP path."""
+import os
+
 import numpy as np
 
 from sketchy_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXP_LIB = os.path.join(ROOT, "sketchy_amd", "libsketchy_hip_exp.so")
+
+
+def exp_env(**knobs):
+    """Environment of a subprocess that loads the EXPERIMENTS build of the library (-DSKX_EXPERIMENTS: the only build that
+    reads SKX_* knobs) with the given knobs set; the product library ignores every one of them."""
+    assert os.path.exists(EXP_LIB), f"{EXP_LIB} not built (python -m sketchy_amd.build)"
+    return dict(os.environ, SKX_LIB_PATH=EXP_LIB, **{k: str(v) for k, v in knobs.items()})
 
 
 def pack_reads(reads):

@@ -37,6 +37,24 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n)
 
 
+def test_product_library_has_no_environment_knobs():
+    """The product .so neither imports getenv nor carries the name of any SKX_* knob; the experiments twin
+    (-DSKX_EXPERIMENTS, loaded only through SKX_LIB_PATH by tests/ and tools/) does both and exports the same ABI."""
+    from sketchy_amd import _lib, build
+    assert os.path.realpath(_lib.LIB_PATH) == os.path.realpath(build.LIB) or os.environ.get("SKX_LIB_PATH")
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", build.LIB], text=True)
+    assert "getenv" not in und
+    blob = open(build.LIB, "rb").read()
+    names = set(re.findall(rb"SKX_[A-Z][A-Z0-9_]{3,}", blob)) - {b"SKX_MAX_TOP"}  # (an error message quotes the header's macro)
+    assert not names, sorted(names)[:5]
+    und_exp = subprocess.check_output(["nm", "-D", "--undefined-only", build.LIB_EXP], text=True)
+    assert "getenv" in und_exp
+    blob_exp = open(build.LIB_EXP, "rb").read()
+    assert b"SKX_SCAN_ABLATE" in blob_exp and b"SKX_NO_FILTER" in blob_exp
+    exp = set(re.findall(r"\bT (skx_[a-z0-9_]+)", subprocess.check_output(["nm", "-D", "--defined-only", build.LIB_EXP], text=True)))
+    assert set(declared_symbols()) <= exp
+
+
 def test_library_contains_gfx950_code_object():
     from sketchy_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()

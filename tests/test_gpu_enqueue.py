@@ -157,13 +157,60 @@ def test_enqueue_errors_surface_one_call_late(gpu):
         d.free()
 
 
+def test_a_refused_batch_leaves_nothing_behind(gpu):
+    """A LARGE batch that fails validation (its speculative pair gather has already filled the pass's hash set) followed by
+    SMALLER batches of DIFFERENT reads: the next passes on that buffer set must see only their own keys (|Q| <= their pair
+    count sizes every matrix of the pass) -- rows and table against the oracle, through both entry points, both failure
+    kinds (offsets not monotonic / a read outside n_bases), twice so both buffer sets are hit."""
+    from sketchy_amd import api, _lib
+    ref, bases, offsets = workload(700, 400, 1300, read_len=900, rng_seed=77)
+    R = api.ReferenceSketch(ref["ref"])
+    n_big, n_small = 1000, 24
+    d_b = api.DeviceBuffer.from_numpy(bases)
+    bad = offsets[:n_big + 1].copy()
+    bad[500], bad[501] = bad[501], bad[500]
+    d_bad = api.DeviceBuffer.from_numpy(np.ascontiguousarray(bad))
+    d_big = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[:n_big + 1]))
+    small = [(n_big + i * n_small, n_big + (i + 1) * n_small) for i in range(6)]
+    d_small = [api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[a:b + 1])) for a, b in small]
+    exp = _expect(ref["ref"], 400, bases[int(offsets[n_big]):], offsets[n_big:] - offsets[n_big], 1)
+    for entry in ("push", "enqueue"):
+        S = api.SumOfSharedHashes(R, top=1, max_batch_reads=n_big, max_batch_bases=int(offsets[n_big]))
+        call = S.push_device if entry == "push" else S.enqueue_device
+        rows = []
+        for i, ((a, b), d_o) in enumerate(zip(small, d_small)):
+            if i in (0, 1, 3):  # a failing large batch in front of this small one
+                with pytest.raises(_lib.SketchyHipError) as e:
+                    if i == 3:   # vouch for fewer bytes than the offsets reach
+                        call(d_b.ptr, d_big.ptr, n_big, int(offsets[n_big // 2]), None, None)
+                    else:
+                        call(d_b.ptr, d_bad.ptr, n_big, int(offsets[n_big]), None, None)
+                    S.flush()
+                assert e.value.code == _lib.ERR_INVALID
+            d_i, d_s = api.DeviceBuffer(n_small * 4), api.DeviceBuffer(n_small * 8)
+            call(d_b.ptr, d_o.ptr, n_small, int(offsets[b] - offsets[a]), d_i.ptr, d_s.ptr)
+            S.sync()
+            rows.append((d_i.to_numpy(np.uint32, (n_small,)), d_s.to_numpy(np.uint64, (n_small,))))
+            d_i.free(); d_s.free()
+        n = n_small * len(small)
+        np.testing.assert_array_equal(np.concatenate([r[0] for r in rows]), exp["topk_idx"][:n, 0], err_msg=entry)
+        np.testing.assert_array_equal(np.concatenate([r[1] for r in rows]), exp["topk_sum"][:n, 0], err_msg=entry)
+        assert S.reads == n
+        full = _expect(ref["ref"], 400, bases[int(offsets[n_big]):int(offsets[n_big + n])], offsets[n_big:n_big + n + 1] - offsets[n_big], 1)
+        np.testing.assert_array_equal(S.table(), full["cum"], err_msg=entry)
+        S.close()
+    for d in [d_b, d_bad, d_big] + d_small:
+        d.free()
+
+
 @pytest.mark.parametrize("env", [{"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "2"}, {"SKX_PIPELINE": "1"}, {"SKX_PASS_READS": "128"}])
 def test_enqueue_under_other_placements(gpu, env):
     """the same stream with the pair gather on the scan stream (never speculative), with fewer pipeline streams, and with
     every batch cut into passes of 128 reads (each enqueue undoes the younger batch's speculation) -- separate
     processes: the knobs are read once"""
     here = os.path.dirname(os.path.abspath(__file__))
-    e = dict(os.environ, **env)
+    from helpers import exp_env
+    e = exp_env(**env)
     r = subprocess.run([sys.executable, os.path.join(here, "enqueue_check.py")], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "enqueue_check ok" in r.stdout

@@ -154,7 +154,8 @@ def test_oracle_sample_at_full_size(c2):
 def test_forced_scan_kernel_variants(gpu, split, big):
     """The split-array and big-table scan variants are picked automatically only for dense full-size passes;
     force each of them (env, read once per process) on small ragged inputs and compare with the oracle."""
-    env = dict(os.environ, SKX_SCAN_SPLIT=split, SKX_SCAN_BIG=big)
+    from helpers import exp_env
+    env = exp_env(SKX_SCAN_SPLIT=split, SKX_SCAN_BIG=big)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=env, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "variant ok" in out.stdout
@@ -168,7 +169,23 @@ def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     """Several passes per push (the path that needs the per-read pair offsets on the host), the pipeline depths, the
     unfiltered dictionary, the ranking without its per-word live flags, seg_sum / chunk_sum on their own stream and the
     pair gather on the scan stream all give the oracle's rows."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=dict(os.environ, **knobs),
+    from helpers import exp_env
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=exp_env(**knobs),
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "variant ok" in out.stdout
+
+
+def test_the_product_library_reads_no_environment_knob(gpu):
+    """SKX_SCAN_ABLATE=1 (no result write-back) and SKX_NO_FILTER make the EXPERIMENTS build compute something else --
+    the product library must not even look: same parity run, knobs set, default library -> the oracle's rows; the
+    experiments build under SKX_SCAN_ABLATE=1 -> wrong rows (which proves the knob is live there, i.e. that this test
+    would notice a product build that still read it)."""
+    from helpers import exp_env
+    script = os.path.join(ROOT, "tests", "variant_check.py")
+    env = dict(os.environ, SKX_SCAN_ABLATE="1", SKX_NO_FILTER="1", SKX_PIPELINE="1", SKX_PASS_READS="37")
+    env.pop("SKX_LIB_PATH", None)
+    out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and "variant ok" in out.stdout, out.stdout + out.stderr
+    bad = subprocess.run([sys.executable, script], env=exp_env(SKX_SCAN_ABLATE=1), capture_output=True, text=True)
+    assert bad.returncode != 0, "the experiments build ignored SKX_SCAN_ABLATE=1"

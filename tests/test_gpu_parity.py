@@ -12,13 +12,15 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def run_both(ref, bases, offsets, top, k=16, seed=0, col_len=None, batches=1, want_shared=True, want_sketches=True):
+def run_both(ref, bases, offsets, top, k=16, seed=0, col_len=None, batches=1, want_shared=True, want_sketches=True, s=None):
+    """s: the size reads are sketched with when it is not the matrix width (the reference: |sketch 0|)"""
     from sketchy_amd import api
     hashes = ref["ref"] if isinstance(ref, dict) else ref
-    n, s = hashes.shape
-    col_len = np.full(n, s, np.uint32) if col_len is None else col_len
+    n, stride = hashes.shape
+    s = stride if s is None else s
+    col_len = np.full(n, stride, np.uint32) if col_len is None else col_len
     exp = orc.stream(k, seed, s, hashes, col_len, bases, offsets, top_k=max(top, 1), want_shared=True, want_sketches=True)
-    R = api.ReferenceSketch(hashes, col_len, k=k, seed=seed)
+    R = api.ReferenceSketch(hashes, col_len, k=k, seed=seed, s=s)
     n_reads = len(offsets) - 1
     S = api.SumOfSharedHashes(R, top=top, max_batch_reads=max(1, n_reads), max_batch_bases=max(1, len(bases)))
     # feed in `batches` pushes to exercise table continuity
@@ -541,6 +543,28 @@ def test_truncation_comes_before_the_membership_filter(gpu):
     got, exp, _, _ = check(hashes, bases, offsets, top=2, want_sketches=False)   # production sketch path, s = 2
     assert exp["shared"][0].tolist() == [1, 0, 1, 0]
     check(hashes, bases, offsets, top=1, want_shared=False, want_sketches=False)
+
+
+@pytest.mark.parametrize("first_len", [40, 300, 1])
+def test_read_sketch_size_is_the_first_sketchs_length(gpu, first_len):
+    """The reference sketches every read with s := number of hashes of the collection's FIRST sketch (src/sketchy.rs:82,
+    :520-527); the other sketches may be longer (first_len = 40, 1: the read sketch is truncated to fewer hashes than a
+    column holds -- a dense reference, so hundreds of a read's hashes are in range and the truncation really bites) or
+    shorter (first_len = 300 = the stride: most columns are shorter than the read sketch).  skx_ref_create takes s and the
+    column stride separately; rows, per-read counts, sketches and table against the oracle, debug and production paths."""
+    ref, bases, offsets = workload(90, 300, 120, read_len=900, genome_len=25000, rng_seed=4100 + first_len)
+    hashes = ref["ref"]
+    rng = np.random.default_rng(first_len)
+    col_len = rng.integers(100, 301, size=len(hashes)).astype(np.uint32)
+    col_len[0] = first_len
+    col_len[5] = 300
+    got, exp, R, S = check(hashes, bases, offsets, top=3, col_len=col_len, s=first_len)
+    assert R.s == first_len and R.stride == 300
+    assert exp["sketch_len"].max() == first_len                       # every read sketch is cut to |sketch 0|
+    full = orc.stream(16, 0, 300, hashes, col_len, bases, offsets, top_k=1, want_shared=True)
+    if first_len < 300:
+        assert (full["shared"].astype(np.int64) - exp["shared"]).max() > 0  # ... and the cut changes the counts
+    check(hashes, bases, offsets, top=1, col_len=col_len, s=first_len, want_shared=False, want_sketches=False, batches=3)
 
 
 def test_randomized_families_leader_switching(gpu):

@@ -114,6 +114,36 @@ def test_predict_stream_rows_fastq_fasta_gz_stdin(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_predict_stream_with_sketches_of_unequal_length(gpu, tmp_path):
+    """A collection whose first sketch is SHORTER than the others: the reference sketches the reads with s = |sketch 0|
+    (src/sketchy.rs:82, :520-527) and still intersects the longer sketches in full; `predict -s` must print the oracle's
+    rows (it used to refuse such collections)."""
+    ref, bases, offsets = workload(30, 128, 25, read_len=600, genome_len=12000, rng_seed=654)
+    names = [f"g{i:02d}.fa" for i in range(30)]
+    lens = np.random.default_rng(3).integers(40, 129, size=30)
+    lens[0] = 24
+    lens[3] = 128
+    msh = str(tmp_path / "ragged.msh")
+    write_msh(msh, names, [ref["ref"][g, :lens[g]] for g in range(30)], kmer=16, seed=0, lengths=[12000] * 30)
+    tsv = str(tmp_path / "geno.tsv")
+    with open(tsv, "w") as f:
+        f.write("id\tmlst\n")
+        for i, nm in enumerate(names):
+            f.write(f"{nm}\tST{i % 4}\n")
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for i, r in enumerate(unpack_reads(bases, offsets)):
+            f.write(f"@r{i}\n{r.decode()}\n+\n{'I' * len(r)}\n")
+    exp = orc.stream(16, 0, 24, ref["ref"], lens.astype(np.uint32), bases, offsets, top_k=2)
+    assert exp["topk_sum"][-1, 0] > 0
+    want = "".join(f"{r + 1}\t{names[exp['topk_idx'][r, j]]}\t{exp['topk_sum'][r, j]}\tST{exp['topk_idx'][r, j] % 4}\n"
+                   for r in range(25) for j in range(2))
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", fq, "-t", "2", "-s")
+    assert rc == 0, err
+    assert out == want
+
+
+@pytest.mark.gpu
 def test_predict_offline_pools_all_reads(gpu, tmp_path):
     """Offline mode (src/sketchy.rs:281-315): ONE sketcher over all reads, one ranking."""
     ref, names, msh, tsv, reads, bases, offsets = _fixture(tmp_path)

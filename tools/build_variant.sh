@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh <name> <extra hipcc flags...>  ->  gpurun_variants/libskx_<name>.so (select with SKX_LIB_PATH)
+# tools/build_variant.sh <name> <extra hipcc flags...>  ->  variants/libskx_<name>.so (select with SKX_LIB_PATH)
 set -e
 N=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/variants; mkdir -p $O/obj_$N

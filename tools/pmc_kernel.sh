@@ -14,7 +14,7 @@ i=0
 : > $P/${TAG}_pmc.csv
 for C in "${PASSES[@]}"; do
   i=$((i+1))
-  timeout 100 rocprofv3 --pmc $C --output-format csv -d $P/pmck_${TAG}_$i -o pmc -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-extra-legs --no-check "$@" > /dev/null 2> $P/${TAG}_pmck_$i.err
+  timeout 100 rocprofv3 --pmc $C --output-format csv -d $P/pmck_${TAG}_$i -o pmc -- python3 bench.py --steps 3 --warmup 1 --reps 1 --cpu-seconds 0 --no-extra-legs --no-check "$@" > /dev/null 2> $P/${TAG}_pmck_$i.err
   F=$(find $P/pmck_${TAG}_$i -name "*counter_collection.csv" 2>/dev/null | head -1)
   if [ -n "$F" ]; then python3 profiles/summarize_pmc.py $F | grep -E "$KPAT" >> $P/${TAG}_pmc.csv; fi
   rm -rf $P/pmck_${TAG}_$i

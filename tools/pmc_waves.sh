@@ -2,7 +2,7 @@
 # wave-residency per kernel (rocprofv3 serialises kernels under --pmc: these are stand-alone figures)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 P=gpurun_out/prof; mkdir -p $P
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $P/pmc_w -o pmc -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-extra-legs --no-check "$@" > /dev/null 2> $P/pmc_w.err
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $P/pmc_w -o pmc -- python3 bench.py --steps 6 --warmup 2 --reps 1 --cpu-seconds 0 --no-extra-legs --no-check "$@" > /dev/null 2> $P/pmc_w.err
 python3 profiles/summarize_pmc.py $(find $P/pmc_w -name "*counter_collection.csv") > $P/pmc_waves_summary.csv
 rm -rf $P/pmc_w
 python3 - <<'PY'

@@ -6,7 +6,7 @@ P=gpurun_out/prof; mkdir -p $P
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt_$TAG -o kt -- python3 bench.py --cpu-seconds 0 --no-extra-legs "$@" > $P/${TAG}_bench_under_rocprof.json 2> $P/${TAG}_bench.err
 python3 profiles/filter_stats.py $(find $P/kt_$TAG -name "*kernel_stats.csv") > $P/${TAG}_kernel_stats.csv; rm -rf $P/kt_$TAG
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --output-format csv -d $P/pmc_${TAG}_$C -o pmc -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --no-extra-legs --no-check "$@" > /dev/null 2> $P/${TAG}_pmc_$C.err
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $P/pmc_${TAG}_$C -o pmc -- python3 bench.py --reps 1 --steps 4 --warmup 1 --cpu-seconds 0 --no-extra-legs --no-check "$@" > /dev/null 2> $P/${TAG}_pmc_$C.err
   python3 profiles/summarize_pmc.py $(find $P/pmc_${TAG}_$C -name "*counter_collection.csv") | grep -E "skx::|^kernel" > $P/${TAG}_pmc_$C.csv; rm -rf $P/pmc_${TAG}_$C
 done
 grep -E "skx::|^kernel" $P/${TAG}_kernel_stats.csv | cut -c1-120; cat $P/${TAG}_pmc_FETCH_SIZE.csv $P/${TAG}_pmc_WRITE_SIZE.csv | grep -E "scan_lean|scan_kernel|transpose"
