@@ -6,5 +6,7 @@ CFG=c2; STEPS=20
 while getopts "c:s:" o; do case $o in c) CFG=$OPTARG;; s) STEPS=$OPTARG;; esac; done; shift $((OPTIND - 1))
 for V in "$@"; do
   set -- $V; L=$1; shift
-  env "$@" timeout 600 python3 bench.py --config $CFG --steps $STEPS --cpu-seconds 0 2>/dev/null | python3 tools/bench_line.py "$L" | cut -c1-220
+  # (variants with knobs load the experiments build: the product library reads no environment variable)
+  X=""; [ $# -gt 0 ] && X="SKX_LIB_PATH=$PWD/sketchy_amd/libsketchy_hip_exp.so"
+  env $X "$@" timeout 600 python3 bench.py --config $CFG --steps $STEPS --cpu-seconds 0 2>/dev/null | python3 tools/bench_line.py "$L" | cut -c1-220
 done
