@@ -149,6 +149,9 @@ def main():
                     help="read lengths log-normal around the config's length with this sigma, 200..50000 (default: the config's)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: every rank uses device 0 (exercises the multi-rank control flow on a 1-GPU box)")
+    ap.add_argument("--allow-host-allreduce", action="store_true",
+                    help="testing only: accept a run whose table was reduced through gloo on the host (RCCL refuses ranks that "
+                         "share a device); without it a multi-GPU run that did not reduce through RCCL over all ranks FAILS")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -274,9 +277,9 @@ def main():
     }
     err = None
     # a multi-GPU line is only valid when RCCL really reduced the table over `world` ranks (a run that silently fell back to
-    # the host path would otherwise print a green line): --share-gpu (testing: all ranks on one device, which RCCL refuses)
-    # is the only way to run N > 1 without it
-    if world > 1 and not args.share_gpu and not (reducer.how == "rccl" and reducer.rccl_ranks == world):
+    # the host path would otherwise print a green line): --allow-host-allreduce (testing: ranks sharing one device, which
+    # RCCL refuses) is the only way to run N > 1 without it
+    if world > 1 and not args.allow_host_allreduce and not (reducer.how == "rccl" and reducer.rccl_ranks == world):
         err = (f"--gpus {world}: the table was not reduced by RCCL over {world} ranks (transport {reducer.how}, RCCL counted "
                f"{reducer.rccl_ranks} ranks; {reducer.err})")
 

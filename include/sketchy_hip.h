@@ -182,9 +182,10 @@ int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
  * Counters for tuning / reporting (no effect on results): out[0] (read, hash) pairs of the last push, [1] scoring
  * passes it took, [2] distinct query hashes of the most recent dictionary, [3] reads sketched by the block sketcher so
  * far, [4] passes so far, [5] of those with the lean scan kernel, [6] pair capacity of a pass, [7] rank groups (512 genomes)
- * that received any bit in the most recent pass.  Waits for the stream's queued work.
+ * that received any bit in the most recent pass, [8] long reads (more than 8192 bases) whose sketch was split over several
+ * wavefronts so far, [9] the segments they were cut into.  Waits for the stream's queued work.
  */
-#define SKX_N_STATS 8
+#define SKX_N_STATS 10
 int skx_stream_stats(skx_stream *st, uint64_t *out, uint32_t n_out);
 /* rank the CURRENT table: first top_k of (sum desc, index asc) per species; idx/sum are host arrays [n_species][top_k] */
 int skx_stream_rank(skx_stream *st, uint32_t top_k, uint32_t *idx, uint64_t *sum);

@@ -452,8 +452,10 @@ struct skx_stream {
     u32* d_wb[2] = {nullptr, nullptr};       // [query words][tiles] bands that can reach a word (launch_word_bands)
     u32* d_retry = nullptr;  // [1 + max_reads] reads the fast sketch variant hands to the full-size one ([0] = count)
     u32* d_big = nullptr;    // [1 + max_reads] reads the wave sketchers hand to the block sketcher ([0] = count)
+    skx::LongReads lr{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};  // long reads of a production batch, split over waves
     u32* d_bsum = nullptr;   // block totals of the pair-count scan
     u64 reads_big = 0;       // reads that went through the block sketcher so far (statistic)
+    u64 reads_split = 0, segs_split = 0;  // long reads split over waves so far, and their segments (statistic)
     u64 last_pairs = 0, last_passes = 0, total_passes = 0, lean_passes = 0;  // statistics (skx_stream_stats)
     // host-fed pipeline (skx_stream_submit): three staging slots, a copy stream, one batch of lag
     struct Staged {
@@ -500,6 +502,7 @@ static void stream_free(skx_stream* st) {
     if (st->h_nq) (void)hipHostFree(st->h_nq);
     if (st->h_chk_base) (void)hipHostFree(st->h_chk_base);
     (void)hipFree(st->d_chk); (void)hipFree(st->d_retry);
+    (void)hipFree(st->lr.list); (void)hipFree(st->lr.seg0); (void)hipFree(st->lr.seg_tab); (void)hipFree(st->lr.seg_cnt); (void)hipFree(st->lr.seg_h);
     (void)hipFree(st->d_ht[0]); (void)hipFree(st->d_ht[1]); (void)hipFree(st->d_dict_ctr[0]); (void)hipFree(st->d_dict_ctr[1]);
     (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
     (void)hipFree(st->d_btot);
@@ -717,6 +720,15 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMemset(st->d_chk, 0, 64));
     SCHK(hipMalloc(&st->d_retry, ((size_t)max_reads + 1) * 4));
     SCHK(hipMemset(st->d_retry, 0, 4));
+    if (max_bases > skx::long_read_split()) {  // (a batch that can hold a long read at all)
+        st->lr.long_cap = (u32)std::min<u64>(max_reads, max_bases / skx::long_read_split() + 1);
+        st->lr.segs_cap = (u32)std::min<u64>(0x7FFFFFFFu, 5 * (max_bases / (4ull * skx::kSketchCap)) + 2);
+        SCHK(hipMalloc(&st->lr.list, (size_t)st->lr.long_cap * 4));
+        SCHK(hipMalloc(&st->lr.seg0, (size_t)st->lr.long_cap * 4));
+        SCHK(hipMalloc(&st->lr.seg_tab, (size_t)st->lr.segs_cap * 4));
+        SCHK(hipMalloc(&st->lr.seg_cnt, (size_t)st->lr.segs_cap * 4));
+        SCHK(hipMalloc(&st->lr.seg_h, (size_t)st->lr.segs_cap * skx::long_read_seg_slots() * 8));
+    }
     SCHK(use_side(st, 0));
     SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocCoherent));
     st->h_nq[0] = st->h_nq[1] = 0;
@@ -1084,7 +1096,9 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     {
         Span sp(st, 0);
         // offsets are looked at on the device (cheap); it also zeroes entry n_reads of the pair counts
-        skx::launch_batch_check(hs, pb.d_offsets, n_reads, (u64)skx::kSketchCap + ref->k - 1, st->d_chk, st->d_cnt + n_reads);
+        // (... and lists the long reads of a production batch with their segments: the sketcher splits those over waves)
+        const skx::LongReads* lr = (pb.inrange_only && st->lr.list) ? &st->lr : nullptr;
+        skx::launch_batch_check(hs, pb.d_offsets, n_reads, pb.n_bases, st->d_chk, st->d_cnt + n_reads, lr);
         if (pb.h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
         // every read, any length: wave sketchers (then the block sketcher for what overflowed: device-side lists)
         // (three-stream pipeline: will the previous pass's scan be in flight?  then this sketch shares the CUs with it)
@@ -1095,7 +1109,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         (void)hipGetLastError();  // (hipErrorNotReady is not an error)
         HIPCHK(skx::launch_sketch(hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s_read, max_ref, pb.inrange_only,
                                   st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big,
-                                  pb.n_bases, st->d_chk, leave_room, st->packed));
+                                  pb.n_bases, st->d_chk, leave_room, st->packed, lr));
         if (!pb.inrange_only) {
             // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
             // not the fast one -- read the count back and run the block sketcher before the rows are copied out
@@ -1158,6 +1172,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
             snprintf(buf, sizeof buf, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
             return refuse(SKX_ERR_INVALID, buf);
         }
+        if (c[6] & 2u) return refuse(SKX_ERR_INVALID, "the long reads of the batch do not fit the stream's tables (offsets not monotonic?)");
         if (c[6]) {
             snprintf(buf, sizeof buf, "a read lies outside the n_bases=%llu bytes given from offsets[0] on", (unsigned long long)pb.n_bases);
             return refuse(SKX_ERR_INVALID, buf);
@@ -1178,6 +1193,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     }
     const u32 total_pairs = st->h_chk[8];
     st->last_pairs = total_pairs; st->last_passes = 0;
+    if (pb.inrange_only && st->lr.list) { st->reads_split += st->h_chk[1]; st->segs_split += st->h_chk[9]; }
 
     const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap;
     // (the batch needs several passes although a speculative gather was queued for it: normally that gather did nothing -- it
@@ -1512,7 +1528,7 @@ SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
         for (u32 f : flags) live += f ? 1 : 0;
     }
     const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)std::max(st->h_nq[0], st->h_nq[1]), st->reads_big,
-                                     st->total_passes, st->lean_passes, st->pcap, live};
+                                     st->total_passes, st->lean_passes, st->pcap, live, st->reads_split, st->segs_split};
     for (uint32_t i = 0; i < n_out; ++i) out[i] = i < SKX_N_STATS ? v[i] : 0;
     return SKX_OK;
 }

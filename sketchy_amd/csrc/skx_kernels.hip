@@ -222,13 +222,123 @@ __device__ __forceinline__ u32 wave_normalise_packed(const uint8_t* __restrict__
     return nb;
 }
 
-template <int KT, int HCAP, bool INRANGE>
+// ---- long reads: split over waves ---------------------------------------------------------------------------------
+// One wavefront per read serialises a long read on one wave: a 50 kb read is 25 chunks in a row next to seven other waves on
+// its SIMD (~2 ms at C4, longer than the rest of the batch takes).  In production mode (INRANGE) a read of more than
+// kLongSplit raw bytes is therefore cut into SEGMENTS = the chunks of kSketchCap raw bytes the serial loop would walk, one
+// wave per segment: the wave finds the k-1 retained codes in front of its chunk itself (scanning backwards over whitespace),
+// hashes exactly the windows that END in the chunk -- the same windows, hence the same multiset of hashes, as the serial
+// loop -- and leaves its in-range hashes in the segment's slot (kSegSlots entries; production keeps ~7 per chunk).  One wave
+// per long read then gathers the slots and finishes like any other read: sort, distinct, truncate to s, membership filter
+// (sketch_merge_kernel).  A slot that overflows, or more than kSketchCap hashes in all, sends the read to the block sketcher.
+constexpr u32 kLongSplit = 4u * kSketchCap;  // raw bytes; reads up to here stay on one wave (<= 4 chunks)
+constexpr u32 kSegSlots = 64;
+constexpr u32 kSegOvf = 0xFFFFFFFFu;
+// the same test in batch_check_kernel (which lists the long reads), the read waves (which skip them) and the segment waves
+__device__ __forceinline__ bool is_split_long(u64 o0, u64 o1, u64 lo, u64 n_bases) {
+    return o0 >= lo && o1 >= o0 && o1 - lo <= n_bases && o1 - o0 > (u64)kLongSplit;
+}
+
+// the tail of every sketch: `m` hashes in the wave's LDS buffer (any order, m <= HCAP) -> ascending, distinct, truncated to
+// s, (production) only those some genome holds -> out_sk row r, out_len[r], out_cnt_in[r]
+template <int HCAP, bool INRANGE>
+__device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, u64 max_ref, u64* __restrict__ out_sk,
+                                              u32 sk_stride, u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
+                                              const u32* __restrict__ filt, u32 filt_shift) {
+    const u32 lane = lane_id();
+    const u64 lt = lanemask_lt();
+    // At most one hash per lane (production: a 1.5 kb read keeps ~8): sort by counting.  Lane l holds hash l; for every j the
+    // wave sees hash j as a scalar, finds the lanes holding the same value (ballot) -- j counts only if it is the first of
+    // them -- and every lane holding something larger moves up one place: ~5 VALU instructions per hash instead of the
+    // ~300 of a 64-element bitonic network through LDS.  Leaves the DISTINCT hashes, ascending, at hashes[0 .. m).
+    if (m <= 64u) {
+        const u64 h = lane < m ? hashes[lane] : kPad;
+        u32 rank = 0;
+        u64 heads = 0;
+        for (u32 j = 0; j < m; ++j) {
+            const u64 hj = make_u64((u32)__builtin_amdgcn_readlane((int)(u32)h, (int)j),
+                                    (u32)__builtin_amdgcn_readlane((int)(u32)(h >> 32), (int)j));
+            const u64 eq = __ballot(h == hj);
+            if ((u32)__builtin_ctzll(eq) == j) {  // (lane j itself is in eq: never zero)
+                heads |= 1ull << j;
+                rank += hj < h ? 1u : 0u;
+            }
+        }
+        wave_sync();
+        if ((heads >> lane) & 1ull) hashes[rank] = h;
+        m = (u32)__popcll(heads);
+        wave_sync();
+    }
+    // pad to a power of two (>= 64) for the bitonic network
+    u32 p2 = 64;
+    while (p2 < m) p2 <<= 1;
+    if (m > 64u) {
+        for (u32 i = m + lane; i < p2; i += 64u) hashes[i] = kPad;
+        wave_sync();
+    }
+
+    // bitonic sort ascending
+    if (m > 64u) {
+        for (u32 size = 2; size <= p2; size <<= 1) {
+            for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+                for (u32 t = lane; t < (p2 >> 1); t += 64u) {
+                    const u32 i = 2u * t - (t & (stride - 1u));
+                    const u32 j = i + stride;
+                    const bool up = (i & size) == 0u;
+                    const u64 a = hashes[i], b = hashes[j];
+                    if ((a > b) == up) { hashes[i] = b; hashes[j] = a; }
+                }
+                wave_sync();
+            }
+        }
+    }
+
+    // distinct, truncate to s, count the part that can meet the reference at all.
+    // INRANGE with a membership bitmap (production): of the hashes that made it into the bottom-s only those some genome
+    // holds are written -- strictly AFTER the truncation: a hash ranked beyond s is not part of the sketch even if
+    // everything before it is dropped (reads with more distinct in-range hashes than s, e.g. small s).
+    u32 outn = 0, cin = 0, wrote = 0;
+    u64* out = out_sk + (size_t)r * sk_stride;
+    for (u32 base = 0; base < m && outn < s; base += 64u) {
+        const u32 i = base + lane;
+        const bool v = i < m;
+        const u64 h = v ? hashes[i] : 0;
+        const bool head = v && (i == 0 || hashes[i - 1] != h);
+        const u64 mask = __ballot(head);
+        const u32 pos = outn + __popcll(mask & lt);
+        const bool take = head && pos < s;
+        if (INRANGE && filt != nullptr) {
+            bool keep = false;
+            if (take) {
+                const u64 idx = h >> filt_shift;
+                keep = (filt[idx >> 5] >> (u32)(idx & 31u)) & 1u;
+            }
+            const u64 km = __ballot(keep);
+            if (keep) out[wrote + __popcll(km & lt)] = h;
+            wrote += __popcll(km);
+        } else {
+            if (take) out[pos] = h;
+            cin += __popcll(__ballot(take && h <= max_ref));
+        }
+        outn += __popcll(mask);
+    }
+    if (lane == 0) {
+        out_len[r] = min(outn, s);
+        out_cnt_in[r] = (INRANGE && filt != nullptr) ? wrote : cin;
+    }
+}
+
+// SEG: the wave hashes ONE chunk (segment seg_i) of a long read and leaves its in-range hashes in seg_h / seg_cnt.
+template <int KT, int HCAP, bool INRANGE, bool SEG = false>
 __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, const uint8_t* __restrict__ bases,
                                                 const u64* __restrict__ offsets, u32 k_rt, u64 seed, u32 s, u64 max_ref,
                                                 u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                 u32* __restrict__ out_cnt_in, u32* __restrict__ retry, u32* __restrict__ big,
                                                 const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
-                                                u32* __restrict__ chk, const unsigned char* lut, bool packed) {
+                                                u32* __restrict__ chk, const unsigned char* lut, bool packed,
+                                                bool split_long = false, u32 seg_i = 0, u64* __restrict__ seg_h = nullptr,
+                                                u32* __restrict__ seg_cnt = nullptr) {
+    static_assert(!SEG || INRANGE, "segments exist in production mode only");
     constexpr u32 CAP = kSketchCap;
     constexpr u32 kPerWave = HCAP * 8 + CAP + 128;  // (32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding)
     constexpr u32 kChunkAt = 32;                    // a chunk's codes start here; the carried k-1 end here
@@ -241,12 +351,18 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     // chk[6]; the push then fails with SKX_ERR_INVALID instead of faulting)
     const u64 lo = offsets[0];
     if (o0 < lo || o1 < o0 || o1 - lo > n_bases) {
+        if constexpr (SEG) {
+            if (lane == 0) *seg_cnt = 0;  // (cannot happen: batch_check_kernel lists only reads inside the batch)
+            return;
+        }
         if (lane == 0) {
             out_len[r] = 0; out_cnt_in[r] = 0;
             if (chk) atomicOr(&chk[6], 1u);
         }
         return;
     }
+    // a long read of a production batch belongs to the segment waves and sketch_merge_kernel
+    if (!SEG && INRANGE && split_long && o1 - o0 > (u64)kLongSplit) return;
     const u32 lraw = (u32)(o1 - o0);
     if (!INRANGE && lraw > CAP + k - 1u) {  // a full sketch of more k-mers than the buffer holds: the block sketcher
         if (lane == 0) { out_len[r] = kSketchRetry; out_cnt_in[r] = 0; list_append(big, r); }
@@ -254,8 +370,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     }
     const uint8_t* rd = bases + o0;
     const u64 lt = lanemask_lt();
-    // a long read is one wave's work for a long time (50 kb next to seven other waves on the SIMD: ~2 ms, longer than the
-    // rest of the batch takes): it goes first (two-phase launch below) and its wave gets issue priority
+    // (reads beyond kLongSplit only get here when they are not split: full sketches, the 2048-slot retry variant)
     if (lraw > 4u * CAP) __builtin_amdgcn_s_setprio(2);
 
     u32 m = 0;    // hashes collected so far (any order: they are sorted afterwards); wave-uniform (kept scalar)
@@ -275,7 +390,39 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     };
 
     u32 carry = 0;  // codes kept from the previous chunk at codes[kChunkAt - carry .. kChunkAt)
-    for (u32 cbase = 0;; cbase += CAP) {
+    u32 cbase0 = 0;
+    if constexpr (SEG) {
+        cbase0 = seg_i * CAP;
+        if (cbase0 >= lraw) {  // (never: the segments of a read cover exactly its chunks)
+            if (lane == 0) *seg_cnt = 0;
+            return;
+        }
+        if (cbase0 > 0u) {
+            // the last k-1 RETAINED codes in front of the chunk (what the serial loop would have carried to here)
+            const u32 want = k - 1u;
+            if (packed) {  // (no whitespace in this format: the k-1 nibbles in front)
+                if (lane < want) codes[kChunkAt - want + lane] = (uint8_t)packed_code(bases, o0 + cbase0 - want + lane);
+                carry = want;  // (cbase0 >= CAP > k - 1)
+            } else {
+                u32 got = 0;
+                for (u32 end = cbase0; end > 0u && got < want;) {
+                    const u32 beg = end > 64u ? end - 64u : 0u;
+                    const u32 idx = beg + lane;
+                    const u32 c = idx < end ? (u32)lut[rd[idx]] : 0x80u;
+                    const bool kept = !(c & 0x80u);
+                    const u64 km = __ballot(kept);
+                    const u64 above = lane == 63u ? 0ull : (~0ull << (lane + 1u));
+                    const u32 rk = got + (u32)__popcll(km & above);  // retained codes between this byte and the chunk
+                    if (kept && rk < want) codes[kChunkAt - 1u - rk] = (uint8_t)c;
+                    got = __builtin_amdgcn_readfirstlane(min(want, got + (u32)__popcll(km)));
+                    end = beg;
+                }
+                carry = got;
+            }
+            wave_sync();
+        }
+    }
+    for (u32 cbase = cbase0;; cbase += CAP) {
         const u32 cend = min(lraw, cbase + CAP);
         // 1. normalise the chunk behind the carried codes
         const u32 cs = kChunkAt - carry;  // first code of the buffer
@@ -395,6 +542,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                 append(valid, h);
             }
         }
+        if constexpr (SEG) break;  // one chunk per segment wave
         if (ovf) {  // hand the read on (fast variant -> 2048-slot variant -> block sketcher)
             if (lane == 0) {
                 out_len[r] = kSketchRetry; out_cnt_in[r] = 0;
@@ -411,127 +559,69 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         if (lane < keep) codes[kChunkAt - keep + lane] = (uint8_t)cv;
         carry = keep;
     }
-    // At most one hash per lane (production: a 1.5 kb read keeps ~8): sort by counting.  Lane l holds hash l; for every j the
-    // wave sees hash j as a scalar, finds the lanes holding the same value (ballot) -- j counts only if it is the first of
-    // them -- and every lane holding something larger moves up one place: ~5 VALU instructions per hash instead of the
-    // ~300 of a 64-element bitonic network through LDS.  Leaves the DISTINCT hashes, ascending, at hashes[0 .. m).
-    if (m <= 64u) {
-        const u64 h = lane < m ? hashes[lane] : kPad;
-        u32 rank = 0;
-        u64 heads = 0;
-        for (u32 j = 0; j < m; ++j) {
-            const u64 hj = make_u64((u32)__builtin_amdgcn_readlane((int)(u32)h, (int)j),
-                                    (u32)__builtin_amdgcn_readlane((int)(u32)(h >> 32), (int)j));
-            const u64 eq = __ballot(h == hj);
-            if ((u32)__builtin_ctzll(eq) == j) {  // (lane j itself is in eq: never zero)
-                heads |= 1ull << j;
-                rank += hj < h ? 1u : 0u;
-            }
-        }
+    if constexpr (SEG) {
+        // the segment's in-range hashes (unsorted, duplicates included) go to its slot; the merge wave does the rest
         wave_sync();
-        if ((heads >> lane) & 1ull) hashes[rank] = h;
-        m = (u32)__popcll(heads);
-        wave_sync();
-    }
-    // pad to a power of two (>= 64) for the bitonic network
-    u32 p2 = 64;
-    while (p2 < m) p2 <<= 1;
-    if (m > 64u) {
-        for (u32 i = m + lane; i < p2; i += 64u) hashes[i] = kPad;
-        wave_sync();
-    }
-
-    // bitonic sort ascending
-    if (m > 64u) {
-        for (u32 size = 2; size <= p2; size <<= 1) {
-            for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-                for (u32 t = lane; t < (p2 >> 1); t += 64u) {
-                    const u32 i = 2u * t - (t & (stride - 1u));
-                    const u32 j = i + stride;
-                    const bool up = (i & size) == 0u;
-                    const u64 a = hashes[i], b = hashes[j];
-                    if ((a > b) == up) { hashes[i] = b; hashes[j] = a; }
-                }
-                wave_sync();
-            }
-        }
-    }
-
-    // distinct, truncate to s, count the part that can meet the reference at all.
-    // INRANGE with a membership bitmap (production): of the hashes that made it into the bottom-s only those some genome
-    // holds are written -- strictly AFTER the truncation: a hash ranked beyond s is not part of the sketch even if
-    // everything before it is dropped (reads with more distinct in-range hashes than s, e.g. small s).
-    u32 outn = 0, cin = 0, wrote = 0;
-    u64* out = out_sk + (size_t)r * sk_stride;
-    for (u32 base = 0; base < m && outn < s; base += 64u) {
-        const u32 i = base + lane;
-        const bool v = i < m;
-        const u64 h = v ? hashes[i] : 0;
-        const bool head = v && (i == 0 || hashes[i - 1] != h);
-        const u64 mask = __ballot(head);
-        const u32 pos = outn + __popcll(mask & lt);
-        const bool take = head && pos < s;
-        if (INRANGE && filt != nullptr) {
-            bool keep = false;
-            if (take) {
-                const u64 idx = h >> filt_shift;
-                keep = (filt[idx >> 5] >> (u32)(idx & 31u)) & 1u;
-            }
-            const u64 km = __ballot(keep);
-            if (keep) out[wrote + __popcll(km & lt)] = h;
-            wrote += __popcll(km);
+        if (ovf || m > kSegSlots) {
+            if (lane == 0) *seg_cnt = kSegOvf;
         } else {
-            if (take) out[pos] = h;
-            cin += __popcll(__ballot(take && h <= max_ref));
+            if (lane < m) seg_h[lane] = hashes[lane];
+            if (lane == 0) *seg_cnt = m;
         }
-        outn += __popcll(mask);
+        return;
     }
-    if (lane == 0) {
-        out_len[r] = min(outn, s);
-        out_cnt_in[r] = (INRANGE && filt != nullptr) ? wrote : cin;
-    }
+    sketch_finish<HCAP, INRANGE>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift);
     __builtin_amdgcn_s_setprio(0);
 }
 // from_list = 0: wave w of the grid sketches read w.  from_list = 1: a small fixed grid walks the reads an earlier
 // variant appended to `retry` -- usually none, and then the launch costs a few microseconds instead of one nearly
-// empty wave per read of the batch.  from_list = 2: like 0 with a grid twice as large, in two phases -- the first
-// half of the blocks (dispatched first) takes the reads with more than kSketchCap k-mers, the second half the others,
-// so that the long reads of a mixed-length batch start before the bulk instead of somewhere inside it (chk[1] =
-// number of such reads, counted by batch_check_kernel: without any the first half returns at once).
+// empty wave per read of the batch.  from_list = 2 (production batches): like 0 behind kSegBlocks leading workgroups
+// -- dispatched first -- whose waves walk the SEGMENTS of the batch's long reads (tables built by batch_check_kernel:
+// chk[1] = long reads, chk[9] = segments; without any those workgroups return at once); the read waves skip long reads.
+constexpr u32 kSegBlocks = 1024;  // x 4 waves: a C4 batch has ~28 000 segments
+// (struct LongReads: skx_kernels.hpp)
 #define SKX_SKETCH_PARAMS                                                                                              \
     const uint8_t *__restrict__ bases, const u64 *__restrict__ offsets, u32 n_reads, u32 k_rt, u64 seed, u32 s, u64 max_ref,  \
         u64 *__restrict__ out_sk, u32 sk_stride, u32 *__restrict__ out_len, u32 *__restrict__ out_cnt_in, u32 from_list,      \
         u32 *__restrict__ retry, u32 *__restrict__ big, const u32 *__restrict__ filt, u32 filt_shift, u64 n_bases,            \
-        u32 *__restrict__ chk
+        u32 *__restrict__ chk, LongReads lr
 #define SKX_SKETCH_ARGS \
-    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk
+    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr
 template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, unsigned char* lut) {
     const bool packed = (from_list & 0x100u) != 0u;  // (bit 8: 4-bit packed input)
     from_list &= 0xFFu;
-    // (whole workgroups that have nothing to do leave before the table is filled: the long-read half of a batch without
+    // (whole workgroups that have nothing to do leave before the table is filled: the segment workgroups of a batch without
     // long reads, the list walk over an empty list)
-    if (from_list == 2u && blockIdx.x < (gridDim.x >> 1) && chk[1] == 0u) return;
+    const bool seg_block = from_list == 2u && blockIdx.x < kSegBlocks;
+    if (seg_block && chk[9] == 0u) return;
     if (from_list == 1u && retry[0] == 0u) return;
     fill_base_lut(lut);
     __syncthreads();
     const u32 wpb = blockDim.x >> 6;  // waves per block: 4, or 1 for the list walk (see launch_sketch)
     u32 w = blockIdx.x * wpb + (threadIdx.x >> 6);
-    if (from_list == 2u) {
-        const u32 half = gridDim.x >> 1;
-        const bool long_phase = blockIdx.x < half;
-        if (!long_phase) w -= half * 4u;
-        if (long_phase && chk[1] == 0u) return;
-        if (w >= n_reads) return;
-        const u32 k = KT > 0 ? (u32)KT : k_rt;
-        const u64 o0 = offsets[w], o1 = offsets[w + 1];
-        const bool is_long = o1 >= o0 && o1 - o0 > (u64)kSketchCap + k - 1u;  // (the same test as batch_check_kernel's count)
-        if (is_long != long_phase) return;
+    if constexpr (INRANGE) {
+        if (seg_block) {
+            if (chk[6] & 2u) return;  // the tables are incomplete (the host refuses the batch)
+            const u32 n_seg = min(chk[9], lr.segs_cap);
+            for (u32 sg = w; sg < n_seg; sg += kSegBlocks * 4u) {
+                const u32 pos = lr.seg_tab[sg];
+                if (pos >= lr.long_cap || lr.list[pos] >= n_reads || sg < lr.seg0[pos]) continue;  // (never: belt and braces)
+                sketch_one_read<KT, HCAP, true, true>(smem, lr.list[pos], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
+                                                      out_len, out_cnt_in, nullptr, nullptr, filt, filt_shift, n_bases, chk, lut,
+                                                      packed, true, sg - lr.seg0[pos], lr.seg_h + (size_t)sg * kSegSlots,
+                                                      lr.seg_cnt + sg);
+                wave_sync();  // the wave's LDS region is reused by its next segment
+            }
+            return;
+        }
     }
+    if (from_list == 2u) w -= kSegBlocks * 4u;
     if (from_list != 1u) {
         if (w < n_reads)
             sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
-                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut, packed);
+                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut, packed,
+                                               from_list == 2u);
         return;
     }
     const u32 n = retry[0];
@@ -546,6 +636,46 @@ __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_ke
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned char lut[256];
     sketch_wave_body<KT, HCAP, INRANGE>(SKX_SKETCH_ARGS, smem, lut);
+}
+// One wave per long read of a production batch (walking the list batch_check_kernel built): the segment waves' hashes are
+// gathered into the wave's LDS buffer (kSketchCap entries) and finished like any other read's.  A segment slot that
+// overflowed, or more hashes than the buffer holds, sends the read to the block sketcher (`big`), which reads it whole.
+__global__ __launch_bounds__(64) void sketch_merge_kernel(const u64* __restrict__ offsets, u32 s, u64 max_ref,
+                                                          u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
+                                                          u32* __restrict__ out_cnt_in, u32* __restrict__ big,
+                                                          const u32* __restrict__ filt, u32 filt_shift,
+                                                          const u32* __restrict__ chk, LongReads lr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* hashes = reinterpret_cast<u64*>(smem);
+    const u32 lane = lane_id();
+    if (chk[6] & 2u) return;  // the tables are incomplete (the host refuses the batch)
+    const u32 n_long = min(chk[1], lr.long_cap);
+    for (u32 pos = blockIdx.x; pos < n_long; pos += gridDim.x) {
+        const u32 r = lr.list[pos], seg0 = lr.seg0[pos];
+        const u32 n_seg = (u32)((offsets[r + 1] - offsets[r] + kSketchCap - 1u) / kSketchCap);
+        u32 m = 0;
+        bool bad = seg0 + n_seg > lr.segs_cap;
+        for (u32 i0 = 0; i0 < n_seg && !bad; i0 += 64u) {
+            const bool on = i0 + lane < n_seg;
+            const u32 c = on ? lr.seg_cnt[seg0 + i0 + lane] : 0u;  // (64 segments' counts at once)
+            if (__ballot(c == kSegOvf)) { bad = true; break; }
+            const u32 incl = wave_incl_scan(c);
+            const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            if (m + tot > (u32)kSketchCap) { bad = true; break; }
+            const u64* src = lr.seg_h + (size_t)(seg0 + i0 + lane) * kSegSlots;
+            u64* dst = hashes + m + incl - c;
+            for (u32 j = 0; __ballot(j < c); ++j)
+                if (j < c) dst[j] = src[j];
+            m += tot;
+        }
+        wave_sync();
+        if (bad) {
+            if (lane == 0) { out_len[r] = kSketchRetry; out_cnt_in[r] = 0; list_append(big, r); }
+        } else {
+            sketch_finish<kSketchCap, true>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift);
+        }
+        wave_sync();  // the buffer is reused by the wave's next read
+    }
 }
 // Experiment (SKX_SKETCH_ROOM=1): the fast in-range variant held to 5 waves per SIMD by its register allocation instead of
 // by unused dynamic LDS.  It gives the scan its stand-alone speed inside the pipeline and costs the step 12 %: the
@@ -759,15 +889,28 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
 // device-side look at a batch's offsets, so the host reads back 24 bytes instead of every offset
 // =====================================================================================
 // chk[0] = 0xFFFFFFFF - (first r with offsets[r+1] < offsets[r])   (0: offsets are monotonic)
-// chk[1] = number of reads with more than `lim` bases (they need the long-read kernels)
-// chk[2..3] = offsets[0], chk[4..5] = offsets[n_reads]               (chk zeroed by the caller)
-__global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads, u64 lim, u32* __restrict__ chk,
-                                   u32* __restrict__ cnt_tail) {
+// chk[1] = number of LONG reads (is_split_long: more than kLongSplit bases, inside the batch), chk[9] = their segments
+// chk[2..3] = offsets[0], chk[4..5] = offsets[n_reads]               (chk zeroed by the caller / the previous publish)
+// lr.list != NULL (production batches): every long read is listed (lr.list / lr.seg0, in arrival order of the atomics) and
+// gets a run of segment slots, each pointing back at it (lr.seg_tab) -- the work list of the segment waves and of
+// sketch_merge_kernel.  A batch that would need more slots than exist (only possible with offsets that are not
+// monotonic: n_bases <= the stream's max_batch_bases bounds the sum of the lengths) is flagged in chk[6].
+__global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads, u64 n_bases, u32* __restrict__ chk,
+                                   u32* __restrict__ cnt_tail, LongReads lr) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
+    const u64 lo = offsets[0];
     for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
         const u64 o0 = offsets[r], o1 = offsets[r + 1];
         if (o1 < o0) atomicMax(&chk[0], 0xFFFFFFFFu - r);
-        else if (o1 - o0 > lim) atomicAdd(&chk[1], 1u);
+        else if (lr.list && is_split_long(o0, o1, lo, n_bases)) {
+            const u32 n_seg = (u32)((o1 - o0 + kSketchCap - 1u) / kSketchCap);
+            const u32 pos = atomicAdd(&chk[1], 1u);
+            const u32 seg0 = atomicAdd(&chk[9], n_seg);
+            if (pos >= lr.long_cap || seg0 + n_seg > lr.segs_cap || seg0 + n_seg < seg0) { atomicOr(&chk[6], 2u); continue; }
+            lr.list[pos] = r;
+            lr.seg0[pos] = seg0;
+            for (u32 i = 0; i < n_seg; ++i) lr.seg_tab[seg0 + i] = pos;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const u64 a = offsets[0], b = offsets[n_reads];
@@ -784,7 +927,9 @@ __global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, u
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (big) { chk[7] = big[0]; big[0] = 0; }  // (reads that needed the block sketcher: a statistic for the host)
-    for (int i = 0; i < 8; ++i) { h_pub[i] = chk[i]; chk[i] = 0; }
+    for (int i = 0; i < 8; ++i) h_pub[i] = chk[i];
+    h_pub[9] = chk[9];  // (segments of the batch's long reads: a statistic)
+    for (int i = 0; i < 16; ++i) chk[i] = 0;
     if (retry) retry[0] = 0;
     h_pub[8] = *total_pairs;
     __threadfence_system();
@@ -2564,7 +2709,8 @@ static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketch
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed) {
+                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed,
+                         const LongReads* long_reads) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
     // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 19 KB: 4 instead of 8 of its blocks fit a CU, and when one
@@ -2618,7 +2764,8 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
         }
     }
     const dim3 list_grid(std::min<u32>(n_reads, 1024u)), blk_grid(std::min<u32>(n_reads, 256u));
-    const dim3 grid2(2u * cdiv(n_reads, 4));  // two-phase (long reads first); needs chk[1] from batch_check_kernel
+    const dim3 grid2(kSegBlocks + cdiv(n_reads, 4));  // segment workgroups first; needs the tables of batch_check_kernel
+    const LongReads lr = long_reads ? *long_reads : LongReads{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
     // (the list walk -- usually over an empty list -- goes out as ONE-wave blocks with a quarter of the LDS, 18.6 KB: a
     // 74 KB block would wait for a CU the scan's blocks have left, i.e. for the end of the scan running beside it:
     // 140-180 us on the sketch stream, measured)
@@ -2626,19 +2773,24 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid,                        \
                        dim3((FROM_LIST) == 1u ? 64 : 256), (FROM_LIST) == 1u ? (LDS) / 4 : (LDS), st, bases,                \
                        offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in,                          \
-                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk)
+                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk, lr)
     (void)blk_grid;
     if (inrange_only) {
         // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
         // does not fit is left on the `big` list for launch_sketch_block -- both lists live on the device, usually empty
-        const u32 first = chk ? 2u : 0u;
+        // (with the long-read tables: segment workgroups in front, long reads skipped by the read waves and finished by
+        // sketch_merge_kernel -- one-wave workgroups with a 16 KB buffer each, walking the list; without long reads they
+        // return at once)
+        const u32 first = (chk && lr.list) ? 2u : 0u;
         if (k == 16) {
             if (capped) SKX_SK_LAUNCH(sketch_wave_kernel_capped<16>, lds_small, first); else SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, first);
-            SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u);
         } else {
             if (capped) SKX_SK_LAUNCH(sketch_wave_kernel_capped<0>, lds_small, first); else SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, first);
-            SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u);
         }
+        if (first == 2u)
+            hipLaunchKernelGGL(sketch_merge_kernel, dim3(512), dim3(64), (size_t)kSketchCap * 8, st, offsets, s, max_ref, out_sk, sk_stride,
+                               out_len, out_cnt_in, big, filt, filt_shift, chk, lr);
+        if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); else SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u);
     } else {
         if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u);
     }
@@ -2761,10 +2913,13 @@ void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), std::min(y_est, 65535u)), dim3(256), 0, st,
                        m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty);
 }
-void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail) {
-    hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, lim, chk,
-                       cnt_tail);
+void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_bases, u32* chk, u32* cnt_tail, const LongReads* long_reads) {
+    const LongReads lr = long_reads ? *long_reads : LongReads{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, n_bases, chk,
+                       cnt_tail, lr);
 }
+u32 long_read_split() { return kLongSplit; }
+u32 long_read_seg_slots() { return kSegSlots; }
 void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, st, chk, retry, big, total_pairs, h_pub, seq);
 }

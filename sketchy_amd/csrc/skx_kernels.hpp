@@ -35,16 +35,33 @@ struct Species { const u32* g0; const u32* n; const u32* of_grp; u32 n_sp; };
 void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 pad_base, u32 g_count);
 void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, u64* lo, u64* hi);
 
+// Long reads of a production batch are split over waves (skx_kernels.hip, "long reads: split over waves"): device tables
+// built by launch_batch_check and consumed by launch_sketch.  Capacities: a read is long beyond long_read_split() raw
+// bytes and takes ceil(length / kSketchCap) segment slots, so a batch of at most B bases needs at most
+// B / long_read_split() + 1 list entries and 5 B / (4 kSketchCap) + 1 slots (the caller sizes them from max_batch_bases).
+struct LongReads {
+    u32* list;     // [long_cap] read index
+    u32* seg0;     // [long_cap] first segment slot of the read
+    u32* seg_tab;  // [segs_cap] position in `list` of the read a segment slot belongs to
+    u32* seg_cnt;  // [segs_cap] hashes the segment kept
+    u64* seg_h;    // [segs_cap][long_read_seg_slots()]
+    u32 segs_cap, long_cap;
+};
+u32 long_read_split();
+u32 long_read_seg_slots();
+
 // sketching: every read of the batch, any length -- one wave per read (256 hash slots, then 2048 for the reads that
 // overflow); what still does not fit (and, for full sketches, every read with more than kSketchCap k-mers) is left on the
 // device-side list `big` for launch_sketch_block (one block per read).  `retry` / `big`: [0] = count, zero on entry.
 // n_bases: bytes the caller vouches for from offsets[0] on; a read reaching outside is skipped and flagged in chk[6]
-// (chk may be NULL).  Returns the launch status (it also opts the big-LDS kernels in, once per device).
+// (chk may be NULL).  long_reads (production batches, with chk): the tables launch_batch_check filled for this batch.
+// Returns the launch status (it also opts the big-LDS kernels in, once per device).
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
                          const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
                          u32* retry /* [1 + n_reads] */, u32* big /* [1 + n_reads] */, u64 n_bases, u32* chk,
-                         int leave_room /* 0 no, 1 a scan overlaps the start, 2 a scan runs beside most of it */ /* a scan is running next to this launch: cap the blocks per CU */, bool packed = false);
+                         int leave_room /* 0 no, 1 a scan overlaps the start, 2 a scan runs beside most of it */, bool packed = false,
+                         const LongReads* long_reads = nullptr);
 // the block sketcher for the n_big reads launch_sketch left on `big` (big[1 ..]); the caller reads the count back first
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
@@ -87,8 +104,10 @@ void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands,
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
                            const u32* n_q, u32* grp_any, const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles,
                            const u32* m_dirty, u64 nq_est /* the host's estimate of the dictionary size: sizes the grid */);
-// chk[0..5] (zeroed by the caller): non-monotonic marker, long-read count, offsets[0], offsets[n_reads]
-void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 lim, u32* chk, u32* cnt_tail /* zeroed */);
+// chk[0..5], [9] (zero on entry): non-monotonic marker, long-read count, offsets[0], offsets[n_reads], segment count;
+// long_reads != NULL: also lists the batch's long reads and their segments (chk[6] |= 2 if they do not fit the tables)
+void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_bases, u32* chk, u32* cnt_tail /* zeroed */,
+                        const LongReads* long_reads);
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
 // ([7] = number of reads the block sketcher took; `big` is re-armed like `retry`)
 void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq);

@@ -113,21 +113,41 @@ def _run(cmd, timeout=600, **env):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
 
 
-def test_bench_self_launches_two_ranks(gpu):
-    """`python bench.py --gpus 2` from a plain invocation (no torchrun, no WORLD_SIZE): the parent starts the ranks
-    itself; both share the box's one GPU.  The JSON line must come back with n_gpus = 2 and green parity."""
+def _bench_two_ranks(*extra):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--share-gpu", "--config", "c1", "--batch", "8192",
-                          "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900,
-                         env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+                          "--steps", "3", "--warmup", "1", "--reps", "2", "--cpu-seconds", "0", "--no-extra-legs", *extra],
+                         capture_output=True, text=True, timeout=900, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, lines
+
+
+def test_bench_self_launches_two_ranks(gpu):
+    """`python bench.py --gpus 2` from a plain invocation (no torchrun, no WORLD_SIZE): the parent starts the ranks
+    itself; both share the box's one GPU, which RCCL refuses -- the table goes through gloo on the host, and the line SAYS
+    so: rccl_ranks = 0, allreduce.how = gloo-host (accepted only because --allow-host-allreduce is given)."""
+    out, lines = _bench_two_ranks("--allow-host-allreduce")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and "parity_error" not in j
     assert j["parity"]["last_timed_step_vs_4096_read_cuts"] is True
-    assert j["config"]["rccl_ranks"] == 2
+    assert j["config"]["rccl_ranks"] == 0
+    ar = j["config"]["allreduce"]
+    assert ar["how"] == "gloo-host" and ar["ranks"] == 0 and ar["world"] == 2 and ar["ms"] > 0
+    assert len(j["values_per_rank"]) == 2 and len(j["values_all"]) == 2 and j["reps"] == 2
+    assert min(j["values_all"]) <= j["value"] <= max(j["values_all"])
     assert j["value"] > 0
+
+
+def test_bench_fails_when_rccl_did_not_reduce_the_table(gpu):
+    """The same run WITHOUT --allow-host-allreduce: a multi-GPU line whose table was not reduced by RCCL over all ranks must
+    not come out green (on the driver's 8-GPU node a broken RCCL bring-up would otherwise look like a valid scaling point)."""
+    out, lines = _bench_two_ranks()
+    assert out.returncode != 0
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(lines[0])
+    assert "not reduced by RCCL" in j["parity_error"] and j["config"]["rccl_ranks"] == 0
 
 
 def test_two_ranks_score_their_shards_on_the_hip_path(gpu, tmp_path):

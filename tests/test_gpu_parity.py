@@ -274,6 +274,89 @@ def test_long_read_edge_cases(gpu):
     check(ref, bases, offsets, top=1, want_sketches=False)
 
 
+def _split_reads():
+    """Reads around and far beyond the 8192-base split point of the production sketcher (kLongSplit = 4 chunks of 2048 raw
+    bytes): a read cut into segments must give the serial loop's hashes whatever sits on the chunk borders."""
+    ref, _, _ = workload(40, 500, 1, read_len=300, genome_len=400000, rng_seed=909)
+    g = ref["genome"].tobytes()
+    ws = b" \t\r\n" * 50                                   # 200 bytes of whitespace
+    reads = [
+        g[0:8192],                                            # at the limit: one wave, four chunks
+        g[100:100 + 8193],                                    # one base beyond: five segments, the last holds ONE raw byte
+        g[9000:9000 + 10240],                                 # a multiple of the chunk size
+        g[20000:20000 + 8192 + 15],                           # the last segment is shorter than k
+        _wrap(g[30000:90000]),                                # FASTA lines of 70 + newline: borders fall between, on and behind newlines
+        g[100000:104000] + ws + g[104000:112000],             # 200 removed bytes in a row, across a chunk border: the carry scan loops
+        g[120000:124090] + b"\n" * 6 + g[124090:131000],      # whitespace right AT a border (raw offset 4096)
+        g[140000:142040] + b"N" * 20 + g[142060:150500],      # an N run over the first border
+        (g[150000:156143] + b"n" + g[156144:160000]).lower(), # lower case, an n one base before a border
+        g[160000:260000],                                     # 100 kb: 49 segments
+        g[200000:399000],                                     # 199 kb: 98 segments (more than one wave's worth of counts in the merge)
+        b"ACGT" * 3000,                                       # 12 kb with two distinct canonical k-mers
+        b"N" * 9000,
+        b"\n" * 9000,                                         # nothing but removed bytes
+        g[1000:2500], b"", g[5000:5000 + 2064],
+    ]
+    return ref, reads
+
+
+def test_long_reads_split_over_waves(gpu):
+    """Production sketch path (no debug sketches): reads beyond 8192 bases are hashed by one wave per 2048-byte chunk and
+    merged (sketch_merge_kernel) -- rows, per-read counts and table against the oracle; in one batch, in several, through
+    the device-resident entry points and as 4-bit packed input."""
+    from sketchy_amd import api
+    ref, reads = _split_reads()
+    bases, offsets = pack_reads(reads)
+    n = len(reads)
+    exp = orc.stream(16, 0, 500, ref["ref"], np.full(40, 500, np.uint32), bases, offsets, top_k=2, want_shared=True)
+    assert exp["shared"][10].max() > 20  # the 199 kb read really shares hashes
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=2, max_batch_reads=n, max_batch_bases=len(bases))
+    got = S.push(bases, offsets, want_shared=True)
+    np.testing.assert_array_equal(got["shared"], exp["shared"])
+    np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"])
+    np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    st = S.stats()
+    n_long = sum(1 for r in reads if len(r) > 8192)
+    assert st["reads_split_over_waves"] == n_long and st["reads_block_sketcher"] == 0
+    assert st["read_segments"] == sum((len(r) + 2047) // 2048 for r in reads if len(r) > 8192)
+    # the debug path (full sketches: the block sketcher takes the long reads) agrees, and so do three batches + device pushes
+    S.reset()
+    full = S.push(bases, offsets, want_shared=True, want_sketches=True)
+    np.testing.assert_array_equal(full["shared"], exp["shared"])
+    S.reset()
+    parts = [_push_device(S, bases, offsets[a:b + 1], 2) for a, b in ((0, 5), (5, 11), (11, n))]
+    np.testing.assert_array_equal(np.concatenate([p_["topk_idx"] for p_ in parts]), exp["topk_idx"])
+    np.testing.assert_array_equal(np.concatenate([p_["topk_sum"] for p_ in parts]), exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    # 4-bit packed input (no whitespace in that format: the packer drops it), starting on an odd nibble
+    packed, poff = api.pack_reads(bases, offsets, first_nibble=1)
+    P = api.SumOfSharedHashes(R, top=2, max_batch_reads=n, max_batch_bases=int(poff[-1]) + 2)
+    P.set_packed_input(True)
+    gp = P.push(packed, poff, want_shared=True)
+    np.testing.assert_array_equal(gp["shared"], exp["shared"])
+    np.testing.assert_array_equal(gp["topk_idx"], exp["topk_idx"])
+    np.testing.assert_array_equal(P.table(), exp["cum"])
+    assert P.stats()["reads_split_over_waves"] > 0
+
+
+def test_long_reads_split_other_k_and_dense_segments(gpu):
+    """k = 21 / 11 / 32 (the carry in front of a segment is k - 1 codes) and a reference dense enough that segments overflow
+    their 64-entry slots: those reads fall through to the block sketcher, same rows."""
+    from sketchy_amd import api
+    for k, seed in ((21, 3), (11, 0), (32, 5)):
+        ref, _, _ = workload(20, 200, 1, read_len=300, k=k, seed=seed, genome_len=150000, rng_seed=250 + k)
+        g = ref["genome"].tobytes()
+        bases, offsets = pack_reads([g[0:9000], g[10000:10500], _wrap(g[20000:60000]), g[60000:60000 + 8193 + k]])
+        check(ref, bases, offsets, top=2, k=k, seed=seed, want_sketches=False)
+    ref, _, _ = workload(12, 6000, 1, read_len=300, genome_len=40000, rng_seed=261)  # ~15 % of the hash space is in range
+    g = ref["genome"].tobytes()
+    bases, offsets = pack_reads([g[0:20000], g[100:1600], g[15000:39000]])
+    got, exp, R, S = check(ref, bases, offsets, top=1, want_sketches=False)
+    assert S.stats()["reads_block_sketcher"] == 2 and S.stats()["reads_split_over_waves"] == 2
+
+
 def test_long_reads_other_k(gpu):
     for k, seed in ((21, 3), (11, 0)):
         ref, _, _ = workload(20, 200, 1, read_len=300, k=k, seed=seed, genome_len=100000, rng_seed=150 + k)
