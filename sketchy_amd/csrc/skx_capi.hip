@@ -1167,6 +1167,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     {
         u32 c[8];
         for (int i = 0; i < 8; ++i) c[i] = st->h_chk[i];
+        if (pb.inrange_only && st->lr.list && !c[0] && !c[6]) { st->reads_split += c[1]; st->segs_split += st->h_chk[9]; }  // (statistics)
         char buf[160];
         if (c[0]) {
             snprintf(buf, sizeof buf, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
@@ -1193,7 +1194,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     }
     const u32 total_pairs = st->h_chk[8];
     st->last_pairs = total_pairs; st->last_passes = 0;
-    if (pb.inrange_only && st->lr.list) { st->reads_split += st->h_chk[1]; st->segs_split += st->h_chk[9]; }
+
 
     const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap;
     // (the batch needs several passes although a speculative gather was queued for it: normally that gather did nothing -- it
