@@ -63,6 +63,19 @@ int skx_device_count(void);
 /* name (<= name_cap bytes), number of CUs and bytes of device memory of `device` */
 int skx_device_info(int device, char *name, size_t name_cap, int *compute_units, uint64_t *total_mem);
 
+/*
+ * Process-wide policies, consulted when a reference or a stream is CREATED (no effect on existing handles, never on
+ * results -- only on memory and speed).  Names:
+ *   "kmer_prefilter"  1 (default) / 0: for k = 16, skx_ref_create also builds a Bloom table over the canonical 16-mers whose
+ *                     hash can meet the reference (every 4^16 / 2 of them is hashed once, ~10 ms on an MI355X); the
+ *                     production sketcher then hashes only the windows of a read that pass it (reads with at most s
+ *                     windows -- longer ones can be truncated and take the plain loop).  Rows, tables and debug outputs
+ *                     are identical either way.
+ * Unknown names fail with SKX_ERR_INVALID.
+ */
+int skx_set_option(const char *name, uint64_t value);
+int skx_get_option(const char *name, uint64_t *value);
+
 /* ---- reference sketch collection, resident in HBM --------------------------------- */
 /*
  * hashes: genome g's ascending distinct 64-bit hashes at [g*stride, g*stride + col_len[g]), col_len[g] <= stride.
@@ -93,6 +106,8 @@ int skx_ref_n_species(const skx_ref *ref, uint32_t *n_species);
 int skx_ref_species_genomes(const skx_ref *ref, uint32_t species, uint32_t *n_genomes);
 /* read sketch size and column stride the reference was created with */
 int skx_ref_sketch_size(const skx_ref *ref, uint32_t *s, uint32_t *stride);
+/* k-mer prefilter of the reference: keys it holds (0: none was built) and the bytes of its table */
+int skx_ref_kmer_filter(const skx_ref *ref, uint64_t *n_keys, uint64_t *table_bytes);
 /* bytes of reference hashes one scoring pass streams from HBM (8*stride*n_genomes) */
 int skx_ref_pass_bytes(const skx_ref *ref, uint64_t *bytes);
 void skx_ref_destroy(skx_ref *ref);

@@ -27,6 +27,9 @@ SYMBOLS = [
     ("skx_version", C.c_char_p, []),
     ("skx_device_count", _i, []),
     ("skx_device_info", _i, [_i, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_u64)]),
+    ("skx_set_option", _i, [C.c_char_p, _u64]),
+    ("skx_get_option", _i, [C.c_char_p, C.POINTER(_u64)]),
+    ("skx_ref_kmer_filter", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("skx_ref_create", _i, [_pp, _i, _u32, _u64, _u32, _u32, _u32, _vp, _vp]),
     ("skx_ref_create_multi", _i, [_pp, _i, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _vp]),
     ("skx_ref_sketch_size", _i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),

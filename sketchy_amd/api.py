@@ -36,6 +36,17 @@ def pack_reads(bases, offsets, first_nibble=0):
     return packed[: (pos + 1) // 2 + 1], out
 
 
+def set_option(name: str, value: int):
+    """Process-wide policy for references / streams created from now on (skx_set_option), e.g. "kmer_prefilter"."""
+    _lib.check(_lib.load().skx_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_uint64(0)
+    _lib.check(_lib.load().skx_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
 def device_count() -> int:
     return _lib.load().skx_device_count()
 
@@ -80,6 +91,13 @@ class ReferenceSketch:
             cp = (C.c_void_p * self.n_species)(*[c.ctypes.data for c in lens])
             _lib.check(L.skx_ref_create_multi(C.byref(h), device, self.k, self.seed, self.s, self.stride, self.n_species, ng, hp, cp))
         self._h = h
+
+    @property
+    def kmer_filter(self):
+        """(keys, table bytes) of the reference's k-mer prefilter; (0, 0) when none was built"""
+        n, b = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(_lib.load().skx_ref_kmer_filter(self._h, C.byref(n), C.byref(b)))
+        return n.value, b.value
 
     @property
     def pass_bytes(self) -> int:

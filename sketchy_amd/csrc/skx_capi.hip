@@ -118,6 +118,20 @@ SKX_API int skx_dev_synchronize(int device) {
     return SKX_OK;
 }
 
+// ------------------------------------------------------------------ policies (skx_set_option)
+static bool g_kmer_prefilter = true;  // build / use the k-mer prefilter for k = 16 references
+
+SKX_API int skx_set_option(const char* name, uint64_t value) {
+    if (!name) return fail(SKX_ERR_INVALID, "NULL option name");
+    if (!strcmp(name, "kmer_prefilter")) { g_kmer_prefilter = value != 0; return SKX_OK; }
+    return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
+}
+SKX_API int skx_get_option(const char* name, uint64_t* value) {
+    if (!name || !value) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (!strcmp(name, "kmer_prefilter")) { *value = g_kmer_prefilter ? 1 : 0; return SKX_OK; }
+    return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
+}
+
 // ------------------------------------------------------------------ reference
 struct skx_ref {
     int device = 0;
@@ -141,6 +155,10 @@ struct skx_ref {
     u32* d_filt = nullptr;
     u32 filt_shift = 0;
     u64 filt_bits = 0;
+    // k-mer prefilter (k = 16): Bloom table over the canonical 16-mers whose hash passes the membership filter
+    u32* d_kf = nullptr;
+    u32 kf_shift = 0, kf_keys = 0;
+    skx::KmerFilter kmer_filter() const { return skx::KmerFilter{d_kf, kf_shift}; }
     skx::Species species() const { return skx::Species{d_sp_g0, d_sp_n, d_grp_sp, n_species}; }
 };
 
@@ -148,7 +166,7 @@ static void ref_free(skx_ref* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     (void)hipFree(r->d_mat); (void)hipFree(r->d_lo); (void)hipFree(r->d_hi);
-    (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h); (void)hipFree(r->d_filt);
+    (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h); (void)hipFree(r->d_filt); (void)hipFree(r->d_kf);
     (void)hipFree(r->d_sp_g0); (void)hipFree(r->d_sp_n); (void)hipFree(r->d_grp_sp); (void)hipFree(r->d_real2pad);
     delete r;
 }
@@ -288,6 +306,25 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipGetLastError());
     }
     RCHK(hipDeviceSynchronize());
+    if (k == 16 && any && g_kmer_prefilter) {
+        // every canonical 16-mer whose hash passes the filter above (two passes over the 2^32 codes: count, then insert);
+        // 16 table bits per key, two probes: ~1.4 % false positives, each costing one murmur3 evaluation per occurrence
+        u32* d_n = nullptr;
+        RCHK(hipMalloc(&d_n, 4));
+        RCHK(hipMemset(d_n, 0, 4));
+        skx::launch_kmer_filter_build(nullptr, seed, max_ref, r->d_filt, r->filt_shift, d_n, nullptr, 0);
+        RCHK(hipGetLastError());
+        RCHK(hipMemcpy(&r->kf_keys, d_n, 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d_n);
+        u32 lg_words = 10;  // 4 KB at least
+        while (lg_words < 27 && (32ull << lg_words) < 16ull * r->kf_keys) ++lg_words;
+        r->kf_shift = 32u - lg_words;
+        RCHK(hipMalloc(&r->d_kf, (size_t)4 << lg_words));
+        RCHK(hipMemset(r->d_kf, 0, (size_t)4 << lg_words));
+        skx::launch_kmer_filter_build(nullptr, seed, max_ref, r->d_filt, r->filt_shift, nullptr, r->d_kf, r->kf_shift);
+        RCHK(hipGetLastError());
+        RCHK(hipDeviceSynchronize());
+    }
 #undef RCHK
     *out = r;
     return SKX_OK;
@@ -320,6 +357,12 @@ SKX_API int skx_ref_species_genomes(const skx_ref* ref, uint32_t species, uint32
     if (!ref || !n_genomes) return fail(SKX_ERR_INVALID, "NULL argument");
     if (species >= ref->n_species) return fail(SKX_ERR_INVALID, "species %u outside 0..%u", species, ref->n_species - 1);
     *n_genomes = ref->sp_n[species];
+    return SKX_OK;
+}
+SKX_API int skx_ref_kmer_filter(const skx_ref* ref, uint64_t* n_keys, uint64_t* table_bytes) {
+    if (!ref) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (n_keys) *n_keys = ref->d_kf ? ref->kf_keys : 0;
+    if (table_bytes) *table_bytes = ref->d_kf ? (4ull << (32u - ref->kf_shift)) : 0;
     return SKX_OK;
 }
 SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
@@ -1098,6 +1141,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         // offsets are looked at on the device (cheap); it also zeroes entry n_reads of the pair counts
         // (... and lists the long reads of a production batch with their segments: the sketcher splits those over waves)
         const skx::LongReads* lr = (pb.inrange_only && st->lr.list) ? &st->lr : nullptr;
+        const skx::KmerFilter kf = ref->kmer_filter();
         skx::launch_batch_check(hs, pb.d_offsets, n_reads, pb.n_bases, st->d_chk, st->d_cnt + n_reads, lr);
         if (pb.h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
         // every read, any length: wave sketchers (then the block sketcher for what overflowed: device-side lists)
@@ -1109,7 +1153,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         (void)hipGetLastError();  // (hipErrorNotReady is not an error)
         HIPCHK(skx::launch_sketch(hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s_read, max_ref, pb.inrange_only,
                                   st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big,
-                                  pb.n_bases, st->d_chk, leave_room, st->packed, lr));
+                                  pb.n_bases, st->d_chk, leave_room, st->packed, lr, ref->d_kf ? &kf : nullptr));
         if (!pb.inrange_only) {
             // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
             // not the fast one -- read the count back and run the block sketcher before the rows are copied out

@@ -239,6 +239,62 @@ __device__ __forceinline__ bool is_split_long(u64 o0, u64 o1, u64 lo, u64 n_base
     return o0 >= lo && o1 >= o0 && o1 - lo <= n_bases && o1 - o0 > (u64)kLongSplit;
 }
 
+// ---- k-mer prefilter (struct KmerFilter: skx_kernels.hpp) ------------------------------------------------------------
+constexpr u32 kKmerMix = 0x9E3779B1u;  // odd: a bijection of the 32-bit code space
+constexpr u32 kPfQueue = 128;          // survivors (canonical codes) a wave parks in LDS before it hashes them, 64 at a time
+__device__ __forceinline__ bool kmer_filter_hit(const u32* __restrict__ words, u32 shift, u32 code) {
+    const u32 m = code * kKmerMix;
+    const u32 w = words[m >> shift];
+    const u32 mask = (1u << (m & 31u)) | (1u << ((m >> 5) & 31u));
+    return (w & mask) == mask;
+}
+// the 16 ASCII bytes of a 2-bit packed 16-mer (first base in the two highest bits), as murmur3's two little-endian words
+__device__ __forceinline__ void ascii16_from_code(u32 code, u64& w0, u64& w1) {
+    u32 a[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const u32 b = code >> (24 - 8 * g);  // bases 4g .. 4g+3 in the low byte, first base in its two highest bits
+        const u32 sel = ((b >> 6) & 3u) | (((b >> 4) & 3u) << 8) | (((b >> 2) & 3u) << 16) | ((b & 3u) << 24);
+        a[g] = __builtin_amdgcn_perm(0u, 0x54474341u, sel);  // "ACGT"[selector byte]
+    }
+    w0 = make_u64(a[0], a[1]);
+    w1 = make_u64(a[2], a[3]);
+}
+__device__ __forceinline__ u32 revcomp16(u32 x) {
+    u32 r = __brev(~x);  // bit-reversed complement: the 2-bit groups are in reverse order, each with its two bits swapped
+    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+// One pass over all 2^32 codes; a code is canonical when it does not exceed its reverse complement (palindromes: equal,
+// the same bytes either way).  INSERT = false: count the k-mers whose hash passes; true: set their two bits.
+template <bool INSERT>
+__global__ __launch_bounds__(256) void kmer_filter_build_kernel(u64 seed, u64 max_ref, const u32* __restrict__ filt, u32 filt_shift,
+                                                                u32* __restrict__ n_keys, u32* __restrict__ words, u32 shift) {
+    constexpr u32 kPerThread = 256;
+    const u32 base = (blockIdx.x * 256u + threadIdx.x) * kPerThread;  // (2^32 codes = 65 536 blocks x 256 threads x 256)
+    u32 mine = 0;
+    for (u32 i = 0; i < kPerThread; ++i) {
+        const u32 x = base + i;
+        if (x > revcomp16(x)) continue;
+        u64 w0, w1;
+        ascii16_from_code(x, w0, w1);
+        const u64 h = murmur3_h1_16<false>(w0, w1, seed);
+        if (h > max_ref) continue;
+        const u64 idx = h >> filt_shift;
+        if (!((filt[idx >> 5] >> (u32)(idx & 31u)) & 1u)) continue;
+        if (INSERT) {
+            const u32 m = x * kKmerMix;
+            atomicOr(&words[m >> shift], (1u << (m & 31u)) | (1u << ((m >> 5) & 31u)));
+        } else {
+            ++mine;
+        }
+    }
+    if (!INSERT) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine += (u32)__shfl_xor((int)mine, d, 64);
+        if (lane_id() == 0 && mine) atomicAdd(n_keys, mine);
+    }
+}
+
 // the tail of every sketch: `m` hashes in the wave's LDS buffer (any order, m <= HCAP) -> ascending, distinct, truncated to
 // s, (production) only those some genome holds -> out_sk row r, out_len[r], out_cnt_in[r]
 template <int HCAP, bool INRANGE>
@@ -337,14 +393,15 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                                                 const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
                                                 u32* __restrict__ chk, const unsigned char* lut, bool packed,
                                                 bool split_long = false, u32 seg_i = 0, u64* __restrict__ seg_h = nullptr,
-                                                u32* __restrict__ seg_cnt = nullptr) {
+                                                u32* __restrict__ seg_cnt = nullptr, KmerFilter kf = KmerFilter{nullptr, 0u}) {
     static_assert(!SEG || INRANGE, "segments exist in production mode only");
     constexpr u32 CAP = kSketchCap;
-    constexpr u32 kPerWave = HCAP * 8 + CAP + 128;  // (32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding)
+    constexpr u32 kPerWave = HCAP * 8 + CAP + 128 + kPfQueue * 4;  // (32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding; the prefilter's queue)
     constexpr u32 kChunkAt = 32;                    // a chunk's codes start here; the carried k-1 end here
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     u64* hashes = reinterpret_cast<u64*>(smem + (size_t)wv * kPerWave);
     uint8_t* codes = smem + (size_t)wv * kPerWave + HCAP * 8;
+    u32* pq = reinterpret_cast<u32*>(smem + (size_t)wv * kPerWave + HCAP * 8 + CAP + 128);  // the prefilter's survivors
     const u32 k = KT > 0 ? (u32)KT : k_rt;
     const u64 o0 = offsets[r], o1 = offsets[r + 1];
     // the caller vouches for n_bases bytes from offsets[0] on: a read reaching outside is never touched (flagged in
@@ -373,6 +430,9 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     // (reads beyond kLongSplit only get here when they are not split: full sketches, the 2048-slot retry variant)
     if (lraw > 4u * CAP) __builtin_amdgcn_s_setprio(2);
 
+    // k-mer prefilter (production, k = 16): a read with at most s windows cannot be truncated, so only windows whose k-mer
+    // the reference can hold at all need their hash (KmerFilter, skx_kernels.hpp); longer reads take the plain loop
+    const bool use_pf = KT == 16 && INRANGE && kf.words != nullptr && filt != nullptr && (u64)lraw <= (u64)s + 15u;
     u32 m = 0;    // hashes collected so far (any order: they are sorted afterwards); wave-uniform (kept scalar)
     u32 ovf = 0;  // the hash buffer overflowed: the read is handed on after the loop (wave-uniform, scalar)
     // (in production mode 99.5 % of the hashes are out of range: three iterations in four keep nothing at all and skip
@@ -509,6 +569,50 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                     clean = (u32)__builtin_clz(((inv & 0x7FFFu) << 17) | 0x10000u);
                 }
                 u32 cnext = codes[min(p0 + 15u, lim)];  // (the next code is requested one iteration ahead of its use)
+                if (use_pf) {
+                    // 2-bit windows only; the table word of window t is requested one iteration before it is tested
+                    u32 qn = 0;  // survivors parked in pq (wave-uniform)
+                    auto drain = [&]() {
+                        wave_sync();
+                        for (u32 i0 = 0; i0 < qn; i0 += 64u) {
+                            const bool v = i0 + lane < qn;
+                            const u32 code = v ? pq[i0 + lane] : 0u;
+                            u64 a0, a1;
+                            ascii16_from_code(code, a0, a1);
+                            const u64 h = seed == 0 ? murmur3_h1_16<true>(a0, a1, 0) : murmur3_h1_16<false>(a0, a1, seed);
+                            append(v, h);
+                        }
+                        qn = 0;
+                        wave_sync();
+                    };
+                    auto test = [&](bool valid, u32 word, u32 mix, u32 canon) {
+                        const u32 mask = (1u << (mix & 31u)) | (1u << ((mix >> 5) & 31u));
+                        const bool hit = valid && (word & mask) == mask;
+                        const u64 hm = __ballot(hit);
+                        if (hm) {
+                            if (hit) pq[qn + (u32)__popcll(hm & lt)] = canon;
+                            qn = __builtin_amdgcn_readfirstlane(qn + (u32)__popcll(hm));
+                            if (qn > kPfQueue - 64u) drain();
+                        }
+                    };
+                    bool pvalid = false;
+                    u32 pword = 0, pmix = 0, pcanon = 0;
+                    for (u32 t = 0; t < run; ++t) {
+                        const u32 ccur = cnext;
+                        cnext = codes[min(p0 + t + 16u, lim)];
+                        clean = (ccur >> 2) ? 0u : clean + 1u;
+                        const u32 c2 = ccur & 3u;
+                        fwd = (fwd << 2) | c2;
+                        rc = __builtin_amdgcn_alignbit(c2 ^ 3u, rc, 2);
+                        const u32 canon = min(fwd, rc);
+                        const u32 mix = canon * kKmerMix;
+                        const u32 word = kf.words[mix >> kf.shift];
+                        test(pvalid, pword, pmix, pcanon);
+                        pvalid = clean >= 16u; pword = word; pmix = mix; pcanon = canon;
+                    }
+                    test(pvalid, pword, pmix, pcanon);
+                    if (qn) drain();
+                } else
                 for (u32 t = 0; t < run; ++t) {
                     const u32 ccur = cnext;
                     cnext = codes[min(p0 + t + 16u, lim)];
@@ -584,9 +688,9 @@ constexpr u32 kSegBlocks = 1024;  // x 4 waves: a C4 batch has ~28 000 segments
     const uint8_t *__restrict__ bases, const u64 *__restrict__ offsets, u32 n_reads, u32 k_rt, u64 seed, u32 s, u64 max_ref,  \
         u64 *__restrict__ out_sk, u32 sk_stride, u32 *__restrict__ out_len, u32 *__restrict__ out_cnt_in, u32 from_list,      \
         u32 *__restrict__ retry, u32 *__restrict__ big, const u32 *__restrict__ filt, u32 filt_shift, u64 n_bases,            \
-        u32 *__restrict__ chk, LongReads lr
+        u32 *__restrict__ chk, LongReads lr, KmerFilter kf
 #define SKX_SKETCH_ARGS \
-    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr
+    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr, kf
 template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, unsigned char* lut) {
     const bool packed = (from_list & 0x100u) != 0u;  // (bit 8: 4-bit packed input)
@@ -610,7 +714,7 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
                 sketch_one_read<KT, HCAP, true, true>(smem, lr.list[pos], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
                                                       out_len, out_cnt_in, nullptr, nullptr, filt, filt_shift, n_bases, chk, lut,
                                                       packed, true, sg - lr.seg0[pos], lr.seg_h + (size_t)sg * kSegSlots,
-                                                      lr.seg_cnt + sg);
+                                                      lr.seg_cnt + sg, kf);
                 wave_sync();  // the wave's LDS region is reused by its next segment
             }
             return;
@@ -621,13 +725,14 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
         if (w < n_reads)
             sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
                                                out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut, packed,
-                                               from_list == 2u);
+                                               from_list == 2u, 0u, nullptr, nullptr, kf);
         return;
     }
     const u32 n = retry[0];
     for (u32 i = w; i < n; i += gridDim.x * wpb) {
         sketch_one_read<KT, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
-                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut, packed);
+                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut, packed, false, 0u,
+                                           nullptr, nullptr, kf);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
 }
@@ -2716,12 +2821,12 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
 }
 
 constexpr int kSketchSmallHashes = 256;  // hash slots per read of the in-range fast variant
-static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketchCap + 128); }
+static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketchCap + 128 + kPfQueue * 4); }
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
                          const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed,
-                         const LongReads* long_reads) {
+                         const LongReads* long_reads, const KmerFilter* kmer_filter) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
     // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 19 KB: 4 instead of 8 of its blocks fit a CU, and when one
@@ -2777,6 +2882,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     const dim3 list_grid(std::min<u32>(n_reads, 1024u)), blk_grid(std::min<u32>(n_reads, 256u));
     const dim3 grid2(kSegBlocks + cdiv(n_reads, 4));  // segment workgroups first; needs the tables of batch_check_kernel
     const LongReads lr = long_reads ? *long_reads : LongReads{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    const KmerFilter kf = (kmer_filter && inrange_only && k == 16) ? *kmer_filter : KmerFilter{nullptr, 0u};
     // (the list walk -- usually over an empty list -- goes out as ONE-wave blocks with a quarter of the LDS, 18.6 KB: a
     // 74 KB block would wait for a CU the scan's blocks have left, i.e. for the end of the scan running beside it:
     // 140-180 us on the sketch stream, measured)
@@ -2784,7 +2890,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid,                        \
                        dim3((FROM_LIST) == 1u ? 64 : 256), (FROM_LIST) == 1u ? (LDS) / 4 : (LDS), st, bases,                \
                        offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in,                          \
-                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk, lr)
+                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk, lr, kf)
     (void)blk_grid;
     if (inrange_only) {
         // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
@@ -2829,6 +2935,10 @@ hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* 
     return hipGetLastError();
 }
 
+void launch_kmer_filter_build(hipStream_t st, u64 seed, u64 max_ref, const u32* filt, u32 filt_shift, u32* n_keys, u32* words, u32 shift) {
+    if (words) hipLaunchKernelGGL((kmer_filter_build_kernel<true>), dim3(65536), dim3(256), 0, st, seed, max_ref, filt, filt_shift, n_keys, words, shift);
+    else hipLaunchKernelGGL((kmer_filter_build_kernel<false>), dim3(65536), dim3(256), 0, st, seed, max_ref, filt, filt_shift, n_keys, words, shift);
+}
 void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum) {
     if (n == 0) return;
     const u32 nb = cdiv(n, 1024);

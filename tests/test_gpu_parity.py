@@ -357,6 +357,48 @@ def test_long_reads_split_other_k_and_dense_segments(gpu):
     assert S.stats()["reads_block_sketcher"] == 2 and S.stats()["reads_split_over_waves"] == 2
 
 
+@pytest.mark.parametrize("seed", [0, 42])
+def test_kmer_prefilter_gives_the_oracles_rows(gpu, seed):
+    """k = 16 references carry a Bloom table over the canonical 16-mers whose hash can meet them; the production sketcher
+    hashes only the windows that pass it -- for reads with at most s windows (no truncation possible); longer reads take
+    the plain loop.  Rows, per-read counts and table against the oracle with the table on (default) and off, around the
+    s + 15 base boundary, with reads that are both split over waves and prefiltered (8193 .. s + 15 bases), N / lower case /
+    whitespace / U, and a dense reference where most windows survive the table (the survivor queue drains mid-chunk)."""
+    from sketchy_amd import api
+    ref, _, _ = workload(60, 9000, 1, read_len=300, seed=seed, genome_len=300000, rng_seed=7000 + seed)
+    g = ref["genome"].tobytes()
+    rng = np.random.default_rng(12)
+    reads = [g[a:a + n] for a, n in ((int(rng.integers(0, 280000)), int(n)) for n in
+                                     [15, 16, 17, 64, 300, 1500, 1500, 2047, 2048, 2049, 2063, 2064, 4000, 8192, 8193, 9000, 9014, 9015, 9016, 12000])]
+    reads += [g[1000:2500].lower(), g[3000:3700] + b"N" + g[3701:4500], _wrap(g[5000:13000]), g[20000:21500].replace(b"T", b"U"),
+              b"ACGT" * 500, b"", g[50000:50040] + b"\n\n" + g[50040:50300]]
+    bases, offsets = pack_reads(reads)
+    exp = orc.stream(16, seed, 9000, ref["ref"], np.full(60, 9000, np.uint32), bases, offsets, top_k=2, want_shared=True)
+    assert exp["shared"].max() > 3
+    try:
+        for on in (1, 0):
+            api.set_option("kmer_prefilter", on)
+            R = api.ReferenceSketch(ref["ref"], seed=seed)
+            keys, nbytes = R.kmer_filter
+            assert (keys > 0 and nbytes >= 4096) if on else (keys == 0 and nbytes == 0)
+            S = api.SumOfSharedHashes(R, top=2, max_batch_reads=len(reads), max_batch_bases=len(bases))
+            got = S.push(bases, offsets, want_shared=True)
+            np.testing.assert_array_equal(got["shared"], exp["shared"], err_msg=f"prefilter {on}")
+            np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"], err_msg=f"prefilter {on}")
+            np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"], err_msg=f"prefilter {on}")
+            np.testing.assert_array_equal(S.table(), exp["cum"])
+            S.reset()
+            full = S.push(bases, offsets, want_shared=True, want_sketches=True)   # debug path: plain loop, full sketches
+            np.testing.assert_array_equal(full["shared"], exp["shared"])
+            S.close(); R.close()
+    finally:
+        api.set_option("kmer_prefilter", 1)
+    # dense: s = 20 000 of a 30 kb genome -- two thirds of all windows are reference k-mers
+    ref, bases, offsets = workload(12, 20000, 60, read_len=1500, seed=seed, genome_len=30000, rng_seed=7100 + seed)
+    got, exp, R, S = check(ref, bases, offsets, top=1, seed=seed, want_sketches=False)
+    assert R.kmer_filter[0] > 10000 and exp["shared"].max() > 256
+
+
 def test_long_reads_other_k(gpu):
     for k, seed in ((21, 3), (11, 0)):
         ref, _, _ = workload(20, 200, 1, read_len=300, k=k, seed=seed, genome_len=100000, rng_seed=150 + k)
