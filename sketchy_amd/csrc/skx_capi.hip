@@ -306,7 +306,9 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipGetLastError());
     }
     RCHK(hipDeviceSynchronize());
-    if (k == 16 && any && g_kmer_prefilter) {
+    static const bool pf_knob = !skx::knob("SKX_KMER_PREFILTER") || atoi(skx::knob("SKX_KMER_PREFILTER")) != 0;  // experiment knob
+    static const u32 kf_bits = skx::knob("SKX_KF_BITS") ? (u32)std::max(1, atoi(skx::knob("SKX_KF_BITS"))) : 16u;  // table bits per key
+    if (k == 16 && any && g_kmer_prefilter && pf_knob) {
         // every canonical 16-mer whose hash passes the filter above (two passes over the 2^32 codes: count, then insert);
         // 16 table bits per key, two probes: ~1.4 % false positives, each costing one murmur3 evaluation per occurrence
         u32* d_n = nullptr;
@@ -317,7 +319,7 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipMemcpy(&r->kf_keys, d_n, 4, hipMemcpyDeviceToHost));
         (void)hipFree(d_n);
         u32 lg_words = 10;  // 4 KB at least
-        while (lg_words < 27 && (32ull << lg_words) < 16ull * r->kf_keys) ++lg_words;
+        while (lg_words < 27 && (32ull << lg_words) < (u64)kf_bits * r->kf_keys) ++lg_words;
         r->kf_shift = 32u - lg_words;
         RCHK(hipMalloc(&r->d_kf, (size_t)4 << lg_words));
         RCHK(hipMemset(r->d_kf, 0, (size_t)4 << lg_words));

@@ -1902,7 +1902,6 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     if (grp >= n_grp || !grp_any[grp]) return;  // (a group without any bit: nobody reads its increments; the whole block leaves)
     const bool on = seg < n_seg;
     const u32 sub = lane >> 3, j = lane & 7u;
-    const u64* mq_gj = mq + (size_t)grp * nq_rows * kRankWords + j;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
     const u32 pa = on ? poff[r_begin + ra] - p_base : 0u, pz = on ? poff[r_begin + rz] - p_base : 0u;
     u32 acc[8];
@@ -1914,23 +1913,26 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
         u64 ones = 0, twos = 0, fours = 0, eights = 0, sixteens = 0, thirtytwos = 0;
         // the query indices of the next 64 pairs are requested before the current rows are counted (one memory round trip
         // per step instead of two in a row; requesting the rows ahead as well needs 82 VGPRs and lost: 417 -> 725 us)
-        auto load_q = [&](u32 p0, u32 (&qv)[8]) {
+        // Addressing kept off the VALU: the group's slice of Mq and the pair list are wave-uniform bases (scalar registers), a
+        // lane's row word is at byte offset (q << 6 | j * 8) and its slot of the pair list at 4 * (p0 + sub) + 32 u -- both fit
+        // 32 bits (a pass holds at most 2^22 pairs / rows), so a load costs one VALU instruction instead of five.  Full steps
+        // of 64 pairs take no bounds tests at all; only the block's last, partial step masks the rows past its end (re-read
+        // from the block's last pair: always a valid address).  (Conditional loads had become sixteen exec-mask branches per
+        // step: 160 VALU instructions per step, 80 of them the counting itself.)
+        const char* const mq_base = reinterpret_cast<const char*>(mq + (size_t)grp * nq_rows * kRankWords);
+        const char* const pq_base = reinterpret_cast<const char*>(pair_q);
+        const u32 j8 = j * 8u;
+        auto row_at = [&](u32 q) -> u64 { return *reinterpret_cast<const u64*>(mq_base + (size_t)((q << 6) | j8)); };
+        auto load_q = [&](u32 p0, u32 (&qv)[8]) {  // (a full step's worth of pairs exists from p0 on)
+            const char* at = pq_base + (size_t)((p0 + sub) * 4u);
 #pragma unroll
-            for (u32 u = 0; u < 8u; ++u) {
-                const u32 p = p0 + 8u * u + sub;
-                qv[u] = p < bz ? pair_q[p] : 0xFFFFFFFFu;
-            }
+            for (u32 u = 0; u < 8u; ++u) qv[u] = *reinterpret_cast<const u32*>(at + 32u * u);
         };
-        auto gather = [&](const u32 (&qv)[8], u64 (&xv)[8]) {
+        auto load_q_tail = [&](u32 p0, u32 (&qv)[8]) {
 #pragma unroll
-            for (u32 u = 0; u < 8u; ++u) xv[u] = qv[u] != 0xFFFFFFFFu ? mq_gj[(size_t)qv[u] * kRankWords] : 0ull;
+            for (u32 u = 0; u < 8u; ++u) qv[u] = *reinterpret_cast<const u32*>(pq_base + (size_t)(min(p0 + 8u * u + sub, bz - 1u) * 4u));
         };
-        u32 qn[8];
-        load_q(b0, qn);
-        for (u32 p0 = b0; p0 < bz; p0 += 64u) {
-            u64 x[8];
-            gather(qn, x);
-            load_q(p0 + 64u, qn);
+        auto count8 = [&](const u64 (&x)[8]) {
             u64 twos_a, twos_b, fours_a, fours_b, eights_a;
             SKX_CSA(twos_a, ones, ones, x[0], x[1])
             SKX_CSA(twos_b, ones, ones, x[2], x[3])
@@ -1944,6 +1946,25 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
             const u64 c16 = sixteens & c8;
             sixteens ^= c8;
             thirtytwos ^= c16;  // (<= 56 rows: no carry out of the sixth plane)
+        };
+        u32 qn[8];
+        u32 p0 = b0;
+        if (p0 + 64u <= bz) load_q(p0, qn); else load_q_tail(p0, qn);
+        for (; p0 + 64u <= bz; p0 += 64u) {  // full steps
+            u64 x[8];
+#pragma unroll
+            for (u32 u = 0; u < 8u; ++u) x[u] = row_at(qn[u]);
+            if (p0 + 128u <= bz) load_q(p0 + 64u, qn); else if (p0 + 64u < bz) load_q_tail(p0 + 64u, qn);
+            count8(x);
+        }
+        if (p0 < bz) {  // the last, partial step
+            u64 x[8];
+#pragma unroll
+            for (u32 u = 0; u < 8u; ++u) {
+                const u64 row = row_at(qn[u]);
+                x[u] = p0 + 8u * u + sub < bz ? row : 0ull;
+            }
+            count8(x);
         }
         // ---- merge the 8 sub-slots of every word (reduce-scatter over lane bits 5, 4, 3), planes get narrower
         const u64 pl[6] = {ones, twos, fours, eights, sixteens, thirtytwos};

@@ -677,7 +677,7 @@ def test_read_sketch_size_is_the_first_sketchs_length(gpu, first_len):
     column holds -- a dense reference, so hundreds of a read's hashes are in range and the truncation really bites) or
     shorter (first_len = 300 = the stride: most columns are shorter than the read sketch).  skx_ref_create takes s and the
     column stride separately; rows, per-read counts, sketches and table against the oracle, debug and production paths."""
-    ref, bases, offsets = workload(90, 300, 120, read_len=900, genome_len=25000, rng_seed=4100 + first_len)
+    ref, bases, offsets = workload(90, 300, 120, read_len=900, genome_len=3000, rng_seed=4100 + first_len)
     hashes = ref["ref"]
     rng = np.random.default_rng(first_len)
     col_len = rng.integers(100, 301, size=len(hashes)).astype(np.uint32)
