@@ -307,7 +307,11 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
     }
     RCHK(hipDeviceSynchronize());
     static const bool pf_knob = !skx::knob("SKX_KMER_PREFILTER") || atoi(skx::knob("SKX_KMER_PREFILTER")) != 0;  // experiment knob
-    static const u32 kf_bits = skx::knob("SKX_KF_BITS") ? (u32)std::max(1, atoi(skx::knob("SKX_KF_BITS"))) : 16u;  // table bits per key
+    // table bits per key.  Measured at C2 (6 M keys): 16 bits (16 MB table, 0.7 % false positives) loses 8 % against no prefilter at
+    // all -- 147 M random 4-byte gathers per batch into a table far beyond the 4 MB of L2 an XCD has become fabric traffic
+    // three times the reference scan's; 4 bits (4 MB, ~15 % false positives = ~4 murmur3 batches per read instead of 24) keeps
+    // the gathers in L2: +2.5 % in the pipeline, +10 % for a lone batch.
+    static const u32 kf_bits = skx::knob("SKX_KF_BITS") ? (u32)std::max(1, atoi(skx::knob("SKX_KF_BITS"))) : 4u;
     if (k == 16 && any && g_kmer_prefilter && pf_knob) {
         // every canonical 16-mer whose hash passes the filter above (two passes over the 2^32 codes: count, then insert);
         // 16 table bits per key, two probes: ~1.4 % false positives, each costing one murmur3 evaluation per occurrence
@@ -411,6 +415,12 @@ struct skx_stream {
     // Everything handed from one stage to the next (Q, windows, pair lists, Mq, the pass's slice of the pair
     // offsets) is double-buffered; events order the hand-offs and the reuse of a buffer set two passes later.
     hipStream_t hs0 = nullptr, hs = nullptr, hs2 = nullptr;  // hs0 / hs2 alias hs at lower pipeline depths
+    // hs1: what follows a batch's MAIN sketch kernel and nothing else depends on until the passes are queued -- long-read
+    // merge, 2048-slot retry, pair counts / offsets, speculative pair gather, published summary.  On their own stream (behind
+    // ev_main) so that the sketch stream runs main kernel after main kernel: those ~8 short, latency-bound kernels cost the
+    // sketch stream 150-250 us per batch next to the other streams' work (kernel trace), a fifth of the step.
+    hipStream_t hs1 = nullptr;  // aliases hs0 below pipeline depth 3
+    hipEvent_t ev_main[2] = {nullptr, nullptr};  // sketch stream: everything of the batch queued on hs0 is done (per side)
     int depth = 2;
     int buf = 0;
     hipEvent_t ev_dict[2] = {nullptr, nullptr}, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
@@ -447,6 +457,8 @@ struct skx_stream {
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
     u64* sd_sk[2] = {nullptr, nullptr};
     u32 *sd_len[2] = {nullptr, nullptr}, *sd_cnt[2] = {nullptr, nullptr}, *sd_poff[2] = {nullptr, nullptr}, *sd_big[2] = {nullptr, nullptr};
+    u32 *sd_chk[2] = {nullptr, nullptr}, *sd_retry[2] = {nullptr, nullptr};  // (per side: batch i's summary is published while batch i + 1 is sketched)
+    skx::LongReads sd_lr[2] = {{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u}, {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u}};
     // pass workspace (per buffer set: pair hashes, hash set and its counters, Q, windows, pair lists, Mq)
     u64 *d_pair_h[2] = {nullptr, nullptr}, *d_q[2] = {nullptr, nullptr};
     u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
@@ -532,6 +544,7 @@ static void stream_free(skx_stream* st) {
     if (!st) return;
     (void)hipSetDevice(st->device);
     if (st->hs0) (void)hipStreamSynchronize(st->hs0);
+    if (st->hs1) (void)hipStreamSynchronize(st->hs1);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     if (st->hs2) (void)hipStreamSynchronize(st->hs2);
     void* ptrs[] = {st->d_bases, st->d_offsets, st->sd_sk[0], st->sd_len[0], st->sd_cnt[0], st->sd_poff[0], st->sd_big[0],
@@ -546,8 +559,13 @@ static void stream_free(skx_stream* st) {
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
     if (st->h_chk_base) (void)hipHostFree(st->h_chk_base);
-    (void)hipFree(st->d_chk); (void)hipFree(st->d_retry);
-    (void)hipFree(st->lr.list); (void)hipFree(st->lr.seg0); (void)hipFree(st->lr.seg_tab); (void)hipFree(st->lr.seg_cnt); (void)hipFree(st->lr.seg_h);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(st->sd_chk[i]); (void)hipFree(st->sd_retry[i]);
+        (void)hipFree(st->sd_lr[i].list); (void)hipFree(st->sd_lr[i].seg0); (void)hipFree(st->sd_lr[i].seg_tab);
+        (void)hipFree(st->sd_lr[i].seg_cnt); (void)hipFree(st->sd_lr[i].seg_h);
+        if (st->ev_main[i]) (void)hipEventDestroy(st->ev_main[i]);
+    }
+    if (st->hs1 && st->hs1 != st->hs0) (void)hipStreamDestroy(st->hs1);
     (void)hipFree(st->d_ht[0]); (void)hipFree(st->d_ht[1]); (void)hipFree(st->d_dict_ctr[0]); (void)hipFree(st->d_dict_ctr[1]);
     (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
     (void)hipFree(st->d_btot);
@@ -586,6 +604,20 @@ static hipError_t alloc_side(skx_stream* st, int i) {
     if ((e = hipMalloc(&st->sd_cnt[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_poff[i], ((size_t)st->max_reads + 2) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_big[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&st->sd_retry[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
+    if ((e = hipMalloc(&st->sd_chk[i], 64)) != hipSuccess) return e;
+    if ((e = hipMemset(st->sd_chk[i], 0, 64)) != hipSuccess) return e;
+    if ((e = hipMemset(st->sd_retry[i], 0, 4)) != hipSuccess) return e;
+    if (st->max_bases > skx::long_read_split()) {  // (a batch that can hold a long read at all)
+        skx::LongReads& lr = st->sd_lr[i];
+        lr.long_cap = (u32)std::min<u64>(st->max_reads, st->max_bases / skx::long_read_split() + 1);
+        lr.segs_cap = (u32)std::min<u64>(0x7FFFFFFFu, 5 * (st->max_bases / (4ull * skx::kSketchCap)) + 2);
+        if ((e = hipMalloc(&lr.list, (size_t)lr.long_cap * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&lr.seg0, (size_t)lr.long_cap * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&lr.seg_tab, (size_t)lr.segs_cap * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&lr.seg_cnt, (size_t)lr.segs_cap * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&lr.seg_h, (size_t)lr.segs_cap * skx::long_read_seg_slots() * 8)) != hipSuccess) return e;
+    }
     return hipMemset(st->sd_big[i], 0, 4);  // (null stream; callers on the pipeline streams synchronise the device once)
 }
 static hipError_t use_side(skx_stream* st, int i) {
@@ -596,7 +628,8 @@ static hipError_t use_side(skx_stream* st, int i) {
     }
     st->side = i;
     st->d_sk = st->sd_sk[i]; st->d_len = st->sd_len[i]; st->d_cnt = st->sd_cnt[i]; st->d_poff = st->sd_poff[i];
-    st->d_big = st->sd_big[i];
+    st->d_big = st->sd_big[i]; st->d_retry = st->sd_retry[i]; st->d_chk = st->sd_chk[i];
+    st->lr = st->sd_lr[i];
     st->h_chk = st->h_chk_base + 16 * i;
     return hipSuccess;
 }
@@ -689,7 +722,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipEventCreateWithFlags(&st->ev_back[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_sketch[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_skread[i], hipEventDisableTiming));
+        SCHK(hipEventCreateWithFlags(&st->ev_main[i], hipEventDisableTiming));
     }
+    if (st->depth >= 3) SCHK(hipStreamCreateWithPriority(&st->hs1, hipStreamNonBlocking, prio_lo)); else st->hs1 = st->hs0;
     SCHK(hipMalloc(&st->d_bases, std::max<u64>(max_bases, 1)));
     SCHK(hipMalloc(&st->d_offsets, ((size_t)max_reads + 1) * 8));
     SCHK(alloc_side(st, 0));
@@ -761,19 +796,6 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_bbase, (size_t)skx::dict_buckets() * 4));
     SCHK(hipHostMalloc((void**)&st->h_chk_base, 2 * 16 * 4, hipHostMallocCoherent));  // kernels write it, the host polls it
     memset(st->h_chk_base, 0, 2 * 16 * 4);
-    SCHK(hipMalloc(&st->d_chk, 64));
-    SCHK(hipMemset(st->d_chk, 0, 64));
-    SCHK(hipMalloc(&st->d_retry, ((size_t)max_reads + 1) * 4));
-    SCHK(hipMemset(st->d_retry, 0, 4));
-    if (max_bases > skx::long_read_split()) {  // (a batch that can hold a long read at all)
-        st->lr.long_cap = (u32)std::min<u64>(max_reads, max_bases / skx::long_read_split() + 1);
-        st->lr.segs_cap = (u32)std::min<u64>(0x7FFFFFFFu, 5 * (max_bases / (4ull * skx::kSketchCap)) + 2);
-        SCHK(hipMalloc(&st->lr.list, (size_t)st->lr.long_cap * 4));
-        SCHK(hipMalloc(&st->lr.seg0, (size_t)st->lr.long_cap * 4));
-        SCHK(hipMalloc(&st->lr.seg_tab, (size_t)st->lr.segs_cap * 4));
-        SCHK(hipMalloc(&st->lr.seg_cnt, (size_t)st->lr.segs_cap * 4));
-        SCHK(hipMalloc(&st->lr.seg_h, (size_t)st->lr.segs_cap * skx::long_read_seg_slots() * 8));
-    }
     SCHK(use_side(st, 0));
     SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocCoherent));
     st->h_nq[0] = st->h_nq[1] = 0;
@@ -838,6 +860,7 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
     SKXCHK(use_device(st->device));
     SKXCHK(flush_pending(st));
     HIPCHK(hipStreamSynchronize(st->hs0));
+    HIPCHK(hipStreamSynchronize(st->hs1));
     HIPCHK(hipStreamSynchronize(st->hs));
     HIPCHK(hipStreamSynchronize(st->hs2));
     collect_spans(st);
@@ -1057,7 +1080,7 @@ static int for_each_pass(skx_stream* st, u32 n_reads, u32 max_pass_reads, F fn) 
 // spin on the published sequence number (looking at the stream now and then so a fault cannot hang the caller)
 static int wait_published(skx_stream* st, const PendingBatch& pb) {
     volatile u32* pub = st->h_chk_base + 16 * pb.side;
-    hipStream_t hs = st->hs0;
+    hipStream_t hs = st->hs1;  // (the publish kernel's stream)
     for (u64 spins = 1; pub[15] != pb.seq; ++spins) {
         if ((spins & 0xFFF) == 0) {
             const hipError_t e = hipStreamQuery(hs);
@@ -1079,11 +1102,19 @@ static const u32* batch_filter(const skx_ref* ref) {
 // counts -> (filter, for rows the sketchers did not filter themselves) -> pair offsets (poff[n_reads] = total pairs)
 // -> speculative pair gather -> the few words the host needs, published to page-locked memory
 // (the stream's d_sk ... names must be on the batch's side)
+// everything of the batch queued on the sketch stream so far comes before what is queued on hs1 from here on
+static int behind_the_sketch(skx_stream* st, int side) {
+    if (st->hs1 == st->hs0) return SKX_OK;
+    HIPCHK(hipEventRecord(st->ev_main[side], st->hs0));
+    HIPCHK(hipStreamWaitEvent(st->hs1, st->ev_main[side], 0));
+    return SKX_OK;
+}
 static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
     const skx_ref* ref = st->ref;
-    hipStream_t hs = st->hs0;
+    hipStream_t hs = st->hs1;
     const u32 n_reads = pb.n_reads;
     const u32* filt = batch_filter(ref);
+    SKXCHK(behind_the_sketch(st, pb.side));
     if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
     if (filt && !pb.inrange_only)
         skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
@@ -1153,9 +1184,15 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
             for (int i = 0; i < 2; ++i)
                 if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
         (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-        HIPCHK(skx::launch_sketch(hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s_read, max_ref, pb.inrange_only,
-                                  st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry, st->d_big,
-                                  pb.n_bases, st->d_chk, leave_room, st->packed, lr, ref->d_kf ? &kf : nullptr));
+        // production: the main kernel on the sketch stream, the list walks behind it (long-read merge, 2048-slot retry) on hs1
+        // with the rest of the batch's front half -- the next batch's main kernel then follows this one directly
+        for (int phase = 1; phase <= (pb.inrange_only ? 2 : 1); ++phase) {
+            if (phase == 2) SKXCHK(behind_the_sketch(st, pb.side));
+            HIPCHK(skx::launch_sketch(phase == 2 ? st->hs1 : hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s_read, max_ref,
+                                      pb.inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry,
+                                      st->d_big, pb.n_bases, st->d_chk, leave_room, st->packed, lr, ref->d_kf ? &kf : nullptr,
+                                      pb.inrange_only ? phase : 3));
+        }
         if (!pb.inrange_only) {
             // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
             // not the fast one -- read the count back and run the block sketcher before the rows are copied out
@@ -1185,9 +1222,10 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
 // buffer sets no longer alternate the way the gather assumed (rare)
 static int cancel_speculation(skx_stream* st, PendingBatch& y) {
     if (!y.spec_insert) return SKX_OK;
-    HIPCHK(hipMemsetAsync(st->d_ht[y.spec_set], 0xFF, (size_t)st->ht_slots * 8, st->hs0));
-    HIPCHK(hipMemsetAsync(st->d_dict_ctr[y.spec_set], 0, 64, st->hs0));
-    HIPCHK(hipStreamSynchronize(st->hs0));
+    // (on the stream the gather was queued on: behind it)
+    HIPCHK(hipMemsetAsync(st->d_ht[y.spec_set], 0xFF, (size_t)st->ht_slots * 8, st->hs1));
+    HIPCHK(hipMemsetAsync(st->d_dict_ctr[y.spec_set], 0, 64, st->hs1));
+    HIPCHK(hipStreamSynchronize(st->hs1));
     y.spec_insert = false;
     return SKX_OK;
 }
@@ -1270,8 +1308,8 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     if (single) {
         pass_rc = one_pass(0, n_reads, 0, total_pairs);  // the whole batch is one pass: no per-read offsets needed
     } else {
-        HIPCHK(hipMemcpyAsync(st->h_poff, st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, hs));
-        HIPCHK(hipStreamSynchronize(hs));
+        HIPCHK(hipMemcpyAsync(st->h_poff, st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, st->hs1));  // (the offsets' stream)
+        HIPCHK(hipStreamSynchronize(st->hs1));
         pass_rc = for_each_pass(st, n_reads, pb.dbg_cap, one_pass);
     }
     if (d_shared) (void)hipFree(d_shared);
@@ -1319,6 +1357,7 @@ static int enqueue_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
             const std::string msg = g_err;
             (void)cancel_speculation(st, nw);
             (void)hipStreamSynchronize(st->hs0);
+            (void)hipStreamSynchronize(st->hs1);
             g_err = msg + " (batch enqueued one call earlier; the batch of this call was dropped too)";
             return rc;
         }
@@ -1516,6 +1555,7 @@ SKX_API int skx_stream_sync(skx_stream* st) {
     SKXCHK(use_device(st->device));
     SKXCHK(flush_pending(st));
     HIPCHK(hipStreamSynchronize(st->hs0));
+    HIPCHK(hipStreamSynchronize(st->hs1));
     HIPCHK(hipStreamSynchronize(st->hs));
     HIPCHK(hipStreamSynchronize(st->hs2));
     if (st->profiling) collect_spans(st);
@@ -1550,6 +1590,7 @@ SKX_API int skx_stream_reset(skx_stream* st) {
     SKXCHK(use_device(st->device));
     SKXCHK(flush_pending(st));
     HIPCHK(hipStreamSynchronize(st->hs0));
+    HIPCHK(hipStreamSynchronize(st->hs1));
     HIPCHK(hipStreamSynchronize(st->hs));
     HIPCHK(hipMemsetAsync(st->d_cum, 0, (size_t)st->ref->n_pad * 8, st->hs2));
     HIPCHK(hipStreamSynchronize(st->hs2));

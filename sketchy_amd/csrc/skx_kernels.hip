@@ -2847,7 +2847,7 @@ static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketch
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
                          const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed,
-                         const LongReads* long_reads, const KmerFilter* kmer_filter) {
+                         const LongReads* long_reads, const KmerFilter* kmer_filter, int phase) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
     // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 19 KB: 4 instead of 8 of its blocks fit a CU, and when one
@@ -2919,16 +2919,22 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
         // (with the long-read tables: segment workgroups in front, long reads skipped by the read waves and finished by
         // sketch_merge_kernel -- one-wave workgroups with a 16 KB buffer each, walking the list; without long reads they
         // return at once)
+        // phase bit 0: the main kernel; bit 1: the two list walks behind it (long-read merge, 2048-slot retry) -- the caller
+        // may put them on another stream (behind an event), so the next batch's main kernel follows this one back to back
         const u32 first = (chk && lr.list) ? 2u : 0u;
-        if (k == 16) {
-            if (capped) SKX_SK_LAUNCH(sketch_wave_kernel_capped<16>, lds_small, first); else SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, first);
-        } else {
-            if (capped) SKX_SK_LAUNCH(sketch_wave_kernel_capped<0>, lds_small, first); else SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, first);
+        if (phase & 1) {
+            if (k == 16) {
+                if (capped) SKX_SK_LAUNCH(sketch_wave_kernel_capped<16>, lds_small, first); else SKX_SK_LAUNCH(SKX_SK_SMALL(16), lds_small, first);
+            } else {
+                if (capped) SKX_SK_LAUNCH(sketch_wave_kernel_capped<0>, lds_small, first); else SKX_SK_LAUNCH(SKX_SK_SMALL(0), lds_small, first);
+            }
         }
-        if (first == 2u)
-            hipLaunchKernelGGL(sketch_merge_kernel, dim3(512), dim3(64), (size_t)kSketchCap * 8, st, offsets, s, max_ref, out_sk, sk_stride,
-                               out_len, out_cnt_in, big, filt, filt_shift, chk, lr);
-        if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); else SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u);
+        if (phase & 2) {
+            if (first == 2u)
+                hipLaunchKernelGGL(sketch_merge_kernel, dim3(512), dim3(64), (size_t)kSketchCap * 8, st, offsets, s, max_ref, out_sk, sk_stride,
+                                   out_len, out_cnt_in, big, filt, filt_shift, chk, lr);
+            if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); else SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u);
+        }
     } else {
         if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, false), lds, 0u); else SKX_SK_LAUNCH(SKX_SK(0, false), lds, 0u);
     }

@@ -73,7 +73,8 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
                          const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
                          u32* retry /* [1 + n_reads] */, u32* big /* [1 + n_reads] */, u64 n_bases, u32* chk,
                          int leave_room /* 0 no, 1 a scan overlaps the start, 2 a scan runs beside most of it */, bool packed = false,
-                         const LongReads* long_reads = nullptr, const KmerFilter* kmer_filter = nullptr /* production, k = 16 */);
+                         const LongReads* long_reads = nullptr, const KmerFilter* kmer_filter = nullptr /* production, k = 16 */,
+                         int phase = 3 /* production batches: 1 = the main kernel only, 2 = only the list walks behind it, 3 = both */);
 // the block sketcher for the n_big reads launch_sketch left on `big` (big[1 ..]); the caller reads the count back first
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
