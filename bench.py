@@ -41,6 +41,7 @@ CONFIGS = {
     "c0": ([500], 1000, 1500, 0.0, "C0: 1.5 kb reads vs 500-genome s=1000 k=16 sketch (plumbing)"),
     "c1": ([5000], 1000, 1500, 0.0, "C1: 1.5 kb reads vs 5k-genome s=1000 k=16 sketch (cache-resident)"),
     "c2": ([40000], 10000, 1500, 0.0, "C2: ~100k x 1.5 kb reads per step vs 40000-genome s=10000 k=16 sketch (HBM-bound scan)"),
+    "c6g": ([40000, 35000], 10000, 1500, 0.0, "experiment: two species resident (75000 genomes, 6 GB), 1.5 kb reads (scan size sweep)"),
     "c4": ([40000, 40000, 30000, 25000, 15000], 10000, 1500, 1.0,
            "C4: 5 species' sketches resident (150000 genomes, s=10000 k=16), log-normal read lengths 200..50000 (median 1.5 kb), "
            "every read scored against all 5"),

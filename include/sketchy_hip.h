@@ -71,6 +71,9 @@ int skx_device_info(int device, char *name, size_t name_cap, int *compute_units,
  *                     production sketcher then hashes only the windows of a read that pass it (reads with at most s
  *                     windows -- longer ones can be truncated and take the plain loop).  Rows, tables and debug outputs
  *                     are identical either way.
+ *   "filter_bits_per_hash"  table bits of the membership filter per DISTINCT reference hash, 4..4096 (default 32: ~0.03 % of
+ *                     the read hashes no genome holds get through and cost an all-zero row each; 32 MB at 40 000 S. aureus-like
+ *                     genomes x 10 000 hashes, which share all but ~6e6 of their 4e8 hashes).
  * Unknown names fail with SKX_ERR_INVALID.
  */
 int skx_set_option(const char *name, uint64_t value);

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -120,15 +121,22 @@ SKX_API int skx_dev_synchronize(int device) {
 
 // ------------------------------------------------------------------ policies (skx_set_option)
 static bool g_kmer_prefilter = true;  // build / use the k-mer prefilter for k = 16 references
+static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
     if (!name) return fail(SKX_ERR_INVALID, "NULL option name");
     if (!strcmp(name, "kmer_prefilter")) { g_kmer_prefilter = value != 0; return SKX_OK; }
+    if (!strcmp(name, "filter_bits_per_hash")) {
+        if (value < 4 || value > 4096) return fail(SKX_ERR_INVALID, "filter_bits_per_hash must be 4..4096");
+        g_filter_bits_per_hash = (u32)value;
+        return SKX_OK;
+    }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 SKX_API int skx_get_option(const char* name, uint64_t* value) {
     if (!name || !value) return fail(SKX_ERR_INVALID, "NULL argument");
     if (!strcmp(name, "kmer_prefilter")) { *value = g_kmer_prefilter ? 1 : 0; return SKX_OK; }
+    if (!strcmp(name, "filter_bits_per_hash")) { *value = g_filter_bits_per_hash; return SKX_OK; }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -152,9 +160,9 @@ struct skx_ref {
     u32* d_exc_g = nullptr;
     u64* d_exc_h = nullptr;
     // membership filter over the union of all reference hashes: bit (h >> filt_shift) of d_filt
-    u32* d_filt = nullptr;
+    u64* d_filt = nullptr;  // 64-bit words; word h >> filt_shift
     u32 filt_shift = 0;
-    u64 filt_bits = 0;
+    u64 filt_bits = 0, n_distinct = 0;  // table bits; distinct reference hashes (linear-counting estimate)
     // k-mer prefilter (k = 16): Bloom table over the canonical 16-mers whose hash passes the membership filter
     u32* d_kf = nullptr;
     u32 kf_shift = 0, kf_keys = 0;
@@ -241,7 +249,15 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
     u64* d_stage = nullptr;
 #define RCHK(expr) do { e = (expr); if (e != hipSuccess) { (void)hipFree(d_eff); (void)hipFree(d_stage); ref_free(r); return fail(SKX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e)); } } while (0)
     const size_t mat_elems = (size_t)r->n_tiles * s * skx::kTileGenomes;
-    RCHK(hipMalloc(&r->d_mat, mat_elems * 8));
+    {
+        // experiment knob SKX_MAT_ALLOC=1: physically contiguous memory for the matrix (hipDeviceMallocContiguous: large page-table
+        // fragments -- the TLB-reach test of the 12 GB scan)
+        static const int mat_alloc = skx::knob("SKX_MAT_ALLOC") ? atoi(skx::knob("SKX_MAT_ALLOC")) : 0;
+        if (mat_alloc == 1) {
+            if (hipExtMallocWithFlags((void**)&r->d_mat, mat_elems * 8, hipDeviceMallocContiguous) != hipSuccess) { (void)hipGetLastError(); r->d_mat = nullptr; }
+        }
+        if (!r->d_mat) RCHK(hipMalloc(&r->d_mat, mat_elems * 8));
+    }
     RCHK(hipMemset(r->d_mat, 0xFF, mat_elems * 8));  // kPad everywhere: short columns, padding genomes
     RCHK(hipMalloc(&r->d_lo, (size_t)r->n_bands * r->n_tiles * 8));
     RCHK(hipMalloc(&r->d_hi, (size_t)r->n_bands * r->n_tiles * 8));
@@ -289,15 +305,43 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipMemcpy(r->d_exc_h, exc_h.data(), (size_t)r->n_exc * 8, hipMemcpyHostToDevice));
     }
     {
-        // bitmap size: 64 bits per reference hash (1.6 % false positives -- each one is an all-zero row of the bit matrices
-        // and an entry of every slice it falls into), between 2^16 and 2^36 bits (8 GB; env SKX_FILTER_LG caps it lower:
-        // at 2^33 bits C2 has 21 bits per hash and half of its dictionary is false positives); shift so that max_ref fits
-        static const u32 lg_cap = skx::knob("SKX_FILTER_LG") ? (u32)std::min(36, std::max(16, atoi(skx::knob("SKX_FILTER_LG")))) : 36u;
-        const u64 want = 64ull * s * total;
+        // Membership filter (skx_common.hpp: a blocked Bloom filter, four bits per key inside one 64-bit word).  Sized from the
+        // number of DISTINCT reference hashes -- the genomes of a collection share most of theirs: C2 holds 4e8 hashes, ~6e6
+        // distinct -- which a linear-counting pass over the matrix gives first (a transient bitmap of 2^32 bits at most;
+        // n = -B ln(1 - fill) corrects for the collisions).  Policy "filter_bits_per_hash" (default 32 per distinct hash:
+        // ~0.03 % false positives, each one an all-zero row of the bit matrices and an entry of every slice it falls into;
+        // rounds 1-2 spent 64 bits per NON-distinct hash on a direct-mapped bitmap: 4 GB at C2 where this takes 32 MB).
+        const u32 max_bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
+        u64 distinct = 0;
+        {
+            u32 lg = 16;
+            while (lg < 32 && (1ull << lg) < 8ull * s * total) ++lg;
+            const u32 shift = max_bits > lg ? max_bits - lg : 0u;
+            u64* d_tmp = nullptr;
+            unsigned long long* d_cnt = nullptr;
+            RCHK(hipMalloc(&d_tmp, (1ull << lg) / 8));
+            e = hipMalloc(&d_cnt, 8);
+            if (e == hipSuccess) e = hipMemset(d_tmp, 0, (1ull << lg) / 8);
+            if (e == hipSuccess) e = hipMemset(d_cnt, 0, 8);
+            if (e == hipSuccess) {
+                skx::launch_filter_build(nullptr, r->d_mat, mat_elems, shift, d_tmp, false, d_cnt);
+                skx::launch_filter_build(nullptr, r->d_exc_h, r->n_exc, shift, d_tmp, true, d_cnt);
+                e = hipGetLastError();
+            }
+            unsigned long long set_bits = 0;
+            if (e == hipSuccess) e = hipMemcpy(&set_bits, d_cnt, 8, hipMemcpyDeviceToHost);
+            (void)hipFree(d_tmp); (void)hipFree(d_cnt);
+            RCHK(e);
+            const double B = (double)(1ull << lg), fill = std::min(0.999999, (double)set_bits / B);
+            distinct = (u64)(-B * std::log1p(-fill)) + 1;
+        }
+        r->n_distinct = distinct;
+        static const u32 lg_cap = skx::knob("SKX_FILTER_LG") ? (u32)std::min(36, std::max(16, atoi(skx::knob("SKX_FILTER_LG")))) : 36u;  // experiment knob
+        const u64 want = (u64)g_filter_bits_per_hash * distinct;
         u32 lg = 16;
         while (lg < lg_cap && (1ull << lg) < want) ++lg;
-        const u32 max_bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
-        r->filt_shift = max_bits > lg ? max_bits - lg : 0u;
+        const u32 lg_words = lg - 6;  // 64-bit words
+        r->filt_shift = max_bits > lg_words ? max_bits - lg_words : 0u;
         r->filt_bits = 1ull << lg;
         RCHK(hipMalloc(&r->d_filt, r->filt_bits / 8));
         RCHK(hipMemset(r->d_filt, 0, r->filt_bits / 8));
@@ -1095,7 +1139,7 @@ static int wait_published(skx_stream* st, const PendingBatch& pb) {
     }
     return SKX_OK;
 }
-static const u32* batch_filter(const skx_ref* ref) {
+static const u64* batch_filter(const skx_ref* ref) {
     static const bool no_filter = skx::knob("SKX_NO_FILTER") != nullptr;  // measurement aid
     return (ref->any && !no_filter) ? ref->d_filt : nullptr;
 }
@@ -1113,7 +1157,7 @@ static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
     const skx_ref* ref = st->ref;
     hipStream_t hs = st->hs1;
     const u32 n_reads = pb.n_reads;
-    const u32* filt = batch_filter(ref);
+    const u64* filt = batch_filter(ref);
     SKXCHK(behind_the_sketch(st, pb.side));
     if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
     if (filt && !pb.inrange_only)
@@ -1152,7 +1196,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     HIPCHK(use_side(st, pb.side));
     pb.inrange_only = !(pb.h_sketches || pb.h_sketch_len);  // production: only what can meet the reference is built
     const u64 max_ref = ref->any ? ref->max_ref : 0;
-    const u32* filt = batch_filter(ref);
+    const u64* filt = batch_filter(ref);
     // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
     pb.dbg_cap = pb.h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
     static const bool spec_env = !skx::knob("SKX_SPEC_INSERT") || atoi(skx::knob("SKX_SPEC_INSERT")) != 0;  // test knob
@@ -1236,7 +1280,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     hipStream_t hs = st->hs0;
     const u32 n_reads = pb.n_reads;
     const u64 max_ref = ref->any ? ref->max_ref : 0;
-    const u32* filt = batch_filter(ref);
+    const u64* filt = batch_filter(ref);
     pb.valid = false;
     HIPCHK(use_side(st, pb.side));
     SKXCHK(wait_published(st, pb));  // the one wait of a batch: 36 bytes, no copy, no stream synchronisation

@@ -136,6 +136,20 @@ __host__ __device__ __forceinline__ u64 murmur3_h1_16(u64 w0, u64 w1, u64 seed) 
     return h1 + h2;
 }
 
+// ---------------------------------------------------------------- membership filter
+// Blocked Bloom filter over the reference's DISTINCT hashes: 64-bit words, word = h >> shift (hashes are uniform up to the
+// largest reference hash, so position in that range needs no hash function), four bit positions inside the word from
+// the low 24 bits of h (independent of the word index whenever shift >= 24).  No false negatives; at 32 table bits per
+// distinct hash a word holds two keys on average: ~12 % of its bits set, false positives ~0.03 % -- where the direct-mapped
+// bitmap of rounds 1-2 needed 64 bits per NON-distinct hash (4 GB at C2 instead of 32 MB) for the same dictionary size.
+__host__ __device__ __forceinline__ u64 filter_mask(u64 h) {
+    return (1ull << (h & 63u)) | (1ull << ((h >> 6) & 63u)) | (1ull << ((h >> 12) & 63u)) | (1ull << ((h >> 18) & 63u));
+}
+__device__ __forceinline__ bool filter_hit(const u64* __restrict__ words, u32 shift, u64 h) {
+    const u64 m = filter_mask(h);
+    return (words[h >> shift] & m) == m;
+}
+
 // ---------------------------------------------------------------- bases
 // 0..3 = A,C,G,T ; 4 = any other retained byte (N, '-', IUPAC -> N) ; 5 = removed (whitespace)
 __host__ __device__ __forceinline__ u32 classify_base(u32 c) {

@@ -267,7 +267,7 @@ __device__ __forceinline__ u32 revcomp16(u32 x) {
 // One pass over all 2^32 codes; a code is canonical when it does not exceed its reverse complement (palindromes: equal,
 // the same bytes either way).  INSERT = false: count the k-mers whose hash passes; true: set their two bits.
 template <bool INSERT>
-__global__ __launch_bounds__(256) void kmer_filter_build_kernel(u64 seed, u64 max_ref, const u32* __restrict__ filt, u32 filt_shift,
+__global__ __launch_bounds__(256) void kmer_filter_build_kernel(u64 seed, u64 max_ref, const u64* __restrict__ filt, u32 filt_shift,
                                                                 u32* __restrict__ n_keys, u32* __restrict__ words, u32 shift) {
     constexpr u32 kPerThread = 256;
     const u32 base = (blockIdx.x * 256u + threadIdx.x) * kPerThread;  // (2^32 codes = 65 536 blocks x 256 threads x 256)
@@ -279,8 +279,7 @@ __global__ __launch_bounds__(256) void kmer_filter_build_kernel(u64 seed, u64 ma
         ascii16_from_code(x, w0, w1);
         const u64 h = murmur3_h1_16<false>(w0, w1, seed);
         if (h > max_ref) continue;
-        const u64 idx = h >> filt_shift;
-        if (!((filt[idx >> 5] >> (u32)(idx & 31u)) & 1u)) continue;
+        if (!filter_hit(filt, filt_shift, h)) continue;
         if (INSERT) {
             const u32 m = x * kKmerMix;
             atomicOr(&words[m >> shift], (1u << (m & 31u)) | (1u << ((m >> 5) & 31u)));
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(256) void kmer_filter_build_kernel(u64 seed, u64 ma
 template <int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, u64 max_ref, u64* __restrict__ out_sk,
                                               u32 sk_stride, u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
-                                              const u32* __restrict__ filt, u32 filt_shift) {
+                                              const u64* __restrict__ filt, u32 filt_shift) {
     const u32 lane = lane_id();
     const u64 lt = lanemask_lt();
     // At most one hash per lane (production: a 1.5 kb read keeps ~8): sort by counting.  Lane l holds hash l; for every j the
@@ -365,10 +364,7 @@ __device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, 
         const bool take = head && pos < s;
         if (INRANGE && filt != nullptr) {
             bool keep = false;
-            if (take) {
-                const u64 idx = h >> filt_shift;
-                keep = (filt[idx >> 5] >> (u32)(idx & 31u)) & 1u;
-            }
+            if (take) keep = filter_hit(filt, filt_shift, h);
             const u64 km = __ballot(keep);
             if (keep) out[wrote + __popcll(km & lt)] = h;
             wrote += __popcll(km);
@@ -390,7 +386,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                                                 const u64* __restrict__ offsets, u32 k_rt, u64 seed, u32 s, u64 max_ref,
                                                 u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                 u32* __restrict__ out_cnt_in, u32* __restrict__ retry, u32* __restrict__ big,
-                                                const u32* __restrict__ filt, u32 filt_shift, u64 n_bases,
+                                                const u64* __restrict__ filt, u32 filt_shift, u64 n_bases,
                                                 u32* __restrict__ chk, const unsigned char* lut, bool packed,
                                                 bool split_long = false, u32 seg_i = 0, u64* __restrict__ seg_h = nullptr,
                                                 u32* __restrict__ seg_cnt = nullptr, KmerFilter kf = KmerFilter{nullptr, 0u}) {
@@ -687,7 +683,7 @@ constexpr u32 kSegBlocks = 1024;  // x 4 waves: a C4 batch has ~28 000 segments
 #define SKX_SKETCH_PARAMS                                                                                              \
     const uint8_t *__restrict__ bases, const u64 *__restrict__ offsets, u32 n_reads, u32 k_rt, u64 seed, u32 s, u64 max_ref,  \
         u64 *__restrict__ out_sk, u32 sk_stride, u32 *__restrict__ out_len, u32 *__restrict__ out_cnt_in, u32 from_list,      \
-        u32 *__restrict__ retry, u32 *__restrict__ big, const u32 *__restrict__ filt, u32 filt_shift, u64 n_bases,            \
+        u32 *__restrict__ retry, u32 *__restrict__ big, const u64 *__restrict__ filt, u32 filt_shift, u64 n_bases,            \
         u32 *__restrict__ chk, LongReads lr, KmerFilter kf
 #define SKX_SKETCH_ARGS \
     bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr, kf
@@ -748,7 +744,7 @@ __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_ke
 __global__ __launch_bounds__(64) void sketch_merge_kernel(const u64* __restrict__ offsets, u32 s, u64 max_ref,
                                                           u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                           u32* __restrict__ out_cnt_in, u32* __restrict__ big,
-                                                          const u32* __restrict__ filt, u32 filt_shift,
+                                                          const u64* __restrict__ filt, u32 filt_shift,
                                                           const u32* __restrict__ chk, LongReads lr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* hashes = reinterpret_cast<u64*>(smem);
@@ -833,7 +829,7 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
                                                             const u32* __restrict__ big, u32 n_big, u32 k_rt, u64 seed, u32 s,
                                                             u64 max_ref, u64* __restrict__ out_sk, u32 sk_stride,
                                                             u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
-                                                            const u32* __restrict__ filt, u32 filt_shift, u32 packed) {
+                                                            const u64* __restrict__ filt, u32 filt_shift, u32 packed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ BlockScratch sh;
     u64* hashes = reinterpret_cast<u64*>(smem);
@@ -960,10 +956,7 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
                 const u64 h = v ? hashes[i] : 0;
                 if (INRANGE && filt != nullptr) {
                     bool kp = false;
-                    if (v) {
-                        const u64 idx = h >> filt_shift;
-                        kp = (filt[idx >> 5] >> (u32)(idx & 31u)) & 1u;
-                    }
+                    if (v) kp = filter_hit(filt, filt_shift, h);
                     u32 tot;
                     const u32 pos = wrote + block_rank(kp, sh, tot);
                     if (kp) out[pos] = h;
@@ -1106,21 +1099,34 @@ __global__ __launch_bounds__(256) void count_scan_b_kernel(u32* __restrict__ out
 // in-range read hashes number ~517 k per pass of which ~10 k exist in the collection; everything downstream (Q, the
 // bit matrices, the pair lists) shrinks by that factor.  The filter is a direct-mapped bitmap over hash >> shift
 // (hashes are uniform, so no second hash function is needed): no false negatives, and a false positive only costs
-// an all-zero row of M.  Built once per reference from the resident matrix.
-__global__ void filter_build_kernel(const u64* __restrict__ vals, u64 n, u32 shift, u32* __restrict__ bits,
-                                    bool markers_are_values) {
+// an all-zero row of M.  Built once per reference from the resident matrix.  (filter_mask / filter_hit: skx_common.hpp)
+// count != NULL: linear counting instead -- set bit (v >> shift) of a plain bitmap and count the bits newly set: the number of
+// distinct values, as long as the bitmap is sparse (skx_ref_create sizes the real filter from it).
+__global__ void filter_build_kernel(const u64* __restrict__ vals, u64 n, u32 shift, u64* __restrict__ words,
+                                    bool markers_are_values, unsigned long long* __restrict__ count) {
+    u32 fresh = 0;
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         const u64 v = vals[i];
         if (!markers_are_values && v >= kEmpty) continue;  // padding / empty cells of the tiled matrix
-        const u64 idx = v >> shift;
-        atomicOr(&bits[idx >> 5], 1u << (u32)(idx & 31u));
+        if (count) {
+            const u64 idx = v >> shift, bit = 1ull << (idx & 63u);
+            if (!(words[idx >> 6] & bit)) fresh += (atomicOr(&words[idx >> 6], bit) & bit) ? 0u : 1u;  // (most values are repeats: test first)
+        } else {
+            const u64 m = filter_mask(v);
+            if ((words[v >> shift] & m) != m) atomicOr(&words[v >> shift], m);
+        }
+    }
+    if (count) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) fresh += (u32)__shfl_xor((int)fresh, d, 64);
+        if (lane_id() == 0 && fresh) atomicAdd(count, (unsigned long long)fresh);
     }
 }
 
 // One wave per read: keeps, in order, those of the first cnt[r] hashes of the read's sketch row that pass the
 // filter (in-place compaction: a hash only ever moves towards the front) and stores the new count.
 __global__ __launch_bounds__(256) void filter_apply_kernel(u64* __restrict__ sk, u32 sk_stride, u32* __restrict__ cnt,
-                                                           u32 n_reads, const u32* __restrict__ bits, u32 shift) {
+                                                           u32 n_reads, const u64* __restrict__ bits, u32 shift) {
     const u32 r = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
     if (r >= n_reads) return;
     u64* row = sk + (size_t)r * sk_stride;
@@ -1132,8 +1138,7 @@ __global__ __launch_bounds__(256) void filter_apply_kernel(u64* __restrict__ sk,
         bool keep = false;
         if (i < n) {
             h = row[i];
-            const u64 idx = h >> shift;
-            keep = (bits[idx >> 5] >> (u32)(idx & 31u)) & 1u;
+            keep = filter_hit(bits, shift, h);
         }
         const u64 b = __ballot(keep);
         if (keep) row[kept + (u32)__popcll(b & ((1ull << lane) - 1ull))] = h;
@@ -2846,7 +2851,7 @@ static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketch
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                         const u32* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed,
+                         const u64* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed,
                          const LongReads* long_reads, const KmerFilter* kmer_filter, int phase) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
@@ -2950,7 +2955,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
 // (40-80 us on the sketch stream per push, measured) -- and it almost always is.
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                               const u32* filt, u32 filt_shift, bool packed) {
+                               const u64* filt, u32 filt_shift, bool packed) {
     if (n_big == 0) return hipSuccess;
     const dim3 blk_grid(std::min<u32>(n_big, 256u));
 #define SKX_BLK_LAUNCH(KERNEL)                                                                                              \
@@ -2962,7 +2967,7 @@ hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* 
     return hipGetLastError();
 }
 
-void launch_kmer_filter_build(hipStream_t st, u64 seed, u64 max_ref, const u32* filt, u32 filt_shift, u32* n_keys, u32* words, u32 shift) {
+void launch_kmer_filter_build(hipStream_t st, u64 seed, u64 max_ref, const u64* filt, u32 filt_shift, u32* n_keys, u32* words, u32 shift) {
     if (words) hipLaunchKernelGGL((kmer_filter_build_kernel<true>), dim3(65536), dim3(256), 0, st, seed, max_ref, filt, filt_shift, n_keys, words, shift);
     else hipLaunchKernelGGL((kmer_filter_build_kernel<false>), dim3(65536), dim3(256), 0, st, seed, max_ref, filt, filt_shift, n_keys, words, shift);
 }
@@ -3071,12 +3076,12 @@ u32 long_read_seg_slots() { return kSegSlots; }
 void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, st, chk, retry, big, total_pairs, h_pub, seq);
 }
-void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values) {
+void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u64* words, bool markers_are_values, unsigned long long* count) {
     if (n == 0) return;
     const u32 blocks = (u32)std::min<u64>((n + 255) / 256, 1u << 16);
-    hipLaunchKernelGGL(filter_build_kernel, dim3(blocks), dim3(256), 0, st, vals, n, shift, bits, markers_are_values);
+    hipLaunchKernelGGL(filter_build_kernel, dim3(blocks), dim3(256), 0, st, vals, n, shift, words, markers_are_values, count);
 }
-void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n_reads, const u32* bits, u32 shift) {
+void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n_reads, const u64* bits, u32 shift) {
     if (n_reads == 0) return;
     hipLaunchKernelGGL(filter_apply_kernel, dim3(cdiv(n_reads, 4)), dim3(256), 0, st, sk, sk_stride, cnt, n_reads, bits, shift);
 }

@@ -59,7 +59,7 @@ u32 long_read_seg_slots();
 // false negatives; false positives are hashed and then dropped by the in-range / membership tests as before.
 struct KmerFilter { const u32* words; u32 shift; };  // word = (code * kKmerMix) >> shift; bits (m & 31), ((m >> 5) & 31)
 // count (pass 1) / insert (pass 2) the canonical 16-mers whose hash passes (max_ref, filt); *n_keys accumulates in pass 1
-void launch_kmer_filter_build(hipStream_t st, u64 seed, u64 max_ref, const u32* filt, u32 filt_shift, u32* n_keys /* pass 1 */,
+void launch_kmer_filter_build(hipStream_t st, u64 seed, u64 max_ref, const u64* filt, u32 filt_shift, u32* n_keys /* pass 1 */,
                               u32* words /* pass 2, zeroed */, u32 shift);
 
 // sketching: every read of the batch, any length -- one wave per read (256 hash slots, then 2048 for the reads that
@@ -70,7 +70,7 @@ void launch_kmer_filter_build(hipStream_t st, u64 seed, u64 max_ref, const u32* 
 // Returns the launch status (it also opts the big-LDS kernels in, once per device).
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                         const u32* filt /* membership bitmap applied in inrange_only mode, or NULL */, u32 filt_shift,
+                         const u64* filt /* membership filter applied in inrange_only mode, or NULL */, u32 filt_shift,
                          u32* retry /* [1 + n_reads] */, u32* big /* [1 + n_reads] */, u64 n_bases, u32* chk,
                          int leave_room /* 0 no, 1 a scan overlaps the start, 2 a scan runs beside most of it */, bool packed = false,
                          const LongReads* long_reads = nullptr, const KmerFilter* kmer_filter = nullptr /* production, k = 16 */,
@@ -78,7 +78,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
 // the block sketcher for the n_big reads launch_sketch left on `big` (big[1 ..]); the caller reads the count back first
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                               const u32* filt, u32 filt_shift, bool packed = false);
+                               const u64* filt, u32 filt_shift, bool packed = false);
 // exclusive scan of n counts (out[i] = sum of in[0..i)); bsum: [ceil(n / 1024)] scratch
 void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum);
 
@@ -124,9 +124,11 @@ void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_b
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
 // ([7] = number of reads the block sketcher took; `big` is re-armed like `retry`)
 void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq);
-// membership filter over the union of the reference hashes (bitmap over hash >> shift)
-void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u32* bits, bool markers_are_values);
-void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n_reads, const u32* bits, u32 shift);
+// membership filter over the union of the reference hashes (blocked Bloom filter, skx_common.hpp: filter_mask / filter_hit);
+// count != NULL: `words` is a plain bitmap over v >> shift instead and *count receives the bits newly set (distinct values)
+void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u64* words, bool markers_are_values,
+                         unsigned long long* count = nullptr);
+void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n_reads, const u64* bits, u32 shift);
 
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
