@@ -201,9 +201,10 @@ int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
  * passes it took, [2] distinct query hashes of the most recent dictionary, [3] reads sketched by the block sketcher so
  * far, [4] passes so far, [5] of those with the lean scan kernel, [6] pair capacity of a pass, [7] rank groups (512 genomes)
  * that received any bit in the most recent pass, [8] long reads (more than 8192 bases) whose sketch was split over several
- * wavefronts so far, [9] the segments they were cut into.  Waits for the stream's queued work.
+ * wavefronts so far, [9] the segments they were cut into, [10] batches that were sketched a second time because their rows
+ * did not fit the stream's row pool (it grows to fit).  Waits for the stream's queued work.
  */
-#define SKX_N_STATS 10
+#define SKX_N_STATS 11
 int skx_stream_stats(skx_stream *st, uint64_t *out, uint32_t n_out);
 /* rank the CURRENT table: first top_k of (sum desc, index asc) per species; idx/sum are host arrays [n_species][top_k] */
 int skx_stream_rank(skx_stream *st, uint32_t top_k, uint32_t *idx, uint64_t *sum);

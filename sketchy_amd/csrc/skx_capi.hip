@@ -122,10 +122,16 @@ SKX_API int skx_dev_synchronize(int device) {
 // ------------------------------------------------------------------ policies (skx_set_option)
 static bool g_kmer_prefilter = true;  // build / use the k-mer prefilter for k = 16 references
 static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
+static u32 g_stream_query_rows = 0;       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
     if (!name) return fail(SKX_ERR_INVALID, "NULL option name");
     if (!strcmp(name, "kmer_prefilter")) { g_kmer_prefilter = value != 0; return SKX_OK; }
+    if (!strcmp(name, "stream_query_rows")) {
+        if (value > (1u << 22)) return fail(SKX_ERR_INVALID, "stream_query_rows must be 0 (default) .. 2^22");
+        g_stream_query_rows = (u32)value;
+        return SKX_OK;
+    }
     if (!strcmp(name, "filter_bits_per_hash")) {
         if (value < 4 || value > 4096) return fail(SKX_ERR_INVALID, "filter_bits_per_hash must be 4..4096");
         g_filter_bits_per_hash = (u32)value;
@@ -137,6 +143,7 @@ SKX_API int skx_get_option(const char* name, uint64_t* value) {
     if (!name || !value) return fail(SKX_ERR_INVALID, "NULL argument");
     if (!strcmp(name, "kmer_prefilter")) { *value = g_kmer_prefilter ? 1 : 0; return SKX_OK; }
     if (!strcmp(name, "filter_bits_per_hash")) { *value = g_filter_bits_per_hash; return SKX_OK; }
+    if (!strcmp(name, "stream_query_rows")) { *value = g_stream_query_rows; return SKX_OK; }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -442,6 +449,7 @@ struct PendingBatch {
     bool spec_insert = false;  // its pairs were gathered into buffer set spec_set / pair slot spec_slot right behind the sketcher
     int spec_set = 0, spec_slot = 0;
     bool inrange_only = true;
+    bool rows_mode = false;    // its sketch rows are full-width rows (debug outputs / no filter), not reservations out of the pool
     u32 dbg_cap = 0xFFFFFFFFu;
     u32* h_shared = nullptr;   // host outputs of the synchronous parity / debug path
     u64* h_sketches = nullptr;
@@ -489,6 +497,7 @@ struct skx_stream {
     u32 top_k = 0, max_reads = 0, sk_stride = 0;
     u64 max_bases = 0;
     u32 pcap = 0;        // pairs per pass
+    u32 qcap = 0;        // distinct query hashes per pass = rows of the pass's bit matrices (|Q| <= pairs, usually far below)
     u32 rpass = 0;       // reads per pass
     u64 reads_total = 0;
     // staging for host pushes
@@ -499,7 +508,11 @@ struct skx_stream {
     // side in use (use_side); side 1 is allocated by the first call that needs it.
     u64* d_sk = nullptr;
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
-    u64* sd_sk[2] = {nullptr, nullptr};
+    u64* sd_sk[2] = {nullptr, nullptr};       // POOL of a side: production rows are exact-size reservations (sketch_finish, pool mode)
+    u64 pool_cap[2] = {0, 0};                // ... its entries
+    u64* sd_rows[2] = {nullptr, nullptr};    // full-width rows [max_reads][sk_stride] of a side: debug outputs / skx_common_hashes; allocated on first use
+    u32 cur_stride = 0;                      // what the kernels get as row stride for d_sk: 0 = pool mode
+    u32 cur_pool_cap = 0;
     u32 *sd_len[2] = {nullptr, nullptr}, *sd_cnt[2] = {nullptr, nullptr}, *sd_poff[2] = {nullptr, nullptr}, *sd_big[2] = {nullptr, nullptr};
     u32 *sd_chk[2] = {nullptr, nullptr}, *sd_retry[2] = {nullptr, nullptr};  // (per side: batch i's summary is published while batch i + 1 is sketched)
     skx::LongReads sd_lr[2] = {{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u}, {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u}};
@@ -557,6 +570,7 @@ struct skx_stream {
     u32* d_bsum = nullptr;   // block totals of the pair-count scan
     u64 reads_big = 0;       // reads that went through the block sketcher so far (statistic)
     u64 reads_split = 0, segs_split = 0;  // long reads split over waves so far, and their segments (statistic)
+    u64 pool_grown = 0;                    // batches repeated with a larger row pool (statistic)
     u64 last_pairs = 0, last_passes = 0, total_passes = 0, lean_passes = 0;  // statistics (skx_stream_stats)
     // host-fed pipeline (skx_stream_submit): three staging slots, a copy stream, one batch of lag
     struct Staged {
@@ -592,7 +606,7 @@ static void stream_free(skx_stream* st) {
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     if (st->hs2) (void)hipStreamSynchronize(st->hs2);
     void* ptrs[] = {st->d_bases, st->d_offsets, st->sd_sk[0], st->sd_len[0], st->sd_cnt[0], st->sd_poff[0], st->sd_big[0],
-                    st->sd_sk[1], st->sd_len[1], st->sd_cnt[1], st->sd_poff[1], st->sd_big[1], st->d_pair_h[0], st->d_pair_h[1],
+                    st->sd_sk[1], st->sd_len[1], st->sd_cnt[1], st->sd_poff[1], st->sd_big[1], st->sd_rows[0], st->sd_rows[1], st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc2[0], st->d_inc2[1] != st->d_inc2[0] ? st->d_inc2[1] : nullptr,
                     st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_has, st->d_lead_seg, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
@@ -643,7 +657,12 @@ static void stream_free(skx_stream* st) {
 // one copy of the per-batch sketch buffers
 static hipError_t alloc_side(skx_stream* st, int i) {
     hipError_t e;
-    if ((e = hipMalloc(&st->sd_sk[i], (size_t)st->max_reads * st->sk_stride * 8)) != hipSuccess) return e;
+    // the pool: 16 row entries per read of the largest batch (C2 keeps 2.4, C4 3.9), never less than 2^20 -- and never more
+    // than full-width rows would take, so small streams cannot overflow it at all; a batch that does is repeated with a
+    // larger pool (batch_back)
+    st->pool_cap[i] = std::min<u64>((u64)st->max_reads * st->sk_stride, std::max<u64>((u64)st->max_reads * 16, 1u << 20));
+    st->pool_cap[i] = std::min<u64>(std::max<u64>(st->pool_cap[i], 64), 0xFFFFFFF0ull);
+    if ((e = hipMalloc(&st->sd_sk[i], (size_t)st->pool_cap[i] * 8)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_len[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_cnt[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_poff[i], ((size_t)st->max_reads + 2) * 4)) != hipSuccess) return e;
@@ -671,35 +690,59 @@ static hipError_t use_side(skx_stream* st, int i) {
         if (e != hipSuccess) return e;
     }
     st->side = i;
-    st->d_sk = st->sd_sk[i]; st->d_len = st->sd_len[i]; st->d_cnt = st->sd_cnt[i]; st->d_poff = st->sd_poff[i];
+    st->d_sk = st->sd_sk[i]; st->cur_stride = 0; st->cur_pool_cap = (u32)st->pool_cap[i];  // (pool mode; use_rows switches)
+    st->d_len = st->sd_len[i]; st->d_cnt = st->sd_cnt[i]; st->d_poff = st->sd_poff[i];
     st->d_big = st->sd_big[i]; st->d_retry = st->sd_retry[i]; st->d_chk = st->sd_chk[i];
     st->lr = st->sd_lr[i];
     st->h_chk = st->h_chk_base + 16 * i;
     return hipSuccess;
 }
 
+// full-width rows for the side in use (debug outputs, unfiltered sketches, skx_common_hashes): allocated by the first call
+// that needs them -- max_reads x min(s, longest read) x 8 bytes, 7.9 GB at C2, which a production stream never touches
+static hipError_t use_rows(skx_stream* st) {
+    const int i = st->side;
+    if (!st->sd_rows[i]) {
+        hipError_t e = hipMalloc(&st->sd_rows[i], (size_t)st->max_reads * st->sk_stride * 8);
+        if (e != hipSuccess) return e;
+    }
+    st->d_sk = st->sd_rows[i]; st->cur_stride = st->sk_stride; st->cur_pool_cap = 0;
+    return hipSuccess;
+}
+
 // pair_hint: pairs (read, hash some genome holds) a read is expected to contribute at most; sizes the pass workspace
 // (a batch with more than it can hold is cut into several passes -- correct at any size)
+// dense_queries: the pairs of a pass are (nearly) all distinct hashes (skx_common_hashes: whole sketches as queries) -- the
+// matrices then get as many rows as the pass has pairs, bounded by a sixth of the free device memory
 static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_k, u32 max_reads, u64 max_bases,
-                                  u32 sk_stride, u32 pair_hint) {
+                                  u32 sk_stride, u32 pair_hint, bool dense_queries = false) {
     SKXCHK(use_device(ref->device));
     skx_stream* st = new skx_stream;
     st->ref = ref; st->device = ref->device; st->top_k = top_k; st->max_reads = max_reads; st->max_bases = max_bases;
     st->sk_stride = sk_stride;
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
-    // pass capacity: bounded by the size of the bit matrices, and never below one read's worth of pairs
-    // (the host cannot know how many DISTINCT hashes a pass will have, so the matrices are sized by its pair count:
-    // 1/32 of the free device memory each, at most 8 GB -- env SKX_PASS_MB overrides)
-    size_t mem_free = 0, mem_total = 0;
-    (void)hipMemGetInfo(&mem_free, &mem_total);
-    static const u64 pass_mb_env = skx::knob("SKX_PASS_MB") ? (u64)atoll(skx::knob("SKX_PASS_MB")) : 0;
-    const u64 pass_mb = pass_mb_env ? pass_mb_env : std::min<u64>(16384, std::max<u64>(256, (u64)(mem_free >> 20) / 16));
-    u64 pc = (pass_mb << 20) * 8 / n_pad;
-    pc = std::min<u64>(pc, max_reads > 65536 ? (1u << 22) : (1u << 20));
-    pc = std::min<u64>(pc, (u64)max_reads * std::min<u32>(sk_stride, pair_hint));  // (a read contributes at most sk_stride pairs)
+    // Pass capacity.  Pairs (read, hash some genome holds): 16 per read on average (C2: 2.4), at most 2^22 -- pair lists and
+    // the hash set cost ~70 bytes per pair.  Rows of the bit matrices = DISTINCT query hashes of a pass (C2: 10 k of 232 k
+    // pairs: the reads of a sample share their matching hashes): policy "stream_query_rows", default 65 536 -- the three
+    // matrices of a pass (M, 2 x Mq) take rows x genomes / 8 bytes each: 1 GB in all at C2.  (Rounds 1-2 sized the matrices
+    // by the PAIR capacity: 51 GB at C2.)  The host learns a batch's |Q| with its published summary (the speculative pair
+    // gather counts its distinct keys); a batch with more pairs or more distinct hashes than a pass holds is cut into
+    // several passes, each bounded by pairs <= min(pcap, qcap) -- correct at any size.
+    static const u64 pass_pairs_env = skx::knob("SKX_PASS_PAIRS") ? (u64)atoll(skx::knob("SKX_PASS_PAIRS")) : 0;  // test knob
+    u64 pc = std::min<u64>((u64)max_reads * std::min<u32>(sk_stride, pair_hint), 1u << 22);  // (a read contributes at most sk_stride pairs)
+    if (pass_pairs_env) pc = pass_pairs_env;
     pc = std::max<u64>(pc, sk_stride);
     pc = (pc + 63) / 64 * 64;
     st->pcap = (u32)pc;
+    u64 qc = g_stream_query_rows ? g_stream_query_rows : 65536;
+    if (dense_queries) {
+        size_t mem_free = 0, mem_total = 0;
+        (void)hipMemGetInfo(&mem_free, &mem_total);
+        qc = std::max<u64>(qc, std::min<u64>(pc, (u64)(mem_free / 6) / (3ull * n_pad / 8)));
+    }
+    qc = std::max<u64>(std::min<u64>(qc, pc), std::min<u64>(pc, sk_stride));  // (never below one read's worth: a read alone must fit a pass)
+    qc = (qc + 63) / 64 * 64;
+    st->qcap = (u32)qc;
     static const u64 pass_reads = skx::knob("SKX_PASS_READS") ? (u64)atoll(skx::knob("SKX_PASS_READS")) : 131072;
     u64 rp = std::min<u64>(max_reads, pass_reads);
     // candidate arrays of the ranking: per (read, rank group, row) for top_k <= 16, per (read, genome word, row) beyond
@@ -784,11 +827,11 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipMalloc(&st->d_nq[i], 64));
         SCHK(hipMalloc(&st->d_win[i], (size_t)n_bt * 8));
     }
-    SCHK(hipMalloc(&st->d_m, (size_t)(st->pcap / 64) * n_pad * 8));
-    SCHK(hipMemset(st->d_m, 0, (size_t)(st->pcap / 64) * n_pad * 8));      // kept all-zero between passes
+    SCHK(hipMalloc(&st->d_m, (size_t)(st->qcap / 64) * n_pad * 8));
+    SCHK(hipMemset(st->d_m, 0, (size_t)(st->qcap / 64) * n_pad * 8));      // kept all-zero between passes
     // (d_mint, the second word array of the split scan variant, is allocated by the first pass that wants it)
     for (int i = 0; i < 2; ++i)
-        SCHK(hipMalloc(&st->d_mq[i], (size_t)st->pcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
+        SCHK(hipMalloc(&st->d_mq[i], (size_t)st->qcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
     SCHK(hipMalloc(&st->d_inc2[0], (size_t)n_seg_max * n_pad * 4));
     if (st->hs3 != st->hs2) SCHK(hipMalloc(&st->d_inc2[1], (size_t)n_seg_max * n_pad * 4)); else st->d_inc2[1] = st->d_inc2[0];
     SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
@@ -821,7 +864,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64) + 1) * 4));
     if (skx::scan_lean_applies(ref->n_bands, false, false)) {
         SCHK(hipMalloc(&st->d_hbuf, (size_t)n_bt * skx::scan_lean_words() * skx::kTileGenomes * 8));
-        for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_wb[i], ((size_t)st->pcap / 64 + 1) * ref->n_tiles * 16));
+        for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_wb[i], ((size_t)st->qcap / 64 + 1) * ref->n_tiles * 16));
     }
     SCHK(hipHostMalloc((void**)&st->h_poff, ((size_t)max_reads + 2) * 4, hipHostMallocDefault));
     SCHK(hipHostMalloc((void**)&st->h_offsets, ((size_t)max_reads + 1) * 8, hipHostMallocDefault));
@@ -919,14 +962,18 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 // ---- one pass: reads [ra, rb) of the batch, pairs [p_base, p_base + P)
 // inserted: the pairs of this pass were already gathered / inserted into the hash set on the sketch stream (the usual
 // case: the whole batch is one pass and process_batch queued launch_dict_insert right behind the sketcher)
+// q_rows: an upper bound of the pass's distinct query hashes (<= qcap): P itself, or -- when the host knows it from the
+// speculative gather -- |Q|
 static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_topk_idx, u64* d_topk_sum,
-                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table, bool inserted = false) {
+                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table, bool inserted = false, u32 q_rows = 0xFFFFFFFFu) {
     const skx_ref* ref = st->ref;
     hipStream_t hs0 = st->hs0, hs = st->hs, hs2 = st->hs2;
     const skx::Species spc = ref->species();
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64, n_reads = rb - ra;
     const u32 n_bt = ref->n_bands * ref->n_tiles;
-    const u32 nq_rows = ((P + 63) / 64) * 64;  // rows per group of the group-major bit matrix of this pass
+    const u32 q_bound = std::min(P, q_rows);
+    if (q_bound > st->qcap) return fail(SKX_ERR_HIP, "internal: pass of %u query rows exceeds the matrices' %u", q_bound, st->qcap);
+    const u32 nq_rows = ((q_bound + 63) / 64) * 64;  // rows per group of the group-major bit matrix of this pass
     const int b = st->buf;                      // buffer set handed from stage to stage for this pass
     st->buf ^= 1;
     const int slot = st->pslot;                 // ... and its slot of the pair lists
@@ -961,8 +1008,8 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     if (P > 0) {
         Span sp(st, 1, hs);
         if (!inserted)
-            skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, ra, rb, p_base, st->d_pair_h[b], d_pair_r, st->d_ht[b],
-                                    st->ht_slots, st->d_dict_ctr[b], st->pcap);
+            skx::launch_dict_insert(hs, st->d_sk, st->cur_stride, st->d_poff, ra, rb, p_base, st->d_pair_h[b], d_pair_r, st->d_ht[b],
+                                    st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len);
         skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
                               st->d_dict_ctr[b], d_q, d_nq);
         skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);  // (also hands |Q| to the host)
@@ -1002,12 +1049,12 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         return SKX_OK;
     };
     if (P > 0) {
-        const u32 n_words = (P + 63) / 64;
+        const u32 n_words = nq_rows / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
         static const int split_env = skx::knob("SKX_SCAN_SPLIT") ? atoi(skx::knob("SKX_SCAN_SPLIT")) : -1;
         bool split = split_env >= 0 ? split_env != 0 : (nq_est * ref->rb / ref->s >= 192);
         if (split && !st->d_mint) {  // dense dictionaries only: most streams never get here
-            const size_t bytes = (size_t)(st->pcap / 64) * n_pad * 8;
+            const size_t bytes = (size_t)(st->qcap / 64) * n_pad * 8;
             if (hipMalloc(&st->d_mint, bytes) == hipSuccess) {
                 HIPCHK(hipMemsetAsync(st->d_mint, 0, bytes, hs));  // (the transpose re-zeroes what it reads)
             } else {
@@ -1106,15 +1153,17 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
 }
 
 // partition [0, n_reads) into passes by the pair counts in h_poff; calls fn(ra, rb, p_base, P)
+// (a pass cut here holds at most min(pcap, qcap) pairs, hence at most qcap distinct query hashes)
 template <class F>
 static int for_each_pass(skx_stream* st, u32 n_reads, u32 max_pass_reads, F fn) {
     const u32 cap = std::max<u32>(1u, std::min<u32>(st->rpass, max_pass_reads));
+    const u32 pair_cap = std::min(st->pcap, st->qcap);
     u32 ra = 0;
     while (ra < n_reads) {
         u32 rb = ra;
-        while (rb < n_reads && rb - ra < cap && st->h_poff[rb + 1] - st->h_poff[ra] <= st->pcap) ++rb;
+        while (rb < n_reads && rb - ra < cap && st->h_poff[rb + 1] - st->h_poff[ra] <= pair_cap) ++rb;
         if (rb == ra) return fail(SKX_ERR_CAPACITY, "read %u alone has %u candidate hashes > pass capacity %u", ra,
-                                  st->h_poff[ra + 1] - st->h_poff[ra], st->pcap);
+                                  st->h_poff[ra + 1] - st->h_poff[ra], pair_cap);
         SKXCHK(fn(ra, rb, st->h_poff[ra], st->h_poff[rb] - st->h_poff[ra]));
         ra = rb;
     }
@@ -1161,7 +1210,7 @@ static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
     SKXCHK(behind_the_sketch(st, pb.side));
     if (!ref->any) HIPCHK(hipMemsetAsync(st->d_cnt, 0, (size_t)n_reads * 4, hs));
     if (filt && !pb.inrange_only)
-        skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);
+        skx::launch_filter_apply(hs, st->d_sk, st->sk_stride, st->d_cnt, n_reads, filt, ref->filt_shift);  // (rows mode)
     skx::launch_count_scan(hs, st->d_cnt, st->d_poff, n_reads + 1, st->d_bsum);
     // the whole batch is normally ONE pass: gather its pairs into the buffer set that pass will use and fill the set's
     // hash set right here, behind the sketcher -- the rest of the dictionary then runs on the scan stream and this
@@ -1173,15 +1222,63 @@ static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
         // pair lists by the ranking three passes back
         if (st->pairq_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pairq[b], 0)); st->pairq_pending[b] = false; }
         if (st->pslot_pending[slot]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pslot[slot], 0)); st->pslot_pending[slot] = false; }
-        skx::launch_dict_insert(hs, st->d_sk, st->sk_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h[b], st->d_pair_r[slot],
-                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap);
+        skx::launch_dict_insert(hs, st->d_sk, st->cur_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h[b], st->d_pair_r[slot],
+                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len);
         HIPCHK(hipMemcpyAsync(st->d_poff_pass[slot], st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
     }
     pb.seq = ++st->pub_seq;
-    skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, pb.seq);
+    skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, pb.seq,
+                        pb.spec_insert ? st->d_dict_ctr[pb.spec_set] : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->ev_sketch[pb.side], hs));
     return SKX_OK;
+}
+
+// the device work of a front half: offsets check (+ long-read tables), sketch, counts, speculative gather, published summary
+// (the stream's names are on the batch's side and row mode; also used to REPEAT a batch whose rows did not fit the pool)
+static int queue_front(skx_stream* st, PendingBatch& pb, int leave_room) {
+    const skx_ref* ref = st->ref;
+    hipStream_t hs = st->hs0;  // sketching and everything the host reads back run on the first pipeline stream
+    const u32 n_reads = pb.n_reads;
+    const u64 max_ref = ref->any ? ref->max_ref : 0;
+    const u64* filt = batch_filter(ref);
+    Span sp(st, 0);
+    // offsets are looked at on the device (cheap); it also zeroes entry n_reads of the pair counts
+    // (... and lists the long reads of a production batch with their segments: the sketcher splits those over waves)
+    const skx::LongReads* lr = (pb.inrange_only && st->lr.list) ? &st->lr : nullptr;
+    const skx::KmerFilter kf = ref->kmer_filter();
+    skx::launch_batch_check(hs, pb.d_offsets, n_reads, pb.n_bases, st->d_chk, st->d_cnt + n_reads, lr);
+    if (pb.h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));  // (rows mode)
+    // every read, any length: wave sketchers (then the block sketcher for what overflowed: device-side lists)
+    // production: the main kernel on the sketch stream, the list walks behind it (long-read merge, 2048-slot retry) on hs1
+    // with the rest of the batch's front half -- the next batch's main kernel then follows this one directly
+    for (int phase = 1; phase <= (pb.inrange_only ? 2 : 1); ++phase) {
+        if (phase == 2) SKXCHK(behind_the_sketch(st, pb.side));
+        HIPCHK(skx::launch_sketch(phase == 2 ? st->hs1 : hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s_read, max_ref,
+                                  pb.inrange_only, st->d_sk, st->cur_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry,
+                                  st->d_big, pb.n_bases, st->d_chk, leave_room, st->packed, lr, ref->d_kf ? &kf : nullptr,
+                                  pb.inrange_only ? phase : 3, st->cur_pool_cap));
+    }
+    if (!pb.inrange_only) {
+        // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
+        // not the fast one -- read the count back and run the block sketcher before the rows are copied out
+        u32 n_big = 0;
+        HIPCHK(hipMemcpyAsync(&n_big, st->d_big, 4, hipMemcpyDeviceToHost, hs));
+        HIPCHK(hipStreamSynchronize(hs));
+        HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s_read, max_ref,
+                                        false, st->d_sk, st->cur_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->packed, st->d_chk,
+                                        st->cur_pool_cap));
+        st->reads_big += n_big;
+        HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
+    }
+    // optional sketch outputs leave now: the filter compacts the rows in place
+    if (pb.h_sketch_len) HIPCHK(hipMemcpyAsync(pb.h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
+    if (pb.h_sketches) {
+        memset(pb.h_sketches, 0, (size_t)n_reads * ref->s_read * 8);
+        HIPCHK(hipMemcpy2DAsync(pb.h_sketches, (size_t)ref->s_read * 8, st->d_sk, (size_t)st->sk_stride * 8,
+                                (size_t)std::min(ref->s_read, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
+    }
+    return queue_counts_and_summary(st, pb);
 }
 
 // front half of a batch already resident on the device: everything up to the published summary, on the sketch stream.
@@ -1189,14 +1286,15 @@ static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
 // filter itself in production mode; rows it did not filter (full sketches for the debug outputs) get the separate pass.
 static int batch_front(skx_stream* st, PendingBatch& pb) {
     const skx_ref* ref = st->ref;
-    hipStream_t hs = st->hs0;  // sketching and everything the host reads back run on the first pipeline stream
+    hipStream_t hs = st->hs0;
     const u32 n_reads = pb.n_reads;
     // the other side while an enqueued batch still owns one; likewise the buffer set that batch's pass will take
     pb.side = st->pend.valid ? st->pend.side ^ 1 : 0;
     HIPCHK(use_side(st, pb.side));
     pb.inrange_only = !(pb.h_sketches || pb.h_sketch_len);  // production: only what can meet the reference is built
-    const u64 max_ref = ref->any ? ref->max_ref : 0;
-    const u64* filt = batch_filter(ref);
+    // production rows are reservations out of the side's pool; full sketches (and unfiltered ones) need full-width rows
+    pb.rows_mode = !pb.inrange_only || batch_filter(ref) == nullptr;
+    if (pb.rows_mode) HIPCHK(use_rows(st));
     // the per-read x per-genome debug matrix is produced in slabs of at most 256 MB
     pb.dbg_cap = pb.h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
     static const bool spec_env = !skx::knob("SKX_SPEC_INSERT") || atoi(skx::knob("SKX_SPEC_INSERT")) != 0;  // test knob
@@ -1213,50 +1311,13 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         HIPCHK(hipStreamWaitEvent(hs, st->ev_skread[pb.side], 0));
         st->sk_reader_pending[pb.side] = false;
     }
-    {
-        Span sp(st, 0);
-        // offsets are looked at on the device (cheap); it also zeroes entry n_reads of the pair counts
-        // (... and lists the long reads of a production batch with their segments: the sketcher splits those over waves)
-        const skx::LongReads* lr = (pb.inrange_only && st->lr.list) ? &st->lr : nullptr;
-        const skx::KmerFilter kf = ref->kmer_filter();
-        skx::launch_batch_check(hs, pb.d_offsets, n_reads, pb.n_bases, st->d_chk, st->d_cnt + n_reads, lr);
-        if (pb.h_sketches) HIPCHK(hipMemsetAsync(st->d_sk, 0, (size_t)n_reads * st->sk_stride * 8, hs));
-        // every read, any length: wave sketchers (then the block sketcher for what overflowed: device-side lists)
-        // (three-stream pipeline: will the previous pass's scan be in flight?  then this sketch shares the CUs with it)
-        int leave_room = (st->depth >= 3 && st->pend.valid) ? 2 : 0;
-        if (st->depth >= 3 && !leave_room)
-            for (int i = 0; i < 2; ++i)
-                if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
-        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-        // production: the main kernel on the sketch stream, the list walks behind it (long-read merge, 2048-slot retry) on hs1
-        // with the rest of the batch's front half -- the next batch's main kernel then follows this one directly
-        for (int phase = 1; phase <= (pb.inrange_only ? 2 : 1); ++phase) {
-            if (phase == 2) SKXCHK(behind_the_sketch(st, pb.side));
-            HIPCHK(skx::launch_sketch(phase == 2 ? st->hs1 : hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s_read, max_ref,
-                                      pb.inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry,
-                                      st->d_big, pb.n_bases, st->d_chk, leave_room, st->packed, lr, ref->d_kf ? &kf : nullptr,
-                                      pb.inrange_only ? phase : 3));
-        }
-        if (!pb.inrange_only) {
-            // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
-            // not the fast one -- read the count back and run the block sketcher before the rows are copied out
-            u32 n_big = 0;
-            HIPCHK(hipMemcpyAsync(&n_big, st->d_big, 4, hipMemcpyDeviceToHost, hs));
-            HIPCHK(hipStreamSynchronize(hs));
-            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s_read, max_ref,
-                                            false, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->packed));
-            st->reads_big += n_big;
-            HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
-        }
-        // optional sketch outputs leave now: the filter compacts the rows in place
-        if (pb.h_sketch_len) HIPCHK(hipMemcpyAsync(pb.h_sketch_len, st->d_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, hs));
-        if (pb.h_sketches) {
-            memset(pb.h_sketches, 0, (size_t)n_reads * ref->s_read * 8);
-            HIPCHK(hipMemcpy2DAsync(pb.h_sketches, (size_t)ref->s_read * 8, st->d_sk, (size_t)st->sk_stride * 8,
-                                    (size_t)std::min(ref->s_read, st->sk_stride) * 8, n_reads, hipMemcpyDeviceToHost, hs));
-        }
-        SKXCHK(queue_counts_and_summary(st, pb));
-    }
+    // (three-stream pipeline: will the previous pass's scan be in flight?  then this sketch shares the CUs with it)
+    int leave_room = (st->depth >= 3 && st->pend.valid) ? 2 : 0;
+    if (st->depth >= 3 && !leave_room)
+        for (int i = 0; i < 2; ++i)
+            if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+    SKXCHK(queue_front(st, pb, leave_room));
     st->chk_dirty = false;  // the publish kernel is queued: it re-arms the device-side counters
     pb.valid = true;
     return SKX_OK;
@@ -1264,13 +1325,13 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
 
 // a younger batch's speculative pair gather has to be undone: the batch before it needs more than one pass, so the
 // buffer sets no longer alternate the way the gather assumed (rare)
-static int cancel_speculation(skx_stream* st, PendingBatch& y) {
+static int cancel_speculation(skx_stream* st, PendingBatch& y, bool keep_flag = false) {
     if (!y.spec_insert) return SKX_OK;
     // (on the stream the gather was queued on: behind it)
     HIPCHK(hipMemsetAsync(st->d_ht[y.spec_set], 0xFF, (size_t)st->ht_slots * 8, st->hs1));
     HIPCHK(hipMemsetAsync(st->d_dict_ctr[y.spec_set], 0, 64, st->hs1));
     HIPCHK(hipStreamSynchronize(st->hs1));
-    y.spec_insert = false;
+    if (!keep_flag) y.spec_insert = false;
     return SKX_OK;
 }
 
@@ -1283,8 +1344,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     const u64* filt = batch_filter(ref);
     pb.valid = false;
     HIPCHK(use_side(st, pb.side));
-    SKXCHK(wait_published(st, pb));  // the one wait of a batch: 36 bytes, no copy, no stream synchronisation
-    if (pb.h_sketches || pb.h_sketch_len) HIPCHK(hipStreamSynchronize(hs));  // (debug outputs: their copies must have landed)
+    if (pb.rows_mode) HIPCHK(use_rows(st));
     // A refused batch must not leave its pairs behind: the speculative gather queued by the front half has already put the
     // batch's keys into the hash set of buffer set spec_set (it only looks at the pair capacity, not at the offsets), and
     // every later pass on that set assumes |Q| <= its own pair count.  Empty the set again before returning the error.
@@ -1292,39 +1352,68 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
         (void)cancel_speculation(st, pb);
         return fail(code, "%s", msg.c_str());
     };
-    {
-        u32 c[8];
-        for (int i = 0; i < 8; ++i) c[i] = st->h_chk[i];
-        if (pb.inrange_only && st->lr.list && !c[0] && !c[6]) { st->reads_split += c[1]; st->segs_split += st->h_chk[9]; }  // (statistics)
+    // The published summary, and the two rare things it can ask for -- each followed by a new summary:
+    //   * c[6] & 4: the batch's rows did not fit the side's pool (far denser than the 16 pairs per read it is sized for).  The
+    //     summary says how many entries were asked for: allocate that, empty what the speculative gather made of the partial
+    //     rows and run the whole front half again (same side, same buffer set: nothing else has looked at this batch yet);
+    //   * c[7]: reads whose in-range hashes overflowed a wave's 2048 slots wait on the `big` list.  The block sketcher was not
+    //     queued blindly (it needs a drained CU even to find the list empty): run it now, then counts, pair gather (into the
+    //     same buffer set: the keys already there are a subset) and the summary once more.
+    bool stats_done = false, outputs_synced = false;
+    u64 big_counted = 0;
+    for (int round = 0;; ++round) {
+        if (round > 6) return fail(SKX_ERR_HIP, "internal: the batch's front half does not settle");
+        SKXCHK(wait_published(st, pb));  // the one wait of a batch: 48 bytes, no copy, no stream synchronisation
+        if ((pb.h_sketches || pb.h_sketch_len) && !outputs_synced) { HIPCHK(hipStreamSynchronize(hs)); outputs_synced = true; }  // (debug outputs: their copies must have landed)
+        u32 c[12];
+        for (int i = 0; i < 12; ++i) c[i] = st->h_chk[i];
         char buf[160];
         if (c[0]) {
             snprintf(buf, sizeof buf, "offsets not monotonic at read %u", 0xFFFFFFFFu - c[0]);
             return refuse(SKX_ERR_INVALID, buf);
         }
         if (c[6] & 2u) return refuse(SKX_ERR_INVALID, "the long reads of the batch do not fit the stream's tables (offsets not monotonic?)");
-        if (c[6]) {
+        if (c[6] & 1u) {
             snprintf(buf, sizeof buf, "a read lies outside the n_bases=%llu bytes given from offsets[0] on", (unsigned long long)pb.n_bases);
             return refuse(SKX_ERR_INVALID, buf);
         }
-        if (c[7]) {
-            // production mode, rare: reads whose in-range hashes overflowed a wave's 2048 slots wait on the `big` list.
-            // The block sketcher was not queued blindly (it needs a drained CU even to find the list empty): run it now,
-            // then counts, pair gather (into the same buffer set: the keys already there are a subset) and the
-            // published summary once more.
-            st->reads_big += c[7];
-            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s_read, max_ref,
-                                            pb.inrange_only, st->d_sk, st->sk_stride, st->d_len, st->d_cnt, filt, ref->filt_shift,
-                                            st->packed));
-            SKXCHK(queue_counts_and_summary(st, pb));
-            SKXCHK(wait_published(st, pb));
-            if (st->h_chk[6]) return refuse(SKX_ERR_INVALID, "a read lies outside the n_bases given from offsets[0] on");
+        if (!stats_done && pb.inrange_only && st->lr.list && (c[1] || c[9])) { st->reads_split += c[1]; st->segs_split += c[9]; stats_done = true; }
+        if (c[6] & 4u) {
+            if (pb.rows_mode) return fail(SKX_ERR_HIP, "internal: pool overflow reported for full-width rows");
+            const u64 need = std::max<u64>(c[11], st->pool_cap[pb.side] + 1);
+            if (need > 0xFFFFFFF0ull) return refuse(SKX_ERR_CAPACITY, "the batch's sketch rows exceed what the pool can index");
+            SKXCHK(cancel_speculation(st, pb, true));
+            HIPCHK(hipStreamSynchronize(st->hs0));
+            HIPCHK(hipStreamSynchronize(st->hs1));
+            (void)hipFree(st->sd_sk[pb.side]); st->sd_sk[pb.side] = nullptr; st->pool_cap[pb.side] = 0;
+            const u64 cap = std::min<u64>(0xFFFFFFF0ull, need + need / 8 + 1024);
+            HIPCHK(hipMalloc(&st->sd_sk[pb.side], (size_t)cap * 8));
+            st->pool_cap[pb.side] = cap;
+            st->pool_grown += 1;
+            st->reads_big -= big_counted; big_counted = 0;
+            HIPCHK(use_side(st, pb.side));
+            SKXCHK(queue_front(st, pb, 0));
+            continue;
         }
+        if (c[7]) {
+            st->reads_big += c[7]; big_counted += c[7];
+            HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s_read, max_ref,
+                                            pb.inrange_only, st->d_sk, st->cur_stride, st->d_len, st->d_cnt, filt, ref->filt_shift,
+                                            st->packed, st->d_chk, st->cur_pool_cap));
+            SKXCHK(queue_counts_and_summary(st, pb));
+            continue;
+        }
+        break;
     }
     const u32 total_pairs = st->h_chk[8];
     st->last_pairs = total_pairs; st->last_passes = 0;
 
 
-    const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap;
+    // one pass: the reads fit, the pairs fit, and the distinct hashes fit the bit matrices -- their number is known when the
+    // speculative gather ran (it counts its new keys; it did nothing when the pairs exceed a pass), else bounded by the pairs
+    const u32 spec_keys = pb.spec_insert ? st->h_chk[10] : 0xFFFFFFFFu;
+    const u32 q_rows = spec_keys != 0xFFFFFFFFu ? spec_keys : total_pairs;
+    const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap && q_rows <= st->qcap;
     // (the batch needs several passes although a speculative gather was queued for it: normally that gather did nothing -- it
     // saw more pairs than a pass holds -- but after the block-sketcher redo above the FIRST gather may have fitted while the
     // recount does not; either way the set must be empty before the passes insert their own pairs)
@@ -1338,7 +1427,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
             if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
         }
-        SKXCHK(run_pass(st, ra, rb, p_base, P, pb.d_topk_idx, pb.d_topk_sum, d_shared, true, inserted));
+        SKXCHK(run_pass(st, ra, rb, p_base, P, pb.d_topk_idx, pb.d_topk_sum, d_shared, true, inserted, inserted ? q_rows : 0xFFFFFFFFu));
         inserted = false;
         st->last_passes += 1;
         if (pb.h_shared) {
@@ -1660,7 +1749,7 @@ SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
         for (u32 f : flags) live += f ? 1 : 0;
     }
     const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)std::max(st->h_nq[0], st->h_nq[1]), st->reads_big,
-                                     st->total_passes, st->lean_passes, st->pcap, live, st->reads_split, st->segs_split};
+                                     st->total_passes, st->lean_passes, st->pcap, live, st->reads_split, st->segs_split, st->pool_grown};
     for (uint32_t i = 0; i < n_out; ++i) out[i] = i < SKX_N_STATS ? v[i] : 0;
     return SKX_OK;
 }
@@ -1747,7 +1836,7 @@ SKX_API int skx_common_hashes(const skx_ref* ref, const uint64_t* query, const u
         max_len = std::max(max_len, query_len[i]);
     }
     skx_stream* st = nullptr;
-    SKXCHK(stream_create_internal(&st, ref, 0, n_query, 1, max_len, max_len));  // (whole sketches: every hash is a pair)
+    SKXCHK(stream_create_internal(&st, ref, 0, n_query, 1, max_len, max_len, true));  // (whole sketches: every hash is a pair)
     int rc = SKX_OK;
     do {
         // candidate prefix of every query: hashes <= max_ref (ascending rows)
@@ -1758,7 +1847,8 @@ SKX_API int skx_common_hashes(const skx_ref* ref, const uint64_t* query, const u
             u32 c = ref->any ? (u32)(std::upper_bound(row, row + query_len[i], (uint64_t)ref->max_ref) - row) : 0;
             st->h_poff[i + 1] = st->h_poff[i] + c;
         }
-        hipError_t e = hipMemcpy2D(st->d_sk, (size_t)max_len * 8, query, (size_t)q_stride * 8, (size_t)max_len * 8, n_query, hipMemcpyHostToDevice);
+        hipError_t e = use_rows(st);  // (the queries are full-width rows)
+        if (e == hipSuccess) e = hipMemcpy2D(st->d_sk, (size_t)max_len * 8, query, (size_t)q_stride * 8, (size_t)max_len * 8, n_query, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(st->d_poff, st->h_poff, ((size_t)n_query + 1) * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) { rc = fail(SKX_ERR_HIP, "skx_common_hashes upload: %s", hipGetErrorString(e)); break; }
         u32* d_shared = nullptr;

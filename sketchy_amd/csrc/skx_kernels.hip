@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void band_bounds_kernel(const u64* __restrict_
 //   HCAP = kSketchCap  -> `big`   (redone by sketch_block_kernel, which holds 16 384 hashes and selects in passes)
 // !INRANGE (full sketches: debug outputs, skx_sketch_reads): reads with more than kSketchCap k-mers go to `big` at once.
 constexpr u32 kSketchRetry = 0xFFFFFFFFu;
+constexpr u32 kChkPool = 11;  // chk[11]: bump counter of the row pool (sketch_finish, pool mode)
 // list layout: [0] = number of entries, [1..] = read indices
 __device__ __forceinline__ void list_append(u32* __restrict__ list, u32 r) { list[1u + atomicAdd(&list[0], 1u)] = r; }
 
@@ -296,10 +297,24 @@ __global__ __launch_bounds__(256) void kmer_filter_build_kernel(u64 seed, u64 ma
 
 // the tail of every sketch: `m` hashes in the wave's LDS buffer (any order, m <= HCAP) -> ascending, distinct, truncated to
 // s, (production) only those some genome holds -> out_sk row r, out_len[r], out_cnt_in[r]
+// POOL MODE (sk_stride == 0; production batches): rows are not max_reads x s entries -- a read keeps a handful of pairs --
+// but exact-size reservations out of one pool: out_sk = the pool, out_len[r] receives the row's start in it (the sketch
+// length has no consumer in production mode), chk[11] is the bump counter, pool_cap the pool's entries.  A reservation that
+// does not fit raises chk[6] |= 4 and writes nothing; chk[11] still sums every request, so the host knows how much to allocate
+// before it repeats the batch (rare: a pool holds 16 pairs per read of the largest batch, C2 needs 2.4).
+__device__ __forceinline__ u32 pool_reserve(u32* __restrict__ chk, u32 pool_cap, u32 want /* wave-uniform */, bool& ok) {
+    u32 off = 0;
+    if (lane_id() == 0 && want) off = atomicAdd(&chk[kChkPool], want);
+    off = __builtin_amdgcn_readfirstlane(off);
+    ok = off + want <= pool_cap && off + want >= off;
+    if (!ok && lane_id() == 0) atomicOr(&chk[6], 4u);
+    return off;
+}
 template <int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, u64 max_ref, u64* __restrict__ out_sk,
                                               u32 sk_stride, u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
-                                              const u64* __restrict__ filt, u32 filt_shift) {
+                                              const u64* __restrict__ filt, u32 filt_shift, u32* __restrict__ chk = nullptr,
+                                              u32 pool_cap = 0) {
     const u32 lane = lane_id();
     const u64 lt = lanemask_lt();
     // At most one hash per lane (production: a 1.5 kb read keeps ~8): sort by counting.  Lane l holds hash l; for every j the
@@ -353,6 +368,49 @@ __device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, 
     // holds are written -- strictly AFTER the truncation: a hash ranked beyond s is not part of the sketch even if
     // everything before it is dropped (reads with more distinct in-range hashes than s, e.g. small s).
     u32 outn = 0, cin = 0, wrote = 0;
+    if (INRANGE && filt != nullptr && sk_stride == 0u) {
+        // pool mode: count what the row will hold, reserve exactly that, write it
+        u64* out = nullptr;
+        u32 off = 0;
+        bool ok = true;
+        if (m <= 64u) {  // (the usual case: one step, the membership lookups are done once)
+            const bool v = lane < m;
+            const u64 h = v ? hashes[lane] : 0;
+            const bool take = v && lane < s;  // (hashes[0 .. m) are distinct here: the counting sort dropped the duplicates)
+            const bool keep = take && filter_hit(filt, filt_shift, h);
+            const u64 km = __ballot(keep);
+            wrote = (u32)__popcll(km);
+            off = pool_reserve(chk, pool_cap, wrote, ok);
+            if (ok && keep) out_sk[(size_t)off + __popcll(km & lt)] = h;
+        } else {
+            for (int pass = 0; pass < 2; ++pass) {
+                outn = 0; wrote = 0;
+                for (u32 base = 0; base < m && outn < s; base += 64u) {
+                    const u32 i = base + lane;
+                    const bool v = i < m;
+                    const u64 h = v ? hashes[i] : 0;
+                    const bool head = v && (i == 0 || hashes[i - 1] != h);
+                    const u64 mask = __ballot(head);
+                    const u32 pos = outn + __popcll(mask & lt);
+                    const bool keep = head && pos < s && filter_hit(filt, filt_shift, h);
+                    const u64 km = __ballot(keep);
+                    if (pass == 1 && keep) out[wrote + __popcll(km & lt)] = h;
+                    wrote += __popcll(km);
+                    outn += __popcll(mask);
+                }
+                if (pass == 0) {
+                    off = pool_reserve(chk, pool_cap, wrote, ok);
+                    if (!ok) break;
+                    out = out_sk + (size_t)off;
+                }
+            }
+        }
+        if (lane == 0) {
+            out_len[r] = off;                 // the row's place in the pool
+            out_cnt_in[r] = ok ? wrote : 0u;  // (a batch with a failed reservation is repeated with a larger pool)
+        }
+        return;
+    }
     u64* out = out_sk + (size_t)r * sk_stride;
     for (u32 base = 0; base < m && outn < s; base += 64u) {
         const u32 i = base + lane;
@@ -389,7 +447,8 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                                                 const u64* __restrict__ filt, u32 filt_shift, u64 n_bases,
                                                 u32* __restrict__ chk, const unsigned char* lut, bool packed,
                                                 bool split_long = false, u32 seg_i = 0, u64* __restrict__ seg_h = nullptr,
-                                                u32* __restrict__ seg_cnt = nullptr, KmerFilter kf = KmerFilter{nullptr, 0u}) {
+                                                u32* __restrict__ seg_cnt = nullptr, KmerFilter kf = KmerFilter{nullptr, 0u},
+                                                u32 pool_cap = 0) {
     static_assert(!SEG || INRANGE, "segments exist in production mode only");
     constexpr u32 CAP = kSketchCap;
     constexpr u32 kPerWave = HCAP * 8 + CAP + 128 + kPfQueue * 4;  // (32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding; the prefilter's queue)
@@ -670,7 +729,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         }
         return;
     }
-    sketch_finish<HCAP, INRANGE>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift);
+    sketch_finish<HCAP, INRANGE>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift, chk, pool_cap);
     __builtin_amdgcn_s_setprio(0);
 }
 // from_list = 0: wave w of the grid sketches read w.  from_list = 1: a small fixed grid walks the reads an earlier
@@ -684,9 +743,9 @@ constexpr u32 kSegBlocks = 1024;  // x 4 waves: a C4 batch has ~28 000 segments
     const uint8_t *__restrict__ bases, const u64 *__restrict__ offsets, u32 n_reads, u32 k_rt, u64 seed, u32 s, u64 max_ref,  \
         u64 *__restrict__ out_sk, u32 sk_stride, u32 *__restrict__ out_len, u32 *__restrict__ out_cnt_in, u32 from_list,      \
         u32 *__restrict__ retry, u32 *__restrict__ big, const u64 *__restrict__ filt, u32 filt_shift, u64 n_bases,            \
-        u32 *__restrict__ chk, LongReads lr, KmerFilter kf
+        u32 *__restrict__ chk, LongReads lr, KmerFilter kf, u32 pool_cap
 #define SKX_SKETCH_ARGS \
-    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr, kf
+    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr, kf, pool_cap
 template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, unsigned char* lut) {
     const bool packed = (from_list & 0x100u) != 0u;  // (bit 8: 4-bit packed input)
@@ -710,7 +769,7 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
                 sketch_one_read<KT, HCAP, true, true>(smem, lr.list[pos], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
                                                       out_len, out_cnt_in, nullptr, nullptr, filt, filt_shift, n_bases, chk, lut,
                                                       packed, true, sg - lr.seg0[pos], lr.seg_h + (size_t)sg * kSegSlots,
-                                                      lr.seg_cnt + sg, kf);
+                                                      lr.seg_cnt + sg, kf, pool_cap);
                 wave_sync();  // the wave's LDS region is reused by its next segment
             }
             return;
@@ -721,14 +780,14 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
         if (w < n_reads)
             sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
                                                out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut, packed,
-                                               from_list == 2u, 0u, nullptr, nullptr, kf);
+                                               from_list == 2u, 0u, nullptr, nullptr, kf, pool_cap);
         return;
     }
     const u32 n = retry[0];
     for (u32 i = w; i < n; i += gridDim.x * wpb) {
         sketch_one_read<KT, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
                                            out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut, packed, false, 0u,
-                                           nullptr, nullptr, kf);
+                                           nullptr, nullptr, kf, pool_cap);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
 }
@@ -745,7 +804,7 @@ __global__ __launch_bounds__(64) void sketch_merge_kernel(const u64* __restrict_
                                                           u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                           u32* __restrict__ out_cnt_in, u32* __restrict__ big,
                                                           const u64* __restrict__ filt, u32 filt_shift,
-                                                          const u32* __restrict__ chk, LongReads lr) {
+                                                          u32* __restrict__ chk, LongReads lr, u32 pool_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* hashes = reinterpret_cast<u64*>(smem);
     const u32 lane = lane_id();
@@ -773,7 +832,7 @@ __global__ __launch_bounds__(64) void sketch_merge_kernel(const u64* __restrict_
         if (bad) {
             if (lane == 0) { out_len[r] = kSketchRetry; out_cnt_in[r] = 0; list_append(big, r); }
         } else {
-            sketch_finish<kSketchCap, true>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift);
+            sketch_finish<kSketchCap, true>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift, chk, pool_cap);
         }
         wave_sync();  // the buffer is reused by the wave's next read
     }
@@ -829,9 +888,11 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
                                                             const u32* __restrict__ big, u32 n_big, u32 k_rt, u64 seed, u32 s,
                                                             u64 max_ref, u64* __restrict__ out_sk, u32 sk_stride,
                                                             u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
-                                                            const u64* __restrict__ filt, u32 filt_shift, u32 packed) {
+                                                            const u64* __restrict__ filt, u32 filt_shift, u32 packed,
+                                                            u32* __restrict__ chk, u32 pool_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ BlockScratch sh;
+    __shared__ u32 s_off, s_ok;
     u64* hashes = reinterpret_cast<u64*>(smem);
     uint8_t* codes = smem + (size_t)kBigHashes * 8;
     const u32 tid = threadIdx.x, lane = lane_id();
@@ -843,6 +904,26 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
         const u32 lraw = (u32)(offsets[r + 1] - o0);
         const uint8_t* rd = bases + o0;
         u64* out = out_sk + (size_t)r * sk_stride;
+        const bool pool = INRANGE && filt != nullptr && sk_stride == 0u;
+        bool pool_ok = true;
+        if (pool) {
+            // pool mode (sketch_finish): the row is reserved before its size is known -- at most min(s, bases) entries
+            if (tid == 0) {
+                const u32 want = min(s, max(lraw, 1u));
+                const u32 off = atomicAdd(&chk[kChkPool], want);
+                s_off = off;
+                s_ok = (off + want <= pool_cap && off + want >= off) ? 1u : 0u;
+                if (!s_ok) atomicOr(&chk[6], 4u);
+            }
+            __syncthreads();
+            out = out_sk + (size_t)s_off;
+            pool_ok = s_ok != 0u;
+            if (!pool_ok) {  // (the batch is repeated with a larger pool)
+                if (tid == 0) { out_len[r] = 0; out_cnt_in[r] = 0; }
+                __syncthreads();
+                continue;
+            }
+        }
         u64 floor_v = 0;
         bool have_floor = false;
         u32 outn = 0;         // sketch entries emitted so far (distinct hashes, ascending)
@@ -975,7 +1056,7 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
             __syncthreads();
         }
         if (tid == 0) {
-            out_len[r] = min(outn, s);
+            out_len[r] = pool ? s_off : min(outn, s);
             out_cnt_in[r] = (INRANGE && filt != nullptr) ? wrote : cin;
         }
         __syncthreads();
@@ -1013,6 +1094,7 @@ __global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const u64 a = offsets[0], b = offsets[n_reads];
         chk[2] = (u32)a; chk[3] = (u32)(a >> 32); chk[4] = (u32)b; chk[5] = (u32)(b >> 32);
+        chk[kChkPool] = 0;  // the batch's rows start at the beginning of the pool
         *cnt_tail = 0;  // entry n_reads of the per-read pair counts: the exclusive scan runs over n_reads + 1 entries
     }
 }
@@ -1021,15 +1103,20 @@ __global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads,
 // cost ~100 us of idle front stream per push (kernel timeline), this costs a launch.  Also re-arms the device-side
 // counters (chk, the retry list) for the next push.
 __global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, u32* __restrict__ big,
-                               const u32* __restrict__ total_pairs, volatile u32* __restrict__ h_pub, u32 seq) {
+                               const u32* __restrict__ total_pairs, volatile u32* __restrict__ h_pub, u32 seq,
+                               const u32* __restrict__ dict_ctr) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (big) { chk[7] = big[0]; big[0] = 0; }  // (reads that needed the block sketcher: a statistic for the host)
     for (int i = 0; i < 8; ++i) h_pub[i] = chk[i];
     h_pub[9] = chk[9];  // (segments of the batch's long reads: a statistic)
-    for (int i = 0; i < 16; ++i) chk[i] = 0;
+    for (int i = 0; i < 16; ++i)
+        if (i != (int)kChkPool) chk[i] = 0;  // (the pool's bump counter lives on: a block-sketcher round of the same batch reserves behind
+                                             // the rows already there; batch_check_kernel restarts it with the next batch)
     if (retry) retry[0] = 0;
     h_pub[8] = *total_pairs;
+    h_pub[10] = dict_ctr ? dict_ctr[2] + (dict_ctr[1] & 1u) : 0xFFFFFFFFu;  // distinct keys of the speculative gather = |Q| of the pass
+    h_pub[11] = chk[kChkPool];  // row entries the batch asked the pool for (all of them, also when the pool was too small)
     __threadfence_system();
     h_pub[15] = seq;
     __threadfence_system();
@@ -1164,24 +1251,29 @@ __device__ __forceinline__ u32 dict_bucket(u64 key, u32 bshift) { return (u32)mi
 // pair_cap: the pair arrays' capacity.  The kernel can be queued before the host knows how many pairs the reads have
 // (right behind the sketcher, on its stream); when they do not fit one pass it does nothing and the host, which learns
 // the count a moment later, cuts the batch into passes and inserts per pass.
+// sk_stride == 0: pool mode -- read r's row starts at sk + row_off[r] (sketch_finish)
 __global__ void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, const u32* __restrict__ poff, u32 r_begin,
                                    u32 r_end, u32 p_base, u64* __restrict__ pair_h, u32* __restrict__ pair_r,
-                                   u64* __restrict__ ht, u32 ht_mask, u32* __restrict__ ctr, u32 pair_cap) {
+                                   u64* __restrict__ ht, u32 ht_mask, u32* __restrict__ ctr, u32 pair_cap,
+                                   const u32* __restrict__ row_off) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();  // one wave per read
     const u32 r = r_begin + wave;
     if (r >= r_end) return;
     if (poff[r_end] - p_base > pair_cap) return;
     const u32 a = poff[r], b = poff[r + 1];
+    if (b == a) return;
+    const u64* row = sk_stride ? sk + (size_t)r * sk_stride : sk + (size_t)row_off[r];
     for (u32 j = lane; j < b - a; j += 64u) {
-        const u64 key = sk[(size_t)r * sk_stride + j];
+        const u64 key = row[j];
         pair_h[a - p_base + j] = key;
         pair_r[a - p_base + j] = r - r_begin;
         if (key == kPad) { atomicOr(&ctr[1], 1u); continue; }  // the empty marker itself: appended to Q at the end
         u32 slot = (u32)(key ^ (key >> 29)) & ht_mask;
         for (;;) {
             const u64 prev = atomicCAS(&ht[slot], kPad, key);
-            if (prev == kPad || prev == key) break;
+            if (prev == kPad) { atomicAdd(&ctr[2], 1u); break; }  // a new key: ctr[2] = distinct keys in the set (|Q| of the pass)
+            if (prev == key) break;
             slot = (slot + 1u) & ht_mask;
         }
     }
@@ -1256,7 +1348,7 @@ __global__ void dict_bucket_sort_kernel(u64* __restrict__ q, const u32* __restri
         while (j > a && q[j - 1] > v) { q[j] = q[j - 1]; --j; }
         q[j] = v;
     }
-    if (b == 0) ctr[1] = 0;  // (the "saw the all-ones hash" flag; its readers ran in earlier kernels)
+    if (b == 0) { ctr[1] = 0; ctr[2] = 0; }  // (the "saw the all-ones hash" flag and the key count; their readers ran in earlier kernels)
 }
 
 __device__ __forceinline__ u32 lower_bound_u64(const u64* __restrict__ a, u32 n, u64 v) {
@@ -2852,7 +2944,7 @@ static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketch
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
                          const u64* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed,
-                         const LongReads* long_reads, const KmerFilter* kmer_filter, int phase) {
+                         const LongReads* long_reads, const KmerFilter* kmer_filter, int phase, u32 pool_cap) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
     // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 19 KB: 4 instead of 8 of its blocks fit a CU, and when one
@@ -2916,7 +3008,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid,                        \
                        dim3((FROM_LIST) == 1u ? 64 : 256), (FROM_LIST) == 1u ? (LDS) / 4 : (LDS), st, bases,                \
                        offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in,                          \
-                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk, lr, kf)
+                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk, lr, kf, pool_cap)
     (void)blk_grid;
     if (inrange_only) {
         // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
@@ -2937,7 +3029,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
         if (phase & 2) {
             if (first == 2u)
                 hipLaunchKernelGGL(sketch_merge_kernel, dim3(512), dim3(64), (size_t)kSketchCap * 8, st, offsets, s, max_ref, out_sk, sk_stride,
-                                   out_len, out_cnt_in, big, filt, filt_shift, chk, lr);
+                                   out_len, out_cnt_in, big, filt, filt_shift, chk, lr, pool_cap);
             if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); else SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u);
         }
     } else {
@@ -2955,12 +3047,12 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
 // (40-80 us on the sketch stream per push, measured) -- and it almost always is.
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                               const u64* filt, u32 filt_shift, bool packed) {
+                               const u64* filt, u32 filt_shift, bool packed, u32* chk, u32 pool_cap) {
     if (n_big == 0) return hipSuccess;
     const dim3 blk_grid(std::min<u32>(n_big, 256u));
 #define SKX_BLK_LAUNCH(KERNEL)                                                                                              \
     hipLaunchKernelGGL((KERNEL), blk_grid, dim3(1024), kBigLds, st, bases, offsets, big, n_big, k, seed, s, max_ref, out_sk, \
-                       sk_stride, out_len, out_cnt_in, filt, filt_shift, packed ? 1u : 0u)
+                       sk_stride, out_len, out_cnt_in, filt, filt_shift, packed ? 1u : 0u, chk, pool_cap)
     if (k == 16) { if (inrange_only) SKX_BLK_LAUNCH((sketch_block_kernel<16, true>)); else SKX_BLK_LAUNCH((sketch_block_kernel<16, false>)); }
     else { if (inrange_only) SKX_BLK_LAUNCH((sketch_block_kernel<0, true>)); else SKX_BLK_LAUNCH((sketch_block_kernel<0, false>)); }
 #undef SKX_BLK_LAUNCH
@@ -2979,10 +3071,10 @@ void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum
 }
 
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
-                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap) {
+                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap, const u32* row_off) {
     if (r_end <= r_begin) return;
     hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 4)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
-                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap);
+                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off);
 }
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q) {
@@ -3073,8 +3165,8 @@ void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_b
 }
 u32 long_read_split() { return kLongSplit; }
 u32 long_read_seg_slots() { return kSegSlots; }
-void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq) {
-    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, st, chk, retry, big, total_pairs, h_pub, seq);
+void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq, const u32* dict_ctr) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, st, chk, retry, big, total_pairs, h_pub, seq, dict_ctr);
 }
 void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u64* words, bool markers_are_values, unsigned long long* count) {
     if (n == 0) return;

@@ -74,11 +74,13 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
                          u32* retry /* [1 + n_reads] */, u32* big /* [1 + n_reads] */, u64 n_bases, u32* chk,
                          int leave_room /* 0 no, 1 a scan overlaps the start, 2 a scan runs beside most of it */, bool packed = false,
                          const LongReads* long_reads = nullptr, const KmerFilter* kmer_filter = nullptr /* production, k = 16 */,
-                         int phase = 3 /* production batches: 1 = the main kernel only, 2 = only the list walks behind it, 3 = both */);
+                         int phase = 3 /* production batches: 1 = the main kernel only, 2 = only the list walks behind it, 3 = both */,
+                         u32 pool_cap = 0 /* sk_stride == 0 (production): out_sk is a pool of this many entries, out_len receives
+                                             every row's start, chk[11] is the bump counter, chk[6] |= 4 on overflow */);
 // the block sketcher for the n_big reads launch_sketch left on `big` (big[1 ..]); the caller reads the count back first
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                               const u64* filt, u32 filt_shift, bool packed = false);
+                               const u64* filt, u32 filt_shift, bool packed = false, u32* chk = nullptr, u32 pool_cap = 0);
 // exclusive scan of n counts (out[i] = sum of in[0..i)); bsum: [ceil(n / 1024)] scratch
 void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum);
 
@@ -90,8 +92,10 @@ void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q,
 // turns the set into q / n_q, the sorted distinct dictionary, and empties it.
 // ht: hash set of ht_slots (power of two, >= 2 x pairs) u64, all-ones between passes; slot_off: [ht_slots] scratch;
 // bcount: [dict_buckets()] zero between passes; bbase: [dict_buckets()]; btot: [129]; ctr: [4] zero between passes
+// (ctr[1]: the all-ones hash was seen, ctr[2]: distinct keys inserted so far)
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
-                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap);
+                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap,
+                        const u32* row_off = nullptr /* sk_stride == 0: row r starts at sk + row_off[r] */);
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q);
 u32 dict_buckets();
@@ -123,7 +127,9 @@ void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_b
                         const LongReads* long_reads);
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
 // ([7] = number of reads the block sketcher took; `big` is re-armed like `retry`)
-void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq);
+// [10] = distinct keys in the hash set dict_ctr belongs to (the speculative gather's |Q|; 0xFFFFFFFF without dict_ctr)
+void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq,
+                    const u32* dict_ctr /* counters of the set the speculative gather filled, or NULL */);
 // membership filter over the union of the reference hashes (blocked Bloom filter, skx_common.hpp: filter_mask / filter_hit);
 // count != NULL: `words` is a plain bitmap over v >> shift instead and *count receives the bits newly set (distinct values)
 void launch_filter_build(hipStream_t st, const u64* vals, u64 n, u32 shift, u64* words, bool markers_are_values,
