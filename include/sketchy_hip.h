@@ -248,6 +248,8 @@ int skx_dev_free(int device, void *d_ptr);
 int skx_dev_upload(int device, void *d_dst, const void *h_src, size_t bytes);
 int skx_dev_download(int device, void *h_dst, const void *d_src, size_t bytes);
 int skx_dev_synchronize(int device);
+/* free / total bytes of device memory (hipMemGetInfo): what a host sizing several streams per GPU looks at */
+int skx_dev_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* page-locked host memory for batch buffers handed to skx_stream_push / skx_sketch_reads: the H2D copy then runs at
  * full PCIe rate and asynchronously (what a double-buffered FASTX front-end wants; needletail's reader in
  * src/sketchy.rs:89-92 has no counterpart, the reference never leaves the host) */

@@ -70,6 +70,7 @@ SYMBOLS = [
     ("skx_dev_upload", _i, [_i, _vp, _vp, _sz]),
     ("skx_dev_download", _i, [_i, _vp, _vp, _sz]),
     ("skx_dev_synchronize", _i, [_i]),
+    ("skx_dev_mem_info", _i, [_i, C.POINTER(_u64), C.POINTER(_u64)]),
     ("skx_host_alloc", _i, [_i, _pp, _sz]),
     ("skx_host_free", _i, [_i, _vp]),
 ]

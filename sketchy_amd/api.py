@@ -59,6 +59,13 @@ def device_info(device=0):
     return dict(name=name.value.decode(), compute_units=cu.value, total_mem=mem.value)
 
 
+def device_mem(device=0):
+    """(free, total) bytes of device memory"""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(_lib.load().skx_dev_mem_info(device, C.byref(f), C.byref(t)))
+    return f.value, t.value
+
+
 class ReferenceSketch:
     """Reference sketch collection(s) resident in HBM.  hashes: [n_genomes, s] uint64, row g = genome g's ascending
     distinct hashes, first col_len[g] valid -- or a LIST of such matrices, one per species (same s, k, seed): they are

@@ -113,6 +113,14 @@ SKX_API int skx_host_free(int device, void* h_ptr) {
     HIPCHK(hipHostFree(h_ptr));
     return SKX_OK;
 }
+SKX_API int skx_dev_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    SKXCHK(use_device(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return SKX_OK;
+}
 SKX_API int skx_dev_synchronize(int device) {
     SKXCHK(use_device(device));
     HIPCHK(hipDeviceSynchronize());
@@ -658,18 +666,23 @@ static void stream_free(skx_stream* st) {
 static hipError_t alloc_side(skx_stream* st, int i) {
     hipError_t e;
     // the pool: 16 row entries per read of the largest batch (C2 keeps 2.4, C4 3.9), never less than 2^20 -- and never more
-    // than full-width rows would take, so small streams cannot overflow it at all; a batch that does is repeated with a
+    // than the worst case needs (every read a full-width row; the pool is cut into 64 sub-pools, a workgroup of four reads
+    // uses sub-pool blockIdx % 64), so small streams cannot overflow it at all; a batch that does is repeated with a
     // larger pool (batch_back)
-    st->pool_cap[i] = std::min<u64>((u64)st->max_reads * st->sk_stride, std::max<u64>((u64)st->max_reads * 16, 1u << 20));
-    st->pool_cap[i] = std::min<u64>(std::max<u64>(st->pool_cap[i], 64), 0xFFFFFFF0ull);
+    {
+        const u64 groups = ((u64)st->max_reads + 3) / 4, per_part = ((groups + 63) / 64) * 4 + 8;
+        const u64 worst = 64 * per_part * st->sk_stride;
+        st->pool_cap[i] = std::min<u64>(worst, std::max<u64>((u64)st->max_reads * 16, 1u << 20));
+    }
+    st->pool_cap[i] = std::min<u64>(std::max<u64>(st->pool_cap[i], 4096), 0xFFFFFF00ull);
     if ((e = hipMalloc(&st->sd_sk[i], (size_t)st->pool_cap[i] * 8)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_len[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_cnt[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_poff[i], ((size_t)st->max_reads + 2) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_big[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_retry[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
-    if ((e = hipMalloc(&st->sd_chk[i], 64)) != hipSuccess) return e;
-    if ((e = hipMemset(st->sd_chk[i], 0, 64)) != hipSuccess) return e;
+    if ((e = hipMalloc(&st->sd_chk[i], (size_t)skx::chk_words() * 4)) != hipSuccess) return e;
+    if ((e = hipMemset(st->sd_chk[i], 0, (size_t)skx::chk_words() * 4)) != hipSuccess) return e;
     if ((e = hipMemset(st->sd_retry[i], 0, 4)) != hipSuccess) return e;
     if (st->max_bases > skx::long_read_split()) {  // (a batch that can hold a long read at all)
         skx::LongReads& lr = st->sd_lr[i];

@@ -124,7 +124,13 @@ __global__ __launch_bounds__(256) void band_bounds_kernel(const u64* __restrict_
 //   HCAP = kSketchCap  -> `big`   (redone by sketch_block_kernel, which holds 16 384 hashes and selects in passes)
 // !INRANGE (full sketches: debug outputs, skx_sketch_reads): reads with more than kSketchCap k-mers go to `big` at once.
 constexpr u32 kSketchRetry = 0xFFFFFFFFu;
-constexpr u32 kChkPool = 11;  // chk[11]: bump counter of the row pool (sketch_finish, pool mode)
+// Row pool (sketch_finish, pool mode): kPoolParts sub-pools, each with its own bump counter on its own cache line behind the 16
+// words of chk (chk[16 + 16 i]); a workgroup uses sub-pool blockIdx.x % kPoolParts.  (ONE counter serialised the batch:
+// 98 304 same-address atomics at ~10 ns each are 1 ms -- twice the sketch kernel -- measured as 48 -> 37 M reads/s for a
+// lone C2 batch.)  chk[11] = the entries the batch asked for, summed by publish_kernel.
+constexpr u32 kChkPool = 11;
+constexpr u32 kPoolParts = 64;
+constexpr u32 kChkWords = 16 + 16 * kPoolParts;  // u32 words of a chk block
 // list layout: [0] = number of entries, [1..] = read indices
 __device__ __forceinline__ void list_append(u32* __restrict__ list, u32 r) { list[1u + atomicAdd(&list[0], 1u)] = r; }
 
@@ -303,12 +309,13 @@ __global__ __launch_bounds__(256) void kmer_filter_build_kernel(u64 seed, u64 ma
 // does not fit raises chk[6] |= 4 and writes nothing; chk[11] still sums every request, so the host knows how much to allocate
 // before it repeats the batch (rare: a pool holds 16 pairs per read of the largest batch, C2 needs 2.4).
 __device__ __forceinline__ u32 pool_reserve(u32* __restrict__ chk, u32 pool_cap, u32 want /* wave-uniform */, bool& ok) {
+    const u32 part = blockIdx.x % kPoolParts, part_cap = pool_cap / kPoolParts;
     u32 off = 0;
-    if (lane_id() == 0 && want) off = atomicAdd(&chk[kChkPool], want);
+    if (lane_id() == 0 && want) off = atomicAdd(&chk[16u + 16u * part], want);
     off = __builtin_amdgcn_readfirstlane(off);
-    ok = off + want <= pool_cap && off + want >= off;
+    ok = off + want <= part_cap && off + want >= off;
     if (!ok && lane_id() == 0) atomicOr(&chk[6], 4u);
-    return off;
+    return part * part_cap + off;
 }
 template <int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, u64 max_ref, u64* __restrict__ out_sk,
@@ -910,9 +917,10 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
             // pool mode (sketch_finish): the row is reserved before its size is known -- at most min(s, bases) entries
             if (tid == 0) {
                 const u32 want = min(s, max(lraw, 1u));
-                const u32 off = atomicAdd(&chk[kChkPool], want);
-                s_off = off;
-                s_ok = (off + want <= pool_cap && off + want >= off) ? 1u : 0u;
+                const u32 part = blockIdx.x % kPoolParts, part_cap = pool_cap / kPoolParts;
+                const u32 off = atomicAdd(&chk[16u + 16u * part], want);
+                s_off = part * part_cap + off;
+                s_ok = (off + want <= part_cap && off + want >= off) ? 1u : 0u;
                 if (!s_ok) atomicOr(&chk[6], 4u);
             }
             __syncthreads();
@@ -1094,7 +1102,7 @@ __global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const u64 a = offsets[0], b = offsets[n_reads];
         chk[2] = (u32)a; chk[3] = (u32)(a >> 32); chk[4] = (u32)b; chk[5] = (u32)(b >> 32);
-        chk[kChkPool] = 0;  // the batch's rows start at the beginning of the pool
+        for (u32 i = 0; i < kPoolParts; ++i) chk[16u + 16u * i] = 0;  // the batch's rows start at the beginning of every sub-pool
         *cnt_tail = 0;  // entry n_reads of the per-read pair counts: the exclusive scan runs over n_reads + 1 entries
     }
 }
@@ -1110,13 +1118,19 @@ __global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, u
     if (big) { chk[7] = big[0]; big[0] = 0; }  // (reads that needed the block sketcher: a statistic for the host)
     for (int i = 0; i < 8; ++i) h_pub[i] = chk[i];
     h_pub[9] = chk[9];  // (segments of the batch's long reads: a statistic)
-    for (int i = 0; i < 16; ++i)
-        if (i != (int)kChkPool) chk[i] = 0;  // (the pool's bump counter lives on: a block-sketcher round of the same batch reserves behind
-                                             // the rows already there; batch_check_kernel restarts it with the next batch)
+    for (int i = 0; i < 16; ++i) chk[i] = 0;  // (the sub-pools' bump counters behind these 16 words live on: a block-sketcher round
+                                              // of the same batch reserves behind the rows already there; batch_check_kernel
+                                              // restarts them with the next batch)
     if (retry) retry[0] = 0;
     h_pub[8] = *total_pairs;
     h_pub[10] = dict_ctr ? dict_ctr[2] + (dict_ctr[1] & 1u) : 0xFFFFFFFFu;  // distinct keys of the speculative gather = |Q| of the pass
-    h_pub[11] = chk[kChkPool];  // row entries the batch asked the pool for (all of them, also when the pool was too small)
+    {
+        // row entries the batch asked the pool for: kPoolParts x the fullest sub-pool's request (what a pool must hold for the
+        // same batch to fit), also when the pool was too small
+        u32 worst = 0;
+        for (u32 i = 0; i < kPoolParts; ++i) worst = max(worst, chk[16u + 16u * i]);
+        h_pub[11] = (u32)min((u64)worst * kPoolParts, (u64)0xFFFFFFFFu);
+    }
     __threadfence_system();
     h_pub[15] = seq;
     __threadfence_system();
@@ -3163,6 +3177,7 @@ void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_b
     hipLaunchKernelGGL(batch_check_kernel, dim3(std::min<u32>(cdiv(n_reads, 256), 1024u)), dim3(256), 0, st, offsets, n_reads, n_bases, chk,
                        cnt_tail, lr);
 }
+u32 chk_words() { return kChkWords; }
 u32 long_read_split() { return kLongSplit; }
 u32 long_read_seg_slots() { return kSegSlots; }
 void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq, const u32* dict_ctr) {

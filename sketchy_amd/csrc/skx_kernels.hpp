@@ -49,6 +49,7 @@ struct LongReads {
 };
 u32 long_read_split();
 u32 long_read_seg_slots();
+u32 chk_words();  // u32 words of a `chk` block: 16 flags / counters + the row pool's bump counters (one cache line each)
 
 // k-mer prefilter (k = 16): a two-probe blocked Bloom table over the 2-bit code of the CANONICAL k-mer, holding every
 // k-mer whose MurmurHash3 value passes the reference's membership filter (<= max_ref and bit set) -- built once per

@@ -203,6 +203,72 @@ def test_a_refused_batch_leaves_nothing_behind(gpu):
         d.free()
 
 
+def test_row_pool_grows_when_a_batch_is_denser_than_it_is_sized_for(gpu):
+    """Production sketch rows are exact-size reservations out of a per-side pool (16 pairs per read of the largest batch, at
+    least 2^20 entries).  9 000 reads with ~160 pairs each ask for more: the summary reports the overflow and the request,
+    the pool is re-allocated and the batch sketched again -- same rows as the oracle, through push_device and enqueue_device,
+    with ordinary batches before and after, and the block-sketcher path on top (long dense reads)."""
+    from sketchy_amd import api, synth
+    ref = synth.make_reference(24, 3000, genome_len=24000, rng_seed=811, device="numpy")
+    dense_b, dense_o = synth.make_reads(ref["genome"], 9000, 1500, err=0.01, rng_seed=812)
+    long_b, long_o = synth.make_reads(ref["genome"], 6, 20000, err=0.01, rng_seed=813)
+    reads = [dense_b[int(dense_o[i]):int(dense_o[i + 1])].tobytes() for i in range(9000)]
+    longs = [long_b[int(long_o[i]):int(long_o[i + 1])].tobytes() for i in range(6)]
+    stream = reads[:50] + reads[50:9000] + longs + reads[:200]
+    cuts = [0, 50, 9000, 9006, 9206]
+    bases, offsets = pack_reads(stream)
+    exp = _expect(ref["ref"], 3000, bases, offsets, 1)
+    R = api.ReferenceSketch(ref["ref"])
+    for entry in ("enqueue", "push"):
+        S = api.SumOfSharedHashes(R, top=1, max_batch_reads=9000, max_batch_bases=int(np.diff(offsets[cuts].astype(np.int64)).max()))
+        if entry == "enqueue":
+            idx, val = _enqueue_stream(S, bases, offsets, cuts, 1)
+        else:
+            d_b = api.DeviceBuffer.from_numpy(bases)
+            parts = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                d_o = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[a:b + 1]))
+                d_i, d_s = api.DeviceBuffer((b - a) * 4), api.DeviceBuffer((b - a) * 8)
+                S.push_device(d_b.ptr, d_o.ptr, b - a, int(offsets[b] - offsets[a]), d_i.ptr, d_s.ptr)
+                S.sync()
+                parts.append((d_i.to_numpy(np.uint32, (b - a, 1)), d_s.to_numpy(np.uint64, (b - a, 1))))
+                for d in (d_o, d_i, d_s):
+                    d.free()
+            d_b.free()
+            idx, val = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        np.testing.assert_array_equal(idx, exp["topk_idx"], err_msg=entry)
+        np.testing.assert_array_equal(val, exp["topk_sum"], err_msg=entry)
+        np.testing.assert_array_equal(S.table(), exp["cum"], err_msg=entry)
+        st = S.stats()
+        assert st["row_pool_grown"] >= 1 and st["reads_block_sketcher"] >= 1, st
+        S.close()
+
+
+def test_more_distinct_query_hashes_than_matrix_rows(gpu):
+    """The bit matrices of a pass have `stream_query_rows` rows (default 65 536); a batch whose distinct query hashes exceed
+    them -- known from the speculative gather's key count in the published summary -- is cut into passes by its pair
+    counts.  Forced with 128 rows: rows and table as the oracle's, several passes, the younger batch's speculation undone."""
+    from sketchy_amd import api
+    ref, bases, offsets = workload(300, 500, 900, read_len=700, rng_seed=821)
+    exp = _expect(ref["ref"], 500, bases, offsets, 2)
+    R = api.ReferenceSketch(ref["ref"])
+    try:
+        api.set_option("stream_query_rows", 128)
+        S = api.SumOfSharedHashes(R, top=2, max_batch_reads=400, max_batch_bases=400 * 700)
+    finally:
+        api.set_option("stream_query_rows", 0)
+    idx, val = _enqueue_stream(S, bases, offsets, [0, 5, 400, 401, 800, 900], 2)
+    np.testing.assert_array_equal(idx, exp["topk_idx"])
+    np.testing.assert_array_equal(val, exp["topk_sum"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    assert S.stats()["passes"] > 8
+    S.reset()
+    got = S.push(bases, offsets[:301], want_shared=True)
+    full = orc.stream(16, 0, 500, ref["ref"], np.full(300, 500, np.uint32), bases, offsets[:301], top_k=2, want_shared=True)
+    np.testing.assert_array_equal(got["shared"], full["shared"])
+    np.testing.assert_array_equal(got["topk_idx"], full["topk_idx"])
+
+
 @pytest.mark.parametrize("env", [{"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "2"}, {"SKX_PIPELINE": "1"}, {"SKX_PASS_READS": "128"}])
 def test_enqueue_under_other_placements(gpu, env):
     """the same stream with the pair gather on the scan stream (never speculative), with fewer pipeline streams, and with

@@ -150,6 +150,37 @@ def test_oracle_sample_at_full_size(c2):
     np.testing.assert_array_equal(S.table(), exp["cum"])
 
 
+def test_c2_footprint_and_four_streams_on_one_reference(c2):
+    """C2 at full size: the reference (3.2 GB of hashes + filter + k-mer table) and ONE full-batch stream take less than 8 GB
+    of device memory together (rounds 1-2: ~75 GB -- rows and bit matrices sized for debug outputs and pair counts); four
+    streams share the reference, each scores its own reads."""
+    from sketchy_amd import api
+    R, bases, offsets = c2["R"], c2["bases"], c2["offsets"]
+    free0, total = api.device_mem(0)
+    streams = []
+    for i in range(4):
+        streams.append(api.SumOfSharedHashes(R, top=1, max_batch_reads=B_FULL, max_batch_bases=B_FULL * 1500))
+        if i == 0:
+            free1, _ = api.device_mem(0)
+    free4, _ = api.device_mem(0)
+    one = free0 - free1
+    ref_bytes = R.pass_bytes + 64 * (1 << 20)  # matrix + filter + k-mer table (upper bound)
+    assert one + ref_bytes < 8 * (1 << 30), (one, ref_bytes)
+    assert free0 - free4 < 4 * one + (1 << 30)
+    tables = []
+    for i, S in enumerate(streams):
+        S.push(bases, offsets[i * 2048:(i + 1) * 2048 + 1])
+        tables.append(S.table())
+    S0 = streams[0]
+    S0.reset()
+    S0.push(bases, offsets[3 * 2048:4 * 2048 + 1])
+    np.testing.assert_array_equal(S0.table(), tables[3])
+    assert not np.array_equal(tables[0], tables[1])
+    print("footprint: one stream %.2f GB, reference <= %.2f GB" % (one / 2**30, ref_bytes / 2**30))
+    for S in streams:
+        S.close()
+
+
 @pytest.mark.parametrize("split,big", [("0", "0"), ("1", "0"), ("1", "1")])
 def test_forced_scan_kernel_variants(gpu, split, big):
     """The split-array and big-table scan variants are picked automatically only for dense full-size passes;
