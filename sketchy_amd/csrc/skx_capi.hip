@@ -568,6 +568,7 @@ struct skx_stream {
     u32* h_chk_base = nullptr;
     u32 pub_seq = 0;         // sequence number of the latest publish
     bool chk_dirty = false;  // a push failed between arming and publishing: re-zero the device-side counters first
+    u64* d_rowany[2] = {nullptr, nullptr};   // [rank groups][qcap / 64] per buffer set: which query rows hold a bit for the group
     u32* d_grp_any[2] = {nullptr, nullptr};  // [rank groups + 1] per buffer set: the group's slice of the bit matrix holds any
                                              // bit; last word = "M itself was written this pass" (m_dirty)
     u64* d_hbuf = nullptr;                   // slabs of the lean scan kernel, [bands * tiles][scan_lean_words()][256]
@@ -619,7 +620,7 @@ static void stream_free(skx_stream* st) {
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc2[0], st->d_inc2[1] != st->d_inc2[0] ? st->d_inc2[1] : nullptr,
                     st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_has, st->d_lead_seg, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
-                    st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1]};
+                    st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1]};
     for (void* p : ptrs) (void)hipFree(p);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
@@ -875,6 +876,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_rank_sum, (size_t)st->rank_cap * 8));
     SCHK(hipMalloc(&st->d_bsum, ((size_t)max_reads / 1024 + 2) * 4));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64) + 1) * 4));
+    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_rowany[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (st->qcap / 64) * 8));
     if (skx::scan_lean_applies(ref->n_bands, false, false)) {
         SCHK(hipMalloc(&st->d_hbuf, (size_t)n_bt * skx::scan_lean_words() * skx::kTileGenomes * 8));
         for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_wb[i], ((size_t)st->qcap / 64 + 1) * ref->n_tiles * 16));
@@ -1096,7 +1098,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         {
             Span sp(st, 3, hs);
             skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq, d_grp_any,
-                                       lean ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, nq_est);
+                                       lean ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, nq_est, st->d_rowany[b]);
         }
     }
     if (P == 0) SKXCHK(wait_back());
@@ -1115,7 +1117,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         // (the chunk sums are accumulated by seg_sum's workgroups: four atomic adds per chunk and genome)
         HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * n_pad * 4, hs3));
         skx::launch_seg_sum(hs3, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
-                            d_csum_raw);
+                            d_csum_raw, P > 0 ? st->d_rowany[b] : nullptr, d_nq);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(st->ev_inc[b], hs3));

@@ -1129,7 +1129,7 @@ __global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, u
         // same batch to fit), also when the pool was too small
         u32 worst = 0;
         for (u32 i = 0; i < kPoolParts; ++i) worst = max(worst, chk[16u + 16u * i]);
-        h_pub[11] = (u32)min((u64)worst * kPoolParts, (u64)0xFFFFFFFFu);
+        h_pub[kChkPool] = (u32)min((u64)worst * kPoolParts, (u64)0xFFFFFFFFu);
     }
     __threadfence_system();
     h_pub[15] = seq;
@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
                                                              const u32* __restrict__ n_q, u32* __restrict__ grp_any,
                                                              const u64* __restrict__ hbuf, const u32* __restrict__ wb,
                                                              const u32* __restrict__ win, u32 n_tiles,
-                                                             const u32* __restrict__ m_dirty) {
+                                                             const u32* __restrict__ m_dirty, u64* __restrict__ rowany) {
     __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u64 tile[2][64][kRankWords + 1];
     // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
     const u32 live_words = min(n_words, (*n_q + 63u) >> 6);
     const u32 grp = blockIdx.x;
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
-    u64 seen = 0;
+    u32 nz_rows = 0;  // (wave 0, lane 0) rows of this group that hold any bit, over the block's words
     for (u32 w0 = blockIdx.y * kWordsPerBlock; w0 < live_words; w0 += gridDim.y * kWordsPerBlock) {
     const u32 w1 = min(live_words, w0 + kWordsPerBlock);
     const bool read_m = hbuf == nullptr || *m_dirty != 0u;
@@ -1914,11 +1914,22 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
     for (u32 i = 0; i < kWordsPerBlock; ++i) {
         const u32 w = w0 + i;
         if (w >= w1) break;
-        seen |= xs[i][0] | xs[i][1];
         const u32 bsel = i & 1u;
         tile[bsel][lane][wv] = transpose64(xs[i][0], lane);
         tile[bsel][lane][wv + 4u] = transpose64(xs[i][1], lane);
         __syncthreads();  // (double-buffered tile: one barrier per word is enough)
+        if (wv == 0u) {
+            // rowany[grp][w]: bit r = query row 64 w + r holds a bit for some genome of this group (the ranking's kernels skip
+            // the all-zero rows of sparse groups); the group's count of such rows replaces the old "any bit" flag
+            u64 any = 0;
+#pragma unroll
+            for (u32 c = 0; c < (u32)kRankWords; ++c) any |= tile[bsel][lane][c];
+            const u64 rm = __ballot(any != 0ull);
+            if (lane == 0u) {
+                if (rowany) rowany[(size_t)grp * n_words + w] = rm;
+                nz_rows += (u32)__popcll(rm);
+            }
+        }
         if (grp * kRankWords + cw < n_gw) {
             mq[mq_index(grp * kRankWords + cw, w * 64u + row, n_words * 64u)] = tile[bsel][row][cw];
             mq[mq_index(grp * kRankWords + cw, w * 64u + row + 32u, n_words * 64u)] = tile[bsel][row + 32u][cw];
@@ -1926,7 +1937,7 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
     }
     __syncthreads();  // (the tile buffers are reused by the block's next word group)
     }
-    if (__ballot(seen != 0) && lane == 0) grp_any[grp] = 1u;  // (plain store of the same value from several waves)
+    if (wv == 0u && lane == 0u && nz_rows) atomicAdd(&grp_any[grp], nz_rows);  // rows with any bit: 0 = the group is dead this pass
 }
 
 // =====================================================================================
@@ -1968,6 +1979,7 @@ __device__ __forceinline__ MaskVec gather_vec(const u64* __restrict__ mq_g, u32 
 //     each followed by a ripple add of the two plane stacks -- after which lane (sub, j) holds 9 planes x 8 bits:
 //     the totals of genomes sub*8 .. sub*8+7 of word j;
 //   * those 8 counts are extracted once per block of <= 448 pairs and stored as 32 contiguous bytes per lane.
+constexpr u32 kSparseQueue = 256;  // query rows a wave parks in LDS while it compacts a sparse group's pairs (<= kBlockPairs)
 #define SKX_CSA(H, L, A, B, C)                 \
     {                                          \
         const u64 u_ = (A) ^ (B);              \
@@ -1992,7 +2004,8 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                       u32 nq_rows, u32* __restrict__ inc, const u32* __restrict__ grp_any,
-                                                      u32* __restrict__ qsum) {
+                                                      u32* __restrict__ qsum, const u64* __restrict__ rowany,
+                                                      const u32* __restrict__ n_q) {
     __builtin_amdgcn_s_setprio(SKX_SEGSUM_PRIO);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     static_assert(kRankWords == 8, "lane = (sub, word) layout assumes 8 words per rank group");
     const u32 lane = lane_id();
@@ -2006,6 +2019,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     // (Summed through 8 KB of LDS first.  Every wave adding its own counts straight to global memory -- no LDS, four times
     // the atomics, scattered 32 bytes per lane -- was measured: 74 -> 39 M reads/s.)
     __shared__ u32 red[4][kRankWords * 64];
+    __shared__ u32 squeue[4][kSparseQueue];
     const u32 xcd = blockIdx.x & 7u, wv = threadIdx.x >> 6;
     const u32 n_q4 = (n_seg + 3u) / 4u, blk = blockIdx.x >> 3;
     const u32 grp = (blk / n_q4) * 8u + xcd, seg4 = blk % n_q4;
@@ -2019,30 +2033,19 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0;
     constexpr u32 kBlockPairs = 8u * 56u;  // <= 56 rows per lane and block: six planes hold the lane's counts
-    for (u32 b0 = pa; b0 < pz; b0 += kBlockPairs) {
-        const u32 bz = min(pz, b0 + kBlockPairs);
+    // Addressing kept off the VALU: the group's slice of Mq and the pair list are wave-uniform bases (scalar registers), a
+    // lane's row word is at byte offset (q << 6 | j * 8) and its slot of the pair list at 4 * (p0 + sub) + 32 u -- both fit
+    // 32 bits (a pass holds at most 2^22 pairs / rows), so a load costs one VALU instruction instead of five.  Full steps
+    // of 64 pairs take no bounds tests at all; only a block's last, partial step masks the rows past its end (re-read
+    // from the block's last pair: always a valid address).  (Conditional loads had become sixteen exec-mask branches per
+    // step: 160 VALU instructions per step, 80 of them the counting itself.)
+    const char* const mq_base = reinterpret_cast<const char*>(mq + (size_t)grp * nq_rows * kRankWords);
+    const char* const pq_base = reinterpret_cast<const char*>(pair_q);
+    const u32 j8 = j * 8u;
+    auto row_at = [&](u32 q) -> u64 { return *reinterpret_cast<const u64*>(mq_base + (size_t)((q << 6) | j8)); };
+    // one block: cnt <= kBlockPairs pairs, q_at(i) = the query row of its i-th pair (i < cnt)
+    auto count_block = [&](u32 cnt, auto q_at) {
         u64 ones = 0, twos = 0, fours = 0, eights = 0, sixteens = 0, thirtytwos = 0;
-        // the query indices of the next 64 pairs are requested before the current rows are counted (one memory round trip
-        // per step instead of two in a row; requesting the rows ahead as well needs 82 VGPRs and lost: 417 -> 725 us)
-        // Addressing kept off the VALU: the group's slice of Mq and the pair list are wave-uniform bases (scalar registers), a
-        // lane's row word is at byte offset (q << 6 | j * 8) and its slot of the pair list at 4 * (p0 + sub) + 32 u -- both fit
-        // 32 bits (a pass holds at most 2^22 pairs / rows), so a load costs one VALU instruction instead of five.  Full steps
-        // of 64 pairs take no bounds tests at all; only the block's last, partial step masks the rows past its end (re-read
-        // from the block's last pair: always a valid address).  (Conditional loads had become sixteen exec-mask branches per
-        // step: 160 VALU instructions per step, 80 of them the counting itself.)
-        const char* const mq_base = reinterpret_cast<const char*>(mq + (size_t)grp * nq_rows * kRankWords);
-        const char* const pq_base = reinterpret_cast<const char*>(pair_q);
-        const u32 j8 = j * 8u;
-        auto row_at = [&](u32 q) -> u64 { return *reinterpret_cast<const u64*>(mq_base + (size_t)((q << 6) | j8)); };
-        auto load_q = [&](u32 p0, u32 (&qv)[8]) {  // (a full step's worth of pairs exists from p0 on)
-            const char* at = pq_base + (size_t)((p0 + sub) * 4u);
-#pragma unroll
-            for (u32 u = 0; u < 8u; ++u) qv[u] = *reinterpret_cast<const u32*>(at + 32u * u);
-        };
-        auto load_q_tail = [&](u32 p0, u32 (&qv)[8]) {
-#pragma unroll
-            for (u32 u = 0; u < 8u; ++u) qv[u] = *reinterpret_cast<const u32*>(pq_base + (size_t)(min(p0 + 8u * u + sub, bz - 1u) * 4u));
-        };
         auto count8 = [&](const u64 (&x)[8]) {
             u64 twos_a, twos_b, fours_a, fours_b, eights_a;
             SKX_CSA(twos_a, ones, ones, x[0], x[1])
@@ -2058,22 +2061,33 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
             sixteens ^= c8;
             thirtytwos ^= c16;  // (<= 56 rows: no carry out of the sixth plane)
         };
+        // the query indices of the next 64 pairs are requested before the current rows are counted (one memory round trip
+        // per step instead of two in a row; requesting the rows ahead as well needs 82 VGPRs and lost: 417 -> 725 us)
+        auto load_q = [&](u32 i0, u32 (&qv)[8]) {
+            if (i0 + 64u <= cnt) {
+#pragma unroll
+                for (u32 u = 0; u < 8u; ++u) qv[u] = q_at(i0 + 8u * u + sub);
+            } else {
+#pragma unroll
+                for (u32 u = 0; u < 8u; ++u) qv[u] = q_at(min(i0 + 8u * u + sub, cnt - 1u));
+            }
+        };
         u32 qn[8];
-        u32 p0 = b0;
-        if (p0 + 64u <= bz) load_q(p0, qn); else load_q_tail(p0, qn);
-        for (; p0 + 64u <= bz; p0 += 64u) {  // full steps
+        u32 i0 = 0;
+        load_q(0, qn);
+        for (; i0 + 64u <= cnt; i0 += 64u) {  // full steps
             u64 x[8];
 #pragma unroll
             for (u32 u = 0; u < 8u; ++u) x[u] = row_at(qn[u]);
-            if (p0 + 128u <= bz) load_q(p0 + 64u, qn); else if (p0 + 64u < bz) load_q_tail(p0 + 64u, qn);
+            if (i0 + 64u < cnt) load_q(i0 + 64u, qn);
             count8(x);
         }
-        if (p0 < bz) {  // the last, partial step
+        if (i0 < cnt) {  // the last, partial step
             u64 x[8];
 #pragma unroll
             for (u32 u = 0; u < 8u; ++u) {
                 const u64 row = row_at(qn[u]);
-                x[u] = p0 + 8u * u + sub < bz ? row : 0ull;
+                x[u] = i0 + 8u * u + sub < cnt ? row : 0ull;
             }
             count8(x);
         }
@@ -2106,21 +2120,61 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
         add_planes<8>(x, y);  // 9 planes x 8 bits: bit i of plane b = bit b of the count of genome sub*8 + i
         // counts out of the planes: the 8 x 8 bits of planes 0..7 are one 64-bit bit matrix (byte b = plane b, bit i = genome
         // i); its transpose has genome i's low 8 count bits in byte i (three masked-swap steps instead of 8 x 9 single-bit
-        // extractions: ~70 instead of ~150 instructions per block and wave), plane 8 adds bit 8
+        // extractions), plane 8 adds bit 8
         {
             u64 t = make_u64(x[0] | (x[1] << 8) | (x[2] << 16) | (x[3] << 24), x[4] | (x[5] << 8) | (x[6] << 16) | (x[7] << 24));
-            u64 y = (t ^ (t >> 7)) & 0x00AA00AA00AA00AAull;
-            t ^= y ^ (y << 7);
-            y = (t ^ (t >> 14)) & 0x0000CCCC0000CCCCull;
-            t ^= y ^ (y << 14);
-            y = (t ^ (t >> 28)) & 0x00000000F0F0F0F0ull;
-            t ^= y ^ (y << 28);
+            u64 y2 = (t ^ (t >> 7)) & 0x00AA00AA00AA00AAull;
+            t ^= y2 ^ (y2 << 7);
+            y2 = (t ^ (t >> 14)) & 0x0000CCCC0000CCCCull;
+            t ^= y2 ^ (y2 << 14);
+            y2 = (t ^ (t >> 28)) & 0x00000000F0F0F0F0ull;
+            t ^= y2 ^ (y2 << 28);
             const u32 tl = (u32)t, th = (u32)(t >> 32), top = x[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 acc[i] += ((tl >> (8 * i)) & 0xFFu) + (((top >> i) & 1u) << 8);
                 acc[i + 4] += ((th >> (8 * i)) & 0xFFu) + (((top >> (i + 4)) & 1u) << 8);
             }
+        }
+    };
+    // SPARSE groups (few of the dictionary's rows hold a bit for any genome of the group: a species the sample does not belong
+    // to still shares a handful of its k-mers with every other species' genomes -- at k = 16 two random 2.8 Mb genomes share
+    // ~3 600 -- so none of its rank groups is without bits, but 98 % of a segment's rows are zero for them): the pairs whose
+    // row holds anything (rowany, one bit per (group, query row), written by the transpose) are compacted into the wave's LDS
+    // queue first, and only those are counted -- usually none or a single partial step per segment instead of four full ones.
+    const u32 nq = *n_q;
+    const bool sparse = rowany != nullptr && grp_any[grp] * 4u < nq;
+    if (sparse) {
+        const u64* ra_g = rowany + (size_t)grp * (nq_rows >> 6);
+        u32* queue = squeue[wv];
+        const u64 lt = lanemask_lt();
+        u32 qcount = 0;
+        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+            const u32 p = p0 + lane;
+            const bool ok = p < pz;
+            const u32 q = ok ? pair_q[p] : 0u;
+            const bool nz = ok && ((ra_g[q >> 6] >> (q & 63u)) & 1ull);
+            const u64 m = __ballot(nz);
+            if (m) {
+                if (nz) queue[qcount + (u32)__popcll(m & lt)] = q;
+                qcount = __builtin_amdgcn_readfirstlane(qcount + (u32)__popcll(m));
+                if (qcount > kSparseQueue - 64u) {
+                    wave_sync();
+                    count_block(qcount, [&](u32 i) -> u32 { return queue[i]; });
+                    qcount = 0;
+                    wave_sync();
+                }
+            }
+        }
+        if (qcount) {
+            wave_sync();
+            count_block(qcount, [&](u32 i) -> u32 { return queue[i]; });
+        }
+    } else {
+        for (u32 b0 = pa; b0 < pz; b0 += kBlockPairs) {
+            const u32 cnt = min(pz, b0 + kBlockPairs) - b0;
+            const char* at = pq_base + (size_t)(b0 * 4u);
+            count_block(cnt, [&](u32 i) -> u32 { return *reinterpret_cast<const u32*>(at + (size_t)(i * 4u)); });
         }
     }
     const u32 gw = grp * kRankWords + j;
@@ -3163,14 +3217,14 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
     else hipLaunchKernelGGL((scan_kernel<2040, 0, false>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
 }
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any,
-                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64 nq_est) {
+                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64 nq_est, u64* rowany) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     // y extent: twice the estimated dictionary size (the blocks stride, see the kernel), at most what the pairs allow
     const u32 y_all = cdiv(n_words, kWordsPerBlock);
     const u32 y_est = (u32)std::min<u64>(y_all, std::max<u64>(16, cdiv((u32)std::min<u64>(2 * nq_est / 64 + 1, 0xFFFFFFF0u), kWordsPerBlock)));
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), std::min(y_est, 65535u)), dim3(256), 0, st,
-                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty);
+                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty, rowany);
 }
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_bases, u32* chk, u32* cnt_tail, const LongReads* long_reads) {
     const LongReads lr = long_reads ? *long_reads : LongReads{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
@@ -3194,12 +3248,12 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any,
-                    u32* qsum /* [ceil(n_seg / 16)][n_pad]: the chunk sums, zero on entry */) {
+                    u32* qsum /* [ceil(n_seg / 16)][n_pad]: the chunk sums, zero on entry */, const u64* rowany, const u32* n_q) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     const u32 n_grp = cdiv(n_gw, kRankWords);
     // 8 XCDs x ceil(groups / 8) groups each x ceil(n_seg / 4) workgroups of 4 waves (= 4 consecutive segments)
     hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv(n_grp, 8) * cdiv(n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
-                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any, qsum);
+                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any, qsum, rowany, n_q);
 }
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32* csum_raw /* same size */, u32 prune_top_k, u32* leader,

@@ -115,13 +115,15 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
                  u64* m_bits, u64* m_int, u32 n_pad, bool big_table, u64* hbuf, u32* m_dirty);
 // wb[w * n_tiles + t] = (first | last << 16) band of tile t whose slice can reach query word w (first > last: none)
 void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb);
-// also re-zeroes m_bits / m_int; words beyond *n_q are skipped; raises grp_any[rank group] (zero on entry) for every
-// rank group whose slice of the matrix holds any bit -- the ranking kernels skip the others (grp_any arguments below)
+// also re-zeroes m_bits / m_int; words beyond *n_q are skipped; grp_any[rank group] (zero on entry) receives the number of
+// query rows that hold a bit for some genome of the group -- the ranking kernels skip groups with none (grp_any arguments
+// below) and compact the pairs of groups with few (rowany)
 // hbuf != NULL: also ORs the lean kernel's slabs in (wb from launch_word_bands, win = the windows) and reads m_bits only
 // when *m_dirty != 0
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
                            const u32* n_q, u32* grp_any, const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles,
-                           const u32* m_dirty, u64 nq_est /* the host's estimate of the dictionary size: sizes the grid */);
+                           const u32* m_dirty, u64 nq_est /* the host's estimate of the dictionary size: sizes the grid */,
+                           u64* rowany /* [rank groups][n_words]: bit r of word w = row 64 w + r holds a bit in the group; or NULL */);
 // chk[0..5], [9] (zero on entry): non-monotonic marker, long-read count, offsets[0], offsets[n_reads], segment count;
 // long_reads != NULL: also lists the batch's long reads and their segments (chk[6] |= 2 if they do not fit the tables)
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_bases, u32* chk, u32* cnt_tail /* zeroed */,
@@ -139,7 +141,8 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any, u32* csum_raw /* [ceil(n_seg / 16)][n_pad] chunk sums, zero on entry */);
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any, u32* csum_raw /* [ceil(n_seg / 16)][n_pad] chunk sums, zero on entry */,
+                    const u64* rowany /* of launch_transpose_bits, or NULL */, const u32* n_q);
 // prune_top_k > 0 (1..rank_topk_fast_max()): also find the first prune_top_k genomes as each chunk of 16 segments begins
 // (leader [n_chunks * k], lead_val [n_chunks]) and every half rank group's best value per chunk boundary (gmax
 // [(n_chunks + 1) * n_pad / 256]); start values are then only written for (chunk, group)s that can hold a candidate.

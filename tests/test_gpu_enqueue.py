@@ -249,22 +249,22 @@ def test_more_distinct_query_hashes_than_matrix_rows(gpu):
     them -- known from the speculative gather's key count in the published summary -- is cut into passes by its pair
     counts.  Forced with 128 rows: rows and table as the oracle's, several passes, the younger batch's speculation undone."""
     from sketchy_amd import api
-    ref, bases, offsets = workload(300, 500, 900, read_len=700, rng_seed=821)
-    exp = _expect(ref["ref"], 500, bases, offsets, 2)
+    ref, bases, offsets = workload(300, 1000, 900, read_len=2000, rng_seed=821)  # (a pass has at least s rows: one read's worth)
+    exp = _expect(ref["ref"], 1000, bases, offsets, 2)
     R = api.ReferenceSketch(ref["ref"])
     try:
         api.set_option("stream_query_rows", 128)
-        S = api.SumOfSharedHashes(R, top=2, max_batch_reads=400, max_batch_bases=400 * 700)
+        S = api.SumOfSharedHashes(R, top=2, max_batch_reads=400, max_batch_bases=400 * 2000)
     finally:
         api.set_option("stream_query_rows", 0)
     idx, val = _enqueue_stream(S, bases, offsets, [0, 5, 400, 401, 800, 900], 2)
     np.testing.assert_array_equal(idx, exp["topk_idx"])
     np.testing.assert_array_equal(val, exp["topk_sum"])
     np.testing.assert_array_equal(S.table(), exp["cum"])
-    assert S.stats()["passes"] > 8
+    assert S.stats()["passes"] > 5 and S.stats()["dictionary_size"] <= 1024
     S.reset()
     got = S.push(bases, offsets[:301], want_shared=True)
-    full = orc.stream(16, 0, 500, ref["ref"], np.full(300, 500, np.uint32), bases, offsets[:301], top_k=2, want_shared=True)
+    full = orc.stream(16, 0, 1000, ref["ref"], np.full(300, 1000, np.uint32), bases, offsets[:301], top_k=2, want_shared=True)
     np.testing.assert_array_equal(got["shared"], full["shared"])
     np.testing.assert_array_equal(got["topk_idx"], full["topk_idx"])
 
