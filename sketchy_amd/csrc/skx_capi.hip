@@ -1140,7 +1140,8 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         if (top1_fast && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
                                       spc, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, d_inc,
-                                      st->d_leader, st->d_gmax, st->d_lead_val, d_grp_any, d_live, st->d_has);
+                                      st->d_leader, st->d_gmax, st->d_lead_val, d_grp_any, d_live, st->d_has,
+                                      P > 0 ? st->d_rowany[b] : nullptr, d_nq);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, d_topk_idx, d_topk_sum, ra, spc, st->d_has,
                                    (n_gw + skx::kRankWords - 1) / skx::kRankWords);
         } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {

@@ -2545,7 +2545,9 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                                                             u32 nq_rows, const u32* __restrict__ inc,
                                                             const u32* __restrict__ leader, const u64* __restrict__ gmax,
                                                             const u64* __restrict__ lead_val, const u32* __restrict__ grp_any,
-                                                            const unsigned char* __restrict__ live, unsigned char* __restrict__ has) {
+                                                            const unsigned char* __restrict__ live, unsigned char* __restrict__ has,
+                                                            const u64* __restrict__ rowany, const u32* __restrict__ n_q) {
+    __shared__ u32 sq_q[4][kSparseQueue], sq_r[4][kSparseQueue];  // a sparse group's pairs worth replaying (per wave)
     __builtin_amdgcn_s_setprio(SKX_RANK1_PRIO);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     constexpr int NW = kRankWords, SH = 6 + 3;
     static_assert(kRankWords == 8, "key layout assumes 8 words per lane");
@@ -2695,21 +2697,55 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         }
     };
     if (!single) {
-    MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
-    u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
-    for (u32 p0 = pa; p0 < pz; p0 += 64u) {
-        const u32 n = min(64u, pz - p0);
-        const MaskVec cur_m = nxt;
-        const u32 rv = rnxt;
-        const u32 pn = p0 + 64u + lane;
-        nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
-        rnxt = pn < pz ? pair_r[pn] : 0u;
-        u64 x[NW];
+        // The segment's pairs go through a queue in the wave's LDS, 64 at a time, and are replayed from there in chunks of 64
+        // (the rows of the next chunk are requested while the current one is replayed).  SPARSE groups (seg_sum_kernel: nearly
+        // all of the segment's rows are zero for this group's genomes) queue only the pairs whose row holds a bit (rowany) --
+        // the reads in between see an unchanged state, and emit_upto is lazy anyway.
+        const bool sparse = rowany != nullptr && grp_any[grp] * 4u < *n_q;
+        const u64* ra_g = rowany + (size_t)grp * (nq_rows >> 6);
+        u32* qq = sq_q[threadIdx.x >> 6];
+        u32* qr = sq_r[threadIdx.x >> 6];
+        const u64 lt = lanemask_lt();
+        u32 qcount = 0;
+        auto flush = [&]() {
+            wave_sync();
+            MaskVec nxt = gather_vec(mq_g, lane < qcount ? qq[lane] : 0u, lane < qcount);
+            u32 rnxt = lane < qcount ? qr[lane] : 0u;
+            for (u32 i0 = 0; i0 < qcount; i0 += 64u) {
+                const u32 n = min(64u, qcount - i0);
+                const MaskVec cur_m = nxt;
+                const u32 rv = rnxt;
+                const u32 in = i0 + 64u + lane;
+                nxt = gather_vec(mq_g, in < qcount ? qq[in] : 0u, in < qcount);
+                rnxt = in < qcount ? qr[in] : 0u;
+                u64 x[NW];
 #pragma unroll
-        for (int j = 0; j < NW; ++j) x[j] = (wmask >> j & 1u) ? transpose64(cur_m.w[j], lane) : 0;  // live words only
-        replay(x, rv, n);
-    }
-    emit_upto(rz);
+                for (int j = 0; j < NW; ++j)  // live words only; a word none of whose rows holds a bit needs no transpose
+                    x[j] = ((wmask >> j & 1u) && __ballot(cur_m.w[j] != 0ull)) ? transpose64(cur_m.w[j], lane) : 0;
+                replay(x, rv, n);
+            }
+            qcount = 0;
+            wave_sync();
+        };
+        for (u32 p0 = pa;; p0 += 64u) {  // (one flush site: the replay code exists once)
+            const bool more = p0 < pz;
+            if (more) {
+                const u32 p = p0 + lane;
+                const bool ok = p < pz;
+                const u32 q = ok ? pair_q[p] : 0u;
+                const bool nz = ok && (!sparse || ((ra_g[q >> 6] >> (q & 63u)) & 1ull));
+                const u64 m = __ballot(nz);
+                if (nz) {
+                    const u32 at = qcount + (u32)__popcll(m & lt);
+                    qq[at] = q;
+                    qr[at] = pair_r[p];
+                }
+                qcount = __builtin_amdgcn_readfirstlane(qcount + (u32)__popcll(m));
+            }
+            if (qcount && (!more || qcount > kSparseQueue - 64u)) flush();
+            if (!more) break;
+        }
+        emit_upto(rz);
     }
     if (lane == 0) has[(size_t)seg * n_grp + grp] = 1;
     if (lane < rz - ra) {
@@ -3290,11 +3326,12 @@ void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, 
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
                           const u64* lead_val, const u32* grp_any, const unsigned char* live,
-                          unsigned char* has /* [segments][rank groups]: the kernel reported something for it */) {
+                          unsigned char* has /* [segments][rank groups]: the kernel reported something for it */,
+                          const u64* rowany, const u32* n_q) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, 64), n_grp = cdiv(n_gw, kRankWords);
     hipLaunchKernelGGL(rank_seg_top1_kernel, dim3(cdiv((u64)n_seg * n_grp, 4)), dim3(256), 0, st, pair_q, pair_r, poff,
                        p_base, r_begin, n_reads, 64u, mq, n_gw, n_pad, sp, cum_in, rel, best_sum, best_idx, nq_rows, inc, leader,
-                       gmax, lead_val, grp_any, live, has);
+                       gmax, lead_val, grp_any, live, has, rowany, n_q);
 }
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,

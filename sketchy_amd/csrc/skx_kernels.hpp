@@ -159,7 +159,8 @@ void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const
 void launch_rank_seg_top1(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                           u32 n_reads, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
                           const u32* rel, u64* best_sum, u32* best_idx, const u32* inc, const u32* leader, const u64* gmax,
-                          const u64* lead_val, const u32* grp_any, const unsigned char* live, unsigned char* has);
+                          const u64* lead_val, const u32* grp_any, const unsigned char* live, unsigned char* has,
+                          const u64* rowany /* of launch_transpose_bits, or NULL */, const u32* n_q);
 // 2 <= top_k <= rank_topk_fast_max(): pruned, one wave per (rank group, segment);
 // cand_sum / cand_idx[(r * n_grp + grp) * top_k + j]
 void launch_rank_seg_topk(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
