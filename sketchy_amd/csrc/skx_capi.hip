@@ -517,10 +517,11 @@ struct skx_stream {
     u64* d_sk = nullptr;
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
     u64* sd_sk[2] = {nullptr, nullptr};       // POOL of a side: production rows are exact-size reservations (sketch_finish, pool mode)
-    u64 pool_cap[2] = {0, 0};                // ... its entries
+    u64 pool_cap[2] = {0, 0};                // ... its entries: a fixed slot per read first (pool_fixed), the reservable part behind
+    u32 pool_fixed = 0;
     u64* sd_rows[2] = {nullptr, nullptr};    // full-width rows [max_reads][sk_stride] of a side: debug outputs / skx_common_hashes; allocated on first use
     u32 cur_stride = 0;                      // what the kernels get as row stride for d_sk: 0 = pool mode
-    u32 cur_pool_cap = 0;
+    u32 cur_pool_cap = 0, cur_pool_fixed = 0;
     u32 *sd_len[2] = {nullptr, nullptr}, *sd_cnt[2] = {nullptr, nullptr}, *sd_poff[2] = {nullptr, nullptr}, *sd_big[2] = {nullptr, nullptr};
     u32 *sd_chk[2] = {nullptr, nullptr}, *sd_retry[2] = {nullptr, nullptr};  // (per side: batch i's summary is published while batch i + 1 is sketched)
     skx::LongReads sd_lr[2] = {{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u}, {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u}};
@@ -666,16 +667,17 @@ static void stream_free(skx_stream* st) {
 // one copy of the per-batch sketch buffers
 static hipError_t alloc_side(skx_stream* st, int i) {
     hipError_t e;
-    // the pool: 16 row entries per read of the largest batch (C2 keeps 2.4, C4 3.9), never less than 2^20 -- and never more
-    // than the worst case needs (every read a full-width row; the pool is cut into 64 sub-pools, a workgroup of four reads
-    // uses sub-pool blockIdx % 64), so small streams cannot overflow it at all; a batch that does is repeated with a
-    // larger pool (batch_back)
+    // the pool: a fixed slot of 16 entries per read (C2 keeps 2.4 per read, C4 3.9: nearly every row fits its slot and costs no
+    // atomic) and, behind it, a reservable part for the longer rows -- as large again, at least 2^20 entries, and never more than
+    // the worst case needs (every read a full-width row; it is cut into 64 sub-pools, a workgroup of four reads uses sub-pool
+    // blockIdx % 64), so small streams cannot overflow it at all; a batch that does is repeated with a larger pool (batch_back)
     {
+        st->pool_fixed = (u32)std::min<u64>((u64)st->max_reads * skx::pool_row_fixed(), 0x7FFFFFF0ull);
         const u64 groups = ((u64)st->max_reads + 3) / 4, per_part = ((groups + 63) / 64) * 4 + 8;
         const u64 worst = 64 * per_part * st->sk_stride;
-        st->pool_cap[i] = std::min<u64>(worst, std::max<u64>((u64)st->max_reads * 16, 1u << 20));
+        const u64 res = std::min<u64>(worst, std::max<u64>((u64)st->max_reads * 16, 1u << 20));
+        st->pool_cap[i] = std::min<u64>((u64)st->pool_fixed + std::max<u64>(res, 4096), 0xFFFFFF00ull);
     }
-    st->pool_cap[i] = std::min<u64>(std::max<u64>(st->pool_cap[i], 4096), 0xFFFFFF00ull);
     if ((e = hipMalloc(&st->sd_sk[i], (size_t)st->pool_cap[i] * 8)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_len[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
     if ((e = hipMalloc(&st->sd_cnt[i], ((size_t)st->max_reads + 1) * 4)) != hipSuccess) return e;
@@ -704,7 +706,7 @@ static hipError_t use_side(skx_stream* st, int i) {
         if (e != hipSuccess) return e;
     }
     st->side = i;
-    st->d_sk = st->sd_sk[i]; st->cur_stride = 0; st->cur_pool_cap = (u32)st->pool_cap[i];  // (pool mode; use_rows switches)
+    st->d_sk = st->sd_sk[i]; st->cur_stride = 0; st->cur_pool_cap = (u32)st->pool_cap[i]; st->cur_pool_fixed = st->pool_fixed;  // (pool mode; use_rows switches)
     st->d_len = st->sd_len[i]; st->d_cnt = st->sd_cnt[i]; st->d_poff = st->sd_poff[i];
     st->d_big = st->sd_big[i]; st->d_retry = st->sd_retry[i]; st->d_chk = st->sd_chk[i];
     st->lr = st->sd_lr[i];
@@ -720,7 +722,7 @@ static hipError_t use_rows(skx_stream* st) {
         hipError_t e = hipMalloc(&st->sd_rows[i], (size_t)st->max_reads * st->sk_stride * 8);
         if (e != hipSuccess) return e;
     }
-    st->d_sk = st->sd_rows[i]; st->cur_stride = st->sk_stride; st->cur_pool_cap = 0;
+    st->d_sk = st->sd_rows[i]; st->cur_stride = st->sk_stride; st->cur_pool_cap = 0; st->cur_pool_fixed = 0;
     return hipSuccess;
 }
 
@@ -1273,7 +1275,7 @@ static int queue_front(skx_stream* st, PendingBatch& pb, int leave_room) {
         HIPCHK(skx::launch_sketch(phase == 2 ? st->hs1 : hs, pb.d_bases, pb.d_offsets, n_reads, ref->k, ref->seed, ref->s_read, max_ref,
                                   pb.inrange_only, st->d_sk, st->cur_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->d_retry,
                                   st->d_big, pb.n_bases, st->d_chk, leave_room, st->packed, lr, ref->d_kf ? &kf : nullptr,
-                                  pb.inrange_only ? phase : 3, st->cur_pool_cap));
+                                  pb.inrange_only ? phase : 3, st->cur_pool_cap, st->cur_pool_fixed));
     }
     if (!pb.inrange_only) {
         // full sketches (debug outputs): reads with more k-mers than a wave holds are on the `big` list; this path is
@@ -1283,7 +1285,7 @@ static int queue_front(skx_stream* st, PendingBatch& pb, int leave_room) {
         HIPCHK(hipStreamSynchronize(hs));
         HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, n_big, ref->k, ref->seed, ref->s_read, max_ref,
                                         false, st->d_sk, st->cur_stride, st->d_len, st->d_cnt, filt, ref->filt_shift, st->packed, st->d_chk,
-                                        st->cur_pool_cap));
+                                        st->cur_pool_cap, st->cur_pool_fixed));
         st->reads_big += n_big;
         HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
     }
@@ -1396,13 +1398,15 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
         if (!stats_done && pb.inrange_only && st->lr.list && (c[1] || c[9])) { st->reads_split += c[1]; st->segs_split += c[9]; stats_done = true; }
         if (c[6] & 4u) {
             if (pb.rows_mode) return fail(SKX_ERR_HIP, "internal: pool overflow reported for full-width rows");
-            const u64 need = std::max<u64>(c[11], st->pool_cap[pb.side] + 1);
-            if (need > 0xFFFFFFF0ull) return refuse(SKX_ERR_CAPACITY, "the batch's sketch rows exceed what the pool can index");
+            const u64 res_now = st->pool_cap[pb.side] - st->pool_fixed;
+            const u64 res_need = std::max<u64>(c[11], res_now + 1);  // (c[11]: 64 x the fullest sub-pool's request)
+            const u64 need = st->pool_fixed + res_need + res_need / 8 + 1024;
+            if (need > 0xFFFFFF00ull) return refuse(SKX_ERR_CAPACITY, "the batch's sketch rows exceed what the pool can index");
             SKXCHK(cancel_speculation(st, pb, true));
             HIPCHK(hipStreamSynchronize(st->hs0));
             HIPCHK(hipStreamSynchronize(st->hs1));
             (void)hipFree(st->sd_sk[pb.side]); st->sd_sk[pb.side] = nullptr; st->pool_cap[pb.side] = 0;
-            const u64 cap = std::min<u64>(0xFFFFFFF0ull, need + need / 8 + 1024);
+            const u64 cap = need;
             HIPCHK(hipMalloc(&st->sd_sk[pb.side], (size_t)cap * 8));
             st->pool_cap[pb.side] = cap;
             st->pool_grown += 1;
@@ -1415,7 +1419,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
             st->reads_big += c[7]; big_counted += c[7];
             HIPCHK(skx::launch_sketch_block(hs, pb.d_bases, pb.d_offsets, st->d_big, c[7], ref->k, ref->seed, ref->s_read, max_ref,
                                             pb.inrange_only, st->d_sk, st->cur_stride, st->d_len, st->d_cnt, filt, ref->filt_shift,
-                                            st->packed, st->d_chk, st->cur_pool_cap));
+                                            st->packed, st->d_chk, st->cur_pool_cap, st->cur_pool_fixed));
             SKXCHK(queue_counts_and_summary(st, pb));
             continue;
         }

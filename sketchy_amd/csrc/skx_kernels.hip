@@ -308,20 +308,28 @@ __global__ __launch_bounds__(256) void kmer_filter_build_kernel(u64 seed, u64 ma
 // length has no consumer in production mode), chk[11] is the bump counter, pool_cap the pool's entries.  A reservation that
 // does not fit raises chk[6] |= 4 and writes nothing; chk[11] still sums every request, so the host knows how much to allocate
 // before it repeats the batch (rare: a pool holds 16 pairs per read of the largest batch, C2 needs 2.4).
-__device__ __forceinline__ u32 pool_reserve(u32* __restrict__ chk, u32 pool_cap, u32 want /* wave-uniform */, bool& ok) {
-    const u32 part = blockIdx.x % kPoolParts, part_cap = pool_cap / kPoolParts;
+// The pool starts with a FIXED part: kRowFixed entries per read (row r at r * kRowFixed) -- a row that fits takes it without any
+// atomic (a returning atomic is a ~2 us round trip next to the other streams' kernels: per read, that was 5 % of the C2 step);
+// only longer rows reserve behind it, in the sub-pools.
+constexpr u32 kRowFixed = 16;
+__device__ __forceinline__ u32 pool_reserve(u32* __restrict__ chk, u32 pool_fixed, u32 pool_cap, u32 want /* wave-uniform */, bool& ok) {
+    const u32 part = blockIdx.x % kPoolParts, part_cap = (pool_cap - pool_fixed) / kPoolParts;
     u32 off = 0;
     if (lane_id() == 0 && want) off = atomicAdd(&chk[16u + 16u * part], want);
     off = __builtin_amdgcn_readfirstlane(off);
     ok = off + want <= part_cap && off + want >= off;
     if (!ok && lane_id() == 0) atomicOr(&chk[6], 4u);
-    return part * part_cap + off;
+    return pool_fixed + part * part_cap + off;
+}
+__device__ __forceinline__ u32 pool_row(u32* __restrict__ chk, u32 pool_fixed, u32 pool_cap, u32 r, u32 want, bool& ok) {
+    if (want <= kRowFixed && (r + 1u) * kRowFixed <= pool_fixed) { ok = true; return r * kRowFixed; }
+    return pool_reserve(chk, pool_fixed, pool_cap, want, ok);
 }
 template <int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, u64 max_ref, u64* __restrict__ out_sk,
                                               u32 sk_stride, u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
                                               const u64* __restrict__ filt, u32 filt_shift, u32* __restrict__ chk = nullptr,
-                                              u32 pool_cap = 0) {
+                                              u32 pool_cap = 0, u32 pool_fixed = 0) {
     const u32 lane = lane_id();
     const u64 lt = lanemask_lt();
     // At most one hash per lane (production: a 1.5 kb read keeps ~8): sort by counting.  Lane l holds hash l; for every j the
@@ -387,7 +395,7 @@ __device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, 
             const bool keep = take && filter_hit(filt, filt_shift, h);
             const u64 km = __ballot(keep);
             wrote = (u32)__popcll(km);
-            off = pool_reserve(chk, pool_cap, wrote, ok);
+            off = pool_row(chk, pool_fixed, pool_cap, r, wrote, ok);
             if (ok && keep) out_sk[(size_t)off + __popcll(km & lt)] = h;
         } else {
             for (int pass = 0; pass < 2; ++pass) {
@@ -406,7 +414,7 @@ __device__ __forceinline__ void sketch_finish(u64* hashes, u32 m, u32 r, u32 s, 
                     outn += __popcll(mask);
                 }
                 if (pass == 0) {
-                    off = pool_reserve(chk, pool_cap, wrote, ok);
+                    off = pool_row(chk, pool_fixed, pool_cap, r, wrote, ok);
                     if (!ok) break;
                     out = out_sk + (size_t)off;
                 }
@@ -455,7 +463,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                                                 u32* __restrict__ chk, const unsigned char* lut, bool packed,
                                                 bool split_long = false, u32 seg_i = 0, u64* __restrict__ seg_h = nullptr,
                                                 u32* __restrict__ seg_cnt = nullptr, KmerFilter kf = KmerFilter{nullptr, 0u},
-                                                u32 pool_cap = 0) {
+                                                u32 pool_cap = 0, u32 pool_fixed = 0) {
     static_assert(!SEG || INRANGE, "segments exist in production mode only");
     constexpr u32 CAP = kSketchCap;
     constexpr u32 kPerWave = HCAP * 8 + CAP + 128 + kPfQueue * 4;  // (32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding; the prefilter's queue)
@@ -736,7 +744,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         }
         return;
     }
-    sketch_finish<HCAP, INRANGE>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift, chk, pool_cap);
+    sketch_finish<HCAP, INRANGE>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift, chk, pool_cap, pool_fixed);
     __builtin_amdgcn_s_setprio(0);
 }
 // from_list = 0: wave w of the grid sketches read w.  from_list = 1: a small fixed grid walks the reads an earlier
@@ -750,9 +758,9 @@ constexpr u32 kSegBlocks = 1024;  // x 4 waves: a C4 batch has ~28 000 segments
     const uint8_t *__restrict__ bases, const u64 *__restrict__ offsets, u32 n_reads, u32 k_rt, u64 seed, u32 s, u64 max_ref,  \
         u64 *__restrict__ out_sk, u32 sk_stride, u32 *__restrict__ out_len, u32 *__restrict__ out_cnt_in, u32 from_list,      \
         u32 *__restrict__ retry, u32 *__restrict__ big, const u64 *__restrict__ filt, u32 filt_shift, u64 n_bases,            \
-        u32 *__restrict__ chk, LongReads lr, KmerFilter kf, u32 pool_cap
+        u32 *__restrict__ chk, LongReads lr, KmerFilter kf, u32 pool_cap, u32 pool_fixed
 #define SKX_SKETCH_ARGS \
-    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr, kf, pool_cap
+    bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr, kf, pool_cap, pool_fixed
 template <int KT, int HCAP, bool INRANGE>
 __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, unsigned char* lut) {
     const bool packed = (from_list & 0x100u) != 0u;  // (bit 8: 4-bit packed input)
@@ -776,7 +784,7 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
                 sketch_one_read<KT, HCAP, true, true>(smem, lr.list[pos], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
                                                       out_len, out_cnt_in, nullptr, nullptr, filt, filt_shift, n_bases, chk, lut,
                                                       packed, true, sg - lr.seg0[pos], lr.seg_h + (size_t)sg * kSegSlots,
-                                                      lr.seg_cnt + sg, kf, pool_cap);
+                                                      lr.seg_cnt + sg, kf, pool_cap, pool_fixed);
                 wave_sync();  // the wave's LDS region is reused by its next segment
             }
             return;
@@ -787,14 +795,14 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
         if (w < n_reads)
             sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
                                                out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut, packed,
-                                               from_list == 2u, 0u, nullptr, nullptr, kf, pool_cap);
+                                               from_list == 2u, 0u, nullptr, nullptr, kf, pool_cap, pool_fixed);
         return;
     }
     const u32 n = retry[0];
     for (u32 i = w; i < n; i += gridDim.x * wpb) {
         sketch_one_read<KT, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
                                            out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut, packed, false, 0u,
-                                           nullptr, nullptr, kf, pool_cap);
+                                           nullptr, nullptr, kf, pool_cap, pool_fixed);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
 }
@@ -811,7 +819,7 @@ __global__ __launch_bounds__(64) void sketch_merge_kernel(const u64* __restrict_
                                                           u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                           u32* __restrict__ out_cnt_in, u32* __restrict__ big,
                                                           const u64* __restrict__ filt, u32 filt_shift,
-                                                          u32* __restrict__ chk, LongReads lr, u32 pool_cap) {
+                                                          u32* __restrict__ chk, LongReads lr, u32 pool_cap, u32 pool_fixed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* hashes = reinterpret_cast<u64*>(smem);
     const u32 lane = lane_id();
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(64) void sketch_merge_kernel(const u64* __restrict_
         if (bad) {
             if (lane == 0) { out_len[r] = kSketchRetry; out_cnt_in[r] = 0; list_append(big, r); }
         } else {
-            sketch_finish<kSketchCap, true>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift, chk, pool_cap);
+            sketch_finish<kSketchCap, true>(hashes, m, r, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, filt, filt_shift, chk, pool_cap, pool_fixed);
         }
         wave_sync();  // the buffer is reused by the wave's next read
     }
@@ -896,7 +904,7 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
                                                             u64 max_ref, u64* __restrict__ out_sk, u32 sk_stride,
                                                             u32* __restrict__ out_len, u32* __restrict__ out_cnt_in,
                                                             const u64* __restrict__ filt, u32 filt_shift, u32 packed,
-                                                            u32* __restrict__ chk, u32 pool_cap) {
+                                                            u32* __restrict__ chk, u32 pool_cap, u32 pool_fixed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ BlockScratch sh;
     __shared__ u32 s_off, s_ok;
@@ -917,9 +925,9 @@ __global__ __launch_bounds__(1024) void sketch_block_kernel(const uint8_t* __res
             // pool mode (sketch_finish): the row is reserved before its size is known -- at most min(s, bases) entries
             if (tid == 0) {
                 const u32 want = min(s, max(lraw, 1u));
-                const u32 part = blockIdx.x % kPoolParts, part_cap = pool_cap / kPoolParts;
+                const u32 part = blockIdx.x % kPoolParts, part_cap = (pool_cap - pool_fixed) / kPoolParts;
                 const u32 off = atomicAdd(&chk[16u + 16u * part], want);
-                s_off = part * part_cap + off;
+                s_off = pool_fixed + part * part_cap + off;
                 s_ok = (off + want <= part_cap && off + want >= off) ? 1u : 0u;
                 if (!s_ok) atomicOr(&chk[6], 4u);
             }
@@ -3048,7 +3056,7 @@ static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketch
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
                          const u64* filt, u32 filt_shift, u32* retry, u32* big, u64 n_bases, u32* chk, int leave_room, bool packed,
-                         const LongReads* long_reads, const KmerFilter* kmer_filter, int phase, u32 pool_cap) {
+                         const LongReads* long_reads, const KmerFilter* kmer_filter, int phase, u32 pool_cap, u32 pool_fixed) {
     if (n_reads == 0) return hipSuccess;
     // leave_room: the previous pass's scan is still running on another stream.  The fast variant then asks for extra
     // dynamic LDS per block (env SKX_SKETCH_LDS_PAD, default 19 KB: 4 instead of 8 of its blocks fit a CU, and when one
@@ -3112,7 +3120,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     hipLaunchKernelGGL((KERNEL), (FROM_LIST) == 1u ? list_grid : (FROM_LIST) == 2u ? grid2 : grid,                        \
                        dim3((FROM_LIST) == 1u ? 64 : 256), (FROM_LIST) == 1u ? (LDS) / 4 : (LDS), st, bases,                \
                        offsets, n_reads, k, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in,                          \
-                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk, lr, kf, pool_cap)
+                       (u32)(FROM_LIST) | (packed ? 0x100u : 0u), retry, big, filt, filt_shift, n_bases, chk, lr, kf, pool_cap, pool_fixed)
     (void)blk_grid;
     if (inrange_only) {
         // fast variant first (256 hash slots: full occupancy); reads it flags are redone with 2048 slots, what still
@@ -3133,7 +3141,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
         if (phase & 2) {
             if (first == 2u)
                 hipLaunchKernelGGL(sketch_merge_kernel, dim3(512), dim3(64), (size_t)kSketchCap * 8, st, offsets, s, max_ref, out_sk, sk_stride,
-                                   out_len, out_cnt_in, big, filt, filt_shift, chk, lr, pool_cap);
+                                   out_len, out_cnt_in, big, filt, filt_shift, chk, lr, pool_cap, pool_fixed);
             if (k == 16) SKX_SK_LAUNCH(SKX_SK(16, true), lds, 1u); else SKX_SK_LAUNCH(SKX_SK(0, true), lds, 1u);
         }
     } else {
@@ -3151,12 +3159,12 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
 // (40-80 us on the sketch stream per push, measured) -- and it almost always is.
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                               const u64* filt, u32 filt_shift, bool packed, u32* chk, u32 pool_cap) {
+                               const u64* filt, u32 filt_shift, bool packed, u32* chk, u32 pool_cap, u32 pool_fixed) {
     if (n_big == 0) return hipSuccess;
     const dim3 blk_grid(std::min<u32>(n_big, 256u));
 #define SKX_BLK_LAUNCH(KERNEL)                                                                                              \
     hipLaunchKernelGGL((KERNEL), blk_grid, dim3(1024), kBigLds, st, bases, offsets, big, n_big, k, seed, s, max_ref, out_sk, \
-                       sk_stride, out_len, out_cnt_in, filt, filt_shift, packed ? 1u : 0u, chk, pool_cap)
+                       sk_stride, out_len, out_cnt_in, filt, filt_shift, packed ? 1u : 0u, chk, pool_cap, pool_fixed)
     if (k == 16) { if (inrange_only) SKX_BLK_LAUNCH((sketch_block_kernel<16, true>)); else SKX_BLK_LAUNCH((sketch_block_kernel<16, false>)); }
     else { if (inrange_only) SKX_BLK_LAUNCH((sketch_block_kernel<0, true>)); else SKX_BLK_LAUNCH((sketch_block_kernel<0, false>)); }
 #undef SKX_BLK_LAUNCH
@@ -3268,6 +3276,7 @@ void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_b
                        cnt_tail, lr);
 }
 u32 chk_words() { return kChkWords; }
+u32 pool_row_fixed() { return kRowFixed; }
 u32 long_read_split() { return kLongSplit; }
 u32 long_read_seg_slots() { return kSegSlots; }
 void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq, const u32* dict_ctr) {

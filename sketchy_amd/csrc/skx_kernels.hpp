@@ -49,6 +49,7 @@ struct LongReads {
 };
 u32 long_read_split();
 u32 long_read_seg_slots();
+u32 pool_row_fixed();  // entries of a read's fixed slot at the start of the row pool
 u32 chk_words();  // u32 words of a `chk` block: 16 flags / counters + the row pool's bump counters (one cache line each)
 
 // k-mer prefilter (k = 16): a two-probe blocked Bloom table over the 2-bit code of the CANONICAL k-mer, holding every
@@ -77,11 +78,13 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
                          const LongReads* long_reads = nullptr, const KmerFilter* kmer_filter = nullptr /* production, k = 16 */,
                          int phase = 3 /* production batches: 1 = the main kernel only, 2 = only the list walks behind it, 3 = both */,
                          u32 pool_cap = 0 /* sk_stride == 0 (production): out_sk is a pool of this many entries, out_len receives
-                                             every row's start, chk[11] is the bump counter, chk[6] |= 4 on overflow */);
+                                             every row's start, chk[6] |= 4 on overflow */,
+                         u32 pool_fixed = 0 /* its first entries: pool_row_fixed() per read, taken without reservation */);
 // the block sketcher for the n_big reads launch_sketch left on `big` (big[1 ..]); the caller reads the count back first
 hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* offsets, const u32* big, u32 n_big, u32 k, u64 seed,
                                u32 s, u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
-                               const u64* filt, u32 filt_shift, bool packed = false, u32* chk = nullptr, u32 pool_cap = 0);
+                               const u64* filt, u32 filt_shift, bool packed = false, u32* chk = nullptr, u32 pool_cap = 0,
+                               u32 pool_fixed = 0);
 // exclusive scan of n counts (out[i] = sum of in[0..i)); bsum: [ceil(n / 1024)] scratch
 void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum);
 
