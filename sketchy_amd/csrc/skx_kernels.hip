@@ -1274,19 +1274,24 @@ __device__ __forceinline__ u32 dict_bucket(u64 key, u32 bshift) { return (u32)mi
 // (right behind the sketcher, on its stream); when they do not fit one pass it does nothing and the host, which learns
 // the count a moment later, cuts the batch into passes and inserts per pass.
 // sk_stride == 0: pool mode -- read r's row starts at sk + row_off[r] (sketch_finish)
-__global__ void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, const u32* __restrict__ poff, u32 r_begin,
-                                   u32 r_end, u32 p_base, u64* __restrict__ pair_h, u32* __restrict__ pair_r,
-                                   u64* __restrict__ ht, u32 ht_mask, u32* __restrict__ ctr, u32 pair_cap,
-                                   const u32* __restrict__ row_off) {
+// One THREAD per read (a read has a handful of pairs: one wave per read made this 98 304 nearly empty waves per C2 batch, each
+// waiting for a wave slot next to the other streams' kernels -- 100-300 us on the critical chain behind the sketcher).
+// Every key new to the set is also appended to `keylist` (ctr[2] counts them; entries beyond list_cap are dropped): a pass
+// with few distinct hashes is then sorted from the list by ONE workgroup (dict_sort_kernel) instead of the five kernels that
+// walk the whole hash set.
+__global__ __launch_bounds__(256) void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, const u32* __restrict__ poff,
+                                                          u32 r_begin, u32 r_end, u32 p_base, u64* __restrict__ pair_h,
+                                                          u32* __restrict__ pair_r, u64* __restrict__ ht, u32 ht_mask,
+                                                          u32* __restrict__ ctr, u32 pair_cap, const u32* __restrict__ row_off,
+                                                          u64* __restrict__ keylist, u32 list_cap) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
-    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();  // one wave per read
-    const u32 r = r_begin + wave;
+    const u32 r = r_begin + blockIdx.x * 256u + threadIdx.x;
     if (r >= r_end) return;
     if (poff[r_end] - p_base > pair_cap) return;
     const u32 a = poff[r], b = poff[r + 1];
     if (b == a) return;
     const u64* row = sk_stride ? sk + (size_t)r * sk_stride : sk + (size_t)row_off[r];
-    for (u32 j = lane; j < b - a; j += 64u) {
+    for (u32 j = 0; j < b - a; ++j) {
         const u64 key = row[j];
         pair_h[a - p_base + j] = key;
         pair_r[a - p_base + j] = r - r_begin;
@@ -1294,11 +1299,62 @@ __global__ void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, co
         u32 slot = (u32)(key ^ (key >> 29)) & ht_mask;
         for (;;) {
             const u64 prev = atomicCAS(&ht[slot], kPad, key);
-            if (prev == kPad) { atomicAdd(&ctr[2], 1u); break; }  // a new key: ctr[2] = distinct keys in the set (|Q| of the pass)
+            if (prev == kPad) {  // a new key: ctr[2] = distinct keys in the set (|Q| of the pass)
+                const u32 pos = atomicAdd(&ctr[2], 1u);
+                if (pos < list_cap) keylist[pos] = key;
+                break;
+            }
             if (prev == key) break;
             slot = (slot + 1u) & ht_mask;
         }
     }
+}
+// The dictionary of a pass with at most kDictLdsKeys distinct hashes, by ONE workgroup: the new keys dict_insert_kernel listed
+// are sorted in LDS (bitonic, 128 KB), written to Q (with the all-ones hash last if it was seen), *n_q set, and the keys' slots
+// of the hash set cleared again -- instead of count / scan / scan / scatter / bucket sort over the whole set, five launches
+// each of which waits tens of microseconds for wave slots on a busy chip (the scan cannot start before them: ~0.25 ms per
+// batch on the scan stream's critical path, kernel timeline).  The caller knows the number of keys (published with the batch
+// summary) or a bound (the pass's pairs) and only launches this when it fits.
+constexpr u32 kDictLdsKeys = 16384;
+__global__ __launch_bounds__(1024) void dict_sort_kernel(const u64* __restrict__ keylist, u64* __restrict__ ht, u32 ht_mask,
+                                                         u32* __restrict__ ctr, u64* __restrict__ q, u32* __restrict__ n_q) {
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    const u32 tid = threadIdx.x;
+    const u32 n = min(ctr[2], kDictLdsKeys);
+    u32 p2 = 2;
+    while (p2 < n) p2 <<= 1;
+    for (u32 i = tid; i < p2; i += 1024u) keys[i] = i < n ? keylist[i] : kPad;
+    __syncthreads();
+    for (u32 size = 2; size <= p2; size <<= 1) {
+        for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+            for (u32 t = tid; t < (p2 >> 1); t += 1024u) {
+                const u32 i = 2u * t - (t & (stride - 1u));
+                const u32 j = i + stride;
+                const bool up = (i & size) == 0u;
+                const u64 a = keys[i], b = keys[j];
+                if ((a > b) == up) { keys[i] = b; keys[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const u32 extra = ctr[1] & 1u;
+    for (u32 i = tid; i < n; i += 1024u) {
+        const u64 key = keys[i];
+        q[i] = key;
+        // empty the key's slot of the hash set for the next pass that uses it (linear probing never deleted anything, so the
+        // key sits in the first slot from its home that holds it)
+        u32 slot = (u32)(key ^ (key >> 29)) & ht_mask;
+        while (ht[slot] != key) slot = (slot + 1u) & ht_mask;
+        ht[slot] = kPad;
+    }
+    if (tid == 0) {
+        if (extra) q[n] = kPad;  // the largest possible hash goes last
+        *n_q = n + extra;
+    }
+    __syncthreads();
+    if (tid == 0) { ctr[1] = 0; ctr[2] = 0; }
 }
 // used slots: count per bucket; the slot remembers its place inside the bucket (atomics spread over 2^17 addresses)
 __global__ __launch_bounds__(256) void dict_count_kernel(const u64* __restrict__ ht, u32 ht_slots, u32 bshift,
@@ -1741,12 +1797,28 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
 // indices.  One block per tile; wb[w * n_tiles + t] = four slab word indices (kWbNone = unused).
 constexpr u32 kWordBandsMax = 2048;  // bands per tile the LDS tables hold (s <= 131 072 at 64 rows per band)
 constexpr u32 kWbNone = 0xFFFFFFFFu, kWbRange = 0xFFFFFFFEu;
-__global__ __launch_bounds__(256) void word_bands_kernel(const u32* __restrict__ win, u32 n_tiles, u32 n_bands,
-                                                         const u32* __restrict__ n_q, u32* __restrict__ wb) {
+// lo != NULL: the block first computes the windows of its tile's bands itself (window_kernel's work: win[2 bt], win[2 bt + 1] =
+// the slice of Q inside [lo[bt], hi[bt]]) -- one launch instead of two on the chain in front of the scan.
+__global__ __launch_bounds__(256) void word_bands_kernel(u32* __restrict__ win, u32 n_tiles, u32 n_bands,
+                                                         const u32* __restrict__ n_q, u32* __restrict__ wb,
+                                                         const u64* __restrict__ lo, const u64* __restrict__ hi,
+                                                         const u64* __restrict__ q, volatile u32* __restrict__ h_nq) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u32 first_w[kWordBandsMax], pmax_w[kWordBandsMax];
     __shared__ u32 wtot[4];
     const u32 t = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    if (lo) {
+        const u32 nq = *n_q;
+        if (t == 0 && tid == 0 && h_nq) { *h_nq = nq; __threadfence_system(); }  // |Q| for the host (page-locked memory), a hint only
+        for (u32 b = tid; b < n_bands; b += 256u) {
+            const u32 bt = b * n_tiles + t;
+            u32 qa = nq, qb = nq;  // (an empty band gets the empty window [nq, nq): window_kernel)
+            if (lo[bt] <= hi[bt]) { qa = lower_bound_u64(q, nq, lo[bt]); qb = upper_bound_u64(q, nq, hi[bt]); }
+            win[2 * bt] = qa;
+            win[2 * bt + 1] = qb;
+        }
+        __syncthreads();  // (the block reads its own writes below: same workgroup, global memory)
+    }
     const u32 n_words = (*n_q + 63u) >> 6;
     // first word / (last word + 1) per band; empty bands reach nothing
     u32 carry = 0;  // prefix maximum of (last word + 1) so far
@@ -3183,10 +3255,30 @@ void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum
 }
 
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
-                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap, const u32* row_off) {
+                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap, const u32* row_off, u64* keylist) {
     if (r_end <= r_begin) return;
-    hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 4)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
-                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off);
+    hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 256)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
+                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off, keylist, keylist ? kDictLdsKeys : 0u);
+}
+u32 dict_sort_max_keys() { return kDictLdsKeys; }
+hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_slots, u32* ctr, u64* q, u32* n_q, u32 key_bound) {
+    {   // > 64 KiB of dynamic LDS needs the opt-in, once per device (as launch_sketch)
+        static std::mutex mu;
+        static unsigned long long done[4] = {0, 0, 0, 0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= 256 || !((done[dev >> 6] >> (dev & 63)) & 1ull)) {
+            e = hipFuncSetAttribute((const void*)&dict_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDictLdsKeys * 8));
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 256) done[dev >> 6] |= 1ull << (dev & 63);
+        }
+    }
+    u32 p2 = 2;
+    while (p2 < std::min(key_bound, kDictLdsKeys)) p2 <<= 1;
+    hipLaunchKernelGGL(dict_sort_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, keylist, ht, ht_slots - 1u, ctr, q, n_q);
+    return hipGetLastError();
 }
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q) {
@@ -3219,8 +3311,9 @@ bool scan_lean_applies(u32 n_bands, bool split, bool big_table) {
     return lean_env && !split && !big_table && n_bands <= kWordBandsMax;
 }
 u32 scan_lean_words() { return kLeanWords; }
-void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb) {
-    hipLaunchKernelGGL(word_bands_kernel, dim3(n_tiles), dim3(256), 0, st, win, n_tiles, n_bands, n_q, wb);
+void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb, const u64* lo, const u64* hi,
+                       const u64* q, u32* h_nq) {
+    hipLaunchKernelGGL(word_bands_kernel, dim3(n_tiles), dim3(256), 0, st, win, n_tiles, n_bands, n_q, wb, lo, hi, q, h_nq);
 }
 
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,

@@ -99,7 +99,12 @@ void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q,
 // (ctr[1]: the all-ones hash was seen, ctr[2]: distinct keys inserted so far)
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
                         u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap,
-                        const u32* row_off = nullptr /* sk_stride == 0: row r starts at sk + row_off[r] */);
+                        const u32* row_off = nullptr /* sk_stride == 0: row r starts at sk + row_off[r] */,
+                        u64* keylist = nullptr /* [dict_sort_max_keys()]: receives the keys new to the set, in arrival order */);
+// (2') a pass known to have at most dict_sort_max_keys() distinct hashes: ONE workgroup turns the key list into q / n_q and
+// empties the keys' slots of the set -- instead of launch_dict_rest's five launches over the whole set
+u32 dict_sort_max_keys();
+hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_slots, u32* ctr, u64* q, u32* n_q, u32 key_bound);
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q);
 u32 dict_buckets();
@@ -117,7 +122,9 @@ u32 scan_lean_words();
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u64* m_int, u32 n_pad, bool big_table, u64* hbuf, u32* m_dirty);
 // wb[w * n_tiles + t] = (first | last << 16) band of tile t whose slice can reach query word w (first > last: none)
-void launch_word_bands(hipStream_t st, const u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb);
+// lo != NULL: also computes the windows (launch_window's work) first: one launch instead of two in front of the scan
+void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb, const u64* lo = nullptr,
+                       const u64* hi = nullptr, const u64* q = nullptr, u32* h_nq = nullptr);
 // also re-zeroes m_bits / m_int; words beyond *n_q are skipped; grp_any[rank group] (zero on entry) receives the number of
 // query rows that hold a bit for some genome of the group -- the ranking kernels skip groups with none (grp_any arguments
 // below) and compact the pairs of groups with few (rowany)
