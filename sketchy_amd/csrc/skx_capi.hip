@@ -543,7 +543,7 @@ struct skx_stream {
     u64* d_lpart_sum = nullptr;   // per-slice leader candidates (chunk_leader_part_kernel)
     u32* d_lpart_idx = nullptr;
     u32* d_rel = nullptr;         // [segments of a pass][n_pad] segment start values relative to the pass-start table
-    u64* d_lead_seg = nullptr;        // [segments of a pass][species] the ranking's bound as every segment begins (seg_lead_kernel)
+    u64* d_lead_seg = nullptr;        // [segments of a pass][species] the ranking's bound as every segment begins (chunk_leader_merge_kernel)
     unsigned char* d_has = nullptr;   // [segments of a pass][rank groups] the pruned ranking kernels reported something (the merges skip the rest)
     unsigned char* d_live = nullptr;  // [segments of a pass][n_pad / 64] top-1 ranking: the word can hold a candidate (seg_prefix_kernel)
     u64* d_cand_sum = nullptr;
@@ -1032,7 +1032,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         // few distinct hashes (known exactly from the speculative gather, else bounded by the pairs): one workgroup sorts the
         // listed keys; otherwise the five kernels that walk the hash set
         if (q_bound <= skx::dict_sort_max_keys())
-            HIPCHK(skx::launch_dict_sort(hs, st->d_keylist[b], st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], d_q, d_nq, q_bound));
+            HIPCHK(skx::launch_dict_sort(hs, st->d_keylist[b], st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], d_q, d_nq, q_bound, ref->max_ref));
         else
             skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
                                   st->d_dict_ctr[b], d_q, d_nq);

@@ -1310,41 +1310,67 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(const u64* __restrict_
     }
 }
 // The dictionary of a pass with at most kDictLdsKeys distinct hashes, by ONE workgroup: the new keys dict_insert_kernel listed
-// are sorted in LDS (bitonic, 128 KB), written to Q (with the all-ones hash last if it was seen), *n_q set, and the keys' slots
-// of the hash set cleared again -- instead of count / scan / scan / scatter / bucket sort over the whole set, five launches
-// each of which waits tens of microseconds for wave slots on a busy chip (the scan cannot start before them: ~0.25 ms per
-// batch on the scan stream's critical path, kernel timeline).  The caller knows the number of keys (published with the batch
-// summary) or a bound (the pass's pairs) and only launches this when it fits.
+// are bucket-sorted in LDS -- 2048 buckets over [0, max_ref] (hashes are uniform: ~5 keys per bucket at C2), a histogram, one
+// prefix scan, a scatter, an insertion sort per bucket: five barriers -- written to Q (with the all-ones hash last if it was
+// seen), *n_q set, and the keys' slots of the hash set cleared again.  Instead of count / scan / scan / scatter / bucket sort
+// over the whole 8 M-slot set: five launches, each of which waits tens of microseconds for wave slots on a busy chip, in front
+// of the scan (~0.25 ms per batch on the scan stream's critical path, kernel timeline).  (A bitonic network in the same place:
+// 105 barriers, 0.68 ms next to the other streams -- measured.)  The caller knows the number of keys (published with the
+// batch summary) or a bound (the pass's pairs) and only launches this when it fits.
 constexpr u32 kDictLdsKeys = 16384;
+constexpr u32 kDictLdsBuckets = 2048;
 __global__ __launch_bounds__(1024) void dict_sort_kernel(const u64* __restrict__ keylist, u64* __restrict__ ht, u32 ht_mask,
-                                                         u32* __restrict__ ctr, u64* __restrict__ q, u32* __restrict__ n_q) {
+                                                         u32* __restrict__ ctr, u64* __restrict__ q, u32* __restrict__ n_q,
+                                                         u32 bshift) {
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);
-    const u32 tid = threadIdx.x;
+    u64* keys = reinterpret_cast<u64*>(smem);  // [n] sorted by bucket
+    __shared__ u32 cnt[kDictLdsBuckets];       // bucket sizes, then fill cursors
+    __shared__ u32 base[kDictLdsBuckets + 1];
+    __shared__ u32 wsum[16];
+    const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const u32 n = min(ctr[2], kDictLdsKeys);
-    u32 p2 = 2;
-    while (p2 < n) p2 <<= 1;
-    for (u32 i = tid; i < p2; i += 1024u) keys[i] = i < n ? keylist[i] : kPad;
+    auto bucket = [&](u64 key) -> u32 { return (u32)min((u64)(kDictLdsBuckets - 1u), key >> bshift); };
+    for (u32 i = tid; i < kDictLdsBuckets; i += 1024u) cnt[i] = 0;
     __syncthreads();
-    for (u32 size = 2; size <= p2; size <<= 1) {
-        for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-            for (u32 t = tid; t < (p2 >> 1); t += 1024u) {
-                const u32 i = 2u * t - (t & (stride - 1u));
-                const u32 j = i + stride;
-                const bool up = (i & size) == 0u;
-                const u64 a = keys[i], b = keys[j];
-                if ((a > b) == up) { keys[i] = b; keys[j] = a; }
-            }
-            __syncthreads();
+    for (u32 i = tid; i < n; i += 1024u) atomicAdd(&cnt[bucket(keylist[i])], 1u);
+    __syncthreads();
+    {   // exclusive scan of the 2048 counts: two per thread, wave scans, 16 wave totals
+        const u32 c0 = cnt[2u * tid], c1 = cnt[2u * tid + 1u];
+        const u32 incl = wave_incl_scan(c0 + c1);
+        if (lane == 63u) wsum[wv] = incl;
+        __syncthreads();
+        u32 before = 0;
+        for (u32 w = 0; w < wv; ++w) before += wsum[w];
+        const u32 ex = before + incl - (c0 + c1);
+        base[2u * tid] = ex;
+        base[2u * tid + 1u] = ex + c0;
+        if (tid == 1023u) base[kDictLdsBuckets] = ex + c0 + c1;
+        cnt[2u * tid] = ex;          // fill cursors
+        cnt[2u * tid + 1u] = ex + c0;
+    }
+    __syncthreads();
+    for (u32 i = tid; i < n; i += 1024u) {
+        const u64 key = keylist[i];
+        keys[atomicAdd(&cnt[bucket(key)], 1u)] = key;
+    }
+    __syncthreads();
+    for (u32 b = tid; b < kDictLdsBuckets; b += 1024u) {  // insertion sort inside every bucket (a handful of keys)
+        const u32 lo = base[b], hi = base[b + 1u];
+        for (u32 i = lo + 1u; i < hi; ++i) {
+            const u64 v = keys[i];
+            u32 j = i;
+            while (j > lo && keys[j - 1u] > v) { keys[j] = keys[j - 1u]; --j; }
+            keys[j] = v;
         }
     }
+    __syncthreads();
     const u32 extra = ctr[1] & 1u;
     for (u32 i = tid; i < n; i += 1024u) {
         const u64 key = keys[i];
         q[i] = key;
         // empty the key's slot of the hash set for the next pass that uses it (linear probing never deleted anything, so the
-        // key sits in the first slot from its home that holds it)
+        // key sits in the first slot from its home that holds it; slots emptied meanwhile do not stop the walk)
         u32 slot = (u32)(key ^ (key >> 29)) & ht_mask;
         while (ht[slot] != key) slot = (slot + 1u) & ht_mask;
         ht[slot] = kPad;
@@ -2345,28 +2371,8 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(const u32* __restrict
     cum_out[g] = base + run;
 }
 // lead_seg[seg][species] = the smallest value, as segment seg begins, among the k genomes that ranked first when its chunk
-// began: the bound the pruned ranking kernels measure candidates against (they recompute it; here it lets seg_prefix_kernel
-// decide per word whether ANY genome of it can be a candidate).  One wave per (chunk, species); lane = segment of the chunk.
-__global__ __launch_bounds__(64) void seg_lead_kernel(const u32* __restrict__ inc, const u32* __restrict__ csum, u32 n_seg, u32 n_pad,
-                                                      const u64* __restrict__ cum_in, const u32* __restrict__ leader, u32 top_k,
-                                                      Species sp, const u32* __restrict__ grp_any, u64* __restrict__ lead_seg) {
-    __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
-    const u32 cs = blockIdx.x, c = cs / sp.n_sp, spi = cs % sp.n_sp, lane = lane_id();
-    const u32 seg = c * 16u + lane;
-    if (lane >= 16u || seg >= n_seg) return;
-    u64 lead = ~0ull;
-    for (u32 j = 0; j < top_k; ++j) {
-        const u32 gl = leader[cs * top_k + j];
-        u64 v = cum_in[gl];
-        if (grp_any[gl / (kRankWords * 64u)]) {
-            u32 run = csum[(size_t)c * n_pad + gl];
-            for (u32 s2 = c * 16u; s2 < seg; ++s2) run += inc[(size_t)s2 * n_pad + gl];
-            v += run;
-        }
-        lead = min(lead, v);
-    }
-    lead_seg[(size_t)seg * sp.n_sp + spi] = lead;
-}
+// began: the bound the pruned ranking kernels measure candidates against (they recompute it; seg_prefix_kernel uses it to decide
+// per word whether ANY genome of it can be a candidate).  Computed by chunk_leader_merge_kernel, one wave per (chunk, species).
 // live != NULL (top-1 ranking): live[seg][genome word] = some genome of the word ENDS segment seg at or above lead_val of
 // the segment's chunk (the leader's value as the chunk began -- the leader only grows, so that is a lower bound of
 // every bound the ranking uses inside the chunk).  Words that cannot are never looked at by rank_seg_top1_kernel, and
@@ -2405,7 +2411,7 @@ __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__
         if (s0 + i < s1) {
             const u32 start = run;
             run += t[i];
-            // (the segment's own bound, seg_lead_kernel: exactly the candidate test of the ranking kernels, per word)
+            // (the segment's own bound, chunk_leader_merge_kernel: exactly the candidate test of the ranking kernels, per word)
             const u64 lv = lead_seg[(size_t)(s0 + i) * sp.n_sp + spi];
             const bool any = __ballot(base + run >= lv) != 0ull;  // (padding genomes: base 0, never gain)
             if (any) rel[(size_t)(s0 + i) * n_pad + g] = start;
@@ -2439,6 +2445,7 @@ __device__ __forceinline__ void wave_best(u64& sum, u32& idx, bool ok) {
 // kLeaderParts blocks per chunk finds the first top_k of its slice of the genomes, (b) one wave per chunk merges the
 // kLeaderParts x top_k candidates.
 constexpr u32 kLeaderParts = 32;
+constexpr u32 kTopkFastMax = 16;  // (= kTopkFast, defined with the top-k kernel below)
 __global__ __launch_bounds__(256) void chunk_leader_part_kernel(const u64* __restrict__ cum_in, const u32* __restrict__ csum,
                                                                  u32 n_pad, Species sp, u32 top_k,
                                                                  u64* __restrict__ part_sum, u32* __restrict__ part_idx) {
@@ -2481,9 +2488,14 @@ __global__ __launch_bounds__(256) void chunk_leader_part_kernel(const u64* __res
     }
 }
 // one wave per chunk
+// lead_seg != NULL: the wave goes on with the per-segment bounds of its (chunk, species) -- one launch less on the ranking chain
 __global__ __launch_bounds__(64) void chunk_leader_merge_kernel(const u64* __restrict__ part_sum, const u32* __restrict__ part_idx,
-                                                                u32 top_k, u32* __restrict__ leader, u64* __restrict__ lead_val) {
+                                                                u32 top_k, u32* __restrict__ leader, u64* __restrict__ lead_val,
+                                                                const u32* __restrict__ inc, const u32* __restrict__ csum, u32 n_seg,
+                                                                u32 n_pad, const u64* __restrict__ cum_in, Species sp,
+                                                                const u32* __restrict__ grp_any, u64* __restrict__ lead_seg) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
+    __shared__ u32 s_leader[kTopkFastMax];
     const u32 c = blockIdx.x, lane = lane_id(), n_cand = kLeaderParts * top_k;
     u64 ps = 0; u32 pi = 0; bool first = true;
     for (u32 j = 0; j < top_k; ++j) {
@@ -2496,10 +2508,28 @@ __global__ __launch_bounds__(64) void chunk_leader_merge_kernel(const u64* __res
             if (bi == 0xFFFFFFFFu || ranks_before(v, g, bs, bi)) { bs = v; bi = g; }
         }
         wave_best(bs, bi, bi != 0xFFFFFFFFu);
-        if (lane == 0) leader[c * top_k + j] = bi;
+        if (lane == 0) { leader[c * top_k + j] = bi; if (j < kTopkFastMax) s_leader[j] = bi; }
         ps = bs; pi = bi; first = false;
     }
     if (lane == 0) lead_val[c] = ps;  // value of the top_k-th ranked genome as the chunk begins (top_k <= n_genomes)
+    if (lead_seg == nullptr) return;
+    // lead_seg[seg][species] (chunk_leader_merge_kernel): lane = segment of the chunk
+    wave_sync();
+    const u32 ch = c / sp.n_sp, spi = c % sp.n_sp;
+    const u32 seg = ch * 16u + lane;
+    if (lane >= 16u || seg >= n_seg) return;
+    u64 lead = ~0ull;
+    for (u32 j = 0; j < top_k; ++j) {
+        const u32 gl = s_leader[j];
+        u64 v = cum_in[gl];
+        if (grp_any[gl / (kRankWords * 64u)]) {
+            u32 run = csum[(size_t)ch * n_pad + gl];
+            for (u32 s2 = ch * 16u; s2 < seg; ++s2) run += inc[(size_t)s2 * n_pad + gl];
+            v += run;
+        }
+        lead = min(lead, v);
+    }
+    lead_seg[(size_t)seg * sp.n_sp + spi] = lead;
 }
 
 // rank_seg (generic, top_k > 16): walk a segment's reads in order from its start values; after every read emit this genome
@@ -2855,6 +2885,7 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
 // and every read takes k rounds of "largest key below the previous winner" over the group's candidates.
 // Non-candidates never take part.  Output: cand_sum / cand_idx[(r * n_grp + grp) * top_k + j], idx 0xFFFFFFFF = none.
 constexpr u32 kTopkFast = 16;
+static_assert(kTopkFast == kTopkFastMax, "chunk_leader_merge_kernel's LDS copy of the leaders");
 __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ pair_r,
                                                             const u32* __restrict__ poff, u32 p_base, u32 r_begin,
                                                             u32 n_reads, const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
@@ -3261,7 +3292,7 @@ void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32*
                        r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off, keylist, keylist ? kDictLdsKeys : 0u);
 }
 u32 dict_sort_max_keys() { return kDictLdsKeys; }
-hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_slots, u32* ctr, u64* q, u32* n_q, u32 key_bound) {
+hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_slots, u32* ctr, u64* q, u32* n_q, u32 key_bound, u64 max_ref) {
     {   // > 64 KiB of dynamic LDS needs the opt-in, once per device (as launch_sketch)
         static std::mutex mu;
         static unsigned long long done[4] = {0, 0, 0, 0};
@@ -3275,9 +3306,10 @@ hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_
             if (dev >= 0 && dev < 256) done[dev >> 6] |= 1ull << (dev & 63);
         }
     }
-    u32 p2 = 2;
-    while (p2 < std::min(key_bound, kDictLdsKeys)) p2 <<= 1;
-    hipLaunchKernelGGL(dict_sort_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, keylist, ht, ht_slots - 1u, ctr, q, n_q);
+    const u32 bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
+    const u32 bshift = bits > 11u ? bits - 11u : 0u;  // hashes <= max_ref  =>  hash >> bshift < 2^11 buckets
+    const size_t lds = (size_t)std::max<u32>(64u, std::min(key_bound, kDictLdsKeys)) * 8;
+    hipLaunchKernelGGL(dict_sort_kernel, dim3(1), dim3(1024), lds, st, keylist, ht, ht_slots - 1u, ctr, q, n_q, bshift);
     return hipGetLastError();
 }
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
@@ -3407,11 +3439,8 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
         hipLaunchKernelGGL(chunk_leader_part_kernel, dim3(n_chunks * sp.n_sp, kLeaderParts), dim3(256), 0, st, cum_in, csum, n_pad,
                            sp, prune_top_k, part_sum, part_idx);
         hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
-                           lead_val);
+                           lead_val, inc, csum, n_seg, n_pad, cum_in, sp, grp_any, live ? lead_seg : nullptr);  // (+ seg_lead's work)
     }
-    if (prune_top_k && live)
-        hipLaunchKernelGGL(seg_lead_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, inc, csum, n_seg, n_pad, cum_in, leader, prune_top_k, sp,
-                           grp_any, lead_seg);
     hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
                        lead_val, n_pad / 256, sp, grp_any, cum_in, prune_top_k ? live : nullptr, lead_seg);  // (live: the caller's choice, top-1 path only)
 }

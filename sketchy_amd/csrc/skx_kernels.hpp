@@ -104,7 +104,7 @@ void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32*
 // (2') a pass known to have at most dict_sort_max_keys() distinct hashes: ONE workgroup turns the key list into q / n_q and
 // empties the keys' slots of the set -- instead of launch_dict_rest's five launches over the whole set
 u32 dict_sort_max_keys();
-hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_slots, u32* ctr, u64* q, u32* n_q, u32 key_bound);
+hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_slots, u32* ctr, u64* q, u32* n_q, u32 key_bound, u64 max_ref);
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q);
 u32 dict_buckets();
