@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip value_cold / value_steady_state / stage breakdown (profiling runs)")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the value_batch_x2 leg (batches of twice --batch reads)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity checks of the timed steps (profiling runs only)")
     ap.add_argument("--no-shuffle", action="store_true", help="experiment: keep genomes grouped by lineage")
     ap.add_argument("--lineages", type=int, default=0, help="experiment: number of lineages of the synthetic clone tree")
@@ -406,6 +407,70 @@ def main():
             out["value_steady_state"] = {"value": n_long * B * world / float(np.median(steady)), "unit": "reads/s", "steps": n_long,
                                          "median_of": 3, "all": [n_long * B * world / t for t in steady],
                                          "what": f"the stream continued past {(W + K) * B} reads per GPU without reset (batches cycled)"}
+        # value_batch_x2: the same stream in batches twice as large (one reference scan amortised over twice the reads; the
+        # rows are the same whatever the batching).  `value` stays on the batch the workload names (one ~100k-read sample per step).
+        if not args.no_large_batch:
+            B2 = 2 * B
+            n2 = 5
+            big = [synth.make_reads_torch(genome_t, B2, read_len, err=0.05, rng_seed=5000 + 1000 * rank + i, lognormal_sigma=sigma, device=tdev)
+                   for i in range(n2)]
+            big_bases = [int(o[-1].item()) for _, o in big]
+            S2 = api.SumOfSharedHashes(R, top=top, max_batch_reads=B2, max_batch_bases=max(big_bases))
+            d2_ti = torch.zeros((B2, rows), dtype=torch.int32, device=tdev)
+            d2_ts = torch.zeros((B2, rows), dtype=torch.int64, device=tdev)
+
+            def step2(i):
+                bb, oo = big[i % n2]
+                S2.enqueue_device(bb.data_ptr(), oo.data_ptr(), B2, big_bases[i % n2], d2_ti.data_ptr() if top else None, d2_ts.data_ptr() if top else None)
+            for i in range(2):
+                step2(i)
+            S2.sync()
+            k2 = max(4, K // 2)
+            t_big = []
+            for rep in range(3):
+                S2.reset()
+                shard.barrier()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for i in range(k2):
+                    step2(i)
+                S2.sync()
+                t_big.append(shard.max_over_ranks(time.perf_counter() - tc))
+            # the rows of the last step against the same reads in 4096-read cuts (table before that step replayed)
+            big_ok = None
+            if not args.no_check and top:
+                last_i = d2_ti.cpu().numpy().view(np.uint32).copy()
+                S2.reset()
+                for i in range(k2 - 1):
+                    step2(i)
+                S2.sync()
+                tp = S2.table()
+                bb, oo = big[(k2 - 1) % n2]
+                cut_lo2 = torch.arange(0, B2, CHECK_CUT, device=tdev)
+                cb = int((oo[torch.clamp(cut_lo2 + CHECK_CUT, max=B2)] - oo[cut_lo2]).max().item())
+                V2 = api.SumOfSharedHashes(R, top=top, max_batch_reads=CHECK_CUT, max_batch_bases=max(cb, 1))
+                V2.table_add(tp)
+                v2 = torch.zeros((B2, rows), dtype=torch.int32, device=tdev)
+                v2s = torch.zeros((B2, rows), dtype=torch.int64, device=tdev)
+                for a in range(0, B2, CHECK_CUT):
+                    n = min(CHECK_CUT, B2 - a)
+                    o = oo[a:a + n + 1]
+                    V2.push_device(bb.data_ptr(), o.data_ptr(), n, int((o[-1] - o[0]).item()), v2[a:].data_ptr(), v2s[a:].data_ptr())
+                V2.sync()
+                big_ok = bool(np.array_equal(v2.cpu().numpy().view(np.uint32), last_i))
+                V2.close()
+                del v2, v2s
+                if not big_ok:
+                    err = err or "rows of a double-size batch differ from the same reads pushed in 4096-read cuts"
+            if rank == 0:
+                tm = float(np.median(t_big))
+                out["value_batch_x2"] = {"value": k2 * B2 * world / tm, "unit": "reads/s", "reads_per_step": B2, "steps": k2, "median_of": 3,
+                                         "ms_per_step": 1e3 * tm / k2, "all": [k2 * B2 * world / t for t in t_big],
+                                         "rows_match_4096_read_cuts": big_ok,
+                                         "what": "the same stream from a fresh table in batches of twice the size (one scan of the reference per "
+                                                 "batch is amortised over twice the reads); same per-read rows"}
+            S2.close()
+            del big, d2_ti, d2_ts
         # value_host_fed: the same stream with every batch coming from PAGE-LOCKED HOST memory through
         # skx_stream_submit (copy of batch i+1 over PCIe while batch i is in the kernels) and the rows going back
         if top:

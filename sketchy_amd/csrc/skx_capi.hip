@@ -561,7 +561,6 @@ struct skx_stream {
     // pass when it picks the scan variant; reads of one sample share most of their matching hashes, so |Q| can be
     // far below it.  A hint only -- every variant gives the same bits.
     // dictionary builder scratch (launch_dictionary): hash set, per-key bucket offsets, bucket counts / bases, counters
-    u64* d_keylist[2] = {nullptr, nullptr};  // keys new to the set, in arrival order (dict_insert_kernel -> dict_sort_kernel)
     u64* d_ht[2] = {nullptr, nullptr};
     u32 ht_slots = 0;
     u32 *d_slot_off = nullptr, *d_bcount = nullptr, *d_bbase = nullptr, *d_btot = nullptr, *d_dict_ctr[2] = {nullptr, nullptr};
@@ -635,7 +634,7 @@ static void stream_free(skx_stream* st) {
         if (st->ev_main[i]) (void)hipEventDestroy(st->ev_main[i]);
     }
     if (st->hs1 && st->hs1 != st->hs0) (void)hipStreamDestroy(st->hs1);
-    (void)hipFree(st->d_ht[0]); (void)hipFree(st->d_ht[1]); (void)hipFree(st->d_keylist[0]); (void)hipFree(st->d_keylist[1]); (void)hipFree(st->d_dict_ctr[0]); (void)hipFree(st->d_dict_ctr[1]);
+    (void)hipFree(st->d_ht[0]); (void)hipFree(st->d_ht[1]); (void)hipFree(st->d_dict_ctr[0]); (void)hipFree(st->d_dict_ctr[1]);
     (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
     (void)hipFree(st->d_btot);
     for (auto& sl : st->slot) {
@@ -760,7 +759,17 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     qc = std::max<u64>(std::min<u64>(qc, pc), std::min<u64>(pc, sk_stride));  // (never below one read's worth: a read alone must fit a pass)
     qc = (qc + 63) / 64 * 64;
     st->qcap = (u32)qc;
-    static const u64 pass_reads = skx::knob("SKX_PASS_READS") ? (u64)atoll(skx::knob("SKX_PASS_READS")) : 131072;
+    // reads per pass: the whole batch if the ranking's per-segment arrays fit (inc / rel: 4 bytes per (64 reads, genome) each, at most
+    // an eighth of the free device memory) -- a batch cut into two passes scans the reference twice
+    static const u64 pass_reads_env = skx::knob("SKX_PASS_READS") ? (u64)atoll(skx::knob("SKX_PASS_READS")) : 0;  // test knob
+    u64 pass_reads = 1u << 20;
+    {
+        size_t mem_free = 0, mem_total = 0;
+        (void)hipMemGetInfo(&mem_free, &mem_total);
+        const u64 per_seg = (u64)n_pad * 4 * 2 + n_pad / 64 + 64;
+        pass_reads = std::min<u64>(pass_reads, std::max<u64>(4096, (u64)(mem_free / 8) / per_seg * skx::kSegLen));
+    }
+    if (pass_reads_env) pass_reads = pass_reads_env;
     u64 rp = std::min<u64>(max_reads, pass_reads);
     // candidate arrays of the ranking: per (read, rank group, row) for top_k <= 16, per (read, genome word, row) beyond
     const u32 n_sp = ref->n_species;
@@ -889,7 +898,6 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     st->ht_slots = 1024;
     while (st->ht_slots < 2ull * st->pcap) st->ht_slots <<= 1;
     for (int i = 0; i < 2; ++i) {
-        SCHK(hipMalloc(&st->d_keylist[i], (size_t)skx::dict_sort_max_keys() * 8));
         SCHK(hipMalloc(&st->d_ht[i], (size_t)st->ht_slots * 8));
         SCHK(hipMemset(st->d_ht[i], 0xFF, (size_t)st->ht_slots * 8));  // all-ones = empty; the compaction empties it again
         SCHK(hipMalloc(&st->d_dict_ctr[i], 64));
@@ -1028,14 +1036,9 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         Span sp(st, 1, hs);
         if (!inserted)
             skx::launch_dict_insert(hs, st->d_sk, st->cur_stride, st->d_poff, ra, rb, p_base, st->d_pair_h[b], d_pair_r, st->d_ht[b],
-                                    st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len, st->d_keylist[b]);
-        // few distinct hashes (known exactly from the speculative gather, else bounded by the pairs): one workgroup sorts the
-        // listed keys; otherwise the five kernels that walk the hash set
-        if (q_bound <= skx::dict_sort_max_keys())
-            HIPCHK(skx::launch_dict_sort(hs, st->d_keylist[b], st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], d_q, d_nq, q_bound, ref->max_ref));
-        else
-            skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
-                                  st->d_dict_ctr[b], d_q, d_nq);
+                                    st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len);
+        skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
+                              st->d_dict_ctr[b], d_q, d_nq);
         if (st->d_hbuf) {  // (windows + word -> bands in one launch; also hands |Q| to the host)
             skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b], ref->d_lo, ref->d_hi, d_q, &st->h_nq[b]);
         } else {
@@ -1251,7 +1254,7 @@ static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
         if (st->pairq_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pairq[b], 0)); st->pairq_pending[b] = false; }
         if (st->pslot_pending[slot]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pslot[slot], 0)); st->pslot_pending[slot] = false; }
         skx::launch_dict_insert(hs, st->d_sk, st->cur_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h[b], st->d_pair_r[slot],
-                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len, st->d_keylist[b]);
+                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len);
         HIPCHK(hipMemcpyAsync(st->d_poff_pass[slot], st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
     }
     pb.seq = ++st->pub_seq;

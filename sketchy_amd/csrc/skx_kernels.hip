@@ -1276,14 +1276,14 @@ __device__ __forceinline__ u32 dict_bucket(u64 key, u32 bshift) { return (u32)mi
 // sk_stride == 0: pool mode -- read r's row starts at sk + row_off[r] (sketch_finish)
 // One THREAD per read (a read has a handful of pairs: one wave per read made this 98 304 nearly empty waves per C2 batch, each
 // waiting for a wave slot next to the other streams' kernels -- 100-300 us on the critical chain behind the sketcher).
-// Every key new to the set is also appended to `keylist` (ctr[2] counts them; entries beyond list_cap are dropped): a pass
-// with few distinct hashes is then sorted from the list by ONE workgroup (dict_sort_kernel) instead of the five kernels that
-// walk the whole hash set.
+// ctr[2] counts the keys new to the set: |Q| of the pass, which the batch summary hands to the host.
+// (Tried on top: listing the new keys and sorting the list by ONE workgroup in LDS instead of the five kernels that walk the
+// hash set -- a bitonic network took 0.68 ms next to the other streams, a five-barrier bucket sort 0.25 ms: a lone workgroup
+// gets a sliver of one busy CU; no gain over the chain it replaced, and quadratic on skewed hashes.  Dropped.)
 __global__ __launch_bounds__(256) void dict_insert_kernel(const u64* __restrict__ sk, u32 sk_stride, const u32* __restrict__ poff,
                                                           u32 r_begin, u32 r_end, u32 p_base, u64* __restrict__ pair_h,
                                                           u32* __restrict__ pair_r, u64* __restrict__ ht, u32 ht_mask,
-                                                          u32* __restrict__ ctr, u32 pair_cap, const u32* __restrict__ row_off,
-                                                          u64* __restrict__ keylist, u32 list_cap) {
+                                                          u32* __restrict__ ctr, u32 pair_cap, const u32* __restrict__ row_off) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 r = r_begin + blockIdx.x * 256u + threadIdx.x;
     if (r >= r_end) return;
@@ -1299,88 +1299,11 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(const u64* __restrict_
         u32 slot = (u32)(key ^ (key >> 29)) & ht_mask;
         for (;;) {
             const u64 prev = atomicCAS(&ht[slot], kPad, key);
-            if (prev == kPad) {  // a new key: ctr[2] = distinct keys in the set (|Q| of the pass)
-                const u32 pos = atomicAdd(&ctr[2], 1u);
-                if (pos < list_cap) keylist[pos] = key;
-                break;
-            }
+            if (prev == kPad) { atomicAdd(&ctr[2], 1u); break; }  // a new key: ctr[2] = distinct keys in the set (|Q| of the pass)
             if (prev == key) break;
             slot = (slot + 1u) & ht_mask;
         }
     }
-}
-// The dictionary of a pass with at most kDictLdsKeys distinct hashes, by ONE workgroup: the new keys dict_insert_kernel listed
-// are bucket-sorted in LDS -- 2048 buckets over [0, max_ref] (hashes are uniform: ~5 keys per bucket at C2), a histogram, one
-// prefix scan, a scatter, an insertion sort per bucket: five barriers -- written to Q (with the all-ones hash last if it was
-// seen), *n_q set, and the keys' slots of the hash set cleared again.  Instead of count / scan / scan / scatter / bucket sort
-// over the whole 8 M-slot set: five launches, each of which waits tens of microseconds for wave slots on a busy chip, in front
-// of the scan (~0.25 ms per batch on the scan stream's critical path, kernel timeline).  (A bitonic network in the same place:
-// 105 barriers, 0.68 ms next to the other streams -- measured.)  The caller knows the number of keys (published with the
-// batch summary) or a bound (the pass's pairs) and only launches this when it fits.
-constexpr u32 kDictLdsKeys = 16384;
-constexpr u32 kDictLdsBuckets = 2048;
-__global__ __launch_bounds__(1024) void dict_sort_kernel(const u64* __restrict__ keylist, u64* __restrict__ ht, u32 ht_mask,
-                                                         u32* __restrict__ ctr, u64* __restrict__ q, u32* __restrict__ n_q,
-                                                         u32 bshift) {
-    __builtin_amdgcn_s_setprio(3);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);  // [n] sorted by bucket
-    __shared__ u32 cnt[kDictLdsBuckets];       // bucket sizes, then fill cursors
-    __shared__ u32 base[kDictLdsBuckets + 1];
-    __shared__ u32 wsum[16];
-    const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const u32 n = min(ctr[2], kDictLdsKeys);
-    auto bucket = [&](u64 key) -> u32 { return (u32)min((u64)(kDictLdsBuckets - 1u), key >> bshift); };
-    for (u32 i = tid; i < kDictLdsBuckets; i += 1024u) cnt[i] = 0;
-    __syncthreads();
-    for (u32 i = tid; i < n; i += 1024u) atomicAdd(&cnt[bucket(keylist[i])], 1u);
-    __syncthreads();
-    {   // exclusive scan of the 2048 counts: two per thread, wave scans, 16 wave totals
-        const u32 c0 = cnt[2u * tid], c1 = cnt[2u * tid + 1u];
-        const u32 incl = wave_incl_scan(c0 + c1);
-        if (lane == 63u) wsum[wv] = incl;
-        __syncthreads();
-        u32 before = 0;
-        for (u32 w = 0; w < wv; ++w) before += wsum[w];
-        const u32 ex = before + incl - (c0 + c1);
-        base[2u * tid] = ex;
-        base[2u * tid + 1u] = ex + c0;
-        if (tid == 1023u) base[kDictLdsBuckets] = ex + c0 + c1;
-        cnt[2u * tid] = ex;          // fill cursors
-        cnt[2u * tid + 1u] = ex + c0;
-    }
-    __syncthreads();
-    for (u32 i = tid; i < n; i += 1024u) {
-        const u64 key = keylist[i];
-        keys[atomicAdd(&cnt[bucket(key)], 1u)] = key;
-    }
-    __syncthreads();
-    for (u32 b = tid; b < kDictLdsBuckets; b += 1024u) {  // insertion sort inside every bucket (a handful of keys)
-        const u32 lo = base[b], hi = base[b + 1u];
-        for (u32 i = lo + 1u; i < hi; ++i) {
-            const u64 v = keys[i];
-            u32 j = i;
-            while (j > lo && keys[j - 1u] > v) { keys[j] = keys[j - 1u]; --j; }
-            keys[j] = v;
-        }
-    }
-    __syncthreads();
-    const u32 extra = ctr[1] & 1u;
-    for (u32 i = tid; i < n; i += 1024u) {
-        const u64 key = keys[i];
-        q[i] = key;
-        // empty the key's slot of the hash set for the next pass that uses it (linear probing never deleted anything, so the
-        // key sits in the first slot from its home that holds it; slots emptied meanwhile do not stop the walk)
-        u32 slot = (u32)(key ^ (key >> 29)) & ht_mask;
-        while (ht[slot] != key) slot = (slot + 1u) & ht_mask;
-        ht[slot] = kPad;
-    }
-    if (tid == 0) {
-        if (extra) q[n] = kPad;  // the largest possible hash goes last
-        *n_q = n + extra;
-    }
-    __syncthreads();
-    if (tid == 0) { ctr[1] = 0; ctr[2] = 0; }
 }
 // used slots: count per bucket; the slot remembers its place inside the bucket (atomics spread over 2^17 addresses)
 __global__ __launch_bounds__(256) void dict_count_kernel(const u64* __restrict__ ht, u32 ht_slots, u32 bshift,
@@ -3286,31 +3209,10 @@ void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum
 }
 
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
-                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap, const u32* row_off, u64* keylist) {
+                        u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap, const u32* row_off) {
     if (r_end <= r_begin) return;
     hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 256)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
-                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off, keylist, keylist ? kDictLdsKeys : 0u);
-}
-u32 dict_sort_max_keys() { return kDictLdsKeys; }
-hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_slots, u32* ctr, u64* q, u32* n_q, u32 key_bound, u64 max_ref) {
-    {   // > 64 KiB of dynamic LDS needs the opt-in, once per device (as launch_sketch)
-        static std::mutex mu;
-        static unsigned long long done[4] = {0, 0, 0, 0};
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        std::lock_guard<std::mutex> lock(mu);
-        if (dev < 0 || dev >= 256 || !((done[dev >> 6] >> (dev & 63)) & 1ull)) {
-            e = hipFuncSetAttribute((const void*)&dict_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kDictLdsKeys * 8));
-            if (e != hipSuccess) return e;
-            if (dev >= 0 && dev < 256) done[dev >> 6] |= 1ull << (dev & 63);
-        }
-    }
-    const u32 bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
-    const u32 bshift = bits > 11u ? bits - 11u : 0u;  // hashes <= max_ref  =>  hash >> bshift < 2^11 buckets
-    const size_t lds = (size_t)std::max<u32>(64u, std::min(key_bound, kDictLdsKeys)) * 8;
-    hipLaunchKernelGGL(dict_sort_kernel, dim3(1), dim3(1024), lds, st, keylist, ht, ht_slots - 1u, ctr, q, n_q, bshift);
-    return hipGetLastError();
+                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off);
 }
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q) {

@@ -99,12 +99,7 @@ void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q,
 // (ctr[1]: the all-ones hash was seen, ctr[2]: distinct keys inserted so far)
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
                         u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap,
-                        const u32* row_off = nullptr /* sk_stride == 0: row r starts at sk + row_off[r] */,
-                        u64* keylist = nullptr /* [dict_sort_max_keys()]: receives the keys new to the set, in arrival order */);
-// (2') a pass known to have at most dict_sort_max_keys() distinct hashes: ONE workgroup turns the key list into q / n_q and
-// empties the keys' slots of the set -- instead of launch_dict_rest's five launches over the whole set
-u32 dict_sort_max_keys();
-hipError_t launch_dict_sort(hipStream_t st, const u64* keylist, u64* ht, u32 ht_slots, u32* ctr, u64* q, u32* n_q, u32 key_bound, u64 max_ref);
+                        const u32* row_off = nullptr /* sk_stride == 0: row r starts at sk + row_off[r] */);
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q);
 u32 dict_buckets();

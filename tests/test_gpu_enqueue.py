@@ -245,13 +245,17 @@ def test_row_pool_grows_when_a_batch_is_denser_than_it_is_sized_for(gpu):
 
 
 def test_more_distinct_query_hashes_than_matrix_rows(gpu):
-    """The bit matrices of a pass have `stream_query_rows` rows (default 65 536); a batch whose distinct query hashes exceed
-    them -- known from the speculative gather's key count in the published summary -- is cut into passes by its pair
-    counts.  Forced with 128 rows: rows and table as the oracle's, several passes, the younger batch's speculation undone."""
+    """The bit matrices of a pass have `stream_query_rows` rows (default 65 536; never fewer than one read can need: s).  A
+    batch whose distinct query hashes exceed them -- known from the speculative gather's key count in the published summary --
+    is cut into passes by its pair counts.  Forced with 128 rows and reads sketched with s = 192 (the collection's FIRST
+    sketch is that short, src/sketchy.rs:520-527): ~1 000 distinct hashes per batch against 192 rows -- rows and table as the
+    oracle's, many passes, the younger batch's speculation undone; the one-workgroup dictionary sort on every pass."""
     from sketchy_amd import api
-    ref, bases, offsets = workload(300, 1000, 900, read_len=2000, rng_seed=821, err=0.01)  # (a pass has at least s rows: one read's worth)
-    exp = _expect(ref["ref"], 1000, bases, offsets, 2)
-    R = api.ReferenceSketch(ref["ref"])
+    ref, bases, offsets = workload(300, 1000, 900, read_len=2000, rng_seed=821, err=0.01)
+    col_len = np.full(300, 1000, np.uint32)
+    col_len[0] = 192
+    exp = orc.stream(16, 0, 192, ref["ref"], col_len, bases, offsets, top_k=2)
+    R = api.ReferenceSketch(ref["ref"], col_len, s=192)
     try:
         api.set_option("stream_query_rows", 128)
         S = api.SumOfSharedHashes(R, top=2, max_batch_reads=400, max_batch_bases=400 * 2000)
@@ -261,10 +265,10 @@ def test_more_distinct_query_hashes_than_matrix_rows(gpu):
     np.testing.assert_array_equal(idx, exp["topk_idx"])
     np.testing.assert_array_equal(val, exp["topk_sum"])
     np.testing.assert_array_equal(S.table(), exp["cum"])
-    assert S.stats()["passes"] > 5 and S.stats()["dictionary_size"] <= 1024
+    assert S.stats()["passes"] > 8 and S.stats()["dictionary_size"] <= 192
     S.reset()
     got = S.push(bases, offsets[:301], want_shared=True)
-    full = orc.stream(16, 0, 1000, ref["ref"], np.full(300, 1000, np.uint32), bases, offsets[:301], top_k=2, want_shared=True)
+    full = orc.stream(16, 0, 192, ref["ref"], col_len, bases, offsets[:301], top_k=2, want_shared=True)
     np.testing.assert_array_equal(got["shared"], full["shared"])
     np.testing.assert_array_equal(got["topk_idx"], full["topk_idx"])
 
