@@ -127,8 +127,21 @@ SKX_API int skx_dev_synchronize(int device) {
     return SKX_OK;
 }
 
+// ------------------------------------------------------------------ host-time accounting (experiments build: SKX_HOST_TIMES=1)
+#ifdef SKX_EXPERIMENTS
+#include <chrono>
+struct HostTimes { double front = 0, wait = 0, back = 0; u64 n = 0; };
+static HostTimes g_ht;
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define SKX_T0() const double t0_ = now_us()
+#define SKX_ACC(field) g_ht.field += now_us() - t0_
+#else
+#define SKX_T0() do {} while (0)
+#define SKX_ACC(field) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------ policies (skx_set_option)
-static bool g_kmer_prefilter = true;  // build / use the k-mer prefilter for k = 16 references
+static bool g_kmer_prefilter = false;  // build / use the k-mer prefilter for k = 16 references (off: no gain inside the pipeline)
 static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
 static u32 g_stream_query_rows = 0;       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
 
@@ -365,13 +378,13 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipGetLastError());
     }
     RCHK(hipDeviceSynchronize());
-    static const bool pf_knob = !skx::knob("SKX_KMER_PREFILTER") || atoi(skx::knob("SKX_KMER_PREFILTER")) != 0;  // experiment knob
+    const bool pf_knob = skx::knob("SKX_KMER_PREFILTER") ? atoi(skx::knob("SKX_KMER_PREFILTER")) != 0 : g_kmer_prefilter;  // (experiment knob overrides the policy)
     // table bits per key.  Measured at C2 (6 M keys): 16 bits (16 MB table, 0.7 % false positives) loses 8 % against no prefilter at
     // all -- 147 M random 4-byte gathers per batch into a table far beyond the 4 MB of L2 an XCD has become fabric traffic
     // three times the reference scan's; 4 bits (4 MB, ~15 % false positives = ~4 murmur3 batches per read instead of 24) keeps
     // the gathers in L2: +2.5 % in the pipeline, +10 % for a lone batch.
     static const u32 kf_bits = skx::knob("SKX_KF_BITS") ? (u32)std::max(1, atoi(skx::knob("SKX_KF_BITS"))) : 4u;
-    if (k == 16 && any && g_kmer_prefilter && pf_knob) {
+    if (k == 16 && any && pf_knob) {
         // every canonical 16-mer whose hash passes the filter above (two passes over the 2^32 codes: count, then insert);
         // 16 table bits per key, two probes: ~1.4 % false positives, each costing one murmur3 evaluation per occurrence
         u32* d_n = nullptr;
@@ -1348,7 +1361,11 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         for (int i = 0; i < 2; ++i)
             if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
     (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-    SKXCHK(queue_front(st, pb, leave_room));
+    {
+        SKX_T0();
+        SKXCHK(queue_front(st, pb, leave_room));
+        SKX_ACC(front);
+    }
     st->chk_dirty = false;  // the publish kernel is queued: it re-arms the device-side counters
     pb.valid = true;
     return SKX_OK;
@@ -1394,7 +1411,11 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     u64 big_counted = 0;
     for (int round = 0;; ++round) {
         if (round > 6) return fail(SKX_ERR_HIP, "internal: the batch's front half does not settle");
-        SKXCHK(wait_published(st, pb));  // the one wait of a batch: 48 bytes, no copy, no stream synchronisation
+        {
+            SKX_T0();
+            SKXCHK(wait_published(st, pb));  // the one wait of a batch: 48 bytes, no copy, no stream synchronisation
+            SKX_ACC(wait);
+        }
         if ((pb.h_sketches || pb.h_sketch_len) && !outputs_synced) { HIPCHK(hipStreamSynchronize(hs)); outputs_synced = true; }  // (debug outputs: their copies must have landed)
         u32 c[12];
         for (int i = 0; i < 12; ++i) c[i] = st->h_chk[i];
@@ -1471,6 +1492,7 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
         return SKX_OK;
     };
     int pass_rc;
+    SKX_T0();
     if (single) {
         pass_rc = one_pass(0, n_reads, 0, total_pairs);  // the whole batch is one pass: no per-read offsets needed
     } else {
@@ -1478,6 +1500,13 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
         HIPCHK(hipStreamSynchronize(st->hs1));
         pass_rc = for_each_pass(st, n_reads, pb.dbg_cap, one_pass);
     }
+    SKX_ACC(back);
+#ifdef SKX_EXPERIMENTS
+    g_ht.n += 1;
+    if (skx::knob("SKX_HOST_TIMES") && (g_ht.n % 64) == 0)
+        fprintf(stderr, "[skx host times] per batch over %llu: front %.1f us, wait for summary %.1f us, queue passes %.1f us\n",
+                (unsigned long long)g_ht.n, g_ht.front / g_ht.n, g_ht.wait / g_ht.n, g_ht.back / g_ht.n);
+#endif
     if (d_shared) (void)hipFree(d_shared);
     SKXCHK(pass_rc);
     st->reads_total += n_reads;

@@ -392,10 +392,14 @@ def test_kmer_prefilter_gives_the_oracles_rows(gpu, seed):
             np.testing.assert_array_equal(full["shared"], exp["shared"])
             S.close(); R.close()
     finally:
-        api.set_option("kmer_prefilter", 1)
+        api.set_option("kmer_prefilter", 0)
     # dense: s = 20 000 of a 30 kb genome -- two thirds of all windows are reference k-mers
     ref, bases, offsets = workload(12, 20000, 60, read_len=1500, seed=seed, genome_len=30000, rng_seed=7100 + seed)
-    got, exp, R, S = check(ref, bases, offsets, top=1, seed=seed, want_sketches=False)
+    try:
+        api.set_option("kmer_prefilter", 1)
+        got, exp, R, S = check(ref, bases, offsets, top=1, seed=seed, want_sketches=False)
+    finally:
+        api.set_option("kmer_prefilter", 0)
     assert R.kmer_filter[0] > 10000 and exp["shared"].max() > 256
 
 
