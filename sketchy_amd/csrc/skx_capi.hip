@@ -144,10 +144,16 @@ static inline double now_us() { return std::chrono::duration<double, std::micro>
 static bool g_kmer_prefilter = false;  // build / use the k-mer prefilter for k = 16 references (off: no gain inside the pipeline)
 static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
 static u32 g_stream_query_rows = 0;       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
+static u32 g_stream_coalesce = 2;         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 or 2)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
     if (!name) return fail(SKX_ERR_INVALID, "NULL option name");
     if (!strcmp(name, "kmer_prefilter")) { g_kmer_prefilter = value != 0; return SKX_OK; }
+    if (!strcmp(name, "stream_coalesce")) {
+        if (value < 1 || value > 2) return fail(SKX_ERR_INVALID, "stream_coalesce must be 1 or 2");
+        g_stream_coalesce = (u32)value;
+        return SKX_OK;
+    }
     if (!strcmp(name, "stream_query_rows")) {
         if (value > (1u << 22)) return fail(SKX_ERR_INVALID, "stream_query_rows must be 0 (default) .. 2^22");
         g_stream_query_rows = (u32)value;
@@ -165,6 +171,7 @@ SKX_API int skx_get_option(const char* name, uint64_t* value) {
     if (!strcmp(name, "kmer_prefilter")) { *value = g_kmer_prefilter ? 1 : 0; return SKX_OK; }
     if (!strcmp(name, "filter_bits_per_hash")) { *value = g_filter_bits_per_hash; return SKX_OK; }
     if (!strcmp(name, "stream_query_rows")) { *value = g_stream_query_rows; return SKX_OK; }
+    if (!strcmp(name, "stream_coalesce")) { *value = g_stream_coalesce; return SKX_OK; }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -469,6 +476,10 @@ struct PendingBatch {
     u32 seq = 0;               // sequence number its summary is published under
     bool spec_insert = false;  // its pairs were gathered into buffer set spec_set / pair slot spec_slot right behind the sketcher
     int spec_set = 0, spec_slot = 0;
+    bool pairable = false;     // it came through an entry point whose batches may share a pass (enqueue / submit, stream_coalesce = 2)
+    bool second = false;       // it shares the pass of the batch enqueued before it: same set / slot, its pairs behind that batch's
+    int first_side = 0;        // ... whose side holds the pair count its gather starts at
+    u32 first_reads = 0;
     bool inrange_only = true;
     bool rows_mode = false;    // its sketch rows are full-width rows (debug outputs / no filter), not reservations out of the pool
     u32 dbg_cap = 0xFFFFFFFFu;
@@ -478,6 +489,7 @@ struct PendingBatch {
     void* slot = nullptr;      // skx_stream::Staged of a host-fed batch: its rows travel to the host behind the ranking
 };
 
+static const int kSides = 3;  // copies of the per-batch sketch outputs: two enqueued batches waiting for their shared pass + the one being sketched
 struct skx_stream {
     const skx_ref* ref = nullptr;
     int device = 0;
@@ -493,16 +505,18 @@ struct skx_stream {
     // ev_main) so that the sketch stream runs main kernel after main kernel: those ~8 short, latency-bound kernels cost the
     // sketch stream 150-250 us per batch next to the other streams' work (kernel trace), a fifth of the step.
     hipStream_t hs1 = nullptr;  // aliases hs0 below pipeline depth 3
-    hipEvent_t ev_main[2] = {nullptr, nullptr};  // sketch stream: everything of the batch queued on hs0 is done (per side)
+    hipEvent_t ev_main[kSides] = {nullptr, nullptr, nullptr};  // sketch stream: everything of the batch queued on hs0 is done (per side)
     int depth = 2;
     int buf = 0;
     hipEvent_t ev_dict[2] = {nullptr, nullptr}, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
     // per side of the sketch buffers (see d_sk below):
-    hipEvent_t ev_sketch[2] = {nullptr, nullptr};  // sketch stream: the batch's sketches, pair offsets (and speculative pair gather) are done
-    hipEvent_t ev_skread[2] = {nullptr, nullptr};  // scan stream: a pass that gathered its own pairs has read the sketch buffers
-    bool sk_reader_pending[2] = {false, false};
+    hipEvent_t ev_sketch[kSides] = {nullptr, nullptr, nullptr};  // hs1: the batch's sketches, pair offsets (and speculative pair gather) are done
+    hipEvent_t ev_skread[kSides] = {nullptr, nullptr, nullptr};  // scan stream: a pass that gathered its own pairs has read the sketch buffers
+    bool sk_reader_pending[kSides] = {false, false, false};
     int side = 0;                                  // the side d_sk ... h_chk currently name
-    PendingBatch pend;                             // skx_stream_enqueue_device: the batch whose back half is still to come
+    PendingBatch pend[2];                          // skx_stream_enqueue_device: the batches whose back half is still to come (two: they share a pass)
+    int n_pend = 0;
+    int side_next = 0;                             // sides are taken in turn: at most two pending batches + the one being sketched
     bool front_pending[2] = {false, false};
     bool back_pending[2] = {false, false};
     // The per-pass pair lists the ranking reads (read of every pair, the pass's pair offsets) rotate over THREE slots, and a
@@ -519,6 +533,7 @@ struct skx_stream {
     u64 max_bases = 0;
     u32 pcap = 0;        // pairs per pass
     u32 qcap = 0;        // distinct query hashes per pass = rows of the pass's bit matrices (|Q| <= pairs, usually far below)
+    u32 coalesce = 1;    // enqueued batches that may share a pass (policy stream_coalesce at creation)
     u32 rpass = 0;       // reads per pass
     u64 reads_total = 0;
     // staging for host pushes
@@ -529,15 +544,15 @@ struct skx_stream {
     // side in use (use_side); side 1 is allocated by the first call that needs it.
     u64* d_sk = nullptr;
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
-    u64* sd_sk[2] = {nullptr, nullptr};       // POOL of a side: production rows are exact-size reservations (sketch_finish, pool mode)
-    u64 pool_cap[2] = {0, 0};                // ... its entries: a fixed slot per read first (pool_fixed), the reservable part behind
+    u64* sd_sk[kSides] = {nullptr, nullptr, nullptr};       // POOL of a side: production rows are exact-size reservations (sketch_finish, pool mode)
+    u64 pool_cap[kSides] = {0, 0, 0};        // ... its entries: a fixed slot per read first (pool_fixed), the reservable part behind
     u32 pool_fixed = 0;
-    u64* sd_rows[2] = {nullptr, nullptr};    // full-width rows [max_reads][sk_stride] of a side: debug outputs / skx_common_hashes; allocated on first use
+    u64* sd_rows[kSides] = {nullptr, nullptr, nullptr};    // full-width rows [max_reads][sk_stride] of a side: debug outputs / skx_common_hashes; allocated on first use
     u32 cur_stride = 0;                      // what the kernels get as row stride for d_sk: 0 = pool mode
     u32 cur_pool_cap = 0, cur_pool_fixed = 0;
-    u32 *sd_len[2] = {nullptr, nullptr}, *sd_cnt[2] = {nullptr, nullptr}, *sd_poff[2] = {nullptr, nullptr}, *sd_big[2] = {nullptr, nullptr};
-    u32 *sd_chk[2] = {nullptr, nullptr}, *sd_retry[2] = {nullptr, nullptr};  // (per side: batch i's summary is published while batch i + 1 is sketched)
-    skx::LongReads sd_lr[2] = {{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u}, {nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u}};
+    u32 *sd_len[kSides] = {}, *sd_cnt[kSides] = {}, *sd_poff[kSides] = {}, *sd_big[kSides] = {};
+    u32 *sd_chk[kSides] = {}, *sd_retry[kSides] = {};  // (per side: batch i's summary is published while batch i + 1 is sketched)
+    skx::LongReads sd_lr[kSides] = {};
     // pass workspace (per buffer set: pair hashes, hash set and its counters, Q, windows, pair lists, Mq)
     u64 *d_pair_h[2] = {nullptr, nullptr}, *d_q[2] = {nullptr, nullptr};
     u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
@@ -603,6 +618,8 @@ struct skx_stream {
         u64 n_bases = 0, ticket = 0;
         u32* out_idx = nullptr;
         u64* out_sum = nullptr;
+        u32* d_rows_idx = nullptr;  // the slot's own device rows (two batches may share a pass: each needs its rows until they are copied out)
+        u64* d_rows_sum = nullptr;
         uint8_t* d_bases = nullptr;
         u64 *d_offsets = nullptr, *h_offsets = nullptr;
         hipEvent_t ev_copy = nullptr, ev_done = nullptr;
@@ -628,8 +645,11 @@ static void stream_free(skx_stream* st) {
     if (st->hs1) (void)hipStreamSynchronize(st->hs1);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     if (st->hs2) (void)hipStreamSynchronize(st->hs2);
-    void* ptrs[] = {st->d_bases, st->d_offsets, st->sd_sk[0], st->sd_len[0], st->sd_cnt[0], st->sd_poff[0], st->sd_big[0],
-                    st->sd_sk[1], st->sd_len[1], st->sd_cnt[1], st->sd_poff[1], st->sd_big[1], st->sd_rows[0], st->sd_rows[1], st->d_pair_h[0], st->d_pair_h[1],
+    for (int i = 0; i < kSides; ++i) {
+        void* side_ptrs[] = {st->sd_sk[i], st->sd_len[i], st->sd_cnt[i], st->sd_poff[i], st->sd_big[i], st->sd_rows[i]};
+        for (void* q : side_ptrs) (void)hipFree(q);
+    }
+    void* ptrs[] = {st->d_bases, st->d_offsets, st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc2[0], st->d_inc2[1] != st->d_inc2[0] ? st->d_inc2[1] : nullptr,
                     st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_has, st->d_lead_seg, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
@@ -640,7 +660,7 @@ static void stream_free(skx_stream* st) {
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
     if (st->h_chk_base) (void)hipHostFree(st->h_chk_base);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kSides; ++i) {
         (void)hipFree(st->sd_chk[i]); (void)hipFree(st->sd_retry[i]);
         (void)hipFree(st->sd_lr[i].list); (void)hipFree(st->sd_lr[i].seg0); (void)hipFree(st->sd_lr[i].seg_tab);
         (void)hipFree(st->sd_lr[i].seg_cnt); (void)hipFree(st->sd_lr[i].seg_h);
@@ -651,7 +671,7 @@ static void stream_free(skx_stream* st) {
     (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
     (void)hipFree(st->d_btot);
     for (auto& sl : st->slot) {
-        (void)hipFree(sl.d_bases); (void)hipFree(sl.d_offsets);
+        (void)hipFree(sl.d_bases); (void)hipFree(sl.d_offsets); (void)hipFree(sl.d_rows_idx); (void)hipFree(sl.d_rows_sum);
         if (sl.h_offsets) (void)hipHostFree(sl.h_offsets);
         if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
@@ -665,6 +685,8 @@ static void stream_free(skx_stream* st) {
         if (st->ev_inc[i]) (void)hipEventDestroy(st->ev_inc[i]);
         if (st->ev_front[i]) (void)hipEventDestroy(st->ev_front[i]);
         if (st->ev_back[i]) (void)hipEventDestroy(st->ev_back[i]);
+    }
+    for (int i = 0; i < kSides; ++i) {
         if (st->ev_sketch[i]) (void)hipEventDestroy(st->ev_sketch[i]);
         if (st->ev_skread[i]) (void)hipEventDestroy(st->ev_skread[i]);
     }
@@ -772,6 +794,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     qc = std::max<u64>(std::min<u64>(qc, pc), std::min<u64>(pc, sk_stride));  // (never below one read's worth: a read alone must fit a pass)
     qc = (qc + 63) / 64 * 64;
     st->qcap = (u32)qc;
+    static const u32 coalesce_env = skx::knob("SKX_COALESCE") ? (u32)atoi(skx::knob("SKX_COALESCE")) : 0u;  // experiment knob
+    st->coalesce = coalesce_env ? std::min(2u, std::max(1u, coalesce_env)) : g_stream_coalesce;
     // reads per pass: the whole batch if the ranking's per-segment arrays fit (inc / rel: 4 bytes per (64 reads, genome) each, at most
     // an eighth of the free device memory) -- a batch cut into two passes scans the reference twice
     static const u64 pass_reads_env = skx::knob("SKX_PASS_READS") ? (u64)atoll(skx::knob("SKX_PASS_READS")) : 0;  // test knob
@@ -846,6 +870,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipEventCreateWithFlags(&st->ev_inc[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_back[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < kSides; ++i) {
         SCHK(hipEventCreateWithFlags(&st->ev_sketch[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_skread[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_main[i], hipEventDisableTiming));
@@ -859,7 +885,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_pair_q[i], (size_t)st->pcap * 4));
     for (int i = 0; i < 3; ++i) {
         SCHK(hipMalloc(&st->d_pair_r[i], (size_t)st->pcap * 4));
-        SCHK(hipMalloc(&st->d_poff_pass[i], ((size_t)st->rpass + 2) * 4));
+        SCHK(hipMalloc(&st->d_poff_pass[i], 2 * ((size_t)st->rpass + 2) * 4));  // (two batches may share a pass: one region each)
         SCHK(hipEventCreateWithFlags(&st->ev_pslot[i], hipEventDisableTiming));
     }
     for (int i = 0; i < 2; ++i) {
@@ -921,8 +947,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_bcount, (size_t)skx::dict_buckets() * 4));
     SCHK(hipMemset(st->d_bcount, 0, (size_t)skx::dict_buckets() * 4));
     SCHK(hipMalloc(&st->d_bbase, (size_t)skx::dict_buckets() * 4));
-    SCHK(hipHostMalloc((void**)&st->h_chk_base, 2 * 16 * 4, hipHostMallocCoherent));  // kernels write it, the host polls it
-    memset(st->h_chk_base, 0, 2 * 16 * 4);
+    SCHK(hipHostMalloc((void**)&st->h_chk_base, kSides * 16 * 4, hipHostMallocCoherent));  // kernels write it, the host polls it
+    memset(st->h_chk_base, 0, kSides * 16 * 4);
     SCHK(use_side(st, 0));
     SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocCoherent));
     st->h_nq[0] = st->h_nq[1] = 0;
@@ -1004,12 +1030,30 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 // case: the whole batch is one pass and process_batch queued launch_dict_insert right behind the sketcher)
 // q_rows: an upper bound of the pass's distinct query hashes (<= qcap): P itself, or -- when the host knows it from the
 // speculative gather -- |Q|
-static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_topk_idx, u64* d_topk_sum,
-                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table, bool inserted = false, u32 q_rows = 0xFFFFFFFFu) {
+// A pass normally ranks ONE run of reads; two batches enqueued back to back share a pass (one dictionary, one scan of the
+// reference, one transpose) and are ranked one after the other from it: `subs` lists them -- their pairs sit one behind the
+// other in the pass's pair lists (p_off), each with its own pair offsets (d_poff, relative to its own first pair), reads and
+// output rows.  The scan is the only cost of a step that does not grow with the reads: two batches per scan is what a batch
+// of twice the size would give, without asking the caller for it.
+struct SubPass {
+    u32 ra = 0, rb = 0;           // reads [ra, rb) of the batch
+    u32 p_off = 0, P = 0;         // its pairs: [p_off, p_off + P) of the pass's pair lists
+    u32 p_base = 0;               // value of the batch's pair offset at read ra (non-speculative passes: absolute offsets)
+    const u32* d_poff = nullptr;  // inserted passes: the copy of the batch's pair offsets the front half left in the slot
+    u32* d_topk_idx = nullptr;
+    u64* d_topk_sum = nullptr;
+    u32* d_shared = nullptr;      // [rb-ra][n_genomes] or NULL
+    int side = 0;
+};
+static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_table, bool inserted, u32 q_rows) {
     const skx_ref* ref = st->ref;
     hipStream_t hs0 = st->hs0, hs = st->hs, hs2 = st->hs2;
     const skx::Species spc = ref->species();
-    const u32 n_pad = ref->n_pad, n_gw = n_pad / 64, n_reads = rb - ra;
+    const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
+    u32 P = 0;
+    for (int i = 0; i < n_sub; ++i) P += subs[i].P;
+    const u32 ra = subs[0].ra, rb = subs[0].rb, p_base = subs[0].p_base;  // (the non-speculative gather below: single-batch passes only)
+    if (!inserted && n_sub != 1) return fail(SKX_ERR_HIP, "internal: a shared pass needs its pairs gathered by the front halves");
     const u32 n_bt = ref->n_bands * ref->n_tiles;
     const u32 q_bound = std::min(P, q_rows);
     if (q_bound > st->qcap) return fail(SKX_ERR_HIP, "internal: pass of %u query rows exceeds the matrices' %u", q_bound, st->qcap);
@@ -1037,13 +1081,14 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
     // and by its ranking on the back stream (pair -> query index, Mq, group flags) -- the wait for that ranking sits
     // further down, right before those are overwritten.
     (void)hs0;
-    HIPCHK(hipStreamWaitEvent(hs, st->ev_sketch[st->side], 0));  // this batch's sketches and pair offsets
+    for (int i = 0; i < n_sub; ++i) HIPCHK(hipStreamWaitEvent(hs, st->ev_sketch[subs[i].side], 0));  // the batches' sketches and pair offsets
     st->front_pending[b] = false;  // (this stream recorded it)
     // (inserted: the sketch stream also copied the pass's pair offsets -- this stream then never touches the sketch buffers,
     // which the next batch's sketch is free to overwrite)
     if (!inserted) {
         if (st->pslot_pending[slot]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pslot[slot], 0)); st->pslot_pending[slot] = false; }
-        HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
+        HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)(rb - ra) + 1) * 4, hipMemcpyDeviceToDevice, hs));
+        subs[0].d_poff = d_poff;
     }
     if (P > 0) {
         Span sp(st, 1, hs);
@@ -1136,15 +1181,22 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
 
     // ---- back half: per-segment increments and their chunk sums (stream hs3: they need this pass's Mq only), then the
     // running table and the per-read rows (stream hs2, in pass order); overlaps the next pass's front half
-    hipStream_t hs3 = st->hs3;
+    hipStream_t hs3 = n_sub > 1 ? st->hs2 : st->hs3;  // (a shared pass ranks its batches strictly one after the other)
     u32 *d_inc = st->d_inc2[b], *d_csum_raw = st->d_csum_raw2[b];
-    const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
     HIPCHK(hipStreamWaitEvent(hs3, st->ev_front[b], 0));
+    for (int si = 0; si < n_sub; ++si) {
+    const SubPass& sb = subs[si];
+    const u32 n_reads = sb.rb - sb.ra, sub_base = sb.p_base;
+    const u32 *sub_pair_q = d_pair_q + sb.p_off, *sub_pair_r = d_pair_r + sb.p_off, *sub_poff = sb.d_poff;
+    u32* const d_topk_idx = sb.d_topk_idx;
+    u64* const d_topk_sum = sb.d_topk_sum;
+    const u32 out_r0 = sb.ra;
+    const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
     if (update_table) {
         Span sp(st, 4, hs3);
         // (the chunk sums are accumulated by seg_sum's workgroups: four atomic adds per chunk and genome)
         HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * n_pad * 4, hs3));
-        skx::launch_seg_sum(hs3, d_pair_q, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
+        skx::launch_seg_sum(hs3, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
                             d_csum_raw, P > 0 ? st->d_rowany[b] : nullptr, d_nq);
         HIPCHK(hipGetLastError());
     }
@@ -1166,34 +1218,44 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
         if (top1_fast && d_topk_idx && d_topk_sum) {
-            skx::launch_rank_seg_top1(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows,
+            skx::launch_rank_seg_top1(hs2, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows,
                                       spc, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, d_inc,
                                       st->d_leader, st->d_gmax, st->d_lead_val, d_grp_any, d_live, st->d_has,
                                       P > 0 ? st->d_rowany[b] : nullptr, d_nq);
-            skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, d_topk_idx, d_topk_sum, ra, spc, st->d_has,
+            skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, d_topk_idx, d_topk_sum, out_r0, spc, st->d_has,
                                    (n_gw + skx::kRankWords - 1) / skx::kRankWords);
         } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
             const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
-            skx::launch_rank_seg_topk(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
+            skx::launch_rank_seg_topk(hs2, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
                                       cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, d_inc, st->d_leader,
                                       st->d_gmax, st->d_lead_val, d_grp_any, d_live, st->d_has);
-            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, ra, spc,
+            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, out_r0, spc,
                                    st->d_has);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
-            skx::launch_rank_seg(hs2, d_pair_q, d_pair_r, d_poff, p_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
+            skx::launch_rank_seg(hs2, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
                                  spc, cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, d_grp_any);
             skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, skx::kRankWords, st->top_k, d_topk_idx,
-                                   d_topk_sum, ra, spc, nullptr);
+                                   d_topk_sum, out_r0, spc, nullptr);
         }
     }
-    if (d_shared)
-        skx::launch_shared_debug(hs2, d_pair_q, d_poff, p_base, 0, n_reads, d_mq, nq_rows, ref->n_genomes, ref->d_real2pad, d_shared, 0);
+    if (sb.d_shared)
+        skx::launch_shared_debug(hs2, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, nq_rows, ref->n_genomes, ref->d_real2pad, sb.d_shared, 0);
     HIPCHK(hipGetLastError());
+    }  // sub-passes
     HIPCHK(hipEventRecord(st->ev_back[b], hs2));
     st->back_pending[b] = true;
     HIPCHK(hipEventRecord(st->ev_pslot[slot], hs2));
     st->pslot_pending[slot] = true;
     return SKX_OK;
+}
+
+static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_topk_idx, u64* d_topk_sum,
+                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table, bool inserted = false, u32 q_rows = 0xFFFFFFFFu) {
+    SubPass sb;
+    sb.ra = ra; sb.rb = rb; sb.p_off = 0; sb.P = P; sb.p_base = p_base; sb.d_topk_idx = d_topk_idx; sb.d_topk_sum = d_topk_sum;
+    sb.d_shared = d_shared; sb.side = st->side;
+    sb.d_poff = st->d_poff_pass[st->pslot];  // (inserted passes: the front half's copy; else run_pass_multi fills the slot itself)
+    return run_pass_multi(st, &sb, 1, update_table, inserted, q_rows);
 }
 
 // partition [0, n_reads) into passes by the pair counts in h_poff; calls fn(ra, rb, p_base, P)
@@ -1266,9 +1328,13 @@ static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
         // pair lists by the ranking three passes back
         if (st->pairq_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pairq[b], 0)); st->pairq_pending[b] = false; }
         if (st->pslot_pending[slot]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pslot[slot], 0)); st->pslot_pending[slot] = false; }
+        // (second: the batch shares the pass of the one before it -- same set, same slot, its pairs behind that batch's, whose
+        // count sits at the end of that batch's pair offsets on the device; its own offsets go to the slot's second region)
+        const u32* p_off_dev = pb.second ? st->sd_poff[pb.first_side] + pb.first_reads : nullptr;
         skx::launch_dict_insert(hs, st->d_sk, st->cur_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h[b], st->d_pair_r[slot],
-                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len);
-        HIPCHK(hipMemcpyAsync(st->d_poff_pass[slot], st->d_poff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToDevice, hs));
+                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len, p_off_dev);
+        HIPCHK(hipMemcpyAsync(st->d_poff_pass[slot] + (pb.second ? (size_t)st->rpass + 2 : 0), st->d_poff, ((size_t)n_reads + 1) * 4,
+                              hipMemcpyDeviceToDevice, hs));
     }
     pb.seq = ++st->pub_seq;
     skx::launch_publish(hs, st->d_chk, st->d_retry, st->d_big, st->d_poff + n_reads, st->h_chk, pb.seq,
@@ -1332,8 +1398,9 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     const skx_ref* ref = st->ref;
     hipStream_t hs = st->hs0;
     const u32 n_reads = pb.n_reads;
-    // the other side while an enqueued batch still owns one; likewise the buffer set that batch's pass will take
-    pb.side = st->pend.valid ? st->pend.side ^ 1 : 0;
+    // sides are taken in turn (two enqueued batches may be waiting for their shared pass while this one is sketched)
+    pb.side = st->side_next;
+    st->side_next = (st->side_next + 1) % kSides;
     HIPCHK(use_side(st, pb.side));
     pb.inrange_only = !(pb.h_sketches || pb.h_sketch_len);  // production: only what can meet the reference is built
     // production rows are reservations out of the side's pool; full sketches (and unfiltered ones) need full-width rows
@@ -1343,8 +1410,21 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     pb.dbg_cap = pb.h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
     static const bool spec_env = !skx::knob("SKX_SPEC_INSERT") || atoi(skx::knob("SKX_SPEC_INSERT")) != 0;  // test knob
     pb.spec_insert = spec_env && n_reads <= std::min(st->rpass, pb.dbg_cap);  // one pass unless the pairs turn out too many
-    pb.spec_set = st->buf ^ (st->pend.valid ? 1 : 0);
-    pb.spec_slot = (st->pslot + (st->pend.valid ? 1 : 0)) % 3;
+    // Two batches enqueued back to back SHARE a pass (run_pass_multi): the second one's pairs are gathered into the first one's
+    // hash set and pair lists.  Decided here, when the second one's front half is queued: the batch before it must be the only
+    // one waiting, speculative and production like this one, and the caller must have asked for it (pb.pairable: the
+    // enqueue / submit entry points of a stream created with stream_coalesce = 2).
+    const PendingBatch* prev = st->n_pend == 1 ? &st->pend[0] : nullptr;
+    pb.second = pb.pairable && prev && prev->pairable && !prev->second && prev->spec_insert && pb.spec_insert && prev->inrange_only &&
+                pb.inrange_only && !prev->rows_mode && !pb.rows_mode;
+    if (pb.second) {
+        pb.spec_set = prev->spec_set; pb.spec_slot = prev->spec_slot;
+        pb.first_side = prev->side; pb.first_reads = prev->n_reads;
+    } else {
+        // (one pass is still to come for the batches waiting -- be it one batch or two sharing it)
+        pb.spec_set = st->buf ^ (st->n_pend ? 1 : 0);
+        pb.spec_slot = (st->pslot + (st->n_pend ? 1 : 0)) % 3;
+    }
     if (st->chk_dirty) {  // an earlier batch failed half-way through this function
         HIPCHK(hipMemsetAsync(st->d_chk, 0, 64, hs));
         HIPCHK(hipMemsetAsync(st->d_retry, 0, 4, hs));
@@ -1356,7 +1436,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         st->sk_reader_pending[pb.side] = false;
     }
     // (three-stream pipeline: will the previous pass's scan be in flight?  then this sketch shares the CUs with it)
-    int leave_room = (st->depth >= 3 && st->pend.valid) ? 2 : 0;
+    int leave_room = (st->depth >= 3 && st->n_pend) ? 2 : 0;
     if (st->depth >= 3 && !leave_room)
         for (int i = 0; i < 2; ++i)
             if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
@@ -1513,14 +1593,68 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     return SKX_OK;
 }
 
-// the back half of the enqueued batch, if there is one (every entry point that looks at the stream's state starts here)
+// back half of TWO enqueued batches that share a pass (F's front half opened hash set and pair lists, S's appended to them):
+// both summaries, one dictionary / scan / transpose, two rankings.  Anything out of the ordinary in either summary -- an
+// error, a row pool that was too small, reads for the block sketcher, more pairs or distinct hashes together than a pass
+// holds -- un-shares them: the joint set is emptied and each batch takes its own pass(es), gathering its pairs on the scan
+// stream.
+static int batch_back_pair(skx_stream* st, PendingBatch& F, PendingBatch& S, PendingBatch* younger) {
+    {
+        SKX_T0();
+        SKXCHK(wait_published(st, F));
+        SKXCHK(wait_published(st, S));
+        SKX_ACC(wait);
+    }
+    const volatile u32* cF = st->h_chk_base + 16 * F.side;
+    const volatile u32* cS = st->h_chk_base + 16 * S.side;
+    const bool clean = !(cF[0] | cF[6] | cF[7] | cS[0] | cS[6] | cS[7]);
+    const u32 P_F = cF[8], P_S = cS[8], q_rows = cS[10];  // (S's summary counts the keys of the joint set)
+    const bool fits = clean && (u64)P_F + P_S <= st->pcap && q_rows != 0xFFFFFFFFu && q_rows <= st->qcap &&
+                      st->buf == F.spec_set && st->pslot == F.spec_slot;
+    if (!fits) {
+        HIPCHK(hipMemsetAsync(st->d_ht[F.spec_set], 0xFF, (size_t)st->ht_slots * 8, st->hs1));
+        HIPCHK(hipMemsetAsync(st->d_dict_ctr[F.spec_set], 0, 64, st->hs1));
+        HIPCHK(hipStreamSynchronize(st->hs1));
+        F.spec_insert = false; S.spec_insert = false; S.second = false;
+        if (younger) SKXCHK(cancel_speculation(st, *younger));  // (it counted on ONE pass ahead of its own)
+        SKXCHK(batch_back(st, F, nullptr));
+        return batch_back(st, S, nullptr);
+    }
+    F.valid = false; S.valid = false;
+    if (st->sd_lr[F.side].list) { st->reads_split += cF[1]; st->segs_split += cF[9]; }
+    if (st->sd_lr[S.side].list) { st->reads_split += cS[1]; st->segs_split += cS[9]; }
+    st->last_pairs = (u64)P_F + P_S; st->last_passes = 1;
+    SubPass subs[2];
+    const PendingBatch* pbs[2] = {&F, &S};
+    for (int i = 0; i < 2; ++i) {
+        subs[i].ra = 0; subs[i].rb = pbs[i]->n_reads; subs[i].p_base = 0; subs[i].side = pbs[i]->side;
+        subs[i].d_topk_idx = pbs[i]->d_topk_idx; subs[i].d_topk_sum = pbs[i]->d_topk_sum;
+    }
+    subs[0].p_off = 0; subs[0].P = P_F; subs[0].d_poff = st->d_poff_pass[F.spec_slot];
+    subs[1].p_off = P_F; subs[1].P = P_S; subs[1].d_poff = st->d_poff_pass[F.spec_slot] + (size_t)st->rpass + 2;
+    {
+        SKX_T0();
+        SKXCHK(run_pass_multi(st, subs, 2, true, true, q_rows));
+        SKX_ACC(back);
+    }
+    st->reads_total += (u64)F.n_reads + S.n_reads;
+    return SKX_OK;
+}
+
+// the back half of the enqueued batch(es), if there are any (every entry point that looks at the stream's state starts here)
 static int staged_rows(skx_stream* st, void* slot);
 static int flush_pending(skx_stream* st) {
-    if (!st->pend.valid) return SKX_OK;
-    PendingBatch pb = st->pend;
-    st->pend.valid = false;
-    SKXCHK(batch_back(st, pb, nullptr));
-    return staged_rows(st, pb.slot);
+    if (st->n_pend == 0) return SKX_OK;
+    PendingBatch a = st->pend[0], b = st->pend[1];
+    const int n = st->n_pend;
+    st->n_pend = 0;
+    if (n == 2) {
+        SKXCHK(batch_back_pair(st, a, b, nullptr));
+        SKXCHK(staged_rows(st, a.slot));
+        return staged_rows(st, b.slot);
+    }
+    SKXCHK(batch_back(st, a, nullptr));
+    return staged_rows(st, a.slot);
 }
 // sketch + score + rank a batch already resident on the device, both halves (synchronous entry points).
 // h_shared / h_sketches / h_sketch_len: optional HOST outputs (parity/debug).
@@ -1535,29 +1669,42 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     SKXCHK(batch_front(st, pb));
     return batch_back(st, pb, nullptr);
 }
-// ... and with the halves of consecutive batches interleaved: front(i + 1), then back(i).  Errors of batch i surface here
-// (or in the flush); the younger batch is then dropped too.
+// ... and with the halves of consecutive batches interleaved: front(i + 1), then back(i) -- or, when batches share passes,
+// front(i + 1) alone (batch i waits for its partner) and, one call later, front(i + 2), then the shared back half of i and
+// i + 1.  Errors of a batch surface here one or two calls late (or in the flush); the batches enqueued after it up to that
+// call are dropped too.
 static int enqueue_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u64 n_bases, u32* d_topk_idx,
                          u64* d_topk_sum, void* slot) {
     PendingBatch nw;
     nw.d_bases = d_bases; nw.d_offsets = d_offsets; nw.n_reads = n_reads; nw.n_bases = n_bases;
     nw.d_topk_idx = d_topk_idx; nw.d_topk_sum = d_topk_sum; nw.slot = slot;
+    nw.pairable = st->coalesce >= 2;
     SKXCHK(batch_front(st, nw));
-    if (st->pend.valid) {
-        PendingBatch old = st->pend;
-        st->pend.valid = false;
-        int rc = batch_back(st, old, &nw);
-        if (rc == SKX_OK) rc = staged_rows(st, old.slot);
-        if (rc != SKX_OK) {
-            const std::string msg = g_err;
-            (void)cancel_speculation(st, nw);
-            (void)hipStreamSynchronize(st->hs0);
-            (void)hipStreamSynchronize(st->hs1);
-            g_err = msg + " (batch enqueued one call earlier; the batch of this call was dropped too)";
-            return rc;
-        }
+    int rc = SKX_OK;
+    if (st->n_pend == 2) {
+        PendingBatch a = st->pend[0], b = st->pend[1];
+        st->n_pend = 0;
+        rc = batch_back_pair(st, a, b, &nw);
+        if (rc == SKX_OK) rc = staged_rows(st, a.slot);
+        if (rc == SKX_OK) rc = staged_rows(st, b.slot);
+    } else if (st->n_pend == 1 && !nw.second) {
+        PendingBatch a = st->pend[0];
+        st->n_pend = 0;
+        rc = batch_back(st, a, &nw);
+        if (rc == SKX_OK) rc = staged_rows(st, a.slot);
     }
-    st->pend = nw;
+    if (rc != SKX_OK) {
+        const std::string msg = g_err;
+        // whatever is still waiting goes with it: empty the sets the speculative gathers filled
+        for (int i = 0; i < st->n_pend; ++i) (void)cancel_speculation(st, st->pend[i]);
+        st->n_pend = 0;
+        (void)cancel_speculation(st, nw);
+        (void)hipStreamSynchronize(st->hs0);
+        (void)hipStreamSynchronize(st->hs1);
+        g_err = msg + " (a batch enqueued earlier; the batches enqueued after it were dropped too)";
+        return rc;
+    }
+    st->pend[st->n_pend++] = nw;
     return SKX_OK;
 }
 
@@ -1634,8 +1781,8 @@ static int staged_rows(skx_stream* st, void* slot) {
     if (!slot) return SKX_OK;
     skx_stream::Staged& sl = *static_cast<skx_stream::Staged*>(slot);
     const size_t rows = (size_t)sl.n_reads * st->ref->n_species * st->top_k;
-    if (sl.out_idx) HIPCHK(hipMemcpyAsync(sl.out_idx, st->d_topk_idx, rows * 4, hipMemcpyDeviceToHost, st->hs2));
-    if (sl.out_sum) HIPCHK(hipMemcpyAsync(sl.out_sum, st->d_topk_sum, rows * 8, hipMemcpyDeviceToHost, st->hs2));
+    if (sl.out_idx) HIPCHK(hipMemcpyAsync(sl.out_idx, sl.d_rows_idx, rows * 4, hipMemcpyDeviceToHost, st->hs2));
+    if (sl.out_sum) HIPCHK(hipMemcpyAsync(sl.out_sum, sl.d_rows_sum, rows * 8, hipMemcpyDeviceToHost, st->hs2));
     HIPCHK(hipEventRecord(sl.ev_done, st->hs2));
     sl.in_flight = true;
     return SKX_OK;
@@ -1645,12 +1792,13 @@ static int staged_process(skx_stream* st, skx_stream::Staged& sl) {
     if (!sl.pending) return SKX_OK;
     sl.pending = false;
     HIPCHK(hipStreamWaitEvent(st->hs0, sl.ev_copy, 0));  // the batch must have landed before the sketcher reads it
-    return enqueue_batch(st, sl.d_bases, sl.d_offsets, sl.n_reads, sl.n_bases, st->d_topk_idx, st->d_topk_sum, &sl);
+    return enqueue_batch(st, sl.d_bases, sl.d_offsets, sl.n_reads, sl.n_bases, sl.d_rows_idx, sl.d_rows_sum, &sl);
 }
 // ... until its rows are on the host
 static int staged_finish(skx_stream* st, skx_stream::Staged& sl) {
     SKXCHK(staged_process(st, sl));
-    if (st->pend.valid && st->pend.slot == &sl) SKXCHK(flush_pending(st));
+    for (int i = 0; i < st->n_pend; ++i)
+        if (st->pend[i].slot == &sl) { SKXCHK(flush_pending(st)); break; }
     if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
     return SKX_OK;
 }
@@ -1672,6 +1820,10 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
         for (auto& sl : st->slot) {
             HIPCHK(hipMalloc(&sl.d_bases, std::max<u64>(st->max_bases, 1)));
             HIPCHK(hipMalloc(&sl.d_offsets, ((size_t)st->max_reads + 1) * 8));
+            if (st->top_k) {
+                HIPCHK(hipMalloc(&sl.d_rows_idx, (size_t)st->max_reads * st->ref->n_species * st->top_k * 4));
+                HIPCHK(hipMalloc(&sl.d_rows_sum, (size_t)st->max_reads * st->ref->n_species * st->top_k * 8));
+            }
             HIPCHK(hipHostMalloc((void**)&sl.h_offsets, ((size_t)st->max_reads + 1) * 8, hipHostMallocDefault));
             HIPCHK(hipEventCreateWithFlags(&sl.ev_copy, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
@@ -1794,7 +1946,8 @@ SKX_API int skx_stream_reset(skx_stream* st) {
 }
 SKX_API int skx_stream_reads(const skx_stream* st, uint64_t* n_reads) {
     if (!st || !n_reads) return fail(SKX_ERR_INVALID, "NULL argument");
-    *n_reads = st->reads_total + (st->pend.valid ? st->pend.n_reads : 0u);  // (an enqueued batch counts once it is accepted)
+    *n_reads = st->reads_total;
+    for (int i = 0; i < st->n_pend; ++i) *n_reads += st->pend[i].n_reads;  // (an enqueued batch counts once it is accepted)
     return SKX_OK;
 }
 SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {

@@ -99,7 +99,8 @@ void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q,
 // (ctr[1]: the all-ones hash was seen, ctr[2]: distinct keys inserted so far)
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
                         u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap,
-                        const u32* row_off = nullptr /* sk_stride == 0: row r starts at sk + row_off[r] */);
+                        const u32* row_off = nullptr /* sk_stride == 0: row r starts at sk + row_off[r] */,
+                        const u32* p_off_dev = nullptr /* device word: pairs already in the lists (a batch sharing the pass of the one before it) */);
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q);
 u32 dict_buckets();
