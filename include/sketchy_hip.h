@@ -75,6 +75,12 @@ int skx_device_info(int device, char *name, size_t name_cap, int *compute_units,
  *   "filter_bits_per_hash"  table bits of the membership filter per DISTINCT reference hash, 4..4096 (default 32: ~0.03 % of
  *                     the read hashes no genome holds get through and cost an all-zero row each; 32 MB at 40 000 S. aureus-like
  *                     genomes x 10 000 hashes, which share all but ~6e6 of their 4e8 hashes).
+ *   "stream_query_rows"  rows of a pass's bit matrices = distinct query hashes one pass can hold; 0 (default) = 65 536, never
+ *                     fewer than one read can need (s).  A batch (or pair of batches) with more distinct in-range hashes is
+ *                     cut into several passes.  The bit matrices take rows x n_genomes / 8 bytes, three times.
+ *   "stream_coalesce" 2 (default) / 1: how many batches of skx_stream_enqueue_device / skx_stream_submit may share one
+ *                     scoring pass (see skx_stream_enqueue_device).  2 halves the scans of the reference per read at the
+ *                     cost of one more batch of latency and a third copy of the per-batch sketch rows.
  * Unknown names fail with SKX_ERR_INVALID.
  */
 int skx_set_option(const char *name, uint64_t value);
@@ -146,15 +152,20 @@ int skx_stream_push_device(skx_stream *st, const uint8_t *d_bases, const uint64_
                            uint64_t n_bases, uint32_t *d_topk_idx, uint64_t *d_topk_sum);
 /*
  * skx_stream_push_device in two halves, so that consecutive batches overlap on the device without the host in between:
- * the call queues the sketch of THIS batch first, then waits for the published summary of the batch enqueued one call
- * earlier and queues that batch's scan / ranking passes.  (skx_stream_push_device does both halves of one batch in one
- * call: the sketch stream then idles while the host queues the passes -- ~0.25 ms per 98,304-read batch, measured.)
- * Consequences: rows of batch i are written by work queued during call i + 1; an error found in batch i (offsets not
- * monotonic, a read outside n_bases) is returned by call i + 1 or by the flush, and the batch of call i + 1 is then
- * dropped as well.  d_bases / d_offsets of batch i must stay untouched until call i + 1 has returned AND the stream has
- * been synchronised, or -- simpler -- until skx_stream_sync().  skx_stream_flush() queues the outstanding half; every
- * other entry point of the stream (sync, table, rank, push, reset, stats ...) flushes first.  Rows and table are those
- * of skx_stream_push_device on the same batches in the same order (src/sketchy.rs:328-354 is sequential over reads).
+ * the call queues the sketch of THIS batch first, then waits for the published summary of the batch(es) enqueued before
+ * and queues their scan / ranking passes.  (skx_stream_push_device does both halves of one batch in one call: the sketch
+ * stream then idles while the host queues the passes -- ~0.25 ms per 98,304-read batch, measured.)
+ * With the stream option "stream_coalesce" = 2 (default) two batches enqueued back to back SHARE one pass -- one
+ * dictionary of their distinct hashes, one scan of the reference, one transpose, then one ranking each, in order -- when
+ * their pairs and distinct hashes together fit a pass; otherwise each takes its own.  The back half of batches i and
+ * i + 1 is then queued by call i + 2 (or the flush).
+ * Consequences: rows of batch i are written by work queued during call i + 1 or i + 2; an error found in batch i (offsets
+ * not monotonic, a read outside n_bases) is returned by one of those calls or by the flush -- batches enqueued BEFORE the
+ * faulty one are processed, the faulty one and those enqueued after it (up to the call that reports the error) are
+ * dropped.  d_bases / d_offsets of a batch must stay untouched until skx_stream_sync() (or any other flushing entry
+ * point followed by a synchronisation).  skx_stream_flush() queues the outstanding half; every other entry point of the
+ * stream (sync, table, rank, push, reset, stats ...) flushes first.  Rows and table are those of skx_stream_push_device
+ * on the same batches in the same order (src/sketchy.rs:328-354 is sequential over reads).
  */
 int skx_stream_enqueue_device(skx_stream *st, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
                               uint64_t n_bases, uint32_t *d_topk_idx, uint64_t *d_topk_sum);
@@ -176,7 +187,8 @@ int skx_stream_sync(skx_stream *st);
 /*
  * Host-fed pipeline.  skx_stream_submit() queues a batch from PAGE-LOCKED host buffers (skx_host_alloc; bases, offsets
  * and the optional row arrays) and returns without waiting for it: the host-to-device copy of batch i+1 runs on its
- * own stream into another staging slot (there are three) while batch i is sketched, scanned and ranked.  Processing lags one call
+ * own stream into another staging slot (three; five when batches share passes, "stream_coalesce" = 2: each holds a batch's
+ * bases, offsets and rows on the device) while batch i is sketched, scanned and ranked.  Processing lags one call
  * behind submission (submit(i) starts the copy of batch i, then runs batch i-1 through the kernels), so a single host
  * thread keeps the copy engine and the kernels busy at the same time -- what needletail's reader plus the loop of
  * src/sketchy.rs:328-354 would look like with the device in between.  Rows of batch `ticket` ([n_reads][n_species]
@@ -203,9 +215,10 @@ int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
  * far, [4] passes so far, [5] of those with the lean scan kernel, [6] pair capacity of a pass, [7] rank groups (512 genomes)
  * that received any bit in the most recent pass, [8] long reads (more than 8192 bases) whose sketch was split over several
  * wavefronts so far, [9] the segments they were cut into, [10] batches that were sketched a second time because their rows
- * did not fit the stream's row pool (it grows to fit).  Waits for the stream's queued work.
+ * did not fit the stream's row pool (it grows to fit), [11] passes that served TWO enqueued batches (option
+ * "stream_coalesce").  Waits for the stream's queued work.
  */
-#define SKX_N_STATS 11
+#define SKX_N_STATS 12
 int skx_stream_stats(skx_stream *st, uint64_t *out, uint32_t n_out);
 /* rank the CURRENT table: first top_k of (sum desc, index asc) per species; idx/sum are host arrays [n_species][top_k] */
 int skx_stream_rank(skx_stream *st, uint32_t top_k, uint32_t *idx, uint64_t *sum);

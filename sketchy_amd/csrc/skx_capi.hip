@@ -490,6 +490,7 @@ struct PendingBatch {
 };
 
 static const int kSides = 3;  // copies of the per-batch sketch outputs: two enqueued batches waiting for their shared pass + the one being sketched
+static const int kSlotsMax = 5;  // staging slots of the host-fed pipeline
 struct skx_stream {
     const skx_ref* ref = nullptr;
     int device = 0;
@@ -609,8 +610,9 @@ struct skx_stream {
     u64 reads_big = 0;       // reads that went through the block sketcher so far (statistic)
     u64 reads_split = 0, segs_split = 0;  // long reads split over waves so far, and their segments (statistic)
     u64 pool_grown = 0;                    // batches repeated with a larger row pool (statistic)
+    u64 shared_passes = 0;                 // passes that served two enqueued batches (statistic)
     u64 last_pairs = 0, last_passes = 0, total_passes = 0, lean_passes = 0;  // statistics (skx_stream_stats)
-    // host-fed pipeline (skx_stream_submit): three staging slots, a copy stream, one batch of lag
+    // host-fed pipeline (skx_stream_submit): staging slots, a copy stream, one batch of lag
     struct Staged {
         bool pending = false;   // copied (or being copied) to the device, not yet processed
         bool in_flight = false; // processed, rows possibly still on their way to the host
@@ -623,7 +625,9 @@ struct skx_stream {
         uint8_t* d_bases = nullptr;
         u64 *d_offsets = nullptr, *h_offsets = nullptr;
         hipEvent_t ev_copy = nullptr, ev_done = nullptr;
-    } slot[3];  // (three: the copy of batch i starts once batch i - 3 is through, not i - 2)
+    } slot[kSlotsMax];  // (three: the copy of batch i starts once batch i - 3 is through, not i - 2; five when two batches share
+                        // a pass -- the pass of batches i - 5 and i - 4 was queued two submits ago, not one)
+    u32 n_slots = 3;
     hipStream_t hs_copy = nullptr;
     u64 next_ticket = 0;
     u32* h_nq = nullptr;     // pinned [2]
@@ -1623,7 +1627,7 @@ static int batch_back_pair(skx_stream* st, PendingBatch& F, PendingBatch& S, Pen
     F.valid = false; S.valid = false;
     if (st->sd_lr[F.side].list) { st->reads_split += cF[1]; st->segs_split += cF[9]; }
     if (st->sd_lr[S.side].list) { st->reads_split += cS[1]; st->segs_split += cS[9]; }
-    st->last_pairs = (u64)P_F + P_S; st->last_passes = 1;
+    st->last_pairs = (u64)P_F + P_S; st->last_passes = 1; st->shared_passes += 1;
     SubPass subs[2];
     const PendingBatch* pbs[2] = {&F, &S};
     for (int i = 0; i < 2; ++i) {
@@ -1815,9 +1819,11 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     if (n_bases && !bases) return fail(SKX_ERR_INVALID, "bases is NULL");
     if ((topk_idx || topk_sum) && st->top_k == 0) return fail(SKX_ERR_INVALID, "stream was created with top_k=0");
     SKXCHK(use_device(st->device));
-    if (!st->hs_copy) {  // first use: copy stream + three staging slots
+    if (!st->hs_copy) {  // first use: copy stream + the staging slots
         HIPCHK(hipStreamCreateWithFlags(&st->hs_copy, hipStreamNonBlocking));
-        for (auto& sl : st->slot) {
+        st->n_slots = st->coalesce >= 2 ? 5 : 3;
+        for (u32 si = 0; si < st->n_slots; ++si) {
+            auto& sl = st->slot[si];
             HIPCHK(hipMalloc(&sl.d_bases, std::max<u64>(st->max_bases, 1)));
             HIPCHK(hipMalloc(&sl.d_offsets, ((size_t)st->max_reads + 1) * 8));
             if (st->top_k) {
@@ -1829,8 +1835,9 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
             HIPCHK(hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
         }
     }
-    skx_stream::Staged& sl = st->slot[st->next_ticket % 3u];
-    skx_stream::Staged& other = st->slot[(st->next_ticket + 2u) % 3u];  // (the previous ticket's)
+    const u32 ns = st->n_slots;
+    skx_stream::Staged& sl = st->slot[st->next_ticket % ns];
+    skx_stream::Staged& other = st->slot[(st->next_ticket + ns - 1) % ns];  // (the previous ticket's)
     // the previous batch goes to the kernels first (its sketch is queued, and the passes of the batch before it) ...
     SKXCHK(staged_process(st, other));
     if (other.ev_copy && other.ticket + 1 == st->next_ticket) HIPCHK(hipEventSynchronize(other.ev_copy));  // its host buffers are free again
@@ -1853,10 +1860,11 @@ SKX_API int skx_stream_wait(skx_stream* st, uint64_t ticket) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     if (ticket >= st->next_ticket) return fail(SKX_ERR_INVALID, "ticket %llu was never issued", (unsigned long long)ticket);
     SKXCHK(use_device(st->device));
-    skx_stream::Staged& sl = st->slot[ticket % 3u];
+    const u32 ns = st->n_slots;
+    skx_stream::Staged& sl = st->slot[ticket % ns];
     if (sl.ticket != ticket) return SKX_OK;  // the slot has moved on: that batch completed before it was reused
-    for (u64 t = ticket >= 2 ? ticket - 2 : 0; t < ticket; ++t) {  // (in submission order)
-        skx_stream::Staged& older = st->slot[t % 3u];
+    for (u64 t = ticket >= ns - 1 ? ticket - (ns - 1) : 0; t < ticket; ++t) {  // (in submission order)
+        skx_stream::Staged& older = st->slot[t % ns];
         if (older.pending && older.ticket == t) SKXCHK(staged_process(st, older));
     }
     SKXCHK(staged_finish(st, sl));
@@ -1867,8 +1875,8 @@ SKX_API int skx_stream_drain(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));
     // oldest first
-    for (u64 t = st->next_ticket >= 3 ? st->next_ticket - 3 : 0; t < st->next_ticket; ++t) {
-        skx_stream::Staged& sl = st->slot[t % 3u];
+    for (u64 t = st->next_ticket >= st->n_slots ? st->next_ticket - st->n_slots : 0; t < st->next_ticket; ++t) {
+        skx_stream::Staged& sl = st->slot[t % st->n_slots];
         if (sl.pending && sl.ticket == t) SKXCHK(staged_process(st, sl));
     }
     SKXCHK(flush_pending(st));
@@ -1963,8 +1971,9 @@ SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
         HIPCHK(hipMemcpy(flags.data(), st->d_grp_any[st->buf ^ 1], (size_t)n_grp * 4, hipMemcpyDeviceToHost));
         for (u32 f : flags) live += f ? 1 : 0;
     }
-    const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)std::max(st->h_nq[0], st->h_nq[1]), st->reads_big,
-                                     st->total_passes, st->lean_passes, st->pcap, live, st->reads_split, st->segs_split, st->pool_grown};
+    const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)st->h_nq[st->buf ^ 1], st->reads_big,
+                                     st->total_passes, st->lean_passes, st->pcap, live, st->reads_split, st->segs_split, st->pool_grown,
+                                     st->shared_passes};
     for (uint32_t i = 0; i < n_out; ++i) out[i] = i < SKX_N_STATS ? v[i] : 0;
     return SKX_OK;
 }

@@ -287,3 +287,102 @@ def test_enqueue_under_other_placements(gpu, env):
     r = subprocess.run([sys.executable, os.path.join(here, "enqueue_check.py")], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "enqueue_check ok" in r.stdout
+
+
+def test_two_enqueued_batches_share_a_pass(gpu):
+    """Option "stream_coalesce" = 2 (default): two batches enqueued back to back take ONE dictionary / scan / transpose and a
+    ranking each.  Same rows and table as the oracle -- with ragged batch sizes, an odd batch left over, entry points that
+    flush in between, pairs that do NOT fit a pass together (matrix rows sized so that one batch fits and two do not: they are
+    un-shared, each takes its own pass), and with the option off.  skx_stream_stats()[11] counts the shared passes."""
+    from sketchy_amd import api
+    ref, bases, offsets = workload(700, 400, 1400, read_len=400, rng_seed=901)
+    exp = _expect(ref["ref"], 400, bases, offsets, 2)
+    R = api.ReferenceSketch(ref["ref"])
+    cuts = [0, 200, 400, 650, 700, 900, 1100, 1400]   # seven batches: three pairs and one left over
+    kw = dict(top=2, max_batch_reads=300, max_batch_bases=len(bases))
+
+    def check(S, shared_expected, poke=None):
+        idx, val = _enqueue_stream(S, bases, offsets, cuts, 2, poke)
+        np.testing.assert_array_equal(idx, exp["topk_idx"])
+        np.testing.assert_array_equal(val, exp["topk_sum"])
+        np.testing.assert_array_equal(S.table(), exp["cum"])
+        st = S.stats()
+        assert st["passes_shared"] == shared_expected, st
+        assert S.reads == 1400
+        return st
+
+    S = api.SumOfSharedHashes(R, **kw)
+    st = check(S, 3)
+    assert st["passes"] == 4, st
+    # a flush between the two batches of a pair: they go alone
+    S = api.SumOfSharedHashes(R, **kw)
+    check(S, 2, poke=lambda i: S.flush() if i in (0, 2, 3, 4) else None)
+    # the option off: one pass per batch
+    try:
+        api.set_option("stream_coalesce", 1)
+        S1 = api.SumOfSharedHashes(R, **kw)
+    finally:
+        api.set_option("stream_coalesce", 2)
+    st = check(S1, 0)
+    assert st["passes"] == 7, st
+    # one batch fits the bit matrices, two together may not: such pairs are un-shared in their back half.  Reads sketched with
+    # s = 192 (the collection's first sketch is that short) so that the matrices may be smaller than the others' 1 000 hashes.
+    ref, bases, offsets = workload(300, 1000, 240, read_len=2000, rng_seed=905, err=0.01)
+    col_len = np.full(300, 1000, np.uint32)
+    col_len[0] = 192
+    exp2 = orc.stream(16, 0, 192, ref["ref"], col_len, bases, offsets, top_k=2)
+    R2 = api.ReferenceSketch(ref["ref"], col_len, s=192)
+    cuts2 = [0, 30, 60, 75, 90, 120, 150, 180, 210, 240]   # nine batches: four pairs (the second one small) and one left over
+    kw2 = dict(top=2, max_batch_reads=60, max_batch_bases=len(bases))
+    P = api.SumOfSharedHashes(R2, **kw2)
+
+    def distinct(a, b):
+        P.reset()
+        P.push(bases, offsets[a:b + 1])
+        assert P.stats()["last_passes"] == 1
+        return P.stats()["dictionary_size"]
+    single = [distinct(a, b) for a, b in zip(cuts2[:-1], cuts2[1:])]
+    joint = [distinct(a, b) for a, b in zip(cuts2[0:-2:2], cuts2[2::2])]
+    rows = (max(single) + 63) // 64 * 64
+    assert rows >= 192
+    fit = sum(j <= rows for j in joint)
+    assert 0 < fit < len(joint), (single, joint, rows)   # (else this workload does not test what it should)
+    try:
+        api.set_option("stream_query_rows", rows)
+        S2 = api.SumOfSharedHashes(R2, **kw2)
+    finally:
+        api.set_option("stream_query_rows", 0)
+    idx, val = _enqueue_stream(S2, bases, offsets, cuts2, 2)
+    np.testing.assert_array_equal(idx, exp2["topk_idx"])
+    np.testing.assert_array_equal(val, exp2["topk_sum"])
+    np.testing.assert_array_equal(S2.table(), exp2["cum"])
+    st = S2.stats()
+    assert st["passes_shared"] == fit and st["passes"] == 9 - fit, (st, single, joint)
+
+
+def test_an_error_in_the_second_batch_of_a_pair(gpu):
+    """the batch enqueued BEFORE a faulty one is processed (it shares nothing with it any more), the faulty one is dropped"""
+    from sketchy_amd import api, _lib
+    ref, bases, offsets = workload(40, 200, 60, rng_seed=75)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=20, max_batch_bases=len(bases))
+    bad = offsets[20:41].copy()
+    bad[7], bad[8] = bad[8], bad[7]
+    d_b = api.DeviceBuffer.from_numpy(bases)
+    d_bad = api.DeviceBuffer.from_numpy(np.ascontiguousarray(bad))
+    d_o0 = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[:21]))
+    d_o1 = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[20:41]))
+    S.enqueue_device(d_b.ptr, d_o0.ptr, 20, int(offsets[20]), None, None)
+    S.enqueue_device(d_b.ptr, d_bad.ptr, 20, int(offsets[40] - offsets[20]), None, None)
+    with pytest.raises(_lib.SketchyHipError) as e:
+        S.flush()
+    assert e.value.code == _lib.ERR_INVALID
+    exp = _expect(ref["ref"], 200, bases, offsets[:21], 1)
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    assert S.reads == 20
+    S.enqueue_device(d_b.ptr, d_o1.ptr, 20, int(offsets[40] - offsets[20]), None, None)
+    exp = _expect(ref["ref"], 200, bases, offsets[:41], 1)
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    assert S.reads == 40
+    for d in (d_b, d_bad, d_o0, d_o1):
+        d.free()
