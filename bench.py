@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--top", type=int, default=1, help="rows ranked after every read (sketchy default 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--coalesce", type=int, default=0, help="set the library option stream_coalesce (1 or 2) before the stream is created; 0 = leave the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip value_cold / value_steady_state / stage breakdown (profiling runs)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the value_batch_x2 leg (batches of twice --batch reads)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity checks of the timed steps (profiling runs only)")
@@ -198,6 +199,9 @@ def main():
     t_gen = time.time() - t0
 
     R = api.ReferenceSketch([r["ref"] for r in refs], [r["col_len"] for r in refs], k=k, seed=hash_seed, device=dev)
+    if args.coalesce:
+        api.set_option("stream_coalesce", args.coalesce)
+    coalesce_policy = api.get_option("stream_coalesce")
     S = api.SumOfSharedHashes(R, top=top, max_batch_reads=B, max_batch_bases=max(batch_bases))
     rows = max(top, 1) * n_sp
     # rows of every step are kept (the timed steps are checked afterwards)
@@ -275,6 +279,8 @@ def main():
                                      what="final sum all-reduce of the u64 table, inside the timed region (max over ranks; includes "
                                           "queueing the last batch's passes and waiting for them)"),
                    "api": "skx_stream_enqueue_device + final sync" if args.api == "enqueue" else "skx_stream_push_device + final sync",
+                   "batches_per_pass": (f"up to {coalesce_policy} (option stream_coalesce: batches enqueued back to back share one scan of "
+                                        f"the reference; {stats['passes_shared']} shared passes so far on this stream)") if args.api == "enqueue" else "1",
                    "parallelism": f"reads sharded x{world}, reference replicated, final table all-reduce via {reducer.how}"},
     }
     err = None
@@ -386,6 +392,40 @@ def main():
         if rank == 0:
             out["value_other_api"] = {"value": K * B * world / other_s, "unit": "reads/s", "api": other_name,
                                       "what": "the same K batches from a fresh table through the other device-resident entry point"}
+        # value_one_pass_per_batch: the timed stream once more on a stream created with "stream_coalesce" = 1 (every batch scans
+        # the reference on its own -- what `value` was before two enqueued batches could share a pass).  Rows must be identical.
+        if args.api == "enqueue":
+            api.set_option("stream_coalesce", 1)
+            try:
+                S1 = api.SumOfSharedHashes(R, top=top, max_batch_reads=B, max_batch_bases=max(batch_bases))
+            finally:
+                api.set_option("stream_coalesce", coalesce_policy)
+            for i in range(min(W, 2)):
+                step(i, slot=0, call=S1.enqueue_device)
+            S1.sync()
+            t_one = []
+            for rep in range(3):
+                S1.reset()
+                shard.barrier()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for i in range(W, W + K):
+                    step(i, slot=0 if i < W + K - 1 else W + K - 1, call=S1.enqueue_device)
+                S1.sync()
+                t_one.append(shard.max_over_ranks(time.perf_counter() - tc))
+            one_ok = None
+            if not args.no_check and top:
+                one_ok = bool(np.array_equal(d_ti[W + K - 1].cpu().numpy().view(np.uint32), ti_last) and
+                              np.array_equal(d_ts[W + K - 1].cpu().numpy().view(np.uint64), ts_last))
+                if not one_ok:
+                    err = err or "rows of the last timed step differ between shared passes and one pass per batch"
+            if rank == 0:
+                t1 = float(np.median(t_one))
+                out["value_one_pass_per_batch"] = {"value": K * B * world / t1, "unit": "reads/s", "ms_per_step": 1e3 * t1 / K, "median_of": 3,
+                                                   "passes_shared": S1.stats()["passes_shared"], "rows_match_timed_run": one_ok,
+                                                   "what": "the same K batches on a stream created with option stream_coalesce = 1: one "
+                                                           "scan of the reference per batch"}
+            S1.close()
         # value_steady_state: the same stream far from its start (no reset, batches cycled), three regions of >= 0.5 s
         n_long = max(32, int(0.5 / (elapsed / K)))
         S.reset()

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -489,6 +490,22 @@ struct PendingBatch {
     void* slot = nullptr;      // skx_stream::Staged of a host-fed batch: its rows travel to the host behind the ranking
 };
 
+// The HIP streams of the pipeline, ONE set per device shared by every skx_stream on it.  Measured (tools/diag_second_stream.py,
+// C2): a second skx_stream with four HIP streams of its own ran at 63 M reads/s beside a first one's 78 M -- its sketch and its
+// scan took their stand-alone times, i.e. never overlapped: the runtime maps HIP streams onto 4 hardware queues per process
+// (GPU_MAX_HW_QUEUES) and the second set aliased.  Kernels of different skx_streams queue behind each other on the shared HIP
+// streams in host order; every skx_stream orders its own work with its own events, as before.  (A skx_stream_sync therefore
+// also waits for work queued by the device's other streams.)
+struct SharedQueues { hipStream_t hs = nullptr, hs0 = nullptr, hs1 = nullptr, hs2 = nullptr; int refs = 0; };
+static std::mutex g_queues_mu;
+static SharedQueues g_queues[64];
+static void release_queues(int device) {
+    std::lock_guard<std::mutex> lk(g_queues_mu);
+    SharedQueues& q = g_queues[device & 63];
+    if (--q.refs > 0) return;
+    for (hipStream_t* h : {&q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
+    q.refs = 0;
+}
 static const int kSides = 3;  // copies of the per-batch sketch outputs: two enqueued batches waiting for their shared pass + the one being sketched
 static const int kSlotsMax = 5;  // staging slots of the host-fed pipeline
 struct skx_stream {
@@ -508,6 +525,7 @@ struct skx_stream {
     hipStream_t hs1 = nullptr;  // aliases hs0 below pipeline depth 3
     hipEvent_t ev_main[kSides] = {nullptr, nullptr, nullptr};  // sketch stream: everything of the batch queued on hs0 is done (per side)
     int depth = 2;
+    bool shared_queues = false;  // hs / hs0 / hs1 / hs2 belong to the device's SharedQueues
     int buf = 0;
     hipEvent_t ev_dict[2] = {nullptr, nullptr}, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
     // per side of the sketch buffers (see d_sk below):
@@ -670,7 +688,7 @@ static void stream_free(skx_stream* st) {
         (void)hipFree(st->sd_lr[i].seg_cnt); (void)hipFree(st->sd_lr[i].seg_h);
         if (st->ev_main[i]) (void)hipEventDestroy(st->ev_main[i]);
     }
-    if (st->hs1 && st->hs1 != st->hs0) (void)hipStreamDestroy(st->hs1);
+    if (!st->shared_queues && st->hs1 && st->hs1 != st->hs0) (void)hipStreamDestroy(st->hs1);
     (void)hipFree(st->d_ht[0]); (void)hipFree(st->d_ht[1]); (void)hipFree(st->d_dict_ctr[0]); (void)hipFree(st->d_dict_ctr[1]);
     (void)hipFree(st->d_slot_off); (void)hipFree(st->d_bcount); (void)hipFree(st->d_bbase);
     (void)hipFree(st->d_btot);
@@ -696,10 +714,14 @@ static void stream_free(skx_stream* st) {
     }
     for (auto ev : st->ev_pslot)
         if (ev) (void)hipEventDestroy(ev);
-    if (st->hs3 && st->hs3 != st->hs2) (void)hipStreamDestroy(st->hs3);
-    if (st->hs2 && st->hs2 != st->hs && st->hs2 != st->hs0) (void)hipStreamDestroy(st->hs2);
-    if (st->hs0 && st->hs0 != st->hs) (void)hipStreamDestroy(st->hs0);
-    if (st->hs) (void)hipStreamDestroy(st->hs);
+    if (st->shared_queues) {
+        release_queues(st->device);
+    } else {
+        if (st->hs3 && st->hs3 != st->hs2) (void)hipStreamDestroy(st->hs3);
+        if (st->hs2 && st->hs2 != st->hs && st->hs2 != st->hs0) (void)hipStreamDestroy(st->hs2);
+        if (st->hs0 && st->hs0 != st->hs) (void)hipStreamDestroy(st->hs0);
+        if (st->hs) (void)hipStreamDestroy(st->hs);
+    }
     delete st;
 }
 
@@ -850,6 +872,23 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipExtStreamCreateWithCUMask(&st->hs, words, m_scan.data()));
         SCHK(hipExtStreamCreateWithCUMask(&st->hs0, words, m_rest.data()));
         SCHK(hipExtStreamCreateWithCUMask(&st->hs2, words, m_rest.data()));
+    } else if (st->depth == 3 && prio_env && !skx::knob("SKX_PRIO_RANK") && !skx::knob("SKX_RANK_SPLIT")) {
+        // the product's configuration: the device's shared set (created by its first stream)
+        std::lock_guard<std::mutex> lk(g_queues_mu);
+        SharedQueues& q = g_queues[st->device & 63];
+        if (q.refs == 0) {
+            hipError_t e = hipStreamCreateWithPriority(&q.hs, hipStreamNonBlocking, prio_hi);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&q.hs0, hipStreamNonBlocking, prio_lo);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&q.hs2, hipStreamNonBlocking, prio_lo);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&q.hs1, hipStreamNonBlocking, prio_lo);
+            if (e != hipSuccess) {
+                for (hipStream_t* h : {&q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
+                SCHK(e);
+            }
+        }
+        q.refs += 1;
+        st->shared_queues = true;
+        st->hs = q.hs; st->hs0 = q.hs0; st->hs2 = q.hs2; st->hs1 = q.hs1;
     } else {
     SCHK(hipStreamCreateWithPriority(&st->hs, hipStreamNonBlocking, prio_hi));
     if (st->depth >= 3) SCHK(hipStreamCreateWithPriority(&st->hs0, hipStreamNonBlocking, prio_lo)); else st->hs0 = st->hs;
@@ -880,7 +919,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipEventCreateWithFlags(&st->ev_skread[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_main[i], hipEventDisableTiming));
     }
-    if (st->depth >= 3) SCHK(hipStreamCreateWithPriority(&st->hs1, hipStreamNonBlocking, prio_lo)); else st->hs1 = st->hs0;
+    if (!st->shared_queues) {
+        if (st->depth >= 3) SCHK(hipStreamCreateWithPriority(&st->hs1, hipStreamNonBlocking, prio_lo)); else st->hs1 = st->hs0;
+    }
     SCHK(hipMalloc(&st->d_bases, std::max<u64>(max_bases, 1)));
     SCHK(hipMalloc(&st->d_offsets, ((size_t)max_reads + 1) * 8));
     SCHK(alloc_side(st, 0));
