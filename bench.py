@@ -339,9 +339,12 @@ def main():
                                "algorithmic_bytes_per_launch": pass_bytes,
                                "note": "achieved = algorithmic bytes (8*s*N) / HIP-event time of the kernel on its own stream in the timed "
                                        "region, where the sketch of the next batch and the ranking of the previous one run beside it "
-                                       "(three-stream pipeline); `isolated` = the same kernel alone",
+                                       "(three-stream pipeline); `isolated` = the same kernel alone.  launches_per_step = 0.5: two enqueued "
+                                       "batches share one launch (option stream_coalesce)",
                                "whole_step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
-                                              "note": "the same bytes over the whole step time (sketch, dictionary, ranking included)"}}
+                                              "note": "algorithmic bytes x launches_per_step over the whole step time (sketch, dictionary, ranking "
+                                                      "included): what the step needs from HBM for the reference, not a quality figure -- it "
+                                                      "halves when two batches share a scan while the reads/s go up"}}
         vi = _valu_insts(args.config, B)
         if vi:
             floor_ms = vi["wave_insts_per_step"] * VALU_CYCLES_PER_WAVE_INST / (N_SIMDS * CLOCK_GHZ * 1e9) * 1e3
@@ -349,7 +352,7 @@ def main():
                                     "insts_source": vi["source"], "per_kernel": vi.get("per_kernel"),
                                     "simds": N_SIMDS, "cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST, "clock_ghz": CLOCK_GHZ,
                                     "floor_ms": floor_ms, "frac": floor_ms / (1e3 * elapsed / K),
-                                    "note": "VALU wave instructions one step issues (all kernels of the step; committed rocprofv3 "
+                                    "note": "VALU wave instructions one step issues (all kernels of the step, shared launches counted at their share; committed rocprofv3 "
                                             "SQ_INSTS_VALU pass, not measured in this run) x 4 cycles per wave64 instruction / "
                                             "(1024 SIMDs x clock): the issue floor of the step; frac = floor / measured step"}
         out["pass_stats"] = stats  # (read, hash) pairs / passes of the last timed push, dictionary size, ...
