@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--top", type=int, default=1, help="rows ranked after every read (sketchy default 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
-    ap.add_argument("--coalesce", type=int, default=0, help="set the library option stream_coalesce (1 or 2) before the stream is created; 0 = leave the default")
+    ap.add_argument("--coalesce", type=int, default=0, help="set the library option stream_coalesce (1 .. 8) before the stream is created; 0 = leave the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip value_cold / value_steady_state / stage breakdown (profiling runs)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the value_batch_x2 leg (batches of twice --batch reads)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity checks of the timed steps (profiling runs only)")

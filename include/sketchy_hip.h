@@ -78,9 +78,12 @@ int skx_device_info(int device, char *name, size_t name_cap, int *compute_units,
  *   "stream_query_rows"  rows of a pass's bit matrices = distinct query hashes one pass can hold; 0 (default) = 65 536, never
  *                     fewer than one read can need (s).  A batch (or pair of batches) with more distinct in-range hashes is
  *                     cut into several passes.  The bit matrices take rows x n_genomes / 8 bytes, three times.
- *   "stream_coalesce" 2 (default) / 1: how many batches of skx_stream_enqueue_device / skx_stream_submit may share one
- *                     scoring pass (see skx_stream_enqueue_device).  2 halves the scans of the reference per read at the
- *                     cost of one more batch of latency and a third copy of the per-batch sketch rows.
+ *   "stream_coalesce" 1 .. 8 (default 8): how many batches of skx_stream_enqueue_device / skx_stream_submit (there: at most 4)
+ *                     may share one scoring pass (see skx_stream_enqueue_device).  n batches per pass divide the scans of the
+ *                     reference per read by n (C2, 98 304-read batches: 77 / 97 / 111 / 116 M reads/s at 1 / 2 / 4 / 8) at
+ *                     the cost of up to n - 1 more batches of latency and n + 1 copies of the per-batch sketch rows (25 MB
+ *                     each at C2).  A group whose pairs or distinct hashes turn out too many for one pass is processed
+ *                     batch by batch, and the stream forms smaller groups from then on.
  * Unknown names fail with SKX_ERR_INVALID.
  */
 int skx_set_option(const char *name, uint64_t value);
@@ -155,11 +158,11 @@ int skx_stream_push_device(skx_stream *st, const uint8_t *d_bases, const uint64_
  * the call queues the sketch of THIS batch first, then waits for the published summary of the batch(es) enqueued before
  * and queues their scan / ranking passes.  (skx_stream_push_device does both halves of one batch in one call: the sketch
  * stream then idles while the host queues the passes -- ~0.25 ms per 98,304-read batch, measured.)
- * With the stream option "stream_coalesce" = 2 (default) two batches enqueued back to back SHARE one pass -- one
- * dictionary of their distinct hashes, one scan of the reference, one transpose, then one ranking each, in order -- when
- * their pairs and distinct hashes together fit a pass; otherwise each takes its own.  The back half of batches i and
- * i + 1 is then queued by call i + 2 (or the flush).
- * Consequences: rows of batch i are written by work queued during call i + 1 or i + 2; an error found in batch i (offsets
+ * With the option "stream_coalesce" = n (default 8) up to n batches enqueued back to back SHARE one pass -- one dictionary
+ * of their distinct hashes, one scan of the reference, one transpose, then one ranking each, in order -- when their pairs
+ * and distinct hashes together fit a pass; otherwise each takes its own.  The back half of a group is queued by the call
+ * that opens the next group (behind that batch's sketch), or by the flush.
+ * Consequences: rows of batch i are written by work queued during one of the calls i + 1 .. i + n; an error found in batch i (offsets
  * not monotonic, a read outside n_bases) is returned by one of those calls or by the flush -- batches enqueued BEFORE the
  * faulty one are processed, the faulty one and those enqueued after it (up to the call that reports the error) are
  * dropped.  d_bases / d_offsets of a batch must stay untouched until skx_stream_sync() (or any other flushing entry
@@ -187,7 +190,7 @@ int skx_stream_sync(skx_stream *st);
 /*
  * Host-fed pipeline.  skx_stream_submit() queues a batch from PAGE-LOCKED host buffers (skx_host_alloc; bases, offsets
  * and the optional row arrays) and returns without waiting for it: the host-to-device copy of batch i+1 runs on its
- * own stream into another staging slot (three; five when batches share passes, "stream_coalesce" = 2: each holds a batch's
+ * own stream into another staging slot (three; up to nine when batches share passes, "stream_coalesce" >= 2: each holds a batch's
  * bases, offsets and rows on the device) while batch i is sketched, scanned and ranked.  Processing lags one call
  * behind submission (submit(i) starts the copy of batch i, then runs batch i-1 through the kernels), so a single host
  * thread keeps the copy engine and the kernels busy at the same time -- what needletail's reader plus the loop of
@@ -215,10 +218,11 @@ int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
  * far, [4] passes so far, [5] of those with the lean scan kernel, [6] pair capacity of a pass, [7] rank groups (512 genomes)
  * that received any bit in the most recent pass, [8] long reads (more than 8192 bases) whose sketch was split over several
  * wavefronts so far, [9] the segments they were cut into, [10] batches that were sketched a second time because their rows
- * did not fit the stream's row pool (it grows to fit), [11] passes that served TWO enqueued batches (option
- * "stream_coalesce").  Waits for the stream's queued work.
+ * did not fit the stream's row pool (it grows to fit), [11] passes that served SEVERAL enqueued batches (option
+ * "stream_coalesce"), [12] groups of enqueued batches that turned out too large for one pass together (or held an error) and were
+ * processed one by one -- the stream forms smaller groups after that.  Waits for the stream's queued work.
  */
-#define SKX_N_STATS 12
+#define SKX_N_STATS 13
 int skx_stream_stats(skx_stream *st, uint64_t *out, uint32_t n_out);
 /* rank the CURRENT table: first top_k of (sum desc, index asc) per species; idx/sum are host arrays [n_species][top_k] */
 int skx_stream_rank(skx_stream *st, uint32_t top_k, uint32_t *idx, uint64_t *sum);

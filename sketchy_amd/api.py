@@ -224,11 +224,11 @@ class SumOfSharedHashes:
 
     def stats(self):
         """Counters of the stream (skx_stream_stats): pairs / passes of the last push, dictionary size, ..."""
-        v = (C.c_uint64 * 12)()
-        _lib.check(_lib.load().skx_stream_stats(self._h, v, 12))
+        v = (C.c_uint64 * 13)()
+        _lib.check(_lib.load().skx_stream_stats(self._h, v, 13))
         names = ("last_pairs", "last_passes", "dictionary_size", "reads_block_sketcher", "passes", "passes_lean_scan",
                  "pair_capacity", "live_rank_groups", "reads_split_over_waves", "read_segments", "row_pool_grown",
-                 "passes_shared")
+                 "passes_shared", "groups_unshared")
         return dict(zip(names, [int(x) for x in v]))
 
     def set_profiling(self, on=True):

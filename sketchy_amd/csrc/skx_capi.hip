@@ -145,13 +145,13 @@ static inline double now_us() { return std::chrono::duration<double, std::micro>
 static bool g_kmer_prefilter = false;  // build / use the k-mer prefilter for k = 16 references (off: no gain inside the pipeline)
 static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
 static u32 g_stream_query_rows = 0;       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
-static u32 g_stream_coalesce = 2;         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 or 2)
+static u32 g_stream_coalesce = 8;         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 .. 8)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
     if (!name) return fail(SKX_ERR_INVALID, "NULL option name");
     if (!strcmp(name, "kmer_prefilter")) { g_kmer_prefilter = value != 0; return SKX_OK; }
     if (!strcmp(name, "stream_coalesce")) {
-        if (value < 1 || value > 2) return fail(SKX_ERR_INVALID, "stream_coalesce must be 1 or 2");
+        if (value < 1 || value > (uint64_t)skx::kPairBaseMax + 1) return fail(SKX_ERR_INVALID, "stream_coalesce must be 1 .. 8");
         g_stream_coalesce = (u32)value;
         return SKX_OK;
     }
@@ -465,6 +465,7 @@ struct TimedSpan { int stage; hipEvent_t a, b; };
 // published summary on the sketch stream; batch_back waits for the summary (the one host wait of a batch) and queues the
 // passes.  skx_stream_push* run both halves in one call; skx_stream_enqueue_device runs the front half of batch i + 1
 // BEFORE the back half of batch i, so the sketch stream never waits for the host between two batches.
+static const int kGroupMax = skx::kPairBaseMax + 1;  // batches that may share one pass (option stream_coalesce)
 struct PendingBatch {
     bool valid = false;
     int side = 0;  // which copy of the sketch buffers holds it
@@ -477,10 +478,12 @@ struct PendingBatch {
     u32 seq = 0;               // sequence number its summary is published under
     bool spec_insert = false;  // its pairs were gathered into buffer set spec_set / pair slot spec_slot right behind the sketcher
     int spec_set = 0, spec_slot = 0;
-    bool pairable = false;     // it came through an entry point whose batches may share a pass (enqueue / submit, stream_coalesce = 2)
-    bool second = false;       // it shares the pass of the batch enqueued before it: same set / slot, its pairs behind that batch's
-    int first_side = 0;        // ... whose side holds the pair count its gather starts at
-    u32 first_reads = 0;
+    bool pairable = false;     // it came through an entry point whose batches may share a pass (enqueue / submit, stream_coalesce >= 2)
+    u32 max_group = 1;         // ... at most so many of them
+    int gi = 0;                // its place in the group of batches that share a pass (0: it opened one): same set / slot as the
+                               // group's first batch, its pairs behind those of the gi batches before it ...
+    int prev_side[kGroupMax - 1] = {};   // ... whose sides hold the pair counts its gather starts behind
+    u32 prev_reads[kGroupMax - 1] = {};
     bool inrange_only = true;
     bool rows_mode = false;    // its sketch rows are full-width rows (debug outputs / no filter), not reservations out of the pool
     u32 dbg_cap = 0xFFFFFFFFu;
@@ -506,8 +509,10 @@ static void release_queues(int device) {
     for (hipStream_t* h : {&q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
     q.refs = 0;
 }
-static const int kSides = 3;  // copies of the per-batch sketch outputs: two enqueued batches waiting for their shared pass + the one being sketched
-static const int kSlotsMax = 5;  // staging slots of the host-fed pipeline
+static const int kSides = kGroupMax + 1;  // copies of the per-batch sketch outputs: the enqueued batches waiting for their shared pass + the one being sketched
+                                          // (a stream uses stream_coalesce + 1 of them, allocated at first use)
+static const u32 kStagedGroupMax = 4;
+static const int kSlotsMax = 2 * kStagedGroupMax + 1;  // staging slots of the host-fed pipeline
 struct skx_stream {
     const skx_ref* ref = nullptr;
     int device = 0;
@@ -523,18 +528,21 @@ struct skx_stream {
     // ev_main) so that the sketch stream runs main kernel after main kernel: those ~8 short, latency-bound kernels cost the
     // sketch stream 150-250 us per batch next to the other streams' work (kernel trace), a fifth of the step.
     hipStream_t hs1 = nullptr;  // aliases hs0 below pipeline depth 3
-    hipEvent_t ev_main[kSides] = {nullptr, nullptr, nullptr};  // sketch stream: everything of the batch queued on hs0 is done (per side)
+    hipEvent_t ev_main[kSides] = {};  // sketch stream: everything of the batch queued on hs0 is done (per side)
     int depth = 2;
     bool shared_queues = false;  // hs / hs0 / hs1 / hs2 belong to the device's SharedQueues
     int buf = 0;
     hipEvent_t ev_dict[2] = {nullptr, nullptr}, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
     // per side of the sketch buffers (see d_sk below):
-    hipEvent_t ev_sketch[kSides] = {nullptr, nullptr, nullptr};  // hs1: the batch's sketches, pair offsets (and speculative pair gather) are done
-    hipEvent_t ev_skread[kSides] = {nullptr, nullptr, nullptr};  // scan stream: a pass that gathered its own pairs has read the sketch buffers
-    bool sk_reader_pending[kSides] = {false, false, false};
+    hipEvent_t ev_sketch[kSides] = {};  // hs1: the batch's sketches, pair offsets (and speculative pair gather) are done
+    hipEvent_t ev_skread[kSides] = {};  // scan stream: a pass that gathered its own pairs has read the sketch buffers
+    bool sk_reader_pending[kSides] = {};
     int side = 0;                                  // the side d_sk ... h_chk currently name
-    PendingBatch pend[2];                          // skx_stream_enqueue_device: the batches whose back half is still to come (two: they share a pass)
+    PendingBatch pend[kGroupMax];                  // skx_stream_enqueue_device: the batches whose back half is still to come (a group: they share a pass)
     int n_pend = 0;
+    u32 group_cap = 1;       // batches a group may hold right now: stream_coalesce, lowered when groups turned out too large for a pass
+    u32 clean_groups = 0;    // shared passes since it was last lowered
+    double ppr_est = 0.0, qpr_est = 0.0;  // pairs / distinct query hashes per read of the recent batches (0: nothing seen yet)
     int side_next = 0;                             // sides are taken in turn: at most two pending batches + the one being sketched
     bool front_pending[2] = {false, false};
     bool back_pending[2] = {false, false};
@@ -563,10 +571,10 @@ struct skx_stream {
     // side in use (use_side); side 1 is allocated by the first call that needs it.
     u64* d_sk = nullptr;
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
-    u64* sd_sk[kSides] = {nullptr, nullptr, nullptr};       // POOL of a side: production rows are exact-size reservations (sketch_finish, pool mode)
-    u64 pool_cap[kSides] = {0, 0, 0};        // ... its entries: a fixed slot per read first (pool_fixed), the reservable part behind
+    u64* sd_sk[kSides] = {};       // POOL of a side: production rows are exact-size reservations (sketch_finish, pool mode)
+    u64 pool_cap[kSides] = {};        // ... its entries: a fixed slot per read first (pool_fixed), the reservable part behind
     u32 pool_fixed = 0;
-    u64* sd_rows[kSides] = {nullptr, nullptr, nullptr};    // full-width rows [max_reads][sk_stride] of a side: debug outputs / skx_common_hashes; allocated on first use
+    u64* sd_rows[kSides] = {};    // full-width rows [max_reads][sk_stride] of a side: debug outputs / skx_common_hashes; allocated on first use
     u32 cur_stride = 0;                      // what the kernels get as row stride for d_sk: 0 = pool mode
     u32 cur_pool_cap = 0, cur_pool_fixed = 0;
     u32 *sd_len[kSides] = {}, *sd_cnt[kSides] = {}, *sd_poff[kSides] = {}, *sd_big[kSides] = {};
@@ -628,7 +636,8 @@ struct skx_stream {
     u64 reads_big = 0;       // reads that went through the block sketcher so far (statistic)
     u64 reads_split = 0, segs_split = 0;  // long reads split over waves so far, and their segments (statistic)
     u64 pool_grown = 0;                    // batches repeated with a larger row pool (statistic)
-    u64 shared_passes = 0;                 // passes that served two enqueued batches (statistic)
+    u64 shared_passes = 0;                 // passes that served several enqueued batches (statistic)
+    u64 groups_unshared = 0;               // groups of enqueued batches that did not fit one pass together and went one by one (statistic)
     u64 last_pairs = 0, last_passes = 0, total_passes = 0, lean_passes = 0;  // statistics (skx_stream_stats)
     // host-fed pipeline (skx_stream_submit): staging slots, a copy stream, one batch of lag
     struct Staged {
@@ -643,8 +652,8 @@ struct skx_stream {
         uint8_t* d_bases = nullptr;
         u64 *d_offsets = nullptr, *h_offsets = nullptr;
         hipEvent_t ev_copy = nullptr, ev_done = nullptr;
-    } slot[kSlotsMax];  // (three: the copy of batch i starts once batch i - 3 is through, not i - 2; five when two batches share
-                        // a pass -- the pass of batches i - 5 and i - 4 was queued two submits ago, not one)
+    } slot[kSlotsMax];  // (three: the copy of batch i starts once batch i - 3 is through, not i - 2; 2 n + 1 when groups of n batches
+                        // share a pass -- the pass of the group that holds batch i - 2 n - 1 was queued n submits ago, not one)
     u32 n_slots = 3;
     hipStream_t hs_copy = nullptr;
     u64 next_ticket = 0;
@@ -821,7 +830,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     qc = (qc + 63) / 64 * 64;
     st->qcap = (u32)qc;
     static const u32 coalesce_env = skx::knob("SKX_COALESCE") ? (u32)atoi(skx::knob("SKX_COALESCE")) : 0u;  // experiment knob
-    st->coalesce = coalesce_env ? std::min(2u, std::max(1u, coalesce_env)) : g_stream_coalesce;
+    st->coalesce = coalesce_env ? std::min<u32>((u32)kGroupMax, std::max(1u, coalesce_env)) : g_stream_coalesce;
+    st->group_cap = st->coalesce;
     // reads per pass: the whole batch if the ranking's per-segment arrays fit (inc / rel: 4 bytes per (64 reads, genome) each, at most
     // an eighth of the free device memory) -- a batch cut into two passes scans the reference twice
     static const u64 pass_reads_env = skx::knob("SKX_PASS_READS") ? (u64)atoll(skx::knob("SKX_PASS_READS")) : 0;  // test knob
@@ -930,7 +940,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_pair_q[i], (size_t)st->pcap * 4));
     for (int i = 0; i < 3; ++i) {
         SCHK(hipMalloc(&st->d_pair_r[i], (size_t)st->pcap * 4));
-        SCHK(hipMalloc(&st->d_poff_pass[i], 2 * ((size_t)st->rpass + 2) * 4));  // (two batches may share a pass: one region each)
+        SCHK(hipMalloc(&st->d_poff_pass[i], (size_t)st->coalesce * ((size_t)st->rpass + 2) * 4));  // (the batches that share a pass: one region each)
         SCHK(hipEventCreateWithFlags(&st->ev_pslot[i], hipEventDisableTiming));
     }
     for (int i = 0; i < 2; ++i) {
@@ -1373,12 +1383,13 @@ static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
         // pair lists by the ranking three passes back
         if (st->pairq_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pairq[b], 0)); st->pairq_pending[b] = false; }
         if (st->pslot_pending[slot]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pslot[slot], 0)); st->pslot_pending[slot] = false; }
-        // (second: the batch shares the pass of the one before it -- same set, same slot, its pairs behind that batch's, whose
-        // count sits at the end of that batch's pair offsets on the device; its own offsets go to the slot's second region)
-        const u32* p_off_dev = pb.second ? st->sd_poff[pb.first_side] + pb.first_reads : nullptr;
+        // (gi > 0: the batch shares the pass of the gi batches before it -- same set, same slot, its pairs behind theirs, whose
+        // counts sit at the end of those batches' pair offsets on the device; its own offsets go to the slot's region gi)
+        skx::PairBase base;
+        for (int i = 0; i < pb.gi; ++i) base.p[i] = st->sd_poff[pb.prev_side[i]] + pb.prev_reads[i];
         skx::launch_dict_insert(hs, st->d_sk, st->cur_stride, st->d_poff, 0, n_reads, 0, st->d_pair_h[b], st->d_pair_r[slot],
-                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len, p_off_dev);
-        HIPCHK(hipMemcpyAsync(st->d_poff_pass[slot] + (pb.second ? (size_t)st->rpass + 2 : 0), st->d_poff, ((size_t)n_reads + 1) * 4,
+                                st->d_ht[b], st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len, base);
+        HIPCHK(hipMemcpyAsync(st->d_poff_pass[slot] + (size_t)pb.gi * ((size_t)st->rpass + 2), st->d_poff, ((size_t)n_reads + 1) * 4,
                               hipMemcpyDeviceToDevice, hs));
     }
     pb.seq = ++st->pub_seq;
@@ -1445,7 +1456,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     const u32 n_reads = pb.n_reads;
     // sides are taken in turn (two enqueued batches may be waiting for their shared pass while this one is sketched)
     pb.side = st->side_next;
-    st->side_next = (st->side_next + 1) % kSides;
+    st->side_next = (st->side_next + 1) % (int)(st->coalesce + 1);
     HIPCHK(use_side(st, pb.side));
     pb.inrange_only = !(pb.h_sketches || pb.h_sketch_len);  // production: only what can meet the reference is built
     // production rows are reservations out of the side's pool; full sketches (and unfiltered ones) need full-width rows
@@ -1455,18 +1466,27 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     pb.dbg_cap = pb.h_shared ? (u32)std::max<u64>(1, (256ull << 20) / ((u64)ref->n_genomes * 4)) : 0xFFFFFFFFu;
     static const bool spec_env = !skx::knob("SKX_SPEC_INSERT") || atoi(skx::knob("SKX_SPEC_INSERT")) != 0;  // test knob
     pb.spec_insert = spec_env && n_reads <= std::min(st->rpass, pb.dbg_cap);  // one pass unless the pairs turn out too many
-    // Two batches enqueued back to back SHARE a pass (run_pass_multi): the second one's pairs are gathered into the first one's
-    // hash set and pair lists.  Decided here, when the second one's front half is queued: the batch before it must be the only
-    // one waiting, speculative and production like this one, and the caller must have asked for it (pb.pairable: the
-    // enqueue / submit entry points of a stream created with stream_coalesce = 2).
-    const PendingBatch* prev = st->n_pend == 1 ? &st->pend[0] : nullptr;
-    pb.second = pb.pairable && prev && prev->pairable && !prev->second && prev->spec_insert && pb.spec_insert && prev->inrange_only &&
-                pb.inrange_only && !prev->rows_mode && !pb.rows_mode;
-    if (pb.second) {
-        pb.spec_set = prev->spec_set; pb.spec_slot = prev->spec_slot;
-        pb.first_side = prev->side; pb.first_reads = prev->n_reads;
+    // Batches enqueued back to back SHARE a pass (run_pass_multi): the later ones' pairs are gathered into the first one's hash
+    // set and pair lists.  Decided here, when a later one's front half is queued: the batches waiting must be one open group
+    // with room left (stream_coalesce), speculative and production like this one, and the caller must have asked for it
+    // (pb.pairable: the enqueue / submit entry points of a stream created with stream_coalesce >= 2).
+    bool joins = pb.pairable && pb.spec_insert && pb.inrange_only && !pb.rows_mode && st->n_pend >= 1 && st->n_pend < (int)std::min(st->group_cap, pb.max_group);
+    if (joins && st->ppr_est > 0.0) {  // would the group still fit a pass?  (a group that does not is un-shared at a price: batch_back_group)
+        u64 reads = pb.n_reads;
+        for (int i = 0; i < st->n_pend; ++i) reads += st->pend[i].n_reads;
+        joins = reads * st->ppr_est * 1.25 <= (double)st->pcap && reads * st->qpr_est * 1.25 <= (double)st->qcap;
+    }
+    for (int i = 0; joins && i < st->n_pend; ++i) {
+        const PendingBatch& q = st->pend[i];
+        joins = q.pairable && q.gi == i && q.spec_insert && q.inrange_only && !q.rows_mode;
+    }
+    if (joins) {
+        pb.gi = st->n_pend;
+        pb.spec_set = st->pend[0].spec_set; pb.spec_slot = st->pend[0].spec_slot;
+        for (int i = 0; i < pb.gi; ++i) { pb.prev_side[i] = st->pend[i].side; pb.prev_reads[i] = st->pend[i].n_reads; }
     } else {
-        // (one pass is still to come for the batches waiting -- be it one batch or two sharing it)
+        // (one pass is still to come for the batches waiting -- be it one batch or a group sharing it)
+        pb.gi = 0;
         pb.spec_set = st->buf ^ (st->n_pend ? 1 : 0);
         pb.spec_slot = (st->pslot + (st->n_pend ? 1 : 0)) % 3;
     }
@@ -1593,6 +1613,10 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     const u32 spec_keys = pb.spec_insert ? st->h_chk[10] : 0xFFFFFFFFu;
     const u32 q_rows = spec_keys != 0xFFFFFFFFu ? spec_keys : total_pairs;
     const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap && q_rows <= st->qcap;
+    if (n_reads && pb.inrange_only) {  // (what the next groups are sized by)
+        st->ppr_est = (double)total_pairs / n_reads;
+        st->qpr_est = (double)std::min(q_rows, total_pairs) / n_reads;
+    }
     // (the batch needs several passes although a speculative gather was queued for it: normally that gather did nothing -- it
     // saw more pairs than a pass holds -- but after the block-sketcher redo above the FIRST gather may have fitted while the
     // recount does not; either way the set must be empty before the passes insert their own pairs)
@@ -1638,69 +1662,92 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     return SKX_OK;
 }
 
-// back half of TWO enqueued batches that share a pass (F's front half opened hash set and pair lists, S's appended to them):
-// both summaries, one dictionary / scan / transpose, two rankings.  Anything out of the ordinary in either summary -- an
-// error, a row pool that was too small, reads for the block sketcher, more pairs or distinct hashes together than a pass
-// holds -- un-shares them: the joint set is emptied and each batch takes its own pass(es), gathering its pairs on the scan
-// stream.
-static int batch_back_pair(skx_stream* st, PendingBatch& F, PendingBatch& S, PendingBatch* younger) {
+// back half of a GROUP of enqueued batches that share a pass (the first one's front half opened hash set and pair lists, the
+// others' appended to them): their summaries, one dictionary / scan / transpose, a ranking each.  Anything out of the ordinary
+// in a summary -- an error, a row pool that was too small, reads for the block sketcher, more pairs or distinct hashes together
+// than a pass holds -- un-shares them: the joint set is emptied and each batch takes its own pass(es), gathering its pairs on
+// the scan stream.
+static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch* younger) {
+    if (n == 1) return batch_back(st, g[0], younger);
     {
         SKX_T0();
-        SKXCHK(wait_published(st, F));
-        SKXCHK(wait_published(st, S));
+        for (int i = 0; i < n; ++i) SKXCHK(wait_published(st, g[i]));
         SKX_ACC(wait);
     }
-    const volatile u32* cF = st->h_chk_base + 16 * F.side;
-    const volatile u32* cS = st->h_chk_base + 16 * S.side;
-    const bool clean = !(cF[0] | cF[6] | cF[7] | cS[0] | cS[6] | cS[7]);
-    const u32 P_F = cF[8], P_S = cS[8], q_rows = cS[10];  // (S's summary counts the keys of the joint set)
-    const bool fits = clean && (u64)P_F + P_S <= st->pcap && q_rows != 0xFFFFFFFFu && q_rows <= st->qcap &&
-                      st->buf == F.spec_set && st->pslot == F.spec_slot;
+    bool fits = st->buf == g[0].spec_set && st->pslot == g[0].spec_slot;
+    u64 pairs = 0;
+    u32 P[kGroupMax];
+    for (int i = 0; i < n; ++i) {
+        const volatile u32* c = st->h_chk_base + 16 * g[i].side;
+        fits = fits && !(c[0] | c[6] | c[7]);
+        P[i] = c[8];
+        pairs += P[i];
+    }
+    const u32 q_rows = (st->h_chk_base + 16 * g[n - 1].side)[10];  // (the last summary counts the keys of the joint set)
+    const bool clean = fits;
+    fits = fits && pairs <= st->pcap && q_rows != 0xFFFFFFFFu && q_rows <= st->qcap;
+    u64 reads = 0;
+    for (int i = 0; i < n; ++i) reads += g[i].n_reads;
+    if (clean && q_rows != 0xFFFFFFFFu && reads) {
+        // (distinct hashes grow less than linearly with the reads: the per-read figure of a group overestimates a larger one's)
+        st->ppr_est = (double)pairs / reads;
+        st->qpr_est = (double)q_rows / reads;
+    }
+    if (clean && !fits) {  // too much for one pass: smaller groups from here on
+        u64 acc = 0;
+        int m = 0;
+        while (m < n && acc + P[m] <= st->pcap / 10 * 9 && (double)(acc + P[m]) / std::max<u64>(pairs, 1) * q_rows <= st->qcap / 10 * 9) acc += P[m++];
+        st->group_cap = (u32)std::max(1, std::min(m, n - 1));
+        st->clean_groups = 0;
+    } else if (fits && ++st->clean_groups >= 64 && st->group_cap < st->coalesce) {
+        st->group_cap += 1;
+        st->clean_groups = 0;
+    }
     if (!fits) {
-        HIPCHK(hipMemsetAsync(st->d_ht[F.spec_set], 0xFF, (size_t)st->ht_slots * 8, st->hs1));
-        HIPCHK(hipMemsetAsync(st->d_dict_ctr[F.spec_set], 0, 64, st->hs1));
+        st->groups_unshared += 1;
+        HIPCHK(hipMemsetAsync(st->d_ht[g[0].spec_set], 0xFF, (size_t)st->ht_slots * 8, st->hs1));
+        HIPCHK(hipMemsetAsync(st->d_dict_ctr[g[0].spec_set], 0, 64, st->hs1));
         HIPCHK(hipStreamSynchronize(st->hs1));
-        F.spec_insert = false; S.spec_insert = false; S.second = false;
+        for (int i = 0; i < n; ++i) { g[i].spec_insert = false; g[i].gi = 0; }
         if (younger) SKXCHK(cancel_speculation(st, *younger));  // (it counted on ONE pass ahead of its own)
-        SKXCHK(batch_back(st, F, nullptr));
-        return batch_back(st, S, nullptr);
+        for (int i = 0; i < n; ++i) SKXCHK(batch_back(st, g[i], nullptr));
+        return SKX_OK;
     }
-    F.valid = false; S.valid = false;
-    if (st->sd_lr[F.side].list) { st->reads_split += cF[1]; st->segs_split += cF[9]; }
-    if (st->sd_lr[S.side].list) { st->reads_split += cS[1]; st->segs_split += cS[9]; }
-    st->last_pairs = (u64)P_F + P_S; st->last_passes = 1; st->shared_passes += 1;
-    SubPass subs[2];
-    const PendingBatch* pbs[2] = {&F, &S};
-    for (int i = 0; i < 2; ++i) {
-        subs[i].ra = 0; subs[i].rb = pbs[i]->n_reads; subs[i].p_base = 0; subs[i].side = pbs[i]->side;
-        subs[i].d_topk_idx = pbs[i]->d_topk_idx; subs[i].d_topk_sum = pbs[i]->d_topk_sum;
+    SubPass subs[kGroupMax];
+    u32 p_off = 0;
+    for (int i = 0; i < n; ++i) {
+        const volatile u32* c = st->h_chk_base + 16 * g[i].side;
+        g[i].valid = false;
+        if (st->sd_lr[g[i].side].list) { st->reads_split += c[1]; st->segs_split += c[9]; }
+        subs[i].ra = 0; subs[i].rb = g[i].n_reads; subs[i].p_base = 0; subs[i].side = g[i].side;
+        subs[i].d_topk_idx = g[i].d_topk_idx; subs[i].d_topk_sum = g[i].d_topk_sum;
+        subs[i].p_off = p_off; subs[i].P = P[i];
+        subs[i].d_poff = st->d_poff_pass[g[0].spec_slot] + (size_t)i * ((size_t)st->rpass + 2);
+        p_off += P[i];
     }
-    subs[0].p_off = 0; subs[0].P = P_F; subs[0].d_poff = st->d_poff_pass[F.spec_slot];
-    subs[1].p_off = P_F; subs[1].P = P_S; subs[1].d_poff = st->d_poff_pass[F.spec_slot] + (size_t)st->rpass + 2;
+    st->last_pairs = pairs; st->last_passes = 1; st->shared_passes += 1;
     {
         SKX_T0();
-        SKXCHK(run_pass_multi(st, subs, 2, true, true, q_rows));
+        SKXCHK(run_pass_multi(st, subs, n, true, true, q_rows));
         SKX_ACC(back);
     }
-    st->reads_total += (u64)F.n_reads + S.n_reads;
+    st->reads_total += reads;
     return SKX_OK;
 }
 
 // the back half of the enqueued batch(es), if there are any (every entry point that looks at the stream's state starts here)
 static int staged_rows(skx_stream* st, void* slot);
-static int flush_pending(skx_stream* st) {
-    if (st->n_pend == 0) return SKX_OK;
-    PendingBatch a = st->pend[0], b = st->pend[1];
+static int pending_back(skx_stream* st, PendingBatch* younger) {
+    PendingBatch g[kGroupMax];
     const int n = st->n_pend;
+    for (int i = 0; i < n; ++i) g[i] = st->pend[i];
     st->n_pend = 0;
-    if (n == 2) {
-        SKXCHK(batch_back_pair(st, a, b, nullptr));
-        SKXCHK(staged_rows(st, a.slot));
-        return staged_rows(st, b.slot);
-    }
-    SKXCHK(batch_back(st, a, nullptr));
-    return staged_rows(st, a.slot);
+    if (n == 0) return SKX_OK;
+    SKXCHK(batch_back_group(st, g, n, younger));
+    for (int i = 0; i < n; ++i) SKXCHK(staged_rows(st, g[i].slot));
+    return SKX_OK;
 }
+static int flush_pending(skx_stream* st) { return pending_back(st, nullptr); }
 // sketch + score + rank a batch already resident on the device, both halves (synchronous entry points).
 // h_shared / h_sketches / h_sketch_len: optional HOST outputs (parity/debug).
 static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u64 n_bases, u32* d_topk_idx,
@@ -1715,34 +1762,22 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     return batch_back(st, pb, nullptr);
 }
 // ... and with the halves of consecutive batches interleaved: front(i + 1), then back(i) -- or, when batches share passes,
-// front(i + 1) alone (batch i waits for its partner) and, one call later, front(i + 2), then the shared back half of i and
-// i + 1.  Errors of a batch surface here one or two calls late (or in the flush); the batches enqueued after it up to that
-// call are dropped too.
+// front(i + 1) alone while the group of batch i has room left (its batches wait for their partners); the call that opens the
+// next group runs the shared back half of the one before it, behind its own front half.  Errors of a batch surface here up to
+// stream_coalesce calls late (or in the flush); the batches enqueued after it up to that call are dropped too.
 static int enqueue_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u64 n_bases, u32* d_topk_idx,
                          u64* d_topk_sum, void* slot) {
     PendingBatch nw;
     nw.d_bases = d_bases; nw.d_offsets = d_offsets; nw.n_reads = n_reads; nw.n_bases = n_bases;
     nw.d_topk_idx = d_topk_idx; nw.d_topk_sum = d_topk_sum; nw.slot = slot;
     nw.pairable = st->coalesce >= 2;
+    // (host-fed batches: every batch waiting for its group holds a staging slot -- bases, offsets, rows -- so groups stay at four)
+    nw.max_group = slot ? std::min<u32>(st->coalesce, kStagedGroupMax) : st->coalesce;
     SKXCHK(batch_front(st, nw));
     int rc = SKX_OK;
-    if (st->n_pend == 2) {
-        PendingBatch a = st->pend[0], b = st->pend[1];
-        st->n_pend = 0;
-        rc = batch_back_pair(st, a, b, &nw);
-        if (rc == SKX_OK) rc = staged_rows(st, a.slot);
-        if (rc == SKX_OK) rc = staged_rows(st, b.slot);
-    } else if (st->n_pend == 1 && !nw.second) {
-        PendingBatch a = st->pend[0];
-        st->n_pend = 0;
-        rc = batch_back(st, a, &nw);
-        if (rc == SKX_OK) rc = staged_rows(st, a.slot);
-    }
+    if (nw.gi == 0) rc = pending_back(st, &nw);  // (it joined nobody: the batches waiting are complete)
     if (rc != SKX_OK) {
         const std::string msg = g_err;
-        // whatever is still waiting goes with it: empty the sets the speculative gathers filled
-        for (int i = 0; i < st->n_pend; ++i) (void)cancel_speculation(st, st->pend[i]);
-        st->n_pend = 0;
         (void)cancel_speculation(st, nw);
         (void)hipStreamSynchronize(st->hs0);
         (void)hipStreamSynchronize(st->hs1);
@@ -1862,7 +1897,7 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     SKXCHK(use_device(st->device));
     if (!st->hs_copy) {  // first use: copy stream + the staging slots
         HIPCHK(hipStreamCreateWithFlags(&st->hs_copy, hipStreamNonBlocking));
-        st->n_slots = st->coalesce >= 2 ? 5 : 3;
+        st->n_slots = st->coalesce >= 2 ? 2 * std::min<u32>(st->coalesce, kStagedGroupMax) + 1 : 3;
         for (u32 si = 0; si < st->n_slots; ++si) {
             auto& sl = st->slot[si];
             HIPCHK(hipMalloc(&sl.d_bases, std::max<u64>(st->max_bases, 1)));
@@ -2014,7 +2049,7 @@ SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
     }
     const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)st->h_nq[st->buf ^ 1], st->reads_big,
                                      st->total_passes, st->lean_passes, st->pcap, live, st->reads_split, st->segs_split, st->pool_grown,
-                                     st->shared_passes};
+                                     st->shared_passes, st->groups_unshared};
     for (uint32_t i = 0; i < n_out; ++i) out[i] = i < SKX_N_STATS ? v[i] : 0;
     return SKX_OK;
 }

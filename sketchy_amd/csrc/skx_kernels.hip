@@ -1284,14 +1284,18 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(const u64* __restrict_
                                                           u32 r_begin, u32 r_end, u32 p_base, u64* __restrict__ pair_h,
                                                           u32* __restrict__ pair_r, u64* __restrict__ ht, u32 ht_mask,
                                                           u32* __restrict__ ctr, u32 pair_cap, const u32* __restrict__ row_off,
-                                                          const u32* __restrict__ p_off_dev) {
+                                                          PairBase base) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 r = r_begin + blockIdx.x * 256u + threadIdx.x;
     if (r >= r_end) return;
-    // p_off_dev: the batch shares its pass with the batch before it -- its pairs go behind that batch's (whose pair count is
-    // only known on the device when this is queued), into the same hash set
-    const u32 p_off = p_off_dev ? *p_off_dev : 0u;
-    if ((u64)(poff[r_end] - p_base) + p_off > pair_cap) return;
+    // base: the batch shares its pass with the batches before it -- its pairs go behind theirs (whose pair counts are only
+    // known on the device when this is queued), into the same hash set
+    u64 p_off64 = 0;
+#pragma unroll
+    for (int i = 0; i < kPairBaseMax; ++i)
+        if (base.p[i]) p_off64 += *base.p[i];
+    if ((u64)(poff[r_end] - p_base) + p_off64 > pair_cap) return;
+    const u32 p_off = (u32)p_off64;
     const u32 a = poff[r], b = poff[r + 1];
     if (b == a) return;
     const u64* row = sk_stride ? sk + (size_t)r * sk_stride : sk + (size_t)row_off[r];
@@ -3215,10 +3219,10 @@ void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum
 
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
                         u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap, const u32* row_off,
-                        const u32* p_off_dev) {
+                        PairBase base) {
     if (r_end <= r_begin) return;
     hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 256)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
-                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off, p_off_dev);
+                       r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off, base);
 }
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q) {

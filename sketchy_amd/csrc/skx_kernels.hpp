@@ -97,10 +97,14 @@ void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q,
 // ht: hash set of ht_slots (power of two, >= 2 x pairs) u64, all-ones between passes; slot_off: [ht_slots] scratch;
 // bcount: [dict_buckets()] zero between passes; bbase: [dict_buckets()]; btot: [129]; ctr: [4] zero between passes
 // (ctr[1]: the all-ones hash was seen, ctr[2]: distinct keys inserted so far)
+// base: device words whose sum is the number of pairs already in the lists (a batch sharing the pass of the batches before it:
+// their pair counts are only known on the device when this is queued)
+static const int kPairBaseMax = 7;
+struct PairBase { const u32* p[kPairBaseMax] = {}; };
 void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32* poff, u32 r_begin, u32 r_end, u32 p_base,
                         u64* pair_h, u32* pair_r, u64* ht, u32 ht_slots, u32* ctr, u32 pair_cap,
                         const u32* row_off = nullptr /* sk_stride == 0: row r starts at sk + row_off[r] */,
-                        const u32* p_off_dev = nullptr /* device word: pairs already in the lists (a batch sharing the pass of the one before it) */);
+                        PairBase base = PairBase());
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q);
 u32 dict_buckets();

@@ -140,11 +140,12 @@ def test_enqueue_errors_surface_one_call_late(gpu):
     d_o0 = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[:21]))
     S.enqueue_device(d_b.ptr, d_bad.ptr, 20, int(bad[20]), None, None)   # accepted: nothing has looked at it yet
     with pytest.raises(_lib.SketchyHipError) as e:
-        # (two batches enqueued back to back share a pass: the second call only queues its sketch, the third -- or a flush --
-        # runs the shared back half and finds the error)
+        # (batches enqueued back to back share a pass: the next calls only queue their sketches; the call that finds the group
+        # full -- or a flush -- runs the shared back half and finds the error)
         S.enqueue_device(d_b.ptr, d_o1.ptr, 20, int(offsets[40] - offsets[20]), None, None)
         S.enqueue_device(d_b.ptr, d_o1.ptr, 20, int(offsets[40] - offsets[20]), None, None)
-    assert e.value.code == _lib.ERR_INVALID and "enqueued earlier" in str(e.value)
+        S.flush()
+    assert e.value.code == _lib.ERR_INVALID
     assert S.reads == 0 and not S.table().any()     # all three batches dropped
     S.enqueue_device(d_b.ptr, d_bad.ptr, 20, int(bad[20]), None, None)
     with pytest.raises(_lib.SketchyHipError):
@@ -289,50 +290,67 @@ def test_enqueue_under_other_placements(gpu, env):
     assert "enqueue_check ok" in r.stdout
 
 
-def test_two_enqueued_batches_share_a_pass(gpu):
-    """Option "stream_coalesce" = 2 (default): two batches enqueued back to back take ONE dictionary / scan / transpose and a
-    ranking each.  Same rows and table as the oracle -- with ragged batch sizes, an odd batch left over, entry points that
-    flush in between, pairs that do NOT fit a pass together (matrix rows sized so that one batch fits and two do not: they are
-    un-shared, each takes its own pass), and with the option off.  skx_stream_stats()[11] counts the shared passes."""
+def _groups(n_batches, n, flush_after=()):
+    """(shared passes, passes) when up to n batches enqueued back to back share a pass and nothing else limits a group"""
+    shared = passes = size = 0
+    for i in range(n_batches):
+        size += 1
+        if size == n or i in flush_after or i == n_batches - 1:
+            passes += 1
+            shared += size > 1
+            size = 0
+    return shared, passes
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_enqueued_batches_share_a_pass(gpu, n):
+    """Option "stream_coalesce" = n: up to n batches enqueued back to back take ONE dictionary / scan / transpose and a ranking
+    each.  Same rows and table as the oracle -- with ragged batch sizes, a group left incomplete at the end, entry points that
+    flush in between, and with the option off.  skx_stream_stats()[11] counts the shared passes."""
     from sketchy_amd import api
     ref, bases, offsets = workload(700, 400, 1400, read_len=400, rng_seed=901)
     exp = _expect(ref["ref"], 400, bases, offsets, 2)
     R = api.ReferenceSketch(ref["ref"])
-    cuts = [0, 200, 400, 650, 700, 900, 1100, 1400]   # seven batches: three pairs and one left over
+    cuts = [0, 200, 400, 650, 700, 900, 1100, 1400]   # seven batches
     kw = dict(top=2, max_batch_reads=300, max_batch_bases=len(bases))
 
-    def check(S, shared_expected, poke=None):
+    def make(coalesce):
+        before = api.get_option("stream_coalesce")
+        try:
+            api.set_option("stream_coalesce", coalesce)
+            return api.SumOfSharedHashes(R, **kw)
+        finally:
+            api.set_option("stream_coalesce", before)
+
+    def check(S, expected, poke=None):
         idx, val = _enqueue_stream(S, bases, offsets, cuts, 2, poke)
         np.testing.assert_array_equal(idx, exp["topk_idx"])
         np.testing.assert_array_equal(val, exp["topk_sum"])
         np.testing.assert_array_equal(S.table(), exp["cum"])
         st = S.stats()
-        assert st["passes_shared"] == shared_expected, st
+        assert (st["passes_shared"], st["passes"]) == expected and st["groups_unshared"] == 0, st
         assert S.reads == 1400
-        return st
 
-    S = api.SumOfSharedHashes(R, **kw)
-    st = check(S, 3)
-    assert st["passes"] == 4, st
-    # a flush between the two batches of a pair: they go alone
-    S = api.SumOfSharedHashes(R, **kw)
-    check(S, 2, poke=lambda i: S.flush() if i in (0, 2, 3, 4) else None)
+    check(make(n), _groups(7, n))
+    # flushes in between: the groups end there
+    S = make(n)
+    check(S, _groups(7, n, (0, 2, 3, 4)), poke=lambda i: S.flush() if i in (0, 2, 3, 4) else None)
     # the option off: one pass per batch
-    try:
-        api.set_option("stream_coalesce", 1)
-        S1 = api.SumOfSharedHashes(R, **kw)
-    finally:
-        api.set_option("stream_coalesce", 2)
-    st = check(S1, 0)
-    assert st["passes"] == 7, st
-    # one batch fits the bit matrices, two together may not: such pairs are un-shared in their back half.  Reads sketched with
-    # s = 192 (the collection's first sketch is that short) so that the matrices may be smaller than the others' 1 000 hashes.
+    check(make(1), (0, 7))
+
+
+def test_a_group_that_does_not_fit_one_pass_is_unshared(gpu):
+    """One batch fits the bit matrices, two together do not (matrix rows sized that way): the pair is un-shared in its back half --
+    the joint hash set emptied, each batch gathered again and given its own pass -- and the stream stops pairing batches of that
+    size.  Reads sketched with s = 192 (the collection's first sketch is that short) so that the matrices may be smaller than the
+    other sketches' 1 000 hashes.  Then the same with groups of up to eight."""
+    from sketchy_amd import api
     ref, bases, offsets = workload(300, 1000, 240, read_len=2000, rng_seed=905, err=0.01)
     col_len = np.full(300, 1000, np.uint32)
     col_len[0] = 192
     exp2 = orc.stream(16, 0, 192, ref["ref"], col_len, bases, offsets, top_k=2)
     R2 = api.ReferenceSketch(ref["ref"], col_len, s=192)
-    cuts2 = [0, 30, 60, 75, 90, 120, 150, 180, 210, 240]   # nine batches: four pairs (the second one small) and one left over
+    cuts2 = [0, 30, 60, 75, 90, 120, 150, 180, 210, 240]   # nine batches
     kw2 = dict(top=2, max_batch_reads=60, max_batch_bases=len(bases))
     P = api.SumOfSharedHashes(R2, **kw2)
 
@@ -342,22 +360,23 @@ def test_two_enqueued_batches_share_a_pass(gpu):
         assert P.stats()["last_passes"] == 1
         return P.stats()["dictionary_size"]
     single = [distinct(a, b) for a, b in zip(cuts2[:-1], cuts2[1:])]
-    joint = [distinct(a, b) for a, b in zip(cuts2[0:-2:2], cuts2[2::2])]
     rows = (max(single) + 63) // 64 * 64
-    assert rows >= 192
-    fit = sum(j <= rows for j in joint)
-    assert 0 < fit < len(joint), (single, joint, rows)   # (else this workload does not test what it should)
-    try:
-        api.set_option("stream_query_rows", rows)
-        S2 = api.SumOfSharedHashes(R2, **kw2)
-    finally:
-        api.set_option("stream_query_rows", 0)
-    idx, val = _enqueue_stream(S2, bases, offsets, cuts2, 2)
-    np.testing.assert_array_equal(idx, exp2["topk_idx"])
-    np.testing.assert_array_equal(val, exp2["topk_sum"])
-    np.testing.assert_array_equal(S2.table(), exp2["cum"])
-    st = S2.stats()
-    assert st["passes_shared"] == fit and st["passes"] == 9 - fit, (st, single, joint)
+    assert rows >= 192 and distinct(0, 60) > rows, (single, rows)   # (else this workload does not test what it should)
+    before = api.get_option("stream_coalesce")
+    for n in (2, 8):
+        try:
+            api.set_option("stream_query_rows", rows)
+            api.set_option("stream_coalesce", n)
+            S2 = api.SumOfSharedHashes(R2, **kw2)
+        finally:
+            api.set_option("stream_query_rows", 0)
+            api.set_option("stream_coalesce", before)
+        idx, val = _enqueue_stream(S2, bases, offsets, cuts2, 2)
+        np.testing.assert_array_equal(idx, exp2["topk_idx"], err_msg=str(n))
+        np.testing.assert_array_equal(val, exp2["topk_sum"], err_msg=str(n))
+        np.testing.assert_array_equal(S2.table(), exp2["cum"], err_msg=str(n))
+        st = S2.stats()
+        assert st["groups_unshared"] >= 1 and st["passes"] <= 9 - st["passes_shared"], (n, st, single)
 
 
 def test_an_error_in_the_second_batch_of_a_pair(gpu):
