@@ -279,6 +279,7 @@ def main():
                                      what="final sum all-reduce of the u64 table, inside the timed region (max over ranks; includes "
                                           "queueing the last batch's passes and waiting for them)"),
                    "api": "skx_stream_enqueue_device + final sync" if args.api == "enqueue" else "skx_stream_push_device + final sync",
+                   "kmer_prefilter": dict(zip(("keys", "table_bytes"), R.kmer_filter)),
                    "batches_per_pass": (f"up to {coalesce_policy} (option stream_coalesce: batches enqueued back to back share one scan of "
                                         f"the reference; {stats['passes_shared']} shared passes so far on this stream)") if args.api == "enqueue" else "1",
                    "parallelism": f"reads sharded x{world}, reference replicated, final table all-reduce via {reducer.how}"},

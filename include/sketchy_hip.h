@@ -66,12 +66,13 @@ int skx_device_info(int device, char *name, size_t name_cap, int *compute_units,
 /*
  * Process-wide policies, consulted when a reference or a stream is CREATED (no effect on existing handles, never on
  * results -- only on memory and speed).  Names:
- *   "kmer_prefilter"  0 (default) / 1: for k = 16, skx_ref_create also builds a Bloom table over the canonical 16-mers whose
- *                     hash can meet the reference (every 4^16 / 2 of them is hashed once, ~10 ms on an MI355X); the
- *                     production sketcher then hashes only the windows of a read that pass it (reads with at most s
- *                     windows -- longer ones can be truncated and take the plain loop).  Rows, tables and debug outputs
- *                     are identical either way.  A quarter less VALU work per batch and +10 % for a lone batch, but no gain
- *                     inside the stream's pipeline (the table gathers compete with the reference scan): off by default.
+ *   "kmer_prefilter"  0 off (default) / 1 on / 2 on when its table fits 32 KB: for k = 16, skx_ref_create also builds a Bloom
+ *                     table over the canonical 16-mers whose hash can meet the reference (every 4^16 / 2 of them is hashed
+ *                     once, ~10 ms on an MI355X; 8 table bits per key); the production sketcher then hashes only the windows
+ *                     of a read that pass it (reads with at most s windows -- longer ones can be truncated and take the plain
+ *                     loop).  Rows, tables and debug outputs are identical either way.  One gather per window: it pays only
+ *                     while the table sits in the L1 caches (a 16 KB table: +10 % reads/s; 128 KB: -10 %; 8 MB: -50 %), i.e.
+ *                     for references with a few thousand distinct hashes -- not for a species-wide collection.
  *   "filter_bits_per_hash"  table bits of the membership filter per DISTINCT reference hash, 4..4096 (default 32: ~0.03 % of
  *                     the read hashes no genome holds get through and cost an all-zero row each; 32 MB at 40 000 S. aureus-like
  *                     genomes x 10 000 hashes, which share all but ~6e6 of their 4e8 hashes).

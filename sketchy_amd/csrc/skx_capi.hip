@@ -142,14 +142,18 @@ static inline double now_us() { return std::chrono::duration<double, std::micro>
 #endif
 
 // ------------------------------------------------------------------ policies (skx_set_option)
-static bool g_kmer_prefilter = false;  // build / use the k-mer prefilter for k = 16 references (off: no gain inside the pipeline)
+static u32 g_kmer_prefilter = 0;  // k-mer prefilter of k = 16 references: 0 off, 1 on, 2 on when its table is small enough to pay
 static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
 static u32 g_stream_query_rows = 0;       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
 static u32 g_stream_coalesce = 8;         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 .. 8)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
     if (!name) return fail(SKX_ERR_INVALID, "NULL option name");
-    if (!strcmp(name, "kmer_prefilter")) { g_kmer_prefilter = value != 0; return SKX_OK; }
+    if (!strcmp(name, "kmer_prefilter")) {
+        if (value > 2) return fail(SKX_ERR_INVALID, "kmer_prefilter must be 0 (off), 1 (on) or 2 (on when its table is small)");
+        g_kmer_prefilter = (u32)value;
+        return SKX_OK;
+    }
     if (!strcmp(name, "stream_coalesce")) {
         if (value < 1 || value > (uint64_t)skx::kPairBaseMax + 1) return fail(SKX_ERR_INVALID, "stream_coalesce must be 1 .. 8");
         g_stream_coalesce = (u32)value;
@@ -169,7 +173,7 @@ SKX_API int skx_set_option(const char* name, uint64_t value) {
 }
 SKX_API int skx_get_option(const char* name, uint64_t* value) {
     if (!name || !value) return fail(SKX_ERR_INVALID, "NULL argument");
-    if (!strcmp(name, "kmer_prefilter")) { *value = g_kmer_prefilter ? 1 : 0; return SKX_OK; }
+    if (!strcmp(name, "kmer_prefilter")) { *value = g_kmer_prefilter; return SKX_OK; }
     if (!strcmp(name, "filter_bits_per_hash")) { *value = g_filter_bits_per_hash; return SKX_OK; }
     if (!strcmp(name, "stream_query_rows")) { *value = g_stream_query_rows; return SKX_OK; }
     if (!strcmp(name, "stream_coalesce")) { *value = g_stream_coalesce; return SKX_OK; }
@@ -386,15 +390,17 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipGetLastError());
     }
     RCHK(hipDeviceSynchronize());
-    const bool pf_knob = skx::knob("SKX_KMER_PREFILTER") ? atoi(skx::knob("SKX_KMER_PREFILTER")) != 0 : g_kmer_prefilter;  // (experiment knob overrides the policy)
-    // table bits per key.  Measured at C2 (6 M keys): 16 bits (16 MB table, 0.7 % false positives) loses 8 % against no prefilter at
-    // all -- 147 M random 4-byte gathers per batch into a table far beyond the 4 MB of L2 an XCD has become fabric traffic
-    // three times the reference scan's; 4 bits (4 MB, ~15 % false positives = ~4 murmur3 batches per read instead of 24) keeps
-    // the gathers in L2: +2.5 % in the pipeline, +10 % for a lone batch.
-    static const u32 kf_bits = skx::knob("SKX_KF_BITS") ? (u32)std::max(1, atoi(skx::knob("SKX_KF_BITS"))) : 4u;
-    if (k == 16 && any && pf_knob) {
-        // every canonical 16-mer whose hash passes the filter above (two passes over the 2^32 codes: count, then insert);
-        // 16 table bits per key, two probes: ~1.4 % false positives, each costing one murmur3 evaluation per occurrence
+    const u32 pf_mode = skx::knob("SKX_KMER_PREFILTER") ? (u32)atoi(skx::knob("SKX_KMER_PREFILTER")) : g_kmer_prefilter;  // (experiment knob overrides the policy)
+    // table bits per key, and how large a table still pays.  Every window of a read costs one random 4-byte gather, and that only
+    // pays while the table sits in the CUs' L1 caches (32 KB).  Measured at C2 (98 304-read batches, eight batches per scan) with the
+    // table blown up to the size a larger key set would need: no table 117 M reads/s; 16 KB 128 M; 128 KB 105 M; 1 MB 96 M; 4 MB
+    // 86 M; 8 MB 59 M; 32 MB 38 M.  The SYNTHETIC C2 reference has only 11 600 keys (its variant hashes are random numbers, not
+    // hashes of 16-mers; 8 bits per key = 16 KB) -- a real collection of that size (6e6 distinct hashes, every one a 16-mer's)
+    // would need megabytes.  Hence: off by default; "2" builds the table only when it fits 32 KB (small panels).
+    static const u32 kf_bits = skx::knob("SKX_KF_BITS") ? (u32)std::max(1, atoi(skx::knob("SKX_KF_BITS"))) : 8u;
+    const u64 kf_auto_bits = 8ull << 15;  // 32 KB
+    if (k == 16 && any && pf_mode) {
+        // every canonical 16-mer whose hash passes the filter above (two passes over the 2^32 codes: count, then insert)
         u32* d_n = nullptr;
         RCHK(hipMalloc(&d_n, 4));
         RCHK(hipMemset(d_n, 0, 4));
@@ -402,14 +408,24 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipGetLastError());
         RCHK(hipMemcpy(&r->kf_keys, d_n, 4, hipMemcpyDeviceToHost));
         (void)hipFree(d_n);
-        u32 lg_words = 10;  // 4 KB at least
-        while (lg_words < 27 && (32ull << lg_words) < (u64)kf_bits * r->kf_keys) ++lg_words;
-        r->kf_shift = 32u - lg_words;
-        RCHK(hipMalloc(&r->d_kf, (size_t)4 << lg_words));
-        RCHK(hipMemset(r->d_kf, 0, (size_t)4 << lg_words));
-        skx::launch_kmer_filter_build(nullptr, seed, max_ref, r->d_filt, r->filt_shift, nullptr, r->d_kf, r->kf_shift);
-        RCHK(hipGetLastError());
-        RCHK(hipDeviceSynchronize());
+        auto table_lg_words = [&](u32 bits) {
+            u32 lg = 10;  // 4 KB at least
+            while (lg < 27 && (32ull << lg) < (u64)bits * r->kf_keys) ++lg;
+            return lg;
+        };
+        u32 lg_words = table_lg_words(kf_bits);
+        if (pf_mode >= 2 && (32ull << lg_words) > kf_auto_bits) {  // auto: half the bits if that fits, else no table at all
+            lg_words = table_lg_words(std::max(1u, kf_bits / 2));
+            if ((32ull << lg_words) > kf_auto_bits) { lg_words = 0; r->kf_keys = 0; }
+        }
+        if (lg_words) {
+            r->kf_shift = 32u - lg_words;
+            RCHK(hipMalloc(&r->d_kf, (size_t)4 << lg_words));
+            RCHK(hipMemset(r->d_kf, 0, (size_t)4 << lg_words));
+            skx::launch_kmer_filter_build(nullptr, seed, max_ref, r->d_filt, r->filt_shift, nullptr, r->d_kf, r->kf_shift);
+            RCHK(hipGetLastError());
+            RCHK(hipDeviceSynchronize());
+        }
     }
 #undef RCHK
     *out = r;
@@ -1455,8 +1471,11 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     hipStream_t hs = st->hs0;
     const u32 n_reads = pb.n_reads;
     // sides are taken in turn (two enqueued batches may be waiting for their shared pass while this one is sketched)
-    pb.side = st->side_next;
-    st->side_next = (st->side_next + 1) % (int)(st->coalesce + 1);
+    // (synchronous pushes have flushed whatever was waiting: they alternate between two sides, so a stream that is only ever
+    // pushed to never allocates the others)
+    const int n_sides = pb.pairable ? (int)st->coalesce + 1 : 2;
+    pb.side = st->side_next % n_sides;
+    st->side_next = (pb.side + 1) % n_sides;
     HIPCHK(use_side(st, pb.side));
     pb.inrange_only = !(pb.h_sketches || pb.h_sketch_len);  // production: only what can meet the reference is built
     // production rows are reservations out of the side's pool; full sketches (and unfiltered ones) need full-width rows

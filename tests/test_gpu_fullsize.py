@@ -156,6 +156,7 @@ def test_c2_footprint_and_four_streams_on_one_reference(c2):
     streams share the reference, each scores its own reads."""
     from sketchy_amd import api
     R, bases, offsets = c2["R"], c2["bases"], c2["offsets"]
+    assert R.kmer_filter == (0, 0)   # (policy "kmer_prefilter": off by default)
     free0, total = api.device_mem(0)
     streams = []
     for i in range(4):
