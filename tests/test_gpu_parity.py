@@ -357,6 +357,14 @@ def test_long_reads_split_other_k_and_dense_segments(gpu):
     assert S.stats()["reads_block_sketcher"] == 2 and S.stats()["reads_split_over_waves"] == 2
 
 
+def synth_reference_with_many_keys(n_keys=90000):
+    """two columns of hashes of REAL 16-mers (a random sequence's), more of them than a 32 KB table takes at 4 bits per key"""
+    from sketchy_amd import synth
+    g = synth.random_genome(40 * n_keys, np.random.default_rng(5))
+    h = np.unique(synth.canonical_kmer_hashes(g, 16, 0))[:n_keys]
+    return np.stack([h, h])
+
+
 @pytest.mark.parametrize("seed", [0, 42])
 def test_kmer_prefilter_gives_the_oracles_rows(gpu, seed):
     """k = 16 references carry a Bloom table over the canonical 16-mers whose hash can meet them; the production sketcher
@@ -401,6 +409,18 @@ def test_kmer_prefilter_gives_the_oracles_rows(gpu, seed):
     finally:
         api.set_option("kmer_prefilter", 0)
     assert R.kmer_filter[0] > 10000 and exp["shared"].max() > 256
+    # policy 2: only a table that fits the L1 caches (32 KB at 8, else 4, bits per key) is built
+    if seed == 0:
+        small, _, _ = workload(6, 2000, 1, read_len=300, rng_seed=7200)
+        large = synth_reference_with_many_keys()
+        try:
+            api.set_option("kmer_prefilter", 2)
+            Rs, Rl = api.ReferenceSketch(small["ref"]), api.ReferenceSketch(large)
+        finally:
+            api.set_option("kmer_prefilter", 0)
+        assert 2000 <= Rs.kmer_filter[0] < 8000 and 0 < Rs.kmer_filter[1] <= 32768, Rs.kmer_filter
+        assert Rl.kmer_filter == (0, 0)
+        Rs.close(); Rl.close()
 
 
 def test_long_reads_other_k(gpu):
