@@ -1146,6 +1146,11 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             st->have_hint = true;
         }
     u64 nq_est = std::max<u64>(1, (u64)(P * st->nq_per_pair));
+    // (a pass whose pairs the front halves gathered knows its |Q| exactly: the gather counted the keys new to the hash set.  The
+    // per-pair figure of an earlier pass misleads when passes differ in size -- a group of eight batches has eight times the
+    // pairs of a single batch but hardly more distinct hashes, and was sent to the dense-dictionary scan kernel)
+    const bool nq_known = inserted && q_rows != 0xFFFFFFFFu;
+    if (nq_known) nq_est = std::max<u64>(1, q_rows);
 
     // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already).  Set b was last used two
     // passes ago: by that pass's dictionary / scan / transpose on THIS stream (Q, windows, hash set: ordered by the stream)
@@ -1183,7 +1188,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     HIPCHK(hipEventRecord(st->ev_dict[b], hs));
 
     // the very first pass of a stream has no hint: wait for its dictionary once rather than run the heaviest variant
-    if (!st->have_hint && P > 0) {
+    if (!st->have_hint && !nq_known && P > 0) {
         HIPCHK(hipStreamSynchronize(hs));
         st->nq_per_pair = std::min(1.0, (double)st->h_nq[b] / P);
         st->hint_pairs[b] = 0;
