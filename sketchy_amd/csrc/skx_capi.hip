@@ -2279,3 +2279,9 @@ SKX_API void skx_comm_destroy(skx_comm* comm) {
     if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->comm);
     delete comm;
 }
+
+#ifdef SKX_EXPERIMENTS
+namespace skx { void rank_debug_counters(unsigned long long* out, bool reset); }
+// experiments build only: counters of rank_seg_top1_kernel (see skx_kernels.hip); out[128]
+SKX_API void skx_debug_rank_counters(unsigned long long* out, int reset) { skx::rank_debug_counters(out, reset != 0); }
+#endif

@@ -2558,6 +2558,15 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__
     }
 }
 
+#ifdef SKX_EXPERIMENTS
+// instrumentation of rank_seg_top1_kernel (experiments build only): [0..4] waves by exit (chunk dead, no live word, no candidate,
+// few candidates, replay), [5] candidates of replaying waves, [6] pairs they replayed, [8..15] replaying waves by candidates
+// (1, 2-4, 5-16, 17-64, 65-512), [16 + c] replaying waves of chunk c (c < 112)
+__device__ unsigned long long g_rank_dbg[128];
+#define SKX_DBG_ADD(i, v) atomicAdd(&g_rank_dbg[i], (unsigned long long)(v))
+#else
+#define SKX_DBG_ADD(i, v)
+#endif
 // ---- top-1 fast path -------------------------------------------------------------------
 // wave-wide max of a u32 (DPP within rows of 16 lanes, then 4 readlanes); every lane returns it.
 __device__ __forceinline__ u32 wave_max_u32(u32 v) {
@@ -2612,6 +2621,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     const bool dead = !grp_any[grp];
     if (!chunk_group_live(gmax, lead_val, n_pad / 256u, seg >> 4, grp, sp)) {  // (its start values were not even written)
         if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;  // nothing to report: the merge skips this (segment, group)
+        if (lane == 0) SKX_DBG_ADD(0, 1);
         return;
     }
     // words none of whose genomes can reach even the chunk's leader bound by the end of the segment (seg_prefix_kernel):
@@ -2621,6 +2631,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         livew = (u32)__ballot(live_byte) & 0xFFu;
         if (livew == 0u) {
             if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;
+            if (lane == 0) SKX_DBG_ADD(1, 1);
             return;
         }
     }
@@ -2672,6 +2683,7 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
     }
     if (wmask == 0) {
         if (lane == 0) has[(size_t)seg * n_grp + grp] = 0;  // nothing to report: the merge skips this (segment, group)
+        if (lane == 0) SKX_DBG_ADD(2, 1);
         return;
     }
     const u64 base = lead - gain - 1u;  // winner sum = base + (key >> SH)   (mod 2^64)
@@ -2693,6 +2705,17 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
         n_cands += (u32)__popcll(cbal[j]);
     }
     const bool single = n_cands <= kFewCands;  // (n_cands >= 1 here: wmask != 0)
+#ifdef SKX_EXPERIMENTS
+    if (lane == 0) {
+        SKX_DBG_ADD(single ? 3 : 4, 1);
+        if (!single) {
+            SKX_DBG_ADD(5, n_cands);
+            SKX_DBG_ADD(6, pz - pa);
+            SKX_DBG_ADD(8 + (n_cands <= 1 ? 0 : n_cands <= 4 ? 1 : n_cands <= 16 ? 2 : n_cands <= 64 ? 3 : 4), 1);
+            if ((seg >> 4) < 112u) SKX_DBG_ADD(16 + (seg >> 4), 1);
+        }
+    }
+#endif
     if (single) {
         const u32 pe = lane < rz - ra ? poff[r_begin + ra + lane + 1u] - p_base - pa : 0u;  // pairs of reads <= this lane's
 #pragma unroll
@@ -3417,3 +3440,15 @@ void launch_gather_table(hipStream_t st, const u64* cum, u64* out, u32 n_real, c
 }
 
 }  // namespace skx
+
+#ifdef SKX_EXPERIMENTS
+namespace skx {
+void rank_debug_counters(unsigned long long* out, bool reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rank_dbg), sizeof(unsigned long long) * 128);
+    if (reset) {
+        unsigned long long z[128] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rank_dbg), z, sizeof z);
+    }
+}
+}  // namespace skx
+#endif

@@ -39,3 +39,29 @@ for i in range(4):
     S.sync()
 p = S.profile()
 print(" ".join(f"{n}={v['ms'] / max(1, v['launches']):.3f}" for n, v in p.items() if v["launches"]))
+
+# experiments build only: where the ranking's waves went in a lone first batch, and in a batch far from the start
+import ctypes as C
+import os
+if "exp" in os.environ.get("SKX_LIB_PATH", ""):
+    from sketchy_amd import _lib
+    L = _lib.load()
+    L.skx_debug_rank_counters.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    L.skx_debug_rank_counters.restype = None
+    buf = (C.c_ulonglong * 128)()
+
+    def show(label):
+        L.skx_debug_rank_counters(buf, 1)
+        v = list(buf)
+        print(label, "waves: chunk-dead %d, no live word %d, no candidate %d, few %d, replay %d; replay: cands/wave %.1f, pairs/wave %.1f; by cands (1|2-4|5-16|17-64|65+): %s"
+              % (v[0], v[1], v[2], v[3], v[4], v[5] / max(1, v[4]), v[6] / max(1, v[4]), v[8:13]))
+        print("   replaying waves per chunk:", v[16:16 + 96])
+    S.set_profiling(0)
+    S.reset(); S.sync(); L.skx_debug_rank_counters(buf, 1)
+    S.enqueue_device(batches[0][0].data_ptr(), batches[0][1].data_ptr(), B, nb[0], d_ti.data_ptr(), d_ts.data_ptr())
+    S.sync()
+    show("first batch:")
+    for i in range(6):
+        S.enqueue_device(batches[(i + 1) % 2][0].data_ptr(), batches[(i + 1) % 2][1].data_ptr(), B, nb[(i + 1) % 2], d_ti.data_ptr(), d_ts.data_ptr())
+        S.sync()
+        show("batch %d:" % (i + 2))
