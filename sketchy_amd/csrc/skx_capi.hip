@@ -614,6 +614,7 @@ struct skx_stream {
     u64* d_lpart_sum = nullptr;   // per-slice leader candidates (chunk_leader_part_kernel)
     u32* d_lpart_idx = nullptr;
     u32* d_rel = nullptr;         // [segments of a pass][n_pad] segment start values relative to the pass-start table
+    u32* d_live_ctr = nullptr;        // [2] sampled (chunk, half group)s that can hold a candidate / tested, of the most recent ranking (seg_prefix_kernel)
     u64* d_lead_seg = nullptr;        // [segments of a pass][species] the ranking's bound as every segment begins (chunk_leader_merge_kernel)
     unsigned char* d_has = nullptr;   // [segments of a pass][rank groups] the pruned ranking kernels reported something (the merges skip the rest)
     unsigned char* d_live = nullptr;  // [segments of a pass][n_pad / 64] top-1 ranking: the word can hold a candidate (seg_prefix_kernel)
@@ -673,7 +674,7 @@ struct skx_stream {
     u32 n_slots = 3;
     hipStream_t hs_copy = nullptr;
     u64 next_ticket = 0;
-    u32* h_nq = nullptr;     // pinned [2]
+    u32* h_nq = nullptr;     // pinned [4]
     u32 hint_pairs[2] = {0, 0};
     double nq_per_pair = 1.0;
     bool have_hint = false;  // false until one dictionary size has been seen
@@ -699,7 +700,7 @@ static void stream_free(skx_stream* st) {
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc2[0], st->d_inc2[1] != st->d_inc2[0] ? st->d_inc2[1] : nullptr,
-                    st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_has, st->d_lead_seg, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
+                    st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_has, st->d_lead_seg, st->d_live_ctr, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
                     st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1]};
     for (void* p : ptrs) (void)hipFree(p);
@@ -974,6 +975,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_live, (size_t)n_seg_max * (n_pad / 64)));
     SCHK(hipMalloc(&st->d_has, (size_t)n_seg_max * (n_pad / (skx::kRankWords * 64))));
     SCHK(hipMalloc(&st->d_lead_seg, (size_t)n_seg_max * n_sp * 8 + 64));
+    SCHK(hipMalloc(&st->d_live_ctr, 8));
     SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
     SCHK(hipMalloc(&st->d_csum_raw2[0], (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
     if (st->hs3 != st->hs2) SCHK(hipMalloc(&st->d_csum_raw2[1], (size_t)((n_seg_max + 15) / 16) * n_pad * 4)); else st->d_csum_raw2[1] = st->d_csum_raw2[0];
@@ -1021,8 +1023,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipHostMalloc((void**)&st->h_chk_base, kSides * 16 * 4, hipHostMallocCoherent));  // kernels write it, the host polls it
     memset(st->h_chk_base, 0, kSides * 16 * 4);
     SCHK(use_side(st, 0));
-    SCHK(hipHostMalloc((void**)&st->h_nq, 2 * 4, hipHostMallocCoherent));
+    SCHK(hipHostMalloc((void**)&st->h_nq, 4 * 4, hipHostMallocCoherent));  // ([2], [3]: the ranking's live sample, d_live_ctr)
     st->h_nq[0] = st->h_nq[1] = 0;
+    st->h_nq[2] = 1; st->h_nq[3] = 1;  // (nothing known yet: everything may hold a candidate)
     // the zero-fills above ran on the null stream, which the (non-blocking) pipeline streams do not wait for
     SCHK(hipDeviceSynchronize());
 #undef SCHK
@@ -1268,20 +1271,36 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     u64* const d_topk_sum = sb.d_topk_sum;
     const u32 out_r0 = sb.ra;
     const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
+    const bool ranked = st->top_k && d_topk_idx && d_topk_sum;
+    const u32 prune_k = (ranked && st->top_k <= skx::rank_topk_fast_max()) ? st->top_k : 0u;
+    // Pruned rankings count in two levels: the chunk sums of EVERYTHING first (one workgroup per (rank group, chunk of 1024
+    // reads): a third less work than per segment), then -- once the chunk-level bounds are known -- the per-segment increments
+    // of the (chunk, rank group)s that can hold a candidate.  Far from the start of a sample that is the leaders' groups and
+    // little else; nobody reads the increments of the others (seg_prefix and the ranking kernels apply the same test).
+    // It pays when most (chunk, group)s are dead -- C2: from the fifth batch of a sample on; the first batches, where nearly every
+    // genome is still a candidate, would count everything twice.  The ranking samples the share of live (chunk, half group)s of
+    // every batch (seg_prefix_kernel -> h_nq[2..3], a few batches stale when read here: both schemes are exact).
+    static const int two_level_env = skx::knob("SKX_TWO_LEVEL") ? atoi(skx::knob("SKX_TWO_LEVEL")) : -1;  // experiment knob: 0 / 1 force
+    const volatile u32* h_live = st->h_nq + 2;
+    const u32 live_now = h_live[0], tested_now = h_live[1];
+    const bool mostly_dead = tested_now != 0 && (u64)live_now * 3 < tested_now;
+    const bool two_level = prune_k != 0 && (two_level_env >= 0 ? two_level_env != 0 : mostly_dead);
+    const u64* rowany_b = P > 0 ? st->d_rowany[b] : nullptr;
     if (update_table) {
         Span sp(st, 4, hs3);
         // (the chunk sums are accumulated by seg_sum's workgroups: four atomic adds per chunk and genome)
         HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * n_pad * 4, hs3));
-        skx::launch_seg_sum(hs3, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
-                            d_csum_raw, P > 0 ? st->d_rowany[b] : nullptr, d_nq);
+        if (two_level)
+            skx::launch_chunk_sum(hs3, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, d_grp_any, d_csum_raw, rowany_b, d_nq, spc);
+        else
+            skx::launch_seg_sum(hs3, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
+                                d_csum_raw, rowany_b, d_nq, spc);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(st->ev_inc[b], hs3));
     HIPCHK(hipStreamWaitEvent(hs2, st->ev_inc[b], 0));  // (implies ev_front[b])
     if (update_table) {
         Span sp(st, 4, hs2);
-        const bool ranked = st->top_k && d_topk_idx && d_topk_sum;
-        const u32 prune_k = (ranked && st->top_k <= skx::rank_topk_fast_max()) ? st->top_k : 0u;
         // the top-1 kernel keeps (value relative to the leader) in 23 bits of a 32-bit key: at most 2 x 64 x s + 1 per
         // segment, so sketch sizes from 2^15 on take the 64-bit-key kernel (with k = 1) instead
         static const bool top1_wide_env = skx::knob("SKX_TOP1_WIDE") != nullptr;  // test knob: force the 64-bit-key kernel
@@ -1289,15 +1308,26 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         static const bool live_env = !skx::knob("SKX_RANK_LIVE") || atoi(skx::knob("SKX_RANK_LIVE")) != 0;  // test knob
         const bool topk_fast = !top1_fast && st->top_k && st->top_k <= skx::rank_topk_fast_max();
         unsigned char* d_live = ((top1_fast || topk_fast) && ranked && live_env) ? st->d_live : nullptr;  // (the pruned kernels look at the flags)
-        skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
-                               st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live, st->d_lead_seg);
+        if (prune_k) HIPCHK(hipMemsetAsync(st->d_live_ctr, 0, 8, hs2));
+        if (two_level) {
+            skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
+                                   st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live, st->d_lead_seg, 1);
+            skx::launch_seg_sum(hs2, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
+                                nullptr, rowany_b, d_nq, spc, st->d_gmax, st->d_lead_val);
+            skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
+                                   st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live, st->d_lead_seg, 2, st->d_live_ctr);
+        } else {
+            skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
+                                   st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live, st->d_lead_seg, 0,
+                                   st->d_live_ctr);
+        }
+        if (prune_k) HIPCHK(hipMemcpyAsync(st->h_nq + 2, st->d_live_ctr, 8, hipMemcpyDeviceToHost, hs2));
         std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
         const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
         if (top1_fast && d_topk_idx && d_topk_sum) {
             skx::launch_rank_seg_top1(hs2, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows,
                                       spc, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, d_inc,
-                                      st->d_leader, st->d_gmax, st->d_lead_val, d_grp_any, d_live, st->d_has,
-                                      P > 0 ? st->d_rowany[b] : nullptr, d_nq);
+                                      st->d_leader, st->d_gmax, st->d_lead_val, d_grp_any, d_live, st->d_has, rowany_b, d_nq);
             skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, d_topk_idx, d_topk_sum, out_r0, spc, st->d_has,
                                    (n_gw + skx::kRankWords - 1) / skx::kRankWords);
         } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
@@ -2050,6 +2080,7 @@ SKX_API int skx_stream_reset(skx_stream* st) {
     HIPCHK(hipMemsetAsync(st->d_cum, 0, (size_t)st->ref->n_pad * 8, st->hs2));
     HIPCHK(hipStreamSynchronize(st->hs2));
     st->reads_total = 0;
+    st->h_nq[2] = 1; st->h_nq[3] = 1;  // (a new sample: every genome is a candidate again)
     return SKX_OK;
 }
 SKX_API int skx_stream_reads(const skx_stream* st, uint64_t* n_reads) {

@@ -2027,7 +2027,7 @@ constexpr u32 kSparseQueue = 256;  // query rows a wave parks in LDS while it co
     }
 // x (N planes) += y (N planes), both bit-sliced little-endian; the carry out becomes plane N of x
 template <int N>
-__device__ __forceinline__ void add_planes(u32 (&x)[10], const u32 (&y)[10]) {
+__device__ __forceinline__ void add_planes(u32 (&x)[12], const u32 (&y)[12]) {
     u32 c = 0;
 #pragma unroll
     for (int b = 0; b < N; ++b) {
@@ -2038,12 +2038,29 @@ __device__ __forceinline__ void add_planes(u32 (&x)[10], const u32 (&y)[10]) {
     }
     x[N] = c;
 }
+// CHUNK (round 3): the same counting for a whole CHUNK per workgroup -- a wave takes a quarter chunk (seg_len = 256 reads),
+// eight planes hold up to 255 rows per lane (one extraction per ~1 984 pairs instead of one per segment: the extraction was
+// 60 % of a segment wave's instructions), only the chunk sums leave.  The pruned rankings run THIS over everything and the
+// per-segment kernel only over the (chunk, rank group)s that can hold a candidate (chunk_group_live: known once the chunk
+// sums are prefixed) -- far from the start of a sample that is the leaders' groups and little else, and nobody reads the
+// per-segment increments of the others.
+// (the test is described with the chunk-level pruning below)
+__device__ __forceinline__ bool chunk_group_live(const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
+                                                 u32 n_half, u32 c, u32 grp, const Species& sp) {
+    const u64 lv = lead_val[c * sp.n_sp + sp.of_grp[grp]];
+    const u64* gm = gmax + (size_t)(c + 1u) * n_half + 2u * grp;  // (n_half = 2 x rank groups: n_pad is a multiple of 512)
+    return gm[0] >= lv || gm[1] >= lv;
+}
+
+struct ChunkLive { const u64* gmax = nullptr; const u64* lead_val = nullptr; u32 n_half = 0; };
+template <bool CHUNK>
 __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ poff,
                                                       u32 p_base, u32 r_begin, u32 n_reads, u32 seg_len,
                                                       const u64* __restrict__ mq, u32 n_gw, u32 n_pad,
                                                       u32 nq_rows, u32* __restrict__ inc, const u32* __restrict__ grp_any,
                                                       u32* __restrict__ qsum, const u64* __restrict__ rowany,
-                                                      const u32* __restrict__ n_q) {
+                                                      const u32* __restrict__ n_q, ChunkLive cl, Species sp) {
+    constexpr int NP = CHUNK ? 8 : 6;  // counter planes per lane: up to 2^NP - 1 rows per lane and block
     __builtin_amdgcn_s_setprio(SKX_SEGSUM_PRIO);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     static_assert(kRankWords == 8, "lane = (sub, word) layout assumes 8 words per rank group");
     const u32 lane = lane_id();
@@ -2063,6 +2080,9 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     const u32 grp = (blk / n_q4) * 8u + xcd, seg4 = blk % n_q4;
     const u32 seg = __builtin_amdgcn_readfirstlane(seg4 * 4u + wv);
     if (grp >= n_grp || !grp_any[grp]) return;  // (a group without any bit: nobody reads its increments; the whole block leaves)
+    // per-segment increments are only read for (chunk, group)s that can hold a candidate (seg_prefix / the pruned rankings test
+    // exactly this): the whole block -- four segments of one chunk -- leaves
+    if (!CHUNK && cl.gmax && !chunk_group_live(cl.gmax, cl.lead_val, cl.n_half, (seg4 * 4u) >> 4, grp, sp)) return;
     const bool on = seg < n_seg;
     const u32 sub = lane >> 3, j = lane & 7u;
     const u32 ra = seg * seg_len, rz = min(n_reads, ra + seg_len);
@@ -2070,7 +2090,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     u32 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0;
-    constexpr u32 kBlockPairs = 8u * 56u;  // <= 56 rows per lane and block: six planes hold the lane's counts
+    constexpr u32 kBlockPairs = CHUNK ? 8u * 248u : 8u * 56u;  // rows per lane and block <= 2^NP - 1: the planes hold the lane's counts
     // Addressing kept off the VALU: the group's slice of Mq and the pair list are wave-uniform bases (scalar registers), a
     // lane's row word is at byte offset (q << 6 | j * 8) and its slot of the pair list at 4 * (p0 + sub) + 32 u -- both fit
     // 32 bits (a pass holds at most 2^22 pairs / rows), so a load costs one VALU instruction instead of five.  Full steps
@@ -2083,7 +2103,10 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     auto row_at = [&](u32 q) -> u64 { return *reinterpret_cast<const u64*>(mq_base + (size_t)((q << 6) | j8)); };
     // one block: cnt <= kBlockPairs pairs, q_at(i) = the query row of its i-th pair (i < cnt)
     auto count_block = [&](u32 cnt, auto q_at) {
-        u64 ones = 0, twos = 0, fours = 0, eights = 0, sixteens = 0, thirtytwos = 0;
+        u64 ones = 0, twos = 0, fours = 0;
+        u64 hi[NP - 3];  // eights, sixteens, ...
+#pragma unroll
+        for (int b = 0; b < NP - 3; ++b) hi[b] = 0;
         auto count8 = [&](const u64 (&x)[8]) {
             u64 twos_a, twos_b, fours_a, fours_b, eights_a;
             SKX_CSA(twos_a, ones, ones, x[0], x[1])
@@ -2093,11 +2116,13 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
             SKX_CSA(twos_b, ones, ones, x[6], x[7])
             SKX_CSA(fours_b, twos, twos, twos_a, twos_b)
             SKX_CSA(eights_a, fours, fours, fours_a, fours_b)
-            const u64 c8 = eights & eights_a;
-            eights ^= eights_a;
-            const u64 c16 = sixteens & c8;
-            sixteens ^= c8;
-            thirtytwos ^= c16;  // (<= 56 rows: no carry out of the sixth plane)
+            u64 c = eights_a;  // ripple into the higher planes (no carry out of the last one: rows per lane <= 2^NP - 1)
+#pragma unroll
+            for (int b = 0; b < NP - 3; ++b) {
+                const u64 t = hi[b] & c;
+                hi[b] ^= c;
+                c = t;
+            }
         };
         // the query indices of the next 64 pairs are requested before the current rows are counted (one memory round trip
         // per step instead of two in a row; requesting the rows ahead as well needs 82 VGPRs and lost: 417 -> 725 us)
@@ -2130,35 +2155,38 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
             count8(x);
         }
         // ---- merge the 8 sub-slots of every word (reduce-scatter over lane bits 5, 4, 3), planes get narrower
-        const u64 pl[6] = {ones, twos, fours, eights, sixteens, thirtytwos};
-        u32 x[10], y[10];
+        u64 pl[NP];
+        pl[0] = ones; pl[1] = twos; pl[2] = fours;
+#pragma unroll
+        for (int b = 0; b < NP - 3; ++b) pl[3 + b] = hi[b];
+        u32 x[12], y[12];
         // lanes l / l^32: lower lanes keep genomes 0..31 of the word, upper lanes 32..63
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
+        for (int b = 0; b < NP; ++b) {
             const u32x2_t r = __builtin_amdgcn_permlane32_swap((u32)pl[b], (u32)(pl[b] >> 32), false, false);
             x[b] = r.x; y[b] = r.y;  // lower lanes: (own low half, partner's low half); upper: (partner's high, own high)
         }
-        add_planes<6>(x, y);  // 7 planes x 32 bits
+        add_planes<NP>(x, y);  // NP + 1 planes x 32 bits
         // lanes l / l^16: 16 genomes each
 #pragma unroll
-        for (int b = 0; b < 7; ++b) {
+        for (int b = 0; b < NP + 1; ++b) {
             const u32x2_t r = __builtin_amdgcn_permlane16_swap(x[b] & 0xFFFFu, x[b] >> 16, false, false);
             x[b] = r.x; y[b] = r.y;
         }
-        add_planes<7>(x, y);  // 8 planes x 16 bits
+        add_planes<NP + 1>(x, y);  // NP + 2 planes x 16 bits
         // lanes l / l^8: 8 genomes each
         const bool up = (lane & 8u) != 0u;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const u32 lo = x[b] & 0xFFu, hi = x[b] >> 8;
-            const u32 send = up ? lo : hi;
-            x[b] = up ? hi : lo;
+        for (int b = 0; b < NP + 2; ++b) {
+            const u32 lo = x[b] & 0xFFu, hi8 = x[b] >> 8;
+            const u32 send = up ? lo : hi8;
+            x[b] = up ? hi8 : lo;
             y[b] = (u32)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xF, 0xF, false);  // row_ror:8 = lane ^ 8
         }
-        add_planes<8>(x, y);  // 9 planes x 8 bits: bit i of plane b = bit b of the count of genome sub*8 + i
+        add_planes<NP + 2>(x, y);  // NP + 3 planes x 8 bits: bit i of plane b = bit b of the count of genome sub*8 + i
         // counts out of the planes: the 8 x 8 bits of planes 0..7 are one 64-bit bit matrix (byte b = plane b, bit i = genome
         // i); its transpose has genome i's low 8 count bits in byte i (three masked-swap steps instead of 8 x 9 single-bit
-        // extractions), plane 8 adds bit 8
+        // extractions), the planes from 8 on add their bits one by one
         {
             u64 t = make_u64(x[0] | (x[1] << 8) | (x[2] << 16) | (x[3] << 24), x[4] | (x[5] << 8) | (x[6] << 16) | (x[7] << 24));
             u64 y2 = (t ^ (t >> 7)) & 0x00AA00AA00AA00AAull;
@@ -2167,11 +2195,17 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
             t ^= y2 ^ (y2 << 14);
             y2 = (t ^ (t >> 28)) & 0x00000000F0F0F0F0ull;
             t ^= y2 ^ (y2 << 28);
-            const u32 tl = (u32)t, th = (u32)(t >> 32), top = x[8];
+            const u32 tl = (u32)t, th = (u32)(t >> 32);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                acc[i] += ((tl >> (8 * i)) & 0xFFu) + (((top >> i) & 1u) << 8);
-                acc[i + 4] += ((th >> (8 * i)) & 0xFFu) + (((top >> (i + 4)) & 1u) << 8);
+                u32 a = (tl >> (8 * i)) & 0xFFu, b2 = (th >> (8 * i)) & 0xFFu;
+#pragma unroll
+                for (int b = 8; b < NP + 3; ++b) {
+                    a += ((x[b] >> i) & 1u) << b;
+                    b2 += ((x[b] >> (i + 4)) & 1u) << b;
+                }
+                acc[i] += a;
+                acc[i + 4] += b2;
             }
         }
     };
@@ -2216,7 +2250,7 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
         }
     }
     const u32 gw = grp * kRankWords + j;
-    if (on && gw < n_gw) {  // words past n_gw hold no genomes
+    if (!CHUNK && on && gw < n_gw) {  // words past n_gw hold no genomes
         u32* out = inc + (size_t)seg * n_pad + gw * 64u + sub * 8u;
         *reinterpret_cast<uint4*>(out) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
         *reinterpret_cast<uint4*>(out + 4) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
@@ -2230,7 +2264,10 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
         for (u32 h = 0; h < 2u; ++h) {
             const u32 t = threadIdx.x + 256u * h;
             const u32 v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-            if (grp * kRankWords * 64u + t < n_pad && v) atomicAdd(&qsum[(size_t)(seg4 >> 2) * n_pad + grp * kRankWords * 64u + t], v);
+            if (grp * kRankWords * 64u + t < n_pad && v) {
+                if (CHUNK) qsum[(size_t)seg4 * n_pad + grp * kRankWords * 64u + t] = v;  // (the workgroup IS the chunk)
+                else atomicAdd(&qsum[(size_t)(seg4 >> 2) * n_pad + grp * kRankWords * 64u + t], v);
+            }
         }
     }
 }
@@ -2244,13 +2281,6 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
 // ranking, so the leaders / bounds are per (chunk, species): lead_val[c * n_sp + sp], leader[(c * n_sp + sp) * k + j].
 // sp.g0[sp] = first (padded) genome index, sp.n[sp] = real genomes, sp.of_grp[grp] = species of a rank group.
 // (struct Species: skx_kernels.hpp)
-__device__ __forceinline__ bool chunk_group_live(const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
-                                                 u32 n_half, u32 c, u32 grp, const Species& sp) {
-    const u64 lv = lead_val[c * sp.n_sp + sp.of_grp[grp]];
-    const u64* gm = gmax + (size_t)(c + 1u) * n_half + 2u * grp;  // (n_half = 2 x rank groups: n_pad is a multiple of 512)
-    return gm[0] >= lv || gm[1] >= lv;
-}
-
 // Segment start values, relative to the table at the start of the pass (32 bits: a pass gains at most its pair
 // count), in three levels so no thread walks a long chain and nothing is read twice:
 //   seg_sum_kernel     : csum_raw[c][g] = sum of inc over the 16 segments of chunk c (atomic adds of its workgroups' sums)
@@ -2315,13 +2345,22 @@ __global__ __launch_bounds__(256) void seg_prefix_kernel(const u32* __restrict__
                                                          const u64* __restrict__ gmax, const u64* __restrict__ lead_val,
                                                          u32 n_half, Species sp, const u32* __restrict__ grp_any,
                                                          const u64* __restrict__ cum_in, unsigned char* __restrict__ live,
-                                                         const u64* __restrict__ lead_seg) {
+                                                         const u64* __restrict__ lead_seg, u32* __restrict__ live_ctr) {
     __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 g = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
-    if (g >= n_pad || !grp_any[blockIdx.x >> 1]) return;  // (a group without any bit starts every segment at the pass-start table)
+    if (g >= n_pad) return;
+    const bool grp_dead = !grp_any[blockIdx.x >> 1];
+    const bool chunk_live = !grp_dead && (!gmax || chunk_group_live(gmax, lead_val, n_half, c, blockIdx.x >> 1, sp));
+    // (a sample of every 16th (chunk, half group): which share of them can hold a candidate -- the host picks the counting
+    // scheme of later batches by it, launch_chunk_sum)
+    if (live_ctr && threadIdx.x == 0 && ((blockIdx.x | blockIdx.y) & 3u) == 0u) {
+        atomicAdd(&live_ctr[1], 1u);
+        if (chunk_live) atomicAdd(&live_ctr[0], 1u);
+    }
+    if (grp_dead) return;  // (a group without any bit starts every segment at the pass-start table)
     // a (chunk, rank group) without any possible candidate is never looked at by the ranking: skip its start values
     // (both halves of a live group are written: the ranking reads the whole group)
-    if (gmax && !chunk_group_live(gmax, lead_val, n_half, c, blockIdx.x >> 1, sp)) return;
+    if (!chunk_live) return;
     const u32 s0 = c * 16u, s1 = min(n_seg, s0 + 16u);
     u32 run = csum[(size_t)c * n_pad + g];
     if (!live) {
@@ -2425,11 +2464,15 @@ __global__ __launch_bounds__(64) void chunk_leader_merge_kernel(const u64* __res
                                                                 u32 top_k, u32* __restrict__ leader, u64* __restrict__ lead_val,
                                                                 const u32* __restrict__ inc, const u32* __restrict__ csum, u32 n_seg,
                                                                 u32 n_pad, const u64* __restrict__ cum_in, Species sp,
-                                                                const u32* __restrict__ grp_any, u64* __restrict__ lead_seg) {
+                                                                const u32* __restrict__ grp_any, u64* __restrict__ lead_seg,
+                                                                u32 mode /* 0: both halves, 1: leaders only, 2: lead_seg only */) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     __shared__ u32 s_leader[kTopkFastMax];
     const u32 c = blockIdx.x, lane = lane_id(), n_cand = kLeaderParts * top_k;
     u64 ps = 0; u32 pi = 0; bool first = true;
+    if (mode == 2u) {  // (the leaders were found by an earlier launch: the per-segment increments did not exist yet)
+        if (lane < top_k && lane < kTopkFastMax) s_leader[lane] = leader[c * top_k + lane];
+    } else
     for (u32 j = 0; j < top_k; ++j) {
         u64 bs = 0; u32 bi = 0xFFFFFFFFu;
         for (u32 x = lane; x < n_cand; x += 64u) {
@@ -2443,8 +2486,8 @@ __global__ __launch_bounds__(64) void chunk_leader_merge_kernel(const u64* __res
         if (lane == 0) { leader[c * top_k + j] = bi; if (j < kTopkFastMax) s_leader[j] = bi; }
         ps = bs; pi = bi; first = false;
     }
-    if (lane == 0) lead_val[c] = ps;  // value of the top_k-th ranked genome as the chunk begins (top_k <= n_genomes)
-    if (lead_seg == nullptr) return;
+    if (mode != 2u && lane == 0) lead_val[c] = ps;  // value of the top_k-th ranked genome as the chunk begins (top_k <= n_genomes)
+    if (lead_seg == nullptr || mode == 1u) return;
     // lead_seg[seg][species] (chunk_leader_merge_kernel): lane = segment of the chunk
     wave_sync();
     const u32 ch = c / sp.n_sp, spi = c % sp.n_sp;
@@ -2563,7 +2606,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__
 // few candidates, replay), [5] candidates of replaying waves, [6] pairs they replayed, [8..15] replaying waves by candidates
 // (1, 2-4, 5-16, 17-64, 65-512), [16 + c] replaying waves of chunk c (c < 112)
 __device__ unsigned long long g_rank_dbg[128];
-#define SKX_DBG_ADD(i, v) atomicAdd(&g_rank_dbg[i], (unsigned long long)(v))
+__device__ int g_rank_dbg_on;  // (off unless skx_debug_rank_counters switched it on: the atomics triple the kernel's time)
+#define SKX_DBG_ADD(i, v) do { if (g_rank_dbg_on) atomicAdd(&g_rank_dbg[i], (unsigned long long)(v)); } while (0)
 #else
 #define SKX_DBG_ADD(i, v)
 #endif
@@ -3353,31 +3397,54 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 }
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
                     u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any,
-                    u32* qsum /* [ceil(n_seg / 16)][n_pad]: the chunk sums, zero on entry */, const u64* rowany, const u32* n_q) {
+                    u32* qsum /* [ceil(n_seg / 16)][n_pad]: the chunk sums, zero on entry; NULL: not wanted */, const u64* rowany,
+                    const u32* n_q, const Species& sp, const u64* gmax /* != NULL: only (chunk, group)s that can hold a candidate */,
+                    const u64* lead_val) {
     const u32 n_gw = n_pad / 64, n_seg = cdiv(n_reads, seg_len);
     const u32 n_grp = cdiv(n_gw, kRankWords);
+    ChunkLive cl;
+    cl.gmax = gmax; cl.lead_val = lead_val; cl.n_half = n_pad / 256;
     // 8 XCDs x ceil(groups / 8) groups each x ceil(n_seg / 4) workgroups of 4 waves (= 4 consecutive segments)
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(8u * cdiv(n_grp, 8) * cdiv(n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
-                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any, qsum, rowany, n_q);
+    hipLaunchKernelGGL(seg_sum_kernel<false>, dim3(8u * cdiv(n_grp, 8) * cdiv(n_seg, 4)), dim3(256), 0, st, pair_q, poff, p_base,
+                       r_begin, n_reads, seg_len, mq, n_gw, n_pad, nq_rows, inc, grp_any, qsum, rowany, n_q, cl, sp);
 }
+// chunk sums only (csum_raw[chunk][g], zero on entry), one workgroup per (rank group, chunk of 16 segments)
+void launch_chunk_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
+                      const u64* mq, u32 n_pad, u32 nq_rows, const u32* grp_any, u32* csum_raw, const u64* rowany, const u32* n_q,
+                      const Species& sp) {
+    const u32 n_gw = n_pad / 64, quarter = 4u * kSegLen, n_quarters = cdiv(n_reads, quarter);
+    const u32 n_grp = cdiv(n_gw, kRankWords);
+    hipLaunchKernelGGL(seg_sum_kernel<true>, dim3(8u * cdiv(n_grp, 8) * cdiv(n_quarters, 4)), dim3(256), 0, st, pair_q, poff, p_base,
+                       r_begin, n_reads, quarter, mq, n_gw, n_pad, nq_rows, nullptr, grp_any, csum_raw, rowany, n_q, ChunkLive(), sp);
+}
+// part: 0 = the whole chain; 1 = what needs only the chunk sums (prefix over the chunks, the table, per-chunk leaders and
+// bounds); 2 = what needs the per-segment increments (per-segment bounds, start values, live flags)
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32* csum_raw /* same size */, u32 prune_top_k, u32* leader,
                        u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx, const u32* grp_any,
                        unsigned char* live /* [n_seg][n_pad / 64] or NULL: every start value is stored */,
-                       u64* lead_seg /* [n_seg][n_sp] scratch (with live) */) {
+                       u64* lead_seg /* [n_seg][n_sp] scratch (with live) */, int part, u32* live_ctr) {
     const u32 n_chunks = cdiv(n_seg, 16);
     dim3 grid(cdiv(n_pad, 256), n_chunks);
-    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(n_pad / 256), dim3(256), 0, st, csum_raw, csum, n_chunks, n_pad, cum_in, cum_out,
-                       prune_top_k ? gmax : nullptr, n_pad / 256);
-    if (prune_top_k) {
-        // who leads (per species) as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
-        hipLaunchKernelGGL(chunk_leader_part_kernel, dim3(n_chunks * sp.n_sp, kLeaderParts), dim3(256), 0, st, cum_in, csum, n_pad,
-                           sp, prune_top_k, part_sum, part_idx);
-        hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
-                           lead_val, inc, csum, n_seg, n_pad, cum_in, sp, grp_any, live ? lead_seg : nullptr);  // (+ seg_lead's work)
+    if (part != 2) {
+        hipLaunchKernelGGL(chunk_prefix_kernel, dim3(n_pad / 256), dim3(256), 0, st, csum_raw, csum, n_chunks, n_pad, cum_in, cum_out,
+                           prune_top_k ? gmax : nullptr, n_pad / 256);
+        if (prune_top_k) {
+            // who leads (per species) as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
+            hipLaunchKernelGGL(chunk_leader_part_kernel, dim3(n_chunks * sp.n_sp, kLeaderParts), dim3(256), 0, st, cum_in, csum, n_pad,
+                               sp, prune_top_k, part_sum, part_idx);
+            hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
+                               lead_val, inc, csum, n_seg, n_pad, cum_in, sp, grp_any, live ? lead_seg : nullptr,
+                               part == 1 ? 1u : 0u);  // (part 0: + seg_lead's work)
+        }
     }
+    if (part == 1) return;
+    if (part == 2 && prune_top_k && live)
+        hipLaunchKernelGGL(chunk_leader_merge_kernel, dim3(n_chunks * sp.n_sp), dim3(64), 0, st, part_sum, part_idx, prune_top_k, leader,
+                           lead_val, inc, csum, n_seg, n_pad, cum_in, sp, grp_any, lead_seg, 2u);
     hipLaunchKernelGGL(seg_prefix_kernel, grid, dim3(256), 0, st, inc, csum, n_seg, n_pad, rel, prune_top_k ? gmax : nullptr,
-                       lead_val, n_pad / 256, sp, grp_any, cum_in, prune_top_k ? live : nullptr, lead_seg);  // (live: the caller's choice, top-1 path only)
+                       lead_val, n_pad / 256, sp, grp_any, cum_in, prune_top_k ? live : nullptr, lead_seg,
+                       prune_top_k ? live_ctr : nullptr);  // (live: the caller's choice, top-1 path only)
 }
 // (the first level of launch_seg_prefix's three: needs only the increments, not the running table -- queued with seg_sum)
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
@@ -3444,6 +3511,8 @@ void launch_gather_table(hipStream_t st, const u64* cum, u64* out, u32 n_real, c
 #ifdef SKX_EXPERIMENTS
 namespace skx {
 void rank_debug_counters(unsigned long long* out, bool reset) {
+    const int on = 1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rank_dbg_on), &on, sizeof on);  // (counting starts with the first call)
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rank_dbg), sizeof(unsigned long long) * 128);
     if (reset) {
         unsigned long long z[128] = {};

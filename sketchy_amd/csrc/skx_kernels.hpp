@@ -151,17 +151,26 @@ void launch_filter_apply(hipStream_t st, u64* sk, u32 sk_stride, u32* cnt, u32 n
 
 // ranking
 void launch_seg_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
-                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any, u32* csum_raw /* [ceil(n_seg / 16)][n_pad] chunk sums, zero on entry */,
-                    const u64* rowany /* of launch_transpose_bits, or NULL */, const u32* n_q);
+                    u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, u32* inc, const u32* grp_any,
+                    u32* csum_raw /* [ceil(n_seg / 16)][n_pad] chunk sums, zero on entry; NULL: not wanted */,
+                    const u64* rowany /* of launch_transpose_bits, or NULL */, const u32* n_q, const Species& sp,
+                    const u64* gmax = nullptr /* != NULL: only the (chunk, rank group)s that can hold a candidate (launch_seg_prefix part 1) */,
+                    const u64* lead_val = nullptr);
+// the chunk sums alone (csum_raw zero on entry): a workgroup per (rank group, chunk), one extraction per quarter chunk
+void launch_chunk_sum(hipStream_t st, const u32* pair_q, const u32* poff, u32 p_base, u32 r_begin, u32 n_reads,
+                      const u64* mq, u32 n_pad, u32 nq_rows, const u32* grp_any, u32* csum_raw, const u64* rowany, const u32* n_q,
+                      const Species& sp);
 // prune_top_k > 0 (1..rank_topk_fast_max()): also find the first prune_top_k genomes as each chunk of 16 segments begins
 // (leader [n_chunks * k], lead_val [n_chunks]) and every half rank group's best value per chunk boundary (gmax
 // [(n_chunks + 1) * n_pad / 256]); start values are then only written for (chunk, group)s that can hold a candidate.
+// part: 0 = everything; 1 = what needs only the chunk sums; 2 = what needs the per-segment increments (after part 1)
 void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, const Species& sp, const u64* cum_in, u64* cum_out,
                        u32* rel /* [n_seg][n_pad]: segment start values minus cum_in */, u32* csum, u32* csum_raw, u32 prune_top_k,
                        u32* leader /* [n_chunks * n_sp * k] */, u64* lead_val /* [n_chunks * n_sp] */, u64* gmax,
                        u64* part_sum, u32* part_idx /* [n_chunks * n_sp * rank_leader_parts() * k] scratch */,
                        const u32* grp_any, unsigned char* live /* [n_seg][n_pad / 64], pruned rankings only; else NULL */,
-                       u64* lead_seg /* [n_seg][n_sp] scratch */);
+                       u64* lead_seg /* [n_seg][n_sp] scratch */, int part = 0,
+                       u32* live_ctr = nullptr /* [2], pruned rankings: += (chunk, half group)s that can hold a candidate / tested (a sample) */);
 u32 rank_leader_parts();
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,

@@ -277,11 +277,13 @@ def test_more_distinct_query_hashes_than_matrix_rows(gpu):
     np.testing.assert_array_equal(got["topk_idx"], full["topk_idx"])
 
 
-@pytest.mark.parametrize("env", [{"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "2"}, {"SKX_PIPELINE": "1"}, {"SKX_PASS_READS": "128"}])
+@pytest.mark.parametrize("env", [{"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "2"}, {"SKX_PIPELINE": "1"}, {"SKX_PASS_READS": "128"},
+                                 {"SKX_TWO_LEVEL": "1"}, {"SKX_TWO_LEVEL": "0"}, {"SKX_COALESCE": "3"}])
 def test_enqueue_under_other_placements(gpu, env):
-    """the same stream with the pair gather on the scan stream (never speculative), with fewer pipeline streams, and with
-    every batch cut into passes of 128 reads (each enqueue undoes the younger batch's speculation) -- separate
-    processes: the knobs are read once"""
+    """the same stream with the pair gather on the scan stream (never speculative), with fewer pipeline streams, with
+    every batch cut into passes of 128 reads (each enqueue undoes the younger batch's speculation), with the ranking's counts
+    always / never in two levels (chunk sums first, per-segment increments only where a candidate can be), and with groups
+    of three batches per pass -- separate processes: the knobs are read once"""
     here = os.path.dirname(os.path.abspath(__file__))
     from helpers import exp_env
     e = exp_env(**env)

@@ -43,4 +43,29 @@ for n, s, n_reads, seed in ((300, 500, 400, 1), (513, 96, 50, 2), (40, 3000, 64,
     assert np.array_equal(S1.table(), exp["cum"]), "top-1 table"
     for d in (d_b, d_o, d_i, d_s):
         d.free()
+# several chunks of 1024 reads, top-1 and top-2 (the pruned rankings: chunk-level bounds, counts in one or two levels), in batches
+# that share passes and through single pushes
+ref, bases, offsets = workload(1300, 300, 5000, read_len=300, rng_seed=9)
+for top in (1, 2):
+    exp = orc.stream(16, 0, 300, ref["ref"], np.full(1300, 300, np.uint32), bases, offsets, top_k=top)
+    R = api.ReferenceSketch(ref["ref"])
+    S = api.SumOfSharedHashes(R, top=top, max_batch_reads=2200, max_batch_bases=len(bases))
+    d_b = api.DeviceBuffer.from_numpy(bases)
+    keep, rows = [d_b], []
+    for a, b in ((0, 2100), (2100, 2200), (2200, 4300), (4300, 5000)):
+        d_o = api.DeviceBuffer.from_numpy(np.ascontiguousarray(offsets[a:b + 1]))
+        d_i, d_s = api.DeviceBuffer((b - a) * top * 4), api.DeviceBuffer((b - a) * top * 8)
+        keep += [d_o, d_i, d_s]
+        rows.append((b - a, d_i, d_s))
+        S.enqueue_device(d_b.ptr, d_o.ptr, b - a, int(offsets[b] - offsets[a]), d_i.ptr, d_s.ptr)
+    S.sync()
+    idx = np.concatenate([d_i.to_numpy(np.uint32, (m, top)) for m, d_i, _ in rows])
+    val = np.concatenate([d_s.to_numpy(np.uint64, (m, top)) for m, _, d_s in rows])
+    assert np.array_equal(idx, exp["topk_idx"]) and np.array_equal(val, exp["topk_sum"]), "rows of the chunked stream, top %d" % top
+    assert np.array_equal(S.table(), exp["cum"]), "table of the chunked stream"
+    S.reset()
+    got = S.push(bases, offsets[:2001])
+    assert np.array_equal(got["topk_idx"], exp["topk_idx"][:2000]) and np.array_equal(got["topk_sum"], exp["topk_sum"][:2000]), "push"
+    for d in keep:
+        d.free()
 print("variant ok", os.environ.get("SKX_SCAN_SPLIT"), os.environ.get("SKX_SCAN_BIG"))
