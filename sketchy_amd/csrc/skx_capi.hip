@@ -1555,7 +1555,14 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         st->sk_reader_pending[pb.side] = false;
     }
     // (three-stream pipeline: will the previous pass's scan be in flight?  then this sketch shares the CUs with it)
-    int leave_room = (st->depth >= 3 && st->n_pend) ? 2 : 0;
+    // (2: the larger LDS pad -- fewer sketch waves per CU, room for the scan AND a heavy ranking chain beside it; 1: the smaller
+    // one, once the ranking has become light: far from the start of a sample most (chunk, rank group)s are dead -- the share the
+    // ranking samples for its own counting scheme -- and with a scan only every few batches the sketch is what should fill the
+    // chip.  Measured at C2, eight batches per scan: 19 KB everywhere 120 M reads/s from a fresh table / 138 M steady; 11 KB
+    // everywhere 118 / 150 M.)
+    static const int room_env = skx::knob("SKX_ROOM_ADAPT") ? atoi(skx::knob("SKX_ROOM_ADAPT")) : 1;  // experiment knob
+    const bool ranking_light = room_env && st->h_nq[3] != 0 && (u64)st->h_nq[2] * 3 < st->h_nq[3];
+    int leave_room = (st->depth >= 3 && st->n_pend) ? (ranking_light ? 1 : 2) : 0;
     if (st->depth >= 3 && !leave_room)
         for (int i = 0; i < 2; ++i)
             if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
