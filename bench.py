@@ -340,12 +340,12 @@ def main():
                                "algorithmic_bytes_per_launch": pass_bytes,
                                "note": "achieved = algorithmic bytes (8*s*N) / HIP-event time of the kernel on its own stream in the timed "
                                        "region, where the sketch of the next batch and the ranking of the previous one run beside it "
-                                       "(three-stream pipeline); `isolated` = the same kernel alone.  launches_per_step = 0.5: two enqueued "
-                                       "batches share one launch (option stream_coalesce)",
+                                       "(multi-stream pipeline); `isolated` = the same kernel alone.  launches_per_step < 1: enqueued "
+                                       "batches share launches (option stream_coalesce)",
                                "whole_step": {"achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                                               "note": "algorithmic bytes x launches_per_step over the whole step time (sketch, dictionary, ranking "
                                                       "included): what the step needs from HBM for the reference, not a quality figure -- it "
-                                                      "halves when two batches share a scan while the reads/s go up"}}
+                                                      "falls as batches share scans while the reads/s go up"}}
         vi = _valu_insts(args.config, B)
         if vi:
             floor_ms = vi["wave_insts_per_step"] * VALU_CYCLES_PER_WAVE_INST / (N_SIMDS * CLOCK_GHZ * 1e9) * 1e3

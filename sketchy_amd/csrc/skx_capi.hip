@@ -1283,7 +1283,8 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     static const int two_level_env = skx::knob("SKX_TWO_LEVEL") ? atoi(skx::knob("SKX_TWO_LEVEL")) : -1;  // experiment knob: 0 / 1 force
     const volatile u32* h_live = st->h_nq + 2;
     const u32 live_now = h_live[0], tested_now = h_live[1];
-    const bool mostly_dead = tested_now != 0 && (u64)live_now * 3 < tested_now;
+    static const u32 live_pct_env = skx::knob("SKX_LIVE_PCT") ? (u32)atoi(skx::knob("SKX_LIVE_PCT")) : 33u;  // experiment knob
+    const bool mostly_dead = tested_now != 0 && (u64)live_now * 100 < (u64)tested_now * live_pct_env;
     const bool two_level = prune_k != 0 && (two_level_env >= 0 ? two_level_env != 0 : mostly_dead);
     const u64* rowany_b = P > 0 ? st->d_rowany[b] : nullptr;
     if (update_table) {
@@ -1561,7 +1562,8 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     // chip.  Measured at C2, eight batches per scan: 19 KB everywhere 120 M reads/s from a fresh table / 138 M steady; 11 KB
     // everywhere 118 / 150 M.)
     static const int room_env = skx::knob("SKX_ROOM_ADAPT") ? atoi(skx::knob("SKX_ROOM_ADAPT")) : 1;  // experiment knob
-    const bool ranking_light = room_env && st->h_nq[3] != 0 && (u64)st->h_nq[2] * 3 < st->h_nq[3];
+    static const u32 room_pct_env = skx::knob("SKX_ROOM_PCT") ? (u32)atoi(skx::knob("SKX_ROOM_PCT")) : 33u;  // experiment knob
+    const bool ranking_light = room_env && st->h_nq[3] != 0 && (u64)st->h_nq[2] * 100 < (u64)st->h_nq[3] * room_pct_env;
     int leave_room = (st->depth >= 3 && st->n_pend) ? (ranking_light ? 1 : 2) : 0;
     if (st->depth >= 3 && !leave_room)
         for (int i = 0; i < 2; ++i)
