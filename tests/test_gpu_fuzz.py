@@ -21,7 +21,15 @@ def _walk(seed):
     col_len = np.full(n, s, np.uint32)
     packed, poff = api.pack_reads(bases, offsets)
     R = api.ReferenceSketch(ref["ref"])
-    S = api.SumOfSharedHashes(R, top=top, max_batch_reads=400, max_batch_bases=400 * 700)
+    # (how many enqueued batches may share a pass, and -- now and then -- bit matrices so small that groups have to be un-shared)
+    before = api.get_option("stream_coalesce")
+    try:
+        api.set_option("stream_coalesce", int(rng.choice([1, 2, 3, 5, 8, 8])))
+        api.set_option("stream_query_rows", int(rng.choice([0, 0, 0, 64])))
+        S = api.SumOfSharedHashes(R, top=top, max_batch_reads=400, max_batch_bases=400 * 700)
+    finally:
+        api.set_option("stream_coalesce", before)
+        api.set_option("stream_query_rows", 0)
     d_ascii, d_packed = api.DeviceBuffer.from_numpy(bases), api.DeviceBuffer.from_numpy(packed)
     h_ascii, h_packed = api.HostBuffer(len(bases)), api.HostBuffer(len(packed))
     h_ascii.view(np.uint8)[:] = bases
