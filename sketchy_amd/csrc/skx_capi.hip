@@ -1154,6 +1154,9 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // pairs of a single batch but hardly more distinct hashes, and was sent to the dense-dictionary scan kernel)
     const bool nq_known = inserted && q_rows != 0xFFFFFFFFu;
     if (nq_known) nq_est = std::max<u64>(1, q_rows);
+    // (decided once per pass, before the dictionary stage picks between windows + word -> bands and windows alone: the lean scan
+    // kernel's results as slabs or straight into M -- skx::scan_lean_into_m)
+    const bool into_m = st->d_hbuf && skx::scan_lean_into_m((nq_est / 64 + 1) * (u64)n_pad * 8);
 
     // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already).  Set b was last used two
     // passes ago: by that pass's dictionary / scan / transpose on THIS stream (Q, windows, hash set: ordered by the stream)
@@ -1176,7 +1179,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                                     st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len);
         skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
                               st->d_dict_ctr[b], d_q, d_nq);
-        if (st->d_hbuf) {  // (windows + word -> bands in one launch; also hands |Q| to the host)
+        if (st->d_hbuf && !into_m) {  // (windows + word -> bands in one launch; also hands |Q| to the host)
             skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b], ref->d_lo, ref->d_hi, d_q, &st->h_nq[b]);
         } else {
             skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);
@@ -1239,7 +1242,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             // sparse dictionaries: the lean kernel with its single-owner slabs; dense ones: scan_kernel's variants into M
             // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
             skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, d_q, d_win, st->d_m,
-                             split ? st->d_mint : nullptr, n_pad, big, lean ? st->d_hbuf : nullptr, d_mdirty);
+                             split ? st->d_mint : nullptr, n_pad, big, lean ? st->d_hbuf : nullptr, d_mdirty, into_m);
         }
         {
             Span sp(st, 1, hs);
@@ -1250,7 +1253,8 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         {
             Span sp(st, 3, hs);
             skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq, d_grp_any,
-                                       lean ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, nq_est, st->d_rowany[b]);
+                                       (lean && !into_m) ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty,
+                                       nq_est, st->d_rowany[b]);
         }
     }
     if (P == 0) SKXCHK(wait_back());

@@ -1738,7 +1738,18 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
         }
         __syncthreads();  // slice and directory are rebuilt by the next sub-window
     }
-    if (!multi && ABLATE != 1) {
+    if (!multi && ABLATE != 1 && (NT & 4)) {
+        // results straight into M[word][genome] by atomicOr, zero words skipped (NT & 4).  Measured (tools/ubench/stream_rates.hip,
+        // the kernel's geometry as a pure stream): ANY plain store stream next to the matrix reads costs a fifth of the read
+        // rate (slabs: 0.63-0.69 of peak against 0.81 for the reads alone, whatever the slabs' size), while a compact M --
+        // 52 MB at C2, every word hit again by the next two or three bands of its tile -- stays on chip: 0.81-0.83 with
+        // non-temporal matrix loads.  The transpose then reads M only (and zeroes it again).
+        if (c == 0) *m_dirty = 1u;
+        for (u32 k = 0; k < n_w; ++k) {
+            const u64 v = acc[k][c];
+            if (v) atomicOr(&m_bits[(size_t)(w0 + k) * n_pad + g], v);
+        }
+    } else if (!multi && ABLATE != 1) {
         // this block's slab: [kLeanWords][256] words, the first n_w of them are read by the transpose
         u64* out = hbuf + (size_t)bt * kLeanWords * kTileGenomes + c;
         for (u32 k = 0; k < n_w; ++k) {
@@ -3322,6 +3333,17 @@ bool scan_lean_applies(u32 n_bands, bool split, bool big_table) {
     return lean_env && !split && !big_table && n_bands <= kWordBandsMax;
 }
 u32 scan_lean_words() { return kLeanWords; }
+// Should the lean kernel put its results straight into M (atomicOr, no slabs; the transpose then reads M only)?  Yes while the
+// pass's M stays on chip: `m_bytes` = (distinct query hashes / 64) words x padded genomes x 8.  Measured, C2 (52-100 MB), scan
+// alone: slabs 0.63-0.67 of the 8 TB/s peak, M with non-temporal matrix loads 0.71-0.75 (in the pipeline 0.63 -> 0.69); C4
+// (378 MB: beyond the 256 MB infinity cache): 0.57 / 0.59, nothing in the pipeline -- slabs stay there.
+bool scan_lean_into_m(u64 m_bytes) {
+#ifdef SKX_EXPERIMENTS
+    static const int nt = env_int("SKX_SCAN_NT", -1);  // experiment knob: bit 2 forces it, 0..3 forbid it
+    if (nt >= 0) return (nt & 4) != 0;
+#endif
+    return m_bytes <= (192ull << 20);
+}
 void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb, const u64* lo, const u64* hi,
                        const u64* q, u32* h_nq) {
     hipLaunchKernelGGL(word_bands_kernel, dim3(n_tiles), dim3(256), 0, st, win, n_tiles, n_bands, n_q, wb, lo, hi, q, h_nq);
@@ -3329,17 +3351,20 @@ void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const
 
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table,
-                 u64* hbuf /* slabs of the lean kernel, or NULL: legacy kernels */, u32* m_dirty) {
+                 u64* hbuf /* slabs of the lean kernel, or NULL: legacy kernels */, u32* m_dirty,
+                 bool into_m /* lean kernel: results by atomicOr into m_bits instead of slabs (scan_lean_into_m) */) {
     dim3 grid(n_tiles * n_bands), block(256);
 #ifdef SKX_EXPERIMENTS
     // profiling aids (results invalid unless 0): the ablated kernels are not even compiled into the product library
     static const int ablate = env_int("SKX_SCAN_ABLATE", 0);
-    static const int nt = env_int("SKX_SCAN_NT", 0);  // 1 = non-temporal slab stores, 2 = matrix loads, 3 = both
+    static const int nt_env = env_int("SKX_SCAN_NT", -1);  // 1 = non-temporal slab stores, 2 = matrix loads, 3 = both, +4 = results into M
+    const int nt = nt_env > 0 ? nt_env : 0;
     static const u32 prio = (u32)env_int("SKX_SCAN_PRIO", 1);
     if (hbuf && (ablate || nt)) {
 #define SKX_SCAN_L(A, N) hipLaunchKernelGGL((scan_lean_kernel<A, N>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio)
         if (ablate == 1) SKX_SCAN_L(1, 0); else if (ablate == 2) SKX_SCAN_L(2, 0); else if (ablate == 3) SKX_SCAN_L(3, 0);
-        else if (nt == 1) SKX_SCAN_L(0, 1); else if (nt == 2) SKX_SCAN_L(0, 2); else SKX_SCAN_L(0, 3);
+        else if (nt == 1) SKX_SCAN_L(0, 1); else if (nt == 2) SKX_SCAN_L(0, 2); else if (nt == 3) SKX_SCAN_L(0, 3);
+        else if (nt == 4) SKX_SCAN_L(0, 4); else if (nt == 5) SKX_SCAN_L(0, 5); else if (nt == 6) SKX_SCAN_L(0, 6); else SKX_SCAN_L(0, 7);
 #undef SKX_SCAN_L
         return;
     }
@@ -3355,7 +3380,8 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 #endif
     // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe
     if (hbuf) {
-        hipLaunchKernelGGL((scan_lean_kernel<0, 0>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+        if (into_m) hipLaunchKernelGGL((scan_lean_kernel<0, 6>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+        else hipLaunchKernelGGL((scan_lean_kernel<0, 0>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
         return;
     }
     // dense passes: 2040-entry slices, interior words by plain stores when the caller has the second array; very dense:

@@ -119,8 +119,9 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
 // dense slices go through atomicOr into m_bits and raise *m_dirty.  hbuf == NULL: scan_kernel variants into m_bits / m_int.
 bool scan_lean_applies(u32 n_bands, bool split, bool big_table);
 u32 scan_lean_words();
+bool scan_lean_into_m(u64 m_bytes);
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
-                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table, u64* hbuf, u32* m_dirty);
+                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table, u64* hbuf, u32* m_dirty, bool into_m = false);
 // wb[w * n_tiles + t] = (first | last << 16) band of tile t whose slice can reach query word w (first > last: none)
 // lo != NULL: also computes the windows (launch_window's work) first: one launch instead of two in front of the scan
 void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb, const u64* lo = nullptr,

@@ -278,7 +278,7 @@ def test_more_distinct_query_hashes_than_matrix_rows(gpu):
 
 
 @pytest.mark.parametrize("env", [{"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "2"}, {"SKX_PIPELINE": "1"}, {"SKX_PASS_READS": "128"},
-                                 {"SKX_TWO_LEVEL": "1"}, {"SKX_TWO_LEVEL": "0"}, {"SKX_COALESCE": "3"}])
+                                 {"SKX_TWO_LEVEL": "1"}, {"SKX_TWO_LEVEL": "0"}, {"SKX_COALESCE": "3"}, {"SKX_SCAN_NT": "0"}])
 def test_enqueue_under_other_placements(gpu, env):
     """the same stream with the pair gather on the scan stream (never speculative), with fewer pipeline streams, with
     every batch cut into passes of 128 reads (each enqueue undoes the younger batch's speculation), with the ranking's counts
