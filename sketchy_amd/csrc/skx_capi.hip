@@ -664,7 +664,7 @@ struct skx_stream {
         u64 n_bases = 0, ticket = 0;
         u32* out_idx = nullptr;
         u64* out_sum = nullptr;
-        u32* d_rows_idx = nullptr;  // the slot's own device rows (two batches may share a pass: each needs its rows until they are copied out)
+        u32* d_rows_idx = nullptr;  // the slot's own device rows (batches may share a pass: each needs its rows until they are copied out)
         u64* d_rows_sum = nullptr;
         uint8_t* d_bases = nullptr;
         u64 *d_offsets = nullptr, *h_offsets = nullptr;
@@ -1104,11 +1104,11 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 // case: the whole batch is one pass and process_batch queued launch_dict_insert right behind the sketcher)
 // q_rows: an upper bound of the pass's distinct query hashes (<= qcap): P itself, or -- when the host knows it from the
 // speculative gather -- |Q|
-// A pass normally ranks ONE run of reads; two batches enqueued back to back share a pass (one dictionary, one scan of the
-// reference, one transpose) and are ranked one after the other from it: `subs` lists them -- their pairs sit one behind the
+// A pass normally ranks ONE run of reads; batches enqueued back to back (up to stream_coalesce of them) share a pass (one
+// dictionary, one scan of the reference, one transpose) and are ranked one after the other from it: `subs` lists them -- their pairs sit one behind the
 // other in the pass's pair lists (p_off), each with its own pair offsets (d_poff, relative to its own first pair), reads and
-// output rows.  The scan is the only cost of a step that does not grow with the reads: two batches per scan is what a batch
-// of twice the size would give, without asking the caller for it.
+// output rows.  The scan is the only cost of a step that does not grow with the reads: n batches per scan is what a batch
+// of n times the size would give, without asking the caller for it.
 struct SubPass {
     u32 ra = 0, rb = 0;           // reads [ra, rb) of the batch
     u32 p_off = 0, P = 0;         // its pairs: [p_off, p_off + P) of the pass's pair lists
