@@ -338,6 +338,11 @@ def main():
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": "scan_lean_kernel", "avg_launch_ms": scan_ms, "launches_per_step": launches_per_step,
                                "algorithmic_bytes_per_launch": pass_bytes,
+                               "pattern_ceiling": {"reads_alone": 0.81, "reads_nontemporal": 0.92, "with_result_slabs": 0.63,
+                                                   "with_compact_m_atomics_nt": 0.81, "unit": "fraction of peak",
+                                                   "source": "profiles/r03f_stream_rates.txt (tools/ubench/stream_rates.hip: this kernel's "
+                                                             "geometry as a pure stream over 3.2 GB, measured on an MI355X; not measured in "
+                                                             "this run)"},
                                "note": "achieved = algorithmic bytes (8*s*N) / HIP-event time of the kernel on its own stream in the timed "
                                        "region, where the sketch of the next batch and the ranking of the previous one run beside it "
                                        "(multi-stream pipeline); `isolated` = the same kernel alone.  launches_per_step < 1: enqueued "
