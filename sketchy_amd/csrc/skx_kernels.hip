@@ -26,7 +26,8 @@
 #include "skx_kernels.hpp"
 
 #ifndef SKX_FEW_CANDS
-#define SKX_FEW_CANDS 1  /* measured at C2: 1 -> 77.0 M reads/s, 6 -> 76.2 M, 16 -> 76.8 M (cold batch: 49.1 / 50.1 / 48.5 M) */
+#define SKX_FEW_CANDS 8  /* up to eight candidates (sixteen, with twice the LDS: the same) take the count path (rows fetched once, counts in LDS); round 2's form -- one
+                            gather loop per candidate -- gained nothing beyond one: 1 -> 77.0 M reads/s, 6 -> 76.2 M, 16 -> 76.8 M */
 #endif
 #ifndef SKX_SCAN_ROWS
 #define SKX_SCAN_ROWS 8
@@ -2773,12 +2774,11 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
 #endif
     if (single) {
         const u32 pe = lane < rz - ra ? poff[r_begin + ra + lane + 1u] - p_base - pa : 0u;  // pairs of reads <= this lane's
+        if (n_cands == 1u) {  // one candidate: one row WORD per pair is all that is needed
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            u64 bal = cbal[j];
-            while (bal) {  // (wave-uniform)
-                const u32 lc = (u32)__builtin_ctzll(bal);
-                bal &= bal - 1ull;
+            for (int j = 0; j < NW; ++j) {
+                if (cbal[j] == 0ull) continue;
+                const u32 lc = (u32)__builtin_ctzll(cbal[j]);
                 const u32 v0 = (u32)__builtin_amdgcn_readlane((int)val[j], (int)lc);
                 u32 cnt = 0;
                 for (u32 p0 = pa; p0 < pz; p0 += 64u) {
@@ -2791,6 +2791,48 @@ __global__ __launch_bounds__(256) void rank_seg_top1_kernel(const u32* __restric
                     cnt += (u32)__popcll(hm & lm);
                 }
                 res_key = max(res_key, ((v0 + cnt) << SH) | ((u32)(NW - 1 - j) << 6) | (63u - lc));
+            }
+        } else {
+            // a handful (first batches of a sample: instrumented, half of the replaying waves held 2-8 candidates): every pair's
+            // 64-byte row is fetched ONCE (as the replay does), each candidate takes one ballot per 64 pairs out of it, and the
+            // per-read counts of the candidates sit in the wave's LDS (slot x lane, private to the lane: no synchronisation)
+            static_assert(kFewCands <= 8u && kSparseQueue >= 256u, "eight count slots of 64 lanes in the wave's two queue arrays");
+            u32* const cnt_lo = sq_q[threadIdx.x >> 6] + lane;  // slots 0..3 at [slot * 64]
+            u32* const cnt_hi = sq_r[threadIdx.x >> 6] + lane;  // slots 4..7
+#pragma unroll
+            for (u32 sl = 0; sl < 4u; ++sl) { cnt_lo[sl * 64u] = 0; cnt_hi[sl * 64u] = 0; }
+            for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+                const u32 p = p0 + lane;
+                const bool v = p < pz;
+                const MaskVec rowv = gather_vec(mq_g, v ? pair_q[p] : 0u, v);
+                const u32 off = p0 - pa, nlow = pe > off ? min(64u, pe - off) : 0u;
+                const u64 lm = nlow >= 64u ? ~0ull : ((1ull << nlow) - 1ull);
+                u32 slot = 0;  // (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    u64 bal = cbal[j];
+                    while (bal) {
+                        const u32 lc = (u32)__builtin_ctzll(bal);
+                        bal &= bal - 1ull;
+                        const u64 hm = __ballot((rowv.w[j] >> lc) & 1ull);  // (rows past the end are zero)
+                        u32* const c = (slot < 4u ? cnt_lo : cnt_hi) + (slot & 3u) * 64u;
+                        *c += (u32)__popcll(hm & lm);
+                        ++slot;
+                    }
+                }
+            }
+            u32 slot = 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                u64 bal = cbal[j];
+                while (bal) {
+                    const u32 lc = (u32)__builtin_ctzll(bal);
+                    bal &= bal - 1ull;
+                    const u32 v0 = (u32)__builtin_amdgcn_readlane((int)val[j], (int)lc);
+                    const u32 cnt = ((slot < 4u ? cnt_lo : cnt_hi) + (slot & 3u) * 64u)[0];
+                    res_key = max(res_key, ((v0 + cnt) << SH) | ((u32)(NW - 1 - j) << 6) | (63u - lc));
+                    ++slot;
+                }
             }
         }
     }
