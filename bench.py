@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--top", type=int, default=1, help="rows ranked after every read (sketchy default 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--profile-all", action="store_true", help="experiment: HIP events around EVERY stage in the timed region (with the "
+                    "experiments build and SKX_SPAN_DUMP=1: the stages' device timeline on stderr)")
     ap.add_argument("--coalesce", type=int, default=0, help="set the library option stream_coalesce (1 .. 8) before the stream is created; 0 = leave the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip value_cold / value_steady_state / stage breakdown (profiling runs)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the value_batch_x2 leg (batches of twice --batch reads)")
@@ -150,6 +152,7 @@ def main():
     ap.add_argument("--lineages", type=int, default=0, help="experiment: number of lineages of the synthetic clone tree")
     ap.add_argument("--lognormal", type=float, default=None,
                     help="read lengths log-normal around the config's length with this sigma, 200..50000 (default: the config's)")
+    ap.add_argument("--read-len", type=int, default=0, help="experiment: reads of this length instead of the config's (instruction-count fits)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing only: every rank uses device 0 (exercises the multi-rank control flow on a 1-GPU box)")
     ap.add_argument("--allow-host-allreduce", action="store_true",
@@ -179,6 +182,8 @@ def main():
     species, s, read_len, sigma, desc = CONFIGS[args.config]
     if args.lognormal is not None:
         sigma = args.lognormal
+    if args.read_len:
+        read_len = args.read_len
     B, K, W = args.batch, args.steps, args.warmup
     k, hash_seed, top = 16, 0, args.top
     n_sp = len(species)
@@ -230,7 +235,7 @@ def main():
     S.reset()
     S.profile()  # clear counters
     if not args.no_profile:
-        S.set_profiling(2)  # the timed region records HIP events around the roofline kernel only (every stage: -2 %)
+        S.set_profiling(1 if args.profile_all else 2)  # the timed region records HIP events around the roofline kernel only (every stage: -2 %)
 
     # ---- timed region: exactly K steps + the final table all-reduce, from a fresh table; repeated --reps times (a single
     # 26 ms shot was the whole headline before) and reported as the median, every repetition listed

@@ -85,8 +85,14 @@ int skx_device_info(int device, char *name, size_t name_cap, int *compute_units,
  *                     the cost of up to n - 1 more batches of latency and n + 1 copies of the per-batch sketch rows (25 MB
  *                     each at C2).  A group whose pairs or distinct hashes turn out too many for one pass is processed
  *                     batch by batch, and the stream forms smaller groups from then on.
+ *   "comm_timeout_ms" 0 (default: no watchdog) .. 86 400 000: skx_comm_create (ncclCommInitRank) and skx_stream_allreduce
+ *                     (ncclAllReduce + its stream synchronisation) block for ever when a peer never arrives.  With a
+ *                     timeout set, a call that has not returned in time prints which rank was stuck in what to stderr and
+ *                     ends the PROCESS with exit code SKX_COMM_TIMEOUT_EXIT -- a hung collective cannot be cancelled, and a
+ *                     rank that exits lets the launcher tear the job down.  Consulted at every call (not at creation).
  * Unknown names fail with SKX_ERR_INVALID.
  */
+#define SKX_COMM_TIMEOUT_EXIT 86
 int skx_set_option(const char *name, uint64_t value);
 int skx_get_option(const char *name, uint64_t *value);
 

@@ -10,14 +10,19 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sketchy_hip.h"
@@ -136,7 +141,22 @@ static HostTimes g_ht;
 static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define SKX_T0() const double t0_ = now_us()
 #define SKX_ACC(field) g_ht.field += now_us() - t0_
+// SKX_HOST_TRACE=1: every marked point of the queueing thread with its time, printed when the stream is synchronised (which
+// call of the host blocks, and for how long: the device timeline only shows that something was queued late)
+struct HostMark { const char* what; int i; double t; };
+static std::vector<HostMark> g_marks;
+static const bool g_trace_on = skx::knob("SKX_HOST_TRACE") != nullptr;
+#define SKX_MARK(what, i) do { if (g_trace_on) g_marks.push_back(HostMark{what, (int)(i), now_us()}); } while (0)
+static void dump_marks() {
+    if (!g_trace_on || g_marks.empty()) return;
+    const double t0 = g_marks.front().t;
+    double prev = t0;
+    for (const HostMark& m : g_marks) { fprintf(stderr, "[skx host] %9.1f (+%7.1f) %s %d\n", m.t - t0, m.t - prev, m.what, m.i); prev = m.t; }
+    g_marks.clear();
+}
 #else
+#define SKX_MARK(what, i) do {} while (0)
+static void dump_marks() {}
 #define SKX_T0() do {} while (0)
 #define SKX_ACC(field) do {} while (0)
 #endif
@@ -146,6 +166,7 @@ static u32 g_kmer_prefilter = 0;  // k-mer prefilter of k = 16 references: 0 off
 static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
 static u32 g_stream_query_rows = 0;       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
 static u32 g_stream_coalesce = 8;         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 .. 8)
+static u64 g_comm_timeout_ms = 0;         // watchdog of skx_comm_create / skx_stream_allreduce: 0 = none (block for ever, as RCCL does)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
     if (!name) return fail(SKX_ERR_INVALID, "NULL option name");
@@ -169,6 +190,11 @@ SKX_API int skx_set_option(const char* name, uint64_t value) {
         g_filter_bits_per_hash = (u32)value;
         return SKX_OK;
     }
+    if (!strcmp(name, "comm_timeout_ms")) {
+        if (value > 86400000ull) return fail(SKX_ERR_INVALID, "comm_timeout_ms must be 0 (no watchdog) .. 86400000");
+        g_comm_timeout_ms = value;
+        return SKX_OK;
+    }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 SKX_API int skx_get_option(const char* name, uint64_t* value) {
@@ -177,6 +203,7 @@ SKX_API int skx_get_option(const char* name, uint64_t* value) {
     if (!strcmp(name, "filter_bits_per_hash")) { *value = g_filter_bits_per_hash; return SKX_OK; }
     if (!strcmp(name, "stream_query_rows")) { *value = g_stream_query_rows; return SKX_OK; }
     if (!strcmp(name, "stream_coalesce")) { *value = g_stream_coalesce; return SKX_OK; }
+    if (!strcmp(name, "comm_timeout_ms")) { *value = g_comm_timeout_ms; return SKX_OK; }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -515,14 +542,15 @@ struct PendingBatch {
 // (GPU_MAX_HW_QUEUES) and the second set aliased.  Kernels of different skx_streams queue behind each other on the shared HIP
 // streams in host order; every skx_stream orders its own work with its own events, as before.  (A skx_stream_sync therefore
 // also waits for work queued by the device's other streams.)
-struct SharedQueues { hipStream_t hs = nullptr, hs0 = nullptr, hs1 = nullptr, hs2 = nullptr; int refs = 0; };
+// hs2b: the stream of the second ranking lane (skx_stream::RankLane), created when the first stream that enqueues asks for it
+struct SharedQueues { hipStream_t hs = nullptr, hs0 = nullptr, hs1 = nullptr, hs2 = nullptr, hs2b = nullptr; int refs = 0; };
 static std::mutex g_queues_mu;
 static SharedQueues g_queues[64];
 static void release_queues(int device) {
     std::lock_guard<std::mutex> lk(g_queues_mu);
     SharedQueues& q = g_queues[device & 63];
     if (--q.refs > 0) return;
-    for (hipStream_t* h : {&q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
+    for (hipStream_t* h : {&q.hs2b, &q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
     q.refs = 0;
 }
 static const int kSides = kGroupMax + 1;  // copies of the per-batch sketch outputs: the enqueued batches waiting for their shared pass + the one being sketched
@@ -546,7 +574,7 @@ struct skx_stream {
     hipStream_t hs1 = nullptr;  // aliases hs0 below pipeline depth 3
     hipEvent_t ev_main[kSides] = {};  // sketch stream: everything of the batch queued on hs0 is done (per side)
     int depth = 2;
-    bool shared_queues = false;  // hs / hs0 / hs1 / hs2 belong to the device's SharedQueues
+    bool shared_queues = false;  // hs / hs0 / hs1 / hs2 (and the second ranking lane's stream) belong to the device's SharedQueues
     int buf = 0;
     hipEvent_t ev_dict[2] = {nullptr, nullptr}, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
     // per side of the sketch buffers (see d_sk below):
@@ -587,6 +615,7 @@ struct skx_stream {
     // side in use (use_side); side 1 is allocated by the first call that needs it.
     u64* d_sk = nullptr;
     u32 *d_len = nullptr, *d_cnt = nullptr, *d_poff = nullptr;
+    bool side_ready[kSides] = {};  // the set is completely allocated (alloc_side is all or nothing)
     u64* sd_sk[kSides] = {};       // POOL of a side: production rows are exact-size reservations (sketch_finish, pool mode)
     u64 pool_cap[kSides] = {};        // ... its entries: a fixed slot per read first (pool_fixed), the reservable part behind
     u32 pool_fixed = 0;
@@ -601,26 +630,47 @@ struct skx_stream {
     u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
     u32 *d_pair_r[3] = {nullptr, nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[3] = {nullptr, nullptr, nullptr};
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
-    // per-segment increments and their chunk sums (before the prefix), per buffer set: they depend on the pass's bit matrix
-    // only, not on the running table, so seg_sum of pass i + 1 can run (stream hs3, SKX_RANK_SPLIT) while pass i is still ranked (hs2)
-    u32* d_inc2[2] = {nullptr, nullptr};
-    u32* d_csum_raw2[2] = {nullptr, nullptr};
-    u32* d_csum = nullptr;        // exclusive prefix of the chunk sums (chunk_prefix)
-    hipStream_t hs3 = nullptr;    // aliases hs2 below pipeline depth 3
-    hipEvent_t ev_inc[2] = {nullptr, nullptr};
-    u32* d_leader = nullptr;      // [chunks of 16 segments][top_k] genomes ranked first as the chunk begins
-    u64* d_lead_val = nullptr;    // [chunks] value of the top_k-th of them
-    u64* d_gmax = nullptr;        // [chunks + 1][half rank groups] best value inside 256 genomes at every chunk boundary
-    u64* d_lpart_sum = nullptr;   // per-slice leader candidates (chunk_leader_part_kernel)
-    u32* d_lpart_idx = nullptr;
-    u32* d_rel = nullptr;         // [segments of a pass][n_pad] segment start values relative to the pass-start table
-    u32* d_live_ctr = nullptr;        // [2] sampled (chunk, half group)s that can hold a candidate / tested, of the most recent ranking (seg_prefix_kernel)
-    u64* d_lead_seg = nullptr;        // [segments of a pass][species] the ranking's bound as every segment begins (chunk_leader_merge_kernel)
-    unsigned char* d_has = nullptr;   // [segments of a pass][rank groups] the pruned ranking kernels reported something (the merges skip the rest)
-    unsigned char* d_live = nullptr;  // [segments of a pass][n_pad / 64] top-1 ranking: the word can hold a candidate (seg_prefix_kernel)
-    u64* d_cand_sum = nullptr;
-    u32* d_cand_idx = nullptr;
-    u64 *d_cum = nullptr, *d_cum2 = nullptr;  // running table (current) and the buffer the next pass writes
+    // RANKING LANES (round 4).  The ranking of a batch is a chain of nine short, latency-bound kernels (counts, three prefix /
+    // leader kernels, per-read arg-max, merge): alone it takes ~0.37 ms and leaves most of the chip idle, and the chains of
+    // consecutive batches depend on each other through ONE thing only -- the table a batch starts from, which the previous
+    // batch's chunk_prefix writes as its second kernel.  So consecutive batches take turns over kRankLanes lanes, each with its
+    // own HIP stream and its own scratch; a chain waits for the event behind the previous chain's chunk_prefix (ev_cum) and
+    // otherwise runs beside it.  The tables rotate over kRankLanes + 1 buffers: batch i reads T[i], writes T[i + 1]; T[i] is
+    // written again by batch i + kRankLanes + 1, which follows batch i + 1's ... on a lane batch i's chain has long left.
+    // Lane 0's stream is hs2, the stream every other user of the table is ordered on: a pass ends by joining the other lanes
+    // into it.  What it buys: the tail of a stream (the last group's rankings used to run one after the other on an empty
+    // chip) and the backlog the ranking stream built up beside the sketches.
+    struct RankLane {
+        hipStream_t s = nullptr;
+        u32 *d_inc = nullptr;       // [segments of a pass][n_pad] per-segment increments (seg_sum)
+        u32 *d_csum_raw = nullptr;  // [chunks][n_pad] chunk sums as counted, d_csum: their exclusive prefix (chunk_prefix)
+        u32 *d_csum = nullptr;
+        u32 *d_rel = nullptr;       // [segments of a pass][n_pad] segment start values relative to the pass-start table
+        u32 *d_leader = nullptr;    // [chunks of 16 segments][species][top_k] genomes ranked first as the chunk begins
+        u64 *d_lead_val = nullptr;  // [chunks][species] value of the top_k-th of them
+        u64 *d_gmax = nullptr;      // [chunks + 1][half rank groups] best value inside 256 genomes at every chunk boundary
+        u64 *d_lpart_sum = nullptr; // per-slice leader candidates (chunk_leader_part_kernel)
+        u32 *d_lpart_idx = nullptr;
+        u32 *d_live_ctr = nullptr;  // [2] sampled (chunk, half group)s that can hold a candidate / tested (seg_prefix_kernel)
+        u64 *d_lead_seg = nullptr;  // [segments of a pass][species] the ranking's bound as every segment begins
+        unsigned char *d_has = nullptr;   // [segments of a pass][rank groups] the pruned ranking kernels reported something
+        unsigned char *d_live = nullptr;  // [segments of a pass][n_pad / 64] top-1 ranking: the word can hold a candidate
+        u64 *d_cand_sum = nullptr;
+        u32 *d_cand_idx = nullptr;
+        hipEvent_t ev_cum = nullptr;   // its chain's chunk_prefix is done: the table the NEXT batch starts from is complete
+        hipEvent_t ev_done = nullptr;  // its chain is done
+        bool ready = false;
+    };
+    static const int kRankLanes = 2;
+    RankLane lane[kRankLanes];
+    int n_lanes = 1;             // lanes in use (the second one is allocated for streams that enqueue)
+    bool own_lane_stream = false;  // lane 1's stream is this skx_stream's own (not the device's shared set's)
+    u32 n_cand_units = 0;        // candidate slots per read of the ranking's per-(read, unit) arrays
+    u64 rank_seq = 0;            // batches ranked so far: batch i takes lane i % n_lanes
+    RankLane* cum_writer = nullptr;  // the lane whose chunk_prefix wrote (or will have written) d_cum
+    u64* d_tab[kRankLanes + 1] = {};  // the rotating tables
+    int tab_cur = 0;             // d_cum == d_tab[tab_cur]
+    u64* d_cum = nullptr;        // running table (current)
     u32* d_topk_idx = nullptr;
     u64* d_topk_sum = nullptr;
     u64* d_tab_tmp = nullptr;   // [n_genomes] staging of skx_stream_table / skx_stream_table_add
@@ -640,7 +690,7 @@ struct skx_stream {
     u32* h_chk = nullptr;    // page-locked, coherent [16] per side: written by publish_kernel: d_chk, [8] = total pairs, [15] = sequence
     u32* h_chk_base = nullptr;
     u32 pub_seq = 0;         // sequence number of the latest publish
-    bool chk_dirty = false;  // a push failed between arming and publishing: re-zero the device-side counters first
+    bool chk_dirty[kSides] = {};  // per set: a push failed between arming and publishing -- re-zero the set's device-side counters before its next batch
     u64* d_rowany[2] = {nullptr, nullptr};   // [rank groups][qcap / 64] per buffer set: which query rows hold a bit for the group
     u32* d_grp_any[2] = {nullptr, nullptr};  // [rank groups + 1] per buffer set: the group's slice of the bit matrix holds any
                                              // bit; last word = "M itself was written this pass" (m_dirty)
@@ -660,6 +710,7 @@ struct skx_stream {
     struct Staged {
         bool pending = false;   // copied (or being copied) to the device, not yet processed
         bool in_flight = false; // processed, rows possibly still on their way to the host
+        bool dropped = false;   // the batch was never scored: a batch enqueued before it failed (skx_stream_wait says so)
         u32 n_reads = 0;
         u64 n_bases = 0, ticket = 0;
         u32* out_idx = nullptr;
@@ -686,6 +737,8 @@ struct skx_stream {
     u64 launches[SKX_N_STAGES] = {0, 0, 0, 0, 0};
 };
 
+static void free_side(skx_stream* st, int i);
+static void free_lane(skx_stream* st, int i);
 static void stream_free(skx_stream* st) {
     if (!st) return;
     (void)hipSetDevice(st->device);
@@ -693,25 +746,23 @@ static void stream_free(skx_stream* st) {
     if (st->hs1) (void)hipStreamSynchronize(st->hs1);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     if (st->hs2) (void)hipStreamSynchronize(st->hs2);
-    for (int i = 0; i < kSides; ++i) {
-        void* side_ptrs[] = {st->sd_sk[i], st->sd_len[i], st->sd_cnt[i], st->sd_poff[i], st->sd_big[i], st->sd_rows[i]};
-        for (void* q : side_ptrs) (void)hipFree(q);
-    }
+    if (st->lane[1].s) (void)hipStreamSynchronize(st->lane[1].s);
+    for (int i = 0; i < kSides; ++i) (void)hipFree(st->sd_rows[i]);
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
-                    st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1], st->d_inc2[0], st->d_inc2[1] != st->d_inc2[0] ? st->d_inc2[1] : nullptr,
-                    st->d_csum, st->d_csum_raw2[0], st->d_csum_raw2[1] != st->d_csum_raw2[0] ? st->d_csum_raw2[1] : nullptr, st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, st->d_rel, st->d_live, st->d_has, st->d_lead_seg, st->d_live_ctr, st->d_cand_sum, st->d_cand_idx, st->d_cum, st->d_cum2, st->d_topk_idx,
-                    st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
+                    st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1],
+                    st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1]};
+    for (auto& t : st->d_tab) (void)hipFree(t);
+    for (int i = 0; i < skx_stream::kRankLanes; ++i) free_lane(st, i);
+    if (st->own_lane_stream && st->lane[1].s) (void)hipStreamDestroy(st->lane[1].s);
     for (void* p : ptrs) (void)hipFree(p);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
     if (st->h_chk_base) (void)hipHostFree(st->h_chk_base);
     for (int i = 0; i < kSides; ++i) {
-        (void)hipFree(st->sd_chk[i]); (void)hipFree(st->sd_retry[i]);
-        (void)hipFree(st->sd_lr[i].list); (void)hipFree(st->sd_lr[i].seg0); (void)hipFree(st->sd_lr[i].seg_tab);
-        (void)hipFree(st->sd_lr[i].seg_cnt); (void)hipFree(st->sd_lr[i].seg_h);
+        free_side(st, i);
         if (st->ev_main[i]) (void)hipEventDestroy(st->ev_main[i]);
     }
     if (!st->shared_queues && st->hs1 && st->hs1 != st->hs0) (void)hipStreamDestroy(st->hs1);
@@ -730,7 +781,6 @@ static void stream_free(skx_stream* st) {
     for (int i = 0; i < 2; ++i) {
         if (st->ev_dict[i]) (void)hipEventDestroy(st->ev_dict[i]);
         if (st->ev_pairq[i]) (void)hipEventDestroy(st->ev_pairq[i]);
-        if (st->ev_inc[i]) (void)hipEventDestroy(st->ev_inc[i]);
         if (st->ev_front[i]) (void)hipEventDestroy(st->ev_front[i]);
         if (st->ev_back[i]) (void)hipEventDestroy(st->ev_back[i]);
     }
@@ -743,7 +793,6 @@ static void stream_free(skx_stream* st) {
     if (st->shared_queues) {
         release_queues(st->device);
     } else {
-        if (st->hs3 && st->hs3 != st->hs2) (void)hipStreamDestroy(st->hs3);
         if (st->hs2 && st->hs2 != st->hs && st->hs2 != st->hs0) (void)hipStreamDestroy(st->hs2);
         if (st->hs0 && st->hs0 != st->hs) (void)hipStreamDestroy(st->hs0);
         if (st->hs) (void)hipStreamDestroy(st->hs);
@@ -752,7 +801,24 @@ static void stream_free(skx_stream* st) {
 }
 
 // one copy of the per-batch sketch buffers
+static void free_side(skx_stream* st, int i) {
+    void* ptrs[] = {st->sd_sk[i], st->sd_len[i], st->sd_cnt[i], st->sd_poff[i], st->sd_big[i], st->sd_retry[i], st->sd_chk[i],
+                    st->sd_lr[i].list, st->sd_lr[i].seg0, st->sd_lr[i].seg_tab, st->sd_lr[i].seg_cnt, st->sd_lr[i].seg_h};
+    for (void* q : ptrs) (void)hipFree(q);
+    st->sd_sk[i] = nullptr; st->sd_len[i] = st->sd_cnt[i] = st->sd_poff[i] = st->sd_big[i] = st->sd_retry[i] = st->sd_chk[i] = nullptr;
+    st->sd_lr[i] = skx::LongReads{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    st->pool_cap[i] = 0;
+    st->side_ready[i] = false;
+}
+static hipError_t alloc_side_parts(skx_stream* st, int i);
+// (all or nothing: a set that could not be completed is released again -- use_side only ever sees whole sets)
 static hipError_t alloc_side(skx_stream* st, int i) {
+    const hipError_t e = alloc_side_parts(st, i);
+    if (e != hipSuccess) { free_side(st, i); (void)hipGetLastError(); }
+    else st->side_ready[i] = true;
+    return e;
+}
+static hipError_t alloc_side_parts(skx_stream* st, int i) {
     hipError_t e;
     // the pool: a fixed slot of 16 entries per read (C2 keeps 2.4 per read, C4 3.9: nearly every row fits its slot and costs no
     // atomic) and, behind it, a reservable part for the longer rows -- as large again, at least 2^20 entries, and never more than
@@ -787,7 +853,9 @@ static hipError_t alloc_side(skx_stream* st, int i) {
     return hipMemset(st->sd_big[i], 0, 4);  // (null stream; callers on the pipeline streams synchronise the device once)
 }
 static hipError_t use_side(skx_stream* st, int i) {
-    if (!st->sd_sk[i]) {
+    if (!st->side_ready[i]) {
+        // (not on the steady path: skx_stream_create allocates every set an enqueueing stream rotates over; this serves the
+        // internal streams of skx_common_hashes, which start with one)
         hipError_t e = alloc_side(st, i);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) return e;
@@ -813,12 +881,66 @@ static hipError_t use_rows(skx_stream* st) {
     return hipSuccess;
 }
 
+// the scratch of one ranking lane (sizes: the stream's pass geometry, set before)
+static hipError_t alloc_lane_parts(skx_stream* st, int i) {
+    skx_stream::RankLane& L = st->lane[i];
+    const skx_ref* ref = st->ref;
+    const u32 n_pad = ref->n_pad, n_sp = ref->n_species, top_k = st->top_k;
+    const u32 n_seg_max = (st->rpass + skx::kSegLen - 1) / skx::kSegLen, n_chunk_max = (n_seg_max + 15) / 16;
+    const u32 k1 = std::max<u32>(top_k, 1);
+    hipError_t e;
+#define LCHK(expr) do { if ((e = (expr)) != hipSuccess) return e; } while (0)
+    LCHK(hipMalloc(&L.d_inc, (size_t)n_seg_max * n_pad * 4));
+    LCHK(hipMalloc(&L.d_rel, (size_t)n_seg_max * n_pad * 4));
+    LCHK(hipMalloc(&L.d_live, (size_t)n_seg_max * (n_pad / 64)));
+    LCHK(hipMalloc(&L.d_has, (size_t)n_seg_max * (n_pad / (skx::kRankWords * 64))));
+    LCHK(hipMalloc(&L.d_lead_seg, (size_t)n_seg_max * n_sp * 8 + 64));
+    LCHK(hipMalloc(&L.d_live_ctr, 8));
+    LCHK(hipMemset(L.d_live_ctr, 0, 8));  // (from here on every ranking leaves it zero: store_host_words_kernel reads and resets)
+    LCHK(hipMalloc(&L.d_csum, (size_t)n_chunk_max * n_pad * 4));
+    LCHK(hipMalloc(&L.d_csum_raw, (size_t)n_chunk_max * n_pad * 4));
+    LCHK(hipMalloc(&L.d_leader, (size_t)n_chunk_max * n_sp * k1 * 4 + 64));
+    LCHK(hipMalloc(&L.d_lead_val, (size_t)n_chunk_max * n_sp * 8 + 64));
+    LCHK(hipMalloc(&L.d_lpart_sum, (size_t)n_chunk_max * n_sp * skx::rank_leader_parts() * k1 * 8 + 64));
+    LCHK(hipMalloc(&L.d_lpart_idx, (size_t)n_chunk_max * n_sp * skx::rank_leader_parts() * k1 * 4 + 64));
+    LCHK(hipMalloc(&L.d_gmax, (size_t)(n_chunk_max + 1) * (n_pad / 256) * 8 + 64));
+    if (top_k) {
+        LCHK(hipMalloc(&L.d_cand_sum, (size_t)st->rpass * st->n_cand_units * top_k * 8));
+        LCHK(hipMalloc(&L.d_cand_idx, (size_t)st->rpass * st->n_cand_units * top_k * 4));
+    }
+    LCHK(hipEventCreateWithFlags(&L.ev_cum, hipEventDisableTiming));
+    LCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+#undef LCHK
+    return hipSuccess;
+}
+static void free_lane(skx_stream* st, int i) {
+    skx_stream::RankLane& L = st->lane[i];
+    void* ptrs[] = {L.d_inc, L.d_rel, L.d_live, L.d_has, L.d_lead_seg, L.d_live_ctr, L.d_csum, L.d_csum_raw, L.d_leader, L.d_lead_val,
+                    L.d_lpart_sum, L.d_lpart_idx, L.d_gmax, L.d_cand_sum, L.d_cand_idx};
+    for (void* q : ptrs) (void)hipFree(q);
+    if (L.ev_cum) (void)hipEventDestroy(L.ev_cum);
+    if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+    const hipStream_t keep = L.s;  // (streams are created and destroyed with the skx_stream, not with the scratch)
+    L = skx_stream::RankLane{};
+    L.s = keep;
+}
+static hipError_t alloc_lane(skx_stream* st, int i) {
+    const hipError_t e = alloc_lane_parts(st, i);
+    if (e != hipSuccess) { free_lane(st, i); (void)hipGetLastError(); }
+    else st->lane[i].ready = true;
+    return e;
+}
+
 // pair_hint: pairs (read, hash some genome holds) a read is expected to contribute at most; sizes the pass workspace
 // (a batch with more than it can hold is cut into several passes -- correct at any size)
 // dense_queries: the pairs of a pass are (nearly) all distinct hashes (skx_common_hashes: whole sketches as queries) -- the
 // matrices then get as many rows as the pass has pairs, bounded by a sixth of the free device memory
+// enqueueing: the stream may be driven through skx_stream_enqueue_device / skx_stream_submit -- every buffer set its batches rotate
+// over (stream_coalesce + 1) is allocated HERE: a hipMalloc and the device-wide synchronisation behind it have no place in
+// the enqueue path (round 3 allocated them at first use: the first stream_coalesce + 1 enqueues of a stream each stalled
+// every stream of the device -- the first repetition of the bench ran at 79 M reads/s, the others at 121 M)
 static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_k, u32 max_reads, u64 max_bases,
-                                  u32 sk_stride, u32 pair_hint, bool dense_queries = false) {
+                                  u32 sk_stride, u32 pair_hint, bool dense_queries = false, bool enqueueing = false) {
     SKXCHK(use_device(ref->device));
     skx_stream* st = new skx_stream;
     st->ref = ref; st->device = ref->device; st->top_k = top_k; st->max_reads = max_reads; st->max_bases = max_bases;
@@ -867,7 +989,6 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (4ull << 30) / ((u64)n_cand_units * top_k * 12)));
     rp = std::max<u64>(rp, 1);
     st->rpass = (u32)rp;
-    const u32 n_seg_max = (st->rpass + skx::kSegLen - 1) / skx::kSegLen;
     const u32 n_bt = ref->n_bands * ref->n_tiles;
 
     hipError_t e;
@@ -899,7 +1020,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipExtStreamCreateWithCUMask(&st->hs, words, m_scan.data()));
         SCHK(hipExtStreamCreateWithCUMask(&st->hs0, words, m_rest.data()));
         SCHK(hipExtStreamCreateWithCUMask(&st->hs2, words, m_rest.data()));
-    } else if (st->depth == 3 && prio_env && !skx::knob("SKX_PRIO_RANK") && !skx::knob("SKX_RANK_SPLIT")) {
+    } else if (st->depth == 3 && prio_env && !skx::knob("SKX_PRIO_RANK")) {
         // the product's configuration: the device's shared set (created by its first stream)
         std::lock_guard<std::mutex> lk(g_queues_mu);
         SharedQueues& q = g_queues[st->device & 63];
@@ -927,17 +1048,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipStreamCreateWithPriority(&st->hs2, hipStreamNonBlocking, rank_hi ? prio_hi : prio_lo));
     } else st->hs2 = st->hs;
     }
-    {
-        // (measured at C2: with the split the stream far from its start gains 5 % (78.6 -> 83 M reads/s), the first 2 M reads
-        // of a sample -- heavy ranking, nothing pruned yet -- lose 10 % (72.5 -> 64.5 M): off by default)
-        static const int split_env = skx::knob("SKX_RANK_SPLIT") ? atoi(skx::knob("SKX_RANK_SPLIT")) : 0;
-        if (st->depth == 3 && split_env && cu_scan_env <= 0) SCHK(hipStreamCreateWithPriority(&st->hs3, hipStreamNonBlocking, prio_lo));
-        else st->hs3 = st->hs2;
-    }
     for (int i = 0; i < 2; ++i) {
         SCHK(hipEventCreateWithFlags(&st->ev_dict[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_pairq[i], hipEventDisableTiming));
-        SCHK(hipEventCreateWithFlags(&st->ev_inc[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_front[i], hipEventDisableTiming));
         SCHK(hipEventCreateWithFlags(&st->ev_back[i], hipEventDisableTiming));
     }
@@ -951,7 +1064,10 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     }
     SCHK(hipMalloc(&st->d_bases, std::max<u64>(max_bases, 1)));
     SCHK(hipMalloc(&st->d_offsets, ((size_t)max_reads + 1) * 8));
-    SCHK(alloc_side(st, 0));
+    {
+        const int n_now = enqueueing ? (st->coalesce >= 2 ? (int)st->coalesce + 1 : 2) : 1;
+        for (int i = 0; i < n_now; ++i) SCHK(alloc_side(st, i));
+    }
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_pair_h[i], (size_t)st->pcap * 8));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_q[i], (size_t)st->pcap * 8));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_pair_q[i], (size_t)st->pcap * 4));
@@ -969,31 +1085,36 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // (d_mint, the second word array of the split scan variant, is allocated by the first pass that wants it)
     for (int i = 0; i < 2; ++i)
         SCHK(hipMalloc(&st->d_mq[i], (size_t)st->qcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
-    SCHK(hipMalloc(&st->d_inc2[0], (size_t)n_seg_max * n_pad * 4));
-    if (st->hs3 != st->hs2) SCHK(hipMalloc(&st->d_inc2[1], (size_t)n_seg_max * n_pad * 4)); else st->d_inc2[1] = st->d_inc2[0];
-    SCHK(hipMalloc(&st->d_rel, (size_t)n_seg_max * n_pad * 4));
-    SCHK(hipMalloc(&st->d_live, (size_t)n_seg_max * (n_pad / 64)));
-    SCHK(hipMalloc(&st->d_has, (size_t)n_seg_max * (n_pad / (skx::kRankWords * 64))));
-    SCHK(hipMalloc(&st->d_lead_seg, (size_t)n_seg_max * n_sp * 8 + 64));
-    SCHK(hipMalloc(&st->d_live_ctr, 8));
-    SCHK(hipMalloc(&st->d_csum, (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
-    SCHK(hipMalloc(&st->d_csum_raw2[0], (size_t)((n_seg_max + 15) / 16) * n_pad * 4));
-    if (st->hs3 != st->hs2) SCHK(hipMalloc(&st->d_csum_raw2[1], (size_t)((n_seg_max + 15) / 16) * n_pad * 4)); else st->d_csum_raw2[1] = st->d_csum_raw2[0];
-    SCHK(hipMalloc(&st->d_leader, (size_t)((n_seg_max + 15) / 16) * n_sp * std::max<u32>(top_k, 1) * 4 + 64));
-    SCHK(hipMalloc(&st->d_lead_val, (size_t)((n_seg_max + 15) / 16) * n_sp * 8 + 64));
-    SCHK(hipMalloc(&st->d_lpart_sum, (size_t)((n_seg_max + 15) / 16) * n_sp * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 8 + 64));
-    SCHK(hipMalloc(&st->d_lpart_idx, (size_t)((n_seg_max + 15) / 16) * n_sp * skx::rank_leader_parts() * std::max<u32>(top_k, 1) * 4 + 64));
-    SCHK(hipMalloc(&st->d_gmax, (size_t)((n_seg_max + 15) / 16 + 1) * (n_pad / 256) * 8 + 64));
+    st->n_cand_units = n_cand_units;
+    {
+        // ranking lanes: the second one only for streams that enqueue (batches back to back are what it overlaps); experiment
+        // knob SKX_RANK_LANES=1 keeps every chain on one lane
+        static const int lanes_env = skx::knob("SKX_RANK_LANES") ? atoi(skx::knob("SKX_RANK_LANES")) : skx_stream::kRankLanes;
+        st->n_lanes = (enqueueing && top_k && st->depth >= 3) ? std::max(1, std::min(lanes_env, (int)skx_stream::kRankLanes)) : 1;
+        st->lane[0].s = st->hs2;
+        if (st->n_lanes > 1) {
+            if (st->shared_queues) {
+                std::lock_guard<std::mutex> lk(g_queues_mu);
+                SharedQueues& q = g_queues[st->device & 63];
+                if (!q.hs2b) SCHK(hipStreamCreateWithPriority(&q.hs2b, hipStreamNonBlocking, prio_lo));
+                st->lane[1].s = q.hs2b;
+            } else {
+                SCHK(hipStreamCreateWithPriority(&st->lane[1].s, hipStreamNonBlocking, prio_lo));
+                st->own_lane_stream = true;
+            }
+        }
+        for (int i = 0; i < st->n_lanes; ++i) SCHK(alloc_lane(st, i));
+    }
+    for (int i = 0; i <= st->n_lanes; ++i) {
+        SCHK(hipMalloc(&st->d_tab[i], (size_t)n_pad * 8));
+        SCHK(hipMemset(st->d_tab[i], 0, (size_t)n_pad * 8));
+    }
+    st->tab_cur = 0;
+    st->d_cum = st->d_tab[0];
     if (top_k) {
-        SCHK(hipMalloc(&st->d_cand_sum, (size_t)st->rpass * n_cand_units * top_k * 8));
-        SCHK(hipMalloc(&st->d_cand_idx, (size_t)st->rpass * n_cand_units * top_k * 4));
         SCHK(hipMalloc(&st->d_topk_idx, (size_t)max_reads * n_sp * top_k * 4));
         SCHK(hipMalloc(&st->d_topk_sum, (size_t)max_reads * n_sp * top_k * 8));
     }
-    SCHK(hipMalloc(&st->d_cum, (size_t)n_pad * 8));
-    SCHK(hipMemset(st->d_cum, 0, (size_t)n_pad * 8));
-    SCHK(hipMalloc(&st->d_cum2, (size_t)n_pad * 8));
-    SCHK(hipMemset(st->d_cum2, 0, (size_t)n_pad * 8));
     SCHK(hipMalloc(&st->d_tab_tmp, (size_t)ref->n_genomes * 8));
     st->rank_cap = n_sp * std::max<u32>(SKX_MAX_TOP, top_k);
     SCHK(hipMalloc(&st->d_rank_idx, (size_t)st->rank_cap * 4));
@@ -1047,7 +1168,7 @@ SKX_API int skx_stream_create(skx_stream** out, const skx_ref* ref, uint32_t top
     if (max_batch_bases >= (1ull << 32)) return fail(SKX_ERR_CAPACITY, "max_batch_bases must be below 2^32");
     // real reads leave a handful of pairs each (C2: ~5 of ~1500 hashes are in range and held by some genome); 64 per read
     // keeps small streams small, and denser batches simply take more passes
-    return stream_create_internal(out, ref, top_k, max_batch_reads, max_batch_bases, sk_stride, 64);
+    return stream_create_internal(out, ref, top_k, max_batch_reads, max_batch_bases, sk_stride, 64, false, true);
 }
 SKX_API void skx_stream_destroy(skx_stream* st) { stream_free(st); }
 
@@ -1070,6 +1191,20 @@ struct Span {
     }
 };
 static void collect_spans(skx_stream* st) {
+#ifdef SKX_EXPERIMENTS
+    // SKX_SPAN_DUMP=1: every recorded span with its start and end relative to the first one (the undistorted device timeline of
+    // the stages: a kernel trace slows the queueing thread enough to change the picture)
+    if (skx::knob("SKX_SPAN_DUMP") && !st->spans.empty()) {
+        static const char* names[SKX_N_STAGES] = {"sketch", "dictionary", "scan", "transpose", "rank"};
+        const hipEvent_t base = st->spans.front().a;
+        for (auto& sp : st->spans) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, base, sp.a) == hipSuccess && hipEventElapsedTime(&b, base, sp.b) == hipSuccess)
+                fprintf(stderr, "[skx span] %-10s %9.3f %9.3f  (%.3f ms)\n", names[sp.stage], a, b, b - a);
+        }
+        fprintf(stderr, "[skx span] ----\n");
+    }
+#endif
     for (auto& sp : st->spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { st->ms[sp.stage] += ms; st->launches[sp.stage] += 1; }
@@ -1163,6 +1298,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // and by its ranking on the back stream (pair -> query index, Mq, group flags) -- the wait for that ranking sits
     // further down, right before those are overwritten.
     (void)hs0;
+    SKX_MARK("pass: begin, subs", n_sub);
     for (int i = 0; i < n_sub; ++i) HIPCHK(hipStreamWaitEvent(hs, st->ev_sketch[subs[i].side], 0));  // the batches' sketches and pair offsets
     st->front_pending[b] = false;  // (this stream recorded it)
     // (inserted: the sketch stream also copied the pass's pair offsets -- this stream then never touches the sketch buffers,
@@ -1205,7 +1341,9 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // ---- scan + transpose (same stream, HBM-bound)
     const u32 n_grp_all = n_pad / (skx::kRankWords * 64);
     u32* d_mdirty = d_grp_any + n_grp_all;
+    SKX_MARK("pass: dictionary queued", 0);
     HIPCHK(hipMemsetAsync(d_mdirty, 0, 4, hs));  // raised by writers of M (read by the transpose, this stream)
+    SKX_MARK("pass: memset mdirty", 0);
     // the ranking two passes back reads this set's pair -> query index, Mq and group flags: from here on they are rewritten
     auto wait_back = [&]() -> int {
         if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
@@ -1262,13 +1400,20 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     HIPCHK(hipEventRecord(st->ev_front[b], hs));
     st->front_pending[b] = true;
 
-    // ---- back half: per-segment increments and their chunk sums (stream hs3: they need this pass's Mq only), then the
-    // running table and the per-read rows (stream hs2, in pass order); overlaps the next pass's front half
-    hipStream_t hs3 = n_sub > 1 ? st->hs2 : st->hs3;  // (a shared pass ranks its batches strictly one after the other)
-    u32 *d_inc = st->d_inc2[b], *d_csum_raw = st->d_csum_raw2[b];
-    HIPCHK(hipStreamWaitEvent(hs3, st->ev_front[b], 0));
+    // ---- back half: the batches of the pass are ranked in order, consecutive ones on alternating LANES (skx_stream::RankLane):
+    // a chain counts its per-segment increments and chunk sums (they need this pass's Mq only), waits for the table the chain
+    // before it leaves behind its chunk_prefix, then: running table, bounds, per-read rows.  Overlaps the next pass's front half.
+    bool lane_used[skx_stream::kRankLanes] = {};
+    SKX_MARK("pass: scan + transpose queued", 0);
     for (int si = 0; si < n_sub; ++si) {
+    SKX_MARK("rank: begin sub", si);
     const SubPass& sb = subs[si];
+    // (only the batches of a SHARED pass take turns: a pass of one batch has the next pass's scan and sketch beside its chain
+    // already -- measured with one pass per batch, option stream_coalesce = 1: 83 M reads/s on one lane, 67 M on two)
+    const int li = (update_table && n_sub > 1) ? (int)(st->rank_seq % (u64)st->n_lanes) : 0;
+    skx_stream::RankLane& L = st->lane[li];
+    hipStream_t ls = L.s;
+    if (!lane_used[li]) { HIPCHK(hipStreamWaitEvent(ls, st->ev_front[b], 0)); lane_used[li] = true; }  // the pass's Mq
     const u32 n_reads = sb.rb - sb.ra, sub_base = sb.p_base;
     const u32 *sub_pair_q = d_pair_q + sb.p_off, *sub_pair_r = d_pair_r + sb.p_off, *sub_poff = sb.d_poff;
     u32* const d_topk_idx = sb.d_topk_idx;
@@ -1291,68 +1436,87 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     const bool mostly_dead = tested_now != 0 && (u64)live_now * 100 < (u64)tested_now * live_pct_env;
     const bool two_level = prune_k != 0 && (two_level_env >= 0 ? two_level_env != 0 : mostly_dead);
     const u64* rowany_b = P > 0 ? st->d_rowany[b] : nullptr;
+    u32 *d_inc = L.d_inc, *d_csum_raw = L.d_csum_raw;
     if (update_table) {
-        Span sp(st, 4, hs3);
+        Span sp(st, 4, ls);
         // (the chunk sums are accumulated by seg_sum's workgroups: four atomic adds per chunk and genome)
-        HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * n_pad * 4, hs3));
+        HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * n_pad * 4, ls));
         if (two_level)
-            skx::launch_chunk_sum(hs3, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, d_grp_any, d_csum_raw, rowany_b, d_nq, spc);
+            skx::launch_chunk_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, d_grp_any, d_csum_raw, rowany_b, d_nq, spc);
         else
-            skx::launch_seg_sum(hs3, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
+            skx::launch_seg_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
                                 d_csum_raw, rowany_b, d_nq, spc);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(st->ev_inc[b], hs3));
-    HIPCHK(hipStreamWaitEvent(hs2, st->ev_inc[b], 0));  // (implies ev_front[b])
+    SKX_MARK("rank: seg_sum queued", si);
     if (update_table) {
-        Span sp(st, 4, hs2);
+        Span sp(st, 4, ls);
+        // the table this batch starts from: complete once the chain before it (usually on the other lane) is past its chunk_prefix
+        if (st->cum_writer && st->cum_writer != &L) HIPCHK(hipStreamWaitEvent(ls, st->cum_writer->ev_cum, 0));
+        const u64* const cum_in = st->d_tab[st->tab_cur];
+        const int tab_next = (st->tab_cur + 1) % (st->n_lanes + 1);
+        u64* const cum_out = st->d_tab[tab_next];
         // the top-1 kernel keeps (value relative to the leader) in 23 bits of a 32-bit key: at most 2 x 64 x s + 1 per
         // segment, so sketch sizes from 2^15 on take the 64-bit-key kernel (with k = 1) instead
         static const bool top1_wide_env = skx::knob("SKX_TOP1_WIDE") != nullptr;  // test knob: force the 64-bit-key kernel
         const bool top1_fast = st->top_k == 1 && ref->s_read < (1u << 15) && !top1_wide_env;
         static const bool live_env = !skx::knob("SKX_RANK_LIVE") || atoi(skx::knob("SKX_RANK_LIVE")) != 0;  // test knob
         const bool topk_fast = !top1_fast && st->top_k && st->top_k <= skx::rank_topk_fast_max();
-        unsigned char* d_live = ((top1_fast || topk_fast) && ranked && live_env) ? st->d_live : nullptr;  // (the pruned kernels look at the flags)
-        if (prune_k) HIPCHK(hipMemsetAsync(st->d_live_ctr, 0, 8, hs2));
+        unsigned char* d_live = ((top1_fast || topk_fast) && ranked && live_env) ? L.d_live : nullptr;  // (the pruned kernels look at the flags)
+        // (ev_cum goes out right behind chunk_prefix, the first kernel of the prefix stage: the next batch's chain only needs the table)
         if (two_level) {
-            skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
-                                   st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live, st->d_lead_seg, 1);
-            skx::launch_seg_sum(hs2, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
-                                nullptr, rowany_b, d_nq, spc, st->d_gmax, st->d_lead_val);
-            skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
-                                   st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live, st->d_lead_seg, 2, st->d_live_ctr);
+            skx::launch_seg_prefix(ls, d_inc, n_seg, n_pad, spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
+                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, d_grp_any, d_live, L.d_lead_seg, 1, nullptr, L.ev_cum);
+            skx::launch_seg_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
+                                nullptr, rowany_b, d_nq, spc, L.d_gmax, L.d_lead_val);
+            skx::launch_seg_prefix(ls, d_inc, n_seg, n_pad, spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
+                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, d_grp_any, d_live, L.d_lead_seg, 2, L.d_live_ctr);
         } else {
-            skx::launch_seg_prefix(hs2, d_inc, n_seg, n_pad, spc, st->d_cum, st->d_cum2, st->d_rel, st->d_csum, d_csum_raw, prune_k,
-                                   st->d_leader, st->d_lead_val, st->d_gmax, st->d_lpart_sum, st->d_lpart_idx, d_grp_any, d_live, st->d_lead_seg, 0,
-                                   st->d_live_ctr);
+            skx::launch_seg_prefix(ls, d_inc, n_seg, n_pad, spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
+                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, d_grp_any, d_live, L.d_lead_seg, 0,
+                                   L.d_live_ctr, L.ev_cum);
         }
-        if (prune_k) HIPCHK(hipMemcpyAsync(st->h_nq + 2, st->d_live_ctr, 8, hipMemcpyDeviceToHost, hs2));
-        std::swap(st->d_cum, st->d_cum2);  // stream-ordered: later work on hs2 sees the new table
-        const u64* cum_in = st->d_cum2;    // the table as this pass began (rewritten by the NEXT pass, same stream)
+        HIPCHK(hipGetLastError());
+        SKX_MARK("rank: prefixes queued", si);
+        // (the live sample reaches the host through a kernel that also re-arms the counters -- NOT hipMemcpyAsync / hipMemsetAsync)
+        if (prune_k) skx::launch_store_host_words(ls, st->h_nq + 2, L.d_live_ctr, 2);
+        st->tab_cur = tab_next;
+        st->d_cum = cum_out;  // (later work ordered behind this lane's ev_cum -- or behind the pass, on hs2 -- sees the new table)
+        st->cum_writer = &L;
+        st->rank_seq += 1;
         if (top1_fast && d_topk_idx && d_topk_sum) {
-            skx::launch_rank_seg_top1(hs2, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows,
-                                      spc, cum_in, st->d_rel, st->d_cand_sum, st->d_cand_idx, d_inc,
-                                      st->d_leader, st->d_gmax, st->d_lead_val, d_grp_any, d_live, st->d_has, rowany_b, d_nq);
-            skx::launch_top1_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, d_topk_idx, d_topk_sum, out_r0, spc, st->d_has,
+            skx::launch_rank_seg_top1(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows,
+                                      spc, cum_in, L.d_rel, L.d_cand_sum, L.d_cand_idx, d_inc,
+                                      L.d_leader, L.d_gmax, L.d_lead_val, d_grp_any, d_live, L.d_has, rowany_b, d_nq);
+            skx::launch_top1_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, d_topk_idx, d_topk_sum, out_r0, spc, L.d_has,
                                    (n_gw + skx::kRankWords - 1) / skx::kRankWords);
         } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
             const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
-            skx::launch_rank_seg_topk(hs2, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
-                                      cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, d_inc, st->d_leader,
-                                      st->d_gmax, st->d_lead_val, d_grp_any, d_live, st->d_has);
-            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, out_r0, spc,
-                                   st->d_has);
+            skx::launch_rank_seg_topk(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
+                                      cum_in, L.d_rel, st->top_k, L.d_cand_sum, L.d_cand_idx, d_inc, L.d_leader,
+                                      L.d_gmax, L.d_lead_val, d_grp_any, d_live, L.d_has);
+            skx::launch_topk_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, out_r0, spc,
+                                   L.d_has);
         } else if (st->top_k && d_topk_idx && d_topk_sum) {
-            skx::launch_rank_seg(hs2, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
-                                 spc, cum_in, st->d_rel, st->top_k, st->d_cand_sum, st->d_cand_idx, d_grp_any);
-            skx::launch_topk_merge(hs2, st->d_cand_sum, st->d_cand_idx, n_reads, n_gw, skx::kRankWords, st->top_k, d_topk_idx,
+            skx::launch_rank_seg(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
+                                 spc, cum_in, L.d_rel, st->top_k, L.d_cand_sum, L.d_cand_idx, d_grp_any);
+            skx::launch_topk_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, n_gw, skx::kRankWords, st->top_k, d_topk_idx,
                                    d_topk_sum, out_r0, spc, nullptr);
         }
     }
     if (sb.d_shared)
-        skx::launch_shared_debug(hs2, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, nq_rows, ref->n_genomes, ref->d_real2pad, sb.d_shared, 0);
+        skx::launch_shared_debug(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, nq_rows, ref->n_genomes, ref->d_real2pad, sb.d_shared, 0);
     HIPCHK(hipGetLastError());
+    SKX_MARK("rank: end sub", si);
     }  // sub-passes
+    // every lane this pass used joins hs2 (lane 0's stream), the stream everybody else who looks at the table or at this pass's
+    // buffers is ordered on
+    if (!lane_used[0]) HIPCHK(hipStreamWaitEvent(hs2, st->ev_front[b], 0));
+    for (int li = 1; li < st->n_lanes; ++li)
+        if (lane_used[li]) {
+            HIPCHK(hipEventRecord(st->lane[li].ev_done, st->lane[li].s));
+            HIPCHK(hipStreamWaitEvent(hs2, st->lane[li].ev_done, 0));
+        }
     HIPCHK(hipEventRecord(st->ev_back[b], hs2));
     st->back_pending[b] = true;
     HIPCHK(hipEventRecord(st->ev_pslot[slot], hs2));
@@ -1549,12 +1713,12 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         pb.spec_set = st->buf ^ (st->n_pend ? 1 : 0);
         pb.spec_slot = (st->pslot + (st->n_pend ? 1 : 0)) % 3;
     }
-    if (st->chk_dirty) {  // an earlier batch failed half-way through this function
-        HIPCHK(hipMemsetAsync(st->d_chk, 0, 64, hs));
+    if (st->chk_dirty[pb.side]) {  // the batch that last used this set failed between arming and publishing: nothing re-armed its counters
+        HIPCHK(hipMemsetAsync(st->d_chk, 0, (size_t)skx::chk_words() * 4, hs));  // (the whole block: the pool's bump counters sit behind word 16)
         HIPCHK(hipMemsetAsync(st->d_retry, 0, 4, hs));
         HIPCHK(hipMemsetAsync(st->d_big, 0, 4, hs));
     }
-    st->chk_dirty = true;
+    st->chk_dirty[pb.side] = true;
     if (st->sk_reader_pending[pb.side]) {  // (rare: this side's previous batch was cut into passes that read it on the scan stream)
         HIPCHK(hipStreamWaitEvent(hs, st->ev_skread[pb.side], 0));
         st->sk_reader_pending[pb.side] = false;
@@ -1568,17 +1732,30 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     static const int room_env = skx::knob("SKX_ROOM_ADAPT") ? atoi(skx::knob("SKX_ROOM_ADAPT")) : 1;  // experiment knob
     static const u32 room_pct_env = skx::knob("SKX_ROOM_PCT") ? (u32)atoi(skx::knob("SKX_ROOM_PCT")) : 33u;  // experiment knob
     const bool ranking_light = room_env && st->h_nq[3] != 0 && (u64)st->h_nq[2] * 100 < (u64)st->h_nq[3] * room_pct_env;
-    int leave_room = (st->depth >= 3 && st->n_pend) ? (ranking_light ? 1 : 2) : 0;
-    if (st->depth >= 3 && !leave_room)
-        for (int i = 0; i < 2; ++i)
-            if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) leave_room = 1;
+    // (round 4: only when something WILL run beside this sketch.  The batches that join the FIRST group of a stream -- or the
+    // first after a pause -- have nothing beside them: no pass is in flight and none is queued before their group closes; with the
+    // pad they ran at half their occupancy alone on the chip, 0.49 instead of 0.40 ms each, seven times per fresh stream.
+    // A batch that opens a new group while others wait gets the pad: this very call queues the waiting group's pass behind it.)
+    bool scan_in_flight = false, pass_in_flight = false;
+    if (st->depth >= 3)
+        for (int i = 0; i < 2; ++i) {
+            if (st->front_pending[i] && hipEventQuery(st->ev_front[i]) == hipErrorNotReady) scan_in_flight = pass_in_flight = true;
+            if (st->back_pending[i] && hipEventQuery(st->ev_back[i]) == hipErrorNotReady) pass_in_flight = true;
+        }
     (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+    static const int room_lazy_env = skx::knob("SKX_ROOM_LAZY") ? atoi(skx::knob("SKX_ROOM_LAZY")) : 1;  // experiment knob: 0 = round 3's rule
+    int leave_room = 0;
+    if (st->depth >= 3) {
+        const bool opens_behind_a_group = st->n_pend && !joins;
+        if (st->n_pend && (!room_lazy_env || opens_behind_a_group || pass_in_flight)) leave_room = ranking_light ? 1 : 2;
+        else if (scan_in_flight) leave_room = 1;
+    }
     {
         SKX_T0();
         SKXCHK(queue_front(st, pb, leave_room));
         SKX_ACC(front);
     }
-    st->chk_dirty = false;  // the publish kernel is queued: it re-arms the device-side counters
+    st->chk_dirty[pb.side] = false;  // the publish kernel is queued: it re-arms the device-side counters
     pb.valid = true;
     return SKX_OK;
 }
@@ -1651,9 +1828,11 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
             SKXCHK(cancel_speculation(st, pb, true));
             HIPCHK(hipStreamSynchronize(st->hs0));
             HIPCHK(hipStreamSynchronize(st->hs1));
-            (void)hipFree(st->sd_sk[pb.side]); st->sd_sk[pb.side] = nullptr; st->pool_cap[pb.side] = 0;
             const u64 cap = need;
-            HIPCHK(hipMalloc(&st->sd_sk[pb.side], (size_t)cap * 8));
+            u64* grown = nullptr;
+            HIPCHK(hipMalloc(&grown, (size_t)cap * 8));  // (the new pool first: a failure leaves the set as it was)
+            (void)hipFree(st->sd_sk[pb.side]);
+            st->sd_sk[pb.side] = grown;
             st->pool_cap[pb.side] = cap;
             st->pool_grown += 1;
             st->reads_big -= big_counted; big_counted = 0;
@@ -1734,8 +1913,15 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
 // in a summary -- an error, a row pool that was too small, reads for the block sketcher, more pairs or distinct hashes together
 // than a pass holds -- un-shares them: the joint set is emptied and each batch takes its own pass(es), gathering its pairs on
 // the scan stream.
-static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch* younger) {
-    if (n == 1) return batch_back(st, g[0], younger);
+// n_done: how many of the batches (in order) were processed completely -- their rows exist and their table updates are
+// applied even when a later batch of the group makes the call fail
+static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch* younger, int* n_done) {
+    *n_done = 0;
+    if (n == 1) {
+        SKXCHK(batch_back(st, g[0], younger));
+        *n_done = 1;
+        return SKX_OK;
+    }
     {
         SKX_T0();
         for (int i = 0; i < n; ++i) SKXCHK(wait_published(st, g[i]));
@@ -1777,7 +1963,10 @@ static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch
         HIPCHK(hipStreamSynchronize(st->hs1));
         for (int i = 0; i < n; ++i) { g[i].spec_insert = false; g[i].gi = 0; }
         if (younger) SKXCHK(cancel_speculation(st, *younger));  // (it counted on ONE pass ahead of its own)
-        for (int i = 0; i < n; ++i) SKXCHK(batch_back(st, g[i], nullptr));
+        for (int i = 0; i < n; ++i) {
+            SKXCHK(batch_back(st, g[i], nullptr));
+            *n_done = i + 1;
+        }
         return SKX_OK;
     }
     SubPass subs[kGroupMax];
@@ -1799,20 +1988,31 @@ static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch
         SKX_ACC(back);
     }
     st->reads_total += reads;
+    *n_done = n;
     return SKX_OK;
 }
 
 // the back half of the enqueued batch(es), if there are any (every entry point that looks at the stream's state starts here)
 static int staged_rows(skx_stream* st, void* slot);
+static void staged_drop(void* slot);
 static int pending_back(skx_stream* st, PendingBatch* younger) {
     PendingBatch g[kGroupMax];
     const int n = st->n_pend;
     for (int i = 0; i < n; ++i) g[i] = st->pend[i];
     st->n_pend = 0;
     if (n == 0) return SKX_OK;
-    SKXCHK(batch_back_group(st, g, n, younger));
-    for (int i = 0; i < n; ++i) SKXCHK(staged_rows(st, g[i].slot));
-    return SKX_OK;
+    // (a group that went batch by batch may fail at batch i: batches 0 .. i - 1 are scored, their rows must still reach the
+    // host; the slots of the others are marked so that skx_stream_wait reports the loss instead of returning stale rows)
+    int done = 0;
+    int rc = batch_back_group(st, g, n, younger, &done);
+    const std::string msg = rc != SKX_OK ? g_err : std::string();
+    for (int i = 0; i < done; ++i) {
+        const int r2 = staged_rows(st, g[i].slot);
+        if (rc == SKX_OK && r2 != SKX_OK) rc = r2;
+    }
+    for (int i = done; i < n; ++i) staged_drop(g[i].slot);
+    if (!msg.empty()) g_err = msg;
+    return rc;
 }
 static int flush_pending(skx_stream* st) { return pending_back(st, nullptr); }
 // sketch + score + rank a batch already resident on the device, both halves (synchronous entry points).
@@ -1840,18 +2040,22 @@ static int enqueue_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     nw.pairable = st->coalesce >= 2;
     // (host-fed batches: every batch waiting for its group holds a staging slot -- bases, offsets, rows -- so groups stay at four)
     nw.max_group = slot ? std::min<u32>(st->coalesce, kStagedGroupMax) : st->coalesce;
+    SKX_MARK("enqueue: begin", st->n_pend);
     SKXCHK(batch_front(st, nw));
+    SKX_MARK("enqueue: front queued, gi", nw.gi);
     int rc = SKX_OK;
     if (nw.gi == 0) rc = pending_back(st, &nw);  // (it joined nobody: the batches waiting are complete)
     if (rc != SKX_OK) {
         const std::string msg = g_err;
         (void)cancel_speculation(st, nw);
+        staged_drop(slot);
         (void)hipStreamSynchronize(st->hs0);
         (void)hipStreamSynchronize(st->hs1);
         g_err = msg + " (a batch enqueued earlier; the batches enqueued after it were dropped too)";
         return rc;
     }
     st->pend[st->n_pend++] = nw;
+    SKX_MARK("enqueue: end", st->n_pend);
     return SKX_OK;
 }
 
@@ -1934,6 +2138,9 @@ static int staged_rows(skx_stream* st, void* slot) {
     sl.in_flight = true;
     return SKX_OK;
 }
+static void staged_drop(void* slot) {
+    if (slot) static_cast<skx_stream::Staged*>(slot)->dropped = true;
+}
 // front half of the slot's batch (and the back half of the one before it)
 static int staged_process(skx_stream* st, skx_stream::Staged& sl) {
     if (!sl.pending) return SKX_OK;
@@ -1993,7 +2200,7 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     HIPCHK(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st->hs_copy));
     if (n_bases) HIPCHK(hipMemcpyAsync(sl.d_bases, bases + byte0, n_bytes, hipMemcpyHostToDevice, st->hs_copy));
     HIPCHK(hipEventRecord(sl.ev_copy, st->hs_copy));
-    sl.pending = true; sl.n_reads = n_reads; sl.n_bases = n_bases; sl.out_idx = topk_idx; sl.out_sum = reinterpret_cast<u64*>(topk_sum);
+    sl.pending = true; sl.dropped = false; sl.n_reads = n_reads; sl.n_bases = n_bases; sl.out_idx = topk_idx; sl.out_sum = reinterpret_cast<u64*>(topk_sum);
     sl.ticket = st->next_ticket;
     if (ticket) *ticket = st->next_ticket;
     st->next_ticket += 1;
@@ -2011,6 +2218,8 @@ SKX_API int skx_stream_wait(skx_stream* st, uint64_t ticket) {
         if (older.pending && older.ticket == t) SKXCHK(staged_process(st, older));
     }
     SKXCHK(staged_finish(st, sl));
+    if (sl.dropped) return fail(SKX_ERR_INVALID, "batch %llu was dropped: a batch submitted before it failed, its rows were never written",
+                                (unsigned long long)ticket);
     if (st->profiling) collect_spans(st);
     return SKX_OK;
 }
@@ -2057,6 +2266,7 @@ SKX_API int skx_stream_sync(skx_stream* st) {
     HIPCHK(hipStreamSynchronize(st->hs));
     HIPCHK(hipStreamSynchronize(st->hs2));
     if (st->profiling) collect_spans(st);
+    dump_marks();
     return SKX_OK;
 }
 
@@ -2270,6 +2480,39 @@ static int rccl_load() {
     return SKX_OK;
 }
 struct skx_comm { int device; int rank, n_ranks; ncclComm_t comm; };
+
+// RCCL's bring-up and its collectives block for ever when a peer never arrives (a rank that died, a wrong id, a fabric that
+// does not come up): on a node where N ranks meet for the first time that is a job hanging until somebody's wall clock kills
+// it.  With the option "comm_timeout_ms" set, the two calls that can block -- ncclCommInitRank and the all-reduce with its
+// stream synchronisation -- run under a watchdog thread that, when the call has not returned in time, says which rank was
+// stuck in what and ends the PROCESS with exit code SKX_COMM_TIMEOUT_EXIT (86).  A hung collective cannot be cancelled and
+// the communicator is unusable afterwards; ending the rank lets the launcher tear the job down (never a re-exec: the process
+// has initialised the GPU).  Off by default: a library does not exit its host unasked.
+struct CommWatchdog {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    CommWatchdog(u64 ms, const char* what, int rank, int n_ranks, int device) {
+        if (!ms) return;
+        th = std::thread([this, ms, what, rank, n_ranks, device] {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!cv.wait_for(lk, std::chrono::milliseconds(ms), [this] { return done; })) {
+                fprintf(stderr, "[sketchy-hip] rank %d of %d (device %d): %s did not return within %llu ms (option comm_timeout_ms) -- "
+                                "a peer is missing or the fabric is down; exiting with code %d\n",
+                        rank, n_ranks, device, what, (unsigned long long)ms, SKX_COMM_TIMEOUT_EXIT);
+                fflush(stderr);
+                _exit(SKX_COMM_TIMEOUT_EXIT);
+            }
+        });
+    }
+    ~CommWatchdog() {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); done = true; }
+        cv.notify_all();
+        th.join();
+    }
+};
 static_assert(sizeof(ncclUniqueId) == SKX_COMM_ID_BYTES, "RCCL unique id size");
 
 SKX_API int skx_comm_unique_id(uint8_t id[SKX_COMM_ID_BYTES]) {
@@ -2290,7 +2533,11 @@ SKX_API int skx_comm_create(skx_comm** out, int device, int rank, int n_ranks, c
     ncclUniqueId u;
     memcpy(&u, id, SKX_COMM_ID_BYTES);
     ncclComm_t c;
-    ncclResult_t r = g_rccl.CommInitRank(&c, n_ranks, u, rank);
+    ncclResult_t r;
+    {
+        CommWatchdog wd(g_comm_timeout_ms, "ncclCommInitRank", rank, n_ranks, device);
+        r = g_rccl.CommInitRank(&c, n_ranks, u, rank);
+    }
     if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     *out = new skx_comm{device, rank, n_ranks, c};
     return SKX_OK;
@@ -2313,6 +2560,7 @@ SKX_API int skx_stream_allreduce(skx_stream* st, skx_comm* comm) {
     SKXCHK(flush_pending(st));  // (an enqueued batch whose passes are still to be queued belongs to the table)
     // one sum all-reduce of the u64 table (8*N bytes: latency-bound); in place
     // (the padded table: padding entries are 0 on every rank)
+    CommWatchdog wd(g_comm_timeout_ms, "ncclAllReduce of the running table", comm->rank, comm->n_ranks, comm->device);
     ncclResult_t r = g_rccl.AllReduce(st->d_cum, st->d_cum, st->ref->n_pad, ncclUint64, ncclSum, comm->comm, st->hs2);
     if (r != ncclSuccess) return fail(SKX_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     HIPCHK(hipStreamSynchronize(st->hs2));

@@ -136,6 +136,58 @@ __host__ __device__ __forceinline__ u64 murmur3_h1_16(u64 w0, u64 w1, u64 seed) 
     return h1 + h2;
 }
 
+// the same from the two FIRST-STAGE PRODUCTS p1 = w0 * c1 and p2 = w1 * c2 (mod 2^64): the k = 16 wave sketcher gets them out
+// of an LDS table indexed by the canonical k-mer's 2-bit code (sketch_mul_tables, skx_kernels.hip) instead of multiplying
+template <bool SEED0>
+__host__ __device__ __forceinline__ u64 murmur3_h1_16_pre(u64 p1, u64 p2, u64 seed) {
+    const u64 c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+    u64 k1 = rotl64c<31>(p1) * c2;
+    u64 k2 = rotl64c<33>(p2) * c1;
+    u64 h1, h2;
+    if (SEED0) {
+        h1 = rotl64c<27>(k1);
+        h1 = mul5(h1) + 0x52dce729ull;
+        h2 = rotl64c<31>(k2) + h1;
+    } else {
+        h1 = rotl64c<27>(seed ^ k1) + seed;
+        h1 = mul5(h1) + 0x52dce729ull;
+        h2 = rotl64c<31>(seed ^ k2) + h1;
+    }
+    h2 = mul5(h2) + 0x38495ab5ull;
+    h1 ^= 16u; h2 ^= 16u;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    return h1 + h2;
+}
+
+// ... stopping one step short: x1, x2 with murmur3_h1_16_pre = f(x1) + f(x2), f(x) = x ^ (x >> 33) -- fmix64's last xor-shift,
+// which only touches the LOW word.  The high word of the hash is hi(x1) + hi(x2) (+ a carry), so a sketcher that only keeps
+// hashes up to some bound can tell from ONE 32-bit add whether a lane can be in range at all, and finish the hash
+// (murmur3_finish_pair) for the few that can.
+template <bool SEED0>
+__host__ __device__ __forceinline__ void murmur3_h1_16_pre_split(u64 p1, u64 p2, u64 seed, u64& x1, u64& x2) {
+    const u64 c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+    u64 k1 = rotl64c<31>(p1) * c2;
+    u64 k2 = rotl64c<33>(p2) * c1;
+    u64 h1, h2;
+    if (SEED0) {
+        h1 = rotl64c<27>(k1);
+        h1 = mul5(h1) + 0x52dce729ull;
+        h2 = rotl64c<31>(k2) + h1;
+    } else {
+        h1 = rotl64c<27>(seed ^ k1) + seed;
+        h1 = mul5(h1) + 0x52dce729ull;
+        h2 = rotl64c<31>(seed ^ k2) + h1;
+    }
+    h2 = mul5(h2) + 0x38495ab5ull;
+    h1 ^= 16u; h2 ^= 16u;
+    h1 += h2; h2 += h1;
+    h1 ^= h1 >> 33; h1 *= 0xff51afd7ed558ccdull; h1 ^= h1 >> 33; h1 *= 0xc4ceb9fe1a85ec53ull;
+    h2 ^= h2 >> 33; h2 *= 0xff51afd7ed558ccdull; h2 ^= h2 >> 33; h2 *= 0xc4ceb9fe1a85ec53ull;
+    x1 = h1; x2 = h2;
+}
+__host__ __device__ __forceinline__ u64 murmur3_finish_pair(u64 x1, u64 x2) { return (x1 ^ (x1 >> 33)) + (x2 ^ (x2 >> 33)); }
+
 // ---------------------------------------------------------------- membership filter
 // Blocked Bloom filter over the reference's DISTINCT hashes: 64-bit words, word = h >> shift (hashes are uniform up to the
 // largest reference hash, so position in that range needs no hash function), four bit positions inside the word from

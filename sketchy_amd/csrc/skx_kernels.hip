@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "skx_common.hpp"
 #include "skx_kernels.hpp"
@@ -125,6 +126,10 @@ __global__ __launch_bounds__(256) void band_bounds_kernel(const u64* __restrict_
 //   HCAP = kSketchCap  -> `big`   (redone by sketch_block_kernel, which holds 16 384 hashes and selects in passes)
 // !INRANGE (full sketches: debug outputs, skx_sketch_reads): reads with more than kSketchCap k-mers go to `big` at once.
 constexpr u32 kSketchRetry = 0xFFFFFFFFu;
+// hash slots per read of the in-range fast variant (production keeps ~8 in-range hashes per 1.5 kb read; a read with more goes
+// to the 2048-slot variant through the retry list).  128 since round 4: with the 4 KB of product tables per workgroup 256
+// slots cost the kernel a workgroup per CU -- 17.2 KB instead of 23.3 KB: 8 per CU alone, 4 beside the scan's LDS pad.
+constexpr int kSketchSmallHashes = 128;
 // Row pool (sketch_finish, pool mode): kPoolParts sub-pools, each with its own bump counter on its own cache line behind the 16
 // words of chk (chk[16 + 16 i]); a workgroup uses sub-pool blockIdx.x % kPoolParts.  (ONE counter serialised the batch:
 // 98 304 same-address atomics at ~10 ns each are 1 ms -- twice the sketch kernel -- measured as 48 -> 37 M reads/s for a
@@ -152,13 +157,66 @@ __device__ __forceinline__ void fill_base_lut(unsigned char* lut) {
         lut[i] = (unsigned char)(c == 5u ? 0x80u : c);
     }
 }
+// First-stage products of murmur3 for k = 16, out of LDS instead of the multiplier (round 4).  The 16 key bytes are ASCII
+// bases, so murmur3's k1 * c1 and k2 * c2 are sums over FOUR bases at a time: with W(i) = the little-endian word of the four
+// bases whose 2-bit codes form byte i (first base in the two highest bits, as in the rolling windows),
+//     k1 * c1 = W(lo) * c1 + ((W(hi) * c1) << 32)    (mod 2^64; lo / hi = bases 0-3 / 4-7, likewise k2 * c2 with bases 8-15)
+// i.e. t1[lo] + (low word of t1[hi] << 32) from a 256-entry table of 64-bit products: two LDS reads and one 32-bit add on the
+// otherwise idle DS pipe instead of four quarter-rate multiplier instructions (v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3: ~21 issue
+// cycles, profiles/r03f_mul_rates.txt) -- and the index is the CANONICAL 2-bit window the loop rolls anyway, so the rolling
+// 16-byte ASCII blocks of both strands (eight v_alignbit / v_perm per k-mer) and the four v_cndmask that picked one are gone
+// too: ~100 -> ~78 VALU instructions per 64 k-mers.
+#ifndef SKX_SK_LOTAB
+#define SKX_SK_LOTAB 1  /* the 32-bit halves of the products from compact tables of their own (conflicts: below) */
+#endif
+#ifndef SKX_SK_EARLY
+#define SKX_SK_EARLY 1  /* in-range test on the hash's high word before its low word is finished (sketch_one_read) */
+#endif
+template <int KT>
+struct SketchTables {
+    unsigned char lut[256];
+    u64 t1[KT == 16 ? 256 : 1];  // W(i) * c1
+    u64 t2[KT == 16 ? 256 : 1];  // W(i) * c2
+    // the low words again, packed: a 4-byte read out of the 8-byte entries above only ever touches the even banks (ds_read_b32
+    // banks = (a / 4) mod 32: 32 random lanes on 16 banks, ~5 deep; on all 32, ~3.4)
+    u32 t1lo[(KT == 16 && SKX_SK_LOTAB) ? 256 : 1];
+    u32 t2lo[(KT == 16 && SKX_SK_LOTAB) ? 256 : 1];
+};
+template <int KT>
+__device__ __forceinline__ void fill_sketch_tables(SketchTables<KT>* tb) {
+    fill_base_lut(tb->lut);
+    if constexpr (KT == 16) {
+        for (u32 i = threadIdx.x; i < 256u; i += blockDim.x) {
+            const u32 sel = ((i >> 6) & 3u) | (((i >> 4) & 3u) << 8) | (((i >> 2) & 3u) << 16) | ((i & 3u) << 24);
+            const u64 w = (u64)__builtin_amdgcn_perm(0u, 0x54474341u, sel);  // "ACGT"[selector byte]
+            tb->t1[i] = w * 0x87c37b91114253d5ull;
+            tb->t2[i] = w * 0x4cf5ad432745937full;
+#if SKX_SK_LOTAB
+            tb->t1lo[i] = (u32)(w * 0x87c37b91114253d5ull);
+            tb->t2lo[i] = (u32)(w * 0x4cf5ad432745937full);
+#endif
+        }
+    }
+}
+// byte `BYTE` of x, shifted left by SH (the byte offset of a table entry of 1 << SH bytes): one SDWA instruction
+template <int BYTE, u32 SH>
+__device__ __forceinline__ u32 byte_shl(u32 x) {
+    u32 r;
+    if constexpr (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(SH), "v"(x));
+    else if constexpr (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(SH), "v"(x));
+    else if constexpr (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(SH), "v"(x));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(SH), "v"(x));
+    return r;
+}
 // normalise raw bytes [from, to) of the read into codes[nb ...]; returns the new end.  Four bytes per lane: one dword
 // load, four table reads, and -- as long as nothing has been removed and the end is word-aligned (the usual case: reads
 // hold no whitespace) -- one word store: ~4 VALU instructions per 64 bases instead of ~22 for the byte-at-a-time
 // classification (measured: the sketch kernel is VALU-bound and a third of its instructions were outside the hash loop).
 // A group of 256 bytes with a removed byte in it, and everything behind it in this call, is compacted byte by byte.
+// `bad` collects (per lane) the invalid-code bits (bit 2 of a byte) of everything normalised: a chunk without any lets the
+// hash loop drop its per-window validity tracking (sketch_one_read)
 __device__ __forceinline__ u32 wave_normalise4(const uint8_t* __restrict__ rd, u32 from, u32 to, uint8_t* codes, u32 nb,
-                                               u32 lane, const unsigned char* lut) {
+                                               u32 lane, const unsigned char* lut, u32& bad) {
     bool packed = (nb & 3u) == 0u;  // wave-uniform
     for (u32 base = from; base < to; base += 256u) {
         const u32 idx = base + 4u * lane;
@@ -171,6 +229,7 @@ __device__ __forceinline__ u32 wave_normalise4(const uint8_t* __restrict__ rd, u
         }
         const u32 w = (u32)lut[x & 0xFFu] | ((u32)lut[(x >> 8) & 0xFFu] << 8) | ((u32)lut[(x >> 16) & 0xFFu] << 16) |
                       ((u32)lut[x >> 24] << 24);
+        bad |= w & 0x04040404u;  // (absent bytes are 'A': code 0; removed bytes are 0x80)
         if (packed && __ballot((w & 0x80808080u) != 0u) == 0ull) {
             uint8_t* dst = codes + nb + 4u * lane;
             if (have == 4u) *reinterpret_cast<u32*>(dst) = w;
@@ -200,7 +259,7 @@ __device__ __forceinline__ u32 packed_code(const uint8_t* __restrict__ bases, u6
 }
 // wave_normalise4 for packed input: bases [nib0 + from, nib0 + to) -> codes[nb ...] (nb a multiple of 4: whole words)
 __device__ __forceinline__ u32 wave_normalise_packed(const uint8_t* __restrict__ bases, u64 nib0, u32 from, u32 to, uint8_t* codes,
-                                                     u32 nb, u32 lane) {
+                                                     u32 nb, u32 lane, u32& bad) {
     for (u32 base = from; base < to; base += 256u) {
         const u32 idx = base + 4u * lane;
         const u32 have = idx < to ? min(4u, to - idx) : 0u;
@@ -221,6 +280,7 @@ __device__ __forceinline__ u32 wave_normalise_packed(const uint8_t* __restrict__
             w = (x & 0xFu) | ((x & 0xF0u) << 4) | ((x & 0xF00u) << 8) | ((x & 0xF000u) << 12);
             const u32 inv = ((w >> 1) | w) & 0x04040404u;  // nibble > 3
             w = ((w & 0x03030303u) & ~((inv >> 2) * 3u)) | inv;
+            bad |= inv;  // (w holds exactly the `have` nibbles of the read: the rest is zero)
         }
         uint8_t* dst = codes + nb + 4u * lane;
         if (have == 4u) *reinterpret_cast<u32*>(dst) = w;
@@ -461,18 +521,19 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                                                 u64* __restrict__ out_sk, u32 sk_stride, u32* __restrict__ out_len,
                                                 u32* __restrict__ out_cnt_in, u32* __restrict__ retry, u32* __restrict__ big,
                                                 const u64* __restrict__ filt, u32 filt_shift, u64 n_bases,
-                                                u32* __restrict__ chk, const unsigned char* lut, bool packed,
+                                                u32* __restrict__ chk, const SketchTables<KT>* tb, bool packed,
                                                 bool split_long = false, u32 seg_i = 0, u64* __restrict__ seg_h = nullptr,
                                                 u32* __restrict__ seg_cnt = nullptr, KmerFilter kf = KmerFilter{nullptr, 0u},
                                                 u32 pool_cap = 0, u32 pool_fixed = 0) {
     static_assert(!SEG || INRANGE, "segments exist in production mode only");
     constexpr u32 CAP = kSketchCap;
-    constexpr u32 kPerWave = HCAP * 8 + CAP + 128 + kPfQueue * 4;  // (32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding; the prefilter's queue)
+    constexpr u32 kPerWave = HCAP * 8 + CAP + 128;  // (hash slots; 32: carry of k-1 codes, ending word-aligned; a chunk; 64 codes of padding)
     constexpr u32 kChunkAt = 32;                    // a chunk's codes start here; the carried k-1 end here
     const u32 wv = threadIdx.x >> 6, lane = lane_id();
     u64* hashes = reinterpret_cast<u64*>(smem + (size_t)wv * kPerWave);
     uint8_t* codes = smem + (size_t)wv * kPerWave + HCAP * 8;
-    u32* pq = reinterpret_cast<u32*>(smem + (size_t)wv * kPerWave + HCAP * 8 + CAP + 128);  // the prefilter's survivors
+    // the prefilter's survivors: behind all waves' buffers, and only there when the launch carries a k-mer filter (launch_sketch)
+    u32* pq = reinterpret_cast<u32*>(smem + (size_t)(blockDim.x >> 6) * kPerWave + (size_t)wv * kPfQueue * 4);
     const u32 k = KT > 0 ? (u32)KT : k_rt;
     const u64 o0 = offsets[r], o1 = offsets[r + 1];
     // the caller vouches for n_bases bytes from offsets[0] on: a read reaching outside is never touched (flagged in
@@ -498,6 +559,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     }
     const uint8_t* rd = bases + o0;
     const u64 lt = lanemask_lt();
+    const unsigned char* lut = tb->lut;
     // (reads beyond kLongSplit only get here when they are not split: full sketches, the 2048-slot retry variant)
     if (lraw > 4u * CAP) __builtin_amdgcn_s_setprio(2);
 
@@ -510,7 +572,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
     // everything below the ballot)
     auto append = [&](bool valid, u64 h) {
         if (INRANGE) valid = valid && (h <= max_ref);
-        const u64 mask = __ballot(valid);
+        const u64 mask = __builtin_amdgcn_ballot_w64(valid);
         if (mask) {
             const u32 cnt = (u32)__popcll(mask);
             const u32 over = __builtin_amdgcn_readfirstlane(m + cnt > (u32)HCAP ? 1u : 0u);
@@ -520,7 +582,20 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         }
     };
 
+    // the same with the validity as a wave mask (production: the in-range test is the only per-lane compare left)
+    auto append_masked = [&](u64 vmask, u64 h) {
+        const u64 mask = INRANGE ? (vmask & __builtin_amdgcn_ballot_w64(h <= max_ref)) : vmask;
+        if (mask) {
+            const u32 cnt = (u32)__popcll(mask);
+            const u32 over = __builtin_amdgcn_readfirstlane(m + cnt > (u32)HCAP ? 1u : 0u);
+            ovf |= over;
+            if (!over && ((mask >> lane) & 1ull)) hashes[m + __popcll(mask & lt)] = h;
+            m = __builtin_amdgcn_readfirstlane(m + cnt);
+        }
+    };
+
     u32 carry = 0;  // codes kept from the previous chunk at codes[kChunkAt - carry .. kChunkAt)
+    bool carry_bad = false;  // ... one of them is not a base (wave-uniform)
     u32 cbase0 = 0;
     if constexpr (SEG) {
         cbase0 = seg_i * CAP;
@@ -532,7 +607,9 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
             // the last k-1 RETAINED codes in front of the chunk (what the serial loop would have carried to here)
             const u32 want = k - 1u;
             if (packed) {  // (no whitespace in this format: the k-1 nibbles in front)
-                if (lane < want) codes[kChunkAt - want + lane] = (uint8_t)packed_code(bases, o0 + cbase0 - want + lane);
+                const u32 pc = lane < want ? packed_code(bases, o0 + cbase0 - want + lane) : 0u;
+                if (lane < want) codes[kChunkAt - want + lane] = (uint8_t)pc;
+                carry_bad = __builtin_amdgcn_ballot_w64(pc > 3u) != 0ull;
                 carry = want;  // (cbase0 >= CAP > k - 1)
             } else {
                 u32 got = 0;
@@ -545,6 +622,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                     const u64 above = lane == 63u ? 0ull : (~0ull << (lane + 1u));
                     const u32 rk = got + (u32)__popcll(km & above);  // retained codes between this byte and the chunk
                     if (kept && rk < want) codes[kChunkAt - 1u - rk] = (uint8_t)c;
+                    carry_bad = carry_bad || __builtin_amdgcn_ballot_w64(kept && rk < want && c > 3u) != 0ull;
                     got = __builtin_amdgcn_readfirstlane(min(want, got + (u32)__popcll(km)));
                     end = beg;
                 }
@@ -557,8 +635,15 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         const u32 cend = min(lraw, cbase + CAP);
         // 1. normalise the chunk behind the carried codes
         const u32 cs = kChunkAt - carry;  // first code of the buffer
-        const u32 ne = __builtin_amdgcn_readfirstlane(packed ? wave_normalise_packed(bases, o0, cbase, cend, codes, kChunkAt, lane)
-                                                             : wave_normalise4(rd, cbase, cend, codes, kChunkAt, lane, lut));  // one past the last
+        u32 bad_bits = 0;
+        const u32 ne = __builtin_amdgcn_readfirstlane(packed ? wave_normalise_packed(bases, o0, cbase, cend, codes, kChunkAt, lane, bad_bits)
+                                                             : wave_normalise4(rd, cbase, cend, codes, kChunkAt, lane, lut, bad_bits));  // one past the last
+        // (no N, no IUPAC code anywhere in the buffer -- the usual case: every window inside it is valid)
+#ifdef SKX_SK_FORCE_CLEAN  /* diagnostic builds only (instruction counts of the specialisation on reads known to be clean) */
+        const bool all_bases = true;
+#else
+        const bool all_bases = !carry_bad && __builtin_amdgcn_ballot_w64(bad_bits != 0u) == 0ull;
+#endif
         codes[ne + lane] = 4;  // 64 invalid codes behind the chunk: lanes past the last window read them unconditionally
         wave_sync();
         // 2. canonical k-mer hashes of the windows that END in this chunk, compacted
@@ -571,37 +656,28 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
             const u32 run = __builtin_amdgcn_readfirstlane((nk + 63u) / 64u);
             const u32 p0 = cs + lane * run;
             u32 fwd = 0, rc = 0;            // 16 bases x 2 bits: forward (first base highest) / reverse complement
-            u32 f0 = 0, f1 = 0, f2 = 0, f3 = 0;  // the 16 ASCII bytes of the forward k-mer, first base in the lowest byte
-            u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // ... of its reverse complement
             u32 clean = 0;                  // consecutive valid bases ending at the newest one
-            auto push = [&](u32 c) {
-                clean = (c >> 2) ? 0u : clean + 1u;
-                c &= 3u;
-                fwd = (fwd << 2) | c;
-                rc = __builtin_amdgcn_alignbit(c ^ 3u, rc, 2);        // (rc >> 2) | (complement << 30)
-                const u32 a = (0x54474341u >> (8u * c)) & 0xFFu;   // "ACGT"[c]
-                const u32 ca = (0x41434754u >> (8u * c)) & 0xFFu;  // complement: "TGCA"[c]
-                // one byte per step: the forward window drops its lowest byte and takes the new base on top, the reverse
-                // complement shifts up and takes the complement at the bottom (v_alignbit_b32 each)
-                f0 = __builtin_amdgcn_alignbit(f1, f0, 8);
-                f1 = __builtin_amdgcn_alignbit(f2, f1, 8);
-                f2 = __builtin_amdgcn_alignbit(f3, f2, 8);
-                f3 = __builtin_amdgcn_alignbit(a, f3, 8);
-                r3 = __builtin_amdgcn_alignbit(r3, r2, 24);
-                r2 = __builtin_amdgcn_alignbit(r2, r1, 24);
-                r1 = __builtin_amdgcn_alignbit(r1, r0, 24);
-                r0 = (r0 << 8) | ca;
-            };
+            // (rounds 1-3 also rolled the 16 ASCII bytes of both strands -- the murmur3 block; the first-stage products now
+            // come out of the tables indexed by the canonical 2-bit window: SketchTables)
+            const unsigned char* t1b = reinterpret_cast<const unsigned char*>(tb->t1);
+            const unsigned char* t2b = reinterpret_cast<const unsigned char*>(tb->t2);
+#if SKX_SK_LOTAB
+            const unsigned char* t1l = reinterpret_cast<const unsigned char*>(tb->t1lo);
+            const unsigned char* t2l = reinterpret_cast<const unsigned char*>(tb->t2lo);
+            constexpr u32 kLoShift = 2;
+#else
+            const unsigned char *t1l = t1b, *t2l = t2b;
+            constexpr u32 kLoShift = 3;
+#endif
             if (nk) {
                 // (a window that reaches past the chunk takes in padding codes, which reset `clean`: no bounds tests --
                 // positions are clamped into the padded buffer, p0 + t + 15 <= nb + 63 whenever the window can be valid)
                 const u32 lim = ne + 63u;
-                // Window state after the first 15 codes of the run, straight from the code bytes (15 push() calls cost
-                // ~285 instructions per chunk, this ~85): five aligned words funnel-shifted to the run's start; ASCII
-                // blocks by v_perm_b32 table lookups (4 codes per instruction), the reverse complement through a byte
-                // swap of the selectors; the 2-bit packings and the validity bits by multiplications that gather one
-                // field per byte into the top byte (fields never overlap: no carries).  A run that starts in the padding
-                // is clamped into it (every window it sees is invalid either way).
+                // Window state after the first 15 codes of the run, straight from the code bytes (15 rolling steps cost
+                // ~150 instructions per chunk, this ~45): five aligned words funnel-shifted to the run's start; the 2-bit
+                // packings and the validity bits by multiplications that gather one field per byte into the top byte
+                // (fields never overlap: no carries).  A run that starts in the padding is clamped into it (every window
+                // it sees is invalid either way).
                 {
                     const u32 al = min(p0 & ~3u, (ne + 44u) & ~3u);
                     const u32* cw = reinterpret_cast<const u32*>(codes + al);
@@ -610,22 +686,6 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                     const u32 b0 = __builtin_amdgcn_alignbyte(w1, w0, sh), b1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
                     const u32 b2 = __builtin_amdgcn_alignbyte(w3, w2, sh), b3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
                     const u32 x0 = b0 & 0x03030303u, x1 = b1 & 0x03030303u, x2 = b2 & 0x03030303u, x3 = b3 & 0x03030303u;
-                    // forward: bytes 1..15 = "ACGT"[c_0 .. c_14]
-                    const u32 a0 = __builtin_amdgcn_perm(0u, 0x54474341u, x0), a1 = __builtin_amdgcn_perm(0u, 0x54474341u, x1);
-                    const u32 a2 = __builtin_amdgcn_perm(0u, 0x54474341u, x2), a3 = __builtin_amdgcn_perm(0u, 0x54474341u, x3);
-                    f0 = a0 << 8;
-                    f1 = __builtin_amdgcn_alignbit(a1, a0, 24);
-                    f2 = __builtin_amdgcn_alignbit(a2, a1, 24);
-                    f3 = __builtin_amdgcn_alignbit(a3, a2, 24);
-                    // reverse complement: byte 14 - j = "TGCA"[c_j]
-                    const u32 m0 = __builtin_amdgcn_perm(0u, 0x41434754u, __builtin_amdgcn_perm(x0, x0, 0x00010203u));
-                    const u32 m1 = __builtin_amdgcn_perm(0u, 0x41434754u, __builtin_amdgcn_perm(x1, x1, 0x00010203u));
-                    const u32 m2 = __builtin_amdgcn_perm(0u, 0x41434754u, __builtin_amdgcn_perm(x2, x2, 0x00010203u));
-                    const u32 m3 = __builtin_amdgcn_perm(0u, 0x41434754u, __builtin_amdgcn_perm(x3, x3, 0x00010203u));
-                    r0 = __builtin_amdgcn_alignbit(m2, m3, 8);
-                    r1 = __builtin_amdgcn_alignbit(m1, m2, 8);
-                    r2 = __builtin_amdgcn_alignbit(m0, m1, 8);
-                    r3 = m0 >> 8;
                     // 2-bit packings: fwd = sum c_j << 2 (14 - j), rc = sum (3 - c_j) << (2 + 2 j), j = 0..14
                     constexpr u32 kF = 0x40100401u, kR = 0x01041040u;
                     const u32 fw16 = (((x0 * kF) >> 24) << 24) | (((x1 * kF) >> 24) << 16) | (((x2 * kF) >> 24) << 8) | ((x3 * kF) >> 24);
@@ -683,15 +743,71 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
                     }
                     test(pvalid, pword, pmix, pcanon);
                     if (qn) drain();
-                } else
-                for (u32 t = 0; t < run; ++t) {
-                    const u32 ccur = cnext;
-                    cnext = codes[min(p0 + t + 16u, lim)];
-                    push(ccur);
-                    const bool use_f = fwd < rc;
-                    const u64 w0 = make_u64(use_f ? f0 : r0, use_f ? f1 : r1), w1 = make_u64(use_f ? f2 : r2, use_f ? f3 : r3);
-                    const u64 h = seed == 0 ? murmur3_h1_16<true>(w0, w1, 0) : murmur3_h1_16<false>(w0, w1, seed);
-                    append(clean >= 16u, h);
+                } else {
+                    // One k-mer per lane and iteration, software-pipelined by hand: the table reads of window t + 1 are issued
+                    // before window t goes through murmur3 (their LDS latency hides under its ~60 instructions).  Two
+                    // specialisations, both wave-uniform: the seed (0 = sketchy's default folds two xors and an add away)
+                    // and `all_bases` (no invalid code in the whole buffer: a window is valid iff it lies inside it -- one
+                    // compare against the lane's window count instead of the four-instruction run-length counter).
+                    const unsigned char* cp = codes + p0 + 16u;  // (p0 + t + 16 <= ne + 63 for every lane and t < run: inside the padding)
+                    // (hash <= max_ref needs hi(hash) <= hi(max_ref); hi(hash) = hi(x1) + hi(x2) + carry: in range only if that sum
+                    // + 1 lies in [0, hi(max_ref) + 1] modulo 2^32 -- with hi(max_ref) all ones or all ones but one every lane passes)
+                    const u32 max_hi = (u32)(max_ref >> 32), max_hi1 = max_hi == 0xFFFFFFFFu ? max_hi : max_hi + 1u;
+                    const u32 mine = nk > lane * run ? nk - lane * run : 0u;  // windows of this lane's run that lie inside the buffer
+                    auto hash_run = [&](auto seed0_c, auto clean_c) {
+                        constexpr bool SEED0 = decltype(seed0_c)::value, CLEAN = decltype(clean_c)::value;
+                        u64 a = 0, b = 0;
+                        u32 ah = 0, bh = 0;
+                        u64 vnext = 0;  // lanes whose window is valid, as a wave mask (kept scalar: it meets the in-range ballot with one s_and)
+                        auto advance = [&](u32 t) {  // window t: roll it in, request its products
+                            const u32 ccur = cnext;
+                            cnext = cp[t];
+                            if constexpr (CLEAN) {
+                                // (the only codes above 3 are the padding behind the buffer: they spoil windows that are
+                                // invalid by position, in this lane's run and nobody else's -- no masking)
+                                vnext = __builtin_amdgcn_ballot_w64(t < mine);
+                                fwd = (fwd << 2) | ccur;
+                            } else {
+                                clean = (ccur >> 2) ? 0u : clean + 1u;
+                                vnext = __builtin_amdgcn_ballot_w64(clean >= 16u);
+                                fwd = (fwd << 2) | (ccur & 3u);
+                            }
+                            rc = __builtin_amdgcn_alignbit(~ccur, rc, 2);  // (rc >> 2) | (complement << 30): the low two bits of ~code
+                            // canonical = bytewise min(forward, reverse complement) = the smaller 2-bit packing (A < C < G < T;
+                            // a palindrome: the same bytes either way); its four bytes index the product tables
+                            const u32 canon = min(fwd, rc);
+                            a = *reinterpret_cast<const u64*>(t1b + byte_shl<3, 3>(canon));
+                            ah = *reinterpret_cast<const u32*>(t1l + byte_shl<2, kLoShift>(canon));
+                            b = *reinterpret_cast<const u64*>(t2b + byte_shl<1, 3>(canon));
+                            bh = *reinterpret_cast<const u32*>(t2l + byte_shl<0, kLoShift>(canon));
+                        };
+                        advance(0u);
+                        auto finish = [&](u32 t) {  // window t through murmur3 while window t + 1 is on its way
+                            const u64 p1 = make_u64((u32)a, (u32)(a >> 32) + ah), p2 = make_u64((u32)b, (u32)(b >> 32) + bh);
+                            const u64 vcur = vnext;
+                            advance(t + 1u);  // (one window past the run at the end: harmless -- padding codes, any table index is inside the table)
+                            if constexpr (INRANGE && SKX_SK_EARLY) {
+                                // production keeps hashes <= max_ref only -- 0.4 % of them: stop in front of fmix64's last
+                                // xor-shift (it touches the low word only), bound the hash's high word with one add, and
+                                // finish the low word for the lanes that can be in range (one iteration in five has any)
+                                u64 x1, x2;
+                                murmur3_h1_16_pre_split<SEED0>(p1, p2, seed, x1, x2);
+                                const u32 hs1 = (u32)(x1 >> 32) + (u32)(x2 >> 32) + 1u;  // high word of the sum, + 1: the carry out of the low words is 0 or 1
+                                const u64 maybe = vcur & __builtin_amdgcn_ballot_w64(hs1 <= max_hi1);
+                                if (maybe) append_masked(maybe, murmur3_finish_pair(x1, x2));
+                            } else {
+                                append_masked(vcur, murmur3_h1_16_pre<SEED0>(p1, p2, seed));
+                            }
+                        };
+                        u32 t = 0;
+                        for (; t + 1u < run; t += 2u) { finish(t); finish(t + 1u); }  // (two per trip: the loop-carried products change registers instead of being copied)
+                        if (t < run) finish(t);
+                    };
+                    if (seed == 0) {
+                        if (all_bases) hash_run(std::true_type{}, std::true_type{}); else hash_run(std::true_type{}, std::false_type{});
+                    } else {
+                        if (all_bases) hash_run(std::false_type{}, std::true_type{}); else hash_run(std::false_type{}, std::false_type{});
+                    }
                 }
             }
         } else {
@@ -733,6 +849,7 @@ __device__ __forceinline__ void sketch_one_read(unsigned char* smem, u32 r, cons
         wave_sync();
         if (lane < keep) codes[kChunkAt - keep + lane] = (uint8_t)cv;
         carry = keep;
+        carry_bad = __builtin_amdgcn_ballot_w64(cv > 3u) != 0ull;
     }
     if constexpr (SEG) {
         // the segment's in-range hashes (unsorted, duplicates included) go to its slot; the merge wave does the rest
@@ -763,7 +880,7 @@ constexpr u32 kSegBlocks = 1024;  // x 4 waves: a C4 batch has ~28 000 segments
 #define SKX_SKETCH_ARGS \
     bases, offsets, n_reads, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len, out_cnt_in, from_list, retry, big, filt, filt_shift, n_bases, chk, lr, kf, pool_cap, pool_fixed
 template <int KT, int HCAP, bool INRANGE>
-__device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, unsigned char* lut) {
+__device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned char* smem, SketchTables<KT>* tb) {
     const bool packed = (from_list & 0x100u) != 0u;  // (bit 8: 4-bit packed input)
     from_list &= 0xFFu;
     // (whole workgroups that have nothing to do leave before the table is filled: the segment workgroups of a batch without
@@ -771,7 +888,7 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
     const bool seg_block = from_list == 2u && blockIdx.x < kSegBlocks;
     if (seg_block && chk[9] == 0u) return;
     if (from_list == 1u && retry[0] == 0u) return;
-    fill_base_lut(lut);
+    fill_sketch_tables<KT>(tb);
     __syncthreads();
     const u32 wpb = blockDim.x >> 6;  // waves per block: 4, or 1 for the list walk (see launch_sketch)
     u32 w = blockIdx.x * wpb + (threadIdx.x >> 6);
@@ -783,7 +900,7 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
                 const u32 pos = lr.seg_tab[sg];
                 if (pos >= lr.long_cap || lr.list[pos] >= n_reads || sg < lr.seg0[pos]) continue;  // (never: belt and braces)
                 sketch_one_read<KT, HCAP, true, true>(smem, lr.list[pos], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
-                                                      out_len, out_cnt_in, nullptr, nullptr, filt, filt_shift, n_bases, chk, lut,
+                                                      out_len, out_cnt_in, nullptr, nullptr, filt, filt_shift, n_bases, chk, tb,
                                                       packed, true, sg - lr.seg0[pos], lr.seg_h + (size_t)sg * kSegSlots,
                                                       lr.seg_cnt + sg, kf, pool_cap, pool_fixed);
                 wave_sync();  // the wave's LDS region is reused by its next segment
@@ -795,14 +912,14 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
     if (from_list != 1u) {
         if (w < n_reads)
             sketch_one_read<KT, HCAP, INRANGE>(smem, w, bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride, out_len,
-                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, lut, packed,
+                                               out_cnt_in, retry, big, filt, filt_shift, n_bases, chk, tb, packed,
                                                from_list == 2u, 0u, nullptr, nullptr, kf, pool_cap, pool_fixed);
         return;
     }
     const u32 n = retry[0];
     for (u32 i = w; i < n; i += gridDim.x * wpb) {
         sketch_one_read<KT, HCAP, INRANGE>(smem, retry[1u + i], bases, offsets, k_rt, seed, s, max_ref, out_sk, sk_stride,
-                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, lut, packed, false, 0u,
+                                           out_len, out_cnt_in, nullptr, big, filt, filt_shift, n_bases, chk, tb, packed, false, 0u,
                                            nullptr, nullptr, kf, pool_cap, pool_fixed);
         wave_sync();  // the wave's LDS region is reused by its next read
     }
@@ -810,8 +927,8 @@ __device__ __forceinline__ void sketch_wave_body(SKX_SKETCH_PARAMS, unsigned cha
 template <int KT, int HCAP, bool INRANGE>
 __global__ __launch_bounds__(256, HCAP < kSketchCap ? 8 : 2) void sketch_wave_kernel(SKX_SKETCH_PARAMS) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned char lut[256];
-    sketch_wave_body<KT, HCAP, INRANGE>(SKX_SKETCH_ARGS, smem, lut);
+    __shared__ SketchTables<KT> tb;
+    sketch_wave_body<KT, HCAP, INRANGE>(SKX_SKETCH_ARGS, smem, &tb);
 }
 // One wave per long read of a production batch (walking the list batch_check_kernel built): the segment waves' hashes are
 // gathered into the wave's LDS buffer (kSketchCap entries) and finished like any other read's.  A segment slot that
@@ -859,8 +976,8 @@ __global__ __launch_bounds__(64) void sketch_merge_kernel(const u64* __restrict_
 template <int KT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 5))) void sketch_wave_kernel_capped(SKX_SKETCH_PARAMS) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned char lut[256];
-    sketch_wave_body<KT, 256, true>(SKX_SKETCH_ARGS, smem, lut);
+    __shared__ SketchTables<KT> tb;
+    sketch_wave_body<KT, kSketchSmallHashes, true>(SKX_SKETCH_ARGS, smem, &tb);
 }
 
 // =====================================================================================
@@ -1119,6 +1236,15 @@ __global__ void batch_check_kernel(const u64* __restrict__ offsets, u32 n_reads,
 // raises a sequence number there; the host spins on it.  A blit copy + stream synchronisation for the same 36 bytes
 // cost ~100 us of idle front stream per push (kernel timeline), this costs a launch.  Also re-arms the device-side
 // counters (chk, the retry list) for the next push.
+// n (<= 64) words from device memory into page-locked host memory, by the device: what a small asynchronous device-to-host
+// copy is for -- except that hipMemcpyAsync made the HOST wait for everything queued in front of it (round 4, kernel trace: the
+// thread that queues a group's eight rankings stood at the 8-byte copy of every ranking's live counters until that ranking's
+// prefix kernels were done, and the sketch of the next batch was queued 2.7 ms late, once per group)
+// (d_src is zeroed as it is read: the counters it serves are published once per use and re-armed here, without a memset)
+__global__ void store_host_words_kernel(volatile u32* __restrict__ h_dst, u32* __restrict__ d_src, u32 n) {
+    if (blockIdx.x == 0 && threadIdx.x < n) { h_dst[threadIdx.x] = d_src[threadIdx.x]; d_src[threadIdx.x] = 0u; }
+    __threadfence_system();
+}
 __global__ void publish_kernel(u32* __restrict__ chk, u32* __restrict__ retry, u32* __restrict__ big,
                                const u32* __restrict__ total_pairs, volatile u32* __restrict__ h_pub, u32 seq,
                                const u32* __restrict__ dict_ctr) {
@@ -3205,8 +3331,7 @@ void launch_band_bounds(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 
     hipLaunchKernelGGL(band_bounds_kernel, dim3(n_tiles * n_bands), dim3(256), 0, st, mat, s, n_tiles, rb, lo, hi);
 }
 
-constexpr int kSketchSmallHashes = 256;  // hash slots per read of the in-range fast variant
-static size_t sketch_wave_lds(int hcap) { return 4 * (size_t)(hcap * 8 + kSketchCap + 128 + kPfQueue * 4); }
+static size_t sketch_wave_lds(int hcap, bool prefilter) { return 4 * (size_t)(hcap * 8 + kSketchCap + 128 + (prefilter ? kPfQueue * 4 : 0)); }
 
 hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offsets, u32 n_reads, u32 k, u64 seed, u32 s,
                          u64 max_ref, bool inrange_only, u64* out_sk, u32 sk_stride, u32* out_len, u32* out_cnt_in,
@@ -3234,7 +3359,8 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
     static const size_t lds_pad_capped = (size_t)env_int("SKX_SKETCH_LDS_PAD_CAPPED", 0);
     const size_t lds_pad = !leave_room ? 0 : room_mode == 2 ? lds_pad_env : room_mode == 1 ? lds_pad_capped : 0;
     const bool capped = leave_room && room_mode == 1;
-    const size_t lds = sketch_wave_lds(kSketchCap), lds_small = sketch_wave_lds(kSketchSmallHashes) + lds_pad;
+    const bool with_pf = kmer_filter && kmer_filter->words && inrange_only && k == 16;
+    const size_t lds = sketch_wave_lds(kSketchCap, with_pf), lds_small = sketch_wave_lds(kSketchSmallHashes, with_pf) + lds_pad;
     dim3 grid(cdiv(n_reads, 4));
 #define SKX_SK(KT, IR) sketch_wave_kernel<KT, kSketchCap, IR>
 #define SKX_SK_SMALL(KT) sketch_wave_kernel<KT, kSketchSmallHashes, true>
@@ -3252,7 +3378,7 @@ hipError_t launch_sketch(hipStream_t st, const uint8_t* bases, const u64* offset
             const void* wave_fns[] = {(const void*)&SKX_SK(16, false), (const void*)&SKX_SK(16, true),
                                       (const void*)&SKX_SK(0, false), (const void*)&SKX_SK(0, true)};
             for (const void* f : wave_fns) {
-                e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sketch_wave_lds(kSketchCap, true));
                 if (e != hipSuccess) return e;
             }
             const void* blk_fns[] = {(const void*)&SKX_BLK(16, false), (const void*)&SKX_BLK(16, true),
@@ -3451,6 +3577,9 @@ u32 chk_words() { return kChkWords; }
 u32 pool_row_fixed() { return kRowFixed; }
 u32 long_read_split() { return kLongSplit; }
 u32 long_read_seg_slots() { return kSegSlots; }
+void launch_store_host_words(hipStream_t st, u32* h_dst, u32* d_src, u32 n) {
+    hipLaunchKernelGGL(store_host_words_kernel, dim3(1), dim3(64), 0, st, h_dst, d_src, n);
+}
 void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq, const u32* dict_ctr) {
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, st, chk, retry, big, total_pairs, h_pub, seq, dict_ctr);
 }
@@ -3491,12 +3620,13 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
                        u32* rel, u32* csum /* [ceil(n_seg/16)][n_pad] scratch */, u32* csum_raw /* same size */, u32 prune_top_k, u32* leader,
                        u64* lead_val, u64* gmax, u64* part_sum, u32* part_idx, const u32* grp_any,
                        unsigned char* live /* [n_seg][n_pad / 64] or NULL: every start value is stored */,
-                       u64* lead_seg /* [n_seg][n_sp] scratch (with live) */, int part, u32* live_ctr) {
+                       u64* lead_seg /* [n_seg][n_sp] scratch (with live) */, int part, u32* live_ctr, hipEvent_t ev_table) {
     const u32 n_chunks = cdiv(n_seg, 16);
     dim3 grid(cdiv(n_pad, 256), n_chunks);
     if (part != 2) {
         hipLaunchKernelGGL(chunk_prefix_kernel, dim3(n_pad / 256), dim3(256), 0, st, csum_raw, csum, n_chunks, n_pad, cum_in, cum_out,
                            prune_top_k ? gmax : nullptr, n_pad / 256);
+        if (ev_table) (void)hipEventRecord(ev_table, st);  // the table the next batch starts from exists from here on
         if (prune_top_k) {
             // who leads (per species) as each chunk of 16 segments begins (bound for the pruning), and which (chunk, group)s can matter
             hipLaunchKernelGGL(chunk_leader_part_kernel, dim3(n_chunks * sp.n_sp, kLeaderParts), dim3(256), 0, st, cum_in, csum, n_pad,

@@ -142,6 +142,9 @@ void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_b
 // h_pub (page-locked host memory, 16 words): [0..7] = chk (then zeroed, as is retry[0]), [8] = *total_pairs, [15] = seq last
 // ([7] = number of reads the block sketcher took; `big` is re-armed like `retry`)
 // [10] = distinct keys in the hash set dict_ctr belongs to (the speculative gather's |Q|; 0xFFFFFFFF without dict_ctr)
+// n <= 64 words, device memory -> page-locked (coherent) host memory, written by a kernel: never blocks the queueing thread
+// (reads AND zeroes d_src: a counter block that is published once per use needs no memset of its own)
+void launch_store_host_words(hipStream_t st, u32* h_dst, u32* d_src, u32 n);
 void launch_publish(hipStream_t st, u32* chk, u32* retry, u32* big, const u32* total_pairs, u32* h_pub, u32 seq,
                     const u32* dict_ctr /* counters of the set the speculative gather filled, or NULL */);
 // membership filter over the union of the reference hashes (blocked Bloom filter, skx_common.hpp: filter_mask / filter_hit);
@@ -171,7 +174,8 @@ void launch_seg_prefix(hipStream_t st, const u32* inc, u32 n_seg, u32 n_pad, con
                        u64* part_sum, u32* part_idx /* [n_chunks * n_sp * rank_leader_parts() * k] scratch */,
                        const u32* grp_any, unsigned char* live /* [n_seg][n_pad / 64], pruned rankings only; else NULL */,
                        u64* lead_seg /* [n_seg][n_sp] scratch */, int part = 0,
-                       u32* live_ctr = nullptr /* [2], pruned rankings: += (chunk, half group)s that can hold a candidate / tested (a sample) */);
+                       u32* live_ctr = nullptr /* [2], pruned rankings: += (chunk, half group)s that can hold a candidate / tested (a sample) */,
+                       hipEvent_t ev_table = nullptr /* recorded right behind chunk_prefix: cum_out is complete (parts 0 and 1) */);
 u32 rank_leader_parts();
 void launch_rank_seg(hipStream_t st, const u32* pair_q, const u32* pair_r, const u32* poff, u32 p_base, u32 r_begin,
                      u32 n_reads, u32 seg_len, const u64* mq, u32 n_pad, u32 nq_rows, const Species& sp, const u64* cum_in,
