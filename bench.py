@@ -60,10 +60,17 @@ def _pmc_traffic(config, batch):
         key = f"{config}_b{batch}"
         e = t.get(key)
         if e:
-            return e.get("bytes_per_launch"), f"profiles/scan_traffic.json:{key} ({e.get('profile', 'committed rocprofv3 --pmc passes')}; not measured in this run)"
+            return (e.get("bytes_per_launch"), f"profiles/scan_traffic.json:{key} ({e.get('profile', 'committed rocprofv3 --pmc passes')}; not measured in this run)",
+                    e.get("source_sha"))
     except (OSError, ValueError):
         pass
-    return None, None
+    return None, None, None
+
+
+def _stale(profile_sha):
+    """True when a quoted profile was taken from other kernel sources than this tree's (or does not say which)."""
+    from sketchy_amd.build import source_sha
+    return profile_sha != source_sha()
 
 
 N_SIMDS = 1024                 # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
@@ -78,7 +85,7 @@ def _valu_insts(config, batch):
         with open(os.path.join(ROOT, "profiles", "valu_insts.json")) as f:
             e = json.load(f).get(f"{config}_b{batch}")
         if e:
-            return {"wave_insts_per_step": e["wave_insts_per_step"], "per_kernel": e.get("per_kernel"),
+            return {"wave_insts_per_step": e["wave_insts_per_step"], "per_kernel": e.get("per_kernel"), "source_sha": e.get("source_sha"),
                     "source": f"profiles/valu_insts.json:{config}_b{batch} ({e.get('profile', 'committed rocprofv3 --pmc SQ_INSTS_VALU pass')}; "
                               "not measured in this run)"}
     except (OSError, ValueError, KeyError):
@@ -106,6 +113,74 @@ def _usable_cores():
         except (OSError, ValueError):
             pass
     return max(1, n)
+
+
+def _end_to_end(refs, batches, batch_bases, B, read_len, top, n_use, S, step_rows, extra_args=()):
+    """value_end_to_end: the C++ host as a user runs it -- `sketchy-hip predict -s` on an uncompressed FASTQ file in /dev/shm with
+    the C2 reference as a `.msh` file, rows to a file in /dev/shm -- timed by the host itself (--timing: from the start of its
+    parser threads to the last written row; loading the 3.2 GB reference is start-up, reported beside it).  The rows it printed are compared
+    with the rows the device-resident path wrote for the same reads (step_rows: (idx, sum) arrays of the first n_use batches)."""
+    import re
+    import shutil
+    import tempfile
+    from sketchy_amd import build, mshio
+    exe = build.build_host()
+    d = tempfile.mkdtemp(prefix="skx_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t0 = time.time()
+        n_g = refs[0]["ref"].shape[0]
+        names = [f"genome{i:05d}.fa" for i in range(n_g)]
+        mshio.write_msh(d + "/ref.msh", names, refs[0]["ref"], col_len=refs[0]["col_len"], kmer=16, seed=0)
+        with open(d + "/geno.tsv", "w") as f:
+            f.write("id\tmlst\tmeca\n" + "".join(f"{n}\tST{i % 97}\t{'R' if i % 3 else 'S'}\n" for i, n in enumerate(names)))
+        L = read_len
+        with open(d + "/reads.fq", "wb") as f:
+            for j in range(n_use):
+                seq = batches[j][0].cpu().numpy().reshape(B, L)
+                rec = np.empty((B, 8 + L + 3 + L + 1), np.uint8)
+                rec[:, :8] = np.frombuffer(b"@read/1\n", np.uint8)
+                rec[:, 8:8 + L] = seq
+                rec[:, 8 + L:8 + L + 3] = np.frombuffer(b"\n+\n", np.uint8)
+                rec[:, 8 + L + 3:8 + 2 * L + 3] = ord("I")
+                rec[:, -1] = 10
+                rec.tofile(f)
+        t_files = time.time() - t0
+        # twice: the first pass over a file that was written a moment ago pays for the kernel moving its 1.2 M tmpfs pages to the
+        # active list under ten threads (measured with nothing behind the C ABI, tools/frontend_rate.sh: 10 M reads/s the first
+        # time, 27-32 M from then on) -- an artefact of generating the input right here; both runs are listed, the better one counts
+        runs = []
+        for _ in range(2):
+            t1 = time.time()
+            with open(d + "/rows.tsv", "wb") as out:
+                p = subprocess.run([exe, "predict", "-r", d + "/ref.msh", "-g", d + "/geno.tsv", "-i", d + "/reads.fq", "-s", "-t", str(max(top, 1)),
+                                    "--timing", *extra_args], stdout=out, stderr=subprocess.PIPE, text=True, timeout=900)
+            wall = time.time() - t1
+            m = re.search(r'\{"sketchy_hip_timing".*\}', p.stderr)
+            if p.returncode != 0 or not m:
+                return {"error": f"sketchy-hip predict failed (rc {p.returncode}): {p.stderr[-500:]}"}
+            runs.append((json.loads(m.group(0))["sketchy_hip_timing"], wall))
+        tm, wall = max(runs, key=lambda r: r[0]["reads_per_s"])
+        import pandas as pd
+        rows = pd.read_csv(d + "/rows.tsv", sep="\t", header=None, usecols=[0, 1, 2], names=["read", "name", "sum"], dtype={"name": str})
+        got_idx = rows["name"].str.slice(6, 11).astype(np.int64).to_numpy()
+        got_sum = rows["sum"].to_numpy().astype(np.uint64)
+        want_idx = np.concatenate([a for a, _ in step_rows]).reshape(-1).astype(np.int64)
+        want_sum = np.concatenate([b for _, b in step_rows]).reshape(-1).astype(np.uint64)
+        ok = bool(len(got_idx) == len(want_idx) and np.array_equal(got_idx, want_idx) and np.array_equal(got_sum, want_sum)
+                  and np.array_equal(rows["read"].to_numpy(), np.repeat(np.arange(1, n_use * B + 1), max(top, 1))))
+        return {"value": tm["reads_per_s"], "unit": "reads/s", "reads": tm["reads"], "seconds": tm["seconds_parse_start_to_last_row"],
+                "batches": tm["batches"], "batch_reads": tm["batch_reads"], "parse_threads": tm["parse_threads"], "format_threads": tm["format_threads"],
+                "cpus_pinned_near_device": tm.get("cpus_pinned_near_device"), "device_thread_s": tm.get("device_thread_s"),
+                "host_cpus_usable": _usable_cores(), "input": f"uncompressed FASTQ in /dev/shm, {os.path.getsize(d + '/reads.fq') / 1e9:.2f} GB",
+                "runs_reads_per_s": [r[0]["reads_per_s"] for r in runs],
+                "process_wall_s": wall, "process_reads_per_s": tm["reads"] / wall, "files_written_s": t_files,
+                "rows_match_device_path": ok,
+                "what": "`sketchy-hip predict -s` (sketchy_amd/host: mapped file cut at record boundaries, parser threads that pack 4-bit "
+                        "bases into page-locked slots, skx_stream_submit, formatter threads, rows in order to a file in /dev/shm), timed by "
+                        "the host from the start of its parser threads to its last written row; process_wall_s adds HIP start-up, reading the "
+                        f"{os.path.getsize(d + '/ref.msh') / 1e9:.1f} GB .msh and uploading it"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def _free_port():
@@ -147,6 +222,8 @@ def main():
     ap.add_argument("--coalesce", type=int, default=0, help="set the library option stream_coalesce (1 .. 8) before the stream is created; 0 = leave the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip value_cold / value_steady_state / stage breakdown (profiling runs)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the value_batch_x2 leg (batches of twice --batch reads)")
+    ap.add_argument("--e2e-args", default="", help="experiment: extra arguments for the sketchy-hip command of the value_end_to_end leg, e.g. '-b 65536 --pin'")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the value_end_to_end leg (FASTQ file -> sketchy-hip predict -s -> rows file)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity checks of the timed steps (profiling runs only)")
     ap.add_argument("--no-shuffle", action="store_true", help="experiment: keep genomes grouped by lineage")
     ap.add_argument("--lineages", type=int, default=0, help="experiment: number of lineages of the synthetic clone tree")
@@ -212,7 +289,7 @@ def main():
     # rows of every step are kept (the timed steps are checked afterwards)
     d_ti = torch.zeros((W + K, B, rows), dtype=torch.int32, device=tdev)
     d_ts = torch.zeros((W + K, B, rows), dtype=torch.int64, device=tdev)
-    reducer = shard.TableReducer(dev)
+    reducer = shard.TableReducer(dev)  # (N > 1: under a watchdog -- a rank whose peers never arrive exits with code 86 and says so)
     torch.cuda.synchronize()
     t_setup = time.time() - t0
 
@@ -336,18 +413,19 @@ def main():
         if prof and prof["scan"]["launches"]:
             scan_ms = prof["scan"]["ms"] / prof["scan"]["launches"]
             achieved = pass_bytes / (scan_ms * 1e-3) / 1e9
-            traffic, traffic_src = _pmc_traffic(args.config, B)
+            traffic, traffic_src, traffic_sha = _pmc_traffic(args.config, B)
             launches_per_step = prof["scan"]["launches"] / (K * reps)
             step_gbs = pass_bytes * launches_per_step / (elapsed / K) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                               "traffic_stale": _stale(traffic_sha) if traffic is not None else None,  # the committed PMC profile predates this tree's kernels
                                "kernel": "scan_lean_kernel", "avg_launch_ms": scan_ms, "launches_per_step": launches_per_step,
                                "algorithmic_bytes_per_launch": pass_bytes,
-                               "pattern_ceiling": {"reads_alone": 0.81, "reads_nontemporal": 0.92, "with_result_slabs": 0.63,
-                                                   "with_compact_m_atomics_nt": 0.81, "unit": "fraction of peak",
-                                                   "source": "profiles/r03f_stream_rates.txt (tools/ubench/stream_rates.hip: this kernel's "
-                                                             "geometry as a pure stream over 3.2 GB, measured on an MI355X; not measured in "
-                                                             "this run)"},
+                               "quoted_not_measured": {"pattern_ceiling": {"reads_alone": 0.81, "reads_nontemporal": 0.92, "with_result_slabs": 0.63,
+                                                                           "with_compact_m_atomics_nt": 0.81, "unit": "fraction of peak"},
+                                                       "source": "profiles/r03f_stream_rates.txt (tools/ubench/stream_rates.hip: this kernel's "
+                                                                 "geometry as a pure stream over 3.2 GB, measured on an MI355X in round 3) -- "
+                                                                 "constants of a committed micro-benchmark, NOT measured in this run"},
                                "note": "achieved = algorithmic bytes (8*s*N) / HIP-event time of the kernel on its own stream in the timed "
                                        "region, where the sketch of the next batch and the ranking of the previous one run beside it "
                                        "(multi-stream pipeline); `isolated` = the same kernel alone.  launches_per_step < 1: enqueued "
@@ -360,7 +438,7 @@ def main():
         if vi:
             floor_ms = vi["wave_insts_per_step"] * VALU_CYCLES_PER_WAVE_INST / (N_SIMDS * CLOCK_GHZ * 1e9) * 1e3
             out["roofline_valu"] = {"bound": "valu_issue", "wave_insts_per_step": vi["wave_insts_per_step"],
-                                    "insts_source": vi["source"], "per_kernel": vi.get("per_kernel"),
+                                    "insts_source": vi["source"], "insts_stale": _stale(vi.get("source_sha")), "per_kernel": vi.get("per_kernel"),
                                     "simds": N_SIMDS, "cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST, "clock_ghz": CLOCK_GHZ,
                                     "floor_ms": floor_ms, "frac": floor_ms / (1e3 * elapsed / K),
                                     "note": "VALU wave instructions one step issues (all kernels of the step, shared launches counted at their share; committed rocprofv3 "
@@ -594,6 +672,23 @@ def main():
                 err = err or "rows of a 4-bit packed batch differ from the same batch as ASCII"
             for h in h_b + h_o + h_ti + h_ts + h_p:
                 h.free()
+        # value_end_to_end: FASTQ file -> C++ host -> rows file (one species, fixed-length reads: the C2 workload)
+        if rank == 0 and world == 1 and n_sp == 1 and sigma == 0.0 and top and not args.no_end_to_end:
+            n_use = min(n_distinct, 16)
+            S.reset()
+            e_ti = torch.zeros((n_use, B, rows), dtype=torch.int32, device=tdev)
+            e_ts = torch.zeros((n_use, B, rows), dtype=torch.int64, device=tdev)
+            for j in range(n_use):
+                S.enqueue_device(batches[j][0].data_ptr(), batches[j][1].data_ptr(), B, batch_bases[j], e_ti[j].data_ptr(), e_ts[j].data_ptr())
+            S.sync()
+            step_rows = [(e_ti[j].cpu().numpy().view(np.uint32), e_ts[j].cpu().numpy().view(np.uint64)) for j in range(n_use)]
+            del e_ti, e_ts
+            e2e = _end_to_end(refs, batches, batch_bases, B, read_len, top, n_use, S, step_rows, tuple(args.e2e_args.split()))
+            out["value_end_to_end"] = e2e
+            if e2e.get("rows_match_device_path") is False:
+                err = err or "rows printed by `sketchy-hip predict -s` differ from the device-resident path's rows for the same reads"
+            if "error" in e2e:
+                err = err or e2e["error"]
         if not args.no_profile:
             # per-stage breakdown from a few extra, untimed steps with every stage bracketed by events
             S.set_profiling(1)

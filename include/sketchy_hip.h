@@ -62,6 +62,9 @@ const char *skx_version(void);
 int skx_device_count(void);
 /* name (<= name_cap bytes), number of CUs and bytes of device memory of `device` */
 int skx_device_info(int device, char *name, size_t name_cap, int *compute_units, uint64_t *total_mem);
+/* PCI address of `device` as "domain:bus:device.function" (>= 13 bytes): what a host that feeds the device from page-locked
+ * memory looks up under /sys/bus/pci/devices/<id>/ (numa_node, local_cpulist) to keep its threads on the device's NUMA node */
+int skx_device_pci_bus_id(int device, char *bus_id, size_t cap);
 
 /*
  * Process-wide policies, consulted when a reference or a stream is CREATED (no effect on existing handles, never on
@@ -193,6 +196,9 @@ int skx_stream_flush(skx_stream *st);
  */
 int skx_stream_set_packed_input(skx_stream *st, int on);
 uint64_t skx_pack_bases(const uint8_t *ascii, uint64_t n, uint8_t *packed, uint64_t nibble_pos);
+/* the same up to the first line feed of ascii[0..n): packs what lies in front of it, *consumed = bytes taken, the line feed
+ * included (n when there is none) -- a FASTX parser finds the end of a sequence line and packs it in one pass over its bytes */
+uint64_t skx_pack_line(const uint8_t *ascii, uint64_t n, uint8_t *packed, uint64_t nibble_pos, uint64_t *consumed);
 int skx_stream_sync(skx_stream *st);
 /*
  * Host-fed pipeline.  skx_stream_submit() queues a batch from PAGE-LOCKED host buffers (skx_host_alloc; bases, offsets

@@ -27,6 +27,7 @@ SYMBOLS = [
     ("skx_version", C.c_char_p, []),
     ("skx_device_count", _i, []),
     ("skx_device_info", _i, [_i, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_u64)]),
+    ("skx_device_pci_bus_id", _i, [_i, C.c_char_p, _sz]),
     ("skx_set_option", _i, [C.c_char_p, _u64]),
     ("skx_get_option", _i, [C.c_char_p, C.POINTER(_u64)]),
     ("skx_ref_kmer_filter", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
@@ -45,6 +46,7 @@ SYMBOLS = [
     ("skx_stream_flush", _i, [_vp]),
     ("skx_stream_set_packed_input", _i, [_vp, _i]),
     ("skx_pack_bases", _u64, [_vp, _u64, _vp, _u64]),
+    ("skx_pack_line", _u64, [_vp, _u64, _vp, _u64, C.POINTER(_u64)]),
     ("skx_stream_sync", _i, [_vp]),
     ("skx_stream_submit", _i, [_vp, _vp, _vp, _u32, _vp, _vp, C.POINTER(_u64)]),
     ("skx_stream_wait", _i, [_vp, _u64]),

@@ -18,6 +18,19 @@ SOURCES = ["skx_kernels.hip", "skx_capi.hip"]
 ARCH = "gfx950"
 
 
+def source_sha():
+    """sha256 (first 16 hex digits) over the kernel / C-ABI sources the library is built from: what ties a committed profile
+    (profiles/scan_traffic.json, profiles/valu_insts.json) to the code that produced it -- bench.py marks a quoted figure
+    `stale` when the tree has moved on since."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [os.path.join("..", "..", "include", "sketchy_hip.h")]
+    for f in names:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 

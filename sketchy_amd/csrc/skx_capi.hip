@@ -86,6 +86,13 @@ SKX_API int skx_device_info(int device, char* name, size_t name_cap, int* comput
     return SKX_OK;
 }
 
+SKX_API int skx_device_pci_bus_id(int device, char* bus_id, size_t cap) {
+    if (!bus_id || cap < 13) return fail(SKX_ERR_INVALID, "bus_id needs room for 13 bytes");
+    SKXCHK(use_device(device));
+    HIPCHK(hipDeviceGetPCIBusId(bus_id, (int)cap, device));
+    return SKX_OK;
+}
+
 // ------------------------------------------------------------------ raw device buffers
 SKX_API int skx_dev_malloc(int device, void** d_ptr, size_t bytes) {
     if (!d_ptr) return fail(SKX_ERR_INVALID, "d_ptr is NULL");
@@ -166,6 +173,8 @@ static u32 g_kmer_prefilter = 0;  // k-mer prefilter of k = 16 references: 0 off
 static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
 static u32 g_stream_query_rows = 0;       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
 static u32 g_stream_coalesce = 8;         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 .. 8)
+static const int kRankLanesMax = 4;
+static u32 g_rank_lanes = 2;               // ranking lanes of a stream that enqueues (1 .. 4): chains of consecutive batches that run side by side
 static u64 g_comm_timeout_ms = 0;         // watchdog of skx_comm_create / skx_stream_allreduce: 0 = none (block for ever, as RCCL does)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
@@ -190,6 +199,11 @@ SKX_API int skx_set_option(const char* name, uint64_t value) {
         g_filter_bits_per_hash = (u32)value;
         return SKX_OK;
     }
+    if (!strcmp(name, "rank_lanes")) {
+        if (value < 1 || value > (uint64_t)kRankLanesMax) return fail(SKX_ERR_INVALID, "rank_lanes must be 1 .. %d", kRankLanesMax);
+        g_rank_lanes = (u32)value;
+        return SKX_OK;
+    }
     if (!strcmp(name, "comm_timeout_ms")) {
         if (value > 86400000ull) return fail(SKX_ERR_INVALID, "comm_timeout_ms must be 0 (no watchdog) .. 86400000");
         g_comm_timeout_ms = value;
@@ -204,6 +218,7 @@ SKX_API int skx_get_option(const char* name, uint64_t* value) {
     if (!strcmp(name, "stream_query_rows")) { *value = g_stream_query_rows; return SKX_OK; }
     if (!strcmp(name, "stream_coalesce")) { *value = g_stream_coalesce; return SKX_OK; }
     if (!strcmp(name, "comm_timeout_ms")) { *value = g_comm_timeout_ms; return SKX_OK; }
+    if (!strcmp(name, "rank_lanes")) { *value = g_rank_lanes; return SKX_OK; }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -542,15 +557,16 @@ struct PendingBatch {
 // (GPU_MAX_HW_QUEUES) and the second set aliased.  Kernels of different skx_streams queue behind each other on the shared HIP
 // streams in host order; every skx_stream orders its own work with its own events, as before.  (A skx_stream_sync therefore
 // also waits for work queued by the device's other streams.)
-// hs2b: the stream of the second ranking lane (skx_stream::RankLane), created when the first stream that enqueues asks for it
-struct SharedQueues { hipStream_t hs = nullptr, hs0 = nullptr, hs1 = nullptr, hs2 = nullptr, hs2b = nullptr; int refs = 0; };
+// lane_s[i]: the stream of ranking lane i + 1 (skx_stream::RankLane; lane 0 is hs2), created when the first stream that enqueues asks for it
+struct SharedQueues { hipStream_t hs = nullptr, hs0 = nullptr, hs1 = nullptr, hs2 = nullptr, lane_s[kRankLanesMax - 1] = {}; int refs = 0; };
 static std::mutex g_queues_mu;
 static SharedQueues g_queues[64];
 static void release_queues(int device) {
     std::lock_guard<std::mutex> lk(g_queues_mu);
     SharedQueues& q = g_queues[device & 63];
     if (--q.refs > 0) return;
-    for (hipStream_t* h : {&q.hs2b, &q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
+    for (hipStream_t& h : q.lane_s) { if (h) (void)hipStreamDestroy(h); h = nullptr; }
+    for (hipStream_t* h : {&q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
     q.refs = 0;
 }
 static const int kSides = kGroupMax + 1;  // copies of the per-batch sketch outputs: the enqueued batches waiting for their shared pass + the one being sketched
@@ -661,10 +677,10 @@ struct skx_stream {
         hipEvent_t ev_done = nullptr;  // its chain is done
         bool ready = false;
     };
-    static const int kRankLanes = 2;
+    static const int kRankLanes = kRankLanesMax;
     RankLane lane[kRankLanes];
     int n_lanes = 1;             // lanes in use (the second one is allocated for streams that enqueue)
-    bool own_lane_stream = false;  // lane 1's stream is this skx_stream's own (not the device's shared set's)
+    bool own_lane_stream = false;  // the streams of lanes 1 .. are this skx_stream's own (not the device's shared set's)
     u32 n_cand_units = 0;        // candidate slots per read of the ranking's per-(read, unit) arrays
     u64 rank_seq = 0;            // batches ranked so far: batch i takes lane i % n_lanes
     RankLane* cum_writer = nullptr;  // the lane whose chunk_prefix wrote (or will have written) d_cum
@@ -746,7 +762,8 @@ static void stream_free(skx_stream* st) {
     if (st->hs1) (void)hipStreamSynchronize(st->hs1);
     if (st->hs) (void)hipStreamSynchronize(st->hs);
     if (st->hs2) (void)hipStreamSynchronize(st->hs2);
-    if (st->lane[1].s) (void)hipStreamSynchronize(st->lane[1].s);
+    for (int i = 1; i < skx_stream::kRankLanes; ++i)
+        if (st->lane[i].s) (void)hipStreamSynchronize(st->lane[i].s);
     for (int i = 0; i < kSides; ++i) (void)hipFree(st->sd_rows[i]);
     void* ptrs[] = {st->d_bases, st->d_offsets, st->d_pair_h[0], st->d_pair_h[1],
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
@@ -755,7 +772,8 @@ static void stream_free(skx_stream* st) {
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1]};
     for (auto& t : st->d_tab) (void)hipFree(t);
     for (int i = 0; i < skx_stream::kRankLanes; ++i) free_lane(st, i);
-    if (st->own_lane_stream && st->lane[1].s) (void)hipStreamDestroy(st->lane[1].s);
+    for (int i = 1; i < skx_stream::kRankLanes; ++i)
+        if (st->own_lane_stream && st->lane[i].s) (void)hipStreamDestroy(st->lane[i].s);
     for (void* p : ptrs) (void)hipFree(p);
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
@@ -1089,17 +1107,18 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     {
         // ranking lanes: the second one only for streams that enqueue (batches back to back are what it overlaps); experiment
         // knob SKX_RANK_LANES=1 keeps every chain on one lane
-        static const int lanes_env = skx::knob("SKX_RANK_LANES") ? atoi(skx::knob("SKX_RANK_LANES")) : skx_stream::kRankLanes;
-        st->n_lanes = (enqueueing && top_k && st->depth >= 3) ? std::max(1, std::min(lanes_env, (int)skx_stream::kRankLanes)) : 1;
+        static const int lanes_env = skx::knob("SKX_RANK_LANES") ? atoi(skx::knob("SKX_RANK_LANES")) : 0;
+        const int want = lanes_env ? lanes_env : (int)g_rank_lanes;
+        st->n_lanes = (enqueueing && top_k && st->depth >= 3) ? std::max(1, std::min(want, (int)skx_stream::kRankLanes)) : 1;
         st->lane[0].s = st->hs2;
-        if (st->n_lanes > 1) {
+        for (int i = 1; i < st->n_lanes; ++i) {
             if (st->shared_queues) {
                 std::lock_guard<std::mutex> lk(g_queues_mu);
                 SharedQueues& q = g_queues[st->device & 63];
-                if (!q.hs2b) SCHK(hipStreamCreateWithPriority(&q.hs2b, hipStreamNonBlocking, prio_lo));
-                st->lane[1].s = q.hs2b;
+                if (!q.lane_s[i - 1]) SCHK(hipStreamCreateWithPriority(&q.lane_s[i - 1], hipStreamNonBlocking, prio_lo));
+                st->lane[i].s = q.lane_s[i - 1];
             } else {
-                SCHK(hipStreamCreateWithPriority(&st->lane[1].s, hipStreamNonBlocking, prio_lo));
+                SCHK(hipStreamCreateWithPriority(&st->lane[i].s, hipStreamNonBlocking, prio_lo));
                 st->own_lane_stream = true;
             }
         }
@@ -2188,11 +2207,11 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     const u32 ns = st->n_slots;
     skx_stream::Staged& sl = st->slot[st->next_ticket % ns];
     skx_stream::Staged& other = st->slot[(st->next_ticket + ns - 1) % ns];  // (the previous ticket's)
-    // the previous batch goes to the kernels first (its sketch is queued, and the passes of the batch before it) ...
-    SKXCHK(staged_process(st, other));
-    if (other.ev_copy && other.ticket + 1 == st->next_ticket) HIPCHK(hipEventSynchronize(other.ev_copy));  // its host buffers are free again
-    // ... then this slot's previous batch (three tickets ago) must be through -- passes queued, rows on the host -- while
-    // the device works on
+    // Order (round 4): (1) this slot's previous batch (n_slots tickets ago) must be through -- passes queued, rows on the host;
+    // (2) the copy of THIS batch starts; (3) the previous batch goes to the kernels (its sketch is queued -- and, when it completes
+    // a group, the host waits for the group's summaries before it can queue their pass).  Round 3 did (3) first: the copy
+    // engine stood still whenever the host waited in (3), and a stream of 32 768-read batches took 1.4 ms per batch where its
+    // copies take 0.45 ms.
     SKXCHK(staged_finish(st, sl));
     const u64 byte0 = st->packed ? base0 >> 1 : base0, rebase = st->packed ? byte0 * 2 : base0;
     const u64 n_bytes = st->packed ? ((offsets[n_reads] + 1) >> 1) - byte0 : n_bases;
@@ -2204,6 +2223,18 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     sl.ticket = st->next_ticket;
     if (ticket) *ticket = st->next_ticket;
     st->next_ticket += 1;
+    if (&other != &sl) {
+        const int rc = staged_process(st, other);
+        // (the previous batch's host buffers are the caller's again when this call returns -- also when it fails)
+        if (other.ev_copy && other.ticket + 2 == st->next_ticket) HIPCHK(hipEventSynchronize(other.ev_copy));
+        if (rc != SKX_OK) {  // (a batch submitted before this one failed: this one is dropped with it, as the header says)
+            const std::string msg = g_err;
+            (void)hipEventSynchronize(sl.ev_copy);
+            sl.pending = false; sl.dropped = true;
+            g_err = msg;
+            return rc;
+        }
+    }
     return SKX_OK;
 }
 SKX_API int skx_stream_wait(skx_stream* st, uint64_t ticket) {
@@ -2246,17 +2277,121 @@ SKX_API int skx_stream_set_packed_input(skx_stream* st, int on) {
     st->packed = on != 0;
     return SKX_OK;
 }
-// host helper (no device involved): ASCII -> 4-bit codes, appended at nibble position `nibble_pos` of `packed`
-SKX_API uint64_t skx_pack_bases(const uint8_t* ascii, uint64_t n, uint8_t* packed, uint64_t nibble_pos) {
+// host helper (no device involved): ASCII -> 4-bit codes, appended at nibble position `nibble_pos` of `packed`.
+// A FASTX front-end packs every base it parses (sketchy_amd/host: ~40 GB/s of sequence at 25 M reads/s), so the body is a
+// table walk with an AVX2 path (32 bases per step: classify by compares, pairs joined by one multiply-add) chosen at run time;
+// both give the bytes the plain definition gives: skx::classify_base per byte, whitespace dropped, an even nibble starts its
+// byte afresh, an odd one keeps the low nibble already there.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+namespace {
+struct PackLut {
+    uint8_t code[256];
+    PackLut() { for (int c = 0; c < 256; ++c) code[c] = (uint8_t)skx::classify_base((u32)c); }
+};
+const PackLut g_pack_lut;
+inline uint64_t pack_scalar(const uint8_t* ascii, uint64_t n, uint8_t* packed, uint64_t pos) {
     for (uint64_t i = 0; i < n; ++i) {
-        const u32 code = skx::classify_base(ascii[i]);
+        const uint8_t code = g_pack_lut.code[ascii[i]];
         if (code == 5u) continue;  // whitespace does not exist in the packed format
-        uint8_t& b = packed[nibble_pos >> 1];
-        b = (nibble_pos & 1ull) ? (uint8_t)((b & 0x0Fu) | (code << 4)) : (uint8_t)code;  // (an even nibble starts its byte afresh)
-        ++nibble_pos;
+        uint8_t& b = packed[pos >> 1];
+        b = (pos & 1ull) ? (uint8_t)((b & 0x0Fu) | (code << 4)) : code;
+        ++pos;
     }
-    return nibble_pos;
+    return pos;
 }
+// LINE: stop at the first line feed (not packed); *consumed = bytes taken, the line feed included
+template <bool LINE>
+__attribute__((target("avx2"))) uint64_t pack_avx2_t(const uint8_t* ascii, uint64_t n, uint8_t* packed, uint64_t pos, uint64_t* consumed) {
+    uint64_t i = 0;
+    if ((pos & 1ull) && n) {  // finish the open byte first: the vector path writes whole bytes
+        while (i < n && (pos & 1ull)) {
+            if (LINE && ascii[i] == '\n') { *consumed = i + 1; return pos; }
+            pos = pack_scalar(ascii + i, 1, packed, pos); ++i;
+        }
+    }
+    // per byte x, keyed by its low nibble (vpshufb as a 16-entry table):
+    //   want[x & 15] = the one upper-cased base letter with that low nibble (A 41, C 43, T 54, U 55, G 47; 0xFF where there is none):
+    //                  x is a base iff (x & 0xDF) == want[x & 15]
+    //   wsp[x & 15]  = the one whitespace byte with that low nibble (space 20, tab 09, LF 0A, CR 0D)
+    //   code         = ((x >> 1) ^ (x >> 2)) & 3  -- A 0, C 1, G 2, T / U 3 in either case (bits 1-2 of the letters) -- else 4
+    const __m256i low = _mm256_set1_epi8(0x0F), up = _mm256_set1_epi8((char)0xDF), three = _mm256_set1_epi8(3), four = _mm256_set1_epi8(4),
+                  join = _mm256_set1_epi16(0x1001);
+    const __m256i want = _mm256_setr_epi8((char)0xFF, 0x41, (char)0xFF, 0x43, 0x54, 0x55, (char)0xFF, 0x47, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF,
+                                          (char)0xFF, 0x41, (char)0xFF, 0x43, 0x54, 0x55, (char)0xFF, 0x47, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF);
+    const __m256i wsp = _mm256_setr_epi8(0x20, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, 0x09, 0x0A, (char)0xFF, (char)0xFF, 0x0D, (char)0xFF, (char)0xFF,
+                                         0x20, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, 0x09, 0x0A, (char)0xFF, (char)0xFF, 0x0D, (char)0xFF, (char)0xFF);
+    while (i + 32 <= n) {
+        const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(ascii + i));
+        const __m256i nib = _mm256_and_si256(x, low);
+        if (_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, _mm256_shuffle_epi8(wsp, nib)))) {
+            // (a block with whitespace in it: byte by byte -- the open byte may end up odd)
+            uint64_t take = 32;
+            if (LINE) {
+                const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, _mm256_set1_epi8('\n')));
+                if (m) { const uint32_t j = (uint32_t)__builtin_ctz(m); *consumed = i + j + 1; return pack_scalar(ascii + i, j, packed, pos); }
+            }
+            pos = pack_scalar(ascii + i, take, packed, pos);
+            i += take;
+            while (i < n && (pos & 1ull)) {
+                if (LINE && ascii[i] == '\n') { *consumed = i + 1; return pos; }
+                pos = pack_scalar(ascii + i, 1, packed, pos); ++i;
+            }
+            continue;
+        }
+        const __m256i is_base = _mm256_cmpeq_epi8(_mm256_and_si256(x, up), _mm256_shuffle_epi8(want, nib));
+        const __m256i c2 = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(x, 1), _mm256_srli_epi16(x, 2)), three);  // (bits shifted in from the neighbour byte land above bit 5)
+        const __m256i code = _mm256_blendv_epi8(four, c2, is_base);
+        const __m256i pairs = _mm256_maddubs_epi16(code, join);           // 16 x (even base | odd base << 4)
+        const __m256i bytes = _mm256_permute4x64_epi64(_mm256_packus_epi16(pairs, pairs), 0x08);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(packed + (pos >> 1)), _mm256_castsi256_si128(bytes));
+        pos += 32; i += 32;
+    }
+    if (LINE) {
+        for (; i < n; ++i) {
+            if (ascii[i] == '\n') { *consumed = i + 1; return pos; }
+            pos = pack_scalar(ascii + i, 1, packed, pos);
+        }
+        *consumed = n;
+        return pos;
+    }
+    return pack_scalar(ascii + i, n - i, packed, pos);
+}
+__attribute__((target("avx2"))) uint64_t pack_avx2(const uint8_t* ascii, uint64_t n, uint8_t* packed, uint64_t pos) {
+    return pack_avx2_t<false>(ascii, n, packed, pos, nullptr);
+}
+}  // namespace
+SKX_API uint64_t skx_pack_bases(const uint8_t* ascii, uint64_t n, uint8_t* packed, uint64_t nibble_pos) {
+    static const bool has_avx2 = __builtin_cpu_supports("avx2");
+    return has_avx2 ? pack_avx2(ascii, n, packed, nibble_pos) : pack_scalar(ascii, n, packed, nibble_pos);
+}
+// ... up to the first line feed: a FASTX parser's sequence line in ONE pass over its bytes (finding the end of the line and
+// packing it are the same scan).  Packs ascii[0 .. m), m = the index of the first '\n' (or n when there is none);
+// *consumed = m + 1 (the line feed included) or n.
+namespace {
+__attribute__((target("avx2"))) uint64_t pack_line_avx2(const uint8_t* ascii, uint64_t n, uint8_t* packed, uint64_t pos, uint64_t* consumed) {
+    *consumed = n;
+    return pack_avx2_t<true>(ascii, n, packed, pos, consumed);
+}
+}  // namespace
+SKX_API uint64_t skx_pack_line(const uint8_t* ascii, uint64_t n, uint8_t* packed, uint64_t nibble_pos, uint64_t* consumed) {
+    static const bool has_avx2 = __builtin_cpu_supports("avx2");
+    uint64_t used = n;
+    uint64_t pos;
+    if (has_avx2) pos = pack_line_avx2(ascii, n, packed, nibble_pos, &used);
+    else {
+        const void* e = memchr(ascii, '\n', n);
+        const uint64_t m = e ? (uint64_t)(static_cast<const uint8_t*>(e) - ascii) : n;
+        used = e ? m + 1 : n;
+        pos = pack_scalar(ascii, m, packed, nibble_pos);
+    }
+    if (consumed) *consumed = used;
+    return pos;
+}
+#else
+SKX_API uint64_t skx_pack_bases(const uint8_t*, uint64_t, uint8_t*, uint64_t);
+SKX_API uint64_t skx_pack_line(const uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t*);
+#endif
 SKX_API int skx_stream_sync(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));

@@ -11,6 +11,10 @@
 // ReferenceList = 1 pointer {references}; Reference = 3 data words {length u32 @0, length64 u64 @8,
 // numValidKmers u64 @16} + 7 pointers {sequence, quality, name, comment, hashes32, hashes64, counts32}.
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cstdint>
@@ -40,6 +44,7 @@ class CapnpMessage {
         if (words.empty()) throw std::runtime_error("empty capnp message");
         const uint32_t* h = reinterpret_cast<const uint32_t*>(words.data());
         const uint64_t nseg = (uint64_t)h[0] + 1;
+        if (nseg > words.size() * 2) throw std::runtime_error("capnp segment table truncated");
         const uint64_t header_words = (4 + 4 * nseg + 7) / 8;
         uint64_t pos = header_words;
         for (uint64_t i = 0; i < nseg; ++i) {
@@ -89,9 +94,12 @@ class CapnpMessage {
             o.kind = 1; o.elem_code = (w >> 32) & 7; o.count = w >> 35;
             if (o.elem_code == 7) {  // composite: tag word first
                 const uint64_t tag = word(content);
+                const uint64_t total_words = w >> 35;     // (of a composite list the pointer holds the WORD count of the content)
                 o.count = (tag >> 2) & 0x3FFFFFFF;
                 o.data_words = (tag >> 32) & 0xFFFF; o.ptr_words = (tag >> 48) & 0xFFFF;
                 o.at = {content.seg, content.off + 1};
+                if (o.count * (uint64_t)(o.data_words + o.ptr_words) > total_words) throw std::runtime_error("capnp composite list larger than its pointer says");
+                check_span(o, total_words);
             }
         } else throw std::runtime_error("unsupported capnp pointer kind");
         return o;
@@ -104,12 +112,20 @@ class CapnpMessage {
         return follow({s.at.seg, s.at.off + s.data_words + idx});
     }
     Obj element(const Obj& l, uint64_t i) const {  // composite list element as a struct
+        if (l.kind != 1 || l.elem_code != 7 || i >= l.count) throw std::runtime_error("capnp list element out of range");
         Obj e; e.kind = 0; e.data_words = l.data_words; e.ptr_words = l.ptr_words;
         e.at = {l.at.seg, l.at.off + i * (l.data_words + l.ptr_words)};
         return e;
     }
+    // (a list's content must lie inside its segment BEFORE anything is allocated for it: a flipped count must not become a
+    // multi-gigabyte resize)
+    void check_span(const Obj& l, uint64_t n_words) const {
+        if (l.at.seg >= seg_off.size() || l.at.off > seg_len[l.at.seg] || n_words > seg_len[l.at.seg] - l.at.off)
+            throw std::runtime_error("capnp list exceeds its segment");
+    }
     std::string text(const Obj& l) const {
         if (l.kind != 1 || l.elem_code != 2 || l.count == 0) return std::string();
+        check_span(l, (l.count + 7) / 8);
         std::string s((size_t)l.count - 1, '\0');
         for (uint64_t i = 0; i + 1 < l.count; ++i) s[i] = (char)(word({l.at.seg, l.at.off + i / 8}) >> (8 * (i % 8)));
         return s;
@@ -117,6 +133,7 @@ class CapnpMessage {
     std::vector<uint64_t> list_u64(const Obj& l) const {
         std::vector<uint64_t> v;
         if (l.kind != 1 || l.elem_code != 5) return v;
+        check_span(l, l.count);
         v.resize((size_t)l.count);
         for (uint64_t i = 0; i < l.count; ++i) v[i] = word({l.at.seg, l.at.off + i});
         return v;
@@ -148,6 +165,7 @@ inline std::vector<Sketch> read_mash_file(const std::string& path) {
     const auto refs = m.ptr(rl, 0);
     std::vector<Sketch> out;
     if (refs.kind != 1) return out;
+    if (refs.elem_code != 7) throw std::runtime_error("not a Mash sketch file (reference list is not a struct list): " + path);
     out.reserve((size_t)refs.count);
     for (uint64_t i = 0; i < refs.count; ++i) {
         const auto r = m.element(refs, i);
@@ -158,6 +176,15 @@ inline std::vector<Sketch> read_mash_file(const std::string& path) {
         if (s.seq_length == 0) s.seq_length = m.data_u32(r, 0);
         s.num_valid_kmers = m.data_u64(r, 2);
         s.hashes = m.list_u64(m.ptr(r, 5));            // hashes64 only, as finch does
+        // A genuine Mash sketch with k <= 16 stores its hashes as hashes32 (pointer 4); finch's reader takes hashes64 only and
+        // would hand sketchy a collection of EMPTY sketches -- every read would score 0 against everything,
+        // silently.  Say so instead.
+        if (s.hashes.empty()) {
+            const auto h32 = m.ptr(r, 4);
+            if (h32.kind == 1 && h32.count > 0)
+                throw std::runtime_error("sketch '" + s.name + "' in " + path + " stores 32-bit hashes only (hashes32: a Mash sketch with k <= 16); "
+                                         "this reader, like finch's, takes hashes64 -- build the reference with `sketchy sketch` (64-bit hashes)");
+        }
         s.kmer_length = kmer; s.hash_seed = seed;
         out.push_back(std::move(s));
     }
@@ -303,4 +330,78 @@ class FastxReader {
     std::string pending, line;
 };
 
+// ------------------------------------------------------------------ FASTX in memory: the parallel front-end's view
+// An uncompressed regular file is mapped and cut into CHUNKS at record boundaries; every chunk is parsed by whichever thread
+// picks it up (sketchy_host.cpp).  needletail reads one record at a time on the thread that scores it (src/sketchy.rs:328-333);
+// the records, their order and their bytes are the same.
+class MappedFile {
+  public:
+    MappedFile() = default;
+    ~MappedFile();
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+    // false: not a regular file (a pipe, stdin) or empty / compressed -- the caller streams it instead
+    bool open(const std::string& path);
+    const char* data() const { return base; }
+    size_t size() const { return len; }
+    // map the pages of [a, b) now (MADV_POPULATE_READ where the kernel has it; else a hint): a parser thread calls it for its chunk
+    void prefetch(size_t a, size_t b) const;
+  private:
+    const char* base = nullptr;
+    size_t len = 0;
+};
+
+// first byte of the first record that starts at or behind `pos` (a line start), or `end` when there is none.
+// FASTQ (four-line records, as needletail's fast path reads them): a line that starts with '@' whose second-next line starts
+// with '+' -- a quality line may start with '@' too, but then the line after it is the next header and the one after that a
+// sequence, which cannot start with '+'.  FASTA: a line that starts with '>'.
+inline const char* next_record_start(const char* begin, const char* pos, const char* end, bool fastq) {
+    const char* p = pos;
+    if (p > begin && p[-1] != '\n') {  // inside a line: go to the next line start
+        p = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+        if (!p) return end;
+        ++p;
+    }
+    while (p < end) {
+        if (!fastq) {
+            if (*p == '>') return p;
+        } else if (*p == '@') {
+            const char* l1 = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            const char* l2 = l1 ? static_cast<const char*>(memchr(l1 + 1, '\n', (size_t)(end - l1 - 1))) : nullptr;
+            if (l2 && l2 + 1 < end && l2[1] == '+') return p;
+            if (!l2) return end;  // (no complete record behind p)
+        }
+        p = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+        if (!p) return end;
+        ++p;
+    }
+    return end;
+}
+
 }  // namespace sketchy
+
+inline sketchy::MappedFile::~MappedFile() { if (base) munmap(const_cast<char*>(base), len); }
+inline bool sketchy::MappedFile::open(const std::string& path) {
+    if (path == "-") return false;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("failed to open Fastx file: " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) { ::close(fd); return false; }
+    unsigned char magic[2] = {0, 0};
+    if (pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) { ::close(fd); return false; }  // gzip: streamed
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) return false;
+    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    base = static_cast<const char*>(m); len = (size_t)st.st_size;
+    return true;
+}
+inline void sketchy::MappedFile::prefetch(size_t a, size_t b) const {
+    if (!base || b <= a) return;
+    const size_t page = 4096, lo = a & ~(page - 1);
+    char* p = const_cast<char*>(base) + lo;
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+    if (madvise(p, b - lo, MADV_POPULATE_READ) != 0) (void)madvise(p, b - lo, MADV_WILLNEED);
+}

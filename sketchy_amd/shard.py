@@ -23,8 +23,14 @@ def env_rank():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend=None):
-    """Initialise torch.distributed from the torchrun environment (MASTER_ADDR/PORT, RANK, ...)."""
+COMM_TIMEOUT_S = 180.0     # what a rank waits for its peers (rendezvous, RCCL bring-up, a collective) before it gives up
+COMM_TIMEOUT_EXIT = 86     # SKX_COMM_TIMEOUT_EXIT (include/sketchy_hip.h): the exit code of a rank that gave up
+
+
+def init_process_group(backend=None, timeout_s=None):
+    """Initialise torch.distributed from the torchrun environment (MASTER_ADDR/PORT, RANK, ...).  Every collective of the
+    control plane gets `timeout_s` (default COMM_TIMEOUT_S): a rank whose peers never arrive fails instead of hanging."""
+    import datetime
     import torch.distributed as dist
     if dist.is_initialized():
         return dist
@@ -34,8 +40,41 @@ def init_process_group(backend=None):
     if backend is None:
         import torch
         backend = "cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo"
-    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=timeout_s or COMM_TIMEOUT_S))
     return dist
+
+
+class deadline:
+    """`with deadline(seconds, "what"):` -- a watchdog thread around a block that may wait for other ranks for ever (a
+    collective whose peer died, a rendezvous nobody joins).  When the block has not finished in time the watchdog says which
+    rank was stuck in what on stderr and ends the PROCESS with COMM_TIMEOUT_EXIT -- never a re-exec: the process may have
+    initialised the GPU; a rank that exits non-zero lets the launcher tear the job down.  ctypes calls and torch collectives
+    release the GIL, so the watchdog runs while the main thread is blocked inside them."""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what, self._timer = float(seconds), what, None
+
+    def _expired(self):
+        import sys
+        rank, local, world = env_rank()
+        sys.stderr.write(f"[sketchy_amd.shard] rank {rank} of {world} (local rank {local}): {self.what} did not finish within "
+                         f"{self.seconds:.0f} s -- a peer is missing or the fabric is down; exiting with code {COMM_TIMEOUT_EXIT}\n")
+        sys.stderr.flush()
+        os._exit(COMM_TIMEOUT_EXIT)
+
+    def __enter__(self):
+        import threading
+        if self.seconds > 0:
+            self._timer = threading.Timer(self.seconds, self._expired)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
 
 
 def barrier():
@@ -120,9 +159,10 @@ class TableReducer:
     """Reduces a stream's running table over ranks: RCCL over xGMI through the C ABI, with a
     gloo fallback.  `how` records which transport ran."""
 
-    def __init__(self, device: int):
+    def __init__(self, device: int, timeout_s=None):
         import torch.distributed as dist
         from . import api
+        self.timeout_s = COMM_TIMEOUT_S if timeout_s is None else float(timeout_s)
         self.how = "single"
         self.comm = None
         self.world = 1        # ranks of the job (torch.distributed)
@@ -134,6 +174,24 @@ class TableReducer:
         rank, world = dist.get_rank(), dist.get_world_size()
         self.world = world
         self.how = "gloo-host"
+        with deadline(self.timeout_s, "the RCCL bring-up of the table reducer"):
+            self._bring_up(device, rank, world, api)
+        self.say(f"table reducer ready: {self.report()}")
+
+    def say(self, msg):
+        """One line per rank on stderr -- also (above all) when the bring-up went wrong: the first N-rank run should not have
+        to be debugged from rank 0's summary alone."""
+        import sys
+        rank, local, _ = env_rank()
+        sys.stderr.write(f"[sketchy_amd.shard rank {rank} dev {local}] {msg}\n")
+        sys.stderr.flush()
+
+    def _bring_up(self, device, rank, world, api):
+        # the C ABI's own watchdog (ncclCommInitRank / the collective inside the library) a little inside ours
+        try:
+            api.set_option("comm_timeout_ms", int(max(1.0, self.timeout_s - 5.0) * 1000))
+        except Exception as e:  # noqa: BLE001  (a library without the option: the Python watchdog still stands)
+            self.err = repr(e)
         # every rank first proves it can load RCCL (making an id does; only rank 0's is used): a rank that cannot
         # would otherwise leave the others blocked inside ncclCommInitRank
         uid = b"\0" * 128
@@ -184,10 +242,11 @@ class TableReducer:
             self.last_ms = 0.0
             return
         t0 = time.perf_counter()
-        if self.comm is not None:
-            stream.allreduce(self.comm)  # (flushes the stream's pending batch, then ncclAllReduce + stream synchronisation)
-        else:
-            mine = stream.table()
-            total = allreduce_table_host(mine)
-            stream.table_add(total - mine)  # u64 wrap-around arithmetic is exact here
+        with deadline(self.timeout_s, f"the table all-reduce ({self.how})"):
+            if self.comm is not None:
+                stream.allreduce(self.comm)  # (flushes the stream's pending batch, then ncclAllReduce + stream synchronisation)
+            else:
+                mine = stream.table()
+                total = allreduce_table_host(mine)
+                stream.table_add(total - mine)  # u64 wrap-around arithmetic is exact here
         self.last_ms = 1e3 * (time.perf_counter() - t0)

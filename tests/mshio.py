@@ -16,7 +16,8 @@ def _lptr(off, code, count):
     return (((off << 2) & 0xFFFFFFFF) | 1) | (code << 32) | (count << 35)
 
 
-def write_msh(path, names, hashes_list, kmer=16, seed=0, lengths=None):
+def write_msh(path, names, hashes_list, kmer=16, seed=0, lengths=None, hashes32=False):
+    """hashes32: store the hashes as Mash does for k <= 16 -- 32-bit values in the hashes32 list (pointer 4), hashes64 empty"""
     w = [0] * (1 + 3 + 4)
     w[0] = _sptr(0, 3, 4)
     root = 1
@@ -39,8 +40,13 @@ def write_msh(path, names, hashes_list, kmer=16, seed=0, lengths=None):
             w.extend(struct.unpack("<%dQ" % (len(buf) // 8), buf))
             w[e + 3 + pidx] = _lptr(at - (e + 3 + pidx) - 1, 2, cnt)
         at = len(w)
-        w.extend(int(x) for x in hs)
-        w[e + 3 + 5] = _lptr(at - (e + 3 + 5) - 1, 5, len(hs))
+        if hashes32:
+            h32 = [int(x) & 0xFFFFFFFF for x in hs] + [0] * (len(hs) & 1)
+            w.extend(h32[j] | (h32[j + 1] << 32) for j in range(0, len(h32), 2))
+            w[e + 3 + 4] = _lptr(at - (e + 3 + 4) - 1, 4, len(hs))
+        else:
+            w.extend(int(x) for x in hs)
+            w[e + 3 + 5] = _lptr(at - (e + 3 + 5) - 1, 5, len(hs))
     arr = np.array(w, dtype=np.uint64)
     with open(path, "wb") as f:
         f.write(struct.pack("<II", 0, len(arr)))

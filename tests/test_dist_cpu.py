@@ -79,10 +79,13 @@ def test_shard_range_covers_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_gloo_allreduce_matches_single_stream(tmp_path):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_allreduce_matches_single_stream(tmp_path, world):
+    """World sizes 2 and 8 (the driver's node): every rank scores its contiguous shard with the oracle; the summed tables and --
+    with the exclusive-prefix extension -- every per-read row equal the single stream's (src/sketchy.rs:326, :341: u64 sums)."""
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     ref, bases, offsets = workload(40, 128, 61, read_len=500, genome_len=40000, rng_seed=77)
     single = orc.stream(16, 0, 128, ref["ref"], ref["col_len"], bases, offsets, top_k=2)
@@ -93,3 +96,22 @@ def test_two_rank_gloo_allreduce_matches_single_stream(tmp_path):
         assert str(p["how"]) == "gloo-host"
     np.testing.assert_array_equal(np.concatenate([p["idx"] for p in parts]), single["topk_idx"])
     np.testing.assert_array_equal(np.concatenate([p["sums"] for p in parts]), single["topk_sum"])
+
+
+def test_deadline_ends_a_rank_that_waits_for_ever(tmp_path):
+    """shard.deadline: a block that outlives its deadline ends the PROCESS with exit code 86 and says which rank was stuck in
+    what (the first N-rank bring-up must fail loudly instead of hanging); a block that finishes in time is left alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from sketchy_amd import shard\n"
+            "with shard.deadline(30, 'a quick block'):\n    pass\n"
+            "print('first block done', flush=True)\n"
+            "with shard.deadline(1, 'the rendezvous nobody joins'):\n    time.sleep(30)\n"
+            "print('never printed')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60,
+                         env=dict(os.environ, RANK="3", LOCAL_RANK="3", WORLD_SIZE="8"))
+    assert out.returncode == 86, (out.returncode, out.stderr[-500:])
+    assert "first block done" in out.stdout and "never printed" not in out.stdout
+    assert "rank 3 of 8" in out.stderr and "the rendezvous nobody joins" in out.stderr

@@ -165,3 +165,35 @@ def test_two_ranks_score_their_shards_on_the_hip_path(gpu, tmp_path):
         np.testing.assert_array_equal(p["reduced"], single["cum"])
     np.testing.assert_array_equal(np.concatenate([p["idx"] for p in parts]), single["topk_idx"])
     np.testing.assert_array_equal(np.concatenate([p["sums"] for p in parts]), single["topk_sum"])
+
+
+def test_bench_eight_ranks_on_one_gpu(gpu):
+    """`python bench.py --gpus 8` the way the driver launches it on its node, here with all eight ranks on the box's one GPU:
+    eight references + eight streams must fit, every rank checks its own shard, rank 0 prints ONE line whose allreduce block
+    says which transport summed the table (RCCL refuses ranks that share a device: gloo-host, accepted only by flag)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--share-gpu", "--allow-host-allreduce", "--config", "c1",
+                          "--batch", "4096", "--steps", "3", "--warmup", "1", "--reps", "2", "--cpu-seconds", "0", "--no-extra-legs"],
+                         capture_output=True, text=True, timeout=1500, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and "parity_error" not in j and len(j["values_per_rank"]) == 8
+    assert j["config"]["allreduce"]["world"] == 8 and j["config"]["allreduce"]["how"] == "gloo-host"
+    # every rank says on stderr what its reducer ended up with
+    assert sum("table reducer ready" in ln for ln in out.stderr.splitlines()) == 8, out.stderr[-3000:]
+
+
+def test_comm_watchdog_ends_a_rank_whose_peer_never_arrives(gpu):
+    """Option comm_timeout_ms: ncclCommInitRank for a 2-rank communicator with only rank 0 present blocks for ever; with the
+    watchdog the PROCESS ends with SKX_COMM_TIMEOUT_EXIT (86) after the stated time and says which rank was stuck where."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from sketchy_amd import api\n"
+            "api.set_option('comm_timeout_ms', 4000)\n"
+            "api.Comm(0, 0, 2, api.Comm.unique_id())\n"
+            "print('never printed')\n" % ROOT)
+    out = _run([sys.executable, "-c", code], timeout=240)
+    assert out.returncode == 86, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
+    assert "never printed" not in out.stdout
+    assert "rank 0 of 2" in out.stderr and "ncclCommInitRank" in out.stderr

@@ -8,5 +8,5 @@ for V in "$@"; do
   set -- $V; L=$1; shift
   # (variants with knobs load the experiments build: the product library reads no environment variable)
   X=""; [ $# -gt 0 ] && X="SKX_LIB_PATH=$PWD/sketchy_amd/libsketchy_hip_exp.so"
-  env $X "$@" timeout 600 python3 bench.py --config $CFG --steps $STEPS --cpu-seconds 0 2>/dev/null | python3 tools/bench_line.py "$L" | cut -c1-220
+  env $X "$@" timeout 600 python3 bench.py --config $CFG --steps $STEPS --cpu-seconds 0 --no-end-to-end 2>/dev/null | python3 tools/bench_line.py "$L" | cut -c1-220
 done

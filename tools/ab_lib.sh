@@ -7,6 +7,6 @@ while getopts "c:s:r:x:" o; do case $o in c) CFG=$OPTARG;; s) STEPS=$OPTARG;; r)
 for i in $(seq $ROUNDS); do
   for V in "$@"; do
     L=${V%%=*}; P=${V#*=}
-    SKX_LIB_PATH=$PWD/$P timeout 600 python3 bench.py --config $CFG --steps $STEPS --cpu-seconds 0 --no-large-batch $EXTRA 2>/dev/null | python3 tools/bench_line.py "$L" | cut -c1-330
+    SKX_LIB_PATH=$PWD/$P timeout 600 python3 bench.py --config $CFG --steps $STEPS --cpu-seconds 0 --no-large-batch --no-end-to-end $EXTRA 2>/dev/null | python3 tools/bench_line.py "$L" | cut -c1-330
   done
 done

@@ -10,3 +10,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python3 profiles/summarize_pmc.py $(find $P/pmc_${TAG}_$C -name "*counter_collection.csv") | grep -E "skx::|^kernel" > $P/${TAG}_pmc_$C.csv; rm -rf $P/pmc_${TAG}_$C
 done
 grep -E "skx::|^kernel" $P/${TAG}_kernel_stats.csv | cut -c1-120; cat $P/${TAG}_pmc_FETCH_SIZE.csv $P/${TAG}_pmc_WRITE_SIZE.csv | grep -E "scan_lean|scan_kernel|transpose"
+# HBM bytes per scan launch -> profiles/scan_traffic.json (with the sha of the sources profiled); a copy travels back in gpurun_out/
+CFG=c2; B=98304; prev=""; for a in "$@"; do [ "$prev" = "--config" ] && CFG=$a; [ "$prev" = "--batch" ] && B=$a; prev=$a; done
+python3 tools/scan_traffic.py $P/${TAG}_pmc_FETCH_SIZE.csv $P/${TAG}_pmc_WRITE_SIZE.csv ${CFG}_b$B $TAG && cp profiles/scan_traffic.json $P/${TAG}_scan_traffic.json

@@ -12,6 +12,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sketchy_amd.build import source_sha  # noqa: E402
 SETUP = ("ref_tile_kernel", "band_bounds_kernel", "filter_build_kernel")
 src, key, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 rows = {}
@@ -26,6 +28,7 @@ with open(src) as f:
 steps = max(n for name, (n, _) in rows.items() if name.startswith("sketch_wave_kernel<") and "256" in name)
 per_kernel = {name: round(tot / steps) for name, (n, tot) in sorted(rows.items(), key=lambda kv: -kv[1][1])}
 entry = {"wave_insts_per_step": int(sum(per_kernel.values())), "steps_profiled": steps, "per_kernel": per_kernel,
+         "source_sha": source_sha(),  # (of the tree the profile was taken from: run this on the box, right behind the PMC pass)
          "profile": f"profiles/{tag}_insts_per_kernel.csv (tools/pmc_all.sh: rocprofv3 --pmc SQ_INSTS_VALU ..., per-kernel totals / steps)"}
 path = os.path.join(ROOT, "profiles", "valu_insts.json")
 try:
