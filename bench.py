@@ -572,6 +572,7 @@ def main():
             big_ok = None
             if not args.no_check and top:
                 last_i = d2_ti.cpu().numpy().view(np.uint32).copy()
+                last_s = d2_ts.cpu().numpy().view(np.uint64).copy()
                 S2.reset()
                 for i in range(k2 - 1):
                     step2(i)
@@ -589,7 +590,8 @@ def main():
                     o = oo[a:a + n + 1]
                     V2.push_device(bb.data_ptr(), o.data_ptr(), n, int((o[-1] - o[0]).item()), v2[a:].data_ptr(), v2s[a:].data_ptr())
                 V2.sync()
-                big_ok = bool(np.array_equal(v2.cpu().numpy().view(np.uint32), last_i))
+                big_ok = bool(np.array_equal(v2.cpu().numpy().view(np.uint32), last_i) and
+                              np.array_equal(v2s.cpu().numpy().view(np.uint64), last_s))
                 V2.close()
                 del v2, v2s
                 if not big_ok:

@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -169,13 +170,15 @@ static void dump_marks() {}
 #endif
 
 // ------------------------------------------------------------------ policies (skx_set_option)
-static u32 g_kmer_prefilter = 0;  // k-mer prefilter of k = 16 references: 0 off, 1 on, 2 on when its table is small enough to pay
-static u32 g_filter_bits_per_hash = 32;  // membership filter: table bits per DISTINCT reference hash
-static u32 g_stream_query_rows = 0;       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
-static u32 g_stream_coalesce = 8;         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 .. 8)
+// (atomics: a host may create references / streams on several threads while another one sets a policy; every reader takes one
+// consistent value at creation)
+static std::atomic<u32> g_kmer_prefilter{0};  // k-mer prefilter of k = 16 references: 0 off, 1 on, 2 on when its table is small enough to pay
+static std::atomic<u32> g_filter_bits_per_hash{32};  // membership filter: table bits per DISTINCT reference hash
+static std::atomic<u32> g_stream_query_rows{0};       // rows of a pass's bit matrices (distinct query hashes per pass); 0 = default (65 536)
+static std::atomic<u32> g_stream_coalesce{8};         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 .. 8)
 static const int kRankLanesMax = 4;
-static u32 g_rank_lanes = 2;               // ranking lanes of a stream that enqueues (1 .. 4): chains of consecutive batches that run side by side
-static u64 g_comm_timeout_ms = 0;         // watchdog of skx_comm_create / skx_stream_allreduce: 0 = none (block for ever, as RCCL does)
+static std::atomic<u32> g_rank_lanes{2};   // ranking lanes of a stream that enqueues (1 .. 4): chains of consecutive batches that run side by side
+static std::atomic<u64> g_comm_timeout_ms{0};  // watchdog of skx_comm_create / skx_stream_allreduce: 0 = none (block for ever, as RCCL does)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
     if (!name) return fail(SKX_ERR_INVALID, "NULL option name");
@@ -432,7 +435,7 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipGetLastError());
     }
     RCHK(hipDeviceSynchronize());
-    const u32 pf_mode = skx::knob("SKX_KMER_PREFILTER") ? (u32)atoi(skx::knob("SKX_KMER_PREFILTER")) : g_kmer_prefilter;  // (experiment knob overrides the policy)
+    const u32 pf_mode = skx::knob("SKX_KMER_PREFILTER") ? (u32)atoi(skx::knob("SKX_KMER_PREFILTER")) : g_kmer_prefilter.load();  // (experiment knob overrides the policy)
     // table bits per key, and how large a table still pays.  Every window of a read costs one random 4-byte gather, and that only
     // pays while the table sits in the CUs' L1 caches (32 KB).  Measured at C2 (98 304-read batches, eight batches per scan) with the
     // table blown up to the size a larger key set would need: no table 117 M reads/s; 16 KB 128 M; 128 KB 105 M; 1 MB 96 M; 4 MB
@@ -977,7 +980,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     pc = std::max<u64>(pc, sk_stride);
     pc = (pc + 63) / 64 * 64;
     st->pcap = (u32)pc;
-    u64 qc = g_stream_query_rows ? g_stream_query_rows : 65536;
+    const u32 rows_policy = g_stream_query_rows.load();
+    u64 qc = rows_policy ? rows_policy : 65536;
     if (dense_queries) {
         size_t mem_free = 0, mem_total = 0;
         (void)hipMemGetInfo(&mem_free, &mem_total);
@@ -987,7 +991,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     qc = (qc + 63) / 64 * 64;
     st->qcap = (u32)qc;
     static const u32 coalesce_env = skx::knob("SKX_COALESCE") ? (u32)atoi(skx::knob("SKX_COALESCE")) : 0u;  // experiment knob
-    st->coalesce = coalesce_env ? std::min<u32>((u32)kGroupMax, std::max(1u, coalesce_env)) : g_stream_coalesce;
+    st->coalesce = coalesce_env ? std::min<u32>((u32)kGroupMax, std::max(1u, coalesce_env)) : g_stream_coalesce.load();
     st->group_cap = st->coalesce;
     // reads per pass: the whole batch if the ranking's per-segment arrays fit (inc / rel: 4 bytes per (64 reads, genome) each, at most
     // an eighth of the free device memory) -- a batch cut into two passes scans the reference twice
@@ -1141,7 +1145,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_bsum, ((size_t)max_reads / 1024 + 2) * 4));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64) + 1) * 4));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_rowany[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (st->qcap / 64) * 8));
-    if (skx::scan_lean_applies(ref->n_bands, false, false)) {
+    // (the slabs of round 3's lean kernel: 252 MB at C2, 0.94 GB at C4 -- only when that kernel can be selected at all: SKX_SCAN_RUN=0)
+    static const bool slabs_env = !(skx::knob("SKX_SCAN_RUN") != nullptr && atoi(skx::knob("SKX_SCAN_RUN")) != 0);
+    if (slabs_env && skx::scan_lean_applies(ref->n_bands, false, false)) {
         SCHK(hipMalloc(&st->d_hbuf, (size_t)n_bt * skx::scan_lean_words() * skx::kTileGenomes * 8));
         for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_wb[i], ((size_t)st->qcap / 64 + 1) * ref->n_tiles * 16));
     }
@@ -1310,7 +1316,20 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     if (nq_known) nq_est = std::max<u64>(1, q_rows);
     // (decided once per pass, before the dictionary stage picks between windows + word -> bands and windows alone: the lean scan
     // kernel's results as slabs or straight into M -- skx::scan_lean_into_m)
-    const bool into_m = st->d_hbuf && skx::scan_lean_into_m((nq_est / 64 + 1) * (u64)n_pad * 8);
+    // Sparse dictionaries (every production pass) go through scan_run_kernel: RUNS of bands per workgroup, results into M.  The run
+    // length from the expected entries of a band's slice -- ~3.1 x rows x |Q| / s: the order statistics of a tile's 256 genomes spread
+    // a band's hash range to three times one genome's -- so that the union window of the run (adjacent bands overlap by two thirds)
+    // stays inside one window of the kernel's tables with a third to spare; 1 .. 4 (longer runs: fewer, larger workgroups -- the
+    // tail of the launch grows).  Experiment knob SKX_SCAN_RUN: 0 = round 3's kernels, n = force runs of n.
+    static const int run_env = skx::knob("SKX_SCAN_RUN") ? atoi(skx::knob("SKX_SCAN_RUN")) : 0;
+    u32 scan_run = 0;
+    if (run_env != 0 && ref->n_bands <= 65535u) {
+        const double per_band = (double)ref->rb * (double)nq_est / (double)std::max<u32>(ref->s, 1u);
+        scan_run = 1;
+        while (scan_run < 4u && (scan_run + 1 + 2.1) * per_band * 1.35 <= (double)skx::scan_run_cap()) ++scan_run;
+        if (run_env > 0) scan_run = (u32)std::min(run_env, 64);
+    }
+    const bool into_m = scan_run != 0 || (st->d_hbuf && skx::scan_lean_into_m((nq_est / 64 + 1) * (u64)n_pad * 8));
 
     // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already).  Set b was last used two
     // passes ago: by that pass's dictionary / scan / transpose on THIS stream (Q, windows, hash set: ordered by the stream)
@@ -1334,7 +1353,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                                     st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len);
         skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
                               st->d_dict_ctr[b], d_q, d_nq);
-        if (st->d_hbuf && !into_m) {  // (windows + word -> bands in one launch; also hands |Q| to the host)
+        if (st->d_hbuf && !into_m) {  // (round 3's slab form only: windows + word -> bands in one launch; also hands |Q| to the host)
             skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b], ref->d_lo, ref->d_hi, d_q, &st->h_nq[b]);
         } else {
             skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);
@@ -1392,14 +1411,16 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         }
         static const int big_env = skx::knob("SKX_SCAN_BIG") ? atoi(skx::knob("SKX_SCAN_BIG")) : -1;
         const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
-        const bool lean = st->d_hbuf && skx::scan_lean_applies(ref->n_bands, split, big);
+        const bool run_scan = scan_run != 0 && !split && !big;  // (dense dictionaries: scan_kernel's variants, as before)
+        const bool lean = run_scan || (st->d_hbuf && skx::scan_lean_applies(ref->n_bands, split, big));
         st->total_passes += 1; st->lean_passes += lean ? 1 : 0;
         {
             Span sp(st, 2, hs);
             // sparse dictionaries: the lean kernel with its single-owner slabs; dense ones: scan_kernel's variants into M
             // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
             skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, d_q, d_win, st->d_m,
-                             split ? st->d_mint : nullptr, n_pad, big, lean ? st->d_hbuf : nullptr, d_mdirty, into_m);
+                             split ? st->d_mint : nullptr, n_pad, big, (lean && !run_scan) ? st->d_hbuf : nullptr, d_mdirty, into_m,
+                             run_scan ? scan_run : 0u);
         }
         {
             Span sp(st, 1, hs);
