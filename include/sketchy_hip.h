@@ -88,6 +88,10 @@ int skx_device_pci_bus_id(int device, char *bus_id, size_t cap);
  *                     the cost of up to n - 1 more batches of latency and n + 1 copies of the per-batch sketch rows (25 MB
  *                     each at C2).  A group whose pairs or distinct hashes turn out too many for one pass is processed
  *                     batch by batch, and the stream forms smaller groups from then on.
+ *   "rank_lanes"      1 .. 4 (default 2): the rankings of the batches that share a pass run as chains on this many HIP streams,
+ *                     each with its own scratch (the table a batch starts from is all a chain needs of the one before it: it waits
+ *                     for that chain's second kernel, not for its end).  C2, 20 batches from a fresh table: 131 M reads/s on one
+ *                     lane, 134 M on two, 129-131 M on three / four; ~0.6 GB of scratch per lane at C2, 2.3 GB at C4.
  *   "comm_timeout_ms" 0 (default: no watchdog) .. 86 400 000: skx_comm_create (ncclCommInitRank) and skx_stream_allreduce
  *                     (ncclAllReduce + its stream synchronisation) block for ever when a peer never arrives.  With a
  *                     timeout set, a call that has not returned in time prints which rank was stuck in what to stderr and
@@ -212,6 +216,13 @@ int skx_stream_sync(skx_stream *st);
  * the input buffers may be reused after the NEXT submit has returned (or after wait / drain).  Results are those of
  * the same batches pushed with skx_stream_push in the same order.  Do not interleave with skx_stream_push[_device]
  * without a drain in between.
+ * Errors: a batch that turns out to be faulty (offsets not monotonic ...) makes the submit that hands it to the kernels -- or a
+ * later wait / drain -- fail; batches submitted BEFORE it are processed and their rows delivered, the faulty one and those
+ * submitted after it (up to the failing call, the failing call's own batch included) are dropped, and skx_stream_wait on a
+ * dropped ticket fails instead of returning rows that were never written.
+ * skx_stream_wait(ticket) on a batch that still waits for the partners of its group closes the group early (a pass for fewer
+ * batches): a host that wants full groups waits for a ticket only once nine younger ones have been submitted -- by then the
+ * batch is through and the call returns at once (sketchy_amd/host/sketchy_host.cpp does exactly that).
  */
 int skx_stream_submit(skx_stream *st, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                       uint32_t *topk_idx, uint64_t *topk_sum, uint64_t *ticket);

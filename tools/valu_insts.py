@@ -3,7 +3,7 @@
 issues, per kernel of this library, from the per-kernel SQ_INSTS_VALU means of tools/pmc_all.sh; merges the entry into
 profiles/valu_insts.json (what bench.py's roofline_valu block quotes).
 
-A step launches sketch_wave_kernel<.., 256, true> exactly once, so a kernel's launches per step = its dispatches / that
+A step launches the main sketch kernel (sketch_wave_kernel<k, HCAP, true> with the smallest HCAP) exactly once, so a kernel's launches per step = its dispatches / that
 kernel's dispatches (set-up kernels -- ref_tile, band_bounds, filter_build -- are left out: they run once per reference)."""
 import csv
 import json
@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 from sketchy_amd.build import source_sha  # noqa: E402
 SETUP = ("ref_tile_kernel", "band_bounds_kernel", "filter_build_kernel")
 src, key, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+sha = sys.argv[4] if len(sys.argv) > 4 else source_sha()   # (argv[4]: re-deriving the JSON from a CSV of an earlier tree)
 rows = {}
 with open(src) as f:
     for r in csv.DictReader(f):
@@ -25,10 +26,13 @@ with open(src) as f:
         if any(name.startswith(s) for s in SETUP):
             continue
         rows[name] = (int(r["dispatches"]), float(r["total_value"]))
-steps = max(n for name, (n, _) in rows.items() if name.startswith("sketch_wave_kernel<") and "256" in name)
+# the main sketch kernel = the INRANGE instance with the smallest hash buffer (HCAP 128 since round 4, 256 before)
+main = min((name for name in rows if re.match(r"sketch_wave_kernel<\d+, \d+, true>", name)),
+           key=lambda name: int(name.split(",")[1]))
+steps = rows[main][0]
 per_kernel = {name: round(tot / steps) for name, (n, tot) in sorted(rows.items(), key=lambda kv: -kv[1][1])}
 entry = {"wave_insts_per_step": int(sum(per_kernel.values())), "steps_profiled": steps, "per_kernel": per_kernel,
-         "source_sha": source_sha(),  # (of the tree the profile was taken from: run this on the box, right behind the PMC pass)
+         "source_sha": sha,  # (of the tree the profile was taken from: run this on the box, right behind the PMC pass)
          "profile": f"profiles/{tag}_insts_per_kernel.csv (tools/pmc_all.sh: rocprofv3 --pmc SQ_INSTS_VALU ..., per-kernel totals / steps)"}
 path = os.path.join(ROOT, "profiles", "valu_insts.json")
 try:
