@@ -1145,9 +1145,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_bsum, ((size_t)max_reads / 1024 + 2) * 4));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64) + 1) * 4));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_rowany[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (st->qcap / 64) * 8));
-    // (the slabs of round 3's lean kernel: 252 MB at C2, 0.94 GB at C4 -- only when that kernel can be selected at all: SKX_SCAN_RUN=0)
-    static const bool slabs_env = !(skx::knob("SKX_SCAN_RUN") != nullptr && atoi(skx::knob("SKX_SCAN_RUN")) != 0);
-    if (slabs_env && skx::scan_lean_applies(ref->n_bands, false, false)) {
+    // (the slabs of round 3's form of the lean kernel, 252 MB at C2, 0.94 GB at C4: experiments build, when a knob asks for that form)
+    if (skx::scan_lean_wants_slabs() && skx::scan_lean_applies(ref->n_bands, false, false)) {
         SCHK(hipMalloc(&st->d_hbuf, (size_t)n_bt * skx::scan_lean_words() * skx::kTileGenomes * 8));
         for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_wb[i], ((size_t)st->qcap / 64 + 1) * ref->n_tiles * 16));
     }
@@ -1314,13 +1313,12 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // pairs of a single batch but hardly more distinct hashes, and was sent to the dense-dictionary scan kernel)
     const bool nq_known = inserted && q_rows != 0xFFFFFFFFu;
     if (nq_known) nq_est = std::max<u64>(1, q_rows);
-    // (decided once per pass, before the dictionary stage picks between windows + word -> bands and windows alone: the lean scan
-    // kernel's results as slabs or straight into M -- skx::scan_lean_into_m)
-    // Sparse dictionaries (every production pass) go through scan_run_kernel: RUNS of bands per workgroup, results into M.  The run
-    // length from the expected entries of a band's slice -- ~3.1 x rows x |Q| / s: the order statistics of a tile's 256 genomes spread
-    // a band's hash range to three times one genome's -- so that the union window of the run (adjacent bands overlap by two thirds)
-    // stays inside one window of the kernel's tables with a third to spare; 1 .. 4 (longer runs: fewer, larger workgroups -- the
-    // tail of the launch grows).  Experiment knob SKX_SCAN_RUN: 0 = round 3's kernels, n = force runs of n.
+    // The lean scan kernel's results go straight into M (skx::scan_lean_into_m; the slab form of round 3 only when an experiment
+    // knob asks for it, in which case the dictionary stage also builds the word -> bands lists).
+    // Experiment knob SKX_SCAN_RUN (default 0 = the lean kernel): scan_run_kernel, RUNS of bands per workgroup -- measured slower
+    // (DESIGN.md).  The run length from the expected entries of a band's slice -- ~3.1 x rows x |Q| / s: the order statistics of a
+    // tile's 256 genomes spread a band's hash range to three times one genome's -- so that the union window of the run (adjacent
+    // bands overlap by two thirds) stays inside one window of the kernel's tables with a third to spare; 1 .. 4; n > 0 forces n.
     static const int run_env = skx::knob("SKX_SCAN_RUN") ? atoi(skx::knob("SKX_SCAN_RUN")) : 0;
     u32 scan_run = 0;
     if (run_env != 0 && ref->n_bands <= 65535u) {
@@ -1329,7 +1327,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         while (scan_run < 4u && (scan_run + 1 + 2.1) * per_band * 1.35 <= (double)skx::scan_run_cap()) ++scan_run;
         if (run_env > 0) scan_run = (u32)std::min(run_env, 64);
     }
-    const bool into_m = scan_run != 0 || (st->d_hbuf && skx::scan_lean_into_m((nq_est / 64 + 1) * (u64)n_pad * 8));
+    const bool into_m = scan_run != 0 || !st->d_hbuf || skx::scan_lean_into_m();
 
     // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already).  Set b was last used two
     // passes ago: by that pass's dictionary / scan / transpose on THIS stream (Q, windows, hash set: ordered by the stream)
@@ -1412,14 +1410,14 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         static const int big_env = skx::knob("SKX_SCAN_BIG") ? atoi(skx::knob("SKX_SCAN_BIG")) : -1;
         const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
         const bool run_scan = scan_run != 0 && !split && !big;  // (dense dictionaries: scan_kernel's variants, as before)
-        const bool lean = run_scan || (st->d_hbuf && skx::scan_lean_applies(ref->n_bands, split, big));
+        const bool lean = run_scan || skx::scan_lean_applies(ref->n_bands, split, big);
         st->total_passes += 1; st->lean_passes += lean ? 1 : 0;
         {
             Span sp(st, 2, hs);
             // sparse dictionaries: the lean kernel with its single-owner slabs; dense ones: scan_kernel's variants into M
             // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
             skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, d_q, d_win, st->d_m,
-                             split ? st->d_mint : nullptr, n_pad, big, (lean && !run_scan) ? st->d_hbuf : nullptr, d_mdirty, into_m,
+                             split ? st->d_mint : nullptr, n_pad, big, lean && !run_scan, (lean && !run_scan) ? st->d_hbuf : nullptr, d_mdirty, into_m,
                              run_scan ? scan_run : 0u);
         }
         {

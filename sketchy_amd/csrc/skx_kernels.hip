@@ -3642,22 +3642,30 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
                        m_bits, n_pad, m_dirty);
 }
 
+bool scan_lean_wants_slabs();
 bool scan_lean_applies(u32 n_bands, bool split, bool big_table) {
     static const int lean_env = env_int("SKX_SCAN_LEAN", 1);
-    return lean_env && !split && !big_table && n_bands <= kWordBandsMax;
+    // (the slab form needs n_bands <= kWordBandsMax for its word -> bands lists; results into M need no list)
+    return lean_env && !split && !big_table && (!scan_lean_wants_slabs() || n_bands <= kWordBandsMax);
 }
 u32 scan_lean_words() { return kLeanWords; }
-// Should the lean kernel put its results straight into M (atomicOr, no slabs; the transpose then reads M only)?  Yes while the
-// pass's M stays on chip: `m_bytes` = (distinct query hashes / 64) words x padded genomes x 8.  Measured, C2 (52-100 MB), scan
-// alone: slabs 0.63-0.67 of the 8 TB/s peak, M with non-temporal matrix loads 0.71-0.75 (in the pipeline 0.63 -> 0.69); C4
-// (378 MB: beyond the 256 MB infinity cache): 0.57 / 0.59, nothing in the pipeline -- slabs stay there.
-bool scan_lean_into_m(u64 m_bytes) {
+// The lean kernel puts its results straight into M (atomicOr at the end of a block, no slabs; the transpose then reads M only and
+// zeroes it again).  Round 3 did so only while the pass's whole M was smaller than the infinity cache (C2: 52-100 MB) and kept
+// per-block slabs for C4 (378 MB).  Round 4: the size of M does not matter -- the launch walks the matrix band by band, and a band's
+// blocks touch the same handful of word rows of M (a few MB, whatever the dictionary's size), which are written back once when
+// the launch has moved on: measured at C4 (tools/ab.sh, same box, twice each) slabs 45.8-46.2 M reads/s, scan alone 0.62-0.63
+// of the 8 TB/s peak; into M 47.4 M, 0.66-0.67, a lone batch +4 %, and 0.9 GB less written per pass.  The slab form survives in
+// the experiments build only (SKX_SCAN_NT = 0..3, SKX_SCAN_ABLATE), which then also allocates the slabs.
+bool scan_lean_wants_slabs() {
 #ifdef SKX_EXPERIMENTS
-    static const int nt = env_int("SKX_SCAN_NT", -1);  // experiment knob: bit 2 forces it, 0..3 forbid it
-    if (nt >= 0) return (nt & 4) != 0;
+    static const int nt = env_int("SKX_SCAN_NT", -1);  // experiment knob: bit 2 = results into M, 0..3 = slabs
+    static const int ablate = env_int("SKX_SCAN_ABLATE", 0);
+    return ablate != 0 || (nt >= 0 && (nt & 4) == 0);
+#else
+    return false;
 #endif
-    return m_bytes <= (192ull << 20);
 }
+bool scan_lean_into_m() { return !scan_lean_wants_slabs(); }
 void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb, const u64* lo, const u64* hi,
                        const u64* q, u32* h_nq) {
     hipLaunchKernelGGL(word_bands_kernel, dim3(n_tiles), dim3(256), 0, st, win, n_tiles, n_bands, n_q, wb, lo, hi, q, h_nq);
@@ -3666,8 +3674,8 @@ void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const
 u32 scan_run_cap() { return kRunCap; }
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table,
-                 u64* hbuf /* slabs of the lean kernel, or NULL: legacy kernels */, u32* m_dirty,
-                 bool into_m /* lean kernel: results by atomicOr into m_bits instead of slabs (scan_lean_into_m) */,
+                 bool lean /* sparse dictionaries: scan_lean_kernel */, u64* hbuf /* its slabs (experiments build; NULL: results into M) */,
+                 u32* m_dirty, bool into_m /* lean kernel: results by atomicOr into m_bits instead of slabs (scan_lean_into_m) */,
                  u32 run /* > 0: scan_run_kernel, one workgroup per `run` consecutive bands of a tile (results into m_bits) */) {
     dim3 grid(n_tiles * n_bands), block(256);
     if (run) {
@@ -3681,7 +3689,7 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
     static const int nt_env = env_int("SKX_SCAN_NT", -1);  // 1 = non-temporal slab stores, 2 = matrix loads, 3 = both, +4 = results into M
     const int nt = nt_env > 0 ? nt_env : 0;
     static const u32 prio = (u32)env_int("SKX_SCAN_PRIO", 1);
-    if (hbuf && (ablate || nt)) {
+    if (lean && hbuf && (ablate || nt)) {
 #define SKX_SCAN_L(A, N) hipLaunchKernelGGL((scan_lean_kernel<A, N>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio)
         if (ablate == 1) SKX_SCAN_L(1, 0); else if (ablate == 2) SKX_SCAN_L(2, 0); else if (ablate == 3) SKX_SCAN_L(3, 0);
         else if (nt == 1) SKX_SCAN_L(0, 1); else if (nt == 2) SKX_SCAN_L(0, 2); else if (nt == 3) SKX_SCAN_L(0, 3);
@@ -3689,7 +3697,7 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 #undef SKX_SCAN_L
         return;
     }
-    if (!hbuf && ablate) {
+    if (!lean && ablate) {
 #define SKX_SCAN_A(CAP, A, SP) hipLaunchKernelGGL((scan_kernel<CAP, A, SP>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad)
         if (big_table && m_int) { if (ablate == 1) SKX_SCAN_A(4088, 1, true); else if (ablate == 2) SKX_SCAN_A(4088, 2, true); else SKX_SCAN_A(4088, 3, true); }
         else if (ablate == 1) SKX_SCAN_A(2040, 1, false); else if (ablate == 2) SKX_SCAN_A(2040, 2, false); else SKX_SCAN_A(2040, 3, false);
@@ -3700,8 +3708,8 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
     const u32 prio = 1u;
 #endif
     // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe
-    if (hbuf) {
-        if (into_m) hipLaunchKernelGGL((scan_lean_kernel<0, 6>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+    if (lean) {
+        if (into_m || !hbuf) hipLaunchKernelGGL((scan_lean_kernel<0, 6>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
         else hipLaunchKernelGGL((scan_lean_kernel<0, 0>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
         return;
     }

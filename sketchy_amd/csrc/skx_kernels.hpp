@@ -114,17 +114,20 @@ void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n
                        u64* m_bits, u32 n_pad, u32* m_dirty /* raised when a bit was set, or NULL */);
 
 // scan + transpose
-// hbuf != NULL: the lean kernel (sparse dictionaries): every (band, tile) block stores the words of its slice into its own
-// slab hbuf[(band * n_tiles + tile) * scan_lean_words() * 256 ...] (plain stores, nothing to clear); only bands with
-// dense slices go through atomicOr into m_bits and raise *m_dirty.  hbuf == NULL: scan_kernel variants into m_bits / m_int.
+// lean: scan_lean_kernel (sparse dictionaries: every production pass) -- every (band, tile) block ORs the words of its slice into
+// m_bits when its band is done (one coalesced atomicOr per non-zero word) and raises *m_dirty; !lean: scan_kernel variants into
+// m_bits / m_int.  Experiments build only: hbuf != NULL with into_m == false = round 3's slab form (every block stores its words
+// into its own slab hbuf[(band * n_tiles + tile) * scan_lean_words() * 256 ...]; scan_lean_wants_slabs() says whether a knob asks
+// for it, and the stream then allocates the slabs).
 bool scan_lean_applies(u32 n_bands, bool split, bool big_table);
 u32 scan_lean_words();
-bool scan_lean_into_m(u64 m_bytes);
+bool scan_lean_wants_slabs();
+bool scan_lean_into_m();
 // run > 0: scan_run_kernel -- one workgroup per `run` consecutive bands of a tile, results OR-ed into m_bits (no slabs, no hbuf);
 // windows of up to scan_run_cap() entries in one pass over the rows
 u32 scan_run_cap();
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
-                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table, u64* hbuf, u32* m_dirty, bool into_m = false, u32 run = 0);
+                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table, bool lean, u64* hbuf, u32* m_dirty, bool into_m = true, u32 run = 0);
 // wb[w * n_tiles + t] = (first | last << 16) band of tile t whose slice can reach query word w (first > last: none)
 // lo != NULL: also computes the windows (launch_window's work) first: one launch instead of two in front of the scan
 void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb, const u64* lo = nullptr,

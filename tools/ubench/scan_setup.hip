@@ -16,7 +16,19 @@ __global__ __launch_bounds__(256) void k(const u64* __restrict__ mat, u64* __res
     __shared__ unsigned char dir[4104];
     __shared__ u64 acc[5][256];
     __shared__ u64 pad[PADKB ? PADKB * 128 : 1];  // (occupancy experiments: more LDS per block, fewer blocks per CU)
-    const u64* band = mat + (size_t)blockIdx.x * 64 * 256;
+    // V >= 10: XCD-aware order -- all bands of a tile on XCD (tile % 8) (observed: block b runs on XCD b % 8; checked per block
+    // with HW_REG_XCC_ID, never assumed), so that the tile's columns of M can be OR-ed by atomics executed in that XCD's L2
+    // (workgroup-scope form: no sc1) instead of at the memory side; a block that finds itself elsewhere uses the device-scope
+    // form on a second copy of M
+    unsigned blk = blockIdx.x, xt = 0, xb = 0; bool home = false;
+    if (V >= 10) {
+        const unsigned nb = 154, x8 = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        xt = (j / nb) * 8u + x8; xb = j % nb;
+        if (xt >= 158u) return;
+        blk = xt * nb + xb;
+        home = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) == x8;
+    }
+    const u64* band = mat + (size_t)blk * 64 * 256;
     const unsigned c = threadIdx.x;
     u64 x = 0;
     if (PADKB) { pad[c] = c; x = pad[(c * 7) & 127]; }
@@ -26,7 +38,7 @@ __global__ __launch_bounds__(256) void k(const u64* __restrict__ mat, u64* __res
         for (int u = 0; u < 8; ++u) h[u] = __builtin_nontemporal_load(&band[(size_t)u * 256 + c]);
     }
     if (V >= 1 && V != 4) {  // (V 6..: the set-up of V3)
-        const u32 qa = win[2 * blockIdx.x], qb = win[2 * blockIdx.x + 1];
+        const u32 qa = win[2 * blk], qb = win[2 * blk + 1];
         const u64 lo = q[qa], hi = q[qb - 1];
         x = lo ^ hi;
         if (V >= 2) {
@@ -57,7 +69,7 @@ __global__ __launch_bounds__(256) void k(const u64* __restrict__ mat, u64* __res
     // V >= 8: the tile's non-zero words go to a compact M by atomicOr when the band is done
     u64* my_acc = &acc[0][c];
     auto probe = [&](u64 hv) {
-        if (V < 6 || V == 9) { x ^= hv; return; }
+        if (V < 6 || V == 9 || V == 10) { x ^= hv; return; }
         const u32 bk = min((u32)(hv >> 32) >> 8, 4096u);
         const u32 j = dir[bk & 4095u];
         const u64 e0 = slice[j & 255u], e1 = slice[(j + 1u) & 255u];
@@ -79,7 +91,15 @@ __global__ __launch_bounds__(256) void k(const u64* __restrict__ mat, u64* __res
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) probe(h[u]);
-    if (V >= 8) {
+    if (V >= 10) {
+        u64* o = out + (1 << 19) + (size_t)(xb / 3u) * (158 * 256) + xt * 256 + c;   // M[word][genome]: a band reaches ~5 words, the next band 1-2 further
+        if (!home) { o += (size_t)64 * 158 * 256; if (c == 0) atomicAdd((unsigned*)out + 8, 1u); }
+#pragma unroll
+        for (int w = 0; w < 5; ++w) {
+            const u64 v = V == 10 ? x + w : my_acc[(size_t)w * 256];
+            if (v) { if (home) __hip_atomic_fetch_or(&o[(size_t)w * 158 * 256], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else atomicOr(&o[(size_t)w * 158 * 256], v); }
+        }
+    } else if (V >= 8) {
         const unsigned n_tiles = 158, t = blockIdx.x % n_tiles, b = blockIdx.x / n_tiles;
         u64* o = out + (1 << 19) + (size_t)b * (n_tiles * 256) + t * 256 + c;   // M[word b + w][genome]
 #pragma unroll
@@ -89,7 +109,7 @@ __global__ __launch_bounds__(256) void k(const u64* __restrict__ mat, u64* __res
 }
 template <int V, int PADKB = 0>
 static void run(const char* name, const u64* mat, size_t bytes, u64* out, const u32* win, const u64* q) {
-    const unsigned blocks = (unsigned)(bytes / (64 * 256 * 8));
+    const unsigned blocks = V >= 10 ? 160u * 154u : (unsigned)(bytes / (64 * 256 * 8));
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     hipLaunchKernelGGL((k<V, PADKB>), dim3(blocks), dim3(256), 0, 0, mat, out, win, q); hipDeviceSynchronize();
     float best = 1e9f;
@@ -119,6 +139,10 @@ int main() {
     run<7>("V7 = V6 + hits OR-ed into the LDS tile", mat, bytes, out, win, q);
     run<8>("V8 = V7 + the tile's words atomicOr-ed into a compact M", mat, bytes, out, win, q);
     run<9>("V9 = V3 + 5 atomicOr per lane into a compact M, no probe", mat, bytes, out, win, q);
+    hipMemset(out, 0, 64);
+    run<10>("V10 = V9 in XCD order, atomics in the XCD's L2", mat, bytes, out, win, q);
+    run<11>("V11 = V8 in XCD order, atomics in the XCD's L2", mat, bytes, out, win, q);
+    { unsigned away = 0; hipMemcpy(&away, (unsigned*)out + 8, 4, hipMemcpyDeviceToHost); printf("blocks that did not run on XCD (block %% 8): %u of %u\n", away, 12 * 158 * 154); }
     run<7, 8>("V7 with 24 KB of LDS in all (6 blocks per CU)", mat, bytes, out, win, q);
     run<7, 16>("V7 with 32 KB (5 per CU)", mat, bytes, out, win, q);
     run<7, 24>("V7 with 40 KB (4 per CU)", mat, bytes, out, win, q);
