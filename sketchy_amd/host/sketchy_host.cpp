@@ -394,10 +394,22 @@ class Sketchy {
             };
             auto lf = [&](const char* q) { return static_cast<const char*>(memchr(q, '\n', (size_t)(b - q))); };
             const char* p = a;
+            size_t stride = 0;  // length of the previous record
+            static const bool guess_next = !getenv("SKETCHY_HIP_NO_PREFETCH");  // (measurement aid, like SKETCHY_HIP_NO_POPULATE)
             while (p < b) {
                 if (*p == '\n' || *p == '\r') { ++p; continue; }
                 if (fastq) {
                     if (*p != '@') throw SketchyError("input is neither FASTA nor FASTQ");
+                    // The quality line is skipped, so every record starts with cache misses the hardware prefetcher cannot see
+                    // coming: the byte that ends this record, the next header, the first lines of its sequence.  Records of one
+                    // file mostly have one length (short-read instruments: exactly), so the previous record's length says where
+                    // they are: requested now, they arrive while this record's sequence is packed.  A wrong guess costs five
+                    // useless prefetches.
+                    if (stride && guess_next && (size_t)(b - p) > stride + 320) {
+                        const char* nx = p + stride;
+                        for (int i = -64; i < 320; i += 64) __builtin_prefetch(nx + i, 0, 1);
+                    }
+                    const char* const rec0 = p;
                     const char* e0 = lf(p);
                     if (!e0 || e0 + 1 >= b) throw SketchyError("truncated FASTQ record");
                     const char* s0 = e0 + 1;
@@ -415,6 +427,7 @@ class Sketchy {
                     pos = pos1;
                     end_record();
                     p = e3 ? e3 + 1 : b;
+                    stride = (size_t)(p - rec0);
                 } else {
                     if (*p != '>') throw SketchyError("input is neither FASTA nor FASTQ");
                     const char* e0 = lf(p);
