@@ -1415,6 +1415,15 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
         const bool run_scan = scan_run != 0 && !split && !big;  // (dense dictionaries: scan_kernel's variants, as before)
         const bool lean = run_scan || skx::scan_lean_applies(ref->n_bands, split, big);
+        // Experiment knob SKX_SCAN_BIGSLICE=1: the lean kernel's BIG instance (slices of up to 510 entries in one pass of the
+        // branch-free probe: two-byte directory, three entries per probe, nine result words, 31 KB of LDS).  A (band, tile) slice
+        // holds ~3.1 x rows per band x |Q| / s entries on average -- C4: ~245 with one batch per pass, ~390 with eight, so most of
+        // its blocks leave the 254-entry probe for the multi-window walk.  Measured at C4 (tools/ab.sh, twice each): the scan
+        // of a shared pass 2.90 -> 2.65 ms in the pipeline (0.52 -> 0.57 of peak), but reads/s 48.1 -> 47.5-48.0 M from a fresh
+        // table, 57.0 -> 53.8 M steady, single-batch passes 0.66-0.68 -> 0.60 alone: the walk costs less than three LDS reads per
+        // element and twice the LDS per block do beside the other streams.  Off.
+        static const int bigslice_env = skx::knob("SKX_SCAN_BIGSLICE") ? atoi(skx::knob("SKX_SCAN_BIGSLICE")) : 0;
+        const bool big_slices = lean && into_m && bigslice_env != 0;
         st->total_passes += 1; st->lean_passes += lean ? 1 : 0;
         {
             Span sp(st, 2, hs);
@@ -1422,7 +1431,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
             skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, d_q, d_win, st->d_m,
                              split ? st->d_mint : nullptr, n_pad, big, lean && !run_scan, (lean && !run_scan) ? st->d_hbuf : nullptr, d_mdirty, into_m,
-                             run_scan ? scan_run : 0u);
+                             run_scan ? scan_run : 0u, big_slices);
         }
         {
             Span sp(st, 1, hs);

@@ -1713,10 +1713,17 @@ constexpr u32 kLeanBigFrom = 96;
 constexpr u32 kLeanMultiCap = 1022;    // entries per sub-window of a slice beyond kLeanCap (tables in the result tile's LDS)
 static_assert((kLeanMultiCap + 2) * 8 <= 5 * 256 * 8 && (2048 + 2) * 2 <= kLeanBucketsMax + 8, "multi-window tables alias the lean ones");
 constexpr u32 kLeanWords = 5;  // query words a slice of <= kLeanCap entries can touch
+// BIG instance (round 4; passes whose slices mostly exceed kLeanCap -- C4 with eight batches per pass: ~390 entries per slice):
+// the same branch-free probe over slices of up to kLeanCapBig entries -- a two-byte directory of 4096 buckets and THREE
+// consecutive entries per probe (more than three entries in one bucket: the walk probe, as before), nine result words.  31 KB
+// of LDS per block instead of 16.  Slices beyond that still take the multi-window path.
+constexpr u32 kLeanCapBig = 510;
+constexpr u32 kLeanWordsBig = 9;
+constexpr u32 kLeanBucketsBig = 4096;
 
 // NT: bit 0 = non-temporal slab stores, bit 1 = non-temporal loads of the matrix (it is streamed once per pass: marking its
 // lines evict-first keeps them from flushing what the kernels running beside the scan gather from -- Mq, the pair lists)
-template <int ABLATE, int NT = 0>
+template <int ABLATE, int NT = 0, bool BIG = false>
 __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64* __restrict__ mat, u32 s, u32 n_tiles, u32 rb,
                                                         const u64* __restrict__ q, const u32* __restrict__ win,
                                                         u64* __restrict__ m_bits, u32 n_pad, u64* __restrict__ hbuf,
@@ -1724,22 +1731,25 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
     // next to the VALU-bound sketch / ranking kernels (three-stream pipeline) the scan's few instructions should not
     // queue behind theirs: its loads are what keeps HBM busy
     if (prio) __builtin_amdgcn_s_setprio(3);
-    __shared__ u64 slice[kLeanCap + 2];
-    __shared__ unsigned char dir[kLeanBucketsMax + 8];
-    __shared__ u64 acc[kLeanWords][kTileGenomes];
-    __shared__ u32 deep;  // some bucket holds more than two entries (or the slice spans < 2^43): walk probe
+    constexpr u32 CAP = BIG ? kLeanCapBig : kLeanCap, WORDS = BIG ? kLeanWordsBig : kLeanWords;
+    static_assert(!BIG || (NT & 4), "the BIG instance writes into M only");
+    static_assert((kLeanMultiCap + 3) * 8 <= WORDS * 256 * 8, "multi-window slice aliases the result tile");
+    __shared__ u64 slice[CAP + 3];
+    __shared__ unsigned char dir[BIG ? 2 * (kLeanBucketsBig + 8) : kLeanBucketsMax + 8];
+    __shared__ u64 acc[WORDS][kTileGenomes];
+    __shared__ u32 deep;  // some bucket holds more than two (BIG: three) entries (or the slice spans < 2^43): walk probe
     const u32 bt = blockIdx.x;
     const u32 t = bt % n_tiles, b = bt / n_tiles, c = threadIdx.x;
     const u32 qa = win[2 * bt], qb = win[2 * bt + 1];
     if (qa >= qb) return;
     const u32 i0 = b * rb, rows = min(s, i0 + rb) - i0;
     const u32 g = t * kTileGenomes + c;
-    const bool multi = qb - qa > kLeanCap;  // several sub-window passes: the atomic path into M
+    const bool multi = qb - qa > CAP;  // several sub-window passes: the atomic path into M
     if (multi && c == 0) *m_dirty = 1u;
     const u32 w0 = qa >> 6, n_w = ((qb - 1u) >> 6) - w0 + 1u;  // (single window: n_w <= kLeanWords)
     if (!multi) {
 #pragma unroll
-        for (u32 k = 0; k < kLeanWords; ++k) acc[k][c] = 0;  // (only this lane ever touches column c: no barrier needed)
+        for (u32 k = 0; k < WORDS; ++k) acc[k][c] = 0;  // (only this lane ever touches column c: no barrier needed)
     }
 
     // A slice of more than kLeanCap entries (C4: nearly half of the blocks -- the order statistics of 256 genomes spread a
@@ -1748,27 +1758,30 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
     // kLeanMultiCap entries and the directory's 4 KB become 2048 two-byte entries: one pass for slices up to 1022.
     u64* const sl = multi ? reinterpret_cast<u64*>(&acc[0][0]) : slice;
     unsigned short* const dir16 = reinterpret_cast<unsigned short*>(dir);
-    const u32 cap = multi ? kLeanMultiCap : kLeanCap;
+    const u32 cap = multi ? kLeanMultiCap : CAP;
     for (u32 sub = qa; sub < qb; sub += cap) {
         const u32 n = min(cap, qb - sub);
         const u64 lo = q[sub], hi = q[sub + n - 1];
         // bucket(h) = (h - lo) >> shift, with (hi - lo) >> shift < n_bk; longer slices get the larger directory (the chance
         // of three entries in one bucket grows with n^3 / n_bk^2: 1 % at n = 64 / 2048 buckets, 13 % at n = 150, and a
         // block that fails the test pays the walk probe for its whole band)
-        const u32 bk_bits = (!multi && n > kLeanBigFrom) ? (u32)__builtin_ctz(kLeanBucketsMax) : (u32)__builtin_ctz(kLeanBuckets);
+        const u32 bk_bits = multi ? (u32)__builtin_ctz(kLeanBuckets)
+                            : BIG ? (u32)__builtin_ctz(kLeanBucketsBig)
+                                  : (n > kLeanBigFrom ? (u32)__builtin_ctz(kLeanBucketsMax) : (u32)__builtin_ctz(kLeanBuckets));
         const u32 n_bk = 1u << bk_bits;
         const u32 span_bits = 64u - (u32)__clzll((hi - lo) | 1ull);
         const u32 shift = span_bits > bk_bits ? span_bits - bk_bits : 0u;
         for (u32 i = c; i < n; i += kTileGenomes) sl[i] = q[sub + i];
-        if (c == 0) { sl[n] = kEmpty; sl[n + 1] = kEmpty; deep = shift < 32u ? 1u : 0u; }
+        if (c == 0) { sl[n] = kEmpty; sl[n + 1] = kEmpty; sl[n + 2] = kEmpty; deep = shift < 32u ? 1u : 0u; }
         __syncthreads();
         for (u32 i = c; i <= n; i += kTileGenomes) {
             // entry i opens every bucket in (bucket(i-1), bucket(i)]; the sentinel closes the rest
             const u32 bj = i < n ? (u32)((sl[i] - lo) >> shift) : n_bk;
             const u32 bp = i == 0 ? 0xFFFFFFFFu : (u32)((sl[i - 1] - lo) >> shift);
-            if (multi) { for (u32 x = bp + 1u; x <= bj; ++x) dir16[x] = (unsigned short)i; }
+            if (multi || BIG) { for (u32 x = bp + 1u; x <= bj; ++x) dir16[x] = (unsigned short)i; }
             else { for (u32 x = bp + 1u; x <= bj; ++x) dir[x] = (unsigned char)i; }
-            if (i >= 2u && i < n && (u32)((sl[i - 2] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
+            constexpr u32 kProbe = BIG ? 3u : 2u;  // entries one probe looks at
+            if (i >= kProbe && i < n && (u32)((sl[i - kProbe] - lo) >> shift) == bj) deep = 1u;  // (benign race: same value)
         }
         __syncthreads();
         const bool lean = deep == 0u && !multi;
@@ -1797,7 +1810,20 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
             // high word of (hv - lo), from the halves
             const u32 dh = (u32)(hv >> 32) - lo_hi - ((u32)hv < lo_lo ? 1u : 0u);
             const u32 bk = min(dh >> sh_hi, n_bk);
-            const u32 j = dir[bk];
+            const u32 j = BIG ? (u32)dir16[bk] : (u32)dir[bk];
+            if constexpr (BIG) {
+                u32 j1 = j + 1u, j2 = j + 2u;
+                asm volatile("" : "+v"(j1), "+v"(j2));  // (three ds_read_b64: see below)
+                const u64 e0 = slice[j], e1 = slice[j1], e2 = slice[j2];
+                if (ABLATE == 3) { cur_bits ^= e0 ^ e1 ^ e2; return; }
+                const bool m1 = e1 == hv, m2 = e2 == hv;
+                if ((e0 == hv) || m1 || m2) {
+                    const u32 qr = rel + j + (m1 ? 1u : 0u) + (m2 ? 2u : 0u);
+                    __hip_atomic_fetch_or(&my_acc[(size_t)(qr >> 6) * kTileGenomes], make_u64(one, zero) << (qr & 63u),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                return;
+            }
 #if SKX_SCAN_SPLIT_READS
             // two ds_read_b64 instead of the ds_read2_b64 the compiler makes of adjacent entries: a wave's 64 random 16-byte
             // reads go through the LDS as 2 x 4 groups of 16 lanes (128 B per clock), two 8-byte reads as 2 x 2 groups of 32
@@ -1821,7 +1847,7 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
             if (ABLATE == 2) { cur_bits ^= hv; return; }
             if (hv < lo || hv > hi) return;  // also drops the padding value
             const u32 bk = (u32)((hv - lo) >> shift);
-            u32 j = multi ? (u32)dir16[bk] : (u32)dir[bk];
+            u32 j = (multi || BIG) ? (u32)dir16[bk] : (u32)dir[bk];
             u64 e = sl[j];
             while (e < hv) e = sl[++j];   // the sentinel ends every walk (hv <= hi < kEmpty)
             if (ABLATE == 3) { cur_bits ^= e; return; }
@@ -3682,11 +3708,13 @@ void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const
 }
 
 u32 scan_run_cap() { return kRunCap; }
+u32 scan_lean_cap(bool big) { return big ? kLeanCapBig : kLeanCap; }
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
                  u64* m_bits, u64* m_int /* NULL = everything atomically into m_bits */, u32 n_pad, bool big_table,
                  bool lean /* sparse dictionaries: scan_lean_kernel */, u64* hbuf /* its slabs (experiments build; NULL: results into M) */,
                  u32* m_dirty, bool into_m /* lean kernel: results by atomicOr into m_bits instead of slabs (scan_lean_into_m) */,
-                 u32 run /* > 0: scan_run_kernel, one workgroup per `run` consecutive bands of a tile (results into m_bits) */) {
+                 u32 run /* > 0: scan_run_kernel, one workgroup per `run` consecutive bands of a tile (results into m_bits) */,
+                 bool big_slices /* lean kernel into M: the instance for slices of up to scan_lean_cap(true) entries */) {
     dim3 grid(n_tiles * n_bands), block(256);
     if (run) {
         const dim3 rgrid(n_tiles * cdiv(n_bands, run));
@@ -3719,7 +3747,8 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 #endif
     // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe
     if (lean) {
-        if (into_m || !hbuf) hipLaunchKernelGGL((scan_lean_kernel<0, 6>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+        if ((into_m || !hbuf) && big_slices) hipLaunchKernelGGL((scan_lean_kernel<0, 6, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+        else if (into_m || !hbuf) hipLaunchKernelGGL((scan_lean_kernel<0, 6>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
         else hipLaunchKernelGGL((scan_lean_kernel<0, 0>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
         return;
     }

@@ -127,7 +127,8 @@ bool scan_lean_into_m();
 // windows of up to scan_run_cap() entries in one pass over the rows
 u32 scan_run_cap();
 void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32 n_bands, const u64* q, const u32* win,
-                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table, bool lean, u64* hbuf, u32* m_dirty, bool into_m = true, u32 run = 0);
+                 u64* m_bits, u64* m_int, u32 n_pad, bool big_table, bool lean, u64* hbuf, u32* m_dirty, bool into_m = true, u32 run = 0, bool big_slices = false);
+u32 scan_lean_cap(bool big);  // entries of a (band, tile) slice the lean kernel's one-pass probe holds (big: the instance for passes with large slices)
 // wb[w * n_tiles + t] = (first | last << 16) band of tile t whose slice can reach query word w (first > last: none)
 // lo != NULL: also computes the windows (launch_window's work) first: one launch instead of two in front of the scan
 void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const u32* n_q, u32* wb, const u64* lo = nullptr,

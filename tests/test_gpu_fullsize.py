@@ -198,12 +198,14 @@ def test_forced_scan_kernel_variants(gpu, split, big):
                                    {"SKX_TOP1_WIDE": "1"}, {"SKX_RANK_LIVE": "0"}, {"SKX_RANK_SPLIT": "1"},
                                    {"SKX_RANK_SPLIT": "1", "SKX_PASS_READS": "100"}, {"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "4"},
                                    {"SKX_TWO_LEVEL": "1"}, {"SKX_TWO_LEVEL": "0"}, {"SKX_TWO_LEVEL": "1", "SKX_RANK_LIVE": "0"},
-                                   {"SKX_SCAN_NT": "0"}, {"SKX_SCAN_NT": "6"}, {"SKX_SCAN_NT": "0", "SKX_PASS_READS": "100"}])
+                                   {"SKX_SCAN_NT": "0"}, {"SKX_SCAN_NT": "6"}, {"SKX_SCAN_NT": "0", "SKX_PASS_READS": "100"},
+                                   {"SKX_SCAN_BIGSLICE": "1"}, {"SKX_SCAN_BIGSLICE": "1", "SKX_PASS_READS": "64"}])
 def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     """Several passes per push (the path that needs the per-read pair offsets on the host), the pipeline depths, the
     unfiltered dictionary, the ranking without its per-word live flags, seg_sum / chunk_sum on their own stream, the
     pair gather on the scan stream, the ranking's counts in two levels / one and the lean scan's results as slabs (SKX_SCAN_NT=0) /
-    straight into M (6; what small passes like these get by default) all give the oracle's rows."""
+    straight into M (6; the default), and the lean scan's instance for large slices (SKX_SCAN_BIGSLICE=1: 510 entries, three-entry
+    probe) all give the oracle's rows."""
     from helpers import exp_env
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=exp_env(**knobs),
                          capture_output=True, text=True)
