@@ -341,6 +341,36 @@ def test_enqueued_batches_share_a_pass(gpu, n):
     check(make(1), (0, 7))
 
 
+@pytest.mark.parametrize("lanes", [1, 3, 4])
+def test_ranking_lanes_option(gpu, lanes):
+    """Option "rank_lanes" (default 2; every other test runs with that): the rankings of the batches of a shared pass run as chains
+    on 1 / 3 / 4 HIP streams, each with its own scratch, the tables rotating over lanes + 1 buffers.  Same rows and table as the
+    oracle -- top-1 (the pruned two-level path) and top-2, with a reset in between (the rotation starts anywhere)."""
+    from sketchy_amd import api
+    ref, bases, offsets = workload(700, 400, 1400, read_len=400, rng_seed=917)
+    R = api.ReferenceSketch(ref["ref"])
+    cuts = [0, 150, 300, 500, 650, 800, 900, 1000, 1150, 1250, 1400]   # ten batches: one full group of eight and a rest
+    before = api.get_option("rank_lanes")
+    try:
+        api.set_option("rank_lanes", lanes)
+        assert api.get_option("rank_lanes") == lanes
+        for top in (1, 2):
+            exp = _expect(ref["ref"], 400, bases, offsets, top)
+            S = api.SumOfSharedHashes(R, top=top, max_batch_reads=300, max_batch_bases=len(bases))
+            for _ in range(2):
+                idx, val = _enqueue_stream(S, bases, offsets, cuts, top)
+                np.testing.assert_array_equal(idx, exp["topk_idx"])
+                np.testing.assert_array_equal(val, exp["topk_sum"])
+                np.testing.assert_array_equal(S.table(), exp["cum"])
+                S.reset()
+            S.close()
+    finally:
+        api.set_option("rank_lanes", before)
+    from sketchy_amd import _lib
+    with pytest.raises(_lib.SketchyHipError):
+        api.set_option("rank_lanes", 5)
+
+
 def test_a_group_that_does_not_fit_one_pass_is_unshared(gpu):
     """One batch fits the bit matrices, two together do not (matrix rows sized that way): the pair is un-shared in its back half --
     the joint hash set emptied, each batch gathered again and given its own pass -- and the stream stops pairing batches of that
