@@ -3716,12 +3716,17 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
                  u32 run /* > 0: scan_run_kernel, one workgroup per `run` consecutive bands of a tile (results into m_bits) */,
                  bool big_slices /* lean kernel into M: the instance for slices of up to scan_lean_cap(true) entries */) {
     dim3 grid(n_tiles * n_bands), block(256);
+#ifdef SKX_EXPERIMENTS
+    // (experiments that lost -- the runs-of-bands kernel, the lean kernel's BIG instance -- are not compiled into the product library)
     if (run) {
         const dim3 rgrid(n_tiles * cdiv(n_bands, run));
         hipLaunchKernelGGL((scan_run_kernel<2>), rgrid, block, 0, st, mat, s, n_tiles, rb, n_bands, run, q, win, m_bits, n_pad, m_dirty, 1u);
         return;
     }
-#ifdef SKX_EXPERIMENTS
+    if (lean && (into_m || !hbuf) && big_slices) {
+        hipLaunchKernelGGL((scan_lean_kernel<0, 6, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, 1u);
+        return;
+    }
     // profiling aids (results invalid unless 0): the ablated kernels are not even compiled into the product library
     static const int ablate = env_int("SKX_SCAN_ABLATE", 0);
     static const int nt_env = env_int("SKX_SCAN_NT", -1);  // 1 = non-temporal slab stores, 2 = matrix loads, 3 = both, +4 = results into M
@@ -3742,14 +3747,17 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 #undef SKX_SCAN_A
         return;
     }
+    if (lean && !into_m && hbuf) {  // round 3's slab form
+        hipLaunchKernelGGL((scan_lean_kernel<0, 0>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+        return;
+    }
 #else
     const u32 prio = 1u;
+    (void)run; (void)big_slices; (void)into_m;
 #endif
-    // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe
+    // sparse dictionaries (the host asked for neither the split nor the big-table variant): the lean probe, results into M
     if (lean) {
-        if ((into_m || !hbuf) && big_slices) hipLaunchKernelGGL((scan_lean_kernel<0, 6, true>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
-        else if (into_m || !hbuf) hipLaunchKernelGGL((scan_lean_kernel<0, 6>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
-        else hipLaunchKernelGGL((scan_lean_kernel<0, 0>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
+        hipLaunchKernelGGL((scan_lean_kernel<0, 6>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, n_pad, hbuf, m_dirty, prio);
         return;
     }
     // dense passes: 2040-entry slices, interior words by plain stores when the caller has the second array; very dense:
