@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed steps (batches of --batch reads)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reps", type=int, default=5,
+    ap.add_argument("--reps", type=int, default=7,
                     help="repetitions of the timed region (each: table reset, exactly --steps steps, the table all-reduce); "
                          "`value` is their median, every repetition is listed in `values_all`")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
