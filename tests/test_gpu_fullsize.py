@@ -195,14 +195,14 @@ def test_forced_scan_kernel_variants(gpu, split, big):
 
 @pytest.mark.parametrize("knobs", [{"SKX_PASS_READS": "64"}, {"SKX_PASS_READS": "100", "SKX_PIPELINE": "1"},
                                    {"SKX_PASS_READS": "37", "SKX_PIPELINE": "2"}, {"SKX_NO_FILTER": "1"},
-                                   {"SKX_TOP1_WIDE": "1"}, {"SKX_RANK_LIVE": "0"}, {"SKX_RANK_SPLIT": "1"},
-                                   {"SKX_RANK_SPLIT": "1", "SKX_PASS_READS": "100"}, {"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "4"},
+                                   {"SKX_TOP1_WIDE": "1"}, {"SKX_RANK_LIVE": "0"}, {"SKX_RANK_LANES": "1"},
+                                   {"SKX_RANK_LANES": "4", "SKX_PASS_READS": "100"}, {"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "4"},
                                    {"SKX_TWO_LEVEL": "1"}, {"SKX_TWO_LEVEL": "0"}, {"SKX_TWO_LEVEL": "1", "SKX_RANK_LIVE": "0"},
                                    {"SKX_SCAN_NT": "0"}, {"SKX_SCAN_NT": "6"}, {"SKX_SCAN_NT": "0", "SKX_PASS_READS": "100"},
                                    {"SKX_SCAN_BIGSLICE": "1"}, {"SKX_SCAN_BIGSLICE": "1", "SKX_PASS_READS": "64"}])
 def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     """Several passes per push (the path that needs the per-read pair offsets on the host), the pipeline depths, the
-    unfiltered dictionary, the ranking without its per-word live flags, seg_sum / chunk_sum on their own stream, the
+    unfiltered dictionary, the ranking without its per-word live flags, the ranking lanes forced to one / four, the
     pair gather on the scan stream, the ranking's counts in two levels / one and the lean scan's results as slabs (SKX_SCAN_NT=0) /
     straight into M (6; the default), and the lean scan's instance for large slices (SKX_SCAN_BIGSLICE=1: 510 entries, three-entry
     probe) all give the oracle's rows."""
