@@ -22,14 +22,17 @@ def _walk(seed):
     packed, poff = api.pack_reads(bases, offsets)
     R = api.ReferenceSketch(ref["ref"])
     # (how many enqueued batches may share a pass, and -- now and then -- bit matrices so small that groups have to be un-shared)
-    before = api.get_option("stream_coalesce")
+    # ... and on how many lanes the rankings of a shared pass run
+    before, lanes_before = api.get_option("stream_coalesce"), api.get_option("rank_lanes")
     try:
         api.set_option("stream_coalesce", int(rng.choice([1, 2, 3, 5, 8, 8])))
         api.set_option("stream_query_rows", int(rng.choice([0, 0, 0, 64])))
+        api.set_option("rank_lanes", int(rng.choice([1, 2, 2, 2, 3, 4])))
         S = api.SumOfSharedHashes(R, top=top, max_batch_reads=400, max_batch_bases=400 * 700)
     finally:
         api.set_option("stream_coalesce", before)
         api.set_option("stream_query_rows", 0)
+        api.set_option("rank_lanes", lanes_before)
     d_ascii, d_packed = api.DeviceBuffer.from_numpy(bases), api.DeviceBuffer.from_numpy(packed)
     h_ascii, h_packed = api.HostBuffer(len(bases)), api.HostBuffer(len(packed))
     h_ascii.view(np.uint8)[:] = bases
