@@ -60,9 +60,9 @@ static int fail(int code, const char* fmt, ...) {
 
 SKX_API const char* skx_last_error(void) { return g_err.c_str(); }
 #ifdef SKX_EXPERIMENTS
-SKX_API const char* skx_version(void) { return "sketchy-hip 0.3.0 (gfx950, experiments build: reads SKX_* environment knobs)"; }
+SKX_API const char* skx_version(void) { return "sketchy-hip 0.4.0 (gfx950, experiments build: reads SKX_* environment knobs)"; }
 #else
-SKX_API const char* skx_version(void) { return "sketchy-hip 0.3.0 (gfx950)"; }
+SKX_API const char* skx_version(void) { return "sketchy-hip 0.4.0 (gfx950)"; }
 #endif
 
 SKX_API int skx_device_count(void) {

@@ -3690,7 +3690,8 @@ u32 scan_lean_words() { return kLeanWords; }
 // per-block slabs for C4 (378 MB).  Round 4: the size of M does not matter -- the launch walks the matrix band by band, and a band's
 // blocks touch the same handful of word rows of M (a few MB, whatever the dictionary's size), which are written back once when
 // the launch has moved on: measured at C4 (tools/ab.sh, same box, twice each) slabs 45.8-46.2 M reads/s, scan alone 0.62-0.63
-// of the 8 TB/s peak; into M 47.4 M, 0.66-0.67, a lone batch +4 %, and 0.9 GB less written per pass.  The slab form survives in
+// of the 8 TB/s peak; into M 47.4 M, 0.66-0.67, a lone batch +4 %, and no slabs to allocate (0.94 GB per stream at C4; the counter
+// WRITE_SIZE still sees 1.2 GB per launch -- now the atomicOr requests of the ~3 bands that reach every word).  The slab form survives in
 // the experiments build only (SKX_SCAN_NT = 0..3, SKX_SCAN_ABLATE), which then also allocates the slabs.
 bool scan_lean_wants_slabs() {
 #ifdef SKX_EXPERIMENTS
