@@ -389,3 +389,198 @@ ORC_EXPORT int orc_stream_mt(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_g
     free(sk); free(idx); free(tmp);
     return 0;
 }
+
+/* ------------------------------------------------------------------ fast exact checker (full-size parity) */
+
+/*
+ * orc_stream_fast -- the rows and the table of orc_stream (src/sketchy.rs:317-356), computed batch-wise so that a
+ * FULL-SIZE batch (98 304 reads against 40 000 x 10 000 hashes) takes seconds on the host's cores instead of the
+ * 4x10^8 merge steps per read of the literal loop.  Still test infrastructure, still exact, and pinned against
+ * orc_stream itself in tests/test_oracle.py (C0, C1-sized and random ragged cases).
+ *
+ * What it restates and why it is the same function:
+ *   - every read is sketched by orc_sketch_heap (finch's MashSketcher, fresh per read, :331-335) at the full size s;
+ *   - _common_hashes (:425-438) is a plain set intersection, and a read hash above the reference's largest hash is in
+ *     no column, so only the sketch's prefix <= max_ref can count (the sketch is ascending: a prefix);
+ *   - for a block of reads, Q = the distinct in-range hashes; member[q][g] = (Q[q] in column g) comes from ONE
+ *     two-pointer merge of Q against every column (the same merge as :425-438, with Q in place of a read's sketch);
+ *     shared(read, g) = number of the read's hashes q with member[q][g] (:341), sum[g] += shared in read order;
+ *   - after every read the first top_k of (sum desc, genome index asc) (:348, :391) by a linear selection.
+ * Host threads split the GENOMES (not the reads): every thread replays all reads in order over its own genome range
+ * and keeps that range's best rows; the ranges' rows are merged per read.
+ *
+ * stats (may be NULL): [0] reads with no in-range hash, [1] pairs (read, in-range hash), [2] sum over blocks of |Q|,
+ * [3] blocks, [4] set bits of all member matrices.
+ */
+typedef struct { uint64_t sum; uint32_t idx; } orc_row_t;
+
+static inline int row_before(uint64_t sa, uint32_t ia, uint64_t sb, uint32_t ib) { /* (sum desc, index asc) */
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+static int fast_block(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, uint32_t n_genomes, const uint64_t *ref,
+                      const uint32_t *col_len, uint64_t max_ref, int have_ref, const uint8_t *bases, const uint64_t *offsets,
+                      uint32_t r0, uint32_t r1, uint32_t top_k, uint64_t *cum, uint32_t *topk_idx, uint64_t *topk_sum,
+                      int n_threads, uint64_t mem_limit, uint64_t *stats) {
+    const uint32_t nr = r1 - r0;
+    uint64_t **lists = (uint64_t **)calloc(nr, sizeof(uint64_t *));
+    uint32_t *lens = (uint32_t *)calloc(nr + 1, sizeof(uint32_t));
+    int64_t i;
+    /* 1. sketches (full size s, faithful sketcher), in-range prefix kept */
+#pragma omp parallel num_threads(n_threads)
+    {
+        uint64_t *sk = (uint64_t *)malloc(((uint64_t)s + 1) * sizeof(uint64_t));
+#pragma omp for schedule(dynamic, 64)
+        for (i = 0; i < (int64_t)nr; ++i) {
+            uint32_t r = r0 + (uint32_t)i;
+            uint64_t len = orc_sketch_heap(bases + offsets[r], offsets[r + 1] - offsets[r], k, seed, s, sk);
+            uint64_t keep = 0;
+            if (have_ref) while (keep < len && sk[keep] <= max_ref) ++keep;
+            if (keep) {
+                lists[i] = (uint64_t *)malloc(keep * sizeof(uint64_t));
+                memcpy(lists[i], sk, keep * sizeof(uint64_t));
+            }
+            lens[i] = (uint32_t)keep;
+        }
+        free(sk);
+    }
+    uint64_t npairs = 0, empty = 0;
+    uint64_t *poff = (uint64_t *)malloc(((uint64_t)nr + 1) * sizeof(uint64_t));
+    for (uint32_t j = 0; j < nr; ++j) { poff[j] = npairs; npairs += lens[j]; empty += lens[j] == 0; }
+    poff[nr] = npairs;
+    /* 2. Q = sorted distinct in-range hashes of the block */
+    uint64_t *Q = (uint64_t *)malloc((npairs + 1) * sizeof(uint64_t));
+    for (uint32_t j = 0; j < nr; ++j) if (lens[j]) memcpy(Q + poff[j], lists[j], lens[j] * sizeof(uint64_t));
+    qsort(Q, npairs, sizeof(uint64_t), cmp_u64);
+    uint64_t nq = 0;
+    for (uint64_t j = 0; j < npairs; ++j) if (j == 0 || Q[j] != Q[j - 1]) Q[nq++] = Q[j];
+    const uint64_t W = ((uint64_t)n_genomes + 63) / 64;
+    if (nq * W * 8 > mem_limit && nr > 1) { /* member matrix too large: halve the block (sketches are recomputed) */
+        for (uint32_t j = 0; j < nr; ++j) free(lists[j]);
+        free(lists); free(lens); free(poff); free(Q);
+        uint32_t mid = r0 + nr / 2;
+        int rc = fast_block(k, seed, s, stride, n_genomes, ref, col_len, max_ref, have_ref, bases, offsets, r0, mid, top_k, cum,
+                            topk_idx, topk_sum, n_threads, mem_limit, stats);
+        if (rc) return rc;
+        return fast_block(k, seed, s, stride, n_genomes, ref, col_len, max_ref, have_ref, bases, offsets, mid, r1, top_k, cum,
+                          topk_idx, topk_sum, n_threads, mem_limit, stats);
+    }
+    /* 3. pair -> index into Q */
+    uint32_t *pq = (uint32_t *)malloc((npairs + 1) * sizeof(uint32_t));
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+    for (i = 0; i < (int64_t)nr; ++i)
+        for (uint32_t j = 0; j < lens[i]; ++j) {
+            uint64_t h = lists[i][j], lo = 0, hi = nq;
+            while (lo < hi) { uint64_t m = (lo + hi) / 2; if (Q[m] < h) lo = m + 1; else hi = m; }
+            pq[poff[i] + j] = (uint32_t)lo;
+        }
+    /* 4. member[q][word]: bit (g & 63) of word g / 64 = Q[q] in column g; a thread owns whole words */
+    uint64_t *member = (uint64_t *)calloc(nq * W + 1, sizeof(uint64_t));
+    uint64_t bits_set = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) reduction(+ : bits_set)
+    for (i = 0; i < (int64_t)W; ++i) {
+        uint32_t g1 = (uint32_t)((i + 1) * 64 < (int64_t)n_genomes ? (i + 1) * 64 : n_genomes);
+        for (uint32_t g = (uint32_t)i * 64; g < g1; ++g) {
+            const uint64_t *col = ref + (uint64_t)g * stride;
+            uint64_t a = 0, b = 0, na = col_len[g];
+            const uint64_t bit = 1ULL << (g & 63);
+            while (a < na && b < nq) { /* src/sketchy.rs:428-437 */
+                if (Q[b] < col[a]) ++b;
+                else if (Q[b] > col[a]) ++a;
+                else { member[b * W + (uint64_t)i] |= bit; ++bits_set; ++a; ++b; }
+            }
+        }
+    }
+    /* 5. replay in read order, genomes split over threads */
+    if (top_k == 0 || (!topk_idx && !topk_sum)) {
+        /* table only: sum[g] += sum over q of multiplicity(q) * member[q][g] */
+        uint32_t *mult = (uint32_t *)calloc(nq + 1, sizeof(uint32_t));
+        for (uint64_t j = 0; j < npairs; ++j) ++mult[pq[j]];
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+        for (i = 0; i < (int64_t)W; ++i)
+            for (uint64_t q = 0; q < nq; ++q) {
+                uint64_t bits = member[q * W + (uint64_t)i];
+                while (bits) { cum[(uint64_t)i * 64 + (uint64_t)__builtin_ctzll(bits)] += mult[q]; bits &= bits - 1; }
+            }
+        free(mult);
+    } else {
+        int T = n_threads;
+        if ((uint64_t)T > W) T = (int)W;
+        orc_row_t *loc = (orc_row_t *)malloc((uint64_t)T * nr * top_k * sizeof(orc_row_t));
+        uint32_t *loc_n = (uint32_t *)calloc((uint64_t)T * nr, sizeof(uint32_t));
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+        for (i = 0; i < (int64_t)T; ++i) {
+            const uint64_t wa = W * (uint64_t)i / (uint64_t)T, wb = W * (uint64_t)(i + 1) / (uint64_t)T;
+            const uint32_t ga = (uint32_t)(wa * 64), gb = (uint32_t)(wb * 64 < n_genomes ? wb * 64 : n_genomes);
+            for (uint32_t j = 0; j < nr; ++j) {
+                for (uint64_t p = poff[j]; p < poff[j + 1]; ++p) {
+                    const uint64_t *row = member + (uint64_t)pq[p] * W;
+                    for (uint64_t w = wa; w < wb; ++w) {
+                        uint64_t bits = row[w];
+                        while (bits) { ++cum[w * 64 + (uint64_t)__builtin_ctzll(bits)]; bits &= bits - 1; }
+                    }
+                }
+                orc_row_t *best = loc + ((uint64_t)i * nr + j) * top_k;
+                uint32_t nb = 0;
+                for (uint32_t g = ga; g < gb; ++g) { /* ascending g: an equal sum never displaces an earlier genome */
+                    uint64_t v = cum[g];
+                    if (nb == top_k && !(v > best[nb - 1].sum)) continue;
+                    uint32_t at = nb < top_k ? nb++ : top_k - 1;
+                    while (at > 0 && v > best[at - 1].sum) { best[at] = best[at - 1]; --at; }
+                    best[at].sum = v; best[at].idx = g;
+                }
+                loc_n[(uint64_t)i * nr + j] = nb;
+            }
+        }
+        /* merge the ranges' rows: ranges ascend in genome index, each list is (sum desc, index asc) */
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+        for (i = 0; i < (int64_t)nr; ++i) {
+            uint32_t head[256];
+            for (int t = 0; t < T; ++t) head[t] = 0;
+            for (uint32_t o = 0; o < top_k; ++o) {
+                int bt = -1;
+                for (int t = 0; t < T; ++t) {
+                    if (head[t] >= loc_n[(uint64_t)t * nr + (uint64_t)i]) continue;
+                    const orc_row_t *c = loc + ((uint64_t)t * nr + (uint64_t)i) * top_k + head[t];
+                    if (bt < 0) { bt = t; continue; }
+                    const orc_row_t *b = loc + ((uint64_t)bt * nr + (uint64_t)i) * top_k + head[bt];
+                    if (row_before(c->sum, c->idx, b->sum, b->idx)) bt = t;
+                }
+                const orc_row_t *b = loc + ((uint64_t)bt * nr + (uint64_t)i) * top_k + head[bt]++;
+                if (topk_idx) topk_idx[((uint64_t)r0 + (uint64_t)i) * top_k + o] = b->idx;
+                if (topk_sum) topk_sum[((uint64_t)r0 + (uint64_t)i) * top_k + o] = b->sum;
+            }
+        }
+        free(loc); free(loc_n);
+    }
+    if (stats) { stats[0] += empty; stats[1] += npairs; stats[2] += nq; stats[3] += 1; stats[4] += bits_set; }
+    for (uint32_t j = 0; j < nr; ++j) free(lists[j]);
+    free(lists); free(lens); free(poff); free(Q); free(pq); free(member);
+    return 0;
+}
+
+ORC_EXPORT int orc_stream_fast(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, uint32_t n_genomes,
+                               const uint64_t *ref_hashes, const uint32_t *col_len,
+                               const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                               uint32_t top_k, uint64_t *cum, uint32_t *topk_idx, uint64_t *topk_sum,
+                               int n_threads, uint32_t block_reads, uint64_t *stats) {
+    if (top_k > n_genomes) return -1; /* the reference panics on [..top] (src/sketchy.rs:391) */
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    if (block_reads == 0) block_reads = 32768;
+    uint64_t max_ref = 0;
+    int have_ref = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g)
+        if (col_len[g]) {
+            uint64_t last = ref_hashes[(uint64_t)g * stride + col_len[g] - 1]; /* columns ascend (:416-418) */
+            if (!have_ref || last > max_ref) max_ref = last;
+            have_ref = 1;
+        }
+    for (uint32_t r0 = 0; r0 < n_reads; r0 += block_reads) {
+        uint32_t r1 = n_reads - r0 > block_reads ? r0 + block_reads : n_reads;
+        int rc = fast_block(k, seed, s, stride, n_genomes, ref_hashes, col_len, max_ref, have_ref, bases, offsets, r0, r1, top_k,
+                            cum, topk_idx, topk_sum, n_threads, 3ULL << 30, stats);
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -64,6 +64,10 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int]
         L.orc_stream_mt.restype = C.c_int
+        L.orc_stream_fast.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_uint32, C.c_void_p]
+        L.orc_stream_fast.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -161,6 +165,56 @@ def stream_mt(k, seed, s, ref_hashes, col_len, bases, offsets, top_k=1, cum=None
     if rc != 0:
         raise ValueError("orc_stream_mt failed (top_k > n_genomes?)")
     return dict(cum=cum, topk_idx=tk_i, topk_sum=tk_s)
+
+
+def usable_threads():
+    """host threads this process may really use (affinity mask and cgroup CPU quota; a 16-CPU quota on a 256-thread box
+    makes 256 threads slower than one)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def stream_fast(k, seed, s, ref_hashes, col_len, bases, offsets, top_k=1, cum=None, n_threads=0, block_reads=0,
+                rows=True):
+    """orc_stream_fast: the rows and the table of stream() for a FULL-SIZE batch in seconds (blocks of reads scored
+    through one distinct-hash membership matrix, genomes split over host threads).  Exact; pinned against stream() in
+    tests/test_oracle.py.  rows=False: table only.  Returns dict(cum, topk_idx, topk_sum, stats)."""
+    ref_hashes = np.ascontiguousarray(ref_hashes, np.uint64)
+    n_genomes, stride = ref_hashes.shape
+    col_len = np.full(n_genomes, stride, np.uint32) if col_len is None else np.ascontiguousarray(col_len, np.uint32)
+    bases = np.ascontiguousarray(bases, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    n_reads = len(offsets) - 1
+    cum = np.zeros(n_genomes, np.uint64) if cum is None else np.ascontiguousarray(cum, np.uint64).copy()
+    tk_i = np.zeros((n_reads, top_k), np.uint32) if rows and top_k else None
+    tk_s = np.zeros((n_reads, top_k), np.uint64) if rows and top_k else None
+    stats = np.zeros(8, np.uint64)
+    bases_p = bases if len(bases) else np.zeros(1, np.uint8)
+    rc = lib().orc_stream_fast(k, seed, s, stride, n_genomes, _ptr(ref_hashes), _ptr(col_len), _ptr(bases_p), _ptr(offsets),
+                               n_reads, top_k, _ptr(cum), _ptr(tk_i), _ptr(tk_s), n_threads or usable_threads(),
+                               block_reads, _ptr(stats))
+    if rc != 0:
+        raise ValueError("orc_stream_fast failed (top_k > n_genomes?)")
+    names = ("reads_without_pairs", "pairs", "distinct_sum", "blocks", "member_bits")
+    return dict(cum=cum, topk_idx=tk_i, topk_sum=tk_s, stats=dict(zip(names, [int(x) for x in stats[:5]])))
+
+
+def stream_fast_species(k, seed, s, refs, bases, offsets, top_k=1, cums=None, n_threads=0, rows=True):
+    """One stream_fast per species over the same reads (one `sketchy predict` run per species, src/sketchy.rs:81-82):
+    rows [n_reads, n_species, top_k] with indices local to the species, cum = the species' tables one after the other."""
+    outs = [stream_fast(k, seed, s, r, None, bases, offsets, top_k, None if cums is None else cums[i], n_threads, rows=rows)
+            for i, r in enumerate(refs)]
+    res = dict(cum=np.concatenate([o["cum"] for o in outs]), cums=[o["cum"] for o in outs], stats=[o["stats"] for o in outs])
+    if rows and top_k:
+        res["topk_idx"] = np.stack([o["topk_idx"] for o in outs], axis=1)
+        res["topk_sum"] = np.stack([o["topk_sum"] for o in outs], axis=1)
+    return res
 
 
 # ----------------------------------------------------------------------------- pure Python

@@ -13,6 +13,12 @@ the generator creates real sharing:
   3. reads are sampled from G itself (random strand, substitution errors), so their
      k-mers genuinely hit the reference hashes.
 
+``make_reference(..., mode="snp")`` is SURVEY.md 8(d)'s generator proper (items 1-3): the variants are SNP copies of
+the ancestor (lineage divergence 1 %, strain divergence 0.05 %), a variant's sketch is the bottom-s of the REAL canonical
+k-mer hashes of its genome (ancestor hashes - k-mers killed by its SNPs + k-mers created, computed incrementally: k
+windows per SNP), and the reads are sampled from ONE truth strain's genome (``ref["truth_genome"]``), so that its
+lineage, and within it the strain, accumulates fastest -- the regime of a real sample (/root/reference/README.md:38).
+
 Nothing here imports oracle/: bench.py and the tests hand the same arrays to the HIP path
 and to the oracle.
 """
@@ -104,8 +110,13 @@ def random_genome(length: int, rng: np.random.Generator) -> np.ndarray:
 
 def make_reference(n_genomes: int, s: int, k: int = 16, hash_seed: int = 0, genome_len: int = 0,
                    n_lineages: int = 0, p_lineage: float = 0.85, p_strain: float = 0.99,
-                   rng_seed: int = 1, shuffle: bool = True, device: str = "auto"):
-    """Returns dict(genome [uint8], ref [n_genomes, s] uint64 ascending rows, col_len)."""
+                   rng_seed: int = 1, shuffle: bool = True, device: str = "auto", mode: str = "pool", **snp_kw):
+    """Returns dict(genome [uint8], ref [n_genomes, s] uint64 ascending rows, col_len).  mode="snp": see
+    make_reference_snp (adds truth_index / truth_genome / lineage)."""
+    if mode == "snp":
+        return make_reference_snp(n_genomes, s, k=k, hash_seed=hash_seed, genome_len=genome_len, n_lineages=n_lineages,
+                                  rng_seed=rng_seed, shuffle=shuffle, device=device, **snp_kw)
+    assert mode == "pool" and not snp_kw
     rng = np.random.default_rng(rng_seed)
     if genome_len <= 0:
         genome_len = max(20000, 280 * s)  # keeps (bottom-s range)/(hash space) near real data
@@ -265,3 +276,211 @@ def make_reads_torch(genome, n_reads: int, read_len=1500, err: float = 0.05, rng
         shift = torch.randint(1, 4, (idx.numel(),), generator=gen, device=dev, dtype=torch.int64)
         bases[idx] = alphabet[(code[bases[idx].long()] + shift) % 4]
     return bases.contiguous(), offsets
+
+
+# ----------------------------------------------------------------------------- SNP clone tree
+_I64_MAX = (1 << 63) - 1
+
+
+def _s64(c):
+    """a 64-bit constant as the signed value torch's int64 holds"""
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _t_shr(x, n):
+    """logical shift right of int64 lanes"""
+    return (x >> n) & ((1 << (64 - n)) - 1)
+
+
+def _t_rotl(x, r):
+    return (x << r) | _t_shr(x, 64 - r)
+
+
+def _t_fmix(h):
+    h = h ^ _t_shr(h, 33)
+    h = h * _s64(0xFF51AFD7ED558CCD)
+    h = h ^ _t_shr(h, 33)
+    h = h * _s64(0xC4CEB9FE1A85EC53)
+    return h ^ _t_shr(h, 33)
+
+
+def torch_murmur3_h1(rows, seed: int):
+    """MurmurHash3_x64_128 h1 of every row of a [m, k] uint8 tensor, as int64 lanes holding the unsigned value's bits
+    (int64 multiplication wraps like u64; shifts are made logical).  Same function as murmur3_h1_rows."""
+    import torch
+    m, k = rows.shape
+    c1, c2 = _s64(0x87C37B91114253D5), _s64(0x4CF5AD432745937F)
+    h1 = torch.full((m,), _s64(seed & 0xFFFFFFFFFFFFFFFF), dtype=torch.int64, device=rows.device)
+    h2 = h1.clone()
+
+    def le64(cols):
+        v = torch.zeros(m, dtype=torch.int64, device=rows.device)
+        for i in range(cols.shape[1]):
+            v |= cols[:, i].to(torch.int64) << (8 * i)
+        return v
+
+    nb = k // 16
+    for b in range(nb):
+        k1 = le64(rows[:, 16 * b:16 * b + 8])
+        k2 = le64(rows[:, 16 * b + 8:16 * b + 16])
+        k1 = k1 * c1; k1 = _t_rotl(k1, 31); k1 = k1 * c2; h1 = h1 ^ k1
+        h1 = _t_rotl(h1, 27); h1 = h1 + h2; h1 = h1 * 5 + 0x52DCE729
+        k2 = k2 * c2; k2 = _t_rotl(k2, 33); k2 = k2 * c1; h2 = h2 ^ k2
+        h2 = _t_rotl(h2, 31); h2 = h2 + h1; h2 = h2 * 5 + 0x38495AB5
+    t = k - 16 * nb
+    if t > 8:
+        k2 = le64(rows[:, 16 * nb + 8:])
+        k2 = k2 * c2; k2 = _t_rotl(k2, 33); k2 = k2 * c1; h2 = h2 ^ k2
+    if t > 0:
+        k1 = le64(rows[:, 16 * nb:16 * nb + min(t, 8)])
+        k1 = k1 * c1; k1 = _t_rotl(k1, 31); k1 = k1 * c2; h1 = h1 ^ k1
+    h1 = h1 ^ k; h2 = h2 ^ k
+    h1 = h1 + h2; h2 = h2 + h1
+    h1 = _t_fmix(h1); h2 = _t_fmix(h2)
+    return h1 + h2
+
+
+def _t_window_hashes(codes, starts, k: int, seed: int, chunk: int = 1 << 21):
+    """Canonical k-mer hashes (int64 bit patterns) of the windows codes[..., start : start + k].  codes: [L] or [J, L] uint8
+    2-bit codes (0..3 = ACGT: the order of the ASCII letters, so comparing codes is the bytewise comparison needletail
+    makes); starts: [n] or [J, n] int64.  canonical = forward if forward < reverse complement else reverse complement."""
+    import torch
+    dev = codes.device
+    flat = codes.reshape(-1)
+    if codes.dim() == 2:
+        J, L = codes.shape
+        base = (torch.arange(J, device=dev, dtype=torch.int64) * L)[:, None]
+        st = (starts + base).reshape(-1)
+    else:
+        st = starts.reshape(-1)
+    out = torch.empty(st.numel(), dtype=torch.int64, device=dev)
+    ar = torch.arange(k, device=dev, dtype=torch.int64)
+    ascii_ = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    kh = min(k, 16)
+    wh = (4 ** torch.arange(kh - 1, -1, -1, device=dev, dtype=torch.int64))
+    wl = (4 ** torch.arange(k - kh - 1, -1, -1, device=dev, dtype=torch.int64)) if k > kh else None
+    for lo in range(0, st.numel(), chunk):
+        a = st[lo:lo + chunk]
+        win = flat[(a[:, None] + ar[None, :])]                     # [m, k] codes
+        rc = (3 - win).flip(1)
+        wf, wr = win.to(torch.int64), rc.to(torch.int64)
+        fh, rh = (wf[:, :kh] * wh).sum(1), (wr[:, :kh] * wh).sum(1)
+        less = fh < rh
+        if wl is not None:
+            fl, rl = (wf[:, kh:] * wl).sum(1), (wr[:, kh:] * wl).sum(1)
+            less = less | ((fh == rh) & (fl < rl))
+        canon = torch.where(less[:, None], win, rc)
+        out[lo:lo + chunk] = torch_murmur3_h1(ascii_[canon.long()], seed)
+    return out.reshape(starts.shape)
+
+
+def _snp_alt(codes_at, pos, salt: int):
+    """the base a SNP puts at `pos`: a function of (position, salt) only, so that a position drawn twice gets one value"""
+    shift = ((pos * 2654435761 + salt * 40503 + 12345) >> 7) % 3 + 1
+    return ((codes_at.to(pos.dtype) + shift) % 4).to(codes_at.dtype)
+
+
+def make_reference_snp(n_genomes: int, s: int, k: int = 16, hash_seed: int = 0, genome_len: int = 0, n_lineages: int = 0,
+                       div_lineage: float = 0.01, div_strain: float = 0.0005, rng_seed: int = 1, shuffle: bool = True,
+                       device: str = "auto", truth: int = -1, strain_chunk_bytes: int = 1 << 30):
+    """a two-level clone tree of SNP variants of one random ancestor.
+
+    Every lineage is the ancestor with SNPs at ``div_lineage`` of its positions, every strain its lineage with further
+    SNPs at ``div_strain``; row g of ``ref`` is the bottom-s of the canonical k-mer hashes of strain g's genome (exactly:
+    positions whose window holds no SNP keep the parent's hash, the k windows over every SNP are hashed again; only hashes
+    below a threshold a little above the ancestor's s-th smallest are tracked, and every row is checked to hold s of them).
+    Returns dict(genome = the ancestor, ref, col_len, k, seed, s, lineage [n_genomes] = lineage of every row,
+    truth_index = row of the truth strain, truth_genome = its genome (ASCII): sample the reads from THAT
+    (``make_reads(ref["truth_genome"], ...)``, item 3).  truth = ordinal of the truth strain before shuffling
+    (default: a strain in the middle of the tree).  torch on ``device`` ("auto": the GPU when there is one)."""
+    import torch
+    if device == "auto":
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    if device == "numpy":
+        device = "cpu"
+    dev = torch.device(device)
+    rng = np.random.default_rng(rng_seed)
+    if genome_len <= 0:
+        genome_len = max(20000, 280 * s)
+    if n_lineages <= 0:
+        n_lineages = max(1, int(round(n_genomes ** 0.5)))
+    per_lin = -(-n_genomes // n_lineages)
+    if truth < 0:
+        truth = (n_lineages // 2) * per_lin + per_lin // 2
+    truth = min(truth, n_genomes - 1)
+    L = genome_len
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(rng_seed * 7919 + 29)
+    anc = torch.from_numpy(rng.integers(0, 4, size=L).astype(np.uint8)).to(dev)          # 2-bit codes
+    ascii_np = np.frombuffer(b"ACGT", np.uint8)
+    m = L - k + 1
+    hg = _t_window_hashes(anc, torch.arange(m, device=dev, dtype=torch.int64), k, hash_seed)
+    pos_h = hg[hg >= 0]
+    pool_n = int(np.ceil(1.35 * s)) + 8
+    if pos_h.numel() < pool_n:
+        raise ValueError("genome too short for requested sketch size")
+    T = int(torch.sort(pos_h).values[pool_n - 1].item()) + 1           # track hashes in [0, T)
+    n_l = max(1, int(round(div_lineage * L)))
+    n_s = max(1, int(round(div_strain * L)))
+    ar_k = torch.arange(k, device=dev, dtype=torch.int64)
+    ref = np.empty((n_genomes, s), np.uint64)
+    lineage = np.empty(n_genomes, np.int32)
+    truth_genome = None
+    done = 0
+    for lin in range(n_lineages):
+        n_here = min(per_lin, n_genomes - done)
+        if n_here <= 0:
+            break
+        # the lineage's genome and position-indexed hashes
+        P = torch.randint(0, L, (n_l,), generator=gen, device=dev, dtype=torch.int64)
+        gl = anc.clone()
+        gl[P] = _snp_alt(anc[P], P, 1 + lin)
+        A = torch.unique((P[:, None] - ar_k[None, :]).clamp(0, m - 1).reshape(-1))
+        hl = hg.clone()
+        hl[A] = _t_window_hashes(gl, A, k, hash_seed)
+        pp = ((hl >= 0) & (hl < T)).nonzero(as_tuple=True)[0]
+        hp, order = torch.sort(hl[pp])
+        pp = pp[order]
+        Np = pp.numel()
+        # strains, a few at a time (dense copies of the lineage genome: J x L bytes, windows J x n_s*k x k x 8 bytes)
+        per_strain = L + n_s * k * (k * 9 + 32) + Np * 24
+        J_max = max(1, int(strain_chunk_bytes // per_strain))
+        for j0 in range(0, n_here, J_max):
+            J = min(J_max, n_here - j0)
+            salt = 1000003 * (1 + lin) + j0
+            Ps = torch.randint(0, L, (J, n_s), generator=gen, device=dev, dtype=torch.int64)
+            sg = gl[None, :].expand(J, L).clone()
+            salts = (salt + torch.arange(J, device=dev, dtype=torch.int64))[:, None]
+            sg.scatter_(1, Ps, _snp_alt(torch.gather(gl[None, :].expand(J, L), 1, Ps), Ps + salts * 7, 0))
+            As = (Ps[:, :, None] - ar_k[None, None, :]).clamp(0, m - 1).reshape(J, n_s * k)
+            hn = _t_window_hashes(sg, As, k, hash_seed)
+            hn = torch.where((hn >= 0) & (hn < T), hn, torch.full_like(hn, _I64_MAX))
+            Psort = torch.sort(Ps, dim=1).values
+            ppe = pp[None, :].expand(J, Np).contiguous()
+            ix = torch.searchsorted(Psort, ppe)                          # first SNP at or behind the window's start
+            nxt = torch.gather(Psort, 1, ix.clamp(max=n_s - 1))
+            killed = (ix < n_s) & (nxt <= ppe + (k - 1))
+            rows = torch.cat([torch.where(killed, torch.full_like(ppe, _I64_MAX), hp[None, :].expand(J, Np)), hn], dim=1)
+            rows = torch.sort(rows, dim=1).values
+            dup = rows[:, 1:] == rows[:, :-1]
+            if bool(dup.any()):
+                rows[:, 1:][dup] = _I64_MAX
+                rows = torch.sort(rows, dim=1).values
+            rows = rows[:, :s]
+            if bool((rows[:, -1] == _I64_MAX).any()):
+                raise ValueError("a strain holds fewer than s hashes below the tracked threshold (genome too short?)")
+            ref[done + j0:done + j0 + J] = rows.cpu().numpy().view(np.uint64)
+            t_local = truth - (done + j0)
+            if 0 <= t_local < J:
+                truth_genome = ascii_np[sg[t_local].cpu().numpy()]
+            del sg, hn, rows, killed, ix, nxt, ppe, As, Ps
+        lineage[done:done + n_here] = lin
+        done += n_here
+    truth_index = truth
+    if shuffle:
+        perm = rng.permutation(n_genomes)
+        ref, lineage = ref[perm], lineage[perm]
+        truth_index = int(np.nonzero(perm == truth)[0][0])
+    col_len = np.full(n_genomes, s, np.uint32)
+    return dict(genome=ascii_np[anc.cpu().numpy()], ref=np.ascontiguousarray(ref), col_len=col_len, k=k, seed=hash_seed, s=s,
+                lineage=lineage, truth_index=truth_index, truth_genome=np.ascontiguousarray(truth_genome))

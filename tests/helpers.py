@@ -62,3 +62,43 @@ def workload_species(sizes, s, n_reads, read_len=1500, k=16, seed=0, genome_len=
     order = np.random.default_rng(rng_seed).permutation(len(reads))
     bases, offsets = pack_reads([reads[i] for i in order])
     return refs, bases, offsets
+
+
+_SNP_CACHE = {}
+
+
+def workload_snp(n_genomes, s, n_reads, read_len=1500, k=16, seed=0, genome_len=0, rng_seed=1, err=0.05, device="cpu",
+                 lognormal_sigma=0.0, max_len=50000, source="truth", **kw):
+    """SURVEY.md 8(d)'s generator (synth.make_reference(mode="snp")): SNP clone tree with real k-mer hashes, reads drawn
+    from ONE truth strain (source="truth") or from the ancestor.  It needs torch, and a process that has loaded the HIP
+    library must not import torch afterwards, so the arrays are made by a child process and cached for the session.
+    Returns (ref dict incl. truth_index / lineage, bases, offsets)."""
+    import subprocess
+    import sys
+    import tempfile
+    key = (n_genomes, s, n_reads, read_len, k, seed, genome_len, rng_seed, err, device, lognormal_sigma, max_len, source,
+           tuple(sorted(kw.items())))
+    if key in _SNP_CACHE:
+        return _SNP_CACHE[key]
+    with tempfile.TemporaryDirectory(prefix="skx_snp_") as d:
+        out = os.path.join(d, "w.npz")
+        code = (
+            "import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from sketchy_amd import synth\n"
+            "dev = %r\n"
+            "dev = ('cuda' if torch.cuda.is_available() else 'cpu') if dev == 'auto' else dev\n"
+            "ref = synth.make_reference(%d, %d, k=%d, hash_seed=%d, genome_len=%d, rng_seed=%d, mode='snp', device=dev, **%r)\n"
+            "src = ref['truth_genome'] if %r == 'truth' else ref['genome']\n"
+            "b, o = synth.make_reads(src, %d, %d, err=%r, rng_seed=%d, lognormal_sigma=%r, max_len=%d)\n"
+            "np.savez(%r, ref=ref['ref'], col_len=ref['col_len'], genome=ref['genome'], truth_genome=ref['truth_genome'],\n"
+            "         lineage=ref['lineage'], truth_index=ref['truth_index'], bases=b, offsets=o)\n"
+        ) % (ROOT, device, n_genomes, s, k, seed, genome_len, rng_seed, kw, source, n_reads, read_len, err, rng_seed + 1,
+             lognormal_sigma, max_len, out)
+        subprocess.check_call([sys.executable, "-c", code])
+        z = np.load(out)
+        ref = dict(ref=z["ref"], col_len=z["col_len"], genome=z["genome"], truth_genome=z["truth_genome"], lineage=z["lineage"],
+                   truth_index=int(z["truth_index"]), k=k, seed=seed, s=s)
+        res = (ref, z["bases"], z["offsets"])
+    _SNP_CACHE[key] = res
+    return res

@@ -56,6 +56,43 @@ def test_c0_plumbing_config(gpu):
     np.testing.assert_array_equal(sm, exp["cum"][order])
 
 
+def test_c0_truth_strain_workload(gpu):
+    """C0 on SURVEY.md 8(d)'s generator: SNP clone tree with real 16-mer hashes, reads from ONE truth strain --
+    strain-specific matches occur and a leader emerges (the regime of a real sample), per-read counts included."""
+    from helpers import workload_snp
+    ref, bases, offsets = workload_snp(500, 1000, 1000, rng_seed=3)
+    got, exp, R, S = check(ref, bases, offsets, top=5)
+    lin, ti = ref["lineage"], ref["truth_index"]
+    assert lin[exp["topk_idx"][-1, 0]] == lin[ti] and exp["cum"][ti] == exp["cum"].max()
+    sh = exp["shared"].astype(np.int64).sum(axis=0)
+    assert (sh[lin == lin[ti]] < sh[ti]).any()        # hashes only the truth strain (and not all its mates) holds
+
+
+@pytest.mark.parametrize("mode", ["pool", "snp"])
+def test_c1_full_config_every_row(gpu, mode):
+    """BASELINE configs[1] at its full size: 100 000 reads x 1.5 kb vs 5 000 genomes x s=1000, every row and the table
+    against the fast checker (orc_stream_fast, pinned against the literal loop in tests/test_oracle.py); the stream is
+    enqueued in uneven batches that share passes."""
+    from helpers import workload_snp
+    from sketchy_amd import api
+    from test_gpu_enqueue import _enqueue_stream
+    n = 100000
+    if mode == "snp":
+        ref, bases, offsets = workload_snp(5000, 1000, n, rng_seed=17)
+    else:
+        ref, bases, offsets = workload(5000, 1000, n, rng_seed=17)
+    exp = orc.stream_fast(16, 0, 1000, ref["ref"], ref["col_len"], bases, offsets, top_k=1)
+    R = api.ReferenceSketch(ref["ref"])
+    cuts = [0, 16384, 16385, 50000, 82768, n]
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=33615, max_batch_bases=int(np.max(np.diff(offsets[cuts].astype(np.int64)))))
+    idx, val = _enqueue_stream(S, bases, offsets, cuts, 1)
+    np.testing.assert_array_equal(val, exp["topk_sum"])
+    np.testing.assert_array_equal(idx, exp["topk_idx"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    if mode == "snp":
+        assert exp["topk_idx"][-1, 0] == ref["truth_index"]
+
+
 def test_multiple_pushes_continue_the_table(gpu):
     ref, bases, offsets = workload(300, 500, 257, rng_seed=7)
     check(ref, bases, offsets, top=3, batches=5)

@@ -156,6 +156,88 @@ def test_stream_rejects_top_above_n():
         orc.stream(16, 0, 16, ref["ref"], ref["col_len"], bases, offsets, top_k=4)
 
 
+def _assert_fast_equals_stream(k, seed, s, hashes, col_len, bases, offsets, top_k, cum=None, **kw):
+    exp = orc.stream(k, seed, s, hashes, col_len, bases, offsets, top_k=top_k, cum=cum)
+    got = orc.stream_fast(k, seed, s, hashes, col_len, bases, offsets, top_k=top_k, cum=cum, **kw)
+    np.testing.assert_array_equal(got["cum"], exp["cum"])
+    np.testing.assert_array_equal(got["topk_idx"], exp["topk_idx"])
+    np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"])
+    tab = orc.stream_fast(k, seed, s, hashes, col_len, bases, offsets, top_k=top_k, cum=cum, rows=False, **kw)
+    np.testing.assert_array_equal(tab["cum"], exp["cum"])
+    return got
+
+
+@pytest.mark.parametrize("threads,block", [(1, 0), (3, 7), (8, 64), (5, 1)])
+def test_fast_checker_equals_the_literal_stream_c0(threads, block):
+    """orc_stream_fast (what the full-size GPU tests compare whole batches with) against the literal loop of
+    src/sketchy.rs:328-354 at config C0's shape (500 genomes x s=1000, 1.5 kb reads), any thread count / block size."""
+    ref, bases, offsets = workload(500, 1000, 120, rng_seed=31)
+    got = _assert_fast_equals_stream(16, 0, 1000, ref["ref"], ref["col_len"], bases, offsets, 5, n_threads=threads, block_reads=block)
+    assert got["stats"]["pairs"] > 0 and got["stats"]["blocks"] == (1 if block == 0 else -(-120 // block))
+
+
+def test_fast_checker_c1_shape_seeded_table_and_ties():
+    """C1's shape (5 000 genomes x s=1000) from a table that already holds an earlier part of the stream, top 1 and 3;
+    duplicated columns (exact ties -> lower index first) and a genome that leads only through its start value."""
+    ref, bases, offsets = workload(5000, 1000, 260, rng_seed=37)
+    hashes = ref["ref"].copy()
+    hashes[4000] = hashes[17]
+    hashes[16] = hashes[17]
+    first = orc.stream(16, 0, 1000, hashes, ref["col_len"], bases, offsets[:61], top_k=1)
+    rest = (bases, offsets[60:] )
+    for top in (1, 3):
+        _assert_fast_equals_stream(16, 0, 1000, hashes, ref["col_len"], rest[0], rest[1], top, cum=first["cum"], n_threads=8)
+    boost = first["cum"].copy()
+    boost[4999] += 40
+    got = _assert_fast_equals_stream(16, 0, 1000, hashes, ref["col_len"], rest[0], rest[1], 2, cum=boost, n_threads=4)
+    assert got["topk_idx"][0, 0] == 4999
+
+
+def test_fast_checker_ragged_truncated_and_degenerate_inputs():
+    """Columns of unequal length (some empty), a row stride above s, reads sketched at an s below their number of distinct
+    k-mers (the in-range prefix is taken AFTER the truncation to s), other k / seed, empty and N-only reads, zero reads,
+    fewer genomes than threads, top = all genomes."""
+    rng = np.random.default_rng(5)
+    ref, bases, offsets = workload(37, 64, 40, read_len=300, genome_len=20000, rng_seed=41)
+    hashes, col_len = ref["ref"].copy(), ref["col_len"].copy()
+    col_len[[3, 11]] = 0
+    col_len[[5, 20, 36]] = [1, 17, 63]
+    _assert_fast_equals_stream(16, 0, 64, hashes, col_len, bases, offsets, 4, n_threads=64, block_reads=9)
+    # s (read sketch size) below the stride, and far below the reads' distinct k-mers: truncation decides what can match
+    for s in (8, 24):
+        _assert_fast_equals_stream(16, 0, s, hashes, col_len, bases, offsets, 3, n_threads=3)
+    # k = 21, seed 42, reads with junk / whitespace / lower case, empty reads
+    ref2, b2, o2 = workload(20, 48, 12, read_len=260, k=21, seed=42, genome_len=20000, rng_seed=43)
+    reads = unpack_reads(b2, o2)
+    reads[2] = b""
+    reads[5] = b"N" * 80
+    reads[7] = reads[7].lower()[:100] + b"\n\r " + reads[7][100:130] + b"RYK" + reads[7][130:]
+    b3, o3 = pack_reads(reads)
+    _assert_fast_equals_stream(21, 42, 48, ref2["ref"], ref2["col_len"], b3, o3, 20, n_threads=7)
+    # zero reads, one genome
+    z = orc.stream_fast(16, 0, 64, hashes, col_len, np.zeros(0, np.uint8), np.zeros(1, np.uint64), top_k=2)
+    assert z["topk_idx"].shape == (0, 2) and not z["cum"].any()
+    _assert_fast_equals_stream(16, 0, 64, hashes[:1], col_len[:1], bases, offsets, 1, n_threads=8)
+    with pytest.raises(ValueError):
+        orc.stream_fast(16, 0, 64, hashes[:2], col_len[:2], bases, offsets, top_k=3)
+    # random small reference hashes that cannot match: all-zero rows, rank = reference order
+    far = np.sort(rng.integers(1 << 62, 1 << 63, size=(9, 16), dtype=np.uint64), axis=1)
+    got = _assert_fast_equals_stream(16, 0, 16, far, None if False else np.full(9, 16, np.uint32), bases, offsets, 3, n_threads=2)
+    assert (got["topk_idx"] == np.arange(3)).all()
+
+
+def test_fast_checker_species_wrapper():
+    from helpers import workload_species
+    refs, bases, offsets = workload_species([70, 40, 25], 128, 50, read_len=400, genome_len=40000, rng_seed=47)
+    mats = [r["ref"] for r in refs]
+    got = orc.stream_fast_species(16, 0, 128, mats, bases, offsets, top_k=2, n_threads=4)
+    for i, m in enumerate(mats):
+        exp = orc.stream(16, 0, 128, m, None if False else np.full(len(m), 128, np.uint32), bases, offsets, top_k=2)
+        np.testing.assert_array_equal(got["topk_idx"][:, i], exp["topk_idx"])
+        np.testing.assert_array_equal(got["topk_sum"][:, i], exp["topk_sum"])
+        np.testing.assert_array_equal(got["cums"][i], exp["cum"])
+
+
 def test_sanitizer_build_of_the_oracle_runs_clean(tmp_path):
     """oracle/Makefile's ASan + UBSan target (CPU only: GPU sanitizers are unavailable on the pool): the streaming driver,
     both sketchers and the OpenMP variant on a small workload, in a child process with the sanitizer runtime preloaded."""
@@ -186,6 +268,10 @@ def test_sanitizer_build_of_the_oracle_runs_clean(tmp_path):
         "for f in (L.orc_sketch_sort, L.orc_sketch_heap):\n"
         "    f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]; f.restype = C.c_uint64\n"
         "    assert f(p(bases), int(offsets[1]), 16, 0, 64, p(out)) <= 64\n"
+        "L.orc_stream_fast.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32] + [C.c_void_p] * 3 + [C.c_int, C.c_uint32, C.c_void_p]\n"
+        "cum3 = np.zeros(30, np.uint64); ti3 = np.zeros((n, 2), np.uint32); ts3 = np.zeros((n, 2), np.uint64); st = np.zeros(8, np.uint64)\n"
+        "rc = L.orc_stream_fast(16, 0, 64, 64, 30, p(ref['ref']), p(ref['col_len']), p(bases), p(offsets), n, 2, p(cum3), p(ti3), p(ts3), 3, 7, p(st))\n"
+        "assert rc == 0 and np.array_equal(cum, cum3) and np.array_equal(ti, ti3) and np.array_equal(ts, ts3)\n"
         "print('asan ok')\n"
     )
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="3")
