@@ -135,6 +135,13 @@ int skx_ref_species_genomes(const skx_ref *ref, uint32_t species, uint32_t *n_ge
 int skx_ref_sketch_size(const skx_ref *ref, uint32_t *s, uint32_t *stride);
 /* k-mer prefilter of the reference: keys it holds (0: none was built) and the bytes of its table */
 int skx_ref_kmer_filter(const skx_ref *ref, uint64_t *n_keys, uint64_t *table_bytes);
+/*
+ * Rare-hash index of the reference (policy "rare_hash_genomes", default 1024, 0 = none): the distinct hashes of the collection
+ * (n_keys), how many of them at most that many genomes hold (n_rare_keys), the entries of their genome lists (n_postings) and the
+ * device memory of the whole index.  A pass looks its rare query hashes up there instead of asking the scan for them (the scan's
+ * dictionary then holds the hashes many genomes share); results are the same with and without it.  All zero: none was built.
+ */
+int skx_ref_rare_index(const skx_ref *ref, uint64_t *n_keys, uint64_t *n_rare_keys, uint64_t *n_postings, uint64_t *bytes);
 /* bytes of reference hashes one scoring pass streams from HBM (8*stride*n_genomes) */
 int skx_ref_pass_bytes(const skx_ref *ref, uint64_t *bytes);
 void skx_ref_destroy(skx_ref *ref);
@@ -244,9 +251,13 @@ int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
  * wavefronts so far, [9] the segments they were cut into, [10] batches that were sketched a second time because their rows
  * did not fit the stream's row pool (it grows to fit), [11] passes that served SEVERAL enqueued batches (option
  * "stream_coalesce"), [12] groups of enqueued batches that turned out too large for one pass together (or held an error) and were
- * processed one by one -- the stream forms smaller groups after that.  Waits for the stream's queued work.
+ * processed one by one -- the stream forms smaller groups after that, [13] rows (distinct query hashes) the bit matrices of a
+ * pass hold right now, [14] how often they grew because a batch held more distinct hashes than that (only without a
+ * "stream_query_rows" policy; at most an eighth of the free device memory is taken), [15] of the most recent dictionary ([2]) the
+ * hashes the scan looked for (all of them without a rare-hash index, skx_ref_rare_index; else those many genomes hold).  Waits for
+ * the stream's queued work.
  */
-#define SKX_N_STATS 13
+#define SKX_N_STATS 16
 int skx_stream_stats(skx_stream *st, uint64_t *out, uint32_t n_out);
 /* rank the CURRENT table: first top_k of (sum desc, index asc) per species; idx/sum are host arrays [n_species][top_k] */
 int skx_stream_rank(skx_stream *st, uint32_t top_k, uint32_t *idx, uint64_t *sum);

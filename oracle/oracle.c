@@ -430,19 +430,33 @@ static int fast_block(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, ui
 #pragma omp parallel num_threads(n_threads)
     {
         uint64_t *sk = (uint64_t *)malloc(((uint64_t)s + 1) * sizeof(uint64_t));
+        uint64_t *hh = NULL, hh_cap = 0;
 #pragma omp for schedule(dynamic, 64)
         for (i = 0; i < (int64_t)nr; ++i) {
             uint32_t r = r0 + (uint32_t)i;
-            uint64_t len = orc_sketch_heap(bases + offsets[r], offsets[r + 1] - offsets[r], k, seed, s, sk);
-            uint64_t keep = 0;
-            if (have_ref) while (keep < len && sk[keep] <= max_ref) ++keep;
+            const uint64_t n = offsets[r + 1] - offsets[r];
+            uint64_t len, keep = 0;
+            if (n <= s) {
+                /* A read with at most s bases has at most s k-mers: MashSketcher never evicts (heap.len() never exceeds s,
+                 * finch push), so its sketch is ALL its distinct hashes, ascending -- no heap needed to know the prefix
+                 * <= max_ref: the distinct hashes <= max_ref, sorted.  (Longer reads go through the faithful sketcher below;
+                 * tests/test_oracle.py pins both branches against orc_stream.) */
+                if (n + 1 > hh_cap) { free(hh); hh_cap = n + 1; hh = (uint64_t *)malloc(hh_cap * sizeof(uint64_t)); }
+                uint64_t m = orc_kmer_hashes(bases + offsets[r], n, k, seed, hh, NULL), w = 0;
+                if (have_ref) for (uint64_t j = 0; j < m; ++j) if (hh[j] <= max_ref) hh[w++] = hh[j];
+                len = bottom_s_sort(hh, w, s, sk);
+                keep = len;
+            } else {
+                len = orc_sketch_heap(bases + offsets[r], n, k, seed, s, sk);
+                if (have_ref) while (keep < len && sk[keep] <= max_ref) ++keep;
+            }
             if (keep) {
                 lists[i] = (uint64_t *)malloc(keep * sizeof(uint64_t));
                 memcpy(lists[i], sk, keep * sizeof(uint64_t));
             }
             lens[i] = (uint32_t)keep;
         }
-        free(sk);
+        free(sk); free(hh);
     }
     uint64_t npairs = 0, empty = 0;
     uint64_t *poff = (uint64_t *)malloc(((uint64_t)nr + 1) * sizeof(uint64_t));

@@ -107,6 +107,13 @@ class ReferenceSketch:
         return n.value, b.value
 
     @property
+    def rare_index(self):
+        """dict(keys, rare_keys, postings, bytes) of the reference's rare-hash index (all 0: none was built)"""
+        v = [C.c_uint64(0) for _ in range(4)]
+        _lib.check(_lib.load().skx_ref_rare_index(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("keys", "rare_keys", "postings", "bytes"), [x.value for x in v]))
+
+    @property
     def pass_bytes(self) -> int:
         b = C.c_uint64(0)
         _lib.check(_lib.load().skx_ref_pass_bytes(self._h, C.byref(b)))
@@ -224,11 +231,11 @@ class SumOfSharedHashes:
 
     def stats(self):
         """Counters of the stream (skx_stream_stats): pairs / passes of the last push, dictionary size, ..."""
-        v = (C.c_uint64 * 13)()
-        _lib.check(_lib.load().skx_stream_stats(self._h, v, 13))
+        v = (C.c_uint64 * 16)()
+        _lib.check(_lib.load().skx_stream_stats(self._h, v, 16))
         names = ("last_pairs", "last_passes", "dictionary_size", "reads_block_sketcher", "passes", "passes_lean_scan",
                  "pair_capacity", "live_rank_groups", "reads_split_over_waves", "read_segments", "row_pool_grown",
-                 "passes_shared", "groups_unshared")
+                 "passes_shared", "groups_unshared", "query_rows", "query_rows_grown", "dictionary_dense")
         return dict(zip(names, [int(x) for x in v]))
 
     def set_profiling(self, on=True):

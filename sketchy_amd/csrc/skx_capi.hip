@@ -178,6 +178,7 @@ static std::atomic<u32> g_stream_query_rows{0};       // rows of a pass's bit ma
 static std::atomic<u32> g_stream_coalesce{8};         // batches of skx_stream_enqueue_device / skx_stream_submit that may share one pass (1 .. 8)
 static const int kRankLanesMax = 4;
 static std::atomic<u32> g_rank_lanes{2};   // ranking lanes of a stream that enqueues (1 .. 4): chains of consecutive batches that run side by side
+static std::atomic<u32> g_rare_hash_genomes{1024};   // rare-hash index of a reference: hashes held by at most this many genomes get genome lists (0 = no index)
 static std::atomic<u64> g_comm_timeout_ms{0};  // watchdog of skx_comm_create / skx_stream_allreduce: 0 = none (block for ever, as RCCL does)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
@@ -207,6 +208,11 @@ SKX_API int skx_set_option(const char* name, uint64_t value) {
         g_rank_lanes = (u32)value;
         return SKX_OK;
     }
+    if (!strcmp(name, "rare_hash_genomes")) {
+        if (value > (1u << 20)) return fail(SKX_ERR_INVALID, "rare_hash_genomes must be 0 (no rare-hash index) .. 2^20");
+        g_rare_hash_genomes = (u32)value;
+        return SKX_OK;
+    }
     if (!strcmp(name, "comm_timeout_ms")) {
         if (value > 86400000ull) return fail(SKX_ERR_INVALID, "comm_timeout_ms must be 0 (no watchdog) .. 86400000");
         g_comm_timeout_ms = value;
@@ -222,6 +228,7 @@ SKX_API int skx_get_option(const char* name, uint64_t* value) {
     if (!strcmp(name, "stream_coalesce")) { *value = g_stream_coalesce; return SKX_OK; }
     if (!strcmp(name, "comm_timeout_ms")) { *value = g_comm_timeout_ms; return SKX_OK; }
     if (!strcmp(name, "rank_lanes")) { *value = g_rank_lanes; return SKX_OK; }
+    if (!strcmp(name, "rare_hash_genomes")) { *value = g_rare_hash_genomes; return SKX_OK; }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -251,6 +258,12 @@ struct skx_ref {
     // k-mer prefilter (k = 16): Bloom table over the canonical 16-mers whose hash passes the membership filter
     u32* d_kf = nullptr;
     u32 kf_shift = 0, kf_keys = 0;
+    // rare-hash index (skx_kernels.hip): table over the distinct reference hashes + genome lists of those few genomes hold
+    u64* d_kt_key = nullptr;
+    u32 *d_kt_cnt = nullptr, *d_kt_off = nullptr, *d_post = nullptr;
+    u32 kt_mask = 0, rare_max = 0;
+    u64 n_keys = 0, n_rare_keys = 0, n_postings = 0;  // distinct hashes (exact), of those rare, entries of their lists
+    skx::RareIndex rare_index() const { return skx::RareIndex{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask}; }
     skx::KmerFilter kmer_filter() const { return skx::KmerFilter{d_kf, kf_shift}; }
     skx::Species species() const { return skx::Species{d_sp_g0, d_sp_n, d_grp_sp, n_species}; }
 };
@@ -261,6 +274,7 @@ static void ref_free(skx_ref* r) {
     (void)hipFree(r->d_mat); (void)hipFree(r->d_lo); (void)hipFree(r->d_hi);
     (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h); (void)hipFree(r->d_filt); (void)hipFree(r->d_kf);
     (void)hipFree(r->d_sp_g0); (void)hipFree(r->d_sp_n); (void)hipFree(r->d_grp_sp); (void)hipFree(r->d_real2pad);
+    (void)hipFree(r->d_kt_key); (void)hipFree(r->d_kt_cnt); (void)hipFree(r->d_kt_off); (void)hipFree(r->d_post);
     delete r;
 }
 
@@ -435,6 +449,60 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         RCHK(hipGetLastError());
     }
     RCHK(hipDeviceSynchronize());
+    {
+        // Rare-hash index (skx_kernels.hip, "rare-hash index of the reference"; policy "rare_hash_genomes", 0 = none): which genomes
+        // hold a hash that only a few hold -- so that a pass asks the scan for the hashes many genomes share and nothing else.
+        // Anything that goes wrong here (no memory, more list entries than 32 bits index) leaves the reference without the index:
+        // every hash then goes to the scan, as in rounds 1-4.
+        static const int rare_env = skx::knob("SKX_RARE_MAX") ? atoi(skx::knob("SKX_RARE_MAX")) : -1;  // experiment knob
+        const u32 rare_max = rare_env >= 0 ? (u32)rare_env : g_rare_hash_genomes.load();
+        if (rare_max && any) {
+            u64 slots = 1024;
+            while (slots < (u64)((double)r->n_distinct * 1.6) + 1024) slots <<= 1;
+            u32* d_over = nullptr;
+            u32* d_cursor = nullptr;
+            auto drop = [&]() {
+                (void)hipFree(r->d_kt_key); (void)hipFree(r->d_kt_cnt); (void)hipFree(r->d_kt_off); (void)hipFree(r->d_post);
+                r->d_kt_key = nullptr; r->d_kt_cnt = r->d_kt_off = r->d_post = nullptr;
+                (void)hipGetLastError();
+            };
+            bool ok = hipMalloc(&d_over, 4) == hipSuccess;
+            for (int attempt = 0; ok && attempt < 4; ++attempt, slots <<= 1) {
+                if (slots > (1ull << 31)) { ok = false; break; }
+                ok = hipMalloc(&r->d_kt_key, slots * 8) == hipSuccess && hipMalloc(&r->d_kt_cnt, slots * 4) == hipSuccess &&
+                     hipMemset(r->d_kt_key, 0xFF, slots * 8) == hipSuccess && hipMemset(r->d_kt_cnt, 0, slots * 4) == hipSuccess &&
+                     hipMemset(d_over, 0, 4) == hipSuccess;
+                if (!ok) break;
+                skx::launch_rare_count(nullptr, r->d_mat, mat_elems, r->d_kt_key, r->d_kt_cnt, (u32)(slots - 1), d_over);
+                u32 over = 0;
+                ok = hipGetLastError() == hipSuccess && hipMemcpy(&over, d_over, 4, hipMemcpyDeviceToHost) == hipSuccess;
+                if (ok && !over) break;
+                drop();  // (the distinct count was an estimate: twice the slots)
+                if (attempt == 3) ok = false;
+            }
+            if (ok && r->d_kt_key) {
+                std::vector<u32> cnt(slots), off(slots);
+                ok = hipMemcpy(cnt.data(), r->d_kt_cnt, slots * 4, hipMemcpyDeviceToHost) == hipSuccess;
+                u64 total = 0, keys = 0, rare = 0;
+                for (u64 i = 0; ok && i < slots; ++i) {
+                    if (cnt[i] && cnt[i] <= rare_max) { off[i] = (u32)total; total += cnt[i]; ++rare; }
+                    else off[i] = 0xFFFFFFFFu;
+                    keys += cnt[i] ? 1 : 0;
+                }
+                ok = ok && total < 0xFFFFFFF0ull;
+                ok = ok && hipMalloc(&r->d_kt_off, slots * 4) == hipSuccess && hipMalloc(&r->d_post, std::max<u64>(total, 1) * 4) == hipSuccess &&
+                     hipMalloc(&d_cursor, slots * 4) == hipSuccess && hipMemset(d_cursor, 0, slots * 4) == hipSuccess &&
+                     hipMemcpy(r->d_kt_off, off.data(), slots * 4, hipMemcpyHostToDevice) == hipSuccess;
+                if (ok) {
+                    skx::launch_rare_fill(nullptr, r->d_mat, mat_elems, s, r->d_kt_key, r->d_kt_off, d_cursor, r->d_post, (u32)(slots - 1));
+                    ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                }
+                if (ok) { r->kt_mask = (u32)(slots - 1); r->rare_max = rare_max; r->n_keys = keys; r->n_rare_keys = rare; r->n_postings = total; }
+            }
+            (void)hipFree(d_over); (void)hipFree(d_cursor);
+            if (!ok) drop();
+        }
+    }
     const u32 pf_mode = skx::knob("SKX_KMER_PREFILTER") ? (u32)atoi(skx::knob("SKX_KMER_PREFILTER")) : g_kmer_prefilter.load();  // (experiment knob overrides the policy)
     // table bits per key, and how large a table still pays.  Every window of a read costs one random 4-byte gather, and that only
     // pays while the table sits in the CUs' L1 caches (32 KB).  Measured at C2 (98 304-read batches, eight batches per scan) with the
@@ -510,6 +578,15 @@ SKX_API int skx_ref_kmer_filter(const skx_ref* ref, uint64_t* n_keys, uint64_t* 
     if (!ref) return fail(SKX_ERR_INVALID, "NULL argument");
     if (n_keys) *n_keys = ref->d_kf ? ref->kf_keys : 0;
     if (table_bytes) *table_bytes = ref->d_kf ? (4ull << (32u - ref->kf_shift)) : 0;
+    return SKX_OK;
+}
+SKX_API int skx_ref_rare_index(const skx_ref* ref, uint64_t* n_keys, uint64_t* n_rare_keys, uint64_t* n_postings, uint64_t* bytes) {
+    if (!ref) return fail(SKX_ERR_INVALID, "NULL argument");
+    const bool on = ref->d_kt_key != nullptr;
+    if (n_keys) *n_keys = on ? ref->n_keys : 0;
+    if (n_rare_keys) *n_rare_keys = on ? ref->n_rare_keys : 0;
+    if (n_postings) *n_postings = on ? ref->n_postings : 0;
+    if (bytes) *bytes = on ? ((u64)ref->kt_mask + 1) * 16 + std::max<u64>(ref->n_postings, 1) * 4 : 0;
     return SKX_OK;
 }
 SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
@@ -623,6 +700,15 @@ struct skx_stream {
     u64 max_bases = 0;
     u32 pcap = 0;        // pairs per pass
     u32 qcap = 0;        // distinct query hashes per pass = rows of the pass's bit matrices (|Q| <= pairs, usually far below)
+    // the split dictionary of a pass (references with a rare-hash index; all on the scan stream, one copy): the hashes the scan looks
+    // for, position in Q -> row, key-table slots of the other rows, scratch of the classify kernels; d_nd = {dense rows, other rows}
+    u64* d_qd = nullptr;
+    u32 *d_qrow = nullptr, *d_sslot = nullptr, *d_qinfo = nullptr, *d_qloc = nullptr, *d_cls_bsum = nullptr, *d_nd = nullptr;
+    u32* h_nd = nullptr;     // page-locked: [2 b] = |Q| of buffer set b's latest pass, [2 b + 1] = its dense rows
+    bool have_split_hint = false;
+    double nd_frac = 1.0;    // dense rows / |Q| of the latest pass whose dictionary is known: which scan variant a pass gets
+    bool qcap_auto = false;  // no "stream_query_rows" policy: the matrices grow when a batch holds more distinct hashes (grow_query_rows)
+    u64 qrows_grown = 0;     // how often they did (statistic)
     u32 coalesce = 1;    // enqueued batches that may share a pass (policy stream_coalesce at creation)
     u32 rpass = 0;       // reads per pass
     u64 reads_total = 0;
@@ -772,7 +858,8 @@ static void stream_free(skx_stream* st) {
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1],
                     st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
-                    st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1]};
+                    st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1],
+                    st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_nd};
     for (auto& t : st->d_tab) (void)hipFree(t);
     for (int i = 0; i < skx_stream::kRankLanes; ++i) free_lane(st, i);
     for (int i = 1; i < skx_stream::kRankLanes; ++i)
@@ -781,6 +868,7 @@ static void stream_free(skx_stream* st) {
     if (st->h_poff) (void)hipHostFree(st->h_poff);
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
+    if (st->h_nd) (void)hipHostFree(st->h_nd);
     if (st->h_chk_base) (void)hipHostFree(st->h_chk_base);
     for (int i = 0; i < kSides; ++i) {
         free_side(st, i);
@@ -990,17 +1078,23 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     qc = std::max<u64>(std::min<u64>(qc, pc), std::min<u64>(pc, sk_stride));  // (never below one read's worth: a read alone must fit a pass)
     qc = (qc + 63) / 64 * 64;
     st->qcap = (u32)qc;
+    st->qcap_auto = rows_policy == 0 && !dense_queries;
     static const u32 coalesce_env = skx::knob("SKX_COALESCE") ? (u32)atoi(skx::knob("SKX_COALESCE")) : 0u;  // experiment knob
     st->coalesce = coalesce_env ? std::min<u32>((u32)kGroupMax, std::max(1u, coalesce_env)) : g_stream_coalesce.load();
     st->group_cap = st->coalesce;
     // reads per pass: the whole batch if the ranking's per-segment arrays fit (inc / rel: 4 bytes per (64 reads, genome) each, at most
     // an eighth of the free device memory) -- a batch cut into two passes scans the reference twice
     static const u64 pass_reads_env = skx::knob("SKX_PASS_READS") ? (u64)atoll(skx::knob("SKX_PASS_READS")) : 0;  // test knob
-    u64 pass_reads = 1u << 20;
+    u64 pass_reads = 1u << 20, lanes_planned = 1;
     {
         size_t mem_free = 0, mem_total = 0;
         (void)hipMemGetInfo(&mem_free, &mem_total);
-        const u64 per_seg = (u64)n_pad * 4 * 2 + n_pad / 64 + 64;
+        // (every ranking lane has its own inc / rel / candidate arrays: the eighth of the free memory is shared by the lanes this
+        // stream will ask for -- round 4 budgeted one lane's worth and allocated up to four)
+        static const int lanes_env0 = skx::knob("SKX_RANK_LANES") ? atoi(skx::knob("SKX_RANK_LANES")) : 0;
+        const int lanes_want = lanes_env0 ? lanes_env0 : (int)g_rank_lanes;
+        lanes_planned = (enqueueing && top_k) ? (u64)std::max(1, std::min(lanes_want, (int)skx_stream::kRankLanes)) : 1;
+        const u64 per_seg = ((u64)n_pad * 4 * 2 + n_pad / 64 + 64) * lanes_planned;
         pass_reads = std::min<u64>(pass_reads, std::max<u64>(4096, (u64)(mem_free / 8) / per_seg * skx::kSegLen));
     }
     if (pass_reads_env) pass_reads = pass_reads_env;
@@ -1008,7 +1102,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // candidate arrays of the ranking: per (read, rank group, row) for top_k <= 16, per (read, genome word, row) beyond
     const u32 n_sp = ref->n_species;
     const u32 n_cand_units = (top_k >= 1 && top_k <= skx::rank_topk_fast_max()) ? (n_gw + skx::kRankWords - 1) / skx::kRankWords : n_gw;
-    if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (4ull << 30) / ((u64)n_cand_units * top_k * 12)));
+    if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (4ull << 30) / lanes_planned / ((u64)n_cand_units * top_k * 12)));
     rp = std::max<u64>(rp, 1);
     st->rpass = (u32)rp;
     const u32 n_bt = ref->n_bands * ref->n_tiles;
@@ -1119,18 +1213,28 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         st->lane[0].s = st->hs2;
         for (int i = 1; i < st->n_lanes; ++i) {
             if (st->shared_queues) {
-                std::lock_guard<std::mutex> lk(g_queues_mu);
-                SharedQueues& q = g_queues[st->device & 63];
-                static const int rank_hi_l = skx::knob("SKX_PRIO_RANK") ? atoi(skx::knob("SKX_PRIO_RANK")) : 0;
-                const int prio_rank_l = rank_hi_l == 1 ? prio_hi : rank_hi_l == 2 ? (prio_lo + prio_hi) / 2 : prio_lo;
-                if (!q.lane_s[i - 1]) SCHK(hipStreamCreateWithPriority(&q.lane_s[i - 1], hipStreamNonBlocking, prio_rank_l));
-                st->lane[i].s = q.lane_s[i - 1];
+                // (the error is checked OUTSIDE the lock: SCHK frees the stream, which releases the shared queues under this mutex)
+                hipError_t lane_err = hipSuccess;
+                {
+                    std::lock_guard<std::mutex> lk(g_queues_mu);
+                    SharedQueues& q = g_queues[st->device & 63];
+                    static const int rank_hi_l = skx::knob("SKX_PRIO_RANK") ? atoi(skx::knob("SKX_PRIO_RANK")) : 0;
+                    const int prio_rank_l = rank_hi_l == 1 ? prio_hi : rank_hi_l == 2 ? (prio_lo + prio_hi) / 2 : prio_lo;
+                    if (!q.lane_s[i - 1]) {
+                        lane_err = hipStreamCreateWithPriority(&q.lane_s[i - 1], hipStreamNonBlocking, prio_rank_l);
+                        if (lane_err != hipSuccess) q.lane_s[i - 1] = nullptr;
+                    }
+                    st->lane[i].s = q.lane_s[i - 1];
+                }
+                SCHK(lane_err);
             } else {
                 SCHK(hipStreamCreateWithPriority(&st->lane[i].s, hipStreamNonBlocking, prio_lo));
                 st->own_lane_stream = true;
             }
         }
-        for (int i = 0; i < st->n_lanes; ++i) SCHK(alloc_lane(st, i));
+        SCHK(alloc_lane(st, 0));
+        for (int i = 1; i < st->n_lanes; ++i)
+            if (alloc_lane(st, i) != hipSuccess) { st->n_lanes = i; break; }  // no room for another lane's scratch: fewer lanes, same results
     }
     for (int i = 0; i <= st->n_lanes; ++i) {
         SCHK(hipMalloc(&st->d_tab[i], (size_t)n_pad * 8));
@@ -1175,6 +1279,18 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipHostMalloc((void**)&st->h_nq, 4 * 4, hipHostMallocCoherent));  // ([2], [3]: the ranking's live sample, d_live_ctr)
     st->h_nq[0] = st->h_nq[1] = 0;
     st->h_nq[2] = 1; st->h_nq[3] = 1;  // (nothing known yet: everything may hold a candidate)
+    SCHK(hipHostMalloc((void**)&st->h_nd, 4 * 4, hipHostMallocCoherent));
+    memset(st->h_nd, 0, 4 * 4);
+    if (ref->d_kt_key) {  // the split dictionary of a pass (rare-hash index)
+        SCHK(hipMalloc(&st->d_qd, (size_t)st->pcap * 8));
+        SCHK(hipMalloc(&st->d_qrow, (size_t)st->pcap * 4));
+        SCHK(hipMalloc(&st->d_sslot, (size_t)st->pcap * 4));
+        SCHK(hipMalloc(&st->d_qinfo, (size_t)st->pcap * 4));
+        SCHK(hipMalloc(&st->d_qloc, (size_t)st->pcap * 4));
+        SCHK(hipMalloc(&st->d_cls_bsum, ((size_t)st->pcap / 1024 + 2) * 4));
+        SCHK(hipMalloc(&st->d_nd, 64));
+        SCHK(hipMemset(st->d_nd, 0, 64));
+    }
     // the zero-fills above ran on the null stream, which the (non-blocking) pipeline streams do not wait for
     SCHK(hipDeviceSynchronize());
 #undef SCHK
@@ -1267,6 +1383,51 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 // case: the whole batch is one pass and process_batch queued launch_dict_insert right behind the sketcher)
 // q_rows: an upper bound of the pass's distinct query hashes (<= qcap): P itself, or -- when the host knows it from the
 // speculative gather -- |Q|
+// The bit matrices of a pass (M, Mq, row flags) have `qcap` rows: 65 536 by default -- 0.33 GB + 2 x 0.33 GB at C2, where a batch of ~100k
+// reads holds ~10 k distinct member hashes when the collection's genomes share most of their hashes.  A collection with millions of
+// strain-specific hashes (SURVEY.md 8(d)'s SNP clone tree at k = 16: 4.4 M distinct reference hashes below the largest one, 45 % of ALL
+// canonical 16-mers in that range -- every sequencing error has an even chance to hit somebody's private hash) leaves ~160 k distinct
+// hashes per batch: cut into passes of 65 536 pairs that was SEVEN scans per batch (10 M reads/s instead of 130 M).  Without a
+// "stream_query_rows" policy the matrices therefore GROW when a batch (or a group of batches that would share a pass) needs more rows:
+// everything in flight is waited for, the new arrays are allocated before the old ones are freed, at most an eighth of the free device
+// memory is taken.  Not on the steady path: a stream grows once or twice, then its groups fit.
+static int grow_query_rows(skx_stream* st, u64 want_rows) {
+    if (!st->qcap_auto) return SKX_OK;
+    const skx_ref* ref = st->ref;
+    const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
+    const size_t mq_words = (size_t)((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords);
+    for (hipStream_t h : {st->hs0, st->hs1, st->hs, st->hs2}) if (h) HIPCHK(hipStreamSynchronize(h));
+    for (int i = 1; i < st->n_lanes; ++i) if (st->lane[i].s) HIPCHK(hipStreamSynchronize(st->lane[i].s));
+    size_t mem_free = 0, mem_total = 0;
+    HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
+    const u64 per_row = (u64)n_pad / 8 * (st->d_mint ? 2 : 1) + 2 * mq_words * 8 + 2 * (u64)(n_pad / (skx::kRankWords * 64)) / 8 + 1;
+    u64 rows = std::min<u64>(want_rows, (u64)(mem_free / 8) / per_row);
+    rows = std::min<u64>(rows, st->pcap) / 64 * 64;
+    if (rows <= st->qcap) return SKX_OK;  // no room (or nothing to gain): the batch is cut into passes as before
+    u64 *m = nullptr, *mint = nullptr, *mq[2] = {nullptr, nullptr}, *ra[2] = {nullptr, nullptr};
+    u32* wb[2] = {nullptr, nullptr};
+    auto undo = [&]() { for (void* q : {(void*)m, (void*)mint, (void*)mq[0], (void*)mq[1], (void*)ra[0], (void*)ra[1], (void*)wb[0], (void*)wb[1]}) if (q) (void)hipFree(q); (void)hipGetLastError(); };
+    hipError_t e = hipMalloc(&m, (size_t)(rows / 64) * n_pad * 8);
+    if (e == hipSuccess && st->d_mint) e = hipMalloc(&mint, (size_t)(rows / 64) * n_pad * 8);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&mq[i], (size_t)rows * mq_words * 8);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&ra[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (rows / 64) * 8);
+    for (int i = 0; i < 2 && e == hipSuccess && st->d_wb[i]; ++i) e = hipMalloc(&wb[i], ((size_t)rows / 64 + 1) * ref->n_tiles * 16);
+    if (e == hipSuccess) e = hipMemset(m, 0, (size_t)(rows / 64) * n_pad * 8);  // (M is all-zero between passes)
+    if (e == hipSuccess && mint) e = hipMemset(mint, 0, (size_t)(rows / 64) * n_pad * 8);
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // (the zero-fills ran on the null stream)
+    if (e != hipSuccess) { undo(); return SKX_OK; }   // (no memory for it: as before)
+    (void)hipFree(st->d_m); st->d_m = m;
+    if (mint) { (void)hipFree(st->d_mint); st->d_mint = mint; }
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(st->d_mq[i]); st->d_mq[i] = mq[i];
+        (void)hipFree(st->d_rowany[i]); st->d_rowany[i] = ra[i];
+        if (wb[i]) { (void)hipFree(st->d_wb[i]); st->d_wb[i] = wb[i]; }
+    }
+    st->qcap = (u32)rows;
+    st->qrows_grown += 1;
+    return SKX_OK;
+}
+
 // A pass normally ranks ONE run of reads; batches enqueued back to back (up to stream_coalesce of them) share a pass (one
 // dictionary, one scan of the reference, one transpose) and are ranked one after the other from it: `subs` lists them -- their pairs sit one behind the
 // other in the pass's pair lists (p_off), each with its own pair offsets (d_poff, relative to its own first pair), reads and
@@ -1304,13 +1465,17 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     u64 *d_mq = st->d_mq[b], *d_q = st->d_q[b];
     u32* d_grp_any = st->d_grp_any[b];
 
-    // |Q| per pair from the latest pass whose dictionary is known to be complete
+    // |Q| per pair from the latest pass whose dictionary is known to be complete (split dictionaries: also the dense share)
+    const bool split_dict = ref->d_kt_key != nullptr;
+    auto hint_nq = [&](int i) -> u32 { return split_dict ? st->h_nd[2 * i] : st->h_nq[i]; };
+    auto take_hint = [&](int i, u32 pairs) {
+        st->nq_per_pair = std::min(1.0, (double)hint_nq(i) / std::max<u32>(pairs, 1u));
+        if (split_dict && st->h_nd[2 * i]) st->nd_frac = std::min(1.0, (double)st->h_nd[2 * i + 1] / st->h_nd[2 * i]);
+        st->hint_pairs[i] = 0;
+        st->have_hint = true;
+    };
     for (int i = 0; i < 2; ++i)
-        if (st->hint_pairs[i] && hipEventQuery(st->ev_dict[i]) == hipSuccess) {
-            st->nq_per_pair = std::min(1.0, (double)st->h_nq[i] / st->hint_pairs[i]);
-            st->hint_pairs[i] = 0;
-            st->have_hint = true;
-        }
+        if (st->hint_pairs[i] && hipEventQuery(st->ev_dict[i]) == hipSuccess) take_hint(i, st->hint_pairs[i]);
     u64 nq_est = std::max<u64>(1, (u64)(P * st->nq_per_pair));
     // (a pass whose pairs the front halves gathered knows its |Q| exactly: the gather counted the keys new to the hash set.  The
     // per-pair figure of an earlier pass misleads when passes differ in size -- a group of eight batches has eight times the
@@ -1326,7 +1491,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     static const int run_env = skx::knob("SKX_SCAN_RUN") ? atoi(skx::knob("SKX_SCAN_RUN")) : 0;
     u32 scan_run = 0;
     if (run_env != 0 && ref->n_bands <= 65535u) {
-        const double per_band = (double)ref->rb * (double)nq_est / (double)std::max<u32>(ref->s, 1u);
+        const double per_band = (double)ref->rb * (double)nq_est * st->nd_frac / (double)std::max<u32>(ref->s, 1u);
         scan_run = 1;
         while (scan_run < 4u && (scan_run + 1 + 2.1) * per_band * 1.35 <= (double)skx::scan_run_cap()) ++scan_run;
         if (run_env > 0) scan_run = (u32)std::min(run_env, 64);
@@ -1348,6 +1513,8 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         HIPCHK(hipMemcpyAsync(d_poff, st->d_poff + ra, ((size_t)(rb - ra) + 1) * 4, hipMemcpyDeviceToDevice, hs));
         subs[0].d_poff = d_poff;
     }
+    const u64* scan_q = d_q;    // the dictionary the scan works on (its dense part when the reference has a rare-hash index)
+    const u32* scan_nq = d_nq;
     if (P > 0) {
         Span sp(st, 1, hs);
         if (!inserted)
@@ -1355,10 +1522,16 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                                     st->ht_slots, st->d_dict_ctr[b], st->pcap, st->d_len);
         skx::launch_dict_rest(hs, st->d_ht[b], st->ht_slots, ref->max_ref, st->d_slot_off, st->d_bcount, st->d_bbase, st->d_btot,
                               st->d_dict_ctr[b], d_q, d_nq);
+        if (split_dict) {
+            // dense hashes -> rows [0, nd), what the scan looks for; the others -> the rows behind, filled from the genome lists
+            skx::launch_classify(hs, d_q, d_nq, q_bound, ref->rare_index(), st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_qd, st->d_nd,
+                                 st->d_qrow, st->d_sslot, st->h_nd + 2 * b);
+            scan_q = st->d_qd; scan_nq = st->d_nd;
+        }
         if (st->d_hbuf && !into_m) {  // (round 3's slab form only: windows + word -> bands in one launch; also hands |Q| to the host)
-            skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, d_nq, st->d_wb[b], ref->d_lo, ref->d_hi, d_q, &st->h_nq[b]);
+            skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, scan_nq, st->d_wb[b], ref->d_lo, ref->d_hi, scan_q, split_dict ? nullptr : &st->h_nq[b]);
         } else {
-            skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, d_q, d_nq, d_win, &st->h_nq[b]);
+            skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, scan_q, scan_nq, d_win, split_dict ? nullptr : &st->h_nq[b]);
         }
         st->hint_pairs[b] = P;
     }
@@ -1370,13 +1543,15 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     HIPCHK(hipEventRecord(st->ev_dict[b], hs));
 
     // the very first pass of a stream has no hint: wait for its dictionary once rather than run the heaviest variant
-    if (!st->have_hint && !nq_known && P > 0) {
+    // (split dictionaries: until a pass has told which share of the hashes is dense, every pass is worth that wait once)
+    if ((!st->have_hint && !nq_known && P > 0) || (split_dict && !st->have_split_hint && P > 0)) {
         HIPCHK(hipStreamSynchronize(hs));
-        st->nq_per_pair = std::min(1.0, (double)st->h_nq[b] / P);
-        st->hint_pairs[b] = 0;
-        st->have_hint = true;
-        nq_est = std::max<u64>(1, st->h_nq[b]);
+        take_hint(b, P);
+        st->have_split_hint = true;
+        if (!nq_known) nq_est = std::max<u64>(1, hint_nq(b));
     }
+    // what the SCAN looks for: the dense part of the dictionary
+    const u64 nd_est = split_dict ? std::max<u64>(1, (u64)((double)nq_est * st->nd_frac * 1.1) + 64) : nq_est;
 
     // ---- scan + transpose (same stream, HBM-bound)
     const u32 n_grp_all = n_pad / (skx::kRankWords * 64);
@@ -1389,7 +1564,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
         HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)n_grp_all * 4, hs));  // raised by the transpose
         if (P > 0) {
-            skx::launch_pair_q(hs, st->d_pair_h[b], P, d_q, d_nq, d_pair_q);
+            skx::launch_pair_q(hs, st->d_pair_h[b], P, d_q, d_nq, d_pair_q, split_dict ? st->d_qrow : nullptr);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(st->ev_pairq[b], hs));  // the set's hash set and pair hashes may be refilled
@@ -1400,7 +1575,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         const u32 n_words = nq_rows / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
         static const int split_env = skx::knob("SKX_SCAN_SPLIT") ? atoi(skx::knob("SKX_SCAN_SPLIT")) : -1;
-        bool split = split_env >= 0 ? split_env != 0 : (nq_est * ref->rb / ref->s >= 192);
+        bool split = split_env >= 0 ? split_env != 0 : (nd_est * ref->rb / ref->s >= 192);
         if (split && !st->d_mint) {  // dense dictionaries only: most streams never get here
             const size_t bytes = (size_t)(st->qcap / 64) * n_pad * 8;
             if (hipMalloc(&st->d_mint, bytes) == hipSuccess) {
@@ -1412,7 +1587,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             }
         }
         static const int big_env = skx::knob("SKX_SCAN_BIG") ? atoi(skx::knob("SKX_SCAN_BIG")) : -1;
-        const bool big = big_env >= 0 ? big_env != 0 : (nq_est * ref->rb / ref->s >= 900);
+        const bool big = big_env >= 0 ? big_env != 0 : (nd_est * ref->rb / ref->s >= 900);
         const bool run_scan = scan_run != 0 && !split && !big;  // (dense dictionaries: scan_kernel's variants, as before)
         const bool lean = run_scan || skx::scan_lean_applies(ref->n_bands, split, big);
         // Experiment knob SKX_SCAN_BIGSLICE=1: the lean kernel's BIG instance (slices of up to 510 entries in one pass of the
@@ -1429,14 +1604,16 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             Span sp(st, 2, hs);
             // sparse dictionaries: the lean kernel with its single-owner slabs; dense ones: scan_kernel's variants into M
             // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
-            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, d_q, d_win, st->d_m,
+            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, scan_q, d_win, st->d_m,
                              split ? st->d_mint : nullptr, n_pad, big, lean && !run_scan, (lean && !run_scan) ? st->d_hbuf : nullptr, d_mdirty, into_m,
                              run_scan ? scan_run : 0u, big_slices);
         }
         {
             Span sp(st, 1, hs);
             // (after the scan: its persistent form writes complete words with plain stores, these OR single bits in)
-            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad, d_mdirty);
+            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad, d_mdirty, split_dict ? st->d_qrow : nullptr);
+            // the rows behind the dense ones: bits from the genome lists of the reference's rare-hash index
+            if (split_dict) skx::launch_sparse_fill(hs, st->d_sslot, st->d_nd, ref->rare_index(), st->d_m, n_pad, d_mdirty, q_bound);
         }
         SKXCHK(wait_back());
         {
@@ -1912,7 +2089,18 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     // speculative gather ran (it counts its new keys; it did nothing when the pairs exceed a pass), else bounded by the pairs
     const u32 spec_keys = pb.spec_insert ? st->h_chk[10] : 0xFFFFFFFFu;
     const u32 q_rows = spec_keys != 0xFFFFFFFFu ? spec_keys : total_pairs;
+    if (spec_keys != 0xFFFFFFFFu && q_rows > st->qcap && total_pairs <= st->pcap) {
+        // more distinct hashes than the pass's matrices have rows: make room for a group of such batches (see grow_query_rows)
+        // (enqueued batches share passes: room for a group of them; a stream that is pushed to needs one batch's worth)
+        const u64 per_batch = (u64)q_rows + q_rows / 4;
+        SKXCHK(grow_query_rows(st, pb.pairable ? std::max<u64>(per_batch, per_batch * std::min<u32>(st->coalesce, 8u) * 3 / 4) : per_batch));
+    }
     const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap && q_rows <= st->qcap;
+#ifdef SKX_EXPERIMENTS
+    if (skx::knob("SKX_DEBUG_PASS"))
+        fprintf(stderr, "[skx pass] reads %u rpass %u dbg_cap %u pairs %u pcap %u spec_insert %d spec_keys %u q_rows %u qcap %u single %d gi %d\n",
+                n_reads, st->rpass, pb.dbg_cap, total_pairs, st->pcap, (int)pb.spec_insert, spec_keys, q_rows, st->qcap, (int)single, pb.gi);
+#endif
     if (n_reads && pb.inrange_only) {  // (what the next groups are sized by)
         st->ppr_est = (double)total_pairs / n_reads;
         st->qpr_est = (double)std::min(q_rows, total_pairs) / n_reads;
@@ -1992,6 +2180,8 @@ static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch
     }
     const u32 q_rows = (st->h_chk_base + 16 * g[n - 1].side)[10];  // (the last summary counts the keys of the joint set)
     const bool clean = fits;
+    if (clean && q_rows != 0xFFFFFFFFu && q_rows > st->qcap && pairs <= st->pcap)
+        SKXCHK(grow_query_rows(st, (u64)q_rows + q_rows / 4));  // (the joint set of the group: see grow_query_rows)
     fits = fits && pairs <= st->pcap && q_rows != 0xFFFFFFFFu && q_rows <= st->qcap;
     u64 reads = 0;
     for (int i = 0; i < n; ++i) reads += g[i].n_reads;
@@ -2095,7 +2285,10 @@ static int enqueue_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     // (host-fed batches: every batch waiting for its group holds a staging slot -- bases, offsets, rows -- so groups stay at four)
     nw.max_group = slot ? std::min<u32>(st->coalesce, kStagedGroupMax) : st->coalesce;
     SKX_MARK("enqueue: begin", st->n_pend);
-    SKXCHK(batch_front(st, nw));
+    {
+        const int rc_front = batch_front(st, nw);
+        if (rc_front != SKX_OK) { staged_drop(slot); return rc_front; }  // (skx_stream_wait on its ticket then fails instead of handing out stale rows)
+    }
     SKX_MARK("enqueue: front queued, gi", nw.gi);
     int rc = SKX_OK;
     if (nw.gi == 0) rc = pending_back(st, &nw);  // (it joined nobody: the batches waiting are complete)
@@ -2260,15 +2453,16 @@ SKX_API int skx_stream_submit(skx_stream* st, const uint8_t* bases, const uint64
     st->next_ticket += 1;
     if (&other != &sl) {
         const int rc = staged_process(st, other);
-        // (the previous batch's host buffers are the caller's again when this call returns -- also when it fails)
-        if (other.ev_copy && other.ticket + 2 == st->next_ticket) HIPCHK(hipEventSynchronize(other.ev_copy));
         if (rc != SKX_OK) {  // (a batch submitted before this one failed: this one is dropped with it, as the header says)
             const std::string msg = g_err;
+            (void)hipEventSynchronize(other.ev_copy);
             (void)hipEventSynchronize(sl.ev_copy);
             sl.pending = false; sl.dropped = true;
             g_err = msg;
             return rc;
         }
+        // (the previous batch's host buffers are the caller's again when this call returns)
+        if (other.ev_copy && other.ticket + 2 == st->next_ticket) HIPCHK(hipEventSynchronize(other.ev_copy));
     }
     return SKX_OK;
 }
@@ -2495,9 +2689,10 @@ SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
         HIPCHK(hipMemcpy(flags.data(), st->d_grp_any[st->buf ^ 1], (size_t)n_grp * 4, hipMemcpyDeviceToHost));
         for (u32 f : flags) live += f ? 1 : 0;
     }
-    const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)st->h_nq[st->buf ^ 1], st->reads_big,
+    const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)(st->ref->d_kt_key ? st->h_nd[2 * (st->buf ^ 1)] : st->h_nq[st->buf ^ 1]), st->reads_big,
                                      st->total_passes, st->lean_passes, st->pcap, live, st->reads_split, st->segs_split, st->pool_grown,
-                                     st->shared_passes, st->groups_unshared};
+                                     st->shared_passes, st->groups_unshared, st->qcap, st->qrows_grown,
+                                     (uint64_t)(st->ref->d_kt_key ? st->h_nd[2 * (st->buf ^ 1) + 1] : st->h_nq[st->buf ^ 1])};
     for (uint32_t i = 0; i < n_out; ++i) out[i] = i < SKX_N_STATS ? v[i] : 0;
     return SKX_OK;
 }

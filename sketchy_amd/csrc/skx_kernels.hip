@@ -1534,11 +1534,15 @@ __device__ __forceinline__ u32 upper_bound_u64(const u64* __restrict__ a, u32 n,
     return lo;
 }
 
+// qrow != NULL: the dictionary was split (classify kernels): position in Q -> row of the bit matrix
 __global__ void pair_q_kernel(const u64* __restrict__ pair_h, u32 n_pairs, const u64* __restrict__ q,
-                              const u32* __restrict__ n_q, u32* __restrict__ pair_q) {
+                              const u32* __restrict__ n_q, u32* __restrict__ pair_q, const u32* __restrict__ qrow) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n_pairs) pair_q[p] = lower_bound_u64(q, *n_q, pair_h[p]);
+    if (p < n_pairs) {
+        const u32 pos = lower_bound_u64(q, *n_q, pair_h[p]);
+        pair_q[p] = qrow ? qrow[pos] : pos;
+    }
 }
 
 // win[2*bt] = qa, win[2*bt+1] = qb : Q[qa..qb) are the query hashes inside [lo[bt], hi[bt]]
@@ -1562,15 +1566,175 @@ __global__ void window_kernel(const u64* __restrict__ lo, const u64* __restrict_
 // markers); set their bits here.  exc_g / exc_h: (genome, hash) pairs.
 __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __restrict__ exc_h, u32 n_exc,
                                   const u64* __restrict__ q, const u32* __restrict__ n_q, u64* __restrict__ m_bits,
-                                  u32 n_pad, u32* __restrict__ m_dirty) {
+                                  u32 n_pad, u32* __restrict__ m_dirty, const u32* __restrict__ qrow) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_exc) return;
     const u32 nq = *n_q;
-    const u32 pos = lower_bound_u64(q, nq, exc_h[e]);
+    u32 pos = lower_bound_u64(q, nq, exc_h[e]);
     if (pos < nq && q[pos] == exc_h[e]) {
+        if (qrow) pos = qrow[pos];
         atomicOr(&m_bits[(size_t)(pos >> 6) * n_pad + exc_g[e]], 1ull << (pos & 63u));
         if (m_dirty) *m_dirty = 1u;  // (the transpose must look at M)
     }
+}
+
+// =====================================================================================
+// rare-hash index of the reference (round 5)
+// =====================================================================================
+// The scan prices a pass by the size of its dictionary: a (band, tile) block holds its slice of Q in LDS, and the lean kernel's
+// one-pass probe takes 254 entries.  That fits a collection whose genomes share most of their hashes (C2's random-hash clone tree:
+// ~10 k distinct member hashes per batch).  SURVEY.md 8(d)'s SNP clone tree at k = 16 does not look like that: 40 000 strains x
+// 1 400 private SNPs x 16 windows put ~4.4 M distinct hashes below the largest reference hash -- 45 % of ALL canonical 16-mers in that
+// range -- so every sequencing error has an even chance to hit SOMEBODY's private hash: ~160 k distinct member hashes per batch of
+// 98 304 reads, 470 k for eight batches, 9 000 entries per slice, 8 ms per scan instead of 0.55.  Almost all of those hashes
+// are RARE: one strain holds them, or one lineage.  Nothing needs to stream 3.2 GB of matrix to find out WHICH genome holds a hash
+// that a handful hold: skx_ref_create builds, once, a hash table over the distinct reference hashes with the number of genomes that
+// hold each (kt_key / kt_cnt) and, for those held by at most R genomes (policy "rare_hash_genomes", default 1024), the list of
+// those genomes (postings).  A pass then splits its dictionary: DENSE hashes (held by more than R genomes) go to the scan as
+// before -- rows [0, nd) of the bit matrix --, RARE ones get the rows behind them and their bits straight from the postings
+// (sparse_fill_kernel: one atomicOr into M per posting).  Same bits, hence the same rows and table; the scan's dictionary is
+// back to the ~10 k hashes the collection shares.
+constexpr u32 kRareDense = 0xFFFFFFFFu;   // kt_off of a key held by more than R genomes: no postings, the scan finds it
+constexpr u32 kSlotNone = 0xFFFFFFFFu;    // sslot of a query hash that no genome holds (a false positive of the membership filter)
+__device__ __forceinline__ u32 kt_start(u64 key, u32 mask) { return (u32)((key ^ (key >> 29)) * 0x9E3779B1u) & mask; }
+
+// every real hash of the tiled matrix: insert its key, count the genomes that hold it (columns hold distinct hashes)
+__global__ __launch_bounds__(256) void rare_count_kernel(const u64* __restrict__ mat, u64 n_elems, u64* __restrict__ key,
+                                                         u32* __restrict__ cnt, u32 mask, u32* __restrict__ overflow) {
+    for (u64 e = (u64)blockIdx.x * 256u + threadIdx.x; e < n_elems; e += (u64)gridDim.x * 256u) {
+        const u64 h = mat[e];
+        if (h >= kEmpty) continue;  // padding; hashes >= kEmpty were lifted into the exception list and stay with the scan path
+        u32 slot = kt_start(h, mask), tries = 0;
+        for (;;) {
+            u64 prev = key[slot];
+            if (prev == kPad) prev = atomicCAS(&key[slot], kPad, h);
+            if (prev == kPad || prev == h) { atomicAdd(&cnt[slot], 1u); break; }
+            slot = (slot + 1u) & mask;
+            if (++tries > mask) { *overflow = 1u; break; }
+        }
+    }
+}
+// the genomes of every rare key (off[slot] != kRareDense): post[off + position], position from the key's cursor
+__global__ __launch_bounds__(256) void rare_fill_kernel(const u64* __restrict__ mat, u64 n_elems, u32 s,
+                                                        const u64* __restrict__ key, const u32* __restrict__ off,
+                                                        u32* __restrict__ cursor, u32* __restrict__ post, u32 mask) {
+    const u64 per_tile = (u64)s * kTileGenomes;
+    for (u64 e = (u64)blockIdx.x * 256u + threadIdx.x; e < n_elems; e += (u64)gridDim.x * 256u) {
+        const u64 h = mat[e];
+        if (h >= kEmpty) continue;
+        u32 slot = kt_start(h, mask);
+        while (key[slot] != h) slot = (slot + 1u) & mask;  // (every real hash was inserted by rare_count_kernel)
+        const u32 o = off[slot];
+        if (o == kRareDense) continue;
+        const u32 g = (u32)(e / per_tile) * kTileGenomes + (u32)(e % kTileGenomes);  // padded genome index of mat[t][i][c]
+        post[o + atomicAdd(&cursor[slot], 1u)] = g;
+    }
+}
+
+// ---- a pass's dictionary, split.  classify_a: look every query hash up (qinfo[q] = its slot | kSlotNone; dense: bit 31 of qloc[q]),
+// block-local exclusive count of the dense ones; classify_b: one block scans the block totals, publishes nd / ns;
+// classify_c: Qd (the dense hashes, still ascending), qrow[q] = the hash's row of the bit matrix (dense rows first, in Qd order,
+// then the others in Q order), sslot[row - nd] = key-table slot of a rare hash.
+__global__ __launch_bounds__(256) void classify_a_kernel(const u64* __restrict__ q, const u32* __restrict__ n_q, RareIndex ri,
+                                                         u32* __restrict__ qinfo, u32* __restrict__ qloc, u32* __restrict__ bsum) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ u32 wtot[4];
+    const u32 nq = *n_q;
+    const u32 q0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+    if (blockIdx.x * 1024u >= nq) return;
+    u32 c[4], e[4], info[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = 0; info[j] = kSlotNone;
+        if (q0 + j < nq) {
+            const u64 h = q[q0 + j];
+            if (h >= kEmpty) c[j] = 1u;  // (lifted hashes: exceptions_kernel sets their bits; they ride with the dense rows)
+            else {
+                u32 slot = kt_start(h, ri.mask);
+                for (;;) {
+                    const u64 kk = ri.key[slot];
+                    if (kk == h) { info[j] = slot; c[j] = ri.off[slot] == kRareDense ? 1u : 0u; break; }
+                    if (kk == kPad) break;
+                    slot = (slot + 1u) & ri.mask;
+                }
+            }
+        }
+    }
+    const u32 total = block256_excl_scan4(c, e, wtot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (q0 + j < nq) { qinfo[q0 + j] = info[j]; qloc[q0 + j] = e[j] | (c[j] << 31); }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void classify_b_kernel(u32* __restrict__ bsum, const u32* __restrict__ n_q, u32* __restrict__ n_d,
+                                                          volatile u32* __restrict__ h_words) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ u32 part[1024];
+    const u32 nq = *n_q, nb = (nq + 1023u) / 1024u, t = threadIdx.x;
+    const u32 per = (nb + 1023u) / 1024u;  // block totals per thread (nq <= 2^22: at most 4)
+    u32 mine = 0;
+    for (u32 i = 0; i < per; ++i) { const u32 b = t * per + i; if (b < nb) mine += bsum[b]; }
+    part[t] = mine;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {
+        const u32 v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u32 run = part[t] - mine;
+    for (u32 i = 0; i < per; ++i) { const u32 b = t * per + i; if (b < nb) { const u32 v = bsum[b]; bsum[b] = run; run += v; } }
+    if (t == 1023u) {
+        const u32 nd = part[t];
+        n_d[0] = nd; n_d[1] = nq - nd;
+        if (h_words) { h_words[0] = nq; h_words[1] = nd; __threadfence_system(); }
+    }
+}
+__global__ __launch_bounds__(256) void classify_c_kernel(const u64* __restrict__ q, const u32* __restrict__ n_q,
+                                                         const u32* __restrict__ qinfo, const u32* __restrict__ qloc,
+                                                         const u32* __restrict__ bsum, const u32* __restrict__ n_d,
+                                                         u64* __restrict__ qd, u32* __restrict__ qrow, u32* __restrict__ sslot) {
+    __builtin_amdgcn_s_setprio(3);
+    const u32 nq = *n_q, i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nq) return;
+    const u32 loc = qloc[i], dr = bsum[i >> 10] + (loc & 0x7FFFFFFFu), nd = n_d[0];
+    if (loc >> 31) { qd[dr] = q[i]; qrow[i] = dr; }
+    else { const u32 sr = i - dr; qrow[i] = nd + sr; sslot[sr] = qinfo[i]; }
+}
+// bits of the rare rows: M[row][g] for every genome g on the hash's list.  A wave takes 64 rows; rows with long lists are walked by
+// the whole wave, 64 postings at a time.
+__global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
+                                                          u64* __restrict__ m_bits, u32 n_pad, u32* __restrict__ m_dirty) {
+    __builtin_amdgcn_s_setprio(2);
+    const u32 nd = n_d[0], ns = n_d[1], lane = lane_id();
+    const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    bool wrote = false;
+    for (u32 r0 = wave * 64u; r0 < ns; r0 += n_waves * 64u) {
+        const u32 sr = r0 + lane;
+        u32 off = 0, cnt = 0;
+        if (sr < ns) {
+            const u32 slot = sslot[sr];
+            if (slot != kSlotNone) { off = ri.off[slot]; cnt = ri.cnt[slot]; }
+        }
+        const u32 row = nd + sr;
+        u64* const mrow = m_bits + (size_t)(row >> 6) * n_pad;
+        const u64 bit = 1ull << (row & 63u);
+        if (cnt && cnt <= 8u) {
+            for (u32 j = 0; j < cnt; ++j) atomicOr(&mrow[ri.post[off + j]], bit);
+            wrote = true;
+        }
+        u64 longs = __ballot(cnt > 8u);
+        while (longs) {
+            const u32 src = (u32)__builtin_ctzll(longs);
+            longs &= longs - 1ull;
+            const u32 o = __shfl(off, (int)src), c = __shfl(cnt, (int)src), rw = nd + r0 + src;
+            u64* const mr = m_bits + (size_t)(rw >> 6) * n_pad;
+            const u64 b = 1ull << (rw & 63u);
+            for (u32 j = lane; j < c; j += 64u) atomicOr(&mr[ri.post[o + j]], b);
+            wrote = true;
+        }
+    }
+    if (wrote && m_dirty) *m_dirty = 1u;
 }
 
 // =====================================================================================
@@ -1926,7 +2090,8 @@ __global__ __launch_bounds__(256, SKX_SCAN_OCC) void scan_lean_kernel(const u64*
 }
 
 // =====================================================================================
-// the reference scan, RUNS of bands (round 4; default for sparse dictionaries)
+// the reference scan, RUNS of bands (round 4 experiment: it LOST -- 0.57 of peak against the lean kernel's 0.68 -- and is
+// compiled into the experiments build only, knob SKX_SCAN_RUN)
 // =====================================================================================
 // What the lean kernel above still paid for was its RESULTS: measured with the kernel's geometry as a pure stream
 // (tools/ubench/scan_setup.hip, profiles/r04_scan_setup.txt) the set-up of a block -- window, slice, directory, two barriers --
@@ -3664,18 +3829,37 @@ void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* s
     hipLaunchKernelGGL(dict_bucket_sort_kernel, dim3(kDictBuckets / 256), dim3(256), 0, st, q, bbase, btot, ctr);
 }
 u32 dict_buckets() { return kDictBuckets; }
-void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q) {
+void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q, const u32* qrow) {
     if (n_pairs == 0) return;
-    hipLaunchKernelGGL(pair_q_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pair_h, n_pairs, q, n_q, pair_q);
+    hipLaunchKernelGGL(pair_q_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pair_h, n_pairs, q, n_q, pair_q, qrow);
+}
+void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow) {
+    if (n_elems == 0) return;
+    hipLaunchKernelGGL(rare_count_kernel, dim3((u32)std::min<u64>((n_elems + 255) / 256, 1u << 16)), dim3(256), 0, st, mat, n_elems, key, cnt, mask, overflow);
+}
+void launch_rare_fill(hipStream_t st, const u64* mat, u64 n_elems, u32 s, const u64* key, const u32* off, u32* cursor, u32* post, u32 mask) {
+    if (n_elems == 0) return;
+    hipLaunchKernelGGL(rare_fill_kernel, dim3((u32)std::min<u64>((n_elems + 255) / 256, 1u << 16)), dim3(256), 0, st, mat, n_elems, s, key, off, cursor, post, mask);
+}
+void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, const RareIndex& ri, u32* qinfo, u32* qloc, u32* bsum,
+                     u64* qd, u32* n_d, u32* qrow, u32* sslot, u32* h_words) {
+    const u32 nb = std::max(1u, cdiv(q_bound, 1024));
+    hipLaunchKernelGGL(classify_a_kernel, dim3(nb), dim3(256), 0, st, q, n_q, ri, qinfo, qloc, bsum);
+    hipLaunchKernelGGL(classify_b_kernel, dim3(1), dim3(1024), 0, st, bsum, n_q, n_d, h_words);
+    hipLaunchKernelGGL(classify_c_kernel, dim3(std::max(1u, cdiv(q_bound, 256))), dim3(256), 0, st, q, n_q, qinfo, qloc, bsum, n_d, qd, qrow, sslot);
+}
+void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* m_bits, u32 n_pad, u32* m_dirty, u32 rows_bound) {
+    const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 256), 2048u));
+    hipLaunchKernelGGL(sparse_fill_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, m_bits, n_pad, m_dirty);
 }
 void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win, u32* h_nq) {
     hipLaunchKernelGGL(window_kernel, dim3(cdiv(n_bt, 256)), dim3(256), 0, st, lo, hi, n_bt, q, n_q, win, h_nq);
 }
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
-                       u64* m_bits, u32 n_pad, u32* m_dirty) {
+                       u64* m_bits, u32 n_pad, u32* m_dirty, const u32* qrow) {
     if (n_exc == 0) return;
     hipLaunchKernelGGL(exceptions_kernel, dim3(cdiv(n_exc, 256)), dim3(256), 0, st, exc_g, exc_h, n_exc, q, n_q,
-                       m_bits, n_pad, m_dirty);
+                       m_bits, n_pad, m_dirty, qrow);
 }
 
 bool scan_lean_wants_slabs();

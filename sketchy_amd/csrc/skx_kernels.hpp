@@ -88,8 +88,27 @@ hipError_t launch_sketch_block(hipStream_t st, const uint8_t* bases, const u64* 
 // exclusive scan of n counts (out[i] = sum of in[0..i)); bsum: [ceil(n / 1024)] scratch
 void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum);
 
+// Rare-hash index of a reference (skx_kernels.hip, "rare-hash index"): open-addressing table over the distinct reference hashes
+// (key, all-ones = empty; mask = slots - 1), cnt = genomes that hold the hash, off = start of its genome list in post (padded genome
+// indices) -- or 0xFFFFFFFF for a hash held by more genomes than the policy "rare_hash_genomes": those stay with the scan.
+struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* post; u32 mask; };
+// build, two passes over the tiled matrix (n_elems = n_tiles * s * 256): count (key / cnt zeroed: all-ones / 0; *overflow raised when
+// the table is too small), then -- offsets from the counts, cursor zeroed -- fill
+void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow);
+void launch_rare_fill(hipStream_t st, const u64* mat, u64 n_elems, u32 s, const u64* key, const u32* off, u32* cursor, u32* post, u32 mask);
+// a pass's dictionary split into the hashes the scan looks for (qd ascending, n_d[0] of them: rows [0, n_d[0]) of the bit matrix)
+// and the others (n_d[1]; rows behind, sslot[row - n_d[0]] = key-table slot or 0xFFFFFFFF); qrow[position in q] = row.
+// q_bound: host's upper bound of *n_q (sizes the grids); qinfo / qloc: [q_bound] scratch; bsum: [q_bound / 1024 + 1] scratch;
+// h_words (page-locked, or NULL): [0] = *n_q, [1] = n_d[0]
+void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, const RareIndex& ri, u32* qinfo, u32* qloc, u32* bsum,
+                     u64* qd, u32* n_d, u32* qrow, u32* sslot, u32* h_words);
+// bits of the rows behind the dense ones, from the genome lists: atomicOr into m_bits (and *m_dirty = 1)
+void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* m_bits, u32 n_pad, u32* m_dirty,
+                        u32 rows_bound);
+
 // dictionary
-void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q);
+// qrow (launch_classify) != NULL: pair_q receives ROWS of the bit matrix instead of positions in q
+void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q, const u32* qrow = nullptr);
 // Dictionary of a pass, in two steps.  (1) launch_dict_insert gathers the pairs of reads [r_begin, r_end) (pair_h, pair_r)
 // and inserts every pair hash into the hash set -- one wave per read, no knowledge of the pair count needed: it can be
 // queued right behind the sketcher; if the reads have more than pair_cap pairs it does nothing.  (2) launch_dict_rest
@@ -111,7 +130,7 @@ u32 dict_buckets();
 void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win,
                    u32* h_nq /* page-locked host word that receives *n_q, or NULL */);
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
-                       u64* m_bits, u32 n_pad, u32* m_dirty /* raised when a bit was set, or NULL */);
+                       u64* m_bits, u32 n_pad, u32* m_dirty /* raised when a bit was set, or NULL */, const u32* qrow = nullptr);
 
 // scan + transpose
 // lean: scan_lean_kernel (sparse dictionaries: every production pass) -- every (band, tile) block ORs the words of its slice into

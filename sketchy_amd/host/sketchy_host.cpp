@@ -278,9 +278,13 @@ class Sketchy {
         size_t chunk_bytes = 0;
         std::vector<size_t> cuts;  // chunk i = [cuts[i], cuts[i + 1]) of the mapped file
         const size_t want_reads = std::max<size_t>(1, batch_);
-        const unsigned hw = config.threads ? (unsigned)config.threads : usable_threads();
+        // Threads: every parser / formatter thread owns a page-locked slot (~100 MB at the default batch of 65 536 x 1.5 kb FASTQ), and the
+        // front-end saturates at 12-16 parsers (tools/frontend_rate.sh) -- an unrestricted 256-thread host must not page-lock 27 GB before
+        // its first read.  Without -j: at most kAutoThreads; with -j: what was asked for, the parsers still capped at kMaxParsers.
+        constexpr unsigned kAutoThreads = 22, kMaxParsers = 32;
+        const unsigned hw = config.threads ? (unsigned)config.threads : std::min(usable_threads(), kAutoThreads);
         const unsigned n_format = std::max(1u, std::min(4u, hw / 4));
-        const unsigned n_parse = mapped ? std::max(1u, hw > n_format + 2 ? hw - n_format - 2 : 1u) : 1u;
+        const unsigned n_parse = mapped ? std::min(kMaxParsers, std::max(1u, hw > n_format + 2 ? hw - n_format - 2 : 1u)) : 1u;
         const unsigned pinned = config.pin ? pin_near_device(device_, std::max(hw, 2u)) : 0u;
         if (mapped) {
             const char* p = fbegin;

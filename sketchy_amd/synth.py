@@ -278,6 +278,31 @@ def make_reads_torch(genome, n_reads: int, read_len=1500, err: float = 0.05, rng
     return bases.contiguous(), offsets
 
 
+def mix_reads_torch(parts, rng_seed: int = 0):
+    """One shuffled read stream out of several (bases, offsets) batches on the same device (make_reads_torch outputs): the
+    reads of all parts in a random order -- a mixed-species sample.  Returns (bases, offsets)."""
+    import torch
+    dev = parts[0][0].device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(rng_seed) * 2654435761 % (1 << 62) + 7)
+    lens = torch.cat([o[1:] - o[:-1] for _, o in parts])
+    base0, starts = 0, []
+    for b, o in parts:
+        starts.append(o[:-1] + base0)
+        base0 += int(b.numel())
+    starts = torch.cat(starts)
+    allb = torch.cat([b for b, _ in parts])
+    n = int(lens.numel())
+    perm = torch.randperm(n, generator=gen, device=dev)
+    nl = lens[perm]
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(nl, 0)
+    total = int(offsets[-1].item())
+    shift = torch.repeat_interleave(starts[perm] - offsets[:-1], nl, output_size=total)
+    bases = allb[torch.arange(total, device=dev, dtype=torch.int64) + shift]
+    return bases.contiguous(), offsets
+
+
 # ----------------------------------------------------------------------------- SURVEY.md 8(d): SNP clone tree
 _I64_MAX = (1 << 63) - 1
 

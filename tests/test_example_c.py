@@ -42,7 +42,7 @@ class _Lcg:
 
 
 @pytest.mark.gpu
-def test_the_c_example_prints_the_oracles_rows(tmp_path):
+def test_the_c_example_prints_the_oracles_rows(gpu, tmp_path):
     from oracle import oracle as orc
     n_g, g_len, s, k, n_reads, r_len = 6, 30000, 200, 16, 240, 600
     lcg = _Lcg()

@@ -226,6 +226,19 @@ def test_fast_checker_ragged_truncated_and_degenerate_inputs():
     assert (got["topk_idx"] == np.arange(3)).all()
 
 
+def test_fast_checker_reads_shorter_than_the_sketch_size():
+    """C2's shape in small: reads of 1.5 kb against sketches of s = 2000 > 1485 k-mers -- nothing is ever evicted from a read's
+    sketch, the checker takes its no-heap branch; mixed with reads longer than s (heap branch) in one stream."""
+    ref, bases, offsets = workload(300, 2000, 90, read_len=1500, genome_len=560000, rng_seed=53)
+    long_b, long_o = __import__("sketchy_amd.synth", fromlist=["x"]).make_reads(ref["genome"], 12, 5000, rng_seed=54)
+    reads = unpack_reads(bases, offsets)
+    longs = unpack_reads(long_b, long_o)
+    mixed = reads[:30] + longs[:6] + reads[30:60] + [b"", reads[60][:15], reads[61][:16]] + longs[6:] + reads[62:]
+    b, o = pack_reads(mixed)
+    got = _assert_fast_equals_stream(16, 0, 2000, ref["ref"], ref["col_len"], b, o, 3, n_threads=5, block_reads=40)
+    assert got["stats"]["pairs"] > 100
+
+
 def test_fast_checker_species_wrapper():
     from helpers import workload_species
     refs, bases, offsets = workload_species([70, 40, 25], 128, 50, read_len=400, genome_len=40000, rng_seed=47)
