@@ -409,6 +409,7 @@ ORC_EXPORT int orc_stream_mt(uint32_t k, uint64_t seed, uint32_t s, uint32_t n_g
  * Host threads split the GENOMES (not the reads): every thread replays all reads in order over its own genome range
  * and keeps that range's best rows; the ranges' rows are merged per read.
  *
+ * index_min: block dictionaries of at least this many hashes go through the bucket index (0 = default 4096; tests force 1).
  * stats (may be NULL): [0] reads with no in-range hash, [1] pairs (read, in-range hash), [2] sum over blocks of |Q|,
  * [3] blocks, [4] set bits of all member matrices.
  */
@@ -421,7 +422,7 @@ static inline int row_before(uint64_t sa, uint32_t ia, uint64_t sb, uint32_t ib)
 static int fast_block(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, uint32_t n_genomes, const uint64_t *ref,
                       const uint32_t *col_len, uint64_t max_ref, int have_ref, const uint8_t *bases, const uint64_t *offsets,
                       uint32_t r0, uint32_t r1, uint32_t top_k, uint64_t *cum, uint32_t *topk_idx, uint64_t *topk_sum,
-                      int n_threads, uint64_t mem_limit, uint64_t *stats) {
+                      int n_threads, uint64_t mem_limit, uint32_t index_min, uint64_t *stats) {
     const uint32_t nr = r1 - r0;
     uint64_t **lists = (uint64_t **)calloc(nr, sizeof(uint64_t *));
     uint32_t *lens = (uint32_t *)calloc(nr + 1, sizeof(uint32_t));
@@ -474,10 +475,10 @@ static int fast_block(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, ui
         free(lists); free(lens); free(poff); free(Q);
         uint32_t mid = r0 + nr / 2;
         int rc = fast_block(k, seed, s, stride, n_genomes, ref, col_len, max_ref, have_ref, bases, offsets, r0, mid, top_k, cum,
-                            topk_idx, topk_sum, n_threads, mem_limit, stats);
+                            topk_idx, topk_sum, n_threads, mem_limit, index_min, stats);
         if (rc) return rc;
         return fast_block(k, seed, s, stride, n_genomes, ref, col_len, max_ref, have_ref, bases, offsets, mid, r1, top_k, cum,
-                          topk_idx, topk_sum, n_threads, mem_limit, stats);
+                          topk_idx, topk_sum, n_threads, mem_limit, index_min, stats);
     }
     /* 3. pair -> index into Q */
     uint32_t *pq = (uint32_t *)malloc((npairs + 1) * sizeof(uint32_t));
@@ -488,9 +489,26 @@ static int fast_block(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, ui
             while (lo < hi) { uint64_t m = (lo + hi) / 2; if (Q[m] < h) lo = m + 1; else hi = m; }
             pq[poff[i] + j] = (uint32_t)lo;
         }
-    /* 4. member[q][word]: bit (g & 63) of word g / 64 = Q[q] in column g; a thread owns whole words */
+    /* 4. member[q][word]: bit (g & 63) of word g / 64 = Q[q] in column g; a thread owns whole words.
+     * Small Q: the two-pointer merge of :428-437, Q against the column.  Large Q (hundreds of thousands of distinct hashes: walking
+     * all of Q once per column is what a full-size batch spent its time in): the same set intersection through a bucket index over Q
+     * -- first[h >> shift] = first position of Q at or above that bucket -- so every column hash looks at the few entries of its
+     * bucket.  (tests/test_oracle.py runs both against orc_stream: the C0 / ragged cases take the merge, C1-sized ones the index.) */
     uint64_t *member = (uint64_t *)calloc(nq * W + 1, sizeof(uint64_t));
     uint64_t bits_set = 0;
+    uint32_t *first = NULL;
+    int shift = 0;
+    uint64_t nbk = 0;
+    if (nq >= index_min) {
+        nbk = 1; while (nbk < 2 * nq) nbk <<= 1;
+        while (shift < 63 && (Q[nq - 1] >> shift) >= nbk) ++shift;
+        first = (uint32_t *)malloc((nbk + 2) * sizeof(uint32_t));
+        uint64_t pos = 0;
+        for (uint64_t bkt = 0; bkt <= nbk; ++bkt) {
+            while (pos < nq && (Q[pos] >> shift) < bkt) ++pos;
+            first[bkt] = (uint32_t)pos;
+        }
+    }
 #pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) reduction(+ : bits_set)
     for (i = 0; i < (int64_t)W; ++i) {
         uint32_t g1 = (uint32_t)((i + 1) * 64 < (int64_t)n_genomes ? (i + 1) * 64 : n_genomes);
@@ -498,6 +516,15 @@ static int fast_block(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, ui
             const uint64_t *col = ref + (uint64_t)g * stride;
             uint64_t a = 0, b = 0, na = col_len[g];
             const uint64_t bit = 1ULL << (g & 63);
+            if (first) {
+                for (a = 0; a < na; ++a) {
+                    const uint64_t h = col[a], bkt = h >> shift;
+                    if (bkt >= nbk) break; /* the column ascends: everything from here on is above every query hash */
+                    for (b = first[bkt]; b < first[bkt + 1]; ++b)
+                        if (Q[b] == h) { member[b * W + (uint64_t)i] |= bit; ++bits_set; break; }
+                }
+                continue;
+            }
             while (a < na && b < nq) { /* src/sketchy.rs:428-437 */
                 if (Q[b] < col[a]) ++b;
                 else if (Q[b] > col[a]) ++a;
@@ -505,6 +532,7 @@ static int fast_block(uint32_t k, uint64_t seed, uint32_t s, uint32_t stride, ui
             }
         }
     }
+    free(first);
     /* 5. replay in read order, genomes split over threads */
     if (top_k == 0 || (!topk_idx && !topk_sum)) {
         /* table only: sum[g] += sum over q of multiplicity(q) * member[q][g] */
@@ -577,7 +605,7 @@ ORC_EXPORT int orc_stream_fast(uint32_t k, uint64_t seed, uint32_t s, uint32_t s
                                const uint64_t *ref_hashes, const uint32_t *col_len,
                                const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                                uint32_t top_k, uint64_t *cum, uint32_t *topk_idx, uint64_t *topk_sum,
-                               int n_threads, uint32_t block_reads, uint64_t *stats) {
+                               int n_threads, uint32_t block_reads, uint32_t index_min, uint64_t *stats) {
     if (top_k > n_genomes) return -1; /* the reference panics on [..top] (src/sketchy.rs:391) */
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
@@ -593,7 +621,7 @@ ORC_EXPORT int orc_stream_fast(uint32_t k, uint64_t seed, uint32_t s, uint32_t s
     for (uint32_t r0 = 0; r0 < n_reads; r0 += block_reads) {
         uint32_t r1 = n_reads - r0 > block_reads ? r0 + block_reads : n_reads;
         int rc = fast_block(k, seed, s, stride, n_genomes, ref_hashes, col_len, max_ref, have_ref, bases, offsets, r0, r1, top_k,
-                            cum, topk_idx, topk_sum, n_threads, 3ULL << 30, stats);
+                            cum, topk_idx, topk_sum, n_threads, 3ULL << 30, index_min ? index_min : 4096u, stats);
         if (rc) return rc;
     }
     return 0;

@@ -66,7 +66,7 @@ def lib():
         L.orc_stream_mt.restype = C.c_int
         L.orc_stream_fast.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_int, C.c_uint32, C.c_void_p]
+                                      C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_stream_fast.restype = C.c_int
         _LIB = L
     return _LIB
@@ -181,7 +181,7 @@ def usable_threads():
 
 
 def stream_fast(k, seed, s, ref_hashes, col_len, bases, offsets, top_k=1, cum=None, n_threads=0, block_reads=0,
-                rows=True):
+                rows=True, index_min=0):
     """orc_stream_fast: the rows and the table of stream() for a FULL-SIZE batch in seconds (blocks of reads scored
     through one distinct-hash membership matrix, genomes split over host threads).  Exact; pinned against stream() in
     tests/test_oracle.py.  rows=False: table only.  Returns dict(cum, topk_idx, topk_sum, stats)."""
@@ -198,7 +198,7 @@ def stream_fast(k, seed, s, ref_hashes, col_len, bases, offsets, top_k=1, cum=No
     bases_p = bases if len(bases) else np.zeros(1, np.uint8)
     rc = lib().orc_stream_fast(k, seed, s, stride, n_genomes, _ptr(ref_hashes), _ptr(col_len), _ptr(bases_p), _ptr(offsets),
                                n_reads, top_k, _ptr(cum), _ptr(tk_i), _ptr(tk_s), n_threads or usable_threads(),
-                               block_reads, _ptr(stats))
+                               block_reads, index_min, _ptr(stats))
     if rc != 0:
         raise ValueError("orc_stream_fast failed (top_k > n_genomes?)")
     names = ("reads_without_pairs", "pairs", "distinct_sum", "blocks", "member_bits")

@@ -164,6 +164,10 @@ def _assert_fast_equals_stream(k, seed, s, hashes, col_len, bases, offsets, top_
     np.testing.assert_array_equal(got["topk_sum"], exp["topk_sum"])
     tab = orc.stream_fast(k, seed, s, hashes, col_len, bases, offsets, top_k=top_k, cum=cum, rows=False, **kw)
     np.testing.assert_array_equal(tab["cum"], exp["cum"])
+    # the membership through the bucket index (what full-size blocks use) instead of the two-pointer merge
+    idx = orc.stream_fast(k, seed, s, hashes, col_len, bases, offsets, top_k=top_k, cum=cum, index_min=1, **kw)
+    for key in ("cum", "topk_idx", "topk_sum"):
+        np.testing.assert_array_equal(idx[key], exp[key], err_msg="bucket index: " + key)
     return got
 
 
@@ -281,9 +285,9 @@ def test_sanitizer_build_of_the_oracle_runs_clean(tmp_path):
         "for f in (L.orc_sketch_sort, L.orc_sketch_heap):\n"
         "    f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]; f.restype = C.c_uint64\n"
         "    assert f(p(bases), int(offsets[1]), 16, 0, 64, p(out)) <= 64\n"
-        "L.orc_stream_fast.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32] + [C.c_void_p] * 3 + [C.c_int, C.c_uint32, C.c_void_p]\n"
+        "L.orc_stream_fast.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_uint32] + [C.c_void_p] * 3 + [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]\n"
         "cum3 = np.zeros(30, np.uint64); ti3 = np.zeros((n, 2), np.uint32); ts3 = np.zeros((n, 2), np.uint64); st = np.zeros(8, np.uint64)\n"
-        "rc = L.orc_stream_fast(16, 0, 64, 64, 30, p(ref['ref']), p(ref['col_len']), p(bases), p(offsets), n, 2, p(cum3), p(ti3), p(ts3), 3, 7, p(st))\n"
+        "rc = L.orc_stream_fast(16, 0, 64, 64, 30, p(ref['ref']), p(ref['col_len']), p(bases), p(offsets), n, 2, p(cum3), p(ti3), p(ts3), 3, 7, 1, p(st))\n"
         "assert rc == 0 and np.array_equal(cum, cum3) and np.array_equal(ti, ti3) and np.array_equal(ts, ts3)\n"
         "print('asan ok')\n"
     )
