@@ -231,11 +231,11 @@ class SumOfSharedHashes:
 
     def stats(self):
         """Counters of the stream (skx_stream_stats): pairs / passes of the last push, dictionary size, ..."""
-        v = (C.c_uint64 * 16)()
-        _lib.check(_lib.load().skx_stream_stats(self._h, v, 16))
+        v = (C.c_uint64 * 18)()
+        _lib.check(_lib.load().skx_stream_stats(self._h, v, 18))
         names = ("last_pairs", "last_passes", "dictionary_size", "reads_block_sketcher", "passes", "passes_lean_scan",
                  "pair_capacity", "live_rank_groups", "reads_split_over_waves", "read_segments", "row_pool_grown",
-                 "passes_shared", "groups_unshared", "query_rows", "query_rows_grown", "dictionary_dense")
+                 "passes_shared", "groups_unshared", "query_rows", "query_rows_grown", "dictionary_dense", "batches_compact", "batches_full")
         return dict(zip(names, [int(x) for x in v]))
 
     def set_profiling(self, on=True):

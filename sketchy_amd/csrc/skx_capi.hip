@@ -649,6 +649,22 @@ static void release_queues(int device) {
     for (hipStream_t* h : {&q.hs1, &q.hs2, &q.hs0, &q.hs}) { if (*h) (void)hipStreamDestroy(*h); *h = nullptr; }
     q.refs = 0;
 }
+// A pass normally ranks ONE run of reads; batches enqueued back to back (up to stream_coalesce of them) share a pass (one
+// dictionary, one scan of the reference, one transpose) and are ranked one after the other from it: `subs` lists them -- their pairs sit one behind the
+// other in the pass's pair lists (p_off), each with its own pair offsets (d_poff, relative to its own first pair), reads and
+// output rows.  The scan is the only cost of a step that does not grow with the reads: n batches per scan is what a batch
+// of n times the size would give, without asking the caller for it.
+struct SubPass {
+    u32 ra = 0, rb = 0;           // reads [ra, rb) of the batch
+    u32 p_off = 0, P = 0;         // its pairs: [p_off, p_off + P) of the pass's pair lists
+    u32 p_base = 0;               // value of the batch's pair offset at read ra (non-speculative passes: absolute offsets)
+    const u32* d_poff = nullptr;  // inserted passes: the copy of the batch's pair offsets the front half left in the slot
+    u32* d_topk_idx = nullptr;
+    u64* d_topk_sum = nullptr;
+    u32* d_shared = nullptr;      // [rb-ra][n_genomes] or NULL
+    int side = 0;
+    void* slot = nullptr;         // host-fed batches: the staging slot whose rows go back to the host behind the ranking
+};
 static const int kSides = kGroupMax + 1;  // copies of the per-batch sketch outputs: the enqueued batches waiting for their shared pass + the one being sketched
                                           // (a stream uses stream_coalesce + 1 of them, allocated at first use)
 static const u32 kStagedGroupMax = 4;
@@ -703,8 +719,40 @@ struct skx_stream {
     // the split dictionary of a pass (references with a rare-hash index; all on the scan stream, one copy): the hashes the scan looks
     // for, position in Q -> row, key-table slots of the other rows, scratch of the classify kernels; d_nd = {dense rows, other rows}
     u64* d_qd = nullptr;
-    u32 *d_qrow = nullptr, *d_sslot = nullptr, *d_qinfo = nullptr, *d_qloc = nullptr, *d_cls_bsum = nullptr, *d_nd = nullptr;
+    u32 *d_qrow = nullptr, *d_sslot = nullptr, *d_qinfo = nullptr, *d_qloc = nullptr, *d_cls_bsum = nullptr;
+    u32* h_nq_sink = nullptr;  // page-locked: where the live sample of a compact chain goes (nobody reads it)
     u32* h_nd = nullptr;     // page-locked: [2 b] = |Q| of buffer set b's latest pass, [2 b + 1] = its dense rows
+    // ---- the table without the ranking, the candidates of a batch (skx_kernels.hip; scan stream unless said otherwise)
+    u32 *d_rowcnt = nullptr;     // [kPassBatchesMax][qcap] occurrences of every row among a batch's pairs
+    u32 *d_gain = nullptr;       // [kPassBatchesMax][n_pad]
+    u32 *d_candslot = nullptr;   // [kPassBatchesMax][n_pad] candidate slot of a genome (or none)
+    u32 *d_cbad = nullptr, *d_nqc = nullptr;  // [kPassBatchesMax] why a batch cannot rank compactly / mapped rare rows
+    u32 *d_spc_g0 = nullptr, *d_spc_grp = nullptr;  // Species layout of the compact problems: kCandCap slots per species
+    u32 n_pad_c = 0, n_grp_c = 0, cand_seq = 0;
+    struct PassSet {  // per buffer set: what a pass hands to its ranking chains
+        u64 *tab = nullptr;      // [kPassBatchesMax + 1][n_pad] the table as every batch begins, [n] = as the pass ends
+        u32 *cand = nullptr;     // [kPassBatchesMax][n_pad_c]
+        u64 *tabc = nullptr;     // [kPassBatchesMax][n_pad_c] the candidates' start values
+        u32 *ncand = nullptr;    // [kPassBatchesMax][n_species]
+        u32 *mode = nullptr, *any_full = nullptr, *nqc_total = nullptr;
+        u64 *mc = nullptr;       // [kPassBatchesMax][kCandRows / 64][n_pad_c] the candidates' columns of M (dense words)
+        u64 *mqc = nullptr;      // [kPassBatchesMax][n_grp_c][kCandRows][8] their group-major matrices
+        u64 *rowany_c = nullptr; // [kPassBatchesMax][n_grp_c][kCandRows / 64]
+        u32 *grp_any_c = nullptr;// [kPassBatchesMax][n_grp_c]
+        u32 *smap = nullptr;     // [kPassBatchesMax][qcap] rare row -> row of the compact matrix + 1
+        u32 *pair_qc = nullptr;  // [pcap] pairs of the compact batches in compact rows
+        u32 *nd = nullptr;       // {dense rows, other rows, first other row, rows in all} of the pass's dictionary
+        u32 *h_pub = nullptr;    // page-locked: modes, candidate counts, any_full, sequence number (cand_publish_kernel)
+    } ps[2];
+    // the ranking chains of the latest pass are queued once its candidates are known (queue_chains)
+    struct PassChains {
+        bool pending = false, ranked = false, has_cand = false, update_table = false;
+        SubPass subs[kGroupMax];
+        int n_sub = 0, b = 0, slot = 0;
+        u32 P = 0, nq_rows = 0, seq = 0;
+        u64 nq_est = 0;
+    } pc;
+    u64 batches_compact = 0, batches_full = 0;  // batches ranked on their candidates / on everything (statistic)
     bool have_split_hint = false;
     double nd_frac = 1.0;    // dense rows / |Q| of the latest pass whose dictionary is known: which scan variant a pass gets
     bool qcap_auto = false;  // no "stream_query_rows" policy: the matrices grow when a batch holds more distinct hashes (grow_query_rows)
@@ -762,6 +810,7 @@ struct skx_stream {
         unsigned char *d_live = nullptr;  // [segments of a pass][n_pad / 64] top-1 ranking: the word can hold a candidate
         u64 *d_cand_sum = nullptr;
         u32 *d_cand_idx = nullptr;
+        u64 *d_cum_sink = nullptr;  // [n_pad] the table the chain's prefix kernels write (round 5: the real one comes from the pass's gains)
         hipEvent_t ev_cum = nullptr;   // its chain's chunk_prefix is done: the table the NEXT batch starts from is complete
         hipEvent_t ev_done = nullptr;  // its chain is done
         bool ready = false;
@@ -859,7 +908,13 @@ static void stream_free(skx_stream* st) {
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1],
                     st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1],
-                    st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_nd};
+                    st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum,
+                    st->d_rowcnt, st->d_gain, st->d_candslot, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp};
+    for (auto& q : st->ps) {
+        for (void* x : {(void*)q.tab, (void*)q.cand, (void*)q.tabc, (void*)q.ncand, (void*)q.mode, (void*)q.any_full, (void*)q.nqc_total, (void*)q.mc, (void*)q.mqc,
+                        (void*)q.rowany_c, (void*)q.grp_any_c, (void*)q.smap, (void*)q.pair_qc, (void*)q.nd}) (void)hipFree(x);
+        if (q.h_pub) (void)hipHostFree(q.h_pub);
+    }
     for (auto& t : st->d_tab) (void)hipFree(t);
     for (int i = 0; i < skx_stream::kRankLanes; ++i) free_lane(st, i);
     for (int i = 1; i < skx_stream::kRankLanes; ++i)
@@ -869,6 +924,7 @@ static void stream_free(skx_stream* st) {
     if (st->h_offsets) (void)hipHostFree(st->h_offsets);
     if (st->h_nq) (void)hipHostFree(st->h_nq);
     if (st->h_nd) (void)hipHostFree(st->h_nd);
+    if (st->h_nq_sink) (void)hipHostFree(st->h_nq_sink);
     if (st->h_chk_base) (void)hipHostFree(st->h_chk_base);
     for (int i = 0; i < kSides; ++i) {
         free_side(st, i);
@@ -994,7 +1050,8 @@ static hipError_t use_rows(skx_stream* st) {
 static hipError_t alloc_lane_parts(skx_stream* st, int i) {
     skx_stream::RankLane& L = st->lane[i];
     const skx_ref* ref = st->ref;
-    const u32 n_pad = ref->n_pad, n_sp = ref->n_species, top_k = st->top_k;
+    // (sized for the larger of the two problems a chain may run on: every genome, or kCandCap candidates per species)
+    const u32 n_sp = ref->n_species, top_k = st->top_k, n_pad = std::max<u32>(ref->n_pad, n_sp * skx::kCandCap);
     const u32 n_seg_max = (st->rpass + skx::kSegLen - 1) / skx::kSegLen, n_chunk_max = (n_seg_max + 15) / 16;
     const u32 k1 = std::max<u32>(top_k, 1);
     hipError_t e;
@@ -1017,6 +1074,7 @@ static hipError_t alloc_lane_parts(skx_stream* st, int i) {
         LCHK(hipMalloc(&L.d_cand_sum, (size_t)st->rpass * st->n_cand_units * top_k * 8));
         LCHK(hipMalloc(&L.d_cand_idx, (size_t)st->rpass * st->n_cand_units * top_k * 4));
     }
+    LCHK(hipMalloc(&L.d_cum_sink, (size_t)n_pad * 8));
     LCHK(hipEventCreateWithFlags(&L.ev_cum, hipEventDisableTiming));
     LCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
 #undef LCHK
@@ -1025,7 +1083,7 @@ static hipError_t alloc_lane_parts(skx_stream* st, int i) {
 static void free_lane(skx_stream* st, int i) {
     skx_stream::RankLane& L = st->lane[i];
     void* ptrs[] = {L.d_inc, L.d_rel, L.d_live, L.d_has, L.d_lead_seg, L.d_live_ctr, L.d_csum, L.d_csum_raw, L.d_leader, L.d_lead_val,
-                    L.d_lpart_sum, L.d_lpart_idx, L.d_gmax, L.d_cand_sum, L.d_cand_idx};
+                    L.d_lpart_sum, L.d_lpart_idx, L.d_gmax, L.d_cand_sum, L.d_cand_idx, L.d_cum_sink};
     for (void* q : ptrs) (void)hipFree(q);
     if (L.ev_cum) (void)hipEventDestroy(L.ev_cum);
     if (L.ev_done) (void)hipEventDestroy(L.ev_done);
@@ -1101,7 +1159,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     u64 rp = std::min<u64>(max_reads, pass_reads);
     // candidate arrays of the ranking: per (read, rank group, row) for top_k <= 16, per (read, genome word, row) beyond
     const u32 n_sp = ref->n_species;
-    const u32 n_cand_units = (top_k >= 1 && top_k <= skx::rank_topk_fast_max()) ? (n_gw + skx::kRankWords - 1) / skx::kRankWords : n_gw;
+    const u32 n_gw_max = std::max<u32>(n_gw, n_sp * skx::kCandCap / 64);  // (... or of the candidates' compact problem, if that is larger)
+    const u32 n_cand_units = (top_k >= 1 && top_k <= skx::rank_topk_fast_max()) ? (n_gw_max + skx::kRankWords - 1) / skx::kRankWords : n_gw_max;
     if (top_k) rp = std::min<u64>(rp, std::max<u64>(skx::kSegLen, (4ull << 30) / lanes_planned / ((u64)n_cand_units * top_k * 12)));
     rp = std::max<u64>(rp, 1);
     st->rpass = (u32)rp;
@@ -1198,11 +1257,12 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipMalloc(&st->d_nq[i], 64));
         SCHK(hipMalloc(&st->d_win[i], (size_t)n_bt * 8));
     }
-    SCHK(hipMalloc(&st->d_m, (size_t)(st->qcap / 64) * n_pad * 8));
-    SCHK(hipMemset(st->d_m, 0, (size_t)(st->qcap / 64) * n_pad * 8));      // kept all-zero between passes
+    // (rows: qcap + 128 -- the rows behind the dense ones start on a word boundary, a pass of qcap hashes can reach 63 rows further)
+    SCHK(hipMalloc(&st->d_m, (size_t)(st->qcap / 64 + 2) * n_pad * 8));
+    SCHK(hipMemset(st->d_m, 0, (size_t)(st->qcap / 64 + 2) * n_pad * 8));      // kept all-zero between passes
     // (d_mint, the second word array of the split scan variant, is allocated by the first pass that wants it)
     for (int i = 0; i < 2; ++i)
-        SCHK(hipMalloc(&st->d_mq[i], (size_t)st->qcap * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
+        SCHK(hipMalloc(&st->d_mq[i], ((size_t)st->qcap + 128) * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
     st->n_cand_units = n_cand_units;
     {
         // ranking lanes: the second one only for streams that enqueue (batches back to back are what it overlaps); experiment
@@ -1252,7 +1312,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_rank_sum, (size_t)st->rank_cap * 8));
     SCHK(hipMalloc(&st->d_bsum, ((size_t)max_reads / 1024 + 2) * 4));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64) + 1) * 4));
-    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_rowany[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (st->qcap / 64) * 8));
+    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_rowany[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (st->qcap / 64 + 2) * 8));
     // (the slabs of round 3's form of the lean kernel, 252 MB at C2, 0.94 GB at C4: experiments build, when a knob asks for that form)
     if (skx::scan_lean_wants_slabs() && skx::scan_lean_applies(ref->n_bands, false, false)) {
         SCHK(hipMalloc(&st->d_hbuf, (size_t)n_bt * skx::scan_lean_words() * skx::kTileGenomes * 8));
@@ -1281,6 +1341,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     st->h_nq[2] = 1; st->h_nq[3] = 1;  // (nothing known yet: everything may hold a candidate)
     SCHK(hipHostMalloc((void**)&st->h_nd, 4 * 4, hipHostMallocCoherent));
     memset(st->h_nd, 0, 4 * 4);
+    SCHK(hipHostMalloc((void**)&st->h_nq_sink, 4 * 4, hipHostMallocCoherent));
     if (ref->d_kt_key) {  // the split dictionary of a pass (rare-hash index)
         SCHK(hipMalloc(&st->d_qd, (size_t)st->pcap * 8));
         SCHK(hipMalloc(&st->d_qrow, (size_t)st->pcap * 4));
@@ -1288,8 +1349,42 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipMalloc(&st->d_qinfo, (size_t)st->pcap * 4));
         SCHK(hipMalloc(&st->d_qloc, (size_t)st->pcap * 4));
         SCHK(hipMalloc(&st->d_cls_bsum, ((size_t)st->pcap / 1024 + 2) * 4));
-        SCHK(hipMalloc(&st->d_nd, 64));
-        SCHK(hipMemset(st->d_nd, 0, 64));
+    }
+    {
+        // the table without the ranking + the candidates of a batch (skx_kernels.hip): hs-only scratch once, what the chains read per set
+        const u32 nb = skx::kPassBatchesMax, cap = skx::kCandCap, rows_c = skx::kCandRows;
+        st->n_pad_c = n_sp * cap;
+        st->n_grp_c = st->n_pad_c / (skx::kRankWords * 64);
+        SCHK(hipMalloc(&st->d_rowcnt, (size_t)nb * ((size_t)st->qcap + 128) * 4));
+        SCHK(hipMalloc(&st->d_gain, (size_t)nb * n_pad * 4));
+        SCHK(hipMalloc(&st->d_candslot, (size_t)nb * n_pad * 4));
+        SCHK(hipMalloc(&st->d_cbad, 64));
+        SCHK(hipMalloc(&st->d_nqc, 64));
+        std::vector<u32> g0c(n_sp), grpc(st->n_grp_c);
+        for (u32 i = 0; i < n_sp; ++i) g0c[i] = i * cap;
+        for (u32 i = 0; i < st->n_grp_c; ++i) grpc[i] = i / (cap / (skx::kRankWords * 64));
+        SCHK(hipMalloc(&st->d_spc_g0, (size_t)n_sp * 4));
+        SCHK(hipMalloc(&st->d_spc_grp, (size_t)st->n_grp_c * 4));
+        SCHK(hipMemcpy(st->d_spc_g0, g0c.data(), (size_t)n_sp * 4, hipMemcpyHostToDevice));
+        SCHK(hipMemcpy(st->d_spc_grp, grpc.data(), (size_t)st->n_grp_c * 4, hipMemcpyHostToDevice));
+        for (auto& q : st->ps) {
+            SCHK(hipMalloc(&q.tab, (size_t)(nb + 1) * n_pad * 8));
+            SCHK(hipMalloc(&q.cand, (size_t)nb * st->n_pad_c * 4));
+            SCHK(hipMalloc(&q.tabc, (size_t)nb * st->n_pad_c * 8));
+            SCHK(hipMalloc(&q.ncand, (size_t)nb * n_sp * 4));
+            SCHK(hipMalloc(&q.mode, 64)); SCHK(hipMalloc(&q.any_full, 64)); SCHK(hipMalloc(&q.nqc_total, 64));
+            SCHK(hipMemset(q.any_full, 0, 64));
+            SCHK(hipMalloc(&q.mc, (size_t)nb * (rows_c / 64) * st->n_pad_c * 8));
+            SCHK(hipMalloc(&q.mqc, (size_t)nb * st->n_grp_c * rows_c * skx::kRankWords * 8));
+            SCHK(hipMalloc(&q.rowany_c, (size_t)nb * st->n_grp_c * (rows_c / 64) * 8));
+            SCHK(hipMalloc(&q.grp_any_c, (size_t)nb * st->n_grp_c * 4 + 64));
+            SCHK(hipMalloc(&q.smap, (size_t)nb * ((size_t)st->qcap + 128) * 4));
+            SCHK(hipMalloc(&q.pair_qc, (size_t)st->pcap * 4));
+            SCHK(hipMalloc(&q.nd, 64));
+            SCHK(hipMemset(q.nd, 0, 64));
+            SCHK(hipHostMalloc((void**)&q.h_pub, 32 * 4, hipHostMallocCoherent));
+            memset(q.h_pub, 0, 32 * 4);
+        }
     }
     // the zero-fills above ran on the null stream, which the (non-blocking) pipeline streams do not wait for
     SCHK(hipDeviceSynchronize());
@@ -1391,8 +1486,11 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 // "stream_query_rows" policy the matrices therefore GROW when a batch (or a group of batches that would share a pass) needs more rows:
 // everything in flight is waited for, the new arrays are allocated before the old ones are freed, at most an eighth of the free device
 // memory is taken.  Not on the steady path: a stream grows once or twice, then its groups fit.
+static int queue_chains(skx_stream* st, bool block);
+static int staged_rows(skx_stream* st, void* slot);
 static int grow_query_rows(skx_stream* st, u64 want_rows) {
     if (!st->qcap_auto) return SKX_OK;
+    SKXCHK(queue_chains(st, true));  // (the latest pass's ranking still wants the arrays that are about to be replaced)
     const skx_ref* ref = st->ref;
     const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
     const size_t mq_words = (size_t)((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords);
@@ -1400,20 +1498,23 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     for (int i = 1; i < st->n_lanes; ++i) if (st->lane[i].s) HIPCHK(hipStreamSynchronize(st->lane[i].s));
     size_t mem_free = 0, mem_total = 0;
     HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
-    const u64 per_row = (u64)n_pad / 8 * (st->d_mint ? 2 : 1) + 2 * mq_words * 8 + 2 * (u64)(n_pad / (skx::kRankWords * 64)) / 8 + 1;
+    const u64 per_row = (u64)n_pad / 8 * (st->d_mint ? 2 : 1) + 2 * mq_words * 8 + 2 * (u64)(n_pad / (skx::kRankWords * 64)) / 8 + 1 +
+                        3ull * skx::kPassBatchesMax * 4;  // (+ the per-batch row counters and the two rare-row maps)
     u64 rows = std::min<u64>(want_rows, (u64)(mem_free / 8) / per_row);
     rows = std::min<u64>(rows, st->pcap) / 64 * 64;
     if (rows <= st->qcap) return SKX_OK;  // no room (or nothing to gain): the batch is cut into passes as before
     u64 *m = nullptr, *mint = nullptr, *mq[2] = {nullptr, nullptr}, *ra[2] = {nullptr, nullptr};
-    u32* wb[2] = {nullptr, nullptr};
-    auto undo = [&]() { for (void* q : {(void*)m, (void*)mint, (void*)mq[0], (void*)mq[1], (void*)ra[0], (void*)ra[1], (void*)wb[0], (void*)wb[1]}) if (q) (void)hipFree(q); (void)hipGetLastError(); };
-    hipError_t e = hipMalloc(&m, (size_t)(rows / 64) * n_pad * 8);
-    if (e == hipSuccess && st->d_mint) e = hipMalloc(&mint, (size_t)(rows / 64) * n_pad * 8);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&mq[i], (size_t)rows * mq_words * 8);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&ra[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (rows / 64) * 8);
+    u32 *wb[2] = {nullptr, nullptr}, *cnt = nullptr, *sm[2] = {nullptr, nullptr};
+    auto undo = [&]() { for (void* q : {(void*)m, (void*)mint, (void*)mq[0], (void*)mq[1], (void*)ra[0], (void*)ra[1], (void*)wb[0], (void*)wb[1], (void*)cnt, (void*)sm[0], (void*)sm[1]}) if (q) (void)hipFree(q); (void)hipGetLastError(); };
+    hipError_t e = hipMalloc(&m, (size_t)(rows / 64 + 2) * n_pad * 8);
+    if (e == hipSuccess && st->d_mint) e = hipMalloc(&mint, (size_t)(rows / 64 + 2) * n_pad * 8);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&mq[i], ((size_t)rows + 128) * mq_words * 8);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&ra[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (rows / 64 + 2) * 8);
     for (int i = 0; i < 2 && e == hipSuccess && st->d_wb[i]; ++i) e = hipMalloc(&wb[i], ((size_t)rows / 64 + 1) * ref->n_tiles * 16);
-    if (e == hipSuccess) e = hipMemset(m, 0, (size_t)(rows / 64) * n_pad * 8);  // (M is all-zero between passes)
-    if (e == hipSuccess && mint) e = hipMemset(mint, 0, (size_t)(rows / 64) * n_pad * 8);
+    if (e == hipSuccess) e = hipMalloc(&cnt, (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 4);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&sm[i], (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 4);
+    if (e == hipSuccess) e = hipMemset(m, 0, (size_t)(rows / 64 + 2) * n_pad * 8);  // (M is all-zero between passes)
+    if (e == hipSuccess && mint) e = hipMemset(mint, 0, (size_t)(rows / 64 + 2) * n_pad * 8);
     if (e == hipSuccess) e = hipDeviceSynchronize();  // (the zero-fills ran on the null stream)
     if (e != hipSuccess) { undo(); return SKX_OK; }   // (no memory for it: as before)
     (void)hipFree(st->d_m); st->d_m = m;
@@ -1422,32 +1523,19 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
         (void)hipFree(st->d_mq[i]); st->d_mq[i] = mq[i];
         (void)hipFree(st->d_rowany[i]); st->d_rowany[i] = ra[i];
         if (wb[i]) { (void)hipFree(st->d_wb[i]); st->d_wb[i] = wb[i]; }
+        (void)hipFree(st->ps[i].smap); st->ps[i].smap = sm[i];
     }
+    (void)hipFree(st->d_rowcnt); st->d_rowcnt = cnt;
     st->qcap = (u32)rows;
     st->qrows_grown += 1;
     return SKX_OK;
 }
 
-// A pass normally ranks ONE run of reads; batches enqueued back to back (up to stream_coalesce of them) share a pass (one
-// dictionary, one scan of the reference, one transpose) and are ranked one after the other from it: `subs` lists them -- their pairs sit one behind the
-// other in the pass's pair lists (p_off), each with its own pair offsets (d_poff, relative to its own first pair), reads and
-// output rows.  The scan is the only cost of a step that does not grow with the reads: n batches per scan is what a batch
-// of n times the size would give, without asking the caller for it.
-struct SubPass {
-    u32 ra = 0, rb = 0;           // reads [ra, rb) of the batch
-    u32 p_off = 0, P = 0;         // its pairs: [p_off, p_off + P) of the pass's pair lists
-    u32 p_base = 0;               // value of the batch's pair offset at read ra (non-speculative passes: absolute offsets)
-    const u32* d_poff = nullptr;  // inserted passes: the copy of the batch's pair offsets the front half left in the slot
-    u32* d_topk_idx = nullptr;
-    u64* d_topk_sum = nullptr;
-    u32* d_shared = nullptr;      // [rb-ra][n_genomes] or NULL
-    int side = 0;
-};
 static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_table, bool inserted, u32 q_rows) {
     const skx_ref* ref = st->ref;
-    hipStream_t hs0 = st->hs0, hs = st->hs, hs2 = st->hs2;
+    hipStream_t hs0 = st->hs0, hs = st->hs;
     const skx::Species spc = ref->species();
-    const u32 n_pad = ref->n_pad, n_gw = n_pad / 64;
+    const u32 n_pad = ref->n_pad;
     u32 P = 0;
     for (int i = 0; i < n_sub; ++i) P += subs[i].P;
     const u32 ra = subs[0].ra, rb = subs[0].rb, p_base = subs[0].p_base;  // (the non-speculative gather below: single-batch passes only)
@@ -1455,7 +1543,10 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     const u32 n_bt = ref->n_bands * ref->n_tiles;
     const u32 q_bound = std::min(P, q_rows);
     if (q_bound > st->qcap) return fail(SKX_ERR_HIP, "internal: pass of %u query rows exceeds the matrices' %u", q_bound, st->qcap);
-    const u32 nq_rows = ((q_bound + 63) / 64) * 64;  // rows per group of the group-major bit matrix of this pass
+    // rows per group of the group-major bit matrix of this pass (the rows behind the dense ones start on a word boundary: up to 63 more
+    // than the dictionary has hashes)
+    const u32 nq_rows = ((q_bound + 63) / 64) * 64 + 64;
+    SKXCHK(queue_chains(st, true));             // the ranking of the pass before this one (its candidates were published long ago)
     const int b = st->buf;                      // buffer set handed from stage to stage for this pass
     st->buf ^= 1;
     const int slot = st->pslot;                 // ... and its slot of the pair lists
@@ -1464,6 +1555,9 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     u32 *d_nq = st->d_nq[b], *d_win = st->d_win[b];
     u64 *d_mq = st->d_mq[b], *d_q = st->d_q[b];
     u32* d_grp_any = st->d_grp_any[b];
+    skx_stream::PassSet& ps = st->ps[b];
+    u32* const d_nd = ps.nd;
+    const u32 qstride = st->qcap + 128;         // rows per batch of the per-row arrays (d_cnt, smap)
 
     // |Q| per pair from the latest pass whose dictionary is known to be complete (split dictionaries: also the dense share)
     const bool split_dict = ref->d_kt_key != nullptr;
@@ -1496,7 +1590,9 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         while (scan_run < 4u && (scan_run + 1 + 2.1) * per_band * 1.35 <= (double)skx::scan_run_cap()) ++scan_run;
         if (run_env > 0) scan_run = (u32)std::min(run_env, 64);
     }
-    const bool into_m = scan_run != 0 || !st->d_hbuf || skx::scan_lean_into_m();
+    // (round 5: always into M -- the pass's tables and the candidates' columns are read from it; the slab form of round 3 is gone
+    // from the experiments build too)
+    const bool into_m = true;
 
     // ---- dictionary (scan stream hs; the pair gather possibly ran on the sketch stream already).  Set b was last used two
     // passes ago: by that pass's dictionary / scan / transpose on THIS stream (Q, windows, hash set: ordered by the stream)
@@ -1524,9 +1620,11 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                               st->d_dict_ctr[b], d_q, d_nq);
         if (split_dict) {
             // dense hashes -> rows [0, nd), what the scan looks for; the others -> the rows behind, filled from the genome lists
-            skx::launch_classify(hs, d_q, d_nq, q_bound, ref->rare_index(), st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_qd, st->d_nd,
+            skx::launch_classify(hs, d_q, d_nq, q_bound, ref->rare_index(), st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_qd, d_nd,
                                  st->d_qrow, st->d_sslot, st->h_nd + 2 * b);
-            scan_q = st->d_qd; scan_nq = st->d_nd;
+            scan_q = st->d_qd; scan_nq = d_nd;
+        } else {
+            skx::launch_nd_from_nq(hs, d_nq, d_nd, st->h_nd + 2 * b);
         }
         if (st->d_hbuf && !into_m) {  // (round 3's slab form only: windows + word -> bands in one launch; also hands |Q| to the host)
             skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, scan_nq, st->d_wb[b], ref->d_lo, ref->d_hi, scan_q, split_dict ? nullptr : &st->h_nq[b]);
@@ -1535,6 +1633,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         }
         st->hint_pairs[b] = P;
     }
+    if (P == 0) HIPCHK(hipMemsetAsync(d_nd, 0, 16, hs));  // (no pairs: no dictionary ran)
     HIPCHK(hipGetLastError());
     if (!inserted) {  // this side of the sketch buffers may be overwritten once the gather above has run
         HIPCHK(hipEventRecord(st->ev_skread[st->side], hs));
@@ -1571,13 +1670,14 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         st->pairq_pending[b] = true;
         return SKX_OK;
     };
+    const u32 n_words = nq_rows / 64;
+    bool split = false, lean_used = false;
     if (P > 0) {
-        const u32 n_words = nq_rows / 64;
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
         static const int split_env = skx::knob("SKX_SCAN_SPLIT") ? atoi(skx::knob("SKX_SCAN_SPLIT")) : -1;
-        bool split = split_env >= 0 ? split_env != 0 : (nd_est * ref->rb / ref->s >= 192);
+        split = split_env >= 0 ? split_env != 0 : (nd_est * ref->rb / ref->s >= 192);
         if (split && !st->d_mint) {  // dense dictionaries only: most streams never get here
-            const size_t bytes = (size_t)(st->qcap / 64) * n_pad * 8;
+            const size_t bytes = (size_t)(st->qcap / 64 + 2) * n_pad * 8;
             if (hipMalloc(&st->d_mint, bytes) == hipSuccess) {
                 HIPCHK(hipMemsetAsync(st->d_mint, 0, bytes, hs));  // (the transpose re-zeroes what it reads)
             } else {
@@ -1590,6 +1690,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         const bool big = big_env >= 0 ? big_env != 0 : (nd_est * ref->rb / ref->s >= 900);
         const bool run_scan = scan_run != 0 && !split && !big;  // (dense dictionaries: scan_kernel's variants, as before)
         const bool lean = run_scan || skx::scan_lean_applies(ref->n_bands, split, big);
+        lean_used = lean;
         // Experiment knob SKX_SCAN_BIGSLICE=1: the lean kernel's BIG instance (slices of up to 510 entries in one pass of the
         // branch-free probe: two-byte directory, three entries per probe, nine result words, 31 KB of LDS).  A (band, tile) slice
         // holds ~3.1 x rows per band x |Q| / s entries on average -- C4: ~245 with one batch per pass, ~390 with eight, so most of
@@ -1612,43 +1713,171 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             Span sp(st, 1, hs);
             // (after the scan: its persistent form writes complete words with plain stores, these OR single bits in)
             skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad, d_mdirty, split_dict ? st->d_qrow : nullptr);
-            // the rows behind the dense ones: bits from the genome lists of the reference's rare-hash index
-            if (split_dict) skx::launch_sparse_fill(hs, st->d_sslot, st->d_nd, ref->rare_index(), st->d_m, n_pad, d_mdirty, q_bound);
         }
         SKXCHK(wait_back());
-        {
-            Span sp(st, 3, hs);
-            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nq, d_grp_any,
-                                       (lean && !into_m) ? st->d_hbuf : nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty,
-                                       nq_est, st->d_rowany[b]);
-        }
     }
     if (P == 0) SKXCHK(wait_back());
+
+    // ---- the table as every batch of the pass begins (and as the pass ends), and the genomes each batch's ranking has to look at
+    // (skx_kernels.hip, "the table without the ranking").  All on the scan stream, before the transpose re-zeroes M.
+    bool ranked = false;
+    for (int i = 0; i < n_sub; ++i) ranked = ranked || (st->top_k && subs[i].d_topk_idx && subs[i].d_topk_sum);
+    const u32* only_if = nullptr;  // device flag: does any batch of the pass rank on the FULL matrix?  (NULL: yes, unconditionally)
+    u32 seq = 0;
+    if (update_table) {
+        Span sp(st, 4, hs);
+        const u32 n_sp = ref->n_species, cap = skx::kCandCap, rows_c = skx::kCandRows;
+        skx::PassBatches pbt;
+        pbt.n = (u32)n_sub;
+        for (int i = 0; i < n_sub; ++i) pbt.p_off[i] = subs[i].p_off;
+        pbt.p_off[n_sub] = P;
+        const u64* m_int = split ? st->d_mint : nullptr;
+        HIPCHK(hipMemsetAsync(st->d_gain, 0, (size_t)n_sub * n_pad * 4, hs));
+        if (P > 0) {
+            HIPCHK(hipMemset2DAsync(st->d_rowcnt, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
+            skx::launch_pass_hist(hs, d_pair_q, pbt, st->d_rowcnt, qstride);
+            const skx::RareIndex ri = ref->rare_index();
+            skx::launch_pass_gain(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain,
+                                  split_dict ? st->d_sslot : nullptr, split_dict ? &ri : nullptr);
+        }
+        skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (u32)n_sub, n_pad, ps.tab);
+        st->d_cum = ps.tab + (size_t)n_sub * n_pad;  // (readers: the next pass on this stream; everybody else behind ev_front / a flush)
+        // candidates.  A batch that wants the per-read x per-genome debug matrix ranks on everything; so does every batch when the
+        // experiment knob SKX_CAND=0 says so
+        static const int cand_env = skx::knob("SKX_CAND") ? atoi(skx::knob("SKX_CAND")) : 1;
+        u32 force_full = cand_env ? 0u : 0xFFu;
+        for (int i = 0; i < n_sub; ++i) if (subs[i].d_shared) force_full |= 1u << i;
+        HIPCHK(hipMemsetAsync(st->d_cbad, 0, 64, hs));
+        HIPCHK(hipMemsetAsync(st->d_nqc, 0, 64, hs));
+        if (ranked) {
+            skx::launch_cand_select(hs, ps.tab, n_pad, spc, (u32)n_sub, st->top_k, cap, ps.cand, st->d_candslot, ps.tabc, ps.ncand, st->d_cbad);
+            HIPCHK(hipMemsetAsync(ps.grp_any_c, 0, (size_t)n_sub * st->n_grp_c * 4, hs));
+            if (split_dict && P > 0) {
+                HIPCHK(hipMemsetAsync(ps.mqc, 0, (size_t)n_sub * st->n_grp_c * rows_c * skx::kRankWords * 8, hs));
+                HIPCHK(hipMemsetAsync(ps.rowany_c, 0, (size_t)n_sub * st->n_grp_c * (rows_c / 64) * 8, hs));
+                HIPCHK(hipMemset2DAsync(ps.smap, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
+                skx::launch_cand_sparse(hs, st->d_sslot, d_nd, q_bound, ref->rare_index(), st->d_candslot, n_pad, st->d_cbad, (u32)n_sub, st->d_nqc,
+                                        ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords, rows_c, ps.rowany_c,
+                                        st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c);
+            }
+        } else {
+            HIPCHK(hipMemsetAsync(ps.ncand, 0, (size_t)n_sub * n_sp * 4, hs));
+        }
+        seq = ++st->cand_seq;
+        skx::launch_cand_publish(hs, st->d_cbad, force_full, ps.ncand, st->d_nqc, d_nd, (u32)n_sub, n_sp, rows_c, ps.mode, ps.any_full,
+                                 ps.nqc_total, ps.h_pub, seq);
+        if (ranked && P > 0)
+            skx::launch_cand_gather_m(hs, st->d_m, m_int, n_pad, d_nd, q_bound, ps.cand, st->n_pad_c, st->d_cbad, (u32)n_sub, ps.mc, rows_c / 64);
+        only_if = ps.any_full;
+        HIPCHK(hipGetLastError());
+    }
+    if (P > 0) {
+        if (split_dict) {
+            Span sp(st, 1, hs);
+            // the rows behind the dense ones of the FULL matrix: bits from the genome lists of the reference's rare-hash index
+            skx::launch_sparse_fill(hs, st->d_sslot, d_nd, ref->rare_index(), st->d_m, n_pad, d_mdirty, q_bound, only_if);
+        }
+        {
+            Span sp(st, 3, hs);
+            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nd + 3, d_grp_any,
+                                       nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, nq_est, st->d_rowany[b], only_if);
+            if (only_if) skx::launch_m_clear(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, d_nd, only_if);
+        }
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->ev_front[b], hs));
     st->front_pending[b] = true;
+    (void)lean_used;
 
-    // ---- back half: the batches of the pass are ranked in order, consecutive ones on alternating LANES (skx_stream::RankLane):
-    // a chain counts its per-segment increments and chunk sums (they need this pass's Mq only), waits for the table the chain
-    // before it leaves behind its chunk_prefix, then: running table, bounds, per-read rows.  Overlaps the next pass's front half.
-    bool lane_used[skx_stream::kRankLanes] = {};
+    // ---- the ranking chains are queued by queue_chains, once the pass's candidates are known
+    skx_stream::PassChains& pc = st->pc;
+    pc.pending = true; pc.ranked = ranked; pc.has_cand = update_table;
+    pc.n_sub = n_sub; pc.b = b; pc.slot = slot; pc.P = P; pc.nq_rows = nq_rows; pc.seq = seq; pc.nq_est = nq_est;
+    for (int i = 0; i < n_sub; ++i) pc.subs[i] = subs[i];
+    pc.update_table = update_table;
     SKX_MARK("pass: scan + transpose queued", 0);
+    return SKX_OK;
+}
+
+// The back half of a pass: its batches are ranked in order, consecutive ones on alternating LANES (skx_stream::RankLane).  Every
+// chain starts from the table the pass's front half computed for it (ps.tab[i]: no chain waits for another one since round 5) and
+// runs either on everything (Mq, 79 rank groups at C2) or -- when the batch's candidates fit -- on the compact problem: the
+// candidates' columns (two rank groups per species), the same kernels, the slots mapped back to genome indices at the end.
+// block: wait for the pass's published candidates (else return when they are not there yet).
+static int queue_chains(skx_stream* st, bool block) {
+    skx_stream::PassChains& pc = st->pc;
+    if (!pc.pending) return SKX_OK;
+    const skx_ref* ref = st->ref;
+    const int b = pc.b, slot = pc.slot, n_sub = pc.n_sub;
+    skx_stream::PassSet& ps = st->ps[b];
+    u32 mode[kGroupMax] = {};
+    if (pc.has_cand) {
+        volatile u32* hp = ps.h_pub;
+        if (hp[2 * skx::kPassBatchesMax + 1] != pc.seq) {
+            if (!block) return SKX_OK;
+            SKX_T0();
+            for (u64 spins = 0; hp[2 * skx::kPassBatchesMax + 1] != pc.seq; ++spins)
+                if ((spins & 0xFFFFu) == 0xFFFFu) {  // (look at the stream now and then so a fault cannot hang the caller)
+                    const hipError_t e = hipStreamQuery(st->hs);
+                    if (e != hipSuccess && e != hipErrorNotReady) return fail(SKX_ERR_HIP, "the scan stream failed: %s", hipGetErrorString(e));
+                    if (e == hipSuccess && hp[2 * skx::kPassBatchesMax + 1] != pc.seq) {
+                        (void)hipGetLastError();
+                        if (hp[2 * skx::kPassBatchesMax + 1] != pc.seq) return fail(SKX_ERR_HIP, "internal: the pass's candidates were never published");
+                    }
+                    (void)hipGetLastError();
+                }
+            SKX_ACC(wait);
+        }
+        for (int i = 0; i < n_sub; ++i) mode[i] = hp[i];
+    }
+    pc.pending = false;
+    hipStream_t hs2 = st->hs2;
+    const skx::Species spc = ref->species();
+    const u32 n_pad = ref->n_pad, n_sp = ref->n_species;
+    const u32 nq_rows = pc.nq_rows, P = pc.P;
+    const bool update_table = pc.update_table;
+    u32 *d_pair_r = st->d_pair_r[slot], *d_pair_q = st->d_pair_q[b];
+    u64* d_mq = st->d_mq[b];
+    u32* d_grp_any = st->d_grp_any[b];
+    u32* const d_nq_rows = ps.nd + 3;  // rows of the pass's matrix (device)
+    bool lane_used[skx_stream::kRankLanes] = {};
     for (int si = 0; si < n_sub; ++si) {
     SKX_MARK("rank: begin sub", si);
-    const SubPass& sb = subs[si];
+    const SubPass& sb = pc.subs[si];
     // (only the batches of a SHARED pass take turns: a pass of one batch has the next pass's scan and sketch beside its chain
     // already -- measured with one pass per batch, option stream_coalesce = 1: 83 M reads/s on one lane, 67 M on two)
     const int li = (update_table && n_sub > 1) ? (int)(st->rank_seq % (u64)st->n_lanes) : 0;
     skx_stream::RankLane& L = st->lane[li];
     hipStream_t ls = L.s;
-    if (!lane_used[li]) { HIPCHK(hipStreamWaitEvent(ls, st->ev_front[b], 0)); lane_used[li] = true; }  // the pass's Mq
+    if (!lane_used[li]) { HIPCHK(hipStreamWaitEvent(ls, st->ev_front[b], 0)); lane_used[li] = true; }  // the pass's matrices and tables
     const u32 n_reads = sb.rb - sb.ra, sub_base = sb.p_base;
-    const u32 *sub_pair_q = d_pair_q + sb.p_off, *sub_pair_r = d_pair_r + sb.p_off, *sub_poff = sb.d_poff;
     u32* const d_topk_idx = sb.d_topk_idx;
     u64* const d_topk_sum = sb.d_topk_sum;
     const u32 out_r0 = sb.ra;
     const u32 n_seg = (n_reads + skx::kSegLen - 1) / skx::kSegLen;
     const bool ranked = st->top_k && d_topk_idx && d_topk_sum;
+    const bool compact = update_table && ranked && mode[si] == 1u;
+    // what the chain works on: everything, or the batch's candidates
+    const u32 c_pad = compact ? st->n_pad_c : n_pad, c_gw = c_pad / 64, c_rows = compact ? skx::kCandRows : nq_rows;
+    const skx::Species c_spc = compact ? skx::Species{st->d_spc_g0, ps.ncand + (size_t)si * n_sp, st->d_spc_grp, n_sp} : spc;
+    const u64* c_mq = compact ? ps.mqc + (size_t)si * st->n_grp_c * skx::kCandRows * skx::kRankWords : d_mq;
+    u32* c_grp_any = compact ? ps.grp_any_c + (size_t)si * st->n_grp_c : d_grp_any;
+    const u64* c_rowany = compact ? ps.rowany_c + (size_t)si * st->n_grp_c * (skx::kCandRows / 64) : (P > 0 ? st->d_rowany[b] : nullptr);
+    const u32* c_nq = compact ? ps.nqc_total + si : d_nq_rows;
+    const u64* const cum_in = update_table ? (compact ? ps.tabc + (size_t)si * st->n_pad_c : ps.tab + (size_t)si * n_pad) : st->d_cum;
+    const u32 *sub_pair_q = (compact ? ps.pair_qc : d_pair_q) + sb.p_off, *sub_pair_r = d_pair_r + sb.p_off, *sub_poff = sb.d_poff;
+    if (update_table && ranked) { if (compact) st->batches_compact += 1; else st->batches_full += 1; }
+    if (compact) {
+        Span sp(st, 3, ls);
+        // the candidates' dense rows: 64 x 64 bit transposes of their columns of M; the pairs in rows of the compact matrix
+        if (P > 0)
+            skx::launch_transpose_bits(ls, ps.mc + (size_t)si * (skx::kCandRows / 64) * st->n_pad_c, nullptr, st->n_pad_c, skx::kCandRows / 64,
+                                       const_cast<u64*>(c_mq), ps.nd, c_grp_any, nullptr, nullptr, nullptr, 0, nullptr, pc.nq_est,
+                                       const_cast<u64*>(c_rowany));
+        skx::launch_cand_pair_rows(ls, d_pair_q + sb.p_off, sb.P, ps.nd, ps.smap + (size_t)si * ((size_t)st->qcap + 128), skx::kCandRows,
+                                   ps.pair_qc + sb.p_off);
+        HIPCHK(hipGetLastError());
+    }
     const u32 prune_k = (ranked && st->top_k <= skx::rank_topk_fast_max()) ? st->top_k : 0u;
     // Pruned rankings count in two levels: the chunk sums of EVERYTHING first (one workgroup per (rank group, chunk of 1024
     // reads): a third less work than per segment), then -- once the chunk-level bounds are known -- the per-segment increments
@@ -1662,81 +1891,77 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     const u32 live_now = h_live[0], tested_now = h_live[1];
     static const u32 live_pct_env = skx::knob("SKX_LIVE_PCT") ? (u32)atoi(skx::knob("SKX_LIVE_PCT")) : 33u;  // experiment knob
     const bool mostly_dead = tested_now != 0 && (u64)live_now * 100 < (u64)tested_now * live_pct_env;
-    const bool two_level = prune_k != 0 && (two_level_env >= 0 ? two_level_env != 0 : mostly_dead);
-    const u64* rowany_b = P > 0 ? st->d_rowany[b] : nullptr;
+    // (a compact chain has two rank groups: one level)
+    const bool two_level = !compact && prune_k != 0 && (two_level_env >= 0 ? two_level_env != 0 : mostly_dead);
     u32 *d_inc = L.d_inc, *d_csum_raw = L.d_csum_raw;
-    if (update_table) {
+    if (update_table && ranked) {
         Span sp(st, 4, ls);
         // (the chunk sums are accumulated by seg_sum's workgroups: four atomic adds per chunk and genome)
-        HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * n_pad * 4, ls));
+        HIPCHK(hipMemsetAsync(d_csum_raw, 0, (size_t)((n_seg + 15) / 16) * c_pad * 4, ls));
         static const int ablate_rank = skx::knob("SKX_ABLATE_RANK") ? atoi(skx::knob("SKX_ABLATE_RANK")) : 0;  // measurement aid (results invalid): 1 = no counts at all
         if (ablate_rank >= 1) {
         } else if (two_level)
-            skx::launch_chunk_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, d_grp_any, d_csum_raw, rowany_b, d_nq, spc);
+            skx::launch_chunk_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, c_mq, c_pad, c_rows, c_grp_any, d_csum_raw, c_rowany, c_nq, c_spc);
         else
-            skx::launch_seg_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
-                                d_csum_raw, rowany_b, d_nq, spc);
+            skx::launch_seg_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, c_mq, c_pad, c_rows, d_inc, c_grp_any,
+                                d_csum_raw, c_rowany, c_nq, c_spc);
         HIPCHK(hipGetLastError());
     }
     SKX_MARK("rank: seg_sum queued", si);
     static const int ablate_rank2 = skx::knob("SKX_ABLATE_RANK") ? atoi(skx::knob("SKX_ABLATE_RANK")) : 0;  // 2 = no ranking stage at all
-    if (update_table && ablate_rank2 != 2) {
+    if (update_table && ranked && ablate_rank2 != 2) {
         Span sp(st, 4, ls);
-        // the table this batch starts from: complete once the chain before it (usually on the other lane) is past its chunk_prefix
-        if (st->cum_writer && st->cum_writer != &L) HIPCHK(hipStreamWaitEvent(ls, st->cum_writer->ev_cum, 0));
-        const u64* const cum_in = st->d_tab[st->tab_cur];
-        const int tab_next = (st->tab_cur + 1) % (st->n_lanes + 1);
-        u64* const cum_out = st->d_tab[tab_next];
+        u64* const cum_out = L.d_cum_sink;  // (the chain's own sum of the table: nobody reads it -- the pass's front half has the tables)
         // the top-1 kernel keeps (value relative to the leader) in 23 bits of a 32-bit key: at most 2 x 64 x s + 1 per
         // segment, so sketch sizes from 2^15 on take the 64-bit-key kernel (with k = 1) instead
         static const bool top1_wide_env = skx::knob("SKX_TOP1_WIDE") != nullptr;  // test knob: force the 64-bit-key kernel
         const bool top1_fast = st->top_k == 1 && ref->s_read < (1u << 15) && !top1_wide_env;
         static const bool live_env = !skx::knob("SKX_RANK_LIVE") || atoi(skx::knob("SKX_RANK_LIVE")) != 0;  // test knob
         const bool topk_fast = !top1_fast && st->top_k && st->top_k <= skx::rank_topk_fast_max();
-        unsigned char* d_live = ((top1_fast || topk_fast) && ranked && live_env) ? L.d_live : nullptr;  // (the pruned kernels look at the flags)
-        // (ev_cum goes out right behind chunk_prefix, the first kernel of the prefix stage: the next batch's chain only needs the table)
+        unsigned char* d_live = ((top1_fast || topk_fast) && live_env) ? L.d_live : nullptr;  // (the pruned kernels look at the flags)
         if (two_level) {
-            skx::launch_seg_prefix(ls, d_inc, n_seg, n_pad, spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
-                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, d_grp_any, d_live, L.d_lead_seg, 1, nullptr, L.ev_cum);
-            skx::launch_seg_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows, d_inc, d_grp_any,
-                                nullptr, rowany_b, d_nq, spc, L.d_gmax, L.d_lead_val);
-            skx::launch_seg_prefix(ls, d_inc, n_seg, n_pad, spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
-                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, d_grp_any, d_live, L.d_lead_seg, 2, L.d_live_ctr);
+            skx::launch_seg_prefix(ls, d_inc, n_seg, c_pad, c_spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
+                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, c_grp_any, d_live, L.d_lead_seg, 1, nullptr, nullptr);
+            skx::launch_seg_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, c_mq, c_pad, c_rows, d_inc, c_grp_any,
+                                nullptr, c_rowany, c_nq, c_spc, L.d_gmax, L.d_lead_val);
+            skx::launch_seg_prefix(ls, d_inc, n_seg, c_pad, c_spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
+                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, c_grp_any, d_live, L.d_lead_seg, 2, L.d_live_ctr);
         } else {
-            skx::launch_seg_prefix(ls, d_inc, n_seg, n_pad, spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
-                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, d_grp_any, d_live, L.d_lead_seg, 0,
-                                   L.d_live_ctr, L.ev_cum);
+            skx::launch_seg_prefix(ls, d_inc, n_seg, c_pad, c_spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
+                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, c_grp_any, d_live, L.d_lead_seg, 0,
+                                   L.d_live_ctr, nullptr);
         }
         HIPCHK(hipGetLastError());
         SKX_MARK("rank: prefixes queued", si);
-        // (the live sample reaches the host through a kernel that also re-arms the counters -- NOT hipMemcpyAsync / hipMemsetAsync)
-        if (prune_k) skx::launch_store_host_words(ls, st->h_nq + 2, L.d_live_ctr, 2);
-        st->tab_cur = tab_next;
-        st->d_cum = cum_out;  // (later work ordered behind this lane's ev_cum -- or behind the pass, on hs2 -- sees the new table)
-        st->cum_writer = &L;
+        // (the live sample reaches the host through a kernel that also re-arms the counters -- NOT hipMemcpyAsync / hipMemsetAsync;
+        // a compact chain's sample says nothing about the full problem and is only re-armed)
+        if (prune_k) skx::launch_store_host_words(ls, compact ? st->h_nq_sink : st->h_nq + 2, L.d_live_ctr, 2);
         st->rank_seq += 1;
-        if (top1_fast && d_topk_idx && d_topk_sum) {
-            skx::launch_rank_seg_top1(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows,
-                                      spc, cum_in, L.d_rel, L.d_cand_sum, L.d_cand_idx, d_inc,
-                                      L.d_leader, L.d_gmax, L.d_lead_val, d_grp_any, d_live, L.d_has, rowany_b, d_nq);
-            skx::launch_top1_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, d_topk_idx, d_topk_sum, out_r0, spc, L.d_has,
-                                   (n_gw + skx::kRankWords - 1) / skx::kRankWords);
-        } else if (st->top_k && st->top_k <= skx::rank_topk_fast_max() && d_topk_idx && d_topk_sum) {
-            const u32 n_grp = (n_gw + skx::kRankWords - 1) / skx::kRankWords;
-            skx::launch_rank_seg_topk(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, d_mq, n_pad, nq_rows, spc,
+        if (top1_fast) {
+            skx::launch_rank_seg_top1(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, c_mq, c_pad, c_rows,
+                                      c_spc, cum_in, L.d_rel, L.d_cand_sum, L.d_cand_idx, d_inc,
+                                      L.d_leader, L.d_gmax, L.d_lead_val, c_grp_any, d_live, L.d_has, c_rowany, c_nq);
+            skx::launch_top1_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, d_topk_idx, d_topk_sum, out_r0, c_spc, L.d_has,
+                                   (c_gw + skx::kRankWords - 1) / skx::kRankWords);
+        } else if (st->top_k <= skx::rank_topk_fast_max()) {
+            const u32 n_grp = (c_gw + skx::kRankWords - 1) / skx::kRankWords;
+            skx::launch_rank_seg_topk(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, c_mq, c_pad, c_rows, c_spc,
                                       cum_in, L.d_rel, st->top_k, L.d_cand_sum, L.d_cand_idx, d_inc, L.d_leader,
-                                      L.d_gmax, L.d_lead_val, d_grp_any, d_live, L.d_has);
-            skx::launch_topk_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, out_r0, spc,
+                                      L.d_gmax, L.d_lead_val, c_grp_any, d_live, L.d_has);
+            skx::launch_topk_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, n_grp, 1, st->top_k, d_topk_idx, d_topk_sum, out_r0, c_spc,
                                    L.d_has);
-        } else if (st->top_k && d_topk_idx && d_topk_sum) {
-            skx::launch_rank_seg(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, skx::kSegLen, d_mq, n_pad, nq_rows,
-                                 spc, cum_in, L.d_rel, st->top_k, L.d_cand_sum, L.d_cand_idx, d_grp_any);
-            skx::launch_topk_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, n_gw, skx::kRankWords, st->top_k, d_topk_idx,
-                                   d_topk_sum, out_r0, spc, nullptr);
+        } else {
+            skx::launch_rank_seg(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, skx::kSegLen, c_mq, c_pad, c_rows,
+                                 c_spc, cum_in, L.d_rel, st->top_k, L.d_cand_sum, L.d_cand_idx, c_grp_any);
+            skx::launch_topk_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, c_gw, skx::kRankWords, st->top_k, d_topk_idx,
+                                   d_topk_sum, out_r0, c_spc, nullptr);
         }
+        if (compact)  // candidate slots -> genome indices (local to the species)
+            skx::launch_cand_rows_back(ls, d_topk_idx + (size_t)out_r0 * n_sp * st->top_k, n_reads, n_sp, st->top_k,
+                                       ps.cand + (size_t)si * st->n_pad_c, skx::kCandCap, ref->d_sp_g0);
     }
     if (sb.d_shared)
-        skx::launch_shared_debug(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, d_mq, nq_rows, ref->n_genomes, ref->d_real2pad, sb.d_shared, 0);
+        skx::launch_shared_debug(ls, d_pair_q + sb.p_off, sub_poff, sub_base, 0, n_reads, d_mq, nq_rows, ref->n_genomes, ref->d_real2pad, sb.d_shared, 0);
     HIPCHK(hipGetLastError());
     SKX_MARK("rank: end sub", si);
     }  // sub-passes
@@ -1752,12 +1977,20 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     st->back_pending[b] = true;
     HIPCHK(hipEventRecord(st->ev_pslot[slot], hs2));
     st->pslot_pending[slot] = true;
-    return SKX_OK;
+    // host-fed batches: their rows go back to the host behind the ranking
+    int rc = SKX_OK;
+    for (int si = 0; si < n_sub; ++si) {
+        const int r2 = staged_rows(st, pc.subs[si].slot);
+        if (rc == SKX_OK && r2 != SKX_OK) rc = r2;
+    }
+    return rc;
 }
 
 static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_topk_idx, u64* d_topk_sum,
-                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table, bool inserted = false, u32 q_rows = 0xFFFFFFFFu) {
+                    u32* d_shared /* [rb-ra][n_genomes] or NULL */, bool update_table, bool inserted = false, u32 q_rows = 0xFFFFFFFFu,
+                    void* slot = nullptr) {
     SubPass sb;
+    sb.slot = slot;
     sb.ra = ra; sb.rb = rb; sb.p_off = 0; sb.P = P; sb.p_base = p_base; sb.d_topk_idx = d_topk_idx; sb.d_topk_sum = d_topk_sum;
     sb.d_shared = d_shared; sb.side = st->side;
     sb.d_poff = st->d_poff_pass[st->pslot];  // (inserted passes: the front half's copy; else run_pass_multi fills the slot itself)
@@ -2118,10 +2351,12 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
             if (d_shared) { (void)hipFree(d_shared); d_shared = nullptr; }
             HIPCHK(hipMalloc(&d_shared, (size_t)(rb - ra) * ref->n_genomes * 4));
         }
-        SKXCHK(run_pass(st, ra, rb, p_base, P, pb.d_topk_idx, pb.d_topk_sum, d_shared, true, inserted, inserted ? q_rows : 0xFFFFFFFFu));
+        SKXCHK(run_pass(st, ra, rb, p_base, P, pb.d_topk_idx, pb.d_topk_sum, d_shared, true, inserted, inserted ? q_rows : 0xFFFFFFFFu,
+                        rb == n_reads ? pb.slot : nullptr));
         inserted = false;
         st->last_passes += 1;
         if (pb.h_shared) {
+            SKXCHK(queue_chains(st, true));  // (the debug matrix comes out of the pass's ranking chain)
             HIPCHK(hipMemcpyAsync(pb.h_shared + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
                                   hipMemcpyDeviceToHost, st->hs2));
             HIPCHK(hipStreamSynchronize(st->hs2));
@@ -2223,6 +2458,7 @@ static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch
         subs[i].d_topk_idx = g[i].d_topk_idx; subs[i].d_topk_sum = g[i].d_topk_sum;
         subs[i].p_off = p_off; subs[i].P = P[i];
         subs[i].d_poff = st->d_poff_pass[g[0].spec_slot] + (size_t)i * ((size_t)st->rpass + 2);
+        subs[i].slot = g[i].slot;
         p_off += P[i];
     }
     st->last_pairs = pairs; st->last_passes = 1; st->shared_passes += 1;
@@ -2250,15 +2486,18 @@ static int pending_back(skx_stream* st, PendingBatch* younger) {
     int done = 0;
     int rc = batch_back_group(st, g, n, younger, &done);
     const std::string msg = rc != SKX_OK ? g_err : std::string();
-    for (int i = 0; i < done; ++i) {
-        const int r2 = staged_rows(st, g[i].slot);
-        if (rc == SKX_OK && r2 != SKX_OK) rc = r2;
-    }
+    // (host-fed batches: the rows of the scored ones go back to the host behind their ranking chains -- queue_chains)
     for (int i = done; i < n; ++i) staged_drop(g[i].slot);
     if (!msg.empty()) g_err = msg;
     return rc;
 }
-static int flush_pending(skx_stream* st) { return pending_back(st, nullptr); }
+static int flush_pending(skx_stream* st) {
+    const int rc = pending_back(st, nullptr);
+    const std::string msg = rc != SKX_OK ? g_err : std::string();
+    const int rc2 = queue_chains(st, true);  // (the ranking of the last pass: waits for its candidates)
+    if (rc != SKX_OK) { g_err = msg; return rc; }
+    return rc2;
+}
 // sketch + score + rank a batch already resident on the device, both halves (synchronous entry points).
 // h_shared / h_sketches / h_sketch_len: optional HOST outputs (parity/debug).
 static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_offsets, u32 n_reads, u64 n_bases, u32* d_topk_idx,
@@ -2285,6 +2524,7 @@ static int enqueue_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     // (host-fed batches: every batch waiting for its group holds a staging slot -- bases, offsets, rows -- so groups stay at four)
     nw.max_group = slot ? std::min<u32>(st->coalesce, kStagedGroupMax) : st->coalesce;
     SKX_MARK("enqueue: begin", st->n_pend);
+    SKXCHK(queue_chains(st, false));  // (the latest pass's ranking, if its candidates have been published by now)
     {
         const int rc_front = batch_front(st, nw);
         if (rc_front != SKX_OK) { staged_drop(slot); return rc_front; }  // (skx_stream_wait on its ticket then fails instead of handing out stale rows)
@@ -2330,6 +2570,7 @@ SKX_API int skx_stream_push(skx_stream* st, const uint8_t* bases, const uint64_t
     if (n_bases) HIPCHK(hipMemcpyAsync(st->d_bases, bases + byte0, n_bytes, hipMemcpyHostToDevice, hs));
     SKXCHK(process_batch(st, st->d_bases, st->d_offsets, n_reads, n_bases, st->d_topk_idx, st->d_topk_sum,
                          per_read_shared, reinterpret_cast<u64*>(sketches), sketch_len));
+    SKXCHK(queue_chains(st, true));    // the ranking of the batch's last pass (waits for its candidates)
     HIPCHK(hipStreamSynchronize(hs));  // sketch copies (first stream)
     const size_t rows = (size_t)n_reads * st->ref->n_species * st->top_k;
     if (topk_idx) HIPCHK(hipMemcpyAsync(topk_idx, st->d_topk_idx, rows * 4, hipMemcpyDeviceToHost, st->hs2));
@@ -2400,6 +2641,9 @@ static int staged_finish(skx_stream* st, skx_stream::Staged& sl) {
     SKXCHK(staged_process(st, sl));
     for (int i = 0; i < st->n_pend; ++i)
         if (st->pend[i].slot == &sl) { SKXCHK(flush_pending(st)); break; }
+    if (st->pc.pending)  // (its pass is queued, its ranking -- and the copy of its rows -- not yet)
+        for (int i = 0; i < st->pc.n_sub; ++i)
+            if (st->pc.subs[i].slot == &sl) { SKXCHK(queue_chains(st, true)); break; }
     if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
     return SKX_OK;
 }
@@ -2692,7 +2936,8 @@ SKX_API int skx_stream_stats(skx_stream* st, uint64_t* out, uint32_t n_out) {
     const uint64_t v[SKX_N_STATS] = {st->last_pairs, st->last_passes, (uint64_t)(st->ref->d_kt_key ? st->h_nd[2 * (st->buf ^ 1)] : st->h_nq[st->buf ^ 1]), st->reads_big,
                                      st->total_passes, st->lean_passes, st->pcap, live, st->reads_split, st->segs_split, st->pool_grown,
                                      st->shared_passes, st->groups_unshared, st->qcap, st->qrows_grown,
-                                     (uint64_t)(st->ref->d_kt_key ? st->h_nd[2 * (st->buf ^ 1) + 1] : st->h_nq[st->buf ^ 1])};
+                                     (uint64_t)(st->ref->d_kt_key ? st->h_nd[2 * (st->buf ^ 1) + 1] : st->h_nq[st->buf ^ 1]),
+                                     st->batches_compact, st->batches_full};
     for (uint32_t i = 0; i < n_out; ++i) out[i] = i < SKX_N_STATS ? v[i] : 0;
     return SKX_OK;
 }
@@ -2803,6 +3048,7 @@ SKX_API int skx_common_hashes(const skx_ref* ref, const uint64_t* query, const u
                 HIPCHK(hipMemsetAsync(d_shared, 0, (size_t)(rb - ra) * ref->n_genomes * 4, st->hs2));
             } else {
                 SKXCHK(run_pass(st, ra, rb, p_base, P, nullptr, nullptr, d_shared, false));
+                SKXCHK(queue_chains(st, true));
             }
             HIPCHK(hipMemcpyAsync(common + (size_t)ra * ref->n_genomes, d_shared, (size_t)(rb - ra) * ref->n_genomes * 4,
                                   hipMemcpyDeviceToHost, st->hs2));

@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(256) void rare_fill_kernel(const u64* __restrict__ 
 // ---- a pass's dictionary, split.  classify_a: look every query hash up (qinfo[q] = its slot | kSlotNone; dense: bit 31 of qloc[q]),
 // block-local exclusive count of the dense ones; classify_b: one block scans the block totals, publishes nd / ns;
 // classify_c: Qd (the dense hashes, still ascending), qrow[q] = the hash's row of the bit matrix (dense rows first, in Qd order,
-// then the others in Q order), sslot[row - nd] = key-table slot of a rare hash.
+// then -- from the next multiple of 64 on -- the others in Q order), sslot[row - nd64] = key-table slot of a rare hash.
 __global__ __launch_bounds__(256) void classify_a_kernel(const u64* __restrict__ q, const u32* __restrict__ n_q, RareIndex ri,
                                                          u32* __restrict__ qinfo, u32* __restrict__ qloc, u32* __restrict__ bsum) {
     __builtin_amdgcn_s_setprio(3);
@@ -1685,8 +1685,8 @@ __global__ __launch_bounds__(1024) void classify_b_kernel(u32* __restrict__ bsum
     u32 run = part[t] - mine;
     for (u32 i = 0; i < per; ++i) { const u32 b = t * per + i; if (b < nb) { const u32 v = bsum[b]; bsum[b] = run; run += v; } }
     if (t == 1023u) {
-        const u32 nd = part[t];
-        n_d[0] = nd; n_d[1] = nq - nd;
+        const u32 nd = part[t], nd64 = (nd + 63u) & ~63u;
+        n_d[0] = nd; n_d[1] = nq - nd; n_d[2] = nd64; n_d[3] = nd64 + (nq - nd);  // dense rows, other rows, first other row, rows in all
         if (h_words) { h_words[0] = nq; h_words[1] = nd; __threadfence_system(); }
     }
 }
@@ -1697,16 +1697,24 @@ __global__ __launch_bounds__(256) void classify_c_kernel(const u64* __restrict__
     __builtin_amdgcn_s_setprio(3);
     const u32 nq = *n_q, i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nq) return;
-    const u32 loc = qloc[i], dr = bsum[i >> 10] + (loc & 0x7FFFFFFFu), nd = n_d[0];
+    const u32 loc = qloc[i], dr = bsum[i >> 10] + (loc & 0x7FFFFFFFu), nd64 = n_d[2];
     if (loc >> 31) { qd[dr] = q[i]; qrow[i] = dr; }
-    else { const u32 sr = i - dr; qrow[i] = nd + sr; sslot[sr] = qinfo[i]; }
+    else { const u32 sr = i - dr; qrow[i] = nd64 + sr; sslot[sr] = qinfo[i]; }  // (the other rows start on a word boundary)
+}
+// a reference without the index: every hash is the scan's, rows = positions in Q
+__global__ void nd_from_nq_kernel(const u32* __restrict__ n_q, u32* __restrict__ n_d, volatile u32* __restrict__ h_words) {
+    const u32 nq = *n_q;
+    n_d[0] = nq; n_d[1] = 0; n_d[2] = (nq + 63u) & ~63u; n_d[3] = nq;
+    if (h_words) { h_words[0] = nq; h_words[1] = nq; __threadfence_system(); }
 }
 // bits of the rare rows: M[row][g] for every genome g on the hash's list.  A wave takes 64 rows; rows with long lists are walked by
 // the whole wave, 64 postings at a time.
 __global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
-                                                          u64* __restrict__ m_bits, u32 n_pad, u32* __restrict__ m_dirty) {
+                                                          u64* __restrict__ m_bits, u32 n_pad, u32* __restrict__ m_dirty,
+                                                          const u32* __restrict__ only_if) {
     __builtin_amdgcn_s_setprio(2);
-    const u32 nd = n_d[0], ns = n_d[1], lane = lane_id();
+    if (only_if && !*only_if) return;  // (no batch of the pass ranks on the full matrix: nobody reads these rows)
+    const u32 nd = n_d[2], ns = n_d[1], lane = lane_id();  // (nd: the first row behind the dense ones)
     const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
     bool wrote = false;
     for (u32 r0 = wave * 64u; r0 < ns; r0 += n_waves * 64u) {
@@ -2367,8 +2375,10 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
                                                              const u32* __restrict__ n_q, u32* __restrict__ grp_any,
                                                              const u64* __restrict__ hbuf, const u32* __restrict__ wb,
                                                              const u32* __restrict__ win, u32 n_tiles,
-                                                             const u32* __restrict__ m_dirty, u64* __restrict__ rowany) {
+                                                             const u32* __restrict__ m_dirty, u64* __restrict__ rowany,
+                                                             const u32* __restrict__ only_if) {
     __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
+    if (only_if && !*only_if) return;  // (every batch of the pass ranks on its candidates' compact matrix: nobody reads this one)
     __shared__ u64 tile[2][64][kRankWords + 1];
     // the grid is sized by the pair count (all the host knows); only the first ceil(nq / 64) words exist -- pairs
     // index Q, so rows of Mq beyond nq are never read
@@ -3665,6 +3675,359 @@ __global__ void gather_table_kernel(const u64* __restrict__ cum, u64* __restrict
 }
 
 // =====================================================================================
+// the table without the ranking, and the genomes a batch's ranking has to look at (round 5)
+// =====================================================================================
+// Rounds 1-4 took the running table out of the ranking chain: per-segment increments, chunk sums, prefixes -- every pair's 64-byte
+// row of Mq fetched once per rank group (232 k pairs x 79 groups per C2 batch) -- and the chain of batch i + 1 waited for the table
+// the chain of batch i left.  But the table only needs how OFTEN each distinct hash occurs in a batch: a batch of ~100 k reads
+// holds ~10 k distinct dense hashes, so   gain_b[g] = sum over rows q of cnt_b[q] * M[q][g]   reads the bit matrix once (50 MB)
+// for all batches of a pass, and   table_{b+1} = table_b + gain_b   is known for every batch of the pass before any ranking starts.
+// With the tables known, so is the set of genomes a batch's ranking has to look at at all: sums never decrease, so a genome
+// whose value at the END of batch b is below the k-th best value at its START cannot be among the first k at any read of it
+// (at least k genomes stay at or above that bound throughout).  The CANDIDATES of batch b -- table_{b+1}[g] >= k-th best of
+// table_b -- are listed in reference order; when a species has at most kCandCap of them the per-read ranking runs on a compact
+// problem (those genomes only: the same kernels on a bit matrix of two rank groups instead of 79), else on everything as before.
+// Reads of a real sample come from one strain: after a few hundred thousand reads the candidates are its lineage.  The bench's
+// near-tie (reads from the common ancestor of all 40 000 genomes) never gets there and keeps the full ranking -- both are exact.
+constexpr u32 kCandNone = 0xFFFFFFFFu;
+
+// cnt[b][row] = occurrences of the row among batch b's pairs (zero on entry)
+__global__ __launch_bounds__(256) void pass_hist_kernel(const u32* __restrict__ pair_q, PassBatches pb, u32* __restrict__ cnt, u32 row_stride) {
+    __builtin_amdgcn_s_setprio(3);
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= pb.p_off[pb.n]) return;
+    u32 b = 0;
+#pragma unroll
+    for (u32 i = 1; i < kPassBatchesMax; ++i) b += (i < pb.n && p >= pb.p_off[i]) ? 1u : 0u;
+    atomicAdd(&cnt[(size_t)b * row_stride + pair_q[p]], 1u);
+}
+// gain[b][g] += sum over the dense rows of cnt[b][row] * M[row][g].  Lane = genome, the counts are wave-uniform (scalar loads).
+// grid: (n_pad / 256, word chunks); M is read before the transpose re-zeroes it.
+constexpr u32 kGainWords = 8;  // query words per block
+template <u32 NB>
+__global__ __launch_bounds__(256) void gain_dense_kernel(const u64* __restrict__ m_bits, const u64* __restrict__ m_int, u32 n_pad,
+                                                         const u32* __restrict__ n_d, const u32* __restrict__ cnt, u32 row_stride,
+                                                         u32* __restrict__ gain) {
+    __builtin_amdgcn_s_setprio(2);
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    const u32 nd = n_d[0], n_words = (nd + 63u) >> 6;
+    const u32 w0 = blockIdx.y * kGainWords;
+    if (w0 >= n_words) return;
+    const u32 w1 = min(n_words, w0 + kGainWords);
+    u32 acc[NB];
+#pragma unroll
+    for (u32 b = 0; b < NB; ++b) acc[b] = 0;
+    for (u32 w = w0; w < w1; ++w) {
+        u64 m = m_bits[(size_t)w * n_pad + g];
+        if (m_int) m |= m_int[(size_t)w * n_pad + g];  // (the split scan variant keeps interior words in a second array)
+        if (__ballot(m != 0ull) == 0ull) continue;
+        const u32 lo = (u32)m, hi = (u32)(m >> 32);
+        const u32 rows = min(64u, nd - w * 64u);
+        const u32* c = cnt + (size_t)w * 64u;
+        for (u32 j = 0; j < rows; ++j) {
+            const u32 bit = j < 32u ? __builtin_amdgcn_ubfe(lo, j, 1u) : __builtin_amdgcn_ubfe(hi, j - 32u, 1u);
+#pragma unroll
+            for (u32 b = 0; b < NB; ++b) acc[b] += __umul24(bit, c[(size_t)b * row_stride + j]);
+        }
+    }
+#pragma unroll
+    for (u32 b = 0; b < NB; ++b)
+        if (acc[b]) atomicAdd(&gain[(size_t)b * n_pad + g], acc[b]);
+}
+// ... and the rows behind the dense ones (rare hashes): cnt[b][row] to every genome on the hash's list
+__global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
+                                                          const u32* __restrict__ cnt, u32 row_stride, u32 n_b, u32 n_pad,
+                                                          u32* __restrict__ gain) {
+    __builtin_amdgcn_s_setprio(2);
+    const u32 nd64 = n_d[2], ns = n_d[1], lane = lane_id();
+    const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    for (u32 r0 = wave * 64u; r0 < ns; r0 += n_waves * 64u) {
+        const u32 sr = r0 + lane;
+        u32 off = 0, np = 0;
+        u32 c[kPassBatchesMax];
+        u32 any = 0;
+#pragma unroll
+        for (u32 b = 0; b < kPassBatchesMax; ++b) c[b] = 0;
+        if (sr < ns) {
+            const u32 slot = sslot[sr];
+            if (slot != kSlotNone) { off = ri.off[slot]; np = ri.cnt[slot]; }
+            if (np) {
+#pragma unroll
+                for (u32 b = 0; b < kPassBatchesMax; ++b)
+                    if (b < n_b) { c[b] = cnt[(size_t)b * row_stride + nd64 + sr]; any |= c[b]; }
+            }
+        }
+        if (!any) np = 0;
+        if (np && np <= 8u) {
+            for (u32 j = 0; j < np; ++j) {
+                const u32 g = ri.post[off + j];
+#pragma unroll
+                for (u32 b = 0; b < kPassBatchesMax; ++b)
+                    if (c[b]) atomicAdd(&gain[(size_t)b * n_pad + g], c[b]);
+            }
+        }
+        u64 longs = __ballot(np > 8u);
+        while (longs) {
+            const u32 src = (u32)__builtin_ctzll(longs);
+            longs &= longs - 1ull;
+            const u32 o = __shfl(off, (int)src), n = __shfl(np, (int)src);
+            u32 cc[kPassBatchesMax];
+#pragma unroll
+            for (u32 b = 0; b < kPassBatchesMax; ++b) cc[b] = __shfl(c[b], (int)src);
+            for (u32 j = lane; j < n; j += 64u) {
+                const u32 g = ri.post[o + j];
+#pragma unroll
+                for (u32 b = 0; b < kPassBatchesMax; ++b)
+                    if (cc[b]) atomicAdd(&gain[(size_t)b * n_pad + g], cc[b]);
+            }
+        }
+    }
+}
+// tab[0] = the table the pass starts from, tab[b + 1] = tab[b] + gain[b]
+__global__ __launch_bounds__(256) void pass_tables_kernel(const u64* __restrict__ prev, const u32* __restrict__ gain, u32 n_b, u32 n_pad,
+                                                          u64* __restrict__ tab) {
+    __builtin_amdgcn_s_setprio(3);
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_pad) return;
+    u64 t = prev[g];
+    tab[g] = t;
+    for (u32 b = 0; b < n_b; ++b) { t += gain[(size_t)b * n_pad + g]; tab[(size_t)(b + 1u) * n_pad + g] = t; }
+}
+
+// block-wide helpers of the candidate selection (1024 threads = 16 waves)
+__device__ __forceinline__ u64 block1024_max_u64(u64 v, u64* sh /* [16] */) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, shfl_xor64(v, d));
+    __syncthreads();
+    if (lane_id() == 0u) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u64 r = sh[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r = max(r, sh[i]);
+    return r;
+}
+__device__ __forceinline__ u32 block1024_sum_u32(u32 v, u32* sh /* [16] */) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += (u32)__shfl_xor((int)v, d, 64);
+    __syncthreads();
+    if (lane_id() == 0u) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += sh[i];
+    return r;
+}
+// One workgroup per (batch, species): theta = the k-th best value of the species as the batch begins; candidates = real genomes
+// whose value as it ENDS reaches theta, in reference order.  cand[(b n_sp + sp) cap + i] = padded genome index, candslot[b][g] =
+// sp cap + i (or none), tabc[b][sp cap + i] = the genome's start value (slots behind the candidates: 0, never ranked: ncand bounds
+// the species), ncand[b n_sp + sp] = min(count, cap), bad[b] |= 1 when a species has more than cap.
+__global__ __launch_bounds__(1024) void cand_select_kernel(const u64* __restrict__ tab, u32 n_pad, Species sp, u32 top_k, u32 cap,
+                                                           u32* __restrict__ cand, u32* __restrict__ candslot, u64* __restrict__ tabc,
+                                                           u32* __restrict__ ncand, u32* __restrict__ bad) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ u64 sh64[16];
+    __shared__ u32 sh32[16];
+    __shared__ u32 wbase[17];
+    const u32 b = blockIdx.x / sp.n_sp, spi = blockIdx.x % sp.n_sp, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 g0 = sp.g0[spi], n = sp.n[spi];
+    const u32 g_end = spi + 1u < sp.n_sp ? sp.g0[spi + 1u] : n_pad;
+    const u64* t0 = tab + (size_t)b * n_pad;
+    const u64* t1 = t0 + n_pad;
+    // theta: at most top_k rounds of "largest value below the previous one", counting multiplicities
+    u64 theta = 0, prev = 0;
+    u32 remaining = max(top_k, 1u);
+    bool first = true;
+    for (u32 round = 0; round < 64u; ++round) {
+        u64 m = 0;
+        u32 any = 0;
+        for (u32 g = g0 + tid; g < g0 + n; g += 1024u) {
+            const u64 v = t0[g];
+            if (first || v < prev) { m = max(m, v); any = 1u; }
+        }
+        m = block1024_max_u64(m, sh64);
+        any = block1024_sum_u32(any, sh32);
+        if (!any) { theta = 0; break; }  // (fewer than top_k distinct positions: everything counts)
+        u32 c = 0;
+        for (u32 g = g0 + tid; g < g0 + n; g += 1024u) c += (t0[g] == m) ? 1u : 0u;
+        c = block1024_sum_u32(c, sh32);
+        if (c >= remaining) { theta = m; break; }
+        remaining -= c;
+        prev = m;
+        first = false;
+        theta = 0;
+    }
+    // ordered compaction
+    u32 base = 0;
+    u32* my_cand = cand + (size_t)(b * sp.n_sp + spi) * cap;
+    u64* my_tabc = tabc + (size_t)b * sp.n_sp * cap + (size_t)spi * cap;
+    for (u32 c0 = g0; c0 < g_end; c0 += 1024u) {
+        const u32 g = c0 + tid;
+        const bool is = g < g0 + n && t1[g] >= theta;
+        const u64 bal = __ballot(is);
+        const u32 before = (u32)__popcll(bal & lanemask_lt()), wtot = (u32)__popcll(bal);
+        __syncthreads();
+        if (lane == 0u) wbase[wv] = wtot;
+        __syncthreads();
+        u32 wb = 0, tot = 0;
+#pragma unroll
+        for (u32 i = 0; i < 16u; ++i) { const u32 v = wbase[i]; wb += i < wv ? v : 0u; tot += v; }
+        const u32 pos = base + wb + before;
+        if (g < g_end) {
+            u32 slot = kCandNone;
+            if (is && pos < cap) { my_cand[pos] = g; my_tabc[pos] = t0[g]; slot = spi * cap + pos; }
+            candslot[(size_t)b * n_pad + g] = slot;
+        }
+        base += tot;
+    }
+    for (u32 i = min(base, cap) + tid; i < cap; i += 1024u) { my_cand[i] = kCandNone; my_tabc[i] = 0; }
+    if (tid == 0u) {
+        ncand[b * sp.n_sp + spi] = min(base, cap);
+        if (base > cap) atomicOr(&bad[b], 1u);
+    }
+}
+// M_c[b][w][c] = M[w][cand[b][c]] for the dense words (batches the selection left in compact mode); slots without a candidate: 0
+__global__ __launch_bounds__(256) void cand_gather_m_kernel(const u64* __restrict__ m_bits, const u64* __restrict__ m_int, u32 n_pad,
+                                                            const u32* __restrict__ n_d,
+                                                            const u32* __restrict__ cand, u32 n_pad_c, const u32* __restrict__ bad,
+                                                            u64* __restrict__ mc, u32 words_c) {
+    __builtin_amdgcn_s_setprio(2);
+    const u32 b = blockIdx.z, w = blockIdx.y, c = blockIdx.x * 256u + threadIdx.x;
+    if (bad[b] || w >= ((n_d[0] + 63u) >> 6) || c >= n_pad_c) return;
+    const u32 g = cand[(size_t)b * n_pad_c + c];
+    u64 x = 0;
+    if (g != kCandNone) { x = m_bits[(size_t)w * n_pad + g]; if (m_int) x |= m_int[(size_t)w * n_pad + g]; }
+    mc[((size_t)b * words_c + w) * n_pad_c + c] = x;
+}
+// the rare rows of the compact problem: a rare hash whose genome list meets batch b's candidates gets a row behind the dense ones
+// (nqc[b] counts them; smap[b][sparse row] = compact row), its bits go straight into the group-major matrix Mq_c[b] (zero on
+// entry behind the dense rows, as are rowany_c / grp_any_c); rows of hashes no candidate holds stay unmapped (the pair remap sends
+// them to an all-zero row).  More rows than the matrix holds: bad[b] |= 2.  grid: (blocks, batches)
+__global__ __launch_bounds__(256) void cand_sparse_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
+                                                          const u32* __restrict__ candslot, u32 n_pad, u32* __restrict__ bad,
+                                                          u32* __restrict__ nqc, u32* __restrict__ smap, u32 smap_stride,
+                                                          u64* __restrict__ mqc, size_t mqc_stride, u32 rows_c, u64* __restrict__ rowany_c,
+                                                          u32 rowany_stride, u32* __restrict__ grp_any_c, u32 n_grp_c) {
+    __builtin_amdgcn_s_setprio(2);
+    const u32 b = blockIdx.y;
+    if (bad[b]) return;
+    const u32 nd64 = n_d[2], ns = n_d[1], lane = lane_id();
+    const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    const u32* cs = candslot + (size_t)b * n_pad;
+    u64* mq = mqc + (size_t)b * mqc_stride;
+    u64* ra = rowany_c + (size_t)b * rowany_stride;
+    u32* ga = grp_any_c + (size_t)b * n_grp_c;
+    auto put = [&](u32 crow, u32 slot) {
+        const u32 gw = slot >> 6, grp = gw / kRankWords;
+        atomicOr(&mq[mq_index(gw, crow, rows_c)], 1ull << (slot & 63u));
+        atomicOr(&ra[(size_t)grp * (rows_c >> 6) + (crow >> 6)], 1ull << (crow & 63u));
+        atomicAdd(&ga[grp], 1u);
+    };
+    auto new_row = [&](u32 sr) -> u32 {
+        const u32 crow = nd64 + atomicAdd(&nqc[b], 1u);
+        if (crow + 1u >= rows_c) { atomicOr(&bad[b], 2u); return kCandNone; }
+        smap[(size_t)b * smap_stride + sr] = crow + 1u;  // (0 = not mapped)
+        return crow;
+    };
+    for (u32 r0 = wave * 64u; r0 < ns; r0 += n_waves * 64u) {
+        const u32 sr = r0 + lane;
+        u32 off = 0, np = 0;
+        if (sr < ns) {
+            const u32 slot = sslot[sr];
+            if (slot != kSlotNone) { off = ri.off[slot]; np = ri.cnt[slot]; }
+        }
+        if (np && np <= 8u) {
+            u32 crow = kCandNone;
+            bool dead = false;
+            for (u32 j = 0; j < np && !dead; ++j) {
+                const u32 s_ = cs[ri.post[off + j]];
+                if (s_ == kCandNone) continue;
+                if (crow == kCandNone) { crow = new_row(sr); dead = crow == kCandNone; }
+                if (!dead) put(crow, s_);
+            }
+        }
+        u64 longs = __ballot(np > 8u);
+        while (longs) {
+            const u32 src = (u32)__builtin_ctzll(longs);
+            longs &= longs - 1ull;
+            const u32 o = __shfl(off, (int)src), n = __shfl(np, (int)src);
+            u32 crow = kCandNone;
+            bool dead = false;
+            for (u32 j0 = 0; j0 < n && !dead; j0 += 64u) {
+                const u32 j = j0 + lane;
+                const u32 s_ = j < n ? cs[ri.post[o + j]] : kCandNone;
+                const u64 hit = __ballot(s_ != kCandNone);
+                if (!hit) continue;
+                if (crow == kCandNone) {
+                    u32 cr = 0;
+                    if (lane == 0u) cr = new_row(r0 + src);
+                    crow = (u32)__shfl((int)cr, 0);
+                    dead = crow == kCandNone;
+                }
+                if (!dead && s_ != kCandNone) put(crow, s_);
+            }
+        }
+    }
+}
+// decisions of a pass, for the host: mode[b] = 1 (compact ranking) / 0 (everything), the candidates' largest count, whether any
+// batch needs the full bit matrix (the transpose of M and the fill of its rare rows only run then), sequence number last
+__global__ void cand_publish_kernel(const u32* __restrict__ bad, u32 force_full, const u32* __restrict__ ncand, const u32* __restrict__ nqc,
+                                    const u32* __restrict__ n_d, u32 n_b, u32 n_sp, u32 rows_c, u32* __restrict__ mode, u32* __restrict__ any_full,
+                                    u32* __restrict__ nqc_total, volatile u32* __restrict__ h_pub, u32 seq) {
+    __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 any = 0;
+    const u32 nd64 = n_d[2];
+    for (u32 b = 0; b < n_b; ++b) {
+        const bool full = bad[b] != 0u || ((force_full >> b) & 1u) || nd64 + 64u >= rows_c;
+        mode[b] = full ? 0u : 1u;
+        any |= full ? 1u : 0u;
+        u32 mx = 0;
+        for (u32 s_ = 0; s_ < n_sp; ++s_) mx = max(mx, ncand[b * n_sp + s_]);
+        nqc_total[b] = nd64 + nqc[b];   // rows of the compact problem (dense rows, padded to 64, + the mapped rare rows)
+        h_pub[b] = full ? 0u : 1u;
+        h_pub[kPassBatchesMax + b] = mx;
+    }
+    *any_full = any;
+    h_pub[2 * kPassBatchesMax] = any;
+    __threadfence_system();
+    h_pub[2 * kPassBatchesMax + 1] = seq;
+    __threadfence_system();
+}
+// nobody needs the full bit matrix this pass: M's dense words go back to all-zero here instead of in the transpose
+__global__ __launch_bounds__(256) void m_clear_kernel(u64* __restrict__ m_bits, u64* __restrict__ m_int, u32 n_pad,
+                                                      const u32* __restrict__ n_d, const u32* __restrict__ any_full) {
+    if (*any_full) return;
+    const u32 n_words = (n_d[0] + 63u) >> 6;
+    const size_t n = (size_t)n_words * n_pad;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        if (m_bits[i]) m_bits[i] = 0ull;
+        if (m_int && m_int[i]) m_int[i] = 0ull;
+    }
+}
+// pairs of a compact batch: row of the pass's matrix -> row of the compact one (dense rows keep theirs; rare rows through smap,
+// unmapped ones to the all-zero last row)
+__global__ __launch_bounds__(256) void cand_pair_rows_kernel(const u32* __restrict__ pair_q, u32 n_pairs, const u32* __restrict__ n_d,
+                                                             const u32* __restrict__ smap, u32 rows_c, u32* __restrict__ pair_qc) {
+    __builtin_amdgcn_s_setprio(3);
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_pairs) return;
+    const u32 row = pair_q[p], nd64 = n_d[2];
+    u32 out = row;
+    if (row >= nd64) { const u32 m = smap[row - nd64]; out = m ? m - 1u : rows_c - 1u; }
+    pair_qc[p] = out;
+}
+// rows of a compact batch: candidate slot (local to the species of the compact problem) -> genome index local to the species
+__global__ __launch_bounds__(256) void cand_rows_back_kernel(u32* __restrict__ out_idx, u32 n_rows /* reads x species x top */, u32 n_sp,
+                                                             u32 top_k, const u32* __restrict__ cand, u32 cap, const u32* __restrict__ g0) {
+    __builtin_amdgcn_s_setprio(3);
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_rows) return;
+    const u32 spi = (i / top_k) % n_sp;
+    const u32 slot = out_idx[i];
+    if (slot < cap) out_idx[i] = cand[(size_t)spi * cap + slot] - g0[spi];
+}
+
+// =====================================================================================
 // launchers
 // =====================================================================================
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
@@ -3848,9 +4211,66 @@ void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, 
     hipLaunchKernelGGL(classify_b_kernel, dim3(1), dim3(1024), 0, st, bsum, n_q, n_d, h_words);
     hipLaunchKernelGGL(classify_c_kernel, dim3(std::max(1u, cdiv(q_bound, 256))), dim3(256), 0, st, q, n_q, qinfo, qloc, bsum, n_d, qd, qrow, sslot);
 }
-void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* m_bits, u32 n_pad, u32* m_dirty, u32 rows_bound) {
+void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* m_bits, u32 n_pad, u32* m_dirty, u32 rows_bound,
+                        const u32* only_if) {
     const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 256), 2048u));
-    hipLaunchKernelGGL(sparse_fill_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, m_bits, n_pad, m_dirty);
+    hipLaunchKernelGGL(sparse_fill_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, m_bits, n_pad, m_dirty, only_if);
+}
+void launch_nd_from_nq(hipStream_t st, const u32* n_q, u32* n_d, u32* h_words) {
+    hipLaunchKernelGGL(nd_from_nq_kernel, dim3(1), dim3(1), 0, st, n_q, n_d, h_words);
+}
+void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, u32* cnt, u32 row_stride) {
+    const u32 n = pb.p_off[pb.n];
+    if (n == 0) return;
+    hipLaunchKernelGGL(pass_hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pair_q, pb, cnt, row_stride);
+}
+void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride,
+                      u32 n_b, u32* gain, const u32* sslot, const RareIndex* ri) {
+    const dim3 grid(n_pad / 256, std::max(1u, cdiv(cdiv(rows_bound, 64), kGainWords)));
+#define SKX_GAIN(NB) hipLaunchKernelGGL(gain_dense_kernel<NB>, grid, dim3(256), 0, st, m_bits, m_int, n_pad, n_d, cnt, row_stride, gain)
+    switch (n_b) {
+        case 1: SKX_GAIN(1); break; case 2: SKX_GAIN(2); break; case 3: SKX_GAIN(3); break; case 4: SKX_GAIN(4); break;
+        case 5: SKX_GAIN(5); break; case 6: SKX_GAIN(6); break; case 7: SKX_GAIN(7); break; default: SKX_GAIN(8); break;
+    }
+#undef SKX_GAIN
+    if (ri && sslot)
+        hipLaunchKernelGGL(gain_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), 2048u))), dim3(256), 0, st, sslot, n_d, *ri, cnt,
+                           row_stride, n_b, n_pad, gain);
+}
+void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, u32 n_b, u32 n_pad, u64* tab) {
+    hipLaunchKernelGGL(pass_tables_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, prev, gain, n_b, n_pad, tab);
+}
+void launch_cand_select(hipStream_t st, const u64* tab, u32 n_pad, const Species& sp, u32 n_b, u32 top_k, u32 cap, u32* cand, u32* candslot,
+                        u64* tabc, u32* ncand, u32* bad) {
+    hipLaunchKernelGGL(cand_select_kernel, dim3(n_b * sp.n_sp), dim3(1024), 0, st, tab, n_pad, sp, top_k, cap, cand, candslot, tabc, ncand, bad);
+}
+void launch_cand_gather_m(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cand, u32 n_pad_c,
+                          const u32* bad, u32 n_b, u64* mc, u32 words_c) {
+    const u32 words = std::min(words_c, std::max(1u, cdiv(rows_bound, 64)));
+    hipLaunchKernelGGL(cand_gather_m_kernel, dim3(cdiv(n_pad_c, 256), words, n_b), dim3(256), 0, st, m_bits, m_int, n_pad, n_d, cand, n_pad_c, bad, mc, words_c);
+}
+void launch_cand_sparse(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const RareIndex& ri, const u32* candslot, u32 n_pad,
+                        u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride, u32 rows_c, u64* rowany_c,
+                        u32 rowany_stride, u32* grp_any_c, u32 n_grp_c) {
+    hipLaunchKernelGGL(cand_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), 1024u)), n_b), dim3(256), 0, st, sslot, n_d, ri, candslot,
+                       n_pad, bad, nqc, smap, smap_stride, mqc, mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
+}
+void launch_cand_publish(hipStream_t st, const u32* bad, u32 force_full, const u32* ncand, const u32* nqc, const u32* n_d, u32 n_b, u32 n_sp,
+                         u32 rows_c, u32* mode, u32* any_full, u32* nqc_total, u32* h_pub, u32 seq) {
+    hipLaunchKernelGGL(cand_publish_kernel, dim3(1), dim3(1), 0, st, bad, force_full, ncand, nqc, n_d, n_b, n_sp, rows_c, mode, any_full, nqc_total,
+                       h_pub, seq);
+}
+void launch_m_clear(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, const u32* n_d, const u32* any_full) {
+    hipLaunchKernelGGL(m_clear_kernel, dim3(512), dim3(256), 0, st, m_bits, m_int, n_pad, n_d, any_full);
+}
+void launch_cand_pair_rows(hipStream_t st, const u32* pair_q, u32 n_pairs, const u32* n_d, const u32* smap, u32 rows_c, u32* pair_qc) {
+    if (n_pairs == 0) return;
+    hipLaunchKernelGGL(cand_pair_rows_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pair_q, n_pairs, n_d, smap, rows_c, pair_qc);
+}
+void launch_cand_rows_back(hipStream_t st, u32* out_idx, u32 n_reads, u32 n_sp, u32 top_k, const u32* cand, u32 cap, const u32* g0) {
+    const u32 n = n_reads * n_sp * top_k;
+    if (n == 0) return;
+    hipLaunchKernelGGL(cand_rows_back_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, out_idx, n, n_sp, top_k, cand, cap, g0);
 }
 void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win, u32* h_nq) {
     hipLaunchKernelGGL(window_kernel, dim3(cdiv(n_bt, 256)), dim3(256), 0, st, lo, hi, n_bt, q, n_q, win, h_nq);
@@ -3952,14 +4372,15 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
     else hipLaunchKernelGGL((scan_kernel<2040, 0, false>), grid, block, 0, st, mat, s, n_tiles, rb, q, win, m_bits, m_int, n_pad);
 }
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any,
-                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64 nq_est, u64* rowany) {
+                           const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64 nq_est, u64* rowany,
+                           const u32* only_if) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     // y extent: twice the estimated dictionary size (the blocks stride, see the kernel), at most what the pairs allow
     const u32 y_all = cdiv(n_words, kWordsPerBlock);
     const u32 y_est = (u32)std::min<u64>(y_all, std::max<u64>(16, cdiv((u32)std::min<u64>(2 * nq_est / 64 + 1, 0xFFFFFFF0u), kWordsPerBlock)));
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), std::min(y_est, 65535u)), dim3(256), 0, st,
-                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty, rowany);
+                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty, rowany, only_if);
 }
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_bases, u32* chk, u32* cnt_tail, const LongReads* long_reads) {
     const LongReads lr = long_reads ? *long_reads : LongReads{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};

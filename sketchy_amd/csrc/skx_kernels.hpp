@@ -104,7 +104,44 @@ void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, 
                      u64* qd, u32* n_d, u32* qrow, u32* sslot, u32* h_words);
 // bits of the rows behind the dense ones, from the genome lists: atomicOr into m_bits (and *m_dirty = 1)
 void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* m_bits, u32 n_pad, u32* m_dirty,
-                        u32 rows_bound);
+                        u32 rows_bound, const u32* only_if = nullptr /* device flag: run only when it is non-zero */);
+// n_d = {dense rows, other rows, first other row (dense rows rounded up to 64), rows in all} -- what launch_classify leaves; for a
+// reference without the index: everything dense, rows = positions in q
+void launch_nd_from_nq(hipStream_t st, const u32* n_q, u32* n_d, u32* h_words);
+
+// ---- the table without the ranking, and the candidates of a batch (skx_kernels.hip, "the table without the ranking")
+static const u32 kPassBatchesMax = 8;          // batches of a pass (stream_coalesce)
+static const u32 kCandCap = 1024;              // candidates per species the compact ranking takes (two rank groups)
+static const u32 kCandRows = 32768;            // rows of a compact bit matrix (dense rows + the rare rows some candidate holds)
+struct PassBatches { u32 n; u32 p_off[kPassBatchesMax + 1]; };  // pairs [p_off[b], p_off[b + 1]) of the pass's lists are batch b's
+// cnt[b][row] (zero on entry; row_stride entries per batch) = occurrences of the row among batch b's pairs
+void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, u32* cnt, u32 row_stride);
+// gain[b][g] (zero on entry) += sum over rows of cnt[b][row] * (row's bit for g): dense rows from m_bits (BEFORE the transpose
+// re-zeroes it), the others from the genome lists (ri / sslot, or NULL)
+void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt,
+                      u32 row_stride, u32 n_b, u32* gain, const u32* sslot, const RareIndex* ri);
+// tab[0] = prev, tab[b + 1] = tab[b] + gain[b]   ([n_b + 1][n_pad])
+void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, u32 n_b, u32 n_pad, u64* tab);
+// per (batch, species): the genomes whose value at the end of the batch reaches the top_k-th best value at its start, in reference
+// order: cand[(b n_sp + sp) cap + i], candslot[b][g] (0xFFFFFFFF: none), tabc[b][sp cap + i] start values, ncand[b n_sp + sp],
+// bad[b] (zero on entry) |= 1 when a species has more than cap
+void launch_cand_select(hipStream_t st, const u64* tab, u32 n_pad, const Species& sp, u32 n_b, u32 top_k, u32 cap, u32* cand, u32* candslot,
+                        u64* tabc, u32* ncand, u32* bad);
+// mc[b][w][c] = m_bits[w][cand[b][c]] (dense words; n_pad_c = n_sp * cap columns, words_c words per batch)
+void launch_cand_gather_m(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cand,
+                          u32 n_pad_c, const u32* bad, u32 n_b, u64* mc, u32 words_c);
+// rare rows of the compact problems: rows behind the dense ones for the hashes some candidate holds (nqc[b] of them, smap[b][.]),
+// their bits into mqc[b] / rowany_c[b] / grp_any_c[b] (all zero on entry); bad[b] |= 2 when they do not fit rows_c
+void launch_cand_sparse(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const RareIndex& ri, const u32* candslot, u32 n_pad,
+                        u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride, u32 rows_c, u64* rowany_c,
+                        u32 rowany_stride, u32* grp_any_c, u32 n_grp_c);
+// mode[b] = 1 compact / 0 everything, *any_full, nqc_total[b] = rows of the compact problem; h_pub (page-locked): [b] mode,
+// [8 + b] largest candidate count, [16] any_full, [17] = seq (written last)
+void launch_cand_publish(hipStream_t st, const u32* bad, u32 force_full, const u32* ncand, const u32* nqc, const u32* n_d, u32 n_b, u32 n_sp,
+                         u32 rows_c, u32* mode, u32* any_full, u32* nqc_total, u32* h_pub, u32 seq);
+void launch_m_clear(hipStream_t st, u64* m_bits, u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, const u32* any_full);
+void launch_cand_pair_rows(hipStream_t st, const u32* pair_q, u32 n_pairs, const u32* n_d, const u32* smap, u32 rows_c, u32* pair_qc);
+void launch_cand_rows_back(hipStream_t st, u32* out_idx, u32 n_reads, u32 n_sp, u32 top_k, const u32* cand, u32 cap, const u32* g0);
 
 // dictionary
 // qrow (launch_classify) != NULL: pair_q receives ROWS of the bit matrix instead of positions in q
@@ -160,7 +197,8 @@ void launch_word_bands(hipStream_t st, u32* win, u32 n_tiles, u32 n_bands, const
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq,
                            const u32* n_q, u32* grp_any, const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles,
                            const u32* m_dirty, u64 nq_est /* the host's estimate of the dictionary size: sizes the grid */,
-                           u64* rowany /* [rank groups][n_words]: bit r of word w = row 64 w + r holds a bit in the group; or NULL */);
+                           u64* rowany /* [rank groups][n_words]: bit r of word w = row 64 w + r holds a bit in the group; or NULL */,
+                           const u32* only_if = nullptr /* device flag: run only when it is non-zero */);
 // chk[0..5], [9] (zero on entry): non-monotonic marker, long-read count, offsets[0], offsets[n_reads], segment count;
 // long_reads != NULL: also lists the batch's long reads and their segments (chk[6] |= 2 if they do not fit the tables)
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_bases, u32* chk, u32* cnt_tail /* zeroed */,
