@@ -725,7 +725,9 @@ struct skx_stream {
     // ---- the table without the ranking, the candidates of a batch (skx_kernels.hip; scan stream unless said otherwise)
     u32 *d_rowcnt = nullptr;     // [kPassBatchesMax][qcap] occurrences of every row among a batch's pairs
     u32 *d_gain = nullptr;       // [kPassBatchesMax][n_pad]
+    u32 *d_gain_s = nullptr;     // the rare rows' part: [kPassBatchesMax][n_pad] entries gain_sparse_stride() words apart (references with the index)
     u32 *d_candslot = nullptr;   // [kPassBatchesMax][n_pad] candidate slot of a genome (or none)
+    u32 *d_candmask = nullptr;   // [n_pad] batches of the pass a genome is a candidate of
     u32 *d_cbad = nullptr, *d_nqc = nullptr;  // [kPassBatchesMax] why a batch cannot rank compactly / mapped rare rows
     u32 *d_spc_g0 = nullptr, *d_spc_grp = nullptr;  // Species layout of the compact problems: kCandCap slots per species
     u32 n_pad_c = 0, n_grp_c = 0, cand_seq = 0;
@@ -746,12 +748,20 @@ struct skx_stream {
     } ps[2];
     // the ranking chains of the latest pass are queued once its candidates are known (queue_chains)
     struct PassChains {
-        bool pending = false, ranked = false, has_cand = false, update_table = false;
+        bool pending = false, ranked = false, has_cand = false, update_table = false, forced_full = false, legacy = false;
         SubPass subs[kGroupMax];
         int n_sub = 0, b = 0, slot = 0;
         u32 P = 0, nq_rows = 0, seq = 0;
         u64 nq_est = 0;
-    } pc;
+    } pcq[2];                 // FIFO: the passes whose chains are not queued yet (at most the latest two: one per buffer set)
+    int pc_head = 0, pc_n = 0;
+    // What the last pass whose candidates were published looked like: every batch with more candidates than a compact ranking takes
+    // (the bench's near-tie: all 40 000 genomes, always) -> the next pass is told to rank on everything right away: its chains are
+    // queued with the pass, nothing waits for a publication, the compact side's scratch is not even touched.  (Ranking on
+    // everything is always exact; a sample that has just found its leader loses one pass of the compact ranking.)
+    bool hint_all_overflow = false;
+    u32 hint_seq = 0;  // sequence number of the pass the hint was taken from
+    u32 legacy_run = 0;  // passes in a row that took the table out of their ranking chains (rounds 1-4's way) instead
     u64 batches_compact = 0, batches_full = 0;  // batches ranked on their candidates / on everything (statistic)
     bool have_split_hint = false;
     double nd_frac = 1.0;    // dense rows / |Q| of the latest pass whose dictionary is known: which scan variant a pass gets
@@ -909,7 +919,7 @@ static void stream_free(skx_stream* st) {
                     st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1],
                     st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum,
-                    st->d_rowcnt, st->d_gain, st->d_candslot, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp};
+                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp};
     for (auto& q : st->ps) {
         for (void* x : {(void*)q.tab, (void*)q.cand, (void*)q.tabc, (void*)q.ncand, (void*)q.mode, (void*)q.any_full, (void*)q.nqc_total, (void*)q.mc, (void*)q.mqc,
                         (void*)q.rowany_c, (void*)q.grp_any_c, (void*)q.smap, (void*)q.pair_qc, (void*)q.nd}) (void)hipFree(x);
@@ -1345,7 +1355,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     if (ref->d_kt_key) {  // the split dictionary of a pass (rare-hash index)
         SCHK(hipMalloc(&st->d_qd, (size_t)st->pcap * 8));
         SCHK(hipMalloc(&st->d_qrow, (size_t)st->pcap * 4));
-        SCHK(hipMalloc(&st->d_sslot, (size_t)st->pcap * 4));
+        SCHK(hipMalloc(&st->d_sslot, (size_t)st->pcap * 8));  // (start, length) of a rare row's genome list
         SCHK(hipMalloc(&st->d_qinfo, (size_t)st->pcap * 4));
         SCHK(hipMalloc(&st->d_qloc, (size_t)st->pcap * 4));
         SCHK(hipMalloc(&st->d_cls_bsum, ((size_t)st->pcap / 1024 + 2) * 4));
@@ -1357,7 +1367,9 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         st->n_grp_c = st->n_pad_c / (skx::kRankWords * 64);
         SCHK(hipMalloc(&st->d_rowcnt, (size_t)nb * ((size_t)st->qcap + 128) * 4));
         SCHK(hipMalloc(&st->d_gain, (size_t)nb * n_pad * 4));
+        if (ref->d_kt_key) SCHK(hipMalloc(&st->d_gain_s, (size_t)nb * n_pad * 4 * skx::gain_sparse_stride()));
         SCHK(hipMalloc(&st->d_candslot, (size_t)nb * n_pad * 4));
+        SCHK(hipMalloc(&st->d_candmask, (size_t)n_pad * 4));
         SCHK(hipMalloc(&st->d_cbad, 64));
         SCHK(hipMalloc(&st->d_nqc, 64));
         std::vector<u32> g0c(n_sp), grpc(st->n_grp_c);
@@ -1487,6 +1499,8 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 // everything in flight is waited for, the new arrays are allocated before the old ones are freed, at most an eighth of the free device
 // memory is taken.  Not on the steady path: a stream grows once or twice, then its groups fit.
 static int queue_chains(skx_stream* st, bool block);
+static int queue_chains_until(skx_stream* st, int leave);
+static void update_cand_hint(skx_stream* st);
 static int staged_rows(skx_stream* st, void* slot);
 static int grow_query_rows(skx_stream* st, u64 want_rows) {
     if (!st->qcap_auto) return SKX_OK;
@@ -1546,7 +1560,11 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // rows per group of the group-major bit matrix of this pass (the rows behind the dense ones start on a word boundary: up to 63 more
     // than the dictionary has hashes)
     const u32 nq_rows = ((q_bound + 63) / 64) * 64 + 64;
-    SKXCHK(queue_chains(st, true));             // the ranking of the pass before this one (its candidates were published long ago)
+    // the ranking of earlier passes whose candidates have been published by now; the pass TWO back (it used this pass's buffer set)
+    // must be through -- the one before this may still be waiting for its scan
+    SKXCHK(queue_chains(st, false));
+    if (st->pc_n == 2) SKXCHK(queue_chains_until(st, 1));
+    update_cand_hint(st);
     const int b = st->buf;                      // buffer set handed from stage to stage for this pass
     st->buf ^= 1;
     const int slot = st->pslot;                 // ... and its slot of the pair lists
@@ -1720,11 +1738,26 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
 
     // ---- the table as every batch of the pass begins (and as the pass ends), and the genomes each batch's ranking has to look at
     // (skx_kernels.hip, "the table without the ranking").  All on the scan stream, before the transpose re-zeroes M.
-    bool ranked = false;
-    for (int i = 0; i < n_sub; ++i) ranked = ranked || (st->top_k && subs[i].d_topk_idx && subs[i].d_topk_sum);
+    bool ranked = false, all_forced = false, all_ranked = true;
+    for (int i = 0; i < n_sub; ++i) {
+        const bool r = st->top_k && subs[i].d_topk_idx && subs[i].d_topk_sum;
+        ranked = ranked || r; all_ranked = all_ranked && r && !subs[i].d_shared;
+    }
     const u32* only_if = nullptr;  // device flag: does any batch of the pass rank on the FULL matrix?  (NULL: yes, unconditionally)
     u32 seq = 0;
-    if (update_table) {
+    // A stream whose batches ALL have more candidates than a compact ranking takes (the bench's near-tie of 40 000 genomes) gains
+    // nothing from knowing its tables early: three passes out of four then take the table out of their ranking chains, as in rounds
+    // 1-4 (no row counts, no gains, no candidate selection: ~0.65 ms of scan-stream work per C2 pass, 9 % of the reads/s next to the
+    // sketches); every fourth pass looks at the candidates again.
+    static const int legacy_env = skx::knob("SKX_TABLE_LEGACY") ? atoi(skx::knob("SKX_TABLE_LEGACY")) : 3;  // experiment knob: passes in a row
+    static const int cand_env0 = skx::knob("SKX_CAND") ? atoi(skx::knob("SKX_CAND")) : 1;
+    const bool legacy = update_table && all_ranked && cand_env0 && st->hint_all_overflow && (int)st->legacy_run < legacy_env;
+    st->legacy_run = legacy ? st->legacy_run + 1 : 0;
+    if (update_table && !legacy && st->cum_writer) {  // (the table the last chain of a legacy pass left: the gains are added to it)
+        HIPCHK(hipStreamWaitEvent(hs, st->cum_writer->ev_cum, 0));
+        st->cum_writer = nullptr;
+    }
+    if (update_table && !legacy) {
         Span sp(st, 4, hs);
         const u32 n_sp = ref->n_species, cap = skx::kCandCap, rows_c = skx::kCandRows;
         skx::PassBatches pbt;
@@ -1737,26 +1770,32 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             HIPCHK(hipMemset2DAsync(st->d_rowcnt, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
             skx::launch_pass_hist(hs, d_pair_q, pbt, st->d_rowcnt, qstride);
             const skx::RareIndex ri = ref->rare_index();
-            skx::launch_pass_gain(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain,
+            if (split_dict) HIPCHK(hipMemsetAsync(st->d_gain_s, 0, (size_t)n_sub * n_pad * 4 * skx::gain_sparse_stride(), hs));
+            skx::launch_pass_gain(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain, st->d_gain_s,
                                   split_dict ? st->d_sslot : nullptr, split_dict ? &ri : nullptr);
         }
-        skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (u32)n_sub, n_pad, ps.tab);
+        skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (split_dict && P > 0) ? st->d_gain_s : nullptr, (u32)n_sub, n_pad, ps.tab);
         st->d_cum = ps.tab + (size_t)n_sub * n_pad;  // (readers: the next pass on this stream; everybody else behind ev_front / a flush)
         // candidates.  A batch that wants the per-read x per-genome debug matrix ranks on everything; so does every batch when the
         // experiment knob SKX_CAND=0 says so
         static const int cand_env = skx::knob("SKX_CAND") ? atoi(skx::knob("SKX_CAND")) : 1;
-        u32 force_full = cand_env ? 0u : 0xFFu;
+        static const int hint_env = skx::knob("SKX_CAND_HINT") ? atoi(skx::knob("SKX_CAND_HINT")) : 1;  // experiment knob: 0 = never predict
+        (void)hint_env;
+        all_forced = !cand_env;
+        u32 force_full = all_forced ? 0xFFu : 0u;
         for (int i = 0; i < n_sub; ++i) if (subs[i].d_shared) force_full |= 1u << i;
         HIPCHK(hipMemsetAsync(st->d_cbad, 0, 64, hs));
         HIPCHK(hipMemsetAsync(st->d_nqc, 0, 64, hs));
         if (ranked) {
-            skx::launch_cand_select(hs, ps.tab, n_pad, spc, (u32)n_sub, st->top_k, cap, ps.cand, st->d_candslot, ps.tabc, ps.ncand, st->d_cbad);
+            HIPCHK(hipMemsetAsync(st->d_candmask, 0, (size_t)n_pad * 4, hs));
+            skx::launch_cand_select(hs, ps.tab, n_pad, spc, (u32)n_sub, st->top_k, cap, ps.cand, st->d_candslot, ps.tabc, ps.ncand, st->d_cbad,
+                                    st->d_candmask);
             HIPCHK(hipMemsetAsync(ps.grp_any_c, 0, (size_t)n_sub * st->n_grp_c * 4, hs));
-            if (split_dict && P > 0) {
+            if (split_dict && P > 0 && !all_forced) {
                 HIPCHK(hipMemsetAsync(ps.mqc, 0, (size_t)n_sub * st->n_grp_c * rows_c * skx::kRankWords * 8, hs));
                 HIPCHK(hipMemsetAsync(ps.rowany_c, 0, (size_t)n_sub * st->n_grp_c * (rows_c / 64) * 8, hs));
                 HIPCHK(hipMemset2DAsync(ps.smap, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
-                skx::launch_cand_sparse(hs, st->d_sslot, d_nd, q_bound, ref->rare_index(), st->d_candslot, n_pad, st->d_cbad, (u32)n_sub, st->d_nqc,
+                skx::launch_cand_sparse(hs, st->d_sslot, d_nd, q_bound, ref->rare_index(), st->d_candmask, st->d_candslot, n_pad, st->d_cbad, (u32)n_sub, st->d_nqc,
                                         ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords, rows_c, ps.rowany_c,
                                         st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c);
             }
@@ -1766,7 +1805,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         seq = ++st->cand_seq;
         skx::launch_cand_publish(hs, st->d_cbad, force_full, ps.ncand, st->d_nqc, d_nd, (u32)n_sub, n_sp, rows_c, ps.mode, ps.any_full,
                                  ps.nqc_total, ps.h_pub, seq);
-        if (ranked && P > 0)
+        if (ranked && P > 0 && !all_forced)
             skx::launch_cand_gather_m(hs, st->d_m, m_int, n_pad, d_nd, q_bound, ps.cand, st->n_pad_c, st->d_cbad, (u32)n_sub, ps.mc, rows_c / 64);
         only_if = ps.any_full;
         HIPCHK(hipGetLastError());
@@ -1790,12 +1829,19 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     (void)lean_used;
 
     // ---- the ranking chains are queued by queue_chains, once the pass's candidates are known
-    skx_stream::PassChains& pc = st->pc;
+    skx_stream::PassChains& pc = st->pcq[(st->pc_head + st->pc_n) & 1];
+    st->pc_n += 1;
     pc.pending = true; pc.ranked = ranked; pc.has_cand = update_table;
     pc.n_sub = n_sub; pc.b = b; pc.slot = slot; pc.P = P; pc.nq_rows = nq_rows; pc.seq = seq; pc.nq_est = nq_est;
     for (int i = 0; i < n_sub; ++i) pc.subs[i] = subs[i];
     pc.update_table = update_table;
+    pc.forced_full = all_forced || legacy;
+    pc.legacy = legacy;
+    if (legacy) { pc.has_cand = false; all_forced = true; }
     SKX_MARK("pass: scan + transpose queued", 0);
+    // (every batch ranks on everything whatever the candidates turn out to be: nothing to wait for -- the chains go out now, behind
+    // those of the passes before, which then cannot wait either)
+    if (all_forced) SKXCHK(queue_chains(st, true));
     return SKX_OK;
 }
 
@@ -1804,17 +1850,52 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
 // runs either on everything (Mq, 79 rank groups at C2) or -- when the batch's candidates fit -- on the compact problem: the
 // candidates' columns (two rank groups per species), the same kernels, the slots mapped back to genome indices at the end.
 // block: wait for the pass's published candidates (else return when they are not there yet).
+static int queue_one(skx_stream* st, skx_stream::PassChains& pc, bool block, bool* done);
+// hint_all_overflow from the most recent pass whose candidates have been published (either buffer set; forced passes publish what
+// their candidates WOULD have been): did every batch have more candidates than the compact ranking takes?
+static void update_cand_hint(skx_stream* st) {
+    for (auto& q : st->ps) {
+        volatile u32* hp = q.h_pub;
+        const u32 seq = hp[2 * skx::kPassBatchesMax + 1], n_b = hp[2 * skx::kPassBatchesMax + 2];
+        if (seq == 0 || (int)(seq - st->hint_seq) <= 0 || n_b == 0 || n_b > skx::kPassBatchesMax) continue;
+        bool all_over = true;
+        for (u32 i = 0; i < n_b; ++i) all_over = all_over && hp[skx::kPassBatchesMax + i] >= skx::kCandCap;
+        if (hp[2 * skx::kPassBatchesMax + 1] != seq) continue;  // (rewritten while we looked)
+        st->hint_all_overflow = all_over && st->top_k != 0;
+        st->hint_seq = seq;
+    }
+}
+// until at most `leave` passes wait for their chains (blocking)
+static int queue_chains_until(skx_stream* st, int leave) {
+    while (st->pc_n > leave) {
+        bool done = false;
+        SKXCHK(queue_one(st, st->pcq[st->pc_head], true, &done));
+        st->pc_head ^= 1; st->pc_n -= 1;
+    }
+    return SKX_OK;
+}
+// block: all of them; else: those whose candidates have been published, in order
 static int queue_chains(skx_stream* st, bool block) {
-    skx_stream::PassChains& pc = st->pc;
-    if (!pc.pending) return SKX_OK;
+    if (block) return queue_chains_until(st, 0);
+    while (st->pc_n > 0) {
+        bool done = false;
+        SKXCHK(queue_one(st, st->pcq[st->pc_head], false, &done));
+        if (!done) break;
+        st->pc_head ^= 1; st->pc_n -= 1;
+    }
+    return SKX_OK;
+}
+static int queue_one(skx_stream* st, skx_stream::PassChains& pc, bool block, bool* done) {
+    *done = false;
+    if (!pc.pending) { *done = true; return SKX_OK; }
     const skx_ref* ref = st->ref;
     const int b = pc.b, slot = pc.slot, n_sub = pc.n_sub;
     skx_stream::PassSet& ps = st->ps[b];
     u32 mode[kGroupMax] = {};
-    if (pc.has_cand) {
+    if (pc.has_cand && !pc.forced_full) {
         volatile u32* hp = ps.h_pub;
         if (hp[2 * skx::kPassBatchesMax + 1] != pc.seq) {
-            if (!block) return SKX_OK;
+            if (!block) return SKX_OK;  // (*done stays false)
             SKX_T0();
             for (u64 spins = 0; hp[2 * skx::kPassBatchesMax + 1] != pc.seq; ++spins)
                 if ((spins & 0xFFFFu) == 0xFFFFu) {  // (look at the stream now and then so a fault cannot hang the caller)
@@ -1830,7 +1911,9 @@ static int queue_chains(skx_stream* st, bool block) {
         }
         for (int i = 0; i < n_sub; ++i) mode[i] = hp[i];
     }
+    update_cand_hint(st);
     pc.pending = false;
+    *done = true;
     hipStream_t hs2 = st->hs2;
     const skx::Species spc = ref->species();
     const u32 n_pad = ref->n_pad, n_sp = ref->n_species;
@@ -1864,7 +1947,15 @@ static int queue_chains(skx_stream* st, bool block) {
     u32* c_grp_any = compact ? ps.grp_any_c + (size_t)si * st->n_grp_c : d_grp_any;
     const u64* c_rowany = compact ? ps.rowany_c + (size_t)si * st->n_grp_c * (skx::kCandRows / 64) : (P > 0 ? st->d_rowany[b] : nullptr);
     const u32* c_nq = compact ? ps.nqc_total + si : d_nq_rows;
-    const u64* const cum_in = update_table ? (compact ? ps.tabc + (size_t)si * st->n_pad_c : ps.tab + (size_t)si * n_pad) : st->d_cum;
+    // the table the batch starts from: the pass's front half computed it (ps.tab / the candidates' tabc) -- or, legacy passes, the chain
+    // before this one leaves it (rotating buffers, as in rounds 1-4)
+    const bool legacy = pc.legacy && update_table;
+    if (legacy && st->cum_writer && st->cum_writer != &L) HIPCHK(hipStreamWaitEvent(ls, st->cum_writer->ev_cum, 0));
+    int tab_next = st->tab_cur;
+    if (legacy) {
+        do { tab_next = (tab_next + 1) % (st->n_lanes + 1); } while (st->d_tab[tab_next] == st->d_cum);
+    }
+    const u64* const cum_in = legacy ? st->d_cum : update_table ? (compact ? ps.tabc + (size_t)si * st->n_pad_c : ps.tab + (size_t)si * n_pad) : st->d_cum;
     const u32 *sub_pair_q = (compact ? ps.pair_qc : d_pair_q) + sb.p_off, *sub_pair_r = d_pair_r + sb.p_off, *sub_poff = sb.d_poff;
     if (update_table && ranked) { if (compact) st->batches_compact += 1; else st->batches_full += 1; }
     if (compact) {
@@ -1911,7 +2002,9 @@ static int queue_chains(skx_stream* st, bool block) {
     static const int ablate_rank2 = skx::knob("SKX_ABLATE_RANK") ? atoi(skx::knob("SKX_ABLATE_RANK")) : 0;  // 2 = no ranking stage at all
     if (update_table && ranked && ablate_rank2 != 2) {
         Span sp(st, 4, ls);
-        u64* const cum_out = L.d_cum_sink;  // (the chain's own sum of the table: nobody reads it -- the pass's front half has the tables)
+        // (the chain's own sum of the table: nobody reads it when the pass's front half has computed the tables)
+        u64* const cum_out = legacy ? st->d_tab[tab_next] : L.d_cum_sink;
+        hipEvent_t ev_tab = legacy ? L.ev_cum : nullptr;
         // the top-1 kernel keeps (value relative to the leader) in 23 bits of a 32-bit key: at most 2 x 64 x s + 1 per
         // segment, so sketch sizes from 2^15 on take the 64-bit-key kernel (with k = 1) instead
         static const bool top1_wide_env = skx::knob("SKX_TOP1_WIDE") != nullptr;  // test knob: force the 64-bit-key kernel
@@ -1921,7 +2014,7 @@ static int queue_chains(skx_stream* st, bool block) {
         unsigned char* d_live = ((top1_fast || topk_fast) && live_env) ? L.d_live : nullptr;  // (the pruned kernels look at the flags)
         if (two_level) {
             skx::launch_seg_prefix(ls, d_inc, n_seg, c_pad, c_spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
-                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, c_grp_any, d_live, L.d_lead_seg, 1, nullptr, nullptr);
+                                   L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, c_grp_any, d_live, L.d_lead_seg, 1, nullptr, ev_tab);
             skx::launch_seg_sum(ls, sub_pair_q, sub_poff, sub_base, 0, n_reads, skx::kSegLen, c_mq, c_pad, c_rows, d_inc, c_grp_any,
                                 nullptr, c_rowany, c_nq, c_spc, L.d_gmax, L.d_lead_val);
             skx::launch_seg_prefix(ls, d_inc, n_seg, c_pad, c_spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
@@ -1929,7 +2022,7 @@ static int queue_chains(skx_stream* st, bool block) {
         } else {
             skx::launch_seg_prefix(ls, d_inc, n_seg, c_pad, c_spc, cum_in, cum_out, L.d_rel, L.d_csum, d_csum_raw, prune_k,
                                    L.d_leader, L.d_lead_val, L.d_gmax, L.d_lpart_sum, L.d_lpart_idx, c_grp_any, d_live, L.d_lead_seg, 0,
-                                   L.d_live_ctr, nullptr);
+                                   L.d_live_ctr, ev_tab);
         }
         HIPCHK(hipGetLastError());
         SKX_MARK("rank: prefixes queued", si);
@@ -1937,6 +2030,7 @@ static int queue_chains(skx_stream* st, bool block) {
         // a compact chain's sample says nothing about the full problem and is only re-armed)
         if (prune_k) skx::launch_store_host_words(ls, compact ? st->h_nq_sink : st->h_nq + 2, L.d_live_ctr, 2);
         st->rank_seq += 1;
+        if (legacy) { st->tab_cur = tab_next; st->d_cum = cum_out; st->cum_writer = &L; }
         if (top1_fast) {
             skx::launch_rank_seg_top1(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, c_mq, c_pad, c_rows,
                                       c_spc, cum_in, L.d_rel, L.d_cand_sum, L.d_cand_idx, d_inc,
@@ -2063,6 +2157,10 @@ static int queue_counts_and_summary(skx_stream* st, PendingBatch& pb) {
     // finds out after the wait and cuts the batch into passes)
     if (pb.spec_insert) {
         const int b = pb.spec_set, slot = pb.spec_slot;
+        // (round 5: that ranking may not even be QUEUED yet -- chains wait for their pass's candidates: make sure it is, so that the
+        // event below covers it.  Its pass was queued two groups ago: its candidates were published long since)
+        for (int k = 0; k < st->pc_n; ++k)
+            if (st->pcq[(st->pc_head + k) & 1].slot == slot) { SKXCHK(queue_chains_until(st, st->pc_n - k - 1)); break; }
         // the set's hash set / pair hashes were last read by the dictionary of the pass two back (scan stream), the slot's
         // pair lists by the ranking three passes back
         if (st->pairq_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_pairq[b], 0)); st->pairq_pending[b] = false; }
@@ -2641,9 +2739,12 @@ static int staged_finish(skx_stream* st, skx_stream::Staged& sl) {
     SKXCHK(staged_process(st, sl));
     for (int i = 0; i < st->n_pend; ++i)
         if (st->pend[i].slot == &sl) { SKXCHK(flush_pending(st)); break; }
-    if (st->pc.pending)  // (its pass is queued, its ranking -- and the copy of its rows -- not yet)
-        for (int i = 0; i < st->pc.n_sub; ++i)
-            if (st->pc.subs[i].slot == &sl) { SKXCHK(queue_chains(st, true)); break; }
+    for (int k = 0; k < st->pc_n; ++k) {  // (its pass is queued, its ranking -- and the copy of its rows -- not yet)
+        const skx_stream::PassChains& pc = st->pcq[(st->pc_head + k) & 1];
+        bool mine = false;
+        for (int i = 0; i < pc.n_sub; ++i) mine = mine || pc.subs[i].slot == &sl;
+        if (mine) { SKXCHK(queue_chains_until(st, st->pc_n - k - 1)); break; }
+    }
     if (sl.in_flight) { HIPCHK(hipEventSynchronize(sl.ev_done)); sl.in_flight = false; }
     return SKX_OK;
 }
@@ -2912,6 +3013,10 @@ SKX_API int skx_stream_reset(skx_stream* st) {
     HIPCHK(hipStreamSynchronize(st->hs2));
     st->reads_total = 0;
     st->h_nq[2] = 1; st->h_nq[3] = 1;  // (a new sample: every genome is a candidate again)
+    st->hint_all_overflow = false;     // (... and nothing is known about its candidates)
+    st->hint_seq = st->cand_seq;
+    st->legacy_run = 0;
+    st->cum_writer = nullptr;          // (everything is synchronised)
     return SKX_OK;
 }
 SKX_API int skx_stream_reads(const skx_stream* st, uint64_t* n_reads) {

@@ -39,6 +39,12 @@
 #ifndef SKX_SCAN_SPLIT_READS
 #define SKX_SCAN_SPLIT_READS 1
 #endif
+#ifndef SKX_WALK_BLOCKS
+#define SKX_WALK_BLOCKS 256
+#endif
+#ifndef SKX_GAIN_SPARSE_STRIDE
+#define SKX_GAIN_SPARSE_STRIDE 16
+#endif
 #ifndef SKX_SEGSUM_PRIO
 #define SKX_SEGSUM_PRIO 2
 #endif
@@ -1693,13 +1699,18 @@ __global__ __launch_bounds__(1024) void classify_b_kernel(u32* __restrict__ bsum
 __global__ __launch_bounds__(256) void classify_c_kernel(const u64* __restrict__ q, const u32* __restrict__ n_q,
                                                          const u32* __restrict__ qinfo, const u32* __restrict__ qloc,
                                                          const u32* __restrict__ bsum, const u32* __restrict__ n_d,
-                                                         u64* __restrict__ qd, u32* __restrict__ qrow, u32* __restrict__ sslot) {
+                                                         u64* __restrict__ qd, u32* __restrict__ qrow, u32* __restrict__ sslot, RareIndex ri) {
     __builtin_amdgcn_s_setprio(3);
     const u32 nq = *n_q, i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nq) return;
     const u32 loc = qloc[i], dr = bsum[i >> 10] + (loc & 0x7FFFFFFFu), nd64 = n_d[2];
     if (loc >> 31) { qd[dr] = q[i]; qrow[i] = dr; }
-    else { const u32 sr = i - dr; qrow[i] = nd64 + sr; sslot[sr] = qinfo[i]; }  // (the other rows start on a word boundary)
+    else {  // (the other rows start on a word boundary; sslot[2 sr], [2 sr + 1] = start and length of the hash's genome list)
+        const u32 sr = i - dr, slot = qinfo[i];
+        qrow[i] = nd64 + sr;
+        sslot[2u * sr] = slot != kSlotNone ? ri.off[slot] : 0u;
+        sslot[2u * sr + 1u] = slot != kSlotNone ? ri.cnt[slot] : 0u;
+    }
 }
 // a reference without the index: every hash is the scan's, rows = positions in Q
 __global__ void nd_from_nq_kernel(const u32* __restrict__ n_q, u32* __restrict__ n_d, volatile u32* __restrict__ h_words) {
@@ -1720,10 +1731,7 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict_
     for (u32 r0 = wave * 64u; r0 < ns; r0 += n_waves * 64u) {
         const u32 sr = r0 + lane;
         u32 off = 0, cnt = 0;
-        if (sr < ns) {
-            const u32 slot = sslot[sr];
-            if (slot != kSlotNone) { off = ri.off[slot]; cnt = ri.cnt[slot]; }
-        }
+        if (sr < ns) { const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr]; off = e.x; cnt = e.y; }
         const u32 row = nd + sr;
         u64* const mrow = m_bits + (size_t)(row >> 6) * n_pad;
         const u64 bit = 1ull << (row & 63u);
@@ -3690,6 +3698,7 @@ __global__ void gather_table_kernel(const u64* __restrict__ cum, u64* __restrict
 // Reads of a real sample come from one strain: after a few hundred thousand reads the candidates are its lineage.  The bench's
 // near-tie (reads from the common ancestor of all 40 000 genomes) never gets there and keeps the full ranking -- both are exact.
 constexpr u32 kCandNone = 0xFFFFFFFFu;
+constexpr u32 kPatWords = 128;  // genome words of a compact problem the long-list path of cand_sparse_kernel holds in LDS (8 species)
 
 // cnt[b][row] = occurrences of the row among batch b's pairs (zero on entry)
 __global__ __launch_bounds__(256) void pass_hist_kernel(const u32* __restrict__ pair_q, PassBatches pb, u32* __restrict__ cnt, u32 row_stride) {
@@ -3704,6 +3713,7 @@ __global__ __launch_bounds__(256) void pass_hist_kernel(const u32* __restrict__ 
 // gain[b][g] += sum over the dense rows of cnt[b][row] * M[row][g].  Lane = genome, the counts are wave-uniform (scalar loads).
 // grid: (n_pad / 256, word chunks); M is read before the transpose re-zeroes it.
 constexpr u32 kGainWords = 8;  // query words per block
+constexpr u32 kGainSparseStride = SKX_GAIN_SPARSE_STRIDE;  // u32 words between two genomes' entries of the rare rows' gain array
 template <u32 NB>
 __global__ __launch_bounds__(256) void gain_dense_kernel(const u64* __restrict__ m_bits, const u64* __restrict__ m_int, u32 n_pad,
                                                          const u32* __restrict__ n_d, const u32* __restrict__ cnt, u32 row_stride,
@@ -3734,7 +3744,12 @@ __global__ __launch_bounds__(256) void gain_dense_kernel(const u64* __restrict__
     for (u32 b = 0; b < NB; ++b)
         if (acc[b]) atomicAdd(&gain[(size_t)b * n_pad + g], acc[b]);
 }
-// ... and the rows behind the dense ones (rare hashes): cnt[b][row] to every genome on the hash's list
+// ... and the rows behind the dense ones (rare hashes): cnt[b][row] to every genome on the hash's list: one walk over the lists, one
+// atomic per posting and batch the row occurs in.  (Device-scope atomics are executed at the memory side, ~2.3 G/s scattered: 8.7 M
+// postings per C2 pass of the SNP workload = 3.7 ms, most of them the ~200 genomes of SOME lineage whose lineage-level hash a
+// sequencing error hit.  Tried: workgroups that own a range of 2048 genomes and add in LDS -- every range walks all the lists:
+// 4.9 ms.  What would remove it: lists shared between hashes stored once -- all lineage-level hashes of a lineage have the SAME
+// list --, counts summed per list first.  DESIGN.md section 9.)
 __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
                                                           const u32* __restrict__ cnt, u32 row_stride, u32 n_b, u32 n_pad,
                                                           u32* __restrict__ gain) {
@@ -3749,8 +3764,8 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
 #pragma unroll
         for (u32 b = 0; b < kPassBatchesMax; ++b) c[b] = 0;
         if (sr < ns) {
-            const u32 slot = sslot[sr];
-            if (slot != kSlotNone) { off = ri.off[slot]; np = ri.cnt[slot]; }
+            const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr];
+            off = e.x; np = e.y;
             if (np) {
 #pragma unroll
                 for (u32 b = 0; b < kPassBatchesMax; ++b)
@@ -3763,7 +3778,7 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
                 const u32 g = ri.post[off + j];
 #pragma unroll
                 for (u32 b = 0; b < kPassBatchesMax; ++b)
-                    if (c[b]) atomicAdd(&gain[(size_t)b * n_pad + g], c[b]);
+                    if (c[b]) atomicAdd(&gain[((size_t)b * n_pad + g) * kGainSparseStride], c[b]);
             }
         }
         u64 longs = __ballot(np > 8u);
@@ -3778,20 +3793,25 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
                 const u32 g = ri.post[o + j];
 #pragma unroll
                 for (u32 b = 0; b < kPassBatchesMax; ++b)
-                    if (cc[b]) atomicAdd(&gain[(size_t)b * n_pad + g], cc[b]);
+                    if (cc[b]) atomicAdd(&gain[((size_t)b * n_pad + g) * kGainSparseStride], cc[b]);
             }
         }
     }
 }
 // tab[0] = the table the pass starts from, tab[b + 1] = tab[b] + gain[b]
-__global__ __launch_bounds__(256) void pass_tables_kernel(const u64* __restrict__ prev, const u32* __restrict__ gain, u32 n_b, u32 n_pad,
-                                                          u64* __restrict__ tab) {
+// gain_s (or NULL): the rare rows' part, one entry per kGainSparseStride words (gain_sparse_kernel)
+__global__ __launch_bounds__(256) void pass_tables_kernel(const u64* __restrict__ prev, const u32* __restrict__ gain,
+                                                          const u32* __restrict__ gain_s, u32 n_b, u32 n_pad, u64* __restrict__ tab) {
     __builtin_amdgcn_s_setprio(3);
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     if (g >= n_pad) return;
     u64 t = prev[g];
     tab[g] = t;
-    for (u32 b = 0; b < n_b; ++b) { t += gain[(size_t)b * n_pad + g]; tab[(size_t)(b + 1u) * n_pad + g] = t; }
+    for (u32 b = 0; b < n_b; ++b) {
+        t += gain[(size_t)b * n_pad + g];
+        if (gain_s) t += gain_s[((size_t)b * n_pad + g) * kGainSparseStride];
+        tab[(size_t)(b + 1u) * n_pad + g] = t;
+    }
 }
 
 // block-wide helpers of the candidate selection (1024 threads = 16 waves)
@@ -3823,7 +3843,7 @@ __device__ __forceinline__ u32 block1024_sum_u32(u32 v, u32* sh /* [16] */) {
 // the species), ncand[b n_sp + sp] = min(count, cap), bad[b] |= 1 when a species has more than cap.
 __global__ __launch_bounds__(1024) void cand_select_kernel(const u64* __restrict__ tab, u32 n_pad, Species sp, u32 top_k, u32 cap,
                                                            u32* __restrict__ cand, u32* __restrict__ candslot, u64* __restrict__ tabc,
-                                                           u32* __restrict__ ncand, u32* __restrict__ bad) {
+                                                           u32* __restrict__ ncand, u32* __restrict__ bad, u32* __restrict__ candmask) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ u64 sh64[16];
     __shared__ u32 sh32[16];
@@ -3874,8 +3894,8 @@ __global__ __launch_bounds__(1024) void cand_select_kernel(const u64* __restrict
         const u32 pos = base + wb + before;
         if (g < g_end) {
             u32 slot = kCandNone;
-            if (is && pos < cap) { my_cand[pos] = g; my_tabc[pos] = t0[g]; slot = spi * cap + pos; }
-            candslot[(size_t)b * n_pad + g] = slot;
+            if (is && pos < cap) { my_cand[pos] = g; my_tabc[pos] = t0[g]; slot = spi * cap + pos; atomicOr(&candmask[g], 1u << b); }
+            candslot[(size_t)b * n_pad + g] = slot;  // (candmask[g], zero on entry: the batches g is a candidate of)
         }
         base += tot;
     }
@@ -3898,31 +3918,32 @@ __global__ __launch_bounds__(256) void cand_gather_m_kernel(const u64* __restric
     if (g != kCandNone) { x = m_bits[(size_t)w * n_pad + g]; if (m_int) x |= m_int[(size_t)w * n_pad + g]; }
     mc[((size_t)b * words_c + w) * n_pad_c + c] = x;
 }
-// the rare rows of the compact problem: a rare hash whose genome list meets batch b's candidates gets a row behind the dense ones
-// (nqc[b] counts them; smap[b][sparse row] = compact row), its bits go straight into the group-major matrix Mq_c[b] (zero on
-// entry behind the dense rows, as are rowany_c / grp_any_c); rows of hashes no candidate holds stay unmapped (the pair remap sends
-// them to an all-zero row).  More rows than the matrix holds: bad[b] |= 2.  grid: (blocks, batches)
+// the rare rows of the compact problems: a rare hash whose genome list meets batch b's candidates gets a row behind the dense ones of
+// b's compact matrix (nqc[b] counts them; smap[b][sparse row] = that row + 1), its bits go straight into the group-major matrix
+// Mq_c[b] (zero on entry behind the dense rows, as are rowany_c / grp_any_c); rows of hashes no candidate holds stay unmapped (the
+// pair remap sends them to an all-zero row).  More rows than the matrix holds: bad[b] |= 2.  ONE walk over the postings for all
+// batches: candmask[g] says which batches genome g is a candidate of (almost always none).
 __global__ __launch_bounds__(256) void cand_sparse_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
-                                                          const u32* __restrict__ candslot, u32 n_pad, u32* __restrict__ bad,
-                                                          u32* __restrict__ nqc, u32* __restrict__ smap, u32 smap_stride,
-                                                          u64* __restrict__ mqc, size_t mqc_stride, u32 rows_c, u64* __restrict__ rowany_c,
-                                                          u32 rowany_stride, u32* __restrict__ grp_any_c, u32 n_grp_c) {
+                                                          const u32* __restrict__ candmask, const u32* __restrict__ candslot, u32 n_pad,
+                                                          u32* __restrict__ bad, u32 n_b, u32* __restrict__ nqc, u32* __restrict__ smap,
+                                                          u32 smap_stride, u64* __restrict__ mqc, size_t mqc_stride, u32 rows_c,
+                                                          u64* __restrict__ rowany_c, u32 rowany_stride, u32* __restrict__ grp_any_c,
+                                                          u32 n_grp_c) {
     __builtin_amdgcn_s_setprio(2);
-    const u32 b = blockIdx.y;
-    if (bad[b]) return;
+    __shared__ u64 pat[4][kPassBatchesMax][kPatWords];  // per wave: the words of a long-list row, per batch
     const u32 nd64 = n_d[2], ns = n_d[1], lane = lane_id();
+    const u32 n_gw_c = n_grp_c * kRankWords;
     const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
-    const u32* cs = candslot + (size_t)b * n_pad;
-    u64* mq = mqc + (size_t)b * mqc_stride;
-    u64* ra = rowany_c + (size_t)b * rowany_stride;
-    u32* ga = grp_any_c + (size_t)b * n_grp_c;
-    auto put = [&](u32 crow, u32 slot) {
-        const u32 gw = slot >> 6, grp = gw / kRankWords;
-        atomicOr(&mq[mq_index(gw, crow, rows_c)], 1ull << (slot & 63u));
-        atomicOr(&ra[(size_t)grp * (rows_c >> 6) + (crow >> 6)], 1ull << (crow & 63u));
-        atomicAdd(&ga[grp], 1u);
+    // (atomics are executed at the memory side, ~0.4 ns each whatever the address: one per BIT, one per (row, batch) for the row
+    // itself and one per (row, batch, rank group) for the row flags -- not one per posting)
+    auto put = [&](u32 b, u32 crow, u32 slot) { atomicOr(&mqc[(size_t)b * mqc_stride + mq_index(slot >> 6, crow, rows_c)], 1ull << (slot & 63u)); };
+    auto flag = [&](u32 b, u32 crow, u32 grp) {
+        atomicOr(&rowany_c[(size_t)b * rowany_stride + (size_t)grp * (rows_c >> 6) + (crow >> 6)], 1ull << (crow & 63u));
+        u32* ga = grp_any_c + (size_t)b * n_grp_c + grp;
+        if (*ga == 0u) atomicOr(ga, 1u);
     };
-    auto new_row = [&](u32 sr) -> u32 {
+    auto new_row = [&](u32 b, u32 sr) -> u32 {
+        if (bad[b]) return kCandNone;
         const u32 crow = nd64 + atomicAdd(&nqc[b], 1u);
         if (crow + 1u >= rows_c) { atomicOr(&bad[b], 2u); return kCandNone; }
         smap[(size_t)b * smap_stride + sr] = crow + 1u;  // (0 = not mapped)
@@ -3931,18 +3952,32 @@ __global__ __launch_bounds__(256) void cand_sparse_kernel(const u32* __restrict_
     for (u32 r0 = wave * 64u; r0 < ns; r0 += n_waves * 64u) {
         const u32 sr = r0 + lane;
         u32 off = 0, np = 0;
-        if (sr < ns) {
-            const u32 slot = sslot[sr];
-            if (slot != kSlotNone) { off = ri.off[slot]; np = ri.cnt[slot]; }
-        }
+        if (sr < ns) { const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr]; off = e.x; np = e.y; }
         if (np && np <= 8u) {
-            u32 crow = kCandNone;
-            bool dead = false;
-            for (u32 j = 0; j < np && !dead; ++j) {
-                const u32 s_ = cs[ri.post[off + j]];
-                if (s_ == kCandNone) continue;
-                if (crow == kCandNone) { crow = new_row(sr); dead = crow == kCandNone; }
-                if (!dead) put(crow, s_);
+            u32 crow[kPassBatchesMax];
+#pragma unroll
+            for (u32 b = 0; b < kPassBatchesMax; ++b) crow[b] = kCandNone;
+            for (u32 j = 0; j < np; ++j) {
+                const u32 g = ri.post[off + j];
+                u32 m = candmask[g];
+                while (m) {
+                    const u32 b = (u32)__builtin_ctz(m);
+                    m &= m - 1u;
+                    if (b >= n_b) break;
+                    u32 cr = kCandNone;
+#pragma unroll
+                    for (u32 i = 0; i < kPassBatchesMax; ++i) cr = i == b ? crow[i] : cr;
+                    const bool fresh = cr == kCandNone;
+                    if (fresh) {
+                        cr = new_row(b, sr);
+#pragma unroll
+                        for (u32 i = 0; i < kPassBatchesMax; ++i) if (i == b) crow[i] = cr == kCandNone ? 0xFFFFFFFEu : cr;
+                    }
+                    if (cr >= 0xFFFFFFFEu) continue;  // (the batch's matrix is full: it ranks on everything)
+                    const u32 s_ = candslot[(size_t)b * n_pad + g];
+                    put(b, cr, s_);
+                    flag(b, cr, (s_ >> 6) / kRankWords);  // (short lists: a flag per bit is at most 8 per row)
+                }
             }
         }
         u64 longs = __ballot(np > 8u);
@@ -3950,20 +3985,93 @@ __global__ __launch_bounds__(256) void cand_sparse_kernel(const u32* __restrict_
             const u32 src = (u32)__builtin_ctzll(longs);
             longs &= longs - 1ull;
             const u32 o = __shfl(off, (int)src), n = __shfl(np, (int)src);
-            u32 crow = kCandNone;
-            bool dead = false;
-            for (u32 j0 = 0; j0 < n && !dead; j0 += 64u) {
-                const u32 j = j0 + lane;
-                const u32 s_ = j < n ? cs[ri.post[o + j]] : kCandNone;
-                const u64 hit = __ballot(s_ != kCandNone);
-                if (!hit) continue;
-                if (crow == kCandNone) {
-                    u32 cr = 0;
-                    if (lane == 0u) cr = new_row(r0 + src);
-                    crow = (u32)__shfl((int)cr, 0);
-                    dead = crow == kCandNone;
+            if (n_gw_c <= kPatWords) {
+                // Long lists (a lineage's hash: ~200 genomes, all of them candidates when it is the sample's own lineage): the row's
+                // words are put together in LDS -- per batch, the bits of the candidates on the list -- and written ONCE, with plain
+                // stores (the row is this wave's alone): 3.2 M atomicOr per C2 pass became 0.26 M stores.
+                u64* pw = &pat[threadIdx.x >> 6][0][0];
+                for (u32 i = lane; i < n_b * n_gw_c; i += 64u) pw[(i / n_gw_c) * kPatWords + i % n_gw_c] = 0ull;
+                wave_sync();
+                u32 seen = 0;  // batches some candidate of which is on the list
+                for (u32 j0 = 0; j0 < n; j0 += 64u) {
+                    const u32 j = j0 + lane;
+                    const u32 g = j < n ? ri.post[o + j] : 0u;
+                    u32 m = j < n ? candmask[g] : 0u;
+                    seen |= m;
+                    while (m) {
+                        const u32 b = (u32)__builtin_ctz(m);
+                        m &= m - 1u;
+                        if (b >= n_b) break;
+                        const u32 s_ = candslot[(size_t)b * n_pad + g];
+                        atomicOr(&pw[b * kPatWords + (s_ >> 6)], 1ull << (s_ & 63u));
+                    }
                 }
-                if (!dead && s_ != kCandNone) put(crow, s_);
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) seen |= (u32)__shfl_xor((int)seen, d, 64);
+                wave_sync();
+                while (seen) {
+                    const u32 b = (u32)__builtin_ctz(seen);
+                    seen &= seen - 1u;
+                    if (b >= n_b) break;
+                    u32 x = 0;
+                    if (lane == 0u) x = new_row(b, r0 + src);
+                    const u32 cr = (u32)__shfl((int)x, 0);
+                    if (cr == kCandNone) continue;  // (the batch's matrix is full: it ranks on everything)
+                    for (u32 w0 = 0; w0 < n_gw_c; w0 += 64u) {
+                        const u32 w = w0 + lane;
+                        const u64 v = w < n_gw_c ? pw[b * kPatWords + w] : 0ull;
+                        if (v) mqc[(size_t)b * mqc_stride + mq_index(w, cr, rows_c)] = v;
+                        // one flag per rank group with a bit: the first lane of every run of kRankWords words
+                        const u64 nz = __ballot(v != 0ull);
+                        const u32 grp_lane0 = (lane / kRankWords) * kRankWords;
+                        const bool first = ((nz >> grp_lane0) & ((1ull << kRankWords) - 1ull)) != 0ull && lane == grp_lane0;
+                        if (first && w < n_gw_c) flag(b, cr, w / kRankWords);
+                    }
+                }
+                wave_sync();
+                continue;
+            }
+            u32 crow[kPassBatchesMax];           // (wave-uniform)
+            u64 flagged[kPassBatchesMax];        // rank groups (mod 64) the row is flagged for already, per batch
+#pragma unroll
+            for (u32 b = 0; b < kPassBatchesMax; ++b) { crow[b] = kCandNone; flagged[b] = 0; }
+            for (u32 j0 = 0; j0 < n; j0 += 64u) {
+                const u32 j = j0 + lane;
+                const u32 g = j < n ? ri.post[o + j] : 0u;
+                const u32 m = j < n ? candmask[g] : 0u;
+                u32 all = m;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) all |= (u32)__shfl_xor((int)all, d, 64);
+                while (all) {
+                    const u32 b = (u32)__builtin_ctz(all);
+                    all &= all - 1u;
+                    if (b >= n_b) break;
+                    u32 cr = kCandNone;
+                    u64 fl = 0;
+#pragma unroll
+                    for (u32 i = 0; i < kPassBatchesMax; ++i) { cr = i == b ? crow[i] : cr; fl = i == b ? flagged[i] : fl; }
+                    if (cr == kCandNone) {
+                        u32 x = 0;
+                        if (lane == 0u) x = new_row(b, r0 + src);
+                        cr = (u32)__shfl((int)x, 0);
+                        if (cr == kCandNone) cr = 0xFFFFFFFEu;
+                    }
+                    const bool mine = (m >> b) & 1u;
+                    u32 s_ = kCandNone;
+                    if (cr < 0xFFFFFFFEu && mine) { s_ = candslot[(size_t)b * n_pad + g]; put(b, cr, s_); }
+                    u64 hit = cr < 0xFFFFFFFEu ? __ballot(mine) : 0ull;
+                    while (hit) {  // one flag per (row, batch, group): the first lane of every group that is new to the row
+                        const u32 l0 = (u32)__builtin_ctzll(hit);
+                        const u32 grp = (u32)__shfl((int)((s_ >> 6) / kRankWords), (int)l0);
+                        hit &= ~__ballot(mine && (s_ >> 6) / kRankWords == grp);
+                        if (!((fl >> (grp & 63u)) & 1ull) || grp >= 64u) {
+                            if (lane == l0) flag(b, cr, grp);
+                            fl |= 1ull << (grp & 63u);
+                        }
+                    }
+#pragma unroll
+                    for (u32 i = 0; i < kPassBatchesMax; ++i) if (i == b) { crow[i] = cr; flagged[i] = fl; }
+                }
             }
         }
     }
@@ -3989,6 +4097,7 @@ __global__ void cand_publish_kernel(const u32* __restrict__ bad, u32 force_full,
     }
     *any_full = any;
     h_pub[2 * kPassBatchesMax] = any;
+    h_pub[2 * kPassBatchesMax + 2] = n_b;
     __threadfence_system();
     h_pub[2 * kPassBatchesMax + 1] = seq;
     __threadfence_system();
@@ -4031,6 +4140,7 @@ __global__ __launch_bounds__(256) void cand_rows_back_kernel(u32* __restrict__ o
 // launchers
 // =====================================================================================
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+static const u32 kWalkBlocks = SKX_WALK_BLOCKS;  // workgroups of the kernels that walk the rare rows' genome lists
 static int env_int(const char* name, int dflt) { const char* e = knob(name); return e ? atoi(e) : dflt; }
 
 void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 pad_base, u32 g_count) {
@@ -4209,11 +4319,11 @@ void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, 
     const u32 nb = std::max(1u, cdiv(q_bound, 1024));
     hipLaunchKernelGGL(classify_a_kernel, dim3(nb), dim3(256), 0, st, q, n_q, ri, qinfo, qloc, bsum);
     hipLaunchKernelGGL(classify_b_kernel, dim3(1), dim3(1024), 0, st, bsum, n_q, n_d, h_words);
-    hipLaunchKernelGGL(classify_c_kernel, dim3(std::max(1u, cdiv(q_bound, 256))), dim3(256), 0, st, q, n_q, qinfo, qloc, bsum, n_d, qd, qrow, sslot);
+    hipLaunchKernelGGL(classify_c_kernel, dim3(std::max(1u, cdiv(q_bound, 256))), dim3(256), 0, st, q, n_q, qinfo, qloc, bsum, n_d, qd, qrow, sslot, ri);
 }
 void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* m_bits, u32 n_pad, u32* m_dirty, u32 rows_bound,
                         const u32* only_if) {
-    const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 256), 2048u));
+    const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks));
     hipLaunchKernelGGL(sparse_fill_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, m_bits, n_pad, m_dirty, only_if);
 }
 void launch_nd_from_nq(hipStream_t st, const u32* n_q, u32* n_d, u32* h_words) {
@@ -4225,7 +4335,7 @@ void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, 
     hipLaunchKernelGGL(pass_hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pair_q, pb, cnt, row_stride);
 }
 void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride,
-                      u32 n_b, u32* gain, const u32* sslot, const RareIndex* ri) {
+                      u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri) {
     const dim3 grid(n_pad / 256, std::max(1u, cdiv(cdiv(rows_bound, 64), kGainWords)));
 #define SKX_GAIN(NB) hipLaunchKernelGGL(gain_dense_kernel<NB>, grid, dim3(256), 0, st, m_bits, m_int, n_pad, n_d, cnt, row_stride, gain)
     switch (n_b) {
@@ -4233,27 +4343,30 @@ void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n
         case 5: SKX_GAIN(5); break; case 6: SKX_GAIN(6); break; case 7: SKX_GAIN(7); break; default: SKX_GAIN(8); break;
     }
 #undef SKX_GAIN
-    if (ri && sslot)
-        hipLaunchKernelGGL(gain_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), 2048u))), dim3(256), 0, st, sslot, n_d, *ri, cnt,
-                           row_stride, n_b, n_pad, gain);
+    // (the walks over the genome lists are bound by the atomics they issue, not by their waves: a grid that fills the chip only keeps
+    // the other streams' kernels -- the next group's sketches -- out of the wave slots: 56 M reads/s with 1832 blocks, measured)
+    if (ri && sslot && gain_s)
+        hipLaunchKernelGGL(gain_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks))), dim3(256), 0, st, sslot, n_d, *ri, cnt,
+                           row_stride, n_b, n_pad, gain_s);
 }
-void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, u32 n_b, u32 n_pad, u64* tab) {
-    hipLaunchKernelGGL(pass_tables_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, prev, gain, n_b, n_pad, tab);
+u32 gain_sparse_stride() { return kGainSparseStride; }
+void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s, u32 n_b, u32 n_pad, u64* tab) {
+    hipLaunchKernelGGL(pass_tables_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, prev, gain, gain_s, n_b, n_pad, tab);
 }
 void launch_cand_select(hipStream_t st, const u64* tab, u32 n_pad, const Species& sp, u32 n_b, u32 top_k, u32 cap, u32* cand, u32* candslot,
-                        u64* tabc, u32* ncand, u32* bad) {
-    hipLaunchKernelGGL(cand_select_kernel, dim3(n_b * sp.n_sp), dim3(1024), 0, st, tab, n_pad, sp, top_k, cap, cand, candslot, tabc, ncand, bad);
+                        u64* tabc, u32* ncand, u32* bad, u32* candmask) {
+    hipLaunchKernelGGL(cand_select_kernel, dim3(n_b * sp.n_sp), dim3(1024), 0, st, tab, n_pad, sp, top_k, cap, cand, candslot, tabc, ncand, bad, candmask);
 }
 void launch_cand_gather_m(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cand, u32 n_pad_c,
                           const u32* bad, u32 n_b, u64* mc, u32 words_c) {
     const u32 words = std::min(words_c, std::max(1u, cdiv(rows_bound, 64)));
     hipLaunchKernelGGL(cand_gather_m_kernel, dim3(cdiv(n_pad_c, 256), words, n_b), dim3(256), 0, st, m_bits, m_int, n_pad, n_d, cand, n_pad_c, bad, mc, words_c);
 }
-void launch_cand_sparse(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const RareIndex& ri, const u32* candslot, u32 n_pad,
-                        u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride, u32 rows_c, u64* rowany_c,
-                        u32 rowany_stride, u32* grp_any_c, u32 n_grp_c) {
-    hipLaunchKernelGGL(cand_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), 1024u)), n_b), dim3(256), 0, st, sslot, n_d, ri, candslot,
-                       n_pad, bad, nqc, smap, smap_stride, mqc, mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
+void launch_cand_sparse(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const RareIndex& ri, const u32* candmask,
+                        const u32* candslot, u32 n_pad, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
+                        u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c) {
+    hipLaunchKernelGGL(cand_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks))), dim3(256), 0, st, sslot, n_d, ri, candmask,
+                       candslot, n_pad, bad, n_b, nqc, smap, smap_stride, mqc, mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
 }
 void launch_cand_publish(hipStream_t st, const u32* bad, u32 force_full, const u32* ncand, const u32* nqc, const u32* n_d, u32 n_b, u32 n_sp,
                          u32 rows_c, u32* mode, u32* any_full, u32* nqc_total, u32* h_pub, u32 seq) {

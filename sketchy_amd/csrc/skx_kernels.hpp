@@ -97,7 +97,7 @@ struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* po
 void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow);
 void launch_rare_fill(hipStream_t st, const u64* mat, u64 n_elems, u32 s, const u64* key, const u32* off, u32* cursor, u32* post, u32 mask);
 // a pass's dictionary split into the hashes the scan looks for (qd ascending, n_d[0] of them: rows [0, n_d[0]) of the bit matrix)
-// and the others (n_d[1]; rows behind, sslot[row - n_d[0]] = key-table slot or 0xFFFFFFFF); qrow[position in q] = row.
+// and the others (n_d[1]; rows from n_d[2] on, sslot[2 i], [2 i + 1] = start and length of row i's genome list); qrow[position in q] = row.
 // q_bound: host's upper bound of *n_q (sizes the grids); qinfo / qloc: [q_bound] scratch; bsum: [q_bound / 1024 + 1] scratch;
 // h_words (page-locked, or NULL): [0] = *n_q, [1] = n_d[0]
 void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, const RareIndex& ri, u32* qinfo, u32* qloc, u32* bsum,
@@ -112,31 +112,34 @@ void launch_nd_from_nq(hipStream_t st, const u32* n_q, u32* n_d, u32* h_words);
 // ---- the table without the ranking, and the candidates of a batch (skx_kernels.hip, "the table without the ranking")
 static const u32 kPassBatchesMax = 8;          // batches of a pass (stream_coalesce)
 static const u32 kCandCap = 1024;              // candidates per species the compact ranking takes (two rank groups)
-static const u32 kCandRows = 32768;            // rows of a compact bit matrix (dense rows + the rare rows some candidate holds)
+static const u32 kCandRows = 131072;           // rows of a compact bit matrix (dense rows + the rare rows some candidate holds)
 struct PassBatches { u32 n; u32 p_off[kPassBatchesMax + 1]; };  // pairs [p_off[b], p_off[b + 1]) of the pass's lists are batch b's
 // cnt[b][row] (zero on entry; row_stride entries per batch) = occurrences of the row among batch b's pairs
 void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, u32* cnt, u32 row_stride);
 // gain[b][g] (zero on entry) += sum over rows of cnt[b][row] * (row's bit for g): dense rows from m_bits (BEFORE the transpose
 // re-zeroes it), the others from the genome lists (ri / sslot, or NULL)
+// gain_s (zero on entry, [n_b][n_pad] entries gain_sparse_stride() words apart): the rare rows' part
 void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt,
-                      u32 row_stride, u32 n_b, u32* gain, const u32* sslot, const RareIndex* ri);
+                      u32 row_stride, u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri);
+u32 gain_sparse_stride();
 // tab[0] = prev, tab[b + 1] = tab[b] + gain[b]   ([n_b + 1][n_pad])
-void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, u32 n_b, u32 n_pad, u64* tab);
+void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s /* or NULL */, u32 n_b, u32 n_pad, u64* tab);
 // per (batch, species): the genomes whose value at the end of the batch reaches the top_k-th best value at its start, in reference
 // order: cand[(b n_sp + sp) cap + i], candslot[b][g] (0xFFFFFFFF: none), tabc[b][sp cap + i] start values, ncand[b n_sp + sp],
 // bad[b] (zero on entry) |= 1 when a species has more than cap
+// candmask[g] (zero on entry) |= 1 << b for every candidate g of batch b
 void launch_cand_select(hipStream_t st, const u64* tab, u32 n_pad, const Species& sp, u32 n_b, u32 top_k, u32 cap, u32* cand, u32* candslot,
-                        u64* tabc, u32* ncand, u32* bad);
+                        u64* tabc, u32* ncand, u32* bad, u32* candmask);
 // mc[b][w][c] = m_bits[w][cand[b][c]] (dense words; n_pad_c = n_sp * cap columns, words_c words per batch)
 void launch_cand_gather_m(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cand,
                           u32 n_pad_c, const u32* bad, u32 n_b, u64* mc, u32 words_c);
 // rare rows of the compact problems: rows behind the dense ones for the hashes some candidate holds (nqc[b] of them, smap[b][.]),
 // their bits into mqc[b] / rowany_c[b] / grp_any_c[b] (all zero on entry); bad[b] |= 2 when they do not fit rows_c
-void launch_cand_sparse(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const RareIndex& ri, const u32* candslot, u32 n_pad,
-                        u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride, u32 rows_c, u64* rowany_c,
-                        u32 rowany_stride, u32* grp_any_c, u32 n_grp_c);
+void launch_cand_sparse(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const RareIndex& ri, const u32* candmask,
+                        const u32* candslot, u32 n_pad, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
+                        u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c);
 // mode[b] = 1 compact / 0 everything, *any_full, nqc_total[b] = rows of the compact problem; h_pub (page-locked): [b] mode,
-// [8 + b] largest candidate count, [16] any_full, [17] = seq (written last)
+// [8 + b] largest candidate count, [16] any_full, [18] = n_b, [17] = seq (written last)
 void launch_cand_publish(hipStream_t st, const u32* bad, u32 force_full, const u32* ncand, const u32* nqc, const u32* n_d, u32 n_b, u32 n_sp,
                          u32 rows_c, u32* mode, u32* any_full, u32* nqc_total, u32* h_pub, u32 seq);
 void launch_m_clear(hipStream_t st, u64* m_bits, u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, const u32* any_full);

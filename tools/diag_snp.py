@@ -26,8 +26,11 @@ for mode in modes:
         S.reset()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        call_ms = []
         for i, (b, o) in enumerate(batches):
+            tq = time.perf_counter()
             S.enqueue_device(b.data_ptr(), o.data_ptr(), B, B * L, ti.data_ptr(), ts.data_ptr())
+            call_ms.append(round(1e3 * (time.perf_counter() - tq), 2))
             if rep == 0 and i in (0, 1, 2, 3, 7, 15):
                 S.sync()
                 t = S.table().astype(np.int64)
@@ -41,6 +44,8 @@ for mode in modes:
                 prev = t
         S.sync()
         dt = time.perf_counter() - t1
+        if rep == 2:
+            print(f"[{mode}] host ms per enqueue call:", call_ms, flush=True)
         if rep:
             print(f"[{mode}] rep {rep}: {K * B / dt / 1e6:.1f} M reads/s ({1e3 * dt / K:.3f} ms per batch)", flush=True)
     S.set_profiling(1)
