@@ -242,6 +242,7 @@ struct skx_ref {
     u32 n_species = 0;
     std::vector<u32> sp_n, sp_g0, sp_real0;  // real genomes / first padded index / first index in the caller's order
     u32 min_species = 0;                     // smallest species (bounds top_k)
+    u32 max_species = 0;                     // largest species (more genomes than a compact ranking takes: a fresh table cannot rank compactly)
     u32 *d_sp_g0 = nullptr, *d_sp_n = nullptr, *d_grp_sp = nullptr;
     u32* d_real2pad = nullptr;               // [n_genomes] caller's genome index -> padded index
     u64* d_mat = nullptr;  // [n_tiles][s][256]
@@ -313,6 +314,7 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
         for (u32 sp = 0; sp < n_species; ++sp) {
             r->sp_n.push_back(n_genomes[sp]); r->sp_g0.push_back(g0); r->sp_real0.push_back(real0);
             r->min_species = std::min(r->min_species, n_genomes[sp]);
+            r->max_species = std::max(r->max_species, n_genomes[sp]);
             g0 += (n_genomes[sp] + kGroupGenomes - 1) / kGroupGenomes * kGroupGenomes;
             real0 += n_genomes[sp];
         }
@@ -720,6 +722,8 @@ struct skx_stream {
     // for, position in Q -> row, key-table slots of the other rows, scratch of the classify kernels; d_nd = {dense rows, other rows}
     u64* d_qd = nullptr;
     u32 *d_qrow = nullptr, *d_sslot = nullptr, *d_qinfo = nullptr, *d_qloc = nullptr, *d_cls_bsum = nullptr;
+    u32* h_lcount = nullptr;   // page-locked: {candidates the latest batch of a legacy pass would have had, its sequence number}
+    u32 lcount_seq = 0, lcount_seen = 0, lcount_floor = 0;  // (floor: counts older than the last reset do not count)
     u32* h_nq_sink = nullptr;  // page-locked: where the live sample of a compact chain goes (nobody reads it)
     u32* h_nd = nullptr;     // page-locked: [2 b] = |Q| of buffer set b's latest pass, [2 b + 1] = its dense rows
     // ---- the table without the ranking, the candidates of a batch (skx_kernels.hip; scan stream unless said otherwise)
@@ -761,10 +765,13 @@ struct skx_stream {
     // everything is always exact; a sample that has just found its leader loses one pass of the compact ranking.)
     bool hint_all_overflow = false;
     u32 hint_seq = 0;  // sequence number of the pass the hint was taken from
+    u32 passes_since_fresh = 0;  // passes queued since the table was last all zeros
+    bool fresh_table = true;  // nothing has been added to the table since the stream was created / reset: every genome ties at zero
     u32 legacy_run = 0;  // passes in a row that took the table out of their ranking chains (rounds 1-4's way) instead
     u64 batches_compact = 0, batches_full = 0;  // batches ranked on their candidates / on everything (statistic)
     bool have_split_hint = false;
     double nd_frac = 1.0;    // dense rows / |Q| of the latest pass whose dictionary is known: which scan variant a pass gets
+    u32 qcap_max = 0;        // rows the matrices may grow to (an eighth of the free device memory at creation)
     bool qcap_auto = false;  // no "stream_query_rows" policy: the matrices grow when a batch holds more distinct hashes (grow_query_rows)
     u64 qrows_grown = 0;     // how often they did (statistic)
     u32 coalesce = 1;    // enqueued batches that may share a pass (policy stream_coalesce at creation)
@@ -935,6 +942,7 @@ static void stream_free(skx_stream* st) {
     if (st->h_nq) (void)hipHostFree(st->h_nq);
     if (st->h_nd) (void)hipHostFree(st->h_nd);
     if (st->h_nq_sink) (void)hipHostFree(st->h_nq_sink);
+    if (st->h_lcount) (void)hipHostFree(st->h_lcount);
     if (st->h_chk_base) (void)hipHostFree(st->h_chk_base);
     for (int i = 0; i < kSides; ++i) {
         free_side(st, i);
@@ -1147,6 +1155,13 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     qc = (qc + 63) / 64 * 64;
     st->qcap = (u32)qc;
     st->qcap_auto = rows_policy == 0 && !dense_queries;
+    st->qcap_max = st->qcap;
+    if (st->qcap_auto) {
+        size_t mem_free = 0, mem_total = 0;
+        (void)hipMemGetInfo(&mem_free, &mem_total);
+        const u64 per_row = (u64)n_pad / 8 + 2ull * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8 + 3ull * skx::kPassBatchesMax * 4 + 8;
+        st->qcap_max = (u32)std::max<u64>(st->qcap, std::min<u64>(st->pcap, (u64)(mem_free / 8) / per_row) / 64 * 64);
+    }
     static const u32 coalesce_env = skx::knob("SKX_COALESCE") ? (u32)atoi(skx::knob("SKX_COALESCE")) : 0u;  // experiment knob
     st->coalesce = coalesce_env ? std::min<u32>((u32)kGroupMax, std::max(1u, coalesce_env)) : g_stream_coalesce.load();
     st->group_cap = st->coalesce;
@@ -1352,6 +1367,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipHostMalloc((void**)&st->h_nd, 4 * 4, hipHostMallocCoherent));
     memset(st->h_nd, 0, 4 * 4);
     SCHK(hipHostMalloc((void**)&st->h_nq_sink, 4 * 4, hipHostMallocCoherent));
+    SCHK(hipHostMalloc((void**)&st->h_lcount, 4 * 4, hipHostMallocCoherent));
+    memset(st->h_lcount, 0, 4 * 4);
     if (ref->d_kt_key) {  // the split dictionary of a pass (rare-hash index)
         SCHK(hipMalloc(&st->d_qd, (size_t)st->pcap * 8));
         SCHK(hipMalloc(&st->d_qrow, (size_t)st->pcap * 4));
@@ -1748,11 +1765,19 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // A stream whose batches ALL have more candidates than a compact ranking takes (the bench's near-tie of 40 000 genomes) gains
     // nothing from knowing its tables early: three passes out of four then take the table out of their ranking chains, as in rounds
     // 1-4 (no row counts, no gains, no candidate selection: ~0.65 ms of scan-stream work per C2 pass, 9 % of the reads/s next to the
-    // sketches); every fourth pass looks at the candidates again.
-    static const int legacy_env = skx::knob("SKX_TABLE_LEGACY") ? atoi(skx::knob("SKX_TABLE_LEGACY")) : 3;  // experiment knob: passes in a row
+    // sketches) -- and every such chain counts what its batch's candidates would have been (cand_count_kernel: two reads of the
+    // table), so the stream notices when a leader has emerged.
+    static const int legacy_env = skx::knob("SKX_TABLE_LEGACY") ? atoi(skx::knob("SKX_TABLE_LEGACY")) : 1 << 30;  // experiment knob: passes in a row (0: never)
     static const int cand_env0 = skx::knob("SKX_CAND") ? atoi(skx::knob("SKX_CAND")) : 1;
-    const bool legacy = update_table && all_ranked && cand_env0 && st->hint_all_overflow && (int)st->legacy_run < legacy_env;
+    // (... and the FIRST pass of a sample: on a table of zeros every genome of a species is a candidate of the first batch, whatever
+    // follows -- with more genomes than a compact ranking takes, the pass that would only find that out is not worth its wait)
+    const bool fresh_overflow = st->fresh_table && ref->max_species > skx::kCandCap;
+    // (the SECOND pass of a sample looks for itself: the counts of the first pass's chains are mostly still on their way when it is
+    // queued, and the first batches' say "everything" in any sample)
+    const bool legacy = update_table && all_ranked && cand_env0 && legacy_env > 0 &&
+                        (fresh_overflow || (st->hint_all_overflow && st->passes_since_fresh != 1 && (int)st->legacy_run < legacy_env));
     st->legacy_run = legacy ? st->legacy_run + 1 : 0;
+    if (update_table) { st->passes_since_fresh = st->fresh_table ? 1 : st->passes_since_fresh + 1; st->fresh_table = false; }
     if (update_table && !legacy && st->cum_writer) {  // (the table the last chain of a legacy pass left: the gains are added to it)
         HIPCHK(hipStreamWaitEvent(hs, st->cum_writer->ev_cum, 0));
         st->cum_writer = nullptr;
@@ -1854,6 +1879,14 @@ static int queue_one(skx_stream* st, skx_stream::PassChains& pc, bool block, boo
 // hint_all_overflow from the most recent pass whose candidates have been published (either buffer set; forced passes publish what
 // their candidates WOULD have been): did every batch have more candidates than the compact ranking takes?
 static void update_cand_hint(skx_stream* st) {
+    {   // the latest batch of a legacy pass whose count has arrived
+        volatile u32* hl = st->h_lcount;
+        const u32 seq = hl[1], count = hl[0];
+        if (seq != st->lcount_seen && (int)(seq - st->lcount_floor) > 0 && hl[1] == seq) {
+            st->hint_all_overflow = count > skx::kCandCap && st->top_k != 0;
+            st->lcount_seen = seq;
+        }
+    }
     for (auto& q : st->ps) {
         volatile u32* hp = q.h_pub;
         const u32 seq = hp[2 * skx::kPassBatchesMax + 1], n_b = hp[2 * skx::kPassBatchesMax + 2];
@@ -2030,7 +2063,11 @@ static int queue_one(skx_stream* st, skx_stream::PassChains& pc, bool block, boo
         // a compact chain's sample says nothing about the full problem and is only re-armed)
         if (prune_k) skx::launch_store_host_words(ls, compact ? st->h_nq_sink : st->h_nq + 2, L.d_live_ctr, 2);
         st->rank_seq += 1;
-        if (legacy) { st->tab_cur = tab_next; st->d_cum = cum_out; st->cum_writer = &L; }
+        if (legacy) {
+            // (what the batch's candidates would have been, for the passes to come: a hint, a few batches stale when it is read)
+            skx::launch_cand_count(ls, cum_in, cum_out, spc, st->top_k, st->h_lcount, ++st->lcount_seq);
+            st->tab_cur = tab_next; st->d_cum = cum_out; st->cum_writer = &L;
+        }
         if (top1_fast) {
             skx::launch_rank_seg_top1(ls, sub_pair_q, sub_pair_r, sub_poff, sub_base, 0, n_reads, c_mq, c_pad, c_rows,
                                       c_spc, cum_in, L.d_rel, L.d_cand_sum, L.d_cand_idx, d_inc,
@@ -2259,7 +2296,8 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     if (joins && st->ppr_est > 0.0) {  // would the group still fit a pass?  (a group that does not is un-shared at a price: batch_back_group)
         u64 reads = pb.n_reads;
         for (int i = 0; i < st->n_pend; ++i) reads += st->pend[i].n_reads;
-        joins = reads * st->ppr_est * 1.25 <= (double)st->pcap && reads * st->qpr_est * 1.25 <= (double)st->qcap;
+        // (distinct hashes: what the matrices can GROW to counts -- batch_back_group makes the room when the group closes)
+        joins = reads * st->ppr_est * 1.25 <= (double)st->pcap && reads * st->qpr_est * 1.25 <= (double)std::max(st->qcap, st->qcap_max);
     }
     for (int i = 0; joins && i < st->n_pend; ++i) {
         const PendingBatch& q = st->pend[i];
@@ -2514,7 +2552,8 @@ static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch
     const u32 q_rows = (st->h_chk_base + 16 * g[n - 1].side)[10];  // (the last summary counts the keys of the joint set)
     const bool clean = fits;
     if (clean && q_rows != 0xFFFFFFFFu && q_rows > st->qcap && pairs <= st->pcap)
-        SKXCHK(grow_query_rows(st, (u64)q_rows + q_rows / 4));  // (the joint set of the group: see grow_query_rows)
+        // (the joint set of the group, scaled to a full group when this one was smaller: see grow_query_rows)
+        SKXCHK(grow_query_rows(st, ((u64)q_rows + q_rows / 4) * std::max<u32>(1u, (st->coalesce + (u32)n - 1) / (u32)n)));
     fits = fits && pairs <= st->pcap && q_rows != 0xFFFFFFFFu && q_rows <= st->qcap;
     u64 reads = 0;
     for (int i = 0; i < n; ++i) reads += g[i].n_reads;
@@ -2998,6 +3037,7 @@ SKX_API int skx_stream_table_add(skx_stream* st, const uint64_t* add) {
     const u32 n = st->ref->n_genomes;
     HIPCHK(hipMemcpyAsync(st->d_tab_tmp, add, (size_t)n * 8, hipMemcpyHostToDevice, st->hs2));
     skx::launch_add_table(st->hs2, st->d_cum, st->d_tab_tmp, n, st->ref->d_real2pad);
+    st->fresh_table = false;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st->hs2));  // `add` is only borrowed for the call
     return SKX_OK;
@@ -3016,6 +3056,8 @@ SKX_API int skx_stream_reset(skx_stream* st) {
     st->hint_all_overflow = false;     // (... and nothing is known about its candidates)
     st->hint_seq = st->cand_seq;
     st->legacy_run = 0;
+    st->lcount_floor = st->lcount_seq;
+    st->fresh_table = true;
     st->cum_writer = nullptr;          // (everything is synchronised)
     return SKX_OK;
 }

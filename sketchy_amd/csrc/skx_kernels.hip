@@ -3837,23 +3837,9 @@ __device__ __forceinline__ u32 block1024_sum_u32(u32 v, u32* sh /* [16] */) {
     for (int i = 0; i < 16; ++i) r += sh[i];
     return r;
 }
-// One workgroup per (batch, species): theta = the k-th best value of the species as the batch begins; candidates = real genomes
-// whose value as it ENDS reaches theta, in reference order.  cand[(b n_sp + sp) cap + i] = padded genome index, candslot[b][g] =
-// sp cap + i (or none), tabc[b][sp cap + i] = the genome's start value (slots behind the candidates: 0, never ranked: ncand bounds
-// the species), ncand[b n_sp + sp] = min(count, cap), bad[b] |= 1 when a species has more than cap.
-__global__ __launch_bounds__(1024) void cand_select_kernel(const u64* __restrict__ tab, u32 n_pad, Species sp, u32 top_k, u32 cap,
-                                                           u32* __restrict__ cand, u32* __restrict__ candslot, u64* __restrict__ tabc,
-                                                           u32* __restrict__ ncand, u32* __restrict__ bad, u32* __restrict__ candmask) {
-    __builtin_amdgcn_s_setprio(3);
-    __shared__ u64 sh64[16];
-    __shared__ u32 sh32[16];
-    __shared__ u32 wbase[17];
-    const u32 b = blockIdx.x / sp.n_sp, spi = blockIdx.x % sp.n_sp, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const u32 g0 = sp.g0[spi], n = sp.n[spi];
-    const u32 g_end = spi + 1u < sp.n_sp ? sp.g0[spi + 1u] : n_pad;
-    const u64* t0 = tab + (size_t)b * n_pad;
-    const u64* t1 = t0 + n_pad;
-    // theta: at most top_k rounds of "largest value below the previous one", counting multiplicities
+// the top_k-th best value among t0[g0 .. g0 + n): at most top_k rounds of "largest value below the previous one", counting multiplicities
+__device__ __forceinline__ u64 species_theta(const u64* __restrict__ t0, u32 g0, u32 n, u32 top_k, u64* sh64, u32* sh32) {
+    const u32 tid = threadIdx.x;
     u64 theta = 0, prev = 0;
     u32 remaining = max(top_k, 1u);
     bool first = true;
@@ -3876,6 +3862,48 @@ __global__ __launch_bounds__(1024) void cand_select_kernel(const u64* __restrict
         first = false;
         theta = 0;
     }
+    return theta;
+}
+// How many candidates did a batch have whose ranking ran on everything (legacy passes: t0 / t1 = the table before / after it)?  The
+// largest count over the species goes to the host (h_out[0], then h_out[1] = seq): a hint for the NEXT passes only.
+__global__ __launch_bounds__(1024) void cand_count_kernel(const u64* __restrict__ t0, const u64* __restrict__ t1, Species sp, u32 top_k,
+                                                          u32* __restrict__ d_max, volatile u32* __restrict__ h_out, u32 seq) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ u64 sh64[16];
+    __shared__ u32 sh32[16];
+    u32 worst = 0;
+    for (u32 spi = 0; spi < sp.n_sp; ++spi) {
+        const u32 g0 = sp.g0[spi], n = sp.n[spi];
+        const u64 theta = species_theta(t0, g0, n, top_k, sh64, sh32);
+        u32 c = 0;
+        for (u32 g = g0 + threadIdx.x; g < g0 + n; g += 1024u) c += t1[g] >= theta ? 1u : 0u;
+        worst = max(worst, block1024_sum_u32(c, sh32));
+    }
+    if (threadIdx.x == 0u) {
+        (void)d_max;
+        h_out[0] = worst;
+        __threadfence_system();
+        h_out[1] = seq;
+        __threadfence_system();
+    }
+}
+// One workgroup per (batch, species): theta = the k-th best value of the species as the batch begins; candidates = real genomes
+// whose value as it ENDS reaches theta, in reference order.  cand[(b n_sp + sp) cap + i] = padded genome index, candslot[b][g] =
+// sp cap + i (or none), tabc[b][sp cap + i] = the genome's start value (slots behind the candidates: 0, never ranked: ncand bounds
+// the species), ncand[b n_sp + sp] = min(count, cap), bad[b] |= 1 when a species has more than cap.
+__global__ __launch_bounds__(1024) void cand_select_kernel(const u64* __restrict__ tab, u32 n_pad, Species sp, u32 top_k, u32 cap,
+                                                           u32* __restrict__ cand, u32* __restrict__ candslot, u64* __restrict__ tabc,
+                                                           u32* __restrict__ ncand, u32* __restrict__ bad, u32* __restrict__ candmask) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ u64 sh64[16];
+    __shared__ u32 sh32[16];
+    __shared__ u32 wbase[17];
+    const u32 b = blockIdx.x / sp.n_sp, spi = blockIdx.x % sp.n_sp, tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 g0 = sp.g0[spi], n = sp.n[spi];
+    const u32 g_end = spi + 1u < sp.n_sp ? sp.g0[spi + 1u] : n_pad;
+    const u64* t0 = tab + (size_t)b * n_pad;
+    const u64* t1 = t0 + n_pad;
+    const u64 theta = species_theta(t0, g0, n, top_k, sh64, sh32);
     // ordered compaction
     u32 base = 0;
     u32* my_cand = cand + (size_t)(b * sp.n_sp + spi) * cap;
@@ -4356,6 +4384,9 @@ void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const 
 void launch_cand_select(hipStream_t st, const u64* tab, u32 n_pad, const Species& sp, u32 n_b, u32 top_k, u32 cap, u32* cand, u32* candslot,
                         u64* tabc, u32* ncand, u32* bad, u32* candmask) {
     hipLaunchKernelGGL(cand_select_kernel, dim3(n_b * sp.n_sp), dim3(1024), 0, st, tab, n_pad, sp, top_k, cap, cand, candslot, tabc, ncand, bad, candmask);
+}
+void launch_cand_count(hipStream_t st, const u64* t0, const u64* t1, const Species& sp, u32 top_k, u32* h_out, u32 seq) {
+    hipLaunchKernelGGL(cand_count_kernel, dim3(1), dim3(1024), 0, st, t0, t1, sp, top_k, nullptr, h_out, seq);
 }
 void launch_cand_gather_m(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cand, u32 n_pad_c,
                           const u32* bad, u32 n_b, u64* mc, u32 words_c) {

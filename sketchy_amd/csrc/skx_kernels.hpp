@@ -130,6 +130,8 @@ void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const 
 // candmask[g] (zero on entry) |= 1 << b for every candidate g of batch b
 void launch_cand_select(hipStream_t st, const u64* tab, u32 n_pad, const Species& sp, u32 n_b, u32 top_k, u32 cap, u32* cand, u32* candslot,
                         u64* tabc, u32* ncand, u32* bad, u32* candmask);
+// candidates a batch would have had (t0 / t1: the table before / after it): the largest count over the species -> h_out[0], seq -> h_out[1]
+void launch_cand_count(hipStream_t st, const u64* t0, const u64* t1, const Species& sp, u32 top_k, u32* h_out, u32 seq);
 // mc[b][w][c] = m_bits[w][cand[b][c]] (dense words; n_pad_c = n_sp * cap columns, words_c words per batch)
 void launch_cand_gather_m(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cand,
                           u32 n_pad_c, const u32* bad, u32 n_b, u64* mc, u32 words_c);

@@ -199,13 +199,18 @@ def test_forced_scan_kernel_variants(gpu, split, big):
                                    {"SKX_RANK_LANES": "4", "SKX_PASS_READS": "100"}, {"SKX_SPEC_INSERT": "0"}, {"SKX_PIPELINE": "4"},
                                    {"SKX_TWO_LEVEL": "1"}, {"SKX_TWO_LEVEL": "0"}, {"SKX_TWO_LEVEL": "1", "SKX_RANK_LIVE": "0"},
                                    {"SKX_SCAN_NT": "0"}, {"SKX_SCAN_NT": "6"}, {"SKX_SCAN_NT": "0", "SKX_PASS_READS": "100"},
-                                   {"SKX_SCAN_BIGSLICE": "1"}, {"SKX_SCAN_BIGSLICE": "1", "SKX_PASS_READS": "64"}])
+                                   {"SKX_SCAN_BIGSLICE": "1"}, {"SKX_SCAN_BIGSLICE": "1", "SKX_PASS_READS": "64"},
+                                   {"SKX_CAND": "0"}, {"SKX_CAND": "0", "SKX_PASS_READS": "64"}, {"SKX_RARE_MAX": "0"}, {"SKX_RARE_MAX": "3"},
+                                   {"SKX_RARE_MAX": "0", "SKX_CAND": "0"}, {"SKX_TABLE_LEGACY": "0"}, {"SKX_TABLE_LEGACY": "100"},
+                                   {"SKX_RARE_MAX": "100000"}])
 def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     """Several passes per push (the path that needs the per-read pair offsets on the host), the pipeline depths, the
     unfiltered dictionary, the ranking without its per-word live flags, the ranking lanes forced to one / four, the
     pair gather on the scan stream, the ranking's counts in two levels / one and the lean scan's results as slabs (SKX_SCAN_NT=0) /
-    straight into M (6; the default), and the lean scan's instance for large slices (SKX_SCAN_BIGSLICE=1: 510 entries, three-entry
-    probe) all give the oracle's rows."""
+    straight into M (6; the default), the lean scan's instance for large slices (SKX_SCAN_BIGSLICE=1: 510 entries, three-entry
+    probe), and round 5's machinery switched off or forced -- no compact ranking on the candidates (SKX_CAND=0), no rare-hash index or
+    one for nearly every hash (SKX_RARE_MAX), the table always / never out of the ranking chains (SKX_TABLE_LEGACY) -- all give the
+    oracle's rows."""
     from helpers import exp_env
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=exp_env(**knobs),
                          capture_output=True, text=True)

@@ -93,6 +93,41 @@ def test_c1_full_config_every_row(gpu, mode):
         assert exp["topk_idx"][-1, 0] == ref["truth_index"]
 
 
+@pytest.mark.parametrize("top", [1, 3])
+def test_candidates_shrink_and_grow_mid_stream(gpu, top):
+    """Round 5: the per-read ranking of a batch runs on its CANDIDATES (genomes whose value at the end of the batch reaches the
+    top-th best value at its start) when a species has at most 1024 of them, else on every genome.  Three unrelated families of
+    900 genomes: a fresh table has 2 700 candidates (full ranking), reads of family 0 soon leave its 900 (compact), then reads
+    of family 1 make it catch up -- both families are candidates again (full), until family 1 leads alone (compact).  Every
+    row and the table against the oracle; both kinds of batches must have occurred.  Enqueued in uneven batches that share passes."""
+    from sketchy_amd import api
+    from test_gpu_enqueue import _enqueue_stream
+    fams = [workload(900, 400, 2600, read_len=500, rng_seed=4000 + i) for i in range(3)]
+    hashes = np.concatenate([f[0]["ref"] for f in fams])
+    perm = np.random.default_rng(9).permutation(len(hashes))
+    hashes = np.ascontiguousarray(hashes[perm])
+
+    def reads_of(i, a, b):
+        bs, of = fams[i][1], fams[i][2]
+        return [bs[int(of[j]):int(of[j + 1])].tobytes() for j in range(a, b)]
+    reads = reads_of(0, 0, 1200) + reads_of(1, 0, 2600) + reads_of(2, 0, 300) + reads_of(1, 0, 400)
+    bases, offsets = pack_reads(reads)
+    exp = orc.stream_fast(16, 0, 400, hashes, None, bases, offsets, top_k=top)
+    R = api.ReferenceSketch(hashes)
+    n = len(reads)
+    cuts = list(range(0, n, 300)) + [n]
+    S = api.SumOfSharedHashes(R, top=top, max_batch_reads=300, max_batch_bases=int(np.max(np.diff(offsets[cuts].astype(np.int64)))))
+    idx, val = _enqueue_stream(S, bases, offsets, cuts, top)
+    np.testing.assert_array_equal(val, exp["topk_sum"])
+    np.testing.assert_array_equal(idx, exp["topk_idx"])
+    np.testing.assert_array_equal(S.table(), exp["cum"])
+    st = S.stats()
+    assert st["batches_compact"] > 0 and st["batches_full"] > 0, st
+    fam_of = perm // 900
+    lead = fam_of[exp["topk_idx"][:, 0]]
+    assert lead[1100] == 0 and lead[-1] == 1
+
+
 def test_multiple_pushes_continue_the_table(gpu):
     ref, bases, offsets = workload(300, 500, 257, rng_seed=7)
     check(ref, bases, offsets, top=3, batches=5)

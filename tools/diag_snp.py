@@ -17,6 +17,7 @@ for mode in modes:
     g = torch.from_numpy(src).to("cuda:0")
     print(f"[{mode}] reference in {time.time() - t0:.1f} s", flush=True)
     R = api.ReferenceSketch([ref["ref"]], [ref["col_len"]], k=16, seed=0, device=0)
+    print(f"[{mode}] rare-hash index: {R.rare_index}", flush=True)
     S = api.SumOfSharedHashes(R, top=1, max_batch_reads=B, max_batch_bases=B * L)
     ti = torch.zeros((B, 1), dtype=torch.int32, device="cuda:0"); ts = torch.zeros((B, 1), dtype=torch.int64, device="cuda:0")
     batches = [synth.make_reads_torch(g, B, L, err=0.05, rng_seed=1000 + i, device="cuda:0") for i in range(K)]
