@@ -264,7 +264,11 @@ struct skx_ref {
     u32 *d_kt_cnt = nullptr, *d_kt_off = nullptr, *d_post = nullptr;
     u32 kt_mask = 0, rare_max = 0;
     u64 n_keys = 0, n_rare_keys = 0, n_postings = 0;  // distinct hashes (exact), of those rare, entries of their lists
-    skx::RareIndex rare_index() const { return skx::RareIndex{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask}; }
+    // long lists (more than 8 genomes) also as bit rows over the genomes (skx_kernels.hip, "long lists as bit rows")
+    u64* d_mlong = nullptr;
+    u32 *d_lid = nullptr, *d_lslot = nullptr;
+    u64 n_long = 0;
+    skx::RareIndex rare_index() const { return skx::RareIndex{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask, d_mlong, d_lid, d_lslot, n_pad / 64}; }
     skx::KmerFilter kmer_filter() const { return skx::KmerFilter{d_kf, kf_shift}; }
     skx::Species species() const { return skx::Species{d_sp_g0, d_sp_n, d_grp_sp, n_species}; }
 };
@@ -276,6 +280,7 @@ static void ref_free(skx_ref* r) {
     (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h); (void)hipFree(r->d_filt); (void)hipFree(r->d_kf);
     (void)hipFree(r->d_sp_g0); (void)hipFree(r->d_sp_n); (void)hipFree(r->d_grp_sp); (void)hipFree(r->d_real2pad);
     (void)hipFree(r->d_kt_key); (void)hipFree(r->d_kt_cnt); (void)hipFree(r->d_kt_off); (void)hipFree(r->d_post);
+    (void)hipFree(r->d_mlong); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot);
     delete r;
 }
 
@@ -500,6 +505,27 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                     ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
                 }
                 if (ok) { r->kt_mask = (u32)(slots - 1); r->rare_max = rare_max; r->n_keys = keys; r->n_rare_keys = rare; r->n_postings = total; }
+                // long lists as bit rows over the genomes (at most an eighth of the free memory; without them the lists are walked)
+                static const int mlong_env = skx::knob("SKX_LONG_ROWS") ? atoi(skx::knob("SKX_LONG_ROWS")) : 1;  // experiment knob
+                if (ok && mlong_env) {
+                    std::vector<u32> lid(slots, 0xFFFFFFFFu), lslot;
+                    for (u64 i = 0; i < slots; ++i)
+                        if (off[i] != 0xFFFFFFFFu && cnt[i] > 8u) { lid[i] = (u32)lslot.size(); lslot.push_back((u32)i); }
+                    const u64 n_long = lslot.size(), row_bytes = (u64)r->n_pad / 8;
+                    size_t mem_free = 0, mem_total = 0;
+                    (void)hipMemGetInfo(&mem_free, &mem_total);
+                    bool lok = n_long > 0 && n_long * row_bytes <= mem_free / 8 &&
+                               hipMalloc(&r->d_mlong, n_long * row_bytes) == hipSuccess && hipMemset(r->d_mlong, 0, n_long * row_bytes) == hipSuccess &&
+                               hipMalloc(&r->d_lid, slots * 4) == hipSuccess && hipMalloc(&r->d_lslot, n_long * 4) == hipSuccess &&
+                               hipMemcpy(r->d_lid, lid.data(), slots * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                               hipMemcpy(r->d_lslot, lslot.data(), n_long * 4, hipMemcpyHostToDevice) == hipSuccess;
+                    if (lok) {
+                        skx::launch_mlong_build(nullptr, r->d_lslot, (u32)n_long, r->d_kt_off, r->d_kt_cnt, r->d_post, r->d_mlong, r->n_pad / 64);
+                        lok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                    }
+                    if (lok) r->n_long = n_long;
+                    else { (void)hipFree(r->d_mlong); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot); r->d_mlong = nullptr; r->d_lid = r->d_lslot = nullptr; (void)hipGetLastError(); }
+                }
             }
             (void)hipFree(d_over); (void)hipFree(d_cursor);
             if (!ok) drop();
@@ -588,7 +614,7 @@ SKX_API int skx_ref_rare_index(const skx_ref* ref, uint64_t* n_keys, uint64_t* n
     if (n_keys) *n_keys = on ? ref->n_keys : 0;
     if (n_rare_keys) *n_rare_keys = on ? ref->n_rare_keys : 0;
     if (n_postings) *n_postings = on ? ref->n_postings : 0;
-    if (bytes) *bytes = on ? ((u64)ref->kt_mask + 1) * 16 + std::max<u64>(ref->n_postings, 1) * 4 : 0;
+    if (bytes) *bytes = on ? ((u64)ref->kt_mask + 1) * 16 + std::max<u64>(ref->n_postings, 1) * 4 + (ref->d_mlong ? ref->n_long * (ref->n_pad / 8 + 4) + ((u64)ref->kt_mask + 1) * 4 : 0) : 0;
     return SKX_OK;
 }
 SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
@@ -732,6 +758,11 @@ struct skx_stream {
     u32 *d_gain_s = nullptr;     // the rare rows' part: [kPassBatchesMax][n_pad] entries gain_sparse_stride() words apart (references with the index)
     u32 *d_candslot = nullptr;   // [kPassBatchesMax][n_pad] candidate slot of a genome (or none)
     u32 *d_candmask = nullptr;   // [n_pad] batches of the pass a genome is a candidate of
+    // long-list rows of a pass (references whose rare-hash index holds bit rows): the rows of every batch, their gains, the candidates by word
+    uint2 *d_lrow = nullptr;     // [kPassBatchesMax][qcap + 128]
+    u32 *d_nlrow = nullptr, *d_gain_l = nullptr, *d_cbase = nullptr, *d_cwl = nullptr, *d_ncwl = nullptr;
+    u64 *d_cw = nullptr;
+    skx::LongRows long_rows() const { return skx::LongRows{d_lrow, d_nlrow, qcap + 128}; }
     u32 *d_cbad = nullptr, *d_nqc = nullptr;  // [kPassBatchesMax] why a batch cannot rank compactly / mapped rare rows
     u32 *d_spc_g0 = nullptr, *d_spc_grp = nullptr;  // Species layout of the compact problems: kCandCap slots per species
     u32 n_pad_c = 0, n_grp_c = 0, cand_seq = 0;
@@ -926,7 +957,7 @@ static void stream_free(skx_stream* st) {
                     st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1],
                     st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum,
-                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp};
+                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_lrow, st->d_nlrow, st->d_gain_l, st->d_cbase, st->d_cwl, st->d_ncwl, st->d_cw, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp};
     for (auto& q : st->ps) {
         for (void* x : {(void*)q.tab, (void*)q.cand, (void*)q.tabc, (void*)q.ncand, (void*)q.mode, (void*)q.any_full, (void*)q.nqc_total, (void*)q.mc, (void*)q.mqc,
                         (void*)q.rowany_c, (void*)q.grp_any_c, (void*)q.smap, (void*)q.pair_qc, (void*)q.nd}) (void)hipFree(x);
@@ -1387,6 +1418,15 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         if (ref->d_kt_key) SCHK(hipMalloc(&st->d_gain_s, (size_t)nb * n_pad * 4 * skx::gain_sparse_stride()));
         SCHK(hipMalloc(&st->d_candslot, (size_t)nb * n_pad * 4));
         SCHK(hipMalloc(&st->d_candmask, (size_t)n_pad * 4));
+        if (ref->d_mlong) {
+            SCHK(hipMalloc(&st->d_lrow, (size_t)nb * ((size_t)st->qcap + 128) * 8));
+            SCHK(hipMalloc(&st->d_nlrow, 64));
+            SCHK(hipMalloc(&st->d_gain_l, (size_t)nb * n_pad * 4));
+            SCHK(hipMalloc(&st->d_cw, (size_t)nb * (n_pad / 64) * 8));
+            SCHK(hipMalloc(&st->d_cbase, (size_t)nb * (n_pad / 64) * 4));
+            SCHK(hipMalloc(&st->d_cwl, (size_t)nb * st->n_pad_c * 4));
+            SCHK(hipMalloc(&st->d_ncwl, 64));
+        }
         SCHK(hipMalloc(&st->d_cbad, 64));
         SCHK(hipMalloc(&st->d_nqc, 64));
         std::vector<u32> g0c(n_sp), grpc(st->n_grp_c);
@@ -1530,19 +1570,21 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     size_t mem_free = 0, mem_total = 0;
     HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
     const u64 per_row = (u64)n_pad / 8 * (st->d_mint ? 2 : 1) + 2 * mq_words * 8 + 2 * (u64)(n_pad / (skx::kRankWords * 64)) / 8 + 1 +
-                        3ull * skx::kPassBatchesMax * 4;  // (+ the per-batch row counters and the two rare-row maps)
+                        5ull * skx::kPassBatchesMax * 4;  // (+ the per-batch row counters, the two rare-row maps, the long-row lists)
     u64 rows = std::min<u64>(want_rows, (u64)(mem_free / 8) / per_row);
     rows = std::min<u64>(rows, st->pcap) / 64 * 64;
     if (rows <= st->qcap) return SKX_OK;  // no room (or nothing to gain): the batch is cut into passes as before
     u64 *m = nullptr, *mint = nullptr, *mq[2] = {nullptr, nullptr}, *ra[2] = {nullptr, nullptr};
     u32 *wb[2] = {nullptr, nullptr}, *cnt = nullptr, *sm[2] = {nullptr, nullptr};
-    auto undo = [&]() { for (void* q : {(void*)m, (void*)mint, (void*)mq[0], (void*)mq[1], (void*)ra[0], (void*)ra[1], (void*)wb[0], (void*)wb[1], (void*)cnt, (void*)sm[0], (void*)sm[1]}) if (q) (void)hipFree(q); (void)hipGetLastError(); };
+    uint2* lrow = nullptr;
+    auto undo = [&]() { for (void* q : {(void*)m, (void*)mint, (void*)mq[0], (void*)mq[1], (void*)ra[0], (void*)ra[1], (void*)wb[0], (void*)wb[1], (void*)cnt, (void*)sm[0], (void*)sm[1], (void*)lrow}) if (q) (void)hipFree(q); (void)hipGetLastError(); };
     hipError_t e = hipMalloc(&m, (size_t)(rows / 64 + 2) * n_pad * 8);
     if (e == hipSuccess && st->d_mint) e = hipMalloc(&mint, (size_t)(rows / 64 + 2) * n_pad * 8);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&mq[i], ((size_t)rows + 128) * mq_words * 8);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&ra[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (rows / 64 + 2) * 8);
     for (int i = 0; i < 2 && e == hipSuccess && st->d_wb[i]; ++i) e = hipMalloc(&wb[i], ((size_t)rows / 64 + 1) * ref->n_tiles * 16);
     if (e == hipSuccess) e = hipMalloc(&cnt, (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 4);
+    if (e == hipSuccess && st->d_lrow) e = hipMalloc(&lrow, (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 8);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&sm[i], (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 4);
     if (e == hipSuccess) e = hipMemset(m, 0, (size_t)(rows / 64 + 2) * n_pad * 8);  // (M is all-zero between passes)
     if (e == hipSuccess && mint) e = hipMemset(mint, 0, (size_t)(rows / 64 + 2) * n_pad * 8);
@@ -1557,6 +1599,7 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
         (void)hipFree(st->ps[i].smap); st->ps[i].smap = sm[i];
     }
     (void)hipFree(st->d_rowcnt); st->d_rowcnt = cnt;
+    if (lrow) { (void)hipFree(st->d_lrow); st->d_lrow = lrow; }
     st->qcap = (u32)rows;
     st->qrows_grown += 1;
     return SKX_OK;
@@ -1772,10 +1815,11 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // (... and the FIRST pass of a sample: on a table of zeros every genome of a species is a candidate of the first batch, whatever
     // follows -- with more genomes than a compact ranking takes, the pass that would only find that out is not worth its wait)
     const bool fresh_overflow = st->fresh_table && ref->max_species > skx::kCandCap;
-    // (the SECOND pass of a sample looks for itself: the counts of the first pass's chains are mostly still on their way when it is
-    // queued, and the first batches' say "everything" in any sample)
+    // (the SECOND pass of a sample goes by a count from the second half of the first pass -- the first batches of ANY sample say
+    // "everything" -- and looks for itself when none has arrived yet)
+    const bool second_blind = st->passes_since_fresh == 1 && !((int)(st->lcount_seen - st->lcount_floor) > 0);
     const bool legacy = update_table && all_ranked && cand_env0 && legacy_env > 0 &&
-                        (fresh_overflow || (st->hint_all_overflow && st->passes_since_fresh != 1 && (int)st->legacy_run < legacy_env));
+                        (fresh_overflow || (st->hint_all_overflow && !second_blind && (int)st->legacy_run < legacy_env));
     st->legacy_run = legacy ? st->legacy_run + 1 : 0;
     if (update_table) { st->passes_since_fresh = st->fresh_table ? 1 : st->passes_since_fresh + 1; st->fresh_table = false; }
     if (update_table && !legacy && st->cum_writer) {  // (the table the last chain of a legacy pass left: the gains are added to it)
@@ -1790,6 +1834,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         for (int i = 0; i < n_sub; ++i) pbt.p_off[i] = subs[i].p_off;
         pbt.p_off[n_sub] = P;
         const u64* m_int = split ? st->d_mint : nullptr;
+        const bool long_rows = split_dict && ref->d_mlong != nullptr;
         HIPCHK(hipMemsetAsync(st->d_gain, 0, (size_t)n_sub * n_pad * 4, hs));
         if (P > 0) {
             HIPCHK(hipMemset2DAsync(st->d_rowcnt, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
@@ -1798,8 +1843,15 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             if (split_dict) HIPCHK(hipMemsetAsync(st->d_gain_s, 0, (size_t)n_sub * n_pad * 4 * skx::gain_sparse_stride(), hs));
             skx::launch_pass_gain(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain, st->d_gain_s,
                                   split_dict ? st->d_sslot : nullptr, split_dict ? &ri : nullptr);
+            if (long_rows) {  // the rows with a bit row: listed per batch, added up with bit-sliced counters
+                HIPCHK(hipMemsetAsync(st->d_nlrow, 0, 64, hs));
+                HIPCHK(hipMemsetAsync(st->d_gain_l, 0, (size_t)n_sub * n_pad * 4, hs));
+                skx::launch_long_rows(hs, st->d_sslot, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->long_rows());
+                skx::launch_gain_long(hs, st->long_rows(), ri, d_nd, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_l);
+            }
         }
-        skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (split_dict && P > 0) ? st->d_gain_s : nullptr, (u32)n_sub, n_pad, ps.tab);
+        skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (split_dict && P > 0) ? st->d_gain_s : nullptr,
+                                (long_rows && P > 0) ? st->d_gain_l : nullptr, (u32)n_sub, n_pad, ps.tab);
         st->d_cum = ps.tab + (size_t)n_sub * n_pad;  // (readers: the next pass on this stream; everybody else behind ev_front / a flush)
         // candidates.  A batch that wants the per-read x per-genome debug matrix ranks on everything; so does every batch when the
         // experiment knob SKX_CAND=0 says so
@@ -1823,6 +1875,16 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                 skx::launch_cand_sparse(hs, st->d_sslot, d_nd, q_bound, ref->rare_index(), st->d_candmask, st->d_candslot, n_pad, st->d_cbad, (u32)n_sub, st->d_nqc,
                                         ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords, rows_c, ps.rowany_c,
                                         st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c);
+                if (long_rows) {  // ... and the rows with a bit row: ANDed with the candidates' words
+                    const u32 n_gw = n_pad / 64;
+                    HIPCHK(hipMemsetAsync(st->d_cw, 0, (size_t)n_sub * n_gw * 8, hs));
+                    HIPCHK(hipMemsetAsync(st->d_cbase, 0xFF, (size_t)n_sub * n_gw * 4, hs));
+                    HIPCHK(hipMemsetAsync(st->d_ncwl, 0, 64, hs));
+                    skx::launch_cand_words(hs, ps.cand, st->n_pad_c, (u32)n_sub, n_gw, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl);
+                    skx::launch_cand_long(hs, st->long_rows(), ref->rare_index(), d_nd, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl, st->n_pad_c,
+                                          st->d_cbad, (u32)n_sub, st->d_nqc, ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords,
+                                          rows_c, ps.rowany_c, st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c);
+                }
             }
         } else {
             HIPCHK(hipMemsetAsync(ps.ncand, 0, (size_t)n_sub * n_sp * 4, hs));
@@ -2065,7 +2127,9 @@ static int queue_one(skx_stream* st, skx_stream::PassChains& pc, bool block, boo
         st->rank_seq += 1;
         if (legacy) {
             // (what the batch's candidates would have been, for the passes to come: a hint, a few batches stale when it is read)
-            skx::launch_cand_count(ls, cum_in, cum_out, spc, st->top_k, st->h_lcount, ++st->lcount_seq);
+            // (two batches of a pass are asked: the middle one and the last -- the kernel is a lone workgroup that reads the table
+            // twice per species, 150 us on a busy chip; a count from the second half of a sample's FIRST pass is what its second pass
+            // goes by)
             st->tab_cur = tab_next; st->d_cum = cum_out; st->cum_writer = &L;
         }
         if (top1_fast) {
@@ -2087,6 +2151,8 @@ static int queue_one(skx_stream* st, skx_stream::PassChains& pc, bool block, boo
             skx::launch_topk_merge(ls, L.d_cand_sum, L.d_cand_idx, n_reads, c_gw, skx::kRankWords, st->top_k, d_topk_idx,
                                    d_topk_sum, out_r0, c_spc, nullptr);
         }
+        if (legacy && (si == n_sub / 2 || si == n_sub - 1))  // (behind the batch's rows: nobody waits for the count)
+            skx::launch_cand_count(ls, cum_in, cum_out, spc, st->top_k, st->h_lcount, ++st->lcount_seq);
         if (compact)  // candidate slots -> genome indices (local to the species)
             skx::launch_cand_rows_back(ls, d_topk_idx + (size_t)out_r0 * n_sp * st->top_k, n_reads, n_sp, st->top_k,
                                        ps.cand + (size_t)si * st->n_pad_c, skx::kCandCap, ref->d_sp_g0);

@@ -1637,6 +1637,26 @@ __global__ __launch_bounds__(256) void rare_fill_kernel(const u64* __restrict__ 
     }
 }
 
+// ---- long lists as bit rows.  A hash held by more than kShortList genomes (a lineage's: ~200) costs a pass one atomic per genome
+// on its list and batch -- 8.7 M per C2 pass of the SNP workload, 3.9 ms at the ~2.3 G/s scattered device-scope atomics reach.  The
+// lists themselves differ from hash to hash (a strain's own SNP removes a lineage hash from that one strain), so they cannot be
+// shared; but as BIT ROWS over the genomes (mlong[row][genome word]: 5 KB per hash at C2, 1.3 GB for its 263 k long lists) a pass
+// adds them up with bit-sliced counters -- coalesced 512-byte reads, no atomics (gain_long_kernel) -- and finds the candidates on a
+// row by ANDing its words with the candidates' (cand_long_kernel).
+constexpr u32 kShortList = 8;            // genomes a list may have to be walked by its row's lane alone
+constexpr u32 kLongFlag = 0x80000000u;   // sslot[2 i + 1]: the hash has a bit row, sslot[2 i] = its index
+__global__ __launch_bounds__(256) void mlong_build_kernel(const u32* __restrict__ lslot, u32 n_long, const u32* __restrict__ off,
+                                                          const u32* __restrict__ cnt, const u32* __restrict__ post, u64* __restrict__ mlong,
+                                                          u32 n_gw) {
+    const u32 w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = lane_id();
+    if (w >= n_long) return;
+    const u32 slot = lslot[w], o = off[slot], n = cnt[slot];
+    for (u32 j = lane; j < n; j += 64u) {
+        const u32 g = post[o + j];
+        atomicOr(&mlong[(size_t)w * n_gw + (g >> 6)], 1ull << (g & 63u));
+    }
+}
+
 // ---- a pass's dictionary, split.  classify_a: look every query hash up (qinfo[q] = its slot | kSlotNone; dense: bit 31 of qloc[q]),
 // block-local exclusive count of the dense ones; classify_b: one block scans the block totals, publishes nd / ns;
 // classify_c: Qd (the dense hashes, still ascending), qrow[q] = the hash's row of the bit matrix (dense rows first, in Qd order,
@@ -1705,11 +1725,14 @@ __global__ __launch_bounds__(256) void classify_c_kernel(const u64* __restrict__
     if (i >= nq) return;
     const u32 loc = qloc[i], dr = bsum[i >> 10] + (loc & 0x7FFFFFFFu), nd64 = n_d[2];
     if (loc >> 31) { qd[dr] = q[i]; qrow[i] = dr; }
-    else {  // (the other rows start on a word boundary; sslot[2 sr], [2 sr + 1] = start and length of the hash's genome list)
+    else {  // (the other rows start on a word boundary; sslot[2 sr], [2 sr + 1] = start and length of the hash's genome list -- or, length with
+        // kLongFlag: the index of its bit row)
         const u32 sr = i - dr, slot = qinfo[i];
         qrow[i] = nd64 + sr;
-        sslot[2u * sr] = slot != kSlotNone ? ri.off[slot] : 0u;
-        sslot[2u * sr + 1u] = slot != kSlotNone ? ri.cnt[slot] : 0u;
+        const u32 np = slot != kSlotNone ? ri.cnt[slot] : 0u;
+        const bool lng = ri.mlong != nullptr && np > kShortList;  // (a long list: the row carries the index of its bit row instead)
+        sslot[2u * sr] = slot == kSlotNone ? 0u : lng ? ri.lid[slot] : ri.off[slot];
+        sslot[2u * sr + 1u] = lng ? (np | kLongFlag) : np;
     }
 }
 // a reference without the index: every hash is the scan's, rows = positions in Q
@@ -1731,7 +1754,11 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict_
     for (u32 r0 = wave * 64u; r0 < ns; r0 += n_waves * 64u) {
         const u32 sr = r0 + lane;
         u32 off = 0, cnt = 0;
-        if (sr < ns) { const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr]; off = e.x; cnt = e.y; }
+        if (sr < ns) {
+            const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr];
+            off = e.x; cnt = e.y;
+            if (cnt & kLongFlag) { cnt &= ~kLongFlag; off = ri.off[ri.lslot[off]]; }  // (a bit row: M wants the list)
+        }
         const u32 row = nd + sr;
         u64* const mrow = m_bits + (size_t)(row >> 6) * n_pad;
         const u64 bit = 1ull << (row & 63u);
@@ -3772,7 +3799,7 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
                     if (b < n_b) { c[b] = cnt[(size_t)b * row_stride + nd64 + sr]; any |= c[b]; }
             }
         }
-        if (!any) np = 0;
+        if (!any || (np & kLongFlag)) np = 0;  // (rows with a bit row: gain_long_kernel)
         if (np && np <= 8u) {
             for (u32 j = 0; j < np; ++j) {
                 const u32 g = ri.post[off + j];
@@ -3799,9 +3826,224 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
     }
 }
 // tab[0] = the table the pass starts from, tab[b + 1] = tab[b] + gain[b]
+// the long-list rows of every batch, compacted: lrow[b][i] = {bit row, sparse row} for the rows that occur in batch b
+__global__ __launch_bounds__(256) void long_rows_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, const u32* __restrict__ cnt,
+                                                        u32 row_stride, u32 n_b, LongRows lr) {
+    __builtin_amdgcn_s_setprio(3);
+    const u32 nd64 = n_d[2], ns = n_d[1], lane = lane_id();
+    for (u32 sr0 = (blockIdx.x * 256u + threadIdx.x) & ~63u; sr0 < ns; sr0 += gridDim.x * 256u) {
+        const u32 sr = sr0 + lane;
+        uint2 e = make_uint2(0u, 0u);
+        if (sr < ns) e = reinterpret_cast<const uint2*>(sslot)[sr];
+        const bool lng = (e.y & kLongFlag) != 0u;
+        if (!__ballot(lng)) continue;
+        for (u32 b = 0; b < n_b; ++b) {
+            const bool in = lng && cnt[(size_t)b * row_stride + nd64 + sr] != 0u;
+            const u64 bal = __ballot(in);
+            if (!bal) continue;
+            u32 base = 0;
+            if (lane == 0u) base = atomicAdd(&lr.nlrow[b], (u32)__popcll(bal));
+            base = (u32)__shfl((int)base, 0);
+            if (in) lr.lrow[(size_t)b * lr.lrow_stride + base + (u32)__popcll(bal & lanemask_lt())] = make_uint2(e.x, sr);
+        }
+    }
+}
+// gain_l[b][g] (zero on entry) += sum over batch b's long-list rows of cnt[b][row] x (bit g of the row).  A workgroup owns 64 genome words
+// (4 096 genomes) of one batch and a share of its rows (gridDim.z): its four waves split them, every lane keeps the counts of its word's 64 genomes BIT-SLICED (plane p =
+// bit p of the 64 counts: adding a row of weight c is a ripple-carry add of the row's word at the planes of c's set bits), the
+// waves' planes are added in LDS and the counts extracted once: coalesced 512-byte reads of the rows, plain stores, no atomics.
+constexpr u32 kGlPlanes = 23;  // counts below 2^23 (a batch has at most 2^22 pairs)
+__device__ __forceinline__ void planes_add(u64 (&pl)[kGlPlanes], u64 m, u32 k0) {
+    u64 carry = m;
+#pragma unroll
+    for (u32 p = 0; p < kGlPlanes; ++p) {
+        if (p >= k0) {
+            const u64 t = pl[p] & carry;
+            pl[p] ^= carry;
+            carry = t;
+            if ((p & 3u) == 3u && __ballot(carry != 0ull) == 0ull) return;  // (the carry dies after a few planes)
+        }
+    }
+}
+__global__ __launch_bounds__(256) void gain_long_kernel(LongRows lr, RareIndex ri, const u32* __restrict__ n_d, const u32* __restrict__ cnt,
+                                                        u32 row_stride, u32 n_pad, u32* __restrict__ gain_l) {
+    __builtin_amdgcn_s_setprio(2);
+    __shared__ u64 xch[3][kGlPlanes][64];
+    const u32 b = blockIdx.y, lane = lane_id(), wv = threadIdx.x >> 6;
+    const u32 n_gw = ri.n_gw, wg = min(blockIdx.x * 64u + lane, n_gw - 1u);
+    const bool mine = blockIdx.x * 64u + lane < n_gw;
+    const u32 nd64 = n_d[2], nr = lr.nlrow[b];
+    const uint2* rows = lr.lrow + (size_t)b * lr.lrow_stride;
+    const u32* cb = cnt + (size_t)b * row_stride + nd64;
+    u64 pl[kGlPlanes];
+#pragma unroll
+    for (u32 p = 0; p < kGlPlanes; ++p) pl[p] = 0ull;
+    constexpr u32 U = 8;  // rows in flight per wave
+    // (the rows are split over gridDim.z workgroups x 4 waves; every load of a round is issued before the first is used: no branch
+    // around them -- rows past the end repeat the last one with weight 0)
+    const u32 n_split = gridDim.z * 4u, me = blockIdx.z * 4u + wv;
+    if (nr == 0u) return;
+    for (u32 i0 = me * U; i0 < nr; i0 += n_split * U) {
+        u64 m[U];
+        u32 c[U];
+        uint2 e[U];
+#pragma unroll
+        for (u32 u = 0; u < U; ++u) e[u] = rows[min(i0 + u, nr - 1u)];
+#pragma unroll
+        for (u32 u = 0; u < U; ++u) { c[u] = cb[e[u].y]; m[u] = ri.mlong[(size_t)e[u].x * n_gw + wg]; }
+#pragma unroll
+        for (u32 u = 0; u < U; ++u) { if (i0 + u >= nr) c[u] = 0u; if (!mine) m[u] = 0ull; }
+#pragma unroll
+        for (u32 u = 0; u < U; ++u) {
+            u32 cc = (u32)__builtin_amdgcn_readfirstlane((int)c[u]);
+            while (cc) {  // (weight c = its set bits, one ripple add each; almost always 1)
+                const u32 k = (u32)__builtin_ctz(cc);
+                cc &= cc - 1u;
+                if (__ballot(m[u] != 0ull)) planes_add(pl, m[u], k);
+            }
+        }
+    }
+    // waves 1..3 hand their planes to wave 0 (bit-sliced addition: a full adder per plane)
+    if (wv) {
+#pragma unroll
+        for (u32 p = 0; p < kGlPlanes; ++p) xch[wv - 1u][p][lane] = pl[p];
+    }
+    __syncthreads();
+    if (wv == 0u) {
+        for (u32 o = 0; o < 3u; ++o) {
+            u64 carry = 0ull;
+#pragma unroll
+            for (u32 p = 0; p < kGlPlanes; ++p) {
+                const u64 a = pl[p], x = xch[o][p][lane];
+                pl[p] = a ^ x ^ carry;
+                carry = (a & x) | (carry & (a ^ x));
+            }
+        }
+        if (mine) {
+            u32* out = gain_l + (size_t)b * n_pad + (size_t)wg * 64u;
+            for (u32 bit = 0; bit < 64u; ++bit) {
+                u32 v = 0;
+#pragma unroll
+                for (u32 p = 0; p < kGlPlanes; ++p) v |= (u32)((pl[p] >> bit) & 1ull) << p;
+                if (v) atomicAdd(&out[bit], v);  // (gridDim.z workgroups share the word: gain_l is zero on entry)
+            }
+        }
+    }
+}
+// the candidates of a batch by genome word (one workgroup per batch)
+__global__ __launch_bounds__(1024) void cand_words_kernel(const u32* __restrict__ cand, u32 n_pad_c, u32 n_gw, u64* __restrict__ cw,
+                                                          u32* __restrict__ cbase, u32* __restrict__ cwl, u32* __restrict__ ncwl) {
+    __builtin_amdgcn_s_setprio(3);
+    const u32 b = blockIdx.x;
+    u64* w = cw + (size_t)b * n_gw;
+    u32* base = cbase + (size_t)b * n_gw;
+    for (u32 c = threadIdx.x; c < n_pad_c; c += 1024u) {
+        const u32 g = cand[(size_t)b * n_pad_c + c];
+        if (g != kCandNone) { atomicOr(&w[g >> 6], 1ull << (g & 63u)); atomicMin(&base[g >> 6], c); }
+    }
+    __syncthreads();
+    for (u32 i0 = 0; i0 < n_gw; i0 += 1024u) {
+        const u32 i = i0 + threadIdx.x;
+        const bool nz = i < n_gw && w[i] != 0ull;
+        const u64 bal = __ballot(nz);
+        u32 at = 0;
+        if (bal && lane_id() == 0u) at = atomicAdd(&ncwl[b], (u32)__popcll(bal));
+        at = (u32)__shfl((int)at, 0);
+        if (nz) cwl[(size_t)b * n_pad_c + at + (u32)__popcll(bal & lanemask_lt())] = i;
+    }
+}
+// the long-list rows of the compact problems: a row of batch b whose bit row meets b's candidates gets a row behind the dense ones
+// of b's compact matrix; its words are put together in LDS (candidate slot = the word's first slot + the rank of the bit among the
+// word's candidates) and written with plain stores.  grid: (blocks, batches)
+__global__ __launch_bounds__(256) void cand_long_kernel(LongRows lr, RareIndex ri, const u32* __restrict__ n_d, const u64* __restrict__ cw,
+                                                        const u32* __restrict__ cbase, const u32* __restrict__ cwl, const u32* __restrict__ ncwl,
+                                                        u32 n_pad_c, u32* __restrict__ bad, u32* __restrict__ nqc, u32* __restrict__ smap,
+                                                        u32 smap_stride, u64* __restrict__ mqc, size_t mqc_stride, u32 rows_c,
+                                                        u64* __restrict__ rowany_c, u32 rowany_stride, u32* __restrict__ grp_any_c, u32 n_grp_c) {
+    __builtin_amdgcn_s_setprio(2);
+    __shared__ u64 pat[4][kPatWords];
+    const u32 b = blockIdx.y, lane = lane_id(), wv = threadIdx.x >> 6;
+    if (bad[b]) return;
+    const u32 nd64 = n_d[2], nr = lr.nlrow[b], n_gw = ri.n_gw, n_gw_c = n_grp_c * kRankWords;
+    const u32 nw = ncwl[b];
+    if (nw == 0u) return;
+    const uint2* rows = lr.lrow + (size_t)b * lr.lrow_stride;
+    const u64* cwb = cw + (size_t)b * n_gw;
+    const u32* cbb = cbase + (size_t)b * n_gw;
+    const u32* wl = cwl + (size_t)b * n_pad_c;
+    u64* pw = pat[wv];
+    const bool in_lds = n_gw_c <= kPatWords;
+    for (u32 i = blockIdx.x * 4u + wv; i < nr; i += gridDim.x * 4u) {
+        const uint2 e = rows[i];
+        const u64* mrow = ri.mlong + (size_t)e.x * n_gw;
+        // does the row meet any candidate at all?  (almost never: the hash of some other clade)
+        u64 any = 0ull;
+        for (u32 k0 = 0; k0 < nw; k0 += 64u) {
+            const u32 k = k0 + lane;
+            u64 bits = 0ull;
+            if (k < nw) { const u32 wg = wl[k]; bits = mrow[wg] & cwb[wg]; }
+            any |= __ballot(bits != 0ull);
+        }
+        if (!any) continue;
+        u32 x = 0;
+        if (lane == 0u) {
+            const u32 crow = nd64 + atomicAdd(&nqc[b], 1u);
+            if (crow + 1u >= rows_c) { atomicOr(&bad[b], 2u); x = kCandNone; }
+            else { smap[(size_t)b * smap_stride + e.y] = crow + 1u; x = crow; }
+        }
+        const u32 cr = (u32)__shfl((int)x, 0);
+        if (cr == kCandNone) return;  // (the batch's matrix is full: it ranks on everything)
+        if (in_lds) {
+            for (u32 w = lane; w < n_gw_c; w += 64u) pw[w] = 0ull;
+            wave_sync();
+        }
+        for (u32 k0 = 0; k0 < nw; k0 += 64u) {
+            const u32 k = k0 + lane;
+            if (k < nw) {
+                const u32 wg = wl[k];
+                const u64 cm = cwb[wg];
+                u64 bits = mrow[wg] & cm;
+                const u32 s0 = cbb[wg];
+                while (bits) {
+                    const u32 bit = (u32)__builtin_ctzll(bits);
+                    bits &= bits - 1ull;
+                    const u32 slot = s0 + (u32)__popcll(cm & ((1ull << bit) - 1ull));
+                    if (in_lds) atomicOr(&pw[slot >> 6], 1ull << (slot & 63u));
+                    else atomicOr(&mqc[(size_t)b * mqc_stride + mq_index(slot >> 6, cr, rows_c)], 1ull << (slot & 63u));
+                }
+            }
+        }
+        if (in_lds) {
+            wave_sync();
+            for (u32 w0 = 0; w0 < n_gw_c; w0 += 64u) {
+                const u32 w = w0 + lane;
+                const u64 v = w < n_gw_c ? pw[w] : 0ull;
+                if (v) mqc[(size_t)b * mqc_stride + mq_index(w, cr, rows_c)] = v;
+                const u64 nzw = __ballot(v != 0ull);
+                const u32 l0 = (lane / kRankWords) * kRankWords;
+                if (lane == l0 && w < n_gw_c && ((nzw >> l0) & ((1ull << kRankWords) - 1ull)) != 0ull) {
+                    const u32 grp = w / kRankWords;
+                    atomicOr(&rowany_c[(size_t)b * rowany_stride + (size_t)grp * (rows_c >> 6) + (cr >> 6)], 1ull << (cr & 63u));
+                    u32* ga = grp_any_c + (size_t)b * n_grp_c + grp;
+                    if (*ga == 0u) atomicOr(ga, 1u);
+                }
+            }
+            wave_sync();
+        } else {
+            // (compact problems wider than the LDS pattern: the bits went straight into the matrix; flag every group -- a flag for a
+            // group without a bit only costs the ranking a look at an all-zero row)
+            for (u32 grp = lane; grp < n_grp_c; grp += 64u) {
+                atomicOr(&rowany_c[(size_t)b * rowany_stride + (size_t)grp * (rows_c >> 6) + (cr >> 6)], 1ull << (cr & 63u));
+                u32* ga = grp_any_c + (size_t)b * n_grp_c + grp;
+                if (*ga == 0u) atomicOr(ga, 1u);
+            }
+        }
+    }
+}
 // gain_s (or NULL): the rare rows' part, one entry per kGainSparseStride words (gain_sparse_kernel)
 __global__ __launch_bounds__(256) void pass_tables_kernel(const u64* __restrict__ prev, const u32* __restrict__ gain,
-                                                          const u32* __restrict__ gain_s, u32 n_b, u32 n_pad, u64* __restrict__ tab) {
+                                                          const u32* __restrict__ gain_s, const u32* __restrict__ gain_l, u32 n_b, u32 n_pad,
+                                                          u64* __restrict__ tab) {
     __builtin_amdgcn_s_setprio(3);
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     if (g >= n_pad) return;
@@ -3810,6 +4052,7 @@ __global__ __launch_bounds__(256) void pass_tables_kernel(const u64* __restrict_
     for (u32 b = 0; b < n_b; ++b) {
         t += gain[(size_t)b * n_pad + g];
         if (gain_s) t += gain_s[((size_t)b * n_pad + g) * kGainSparseStride];
+        if (gain_l) t += gain_l[(size_t)b * n_pad + g];  // (the long-list rows' part: gain_long_kernel)
         tab[(size_t)(b + 1u) * n_pad + g] = t;
     }
 }
@@ -3981,6 +4224,7 @@ __global__ __launch_bounds__(256) void cand_sparse_kernel(const u32* __restrict_
         const u32 sr = r0 + lane;
         u32 off = 0, np = 0;
         if (sr < ns) { const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr]; off = e.x; np = e.y; }
+        if (np & kLongFlag) np = 0;  // (rows with a bit row: cand_long_kernel)
         if (np && np <= 8u) {
             u32 crow[kPassBatchesMax];
 #pragma unroll
@@ -4168,7 +4412,8 @@ __global__ __launch_bounds__(256) void cand_rows_back_kernel(u32* __restrict__ o
 // launchers
 // =====================================================================================
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
-static const u32 kWalkBlocks = SKX_WALK_BLOCKS;  // workgroups of the kernels that walk the rare rows' genome lists
+static int getenv_int_early(const char* name, int dflt) { const char* e = knob(name); return e ? atoi(e) : dflt; }
+static const u32 kWalkBlocks = (u32)(getenv_int_early("SKX_WALK_BLOCKS", SKX_WALK_BLOCKS));  // workgroups of the kernels that walk the rare rows' genome lists
 static int env_int(const char* name, int dflt) { const char* e = knob(name); return e ? atoi(e) : dflt; }
 
 void launch_ref_tile(hipStream_t st, const u64* src, const u32* eff_len, u64* dst, u32 s, u32 pad_base, u32 g_count) {
@@ -4378,8 +4623,28 @@ void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n
                            row_stride, n_b, n_pad, gain_s);
 }
 u32 gain_sparse_stride() { return kGainSparseStride; }
-void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s, u32 n_b, u32 n_pad, u64* tab) {
-    hipLaunchKernelGGL(pass_tables_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, prev, gain, gain_s, n_b, n_pad, tab);
+void launch_mlong_build(hipStream_t st, const u32* lslot, u32 n_long, const u32* off, const u32* cnt, const u32* post, u64* mlong, u32 n_gw) {
+    if (n_long == 0) return;
+    hipLaunchKernelGGL(mlong_build_kernel, dim3(cdiv(n_long, 4)), dim3(256), 0, st, lslot, n_long, off, cnt, post, mlong, n_gw);
+}
+void launch_long_rows(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride, u32 n_b, const LongRows& lr) {
+    hipLaunchKernelGGL(long_rows_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), (u32)env_int("SKX_G_LONGROWS", 1024)))), dim3(256), 0, st, sslot, n_d, cnt, row_stride, n_b, lr);
+}
+void launch_gain_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u32* cnt, u32 row_stride, u32 n_b, u32 n_pad,
+                      u32* gain_l) {
+    hipLaunchKernelGGL(gain_long_kernel, dim3(cdiv(ri.n_gw, 64), n_b, (u32)env_int("SKX_G_GAINLONG", 8)), dim3(256), 0, st, lr, ri, n_d, cnt, row_stride, n_pad, gain_l);
+}
+void launch_cand_words(hipStream_t st, const u32* cand, u32 n_pad_c, u32 n_b, u32 n_gw, u64* cw, u32* cbase, u32* cwl, u32* ncwl) {
+    hipLaunchKernelGGL(cand_words_kernel, dim3(n_b), dim3(1024), 0, st, cand, n_pad_c, n_gw, cw, cbase, cwl, ncwl);
+}
+void launch_cand_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u64* cw, const u32* cbase, const u32* cwl,
+                      const u32* ncwl, u32 n_pad_c, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
+                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c) {
+    hipLaunchKernelGGL(cand_long_kernel, dim3((u32)env_int("SKX_G_CANDLONG", 192), n_b), dim3(256), 0, st, lr, ri, n_d, cw, cbase, cwl, ncwl, n_pad_c, bad, nqc, smap, smap_stride, mqc,
+                       mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
+}
+void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s, const u32* gain_l, u32 n_b, u32 n_pad, u64* tab) {
+    hipLaunchKernelGGL(pass_tables_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, prev, gain, gain_s, gain_l, n_b, n_pad, tab);
 }
 void launch_cand_select(hipStream_t st, const u64* tab, u32 n_pad, const Species& sp, u32 n_b, u32 top_k, u32 cap, u32* cand, u32* candslot,
                         u64* tabc, u32* ncand, u32* bad, u32* candmask) {

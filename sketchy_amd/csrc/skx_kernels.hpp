@@ -91,7 +91,23 @@ void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum
 // Rare-hash index of a reference (skx_kernels.hip, "rare-hash index"): open-addressing table over the distinct reference hashes
 // (key, all-ones = empty; mask = slots - 1), cnt = genomes that hold the hash, off = start of its genome list in post (padded genome
 // indices) -- or 0xFFFFFFFF for a hash held by more genomes than the policy "rare_hash_genomes": those stay with the scan.
-struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* post; u32 mask; };
+struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* post; u32 mask;
+                   // long lists (more than 8 genomes) also as BIT ROWS: mlong[lid][n_gw] u64, bit g of a row = genome g holds the hash;
+                   // lid[key slot] = row (0xFFFFFFFF: none), lslot[row] = key slot.  NULL when there was no room for the rows.
+                   const u64* mlong = nullptr; const u32* lid = nullptr; const u32* lslot = nullptr; u32 n_gw = 0; };
+// long-list rows of a pass, per batch: lrow[b][i] = {bit row, sparse row of the pass's matrix} (nlrow[b] of them, lrow_stride apart)
+struct LongRows { uint2* lrow; u32* nlrow; u32 lrow_stride; };
+void launch_mlong_build(hipStream_t st, const u32* lslot, u32 n_long, const u32* off, const u32* cnt, const u32* post, u64* mlong, u32 n_gw);
+void launch_long_rows(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride, u32 n_b, const LongRows& lr);
+// gain_l[b][g] (zero on entry) += sum over batch b's long-list rows of cnt x bit: bit-sliced counters over the rows' 64-bit words
+void launch_gain_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u32* cnt, u32 row_stride, u32 n_b, u32 n_pad,
+                      u32* gain_l);
+// the candidates of every batch by genome word: cw[b][w] their bits, cbase[b][w] the slot of the word's first one, cwl[b][.] / ncwl[b] the
+// words that hold any (cw, ncwl zero on entry; cbase all-ones)
+void launch_cand_words(hipStream_t st, const u32* cand, u32 n_pad_c, u32 n_b, u32 n_gw, u64* cw, u32* cbase, u32* cwl, u32* ncwl);
+void launch_cand_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u64* cw, const u32* cbase, const u32* cwl,
+                      const u32* ncwl, u32 n_pad_c, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
+                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c);
 // build, two passes over the tiled matrix (n_elems = n_tiles * s * 256): count (key / cnt zeroed: all-ones / 0; *overflow raised when
 // the table is too small), then -- offsets from the counts, cursor zeroed -- fill
 void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow);
@@ -123,7 +139,8 @@ void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int /* or 
                       u32 row_stride, u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri);
 u32 gain_sparse_stride();
 // tab[0] = prev, tab[b + 1] = tab[b] + gain[b]   ([n_b + 1][n_pad])
-void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s /* or NULL */, u32 n_b, u32 n_pad, u64* tab);
+void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s /* or NULL */, const u32* gain_l /* or NULL */, u32 n_b,
+                        u32 n_pad, u64* tab);
 // per (batch, species): the genomes whose value at the end of the batch reaches the top_k-th best value at its start, in reference
 // order: cand[(b n_sp + sp) cap + i], candslot[b][g] (0xFFFFFFFF: none), tabc[b][sp cap + i] start values, ncand[b n_sp + sp],
 // bad[b] (zero on entry) |= 1 when a species has more than cap
