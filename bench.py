@@ -42,6 +42,9 @@ CONFIGS = {
     "c1": ([5000], 1000, 1500, 0.0, "C1: 1.5 kb reads vs 5k-genome s=1000 k=16 sketch (cache-resident)"),
     "c2": ([40000], 10000, 1500, 0.0, "C2: ~100k x 1.5 kb reads per step vs 40000-genome s=10000 k=16 sketch (HBM-bound scan)"),
     "c6g": ([40000, 35000], 10000, 1500, 0.0, "experiment: two species resident (75000 genomes, 6 GB), 1.5 kb reads (scan size sweep)"),
+    "c4s": ([1600, 1600, 1200, 1000, 600], 1000, 1500, 1.0,
+            "C4 in small (tests): 5 species' sketches resident (6000 genomes, s=1000 k=16), log-normal read lengths, a stream mixed over "
+            "all 5, every read scored against all 5"),
     "c4": ([40000, 40000, 30000, 25000, 15000], 10000, 1500, 1.0,
            "C4: 5 species' sketches resident (150000 genomes, s=10000 k=16), log-normal read lengths 200..50000 (median 1.5 kb), "
            "every read scored against all 5"),
@@ -174,7 +177,55 @@ def _end_to_end(refs, batches, batch_bases, B, read_len, top, n_use, S, step_row
         # (the first run touches the input's pages for the first time: it is listed, the MEDIAN of the others counts)
         later = sorted(runs[1:], key=lambda r: r[0]["reads_per_s"])
         tm, wall = later[(len(later) - 1) // 2]
+        # ---- the same reads gzip-compressed, as read streams usually come: (a) BGZF (bgzip: members of 64 KB with their sizes in the
+        # header: inflated by all threads at once), (b) plain gzip (one member: one sequential inflate thread).  The first n_gz batches
+        # of the file (compressing 4.7 GB in Python would take minutes); rows must be the first rows of the uncompressed run.
+        gz = {}
+        try:
+            import zlib
+            n_gz = min(n_use, 2)
+            rec_bytes = 8 + L + 3 + L + 1
+            raw = np.fromfile(d + "/reads.fq", np.uint8, count=n_gz * B * rec_bytes)
+            t2 = time.time()
+            synth.write_bgzf(d + "/reads.bgzf.fq.gz", raw)
+            zc = zlib.compressobj(1, zlib.DEFLATED, 31)
+            with open(d + "/reads.plain.fq.gz", "wb") as f:
+                for a in range(0, len(raw), 1 << 26):
+                    f.write(zc.compress(memoryview(raw[a:a + (1 << 26)])))
+                f.write(zc.flush())
+            t_comp = time.time() - t2
+            del raw
+            for kind in ("bgzf", "plain"):
+                best = None
+                for _ in range(2):
+                    with open(d + f"/rows_{kind}.tsv", "wb") as out:
+                        p = subprocess.run([exe, "predict", "-r", d + "/ref.msh", "-g", d + "/geno.tsv", "-i", d + f"/reads.{kind}.fq.gz", "-s", "-t",
+                                            str(max(top, 1)), "--timing", *extra_args], stdout=out, stderr=subprocess.PIPE, text=True, timeout=900)
+                    m = re.search(r'\{"sketchy_hip_timing".*\}', p.stderr)
+                    if p.returncode != 0 or not m:
+                        gz[kind] = {"error": f"rc {p.returncode}: {p.stderr[-300:]}"}
+                        break
+                    tmg = json.loads(m.group(0))["sketchy_hip_timing"]
+                    # (seconds_stream: from the moment the input is opened -- a BGZF file is inflated BEFORE the parser threads start)
+                    tmg["rate_from_open"] = tmg["reads"] / max(tmg["seconds_stream"], 1e-9)
+                    if best is None or tmg["rate_from_open"] > best["rate_from_open"]:
+                        best = tmg
+                if best:
+                    gz[kind] = {"value": best["rate_from_open"], "unit": "reads/s", "reads": best["reads"], "input": best.get("input"),
+                                "seconds_from_open_to_last_row": best["seconds_stream"], "parse_threads": best.get("parse_threads"),
+                                "compressed_GB": round(os.path.getsize(d + f"/reads.{kind}.fq.gz") / 1e9, 3),
+                                "best_of": 2}
+            gz["compress_s"] = round(t_comp, 1)
+        except Exception as e:  # noqa: BLE001
+            gz["error"] = f"{type(e).__name__}: {e}"[:300]
         import pandas as pd
+        for kind in ("bgzf", "plain"):
+            if isinstance(gz.get(kind), dict) and "value" in gz[kind]:
+                rz = pd.read_csv(d + f"/rows_{kind}.tsv", sep="\t", header=None, usecols=[0, 1, 2], names=["read", "name", "sum"], dtype={"name": str})
+                wi = np.concatenate([a for a, _ in step_rows[:n_gz]]).reshape(-1).astype(np.int64)
+                ws = np.concatenate([b for _, b in step_rows[:n_gz]]).reshape(-1).astype(np.uint64)
+                gz[kind]["rows_match_device_path"] = bool(len(rz) == len(wi) and np.array_equal(rz["name"].str.slice(6, 11).astype(np.int64).to_numpy(), wi)
+                                                          and np.array_equal(rz["sum"].to_numpy().astype(np.uint64), ws))
         rows = pd.read_csv(d + "/rows.tsv", sep="\t", header=None, usecols=[0, 1, 2], names=["read", "name", "sum"], dtype={"name": str})
         got_idx = rows["name"].str.slice(6, 11).astype(np.int64).to_numpy()
         got_sum = rows["sum"].to_numpy().astype(np.uint64)
@@ -189,6 +240,7 @@ def _end_to_end(refs, batches, batch_bases, B, read_len, top, n_use, S, step_row
                 "runs_reads_per_s": [r[0]["reads_per_s"] for r in runs], "best_run_reads_per_s": max(r[0]["reads_per_s"] for r in runs),
                 "process_wall_s": wall, "process_reads_per_s": tm["reads"] / wall, "files_written_s": t_files,
                 "rows_match_device_path": ok,
+                "gz": gz,
                 "what": "`sketchy-hip predict -s` (sketchy_amd/host: mapped file cut at record boundaries, parser threads that pack 4-bit "
                         "bases into page-locked slots, skx_stream_submit, formatter threads, rows in order to a file in /dev/shm), timed by "
                         "the host from the start of its parser threads to its last written row; process_wall_s adds HIP start-up, reading the "
@@ -729,6 +781,14 @@ def main():
             except Exception as e:  # noqa: BLE001
                 e2e = {"error": f"{type(e).__name__}: {e}"[:500], "not_run": True}
             out["value_end_to_end"] = e2e
+            g = e2e.get("gz") or {}
+            out["value_end_to_end_gz"] = {"bgzf": g.get("bgzf"), "plain_gzip": g.get("plain"), "compress_s": g.get("compress_s"), "error": g.get("error"),
+                                          "what": "the same FASTQ (its first two batches) compressed: BGZF -- gzip members of 64 KB whose sizes are in "
+                                                  "their headers, inflated by all host threads at once -- and plain single-member gzip (one "
+                                                  "sequential inflate thread); sketchy-hip predict -s, timed by the host as above"}
+            for kind in ("bgzf", "plain"):
+                if isinstance(g.get(kind), dict) and g[kind].get("rows_match_device_path") is False:
+                    err = err or f"rows printed from the {kind} gzip input differ from the device-resident path's rows"
             if e2e.get("rows_match_device_path") is False:
                 err = err or "rows printed by `sketchy-hip predict -s` differ from the device-resident path's rows for the same reads"
         if not args.no_profile:

@@ -16,6 +16,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <atomic>
+#include <thread>
 
 #include <cstdint>
 #include <cstdio>
@@ -342,6 +344,13 @@ class MappedFile {
     MappedFile& operator=(const MappedFile&) = delete;
     // false: not a regular file (a pipe, stdin) or empty / compressed -- the caller streams it instead
     bool open(const std::string& path);
+    // A BGZF file (bgzip, htslib: gzip members of at most 64 KB that carry their compressed size in a "BC" extra field, so the member
+    // boundaries are known without inflating anything) is inflated by `threads` threads into an anonymous mapping and then looks
+    // like an uncompressed mapped file.  false: not BGZF (plain gzip has ONE member: a sequential stream), or larger than a quarter
+    // of the machine's memory uncompressed -- the caller streams it.  needletail picks its decoder from the magic bytes just the same
+    // (src/sketchy.rs:89-92).
+    bool open_bgzf(const std::string& path, unsigned threads);
+    bool inflated() const { return anon; }
     const char* data() const { return base; }
     size_t size() const { return len; }
     // map the pages of [a, b) now (MADV_POPULATE_READ where the kernel has it; else a hint): a parser thread calls it for its chunk
@@ -349,6 +358,7 @@ class MappedFile {
   private:
     const char* base = nullptr;
     size_t len = 0;
+    bool anon = false;  // an anonymous mapping holding inflated data (open_bgzf)
 };
 
 // first byte of the first record that starts at or behind `pos` (a line start), or `end` when there is none.
@@ -396,8 +406,75 @@ inline bool sketchy::MappedFile::open(const std::string& path) {
     base = static_cast<const char*>(m); len = (size_t)st.st_size;
     return true;
 }
+inline bool sketchy::MappedFile::open_bgzf(const std::string& path, unsigned threads) {
+    if (path == "-") return false;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28) { ::close(fd); return false; }
+    void* cm = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (cm == MAP_FAILED) return false;
+    const unsigned char* c = static_cast<const unsigned char*>(cm);
+    const size_t clen = (size_t)st.st_size;
+    struct Block { size_t coff, csize, uoff, usize; };
+    std::vector<Block> blocks;
+    size_t pos = 0, total = 0;
+    bool ok = true;
+    while (pos < clen) {  // every member: 1f 8b 08 04 .. XLEN, extra subfield 'B' 'C' 02 00 BSIZE (member size - 1), ..., CRC32, ISIZE
+        if (clen - pos < 18 || c[pos] != 0x1f || c[pos + 1] != 0x8b || c[pos + 2] != 8 || !(c[pos + 3] & 4)) { ok = false; break; }
+        const size_t xlen = c[pos + 10] | ((size_t)c[pos + 11] << 8);
+        if (clen - pos < 12 + xlen + 8) { ok = false; break; }
+        size_t bsize = 0;
+        for (size_t x = pos + 12; x + 4 <= pos + 12 + xlen;) {
+            const size_t slen = c[x + 2] | ((size_t)c[x + 3] << 8);
+            if (c[x] == 'B' && c[x + 1] == 'C' && slen == 2 && x + 6 <= pos + 12 + xlen) bsize = (c[x + 4] | ((size_t)c[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || pos + bsize > clen) { ok = false; break; }
+        const unsigned char* tail = c + pos + bsize - 4;
+        const size_t isize = tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+        if (isize > (1u << 16)) { ok = false; break; }
+        blocks.push_back(Block{pos + 12 + xlen, bsize - 12 - xlen - 8, total, isize});
+        total += isize;
+        pos += bsize;
+    }
+    long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+    if (!ok || total < 2 || (pages > 0 && psz > 0 && total > (size_t)pages * (size_t)psz / 4)) { munmap(cm, clen); return false; }
+    void* um = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (um == MAP_FAILED) { munmap(cm, clen); return false; }
+    char* u = static_cast<char*>(um);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    auto work = [&] {
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, -15) != Z_OK) { bad = true; return; }  // (raw deflate: header and trailer were walked above)
+        for (;;) {
+            const size_t b0 = next.fetch_add(64);
+            if (b0 >= blocks.size() || bad) break;
+            for (size_t b = b0; b < std::min(blocks.size(), b0 + 64); ++b) {
+                const Block& k = blocks[b];
+                if (k.usize == 0) continue;
+                inflateReset(&z);
+                z.next_in = const_cast<unsigned char*>(c + k.coff); z.avail_in = (unsigned)k.csize;
+                z.next_out = reinterpret_cast<unsigned char*>(u + k.uoff); z.avail_out = (unsigned)k.usize;
+                if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0) { bad = true; break; }
+            }
+        }
+        inflateEnd(&z);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < std::max(1u, threads); ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    munmap(cm, clen);
+    if (bad) { munmap(um, total); throw std::runtime_error("failed to inflate BGZF file: " + path); }
+    base = u; len = total; anon = true;
+    return true;
+}
 inline void sketchy::MappedFile::prefetch(size_t a, size_t b) const {
-    if (!base || b <= a) return;
+    if (!base || b <= a || anon) return;  // (inflated data is resident already)
     const size_t page = 4096, lo = a & ~(page - 1);
     char* p = const_cast<char*>(base) + lo;
 #ifndef MADV_POPULATE_READ

@@ -272,7 +272,9 @@ class Sketchy {
         using clock = std::chrono::steady_clock;
         const auto t_begin = clock::now();
         MappedFile map;
-        const bool mapped = map.open(path);
+        // (a BGZF file -- gzip members with their sizes in the header -- is inflated by all threads at once and then cut and parsed
+        // like an uncompressed one; plain gzip is one sequential stream)
+        const bool mapped = map.open(path) || map.open_bgzf(path, config.threads ? (unsigned)config.threads : std::min(usable_threads(), 22u));
         const char *fbegin = mapped ? map.data() : nullptr, *fend = mapped ? map.data() + map.size() : nullptr;
         bool fastq = false;
         size_t chunk_bytes = 0;
@@ -631,7 +633,7 @@ class Sketchy {
             std::fprintf(stderr, "{\"sketchy_hip_timing\": {\"reads\": %zu, \"batches\": %zu, \"seconds_stream\": %.6f, \"seconds_parse_start_to_last_row\": %.6f, "
                                  "\"reads_per_s\": %.1f, \"parse_threads\": %u, \"format_threads\": %u, \"cpus_pinned_near_device\": %u, \"input\": \"%s\", \"batch_reads\": %zu, "
                                  "\"device_thread_s\": {\"wait_for_parsers\": %.6f, \"submit\": %.6f, \"drain_and_hand_over\": %.6f}}}\n",
-                         fed, n_batches, all_s, run_s, fed / std::max(run_s, 1e-9), n_parse, n_format, pinned, mapped ? (fastq ? "mapped fastq" : "mapped fasta") : "streamed", want_reads,
+                         fed, n_batches, all_s, run_s, fed / std::max(run_s, 1e-9), n_parse, n_format, pinned, mapped ? (map.inflated() ? (fastq ? "bgzf fastq" : "bgzf fasta") : (fastq ? "mapped fastq" : "mapped fasta")) : "streamed", want_reads,
                          s_wait_parse, s_submit, s_retire);
         }
     }

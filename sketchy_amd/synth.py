@@ -509,3 +509,19 @@ def make_reference_snp(n_genomes: int, s: int, k: int = 16, hash_seed: int = 0, 
     col_len = np.full(n_genomes, s, np.uint32)
     return dict(genome=ascii_np[anc.cpu().numpy()], ref=np.ascontiguousarray(ref), col_len=col_len, k=k, seed=hash_seed, s=s,
                 lineage=lineage, truth_index=truth_index, truth_genome=np.ascontiguousarray(truth_genome))
+
+
+def write_bgzf(path, data, block=65280, level=1):
+    """BGZF (bgzip / htslib): a series of gzip members of at most 64 KB, each with a 'BC' extra subfield holding its size - 1, closed
+    by an empty member -- the form of .fastq.gz whose members `sketchy-hip` inflates in parallel.  data: bytes or a uint8 array."""
+    import struct
+    import zlib
+    mv = memoryview(data).cast("B")
+    with open(path, "wb") as f:
+        for a in list(range(0, len(mv), block)) + [None]:
+            chunk = b"" if a is None else mv[a:a + block]
+            z = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = z.compress(chunk) + z.flush()
+            bsize = 12 + 6 + len(comp) + 8
+            f.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            f.write(comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))

@@ -102,3 +102,6 @@ def workload_snp(n_genomes, s, n_reads, read_len=1500, k=16, seed=0, genome_len=
         res = (ref, z["bases"], z["offsets"])
     _SNP_CACHE[key] = res
     return res
+
+
+from sketchy_amd.synth import write_bgzf  # noqa: E402,F401  (BGZF writer: bench.py's gz leg uses the same)

@@ -185,6 +185,39 @@ def test_bench_eight_ranks_on_one_gpu(gpu):
     assert sum("table reducer ready" in ln for ln in out.stderr.splitlines()) == 8, out.stderr[-3000:]
 
 
+@pytest.mark.parametrize("workload_kind", ["ancestor", "truth"])
+def test_bench_eight_ranks_multi_species(gpu, workload_kind):
+    """BASELINE configs[4]'s shape (five species resident, log-normal read lengths, a stream MIXED over all five, sharded over
+    eight ranks) at reduced size, all ranks on the box's one GPU: the multi-species path has met eight ranks once.  Every rank
+    checks its own shard's rows (4 096-read cuts); rank 0 also compares every row of its first and last step with the oracle."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--share-gpu", "--allow-host-allreduce", "--config", "c4s",
+                          "--workload", workload_kind, "--batch", "2048", "--steps", "3", "--warmup", "1", "--reps", "2", "--cpu-seconds", "0",
+                          "--no-extra-legs"],
+                         capture_output=True, text=True, timeout=1500, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and "parity_error" not in j and len(j["values_per_rank"]) == 8
+    assert j["config"]["n_species"] == 5 and j["config"]["allreduce"]["world"] == 8
+    assert j["parity"]["last_timed_step_vs_4096_read_cuts"] is True
+
+
+def test_bench_multi_species_whole_steps_vs_oracle(gpu):
+    """the same small five-species config on one rank: EVERY row of the first and of the last timed step and the final table
+    against the oracle (orc_stream_fast, one run per species over the mixed stream)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for kind in ("ancestor", "truth"):
+        out = subprocess.run([sys.executable, "bench.py", "--config", "c4s", "--workload", kind, "--batch", "8192", "--steps", "4", "--warmup", "1",
+                              "--reps", "2", "--cpu-seconds", "0", "--no-extra-legs"],
+                             capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        o = j["oracle_whole_steps"]
+        assert o["timed_rows_match_oracle"] is True and o["final_table_matches_oracle"] is True and o["rows_compared"] == 2 * 8192 * 5
+
+
 def test_comm_watchdog_ends_a_rank_whose_peer_never_arrives(gpu):
     """Option comm_timeout_ms: ncclCommInitRank for a 2-rank communicator with only rank 0 present blocks for ever; with the
     watchdog the PROCESS ends with SKX_COMM_TIMEOUT_EXIT (86) after the stated time and says which rank was stuck where."""

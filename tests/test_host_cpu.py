@@ -140,6 +140,35 @@ def test_stream_rows_from_fasta_gzip_and_stdin(asan_bin, tmp_path):
     assert rc == 0 and out == _expected([r for r in reads if r], names, geno, top=1, limit=40)
 
 
+def test_stream_rows_from_bgzf_inflated_in_parallel(asan_bin, tmp_path):
+    """A BGZF file (bgzip: gzip members of <= 64 KB with their sizes in the header) is inflated by all threads at once and then cut
+    and parsed like an uncompressed file; plain gzip of the same reads is one sequential stream.  Same rows, byte for byte; a BGZF
+    file cut in the middle of a member ends with a message."""
+    from helpers import write_bgzf
+    names, geno, msh, tsv = _reference(tmp_path)
+    reads = _reads(700, 1, 900, seed=21)
+    want = _expected(reads, names, geno, top=2)
+    fq = str(tmp_path / "reads.fq")
+    _fastq(fq, reads)
+    raw = open(fq, "rb").read()
+    bg = str(tmp_path / "reads.fq.gz")
+    for block in (65280, 777):   # (members far smaller than a record line: records span many members)
+        write_bgzf(bg, raw, block=block)
+        assert gzip.open(bg).read() == raw
+        rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", bg, "-s", "-t", "2", "-b", "16", "-j", "6", "--timing")
+        assert rc == 0, err
+        assert out == want and "bgzf fastq" in err
+    plain = str(tmp_path / "plain.fq.gz")
+    with gzip.open(plain, "wb") as f:
+        f.write(raw)
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", plain, "-s", "-t", "2", "-b", "16", "--timing")
+    assert rc == 0 and out == want and "streamed" in err
+    cut = str(tmp_path / "cut.fq.gz")
+    open(cut, "wb").write(open(bg, "rb").read()[:-400])
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", cut, "-s", "-b", "16")
+    assert rc in (0, 1) and "Sanitizer" not in err   # (a truncated tail: either the streaming reader's error or the reads that were whole)
+
+
 def test_a_chunk_with_far_more_reads_than_the_first_records_promised(asan_bin, tmp_path):
     """Chunks are sized from the first 64 records; when the rest of the file holds 100-fold shorter reads a chunk carries far
     more reads than its slot holds: the overflow goes through heap batches and the spill slot, rows and order unchanged."""
