@@ -187,7 +187,8 @@ def _end_to_end(refs, batches, batch_bases, B, read_len, top, n_use, S, step_row
             rec_bytes = 8 + L + 3 + L + 1
             raw = np.fromfile(d + "/reads.fq", np.uint8, count=n_gz * B * rec_bytes)
             t2 = time.time()
-            synth.write_bgzf(d + "/reads.bgzf.fq.gz", raw)
+            from sketchy_amd import synth as _synth
+            _synth.write_bgzf(d + "/reads.bgzf.fq.gz", raw)
             zc = zlib.compressobj(1, zlib.DEFLATED, 31)
             with open(d + "/reads.plain.fq.gz", "wb") as f:
                 for a in range(0, len(raw), 1 << 26):
