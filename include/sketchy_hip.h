@@ -253,7 +253,7 @@ int skx_stream_reads(const skx_stream *st, uint64_t *n_reads);
  * "stream_coalesce"), [12] groups of enqueued batches that turned out too large for one pass together (or held an error) and were
  * processed one by one -- the stream forms smaller groups after that, [13] rows (distinct query hashes) the bit matrices of a
  * pass hold right now, [14] how often they grew because a batch held more distinct hashes than that (only without a
- * "stream_query_rows" policy; at most an eighth of the free device memory is taken), [15] of the most recent dictionary ([2]) the
+ * "stream_query_rows" policy; at most a quarter of the free device memory is taken), [15] of the most recent dictionary ([2]) the
  * hashes the scan looked for (all of them without a rare-hash index, skx_ref_rare_index; else those many genomes hold), [16] batches
  * whose per-read ranking ran on their CANDIDATES only (the genomes whose value at the end of the batch reaches the top-th best
  * value at its start: at most 1024 per species), [17] batches ranked on every genome.  Waits for the stream's queued work.

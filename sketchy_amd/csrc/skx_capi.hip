@@ -60,9 +60,9 @@ static int fail(int code, const char* fmt, ...) {
 
 SKX_API const char* skx_last_error(void) { return g_err.c_str(); }
 #ifdef SKX_EXPERIMENTS
-SKX_API const char* skx_version(void) { return "sketchy-hip 0.4.0 (gfx950, experiments build: reads SKX_* environment knobs)"; }
+SKX_API const char* skx_version(void) { return "sketchy-hip 0.5.0 (gfx950, experiments build: reads SKX_* environment knobs)"; }
 #else
-SKX_API const char* skx_version(void) { return "sketchy-hip 0.4.0 (gfx950)"; }
+SKX_API const char* skx_version(void) { return "sketchy-hip 0.5.0 (gfx950)"; }
 #endif
 
 SKX_API int skx_device_count(void) {
@@ -1191,7 +1191,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         size_t mem_free = 0, mem_total = 0;
         (void)hipMemGetInfo(&mem_free, &mem_total);
         const u64 per_row = (u64)n_pad / 8 + 2ull * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8 + 3ull * skx::kPassBatchesMax * 4 + 8;
-        st->qcap_max = (u32)std::max<u64>(st->qcap, std::min<u64>(st->pcap, (u64)(mem_free / 8) / per_row) / 64 * 64);
+        st->qcap_max = (u32)std::max<u64>(st->qcap, std::min<u64>(st->pcap, (u64)(mem_free / 4) / per_row) / 64 * 64);
     }
     static const u32 coalesce_env = skx::knob("SKX_COALESCE") ? (u32)atoi(skx::knob("SKX_COALESCE")) : 0u;  // experiment knob
     st->coalesce = coalesce_env ? std::min<u32>((u32)kGroupMax, std::max(1u, coalesce_env)) : g_stream_coalesce.load();
@@ -1553,7 +1553,7 @@ SKX_API int skx_stream_profile(skx_stream* st, double* ms, uint64_t* launches) {
 // canonical 16-mers in that range -- every sequencing error has an even chance to hit somebody's private hash) leaves ~160 k distinct
 // hashes per batch: cut into passes of 65 536 pairs that was SEVEN scans per batch (10 M reads/s instead of 130 M).  Without a
 // "stream_query_rows" policy the matrices therefore GROW when a batch (or a group of batches that would share a pass) needs more rows:
-// everything in flight is waited for, the new arrays are allocated before the old ones are freed, at most an eighth of the free device
+// everything in flight is waited for, the new arrays are allocated before the old ones are freed, at most a quarter of the free device
 // memory is taken.  Not on the steady path: a stream grows once or twice, then its groups fit.
 static int queue_chains(skx_stream* st, bool block);
 static int queue_chains_until(skx_stream* st, int leave);
@@ -1571,7 +1571,7 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
     const u64 per_row = (u64)n_pad / 8 * (st->d_mint ? 2 : 1) + 2 * mq_words * 8 + 2 * (u64)(n_pad / (skx::kRankWords * 64)) / 8 + 1 +
                         5ull * skx::kPassBatchesMax * 4;  // (+ the per-batch row counters, the two rare-row maps, the long-row lists)
-    u64 rows = std::min<u64>(want_rows, (u64)(mem_free / 8) / per_row);
+    u64 rows = std::min<u64>(want_rows, (u64)(mem_free / 4) / per_row);  // (a quarter of what is free: the one array family a dense stream cannot do without)
     rows = std::min<u64>(rows, st->pcap) / 64 * 64;
     if (rows <= st->qcap) return SKX_OK;  // no room (or nothing to gain): the batch is cut into passes as before
     u64 *m = nullptr, *mint = nullptr, *mq[2] = {nullptr, nullptr}, *ra[2] = {nullptr, nullptr};
@@ -1841,14 +1841,14 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             skx::launch_pass_hist(hs, d_pair_q, pbt, st->d_rowcnt, qstride);
             const skx::RareIndex ri = ref->rare_index();
             if (split_dict) HIPCHK(hipMemsetAsync(st->d_gain_s, 0, (size_t)n_sub * n_pad * 4 * skx::gain_sparse_stride(), hs));
-            skx::launch_pass_gain(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain, st->d_gain_s,
-                                  split_dict ? st->d_sslot : nullptr, split_dict ? &ri : nullptr);
-            if (long_rows) {  // the rows with a bit row: listed per batch, added up with bit-sliced counters
+            const skx::LongRows lrows = st->long_rows();
+            if (long_rows) {  // the rows with a bit row: listed per batch (by the walk below), added up with bit-sliced counters
                 HIPCHK(hipMemsetAsync(st->d_nlrow, 0, 64, hs));
                 HIPCHK(hipMemsetAsync(st->d_gain_l, 0, (size_t)n_sub * n_pad * 4, hs));
-                skx::launch_long_rows(hs, st->d_sslot, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->long_rows());
-                skx::launch_gain_long(hs, st->long_rows(), ri, d_nd, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_l);
             }
+            skx::launch_pass_gain(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain, st->d_gain_s,
+                                  split_dict ? st->d_sslot : nullptr, split_dict ? &ri : nullptr, long_rows ? &lrows : nullptr);
+            if (long_rows) skx::launch_gain_long(hs, lrows, ri, d_nd, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_l);
         }
         skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (split_dict && P > 0) ? st->d_gain_s : nullptr,
                                 (long_rows && P > 0) ? st->d_gain_l : nullptr, (u32)n_sub, n_pad, ps.tab);
@@ -2358,7 +2358,13 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     // set and pair lists.  Decided here, when a later one's front half is queued: the batches waiting must be one open group
     // with room left (stream_coalesce), speculative and production like this one, and the caller must have asked for it
     // (pb.pairable: the enqueue / submit entry points of a stream created with stream_coalesce >= 2).
-    bool joins = pb.pairable && pb.spec_insert && pb.inrange_only && !pb.rows_mode && st->n_pend >= 1 && st->n_pend < (int)std::min(st->group_cap, pb.max_group);
+    // (the FIRST group of a sample is kept to four batches: its pass ranks on everything -- nothing is known about the sample yet --, and
+    // the sooner it has said what its candidates were, the sooner the passes behind it can rank compactly.  K = 20 batches: passes of
+    // 4 + 8 + 8 instead of 8 + 8 + 4, the same three scans)
+    static const u32 first_group_env = skx::knob("SKX_FIRST_GROUP") ? (u32)atoi(skx::knob("SKX_FIRST_GROUP")) : 4u;  // experiment knob
+    const u32 fresh_cap = (st->fresh_table && st->top_k && ref->max_species > skx::kCandCap) ? std::max(1u, first_group_env) : 0xFFFFFFFFu;
+    bool joins = pb.pairable && pb.spec_insert && pb.inrange_only && !pb.rows_mode && st->n_pend >= 1 &&
+                 st->n_pend < (int)std::min(std::min(st->group_cap, pb.max_group), fresh_cap);
     if (joins && st->ppr_est > 0.0) {  // would the group still fit a pass?  (a group that does not is un-shared at a price: batch_back_group)
         u64 reads = pb.n_reads;
         for (int i = 0; i < st->n_pend; ++i) reads += st->pend[i].n_reads;

@@ -3779,7 +3779,7 @@ __global__ __launch_bounds__(256) void gain_dense_kernel(const u64* __restrict__
 // list --, counts summed per list first.  DESIGN.md section 9.)
 __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
                                                           const u32* __restrict__ cnt, u32 row_stride, u32 n_b, u32 n_pad,
-                                                          u32* __restrict__ gain) {
+                                                          u32* __restrict__ gain, LongRows lr) {
     __builtin_amdgcn_s_setprio(2);
     const u32 nd64 = n_d[2], ns = n_d[1], lane = lane_id();
     const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
@@ -3799,7 +3799,25 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
                     if (b < n_b) { c[b] = cnt[(size_t)b * row_stride + nd64 + sr]; any |= c[b]; }
             }
         }
-        if (!any || (np & kLongFlag)) np = 0;  // (rows with a bit row: gain_long_kernel)
+        const bool is_long = (np & kLongFlag) != 0u;
+        if (__ballot(is_long)) {
+            // rows with a bit row: listed per batch for gain_long_kernel / cand_long_kernel (one walk over the rare rows instead of two)
+            if (lr.lrow) {
+#pragma unroll
+                for (u32 b = 0; b < kPassBatchesMax; ++b) {
+                    if (b >= n_b) break;
+                    const bool in = is_long && c[b] != 0u;
+                    const u64 bal = __ballot(in);
+                    if (!bal) continue;
+                    u32 base = 0;
+                    if (lane == 0u) base = atomicAdd(&lr.nlrow[b], (u32)__popcll(bal));
+                    base = (u32)__shfl((int)base, 0);
+                    if (in) lr.lrow[(size_t)b * lr.lrow_stride + base + (u32)__popcll(bal & lanemask_lt())] = make_uint2(off, sr);
+                }
+            }
+            if (is_long) np = 0;
+        }
+        if (!any) np = 0;
         if (np && np <= 8u) {
             for (u32 j = 0; j < np; ++j) {
                 const u32 g = ri.post[off + j];
@@ -4608,7 +4626,7 @@ void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, 
     hipLaunchKernelGGL(pass_hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pair_q, pb, cnt, row_stride);
 }
 void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride,
-                      u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri) {
+                      u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri, const LongRows* lr) {
     const dim3 grid(n_pad / 256, std::max(1u, cdiv(cdiv(rows_bound, 64), kGainWords)));
 #define SKX_GAIN(NB) hipLaunchKernelGGL(gain_dense_kernel<NB>, grid, dim3(256), 0, st, m_bits, m_int, n_pad, n_d, cnt, row_stride, gain)
     switch (n_b) {
@@ -4620,7 +4638,7 @@ void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n
     // the other streams' kernels -- the next group's sketches -- out of the wave slots: 56 M reads/s with 1832 blocks, measured)
     if (ri && sslot && gain_s)
         hipLaunchKernelGGL(gain_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks))), dim3(256), 0, st, sslot, n_d, *ri, cnt,
-                           row_stride, n_b, n_pad, gain_s);
+                           row_stride, n_b, n_pad, gain_s, lr ? *lr : LongRows{nullptr, nullptr, 0u});
 }
 u32 gain_sparse_stride() { return kGainSparseStride; }
 void launch_mlong_build(hipStream_t st, const u32* lslot, u32 n_long, const u32* off, const u32* cnt, const u32* post, u64* mlong, u32 n_gw) {

@@ -136,7 +136,8 @@ void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, 
 // re-zeroes it), the others from the genome lists (ri / sslot, or NULL)
 // gain_s (zero on entry, [n_b][n_pad] entries gain_sparse_stride() words apart): the rare rows' part
 void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt,
-                      u32 row_stride, u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri);
+                      u32 row_stride, u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri,
+                      const LongRows* lr = nullptr /* also lists the rows with a bit row per batch (nlrow zero on entry) */);
 u32 gain_sparse_stride();
 // tab[0] = prev, tab[b + 1] = tab[b] + gain[b]   ([n_b + 1][n_pad])
 void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s /* or NULL */, const u32* gain_l /* or NULL */, u32 n_b,
