@@ -1898,15 +1898,21 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         HIPCHK(hipGetLastError());
     }
     if (P > 0) {
-        if (split_dict) {
+        // the rows behind the dense ones of the FULL matrix: from the reference's rare-hash index.  With a bit row for every list of
+        // more than eight genomes they go straight into the group-major matrix (rare_to_mq_kernel) and M -- hence the transpose --
+        // holds the dense rows only; without (no room for the bit rows): bits from the genome lists into M, as the scan's.
+        static const int direct_env = skx::knob("SKX_RARE_DIRECT") ? atoi(skx::knob("SKX_RARE_DIRECT")) : 1;  // experiment knob: 0 = through M
+        const bool direct_rare = split_dict && ref->d_mlong != nullptr && direct_env != 0;
+        if (split_dict && !direct_rare) {
             Span sp(st, 1, hs);
-            // the rows behind the dense ones of the FULL matrix: bits from the genome lists of the reference's rare-hash index
             skx::launch_sparse_fill(hs, st->d_sslot, d_nd, ref->rare_index(), st->d_m, n_pad, d_mdirty, q_bound, only_if);
         }
         {
             Span sp(st, 3, hs);
-            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, d_nd + 3, d_grp_any,
-                                       nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, nq_est, st->d_rowany[b], only_if);
+            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, direct_rare ? d_nd + 2 : d_nd + 3, d_grp_any,
+                                       nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, direct_rare ? nd_est : nq_est, st->d_rowany[b], only_if);
+            if (direct_rare)
+                skx::launch_rare_to_mq(hs, st->d_sslot, d_nd, ref->rare_index(), d_mq, nq_rows, n_pad, st->d_rowany[b], d_grp_any, q_bound, only_if);
             if (only_if) skx::launch_m_clear(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, d_nd, only_if);
         }
     }
@@ -2362,7 +2368,10 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     // the sooner it has said what its candidates were, the sooner the passes behind it can rank compactly.  K = 20 batches: passes of
     // 4 + 8 + 8 instead of 8 + 8 + 4, the same three scans)
     static const u32 first_group_env = skx::knob("SKX_FIRST_GROUP") ? (u32)atoi(skx::knob("SKX_FIRST_GROUP")) : 4u;  // experiment knob
-    const u32 fresh_cap = (st->fresh_table && st->top_k && ref->max_species > skx::kCandCap) ? std::max(1u, first_group_env) : 0xFFFFFFFFu;
+    // (... where a scan of the reference costs no more than the rankings it spares: the smaller first group can add one scan to the
+    // sample -- K = 8 batches: 4 + 4 instead of 8.  Five species resident, 12 GB per scan: 36 M reads/s became 27 M.  Up to 6 GB.)
+    const bool scan_is_cheap = (u64)ref->n_pad * ref->s * 8ull <= (6ull << 30);
+    const u32 fresh_cap = (st->fresh_table && st->top_k && ref->max_species > skx::kCandCap && scan_is_cheap) ? std::max(1u, first_group_env) : 0xFFFFFFFFu;
     bool joins = pb.pairable && pb.spec_insert && pb.inrange_only && !pb.rows_mode && st->n_pend >= 1 &&
                  st->n_pend < (int)std::min(std::min(st->group_cap, pb.max_group), fresh_cap);
     if (joins && st->ppr_est > 0.0) {  // would the group still fit a pass?  (a group that does not is un-shared at a price: batch_back_group)

@@ -1423,19 +1423,19 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(const u64* __restrict_
                                                           PairBase base) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 r = r_begin + blockIdx.x * 256u + threadIdx.x;
-    if (r >= r_end) return;
     // base: the batch shares its pass with the batches before it -- its pairs go behind theirs (whose pair counts are only
     // known on the device when this is queued), into the same hash set
     u64 p_off64 = 0;
 #pragma unroll
     for (int i = 0; i < kPairBaseMax; ++i)
         if (base.p[i]) p_off64 += *base.p[i];
-    if ((u64)(poff[r_end] - p_base) + p_off64 > pair_cap) return;
+    if ((u64)(poff[r_end] - p_base) + p_off64 > pair_cap) return;  // (uniform)
     const u32 p_off = (u32)p_off64;
-    const u32 a = poff[r], b = poff[r + 1];
-    if (b == a) return;
-    const u64* row = sk_stride ? sk + (size_t)r * sk_stride : sk + (size_t)row_off[r];
+    u32 a = 0, b = 0;
+    if (r < r_end) { a = poff[r]; b = poff[r + 1]; }
+    const u64* row = sk_stride ? sk + (size_t)r * sk_stride : (r < r_end ? sk + (size_t)row_off[r] : sk);
     pair_h += p_off; pair_r += p_off;
+    u32 fresh = 0;  // keys this thread put into the set
     for (u32 j = 0; j < b - a; ++j) {
         const u64 key = row[j];
         pair_h[a - p_base + j] = key;
@@ -1443,12 +1443,19 @@ __global__ __launch_bounds__(256) void dict_insert_kernel(const u64* __restrict_
         if (key == kPad) { atomicOr(&ctr[1], 1u); continue; }  // the empty marker itself: appended to Q at the end
         u32 slot = (u32)(key ^ (key >> 29)) & ht_mask;
         for (;;) {
-            const u64 prev = atomicCAS(&ht[slot], kPad, key);
-            if (prev == kPad) { atomicAdd(&ctr[2], 1u); break; }  // a new key: ctr[2] = distinct keys in the set (|Q| of the pass)
+            // (a look before the compare-and-swap: a slot only ever goes from empty to its key inside a pass, so a key seen is final --
+            // most pairs repeat a key that is already there, and a load is served where the atomic has to go to the memory side)
+            u64 prev = __hip_atomic_load(&ht[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == kPad) prev = atomicCAS(&ht[slot], kPad, key);
+            if (prev == kPad) { ++fresh; break; }  // a new key
             if (prev == key) break;
             slot = (slot + 1u) & ht_mask;
         }
     }
+    // ctr[2] = distinct keys in the set (|Q| of the pass): one add per wave, not per key (truth-strain batches bring 160 k new keys)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) fresh += __shfl_xor(fresh, d);
+    if ((threadIdx.x & 63u) == 0 && fresh) atomicAdd(&ctr[2], fresh);
 }
 // used slots: count per bucket; the slot remembers its place inside the bucket (atomics spread over 2^17 addresses)
 __global__ __launch_bounds__(256) void dict_count_kernel(const u64* __restrict__ ht, u32 ht_slots, u32 bshift,
@@ -1778,6 +1785,103 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict_
         }
     }
     if (wrote && m_dirty) *m_dirty = 1u;
+}
+
+// The rare rows of a pass straight into the group-major matrix Mq -- not through M and the transpose.  A rare row's bits are known
+// without the scan: a bit row of the reference's index (long lists: Mq[grp][row] IS words 8 grp .. 8 grp + 7 of it) or at most
+// kShortList genomes.  Through M (sparse_fill_kernel + transpose_bits_kernel) a truth-strain pass of 469 k rows paid one scattered
+// atomic per posting (2.0 ms) and a transpose of 2.4 GB of mostly zeros (1.7 ms) whenever one of its batches ranked on everything.
+// Here: one block per 64 rows (= one word of rowany per group); thread (row, word of the group) walks the groups, copying or
+// zero-filling -- 512-byte runs per wave, 2 KB per block and group --, then the short rows' few words are written over their zeros.
+// rowany[grp][word of these rows] is written for every group (plain stores), grp_any[grp] += rows of the group that hold a bit.
+constexpr u32 kRareGrpChunk = 512;  // groups per turn (rowany words of a block in LDS)
+__global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
+                                                         u64* __restrict__ mq, u32 nq_rows, u32 n_gw, u64* __restrict__ rowany,
+                                                         u32* __restrict__ grp_any, const u32* __restrict__ only_if) {
+    __builtin_amdgcn_s_setprio(2);
+    if (only_if && !*only_if) return;  // (no batch of the pass ranks on the full matrix)
+    __shared__ u32 lpost[64][kShortList];
+    __shared__ unsigned long long lany[kRareGrpChunk];
+    const u32 nd64 = n_d[2], ns = n_d[1], n_grp = n_gw / kRankWords, n_words = nq_rows >> 6;
+    const u32 r = threadIdx.x >> 3, cw = threadIdx.x & 7u, lane = lane_id();
+    static_assert(kRankWords == 8 && kShortList == 8, "thread = (row, word of the group) = (row, posting)");
+    u32 acc = 0;  // (threads 0 .. chunk - 1 of the first turn) rows of "their" group that hold a bit, over the block's row blocks
+    for (u32 sr0 = blockIdx.x * 64u; sr0 < ns; sr0 += gridDim.x * 64u) {
+        // this thread's two rows: sr0 + r and sr0 + r + 32
+        u32 lid[2], np[2];
+        bool lng[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32 sr = sr0 + r + 32u * h;
+            lid[h] = 0; np[h] = 0; lng[h] = false;
+            u32 mine = 0xFFFFFFFFu;
+            if (sr < ns) {
+                const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr];
+                lng[h] = (e.y & kLongFlag) != 0u;
+                np[h] = e.y & ~kLongFlag;
+                lid[h] = e.x;
+                if (!lng[h] && cw < np[h]) mine = ri.post[e.x + cw];
+            }
+            lpost[r + 32u * h][cw] = mine;
+        }
+        const u32 row0 = nd64 + sr0;
+        for (u32 g0 = 0; g0 < n_grp; g0 += kRareGrpChunk) {
+            const u32 g1 = min(n_grp, g0 + kRareGrpChunk);
+            for (u32 i = threadIdx.x; i < g1 - g0; i += 256u) lany[i] = 0ull;
+            __syncthreads();
+            // long rows: copy; short rows: zeros.  Four groups in flight per thread (the loads of a bit row are 64-byte pieces)
+            for (u32 g = g0; g < g1; g += 4u) {
+                u64 v[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        v[u][h] = (lng[h] && g + u < g1) ? __builtin_nontemporal_load(&ri.mlong[(size_t)lid[h] * n_gw + (size_t)(g + u) * kRankWords + cw]) : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (g + u >= g1) break;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        mq[((size_t)(g + u) * nq_rows + row0 + r + 32u * h) * kRankWords + cw] = v[u][h];
+                        // rows of this wave (8 of them: 8 lanes each) that hold a bit for the group
+                        u64 m = __ballot(v[u][h] != 0ull);
+                        if (m) {
+                            m |= m >> 4; m |= m >> 2; m |= m >> 1; m &= 0x0101010101010101ull;
+                            const u64 rows8 = (m * 0x0102040810204080ull) >> 56;  // bit i = row i of the wave
+                            if (lane == 0u) atomicOr(&lany[g + u - g0], rows8 << ((threadIdx.x >> 6) * 8u + 32u * h));
+                        }
+                    }
+                }
+            }
+            __threadfence();   // (the zeros have arrived before the short rows' words follow them to the same addresses)
+            __syncthreads();
+            // short rows: thread (row, j) owns posting j -- the word it falls into gets every bit of the row's postings in that word
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32 rr = r + 32u * h, pj = lpost[rr][cw];
+                if (pj == 0xFFFFFFFFu) continue;
+                const u32 gw = pj >> 6, g = gw / kRankWords;
+                if (g < g0 || g >= g1) continue;
+                u64 val = 0;
+#pragma unroll
+                for (u32 k = 0; k < kShortList; ++k) {
+                    const u32 pk = lpost[rr][k];
+                    if (pk != 0xFFFFFFFFu && (pk >> 6) == gw) val |= 1ull << (pk & 63u);
+                }
+                mq[((size_t)g * nq_rows + row0 + rr) * kRankWords + gw % kRankWords] = val;
+                atomicOr(&lany[g - g0], 1ull << rr);
+            }
+            __syncthreads();
+            for (u32 i = threadIdx.x; i < g1 - g0; i += 256u) {
+                const u64 a = lany[i];
+                rowany[(size_t)(g0 + i) * n_words + (row0 >> 6)] = a;
+                if (g0 == 0u && n_grp <= kRareGrpChunk && i == threadIdx.x) acc += (u32)__popcll(a);
+                else if (a) atomicAdd(&grp_any[g0 + i], (u32)__popcll(a));
+            }
+            __syncthreads();  // (lany and lpost are reused)
+        }
+    }
+    if (acc) atomicAdd(&grp_any[threadIdx.x], acc);
 }
 
 // =====================================================================================
@@ -4616,6 +4720,11 @@ void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const 
                         const u32* only_if) {
     const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks));
     hipLaunchKernelGGL(sparse_fill_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, m_bits, n_pad, m_dirty, only_if);
+}
+void launch_rare_to_mq(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* mq, u32 nq_rows, u32 n_pad, u64* rowany,
+                       u32* grp_any, u32 rows_bound, const u32* only_if) {
+    const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 64), 1024u));
+    hipLaunchKernelGGL(rare_to_mq_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, mq, nq_rows, n_pad / 64, rowany, grp_any, only_if);
 }
 void launch_nd_from_nq(hipStream_t st, const u32* n_q, u32* n_d, u32* h_words) {
     hipLaunchKernelGGL(nd_from_nq_kernel, dim3(1), dim3(1), 0, st, n_q, n_d, h_words);

@@ -443,6 +443,9 @@ inline bool sketchy::MappedFile::open_bgzf(const std::string& path, unsigned thr
     if (!ok || total < 2 || (pages > 0 && psz > 0 && total > (size_t)pages * (size_t)psz / 4)) { munmap(cm, clen); return false; }
     void* um = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (um == MAP_FAILED) { munmap(cm, clen); return false; }
+#ifdef MADV_HUGEPAGE
+    (void)madvise(um, total, MADV_HUGEPAGE);  // (first touch by all threads at once: 2 MB pages where the kernel gives them -- 512 x fewer faults)
+#endif
     char* u = static_cast<char*>(um);
     std::atomic<size_t> next{0};
     std::atomic<bool> bad{false};

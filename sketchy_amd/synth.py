@@ -184,9 +184,10 @@ def make_reference(n_genomes: int, s: int, k: int = 16, hash_seed: int = 0, geno
 
 def _dedup_take(rows: np.ndarray, s: int) -> np.ndarray:
     """rows ascending per row; make each row strictly ascending (columns must be distinct
-    hashes) by bumping the rare duplicate, then keep the first s."""
+    hashes) by bumping the rare duplicate, then keep the first s.  (<=, not ==: a row that came back from the device
+    sort out of order -- seen once, under the profiler -- is sorted again here instead of being refused by skx_ref_create)"""
     rows = rows.copy()
-    dup = rows[:, 1:] == rows[:, :-1]
+    dup = rows[:, 1:] <= rows[:, :-1]
     if dup.any():
         for r in np.nonzero(dup.any(axis=1))[0]:
             u = np.unique(rows[r])
