@@ -712,6 +712,7 @@ struct skx_stream {
     // ev_main) so that the sketch stream runs main kernel after main kernel: those ~8 short, latency-bound kernels cost the
     // sketch stream 150-250 us per batch next to the other streams' work (kernel trace), a fifth of the step.
     hipStream_t hs1 = nullptr;  // aliases hs0 below pipeline depth 3
+    bool tail_pass = false;     // the pass being queued closes a flush: no younger batch is sketched beside it
     hipEvent_t ev_main[kSides] = {};  // sketch stream: everything of the batch queued on hs0 is done (per side)
     int depth = 2;
     bool shared_queues = false;  // hs / hs0 / hs1 / hs2 (and the second ranking lane's stream) belong to the device's SharedQueues
@@ -1420,7 +1421,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipMalloc(&st->d_candmask, (size_t)n_pad * 4));
         if (ref->d_mlong) {
             SCHK(hipMalloc(&st->d_lrow, (size_t)nb * ((size_t)st->qcap + 128) * 8));
-            SCHK(hipMalloc(&st->d_nlrow, 64));
+            SCHK(hipMalloc(&st->d_nlrow, skx::pass_counter_bytes()));
             SCHK(hipMalloc(&st->d_gain_l, (size_t)nb * n_pad * 4));
             SCHK(hipMalloc(&st->d_cw, (size_t)nb * (n_pad / 64) * 8));
             SCHK(hipMalloc(&st->d_cbase, (size_t)nb * (n_pad / 64) * 4));
@@ -1428,7 +1429,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
             SCHK(hipMalloc(&st->d_ncwl, 64));
         }
         SCHK(hipMalloc(&st->d_cbad, 64));
-        SCHK(hipMalloc(&st->d_nqc, 64));
+        SCHK(hipMalloc(&st->d_nqc, skx::pass_counter_bytes()));
         std::vector<u32> g0c(n_sp), grpc(st->n_grp_c);
         for (u32 i = 0; i < n_sp; ++i) g0c[i] = i * cap;
         for (u32 i = 0; i < st->n_grp_c; ++i) grpc[i] = i / (cap / (skx::kRankWords * 64));
@@ -1622,7 +1623,8 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     const u32 nq_rows = ((q_bound + 63) / 64) * 64 + 64;
     // the ranking of earlier passes whose candidates have been published by now; the pass TWO back (it used this pass's buffer set)
     // must be through -- the one before this may still be waiting for its scan
-    SKXCHK(queue_chains(st, false));
+    // (the pass ONE back is queued BEHIND this pass's front half, further down: its eight chains are a hundred launches, 0.3-0.4 ms of
+    // this thread, and the dictionary and scan of this pass need not wait for them)
     if (st->pc_n == 2) SKXCHK(queue_chains_until(st, 1));
     update_cand_hint(st);
     const int b = st->buf;                      // buffer set handed from stage to stage for this pass
@@ -1741,11 +1743,67 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
         HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)n_grp_all * 4, hs));  // raised by the transpose
         if (P > 0) {
-            skx::launch_pair_q(hs, st->d_pair_h[b], P, d_q, d_nq, d_pair_q, split_dict ? st->d_qrow : nullptr);
+            skx::launch_pair_q(hs, st->d_pair_h[b], P, d_q, d_nq, d_pair_q, split_dict ? st->d_qrow : nullptr, st->d_bbase, st->d_btot, ref->max_ref);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(st->ev_pairq[b], hs));  // the set's hash set and pair hashes may be refilled
         st->pairq_pending[b] = true;
+        return SKX_OK;
+    };
+    // ---- the table as every batch of the pass begins (and as the pass ends), and the genomes each batch's ranking has to look at
+    // (skx_kernels.hip, "the table without the ranking").  All on the scan stream, before the transpose re-zeroes M.
+    bool ranked = false, all_forced = false, all_ranked = true;
+    for (int i = 0; i < n_sub; ++i) {
+        const bool r = st->top_k && subs[i].d_topk_idx && subs[i].d_topk_sum;
+        ranked = ranked || r; all_ranked = all_ranked && r && !subs[i].d_shared;
+    }
+    const u32* only_if = nullptr;  // device flag: does any batch of the pass rank on the FULL matrix?  (NULL: yes, unconditionally)
+    u32 seq = 0;
+    // A stream whose batches ALL have more candidates than a compact ranking takes (the bench's near-tie of 40 000 genomes) gains
+    // nothing from knowing its tables early: three passes out of four then take the table out of their ranking chains, as in rounds
+    // 1-4 (no row counts, no gains, no candidate selection: ~0.65 ms of scan-stream work per C2 pass, 9 % of the reads/s next to the
+    // sketches) -- and every such chain counts what its batch's candidates would have been (cand_count_kernel: two reads of the
+    // table), so the stream notices when a leader has emerged.
+    static const int legacy_env = skx::knob("SKX_TABLE_LEGACY") ? atoi(skx::knob("SKX_TABLE_LEGACY")) : 1 << 30;  // experiment knob: passes in a row (0: never)
+    static const int cand_env0 = skx::knob("SKX_CAND") ? atoi(skx::knob("SKX_CAND")) : 1;
+    // (... and the FIRST pass of a sample: on a table of zeros every genome of a species is a candidate of the first batch, whatever
+    // follows -- with more genomes than a compact ranking takes, the pass that would only find that out is not worth its wait)
+    const bool fresh_overflow = st->fresh_table && ref->max_species > skx::kCandCap;
+    // (the SECOND pass of a sample goes by a count from the second half of the first pass -- the first batches of ANY sample say
+    // "everything" -- and looks for itself when none has arrived yet)
+    const bool second_blind = st->passes_since_fresh == 1 && !((int)(st->lcount_seen - st->lcount_floor) > 0);
+    const bool legacy = update_table && all_ranked && cand_env0 && legacy_env > 0 &&
+                        (fresh_overflow || (st->hint_all_overflow && !second_blind && (int)st->legacy_run < legacy_env));
+    st->legacy_run = legacy ? st->legacy_run + 1 : 0;
+    if (update_table) { st->passes_since_fresh = st->fresh_table ? 1 : st->passes_since_fresh + 1; st->fresh_table = false; }
+    const bool long_rows = split_dict && ref->d_mlong != nullptr;
+    // (nothing is sketched beside a sample's last pass, or beside a synchronous push: the walks over the rare rows' lists and bit rows may
+    // fill the chip -- beside the next group's sketches the same grids cost 3-5 % of the reads/s.  Measured on the truth-strain workload:
+    // batches of twice the size 75 -> 91 M reads/s, 20 batches from a fresh table +1 %.  Tried and dropped: those gains on a stream of
+    // their own beside the scan -- nothing gained from a fresh table, and the mere existence of one more HIP stream cost the steady state
+    // 12 % on both workloads (176 -> 155 M, 133 -> 120 M reads/s: more streams than hardware queues).)
+    static const int tail_env = skx::knob("SKX_TAIL_SCALE") ? atoi(skx::knob("SKX_TAIL_SCALE")) : 8;  // experiment knob
+    const u32 walk_scale = st->tail_pass ? (u32)std::max(1, tail_env) : 1u;  // (nothing is sketched beside a sample's last pass: its list walks may fill the chip)
+    skx::PassBatches pbt;
+    pbt.n = (u32)n_sub;
+    for (int i = 0; i < n_sub; ++i) pbt.p_off[i] = subs[i].p_off;
+    pbt.p_off[n_sub] = P;
+    auto rare_gains = [&](hipStream_t on) -> int {  // row counts known: the short lists' adds, the bit rows' bit-sliced sums
+        const skx::RareIndex ri = ref->rare_index();
+        const skx::LongRows lrows = st->long_rows();
+        skx::launch_gain_sparse(on, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_s, st->d_sslot, ri, long_rows ? &lrows : nullptr, walk_scale);
+        if (long_rows) skx::launch_gain_long(on, lrows, ri, d_nd, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_l, walk_scale);
+        HIPCHK(hipGetLastError());
+        return SKX_OK;
+    };
+    auto row_counts = [&]() -> int {
+        HIPCHK(hipMemset2DAsync(st->d_rowcnt, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
+        skx::launch_pass_hist(hs, d_pair_q, pbt, st->d_rowcnt, qstride);
+        if (split_dict) HIPCHK(hipMemsetAsync(st->d_gain_s, 0, (size_t)n_sub * n_pad * 4 * skx::gain_sparse_stride(), hs));
+        if (long_rows) {  // the rows with a bit row: listed per batch (by the short lists' walk), added up with bit-sliced counters
+            HIPCHK(hipMemsetAsync(st->d_nlrow, 0, skx::pass_counter_bytes(), hs));
+            HIPCHK(hipMemsetAsync(st->d_gain_l, 0, (size_t)n_sub * n_pad * 4, hs));
+        }
         return SKX_OK;
     };
     const u32 n_words = nq_rows / 64;
@@ -1796,32 +1854,6 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     }
     if (P == 0) SKXCHK(wait_back());
 
-    // ---- the table as every batch of the pass begins (and as the pass ends), and the genomes each batch's ranking has to look at
-    // (skx_kernels.hip, "the table without the ranking").  All on the scan stream, before the transpose re-zeroes M.
-    bool ranked = false, all_forced = false, all_ranked = true;
-    for (int i = 0; i < n_sub; ++i) {
-        const bool r = st->top_k && subs[i].d_topk_idx && subs[i].d_topk_sum;
-        ranked = ranked || r; all_ranked = all_ranked && r && !subs[i].d_shared;
-    }
-    const u32* only_if = nullptr;  // device flag: does any batch of the pass rank on the FULL matrix?  (NULL: yes, unconditionally)
-    u32 seq = 0;
-    // A stream whose batches ALL have more candidates than a compact ranking takes (the bench's near-tie of 40 000 genomes) gains
-    // nothing from knowing its tables early: three passes out of four then take the table out of their ranking chains, as in rounds
-    // 1-4 (no row counts, no gains, no candidate selection: ~0.65 ms of scan-stream work per C2 pass, 9 % of the reads/s next to the
-    // sketches) -- and every such chain counts what its batch's candidates would have been (cand_count_kernel: two reads of the
-    // table), so the stream notices when a leader has emerged.
-    static const int legacy_env = skx::knob("SKX_TABLE_LEGACY") ? atoi(skx::knob("SKX_TABLE_LEGACY")) : 1 << 30;  // experiment knob: passes in a row (0: never)
-    static const int cand_env0 = skx::knob("SKX_CAND") ? atoi(skx::knob("SKX_CAND")) : 1;
-    // (... and the FIRST pass of a sample: on a table of zeros every genome of a species is a candidate of the first batch, whatever
-    // follows -- with more genomes than a compact ranking takes, the pass that would only find that out is not worth its wait)
-    const bool fresh_overflow = st->fresh_table && ref->max_species > skx::kCandCap;
-    // (the SECOND pass of a sample goes by a count from the second half of the first pass -- the first batches of ANY sample say
-    // "everything" -- and looks for itself when none has arrived yet)
-    const bool second_blind = st->passes_since_fresh == 1 && !((int)(st->lcount_seen - st->lcount_floor) > 0);
-    const bool legacy = update_table && all_ranked && cand_env0 && legacy_env > 0 &&
-                        (fresh_overflow || (st->hint_all_overflow && !second_blind && (int)st->legacy_run < legacy_env));
-    st->legacy_run = legacy ? st->legacy_run + 1 : 0;
-    if (update_table) { st->passes_since_fresh = st->fresh_table ? 1 : st->passes_since_fresh + 1; st->fresh_table = false; }
     if (update_table && !legacy && st->cum_writer) {  // (the table the last chain of a legacy pass left: the gains are added to it)
         HIPCHK(hipStreamWaitEvent(hs, st->cum_writer->ev_cum, 0));
         st->cum_writer = nullptr;
@@ -1829,26 +1861,12 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     if (update_table && !legacy) {
         Span sp(st, 4, hs);
         const u32 n_sp = ref->n_species, cap = skx::kCandCap, rows_c = skx::kCandRows;
-        skx::PassBatches pbt;
-        pbt.n = (u32)n_sub;
-        for (int i = 0; i < n_sub; ++i) pbt.p_off[i] = subs[i].p_off;
-        pbt.p_off[n_sub] = P;
         const u64* m_int = split ? st->d_mint : nullptr;
-        const bool long_rows = split_dict && ref->d_mlong != nullptr;
         HIPCHK(hipMemsetAsync(st->d_gain, 0, (size_t)n_sub * n_pad * 4, hs));
         if (P > 0) {
-            HIPCHK(hipMemset2DAsync(st->d_rowcnt, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
-            skx::launch_pass_hist(hs, d_pair_q, pbt, st->d_rowcnt, qstride);
-            const skx::RareIndex ri = ref->rare_index();
-            if (split_dict) HIPCHK(hipMemsetAsync(st->d_gain_s, 0, (size_t)n_sub * n_pad * 4 * skx::gain_sparse_stride(), hs));
-            const skx::LongRows lrows = st->long_rows();
-            if (long_rows) {  // the rows with a bit row: listed per batch (by the walk below), added up with bit-sliced counters
-                HIPCHK(hipMemsetAsync(st->d_nlrow, 0, 64, hs));
-                HIPCHK(hipMemsetAsync(st->d_gain_l, 0, (size_t)n_sub * n_pad * 4, hs));
-            }
-            skx::launch_pass_gain(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain, st->d_gain_s,
-                                  split_dict ? st->d_sslot : nullptr, split_dict ? &ri : nullptr, long_rows ? &lrows : nullptr);
-            if (long_rows) skx::launch_gain_long(hs, lrows, ri, d_nd, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_l);
+            SKXCHK(row_counts());
+            skx::launch_gain_dense(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain);
+            if (split_dict) SKXCHK(rare_gains(hs));
         }
         skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (split_dict && P > 0) ? st->d_gain_s : nullptr,
                                 (long_rows && P > 0) ? st->d_gain_l : nullptr, (u32)n_sub, n_pad, ps.tab);
@@ -1862,7 +1880,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         u32 force_full = all_forced ? 0xFFu : 0u;
         for (int i = 0; i < n_sub; ++i) if (subs[i].d_shared) force_full |= 1u << i;
         HIPCHK(hipMemsetAsync(st->d_cbad, 0, 64, hs));
-        HIPCHK(hipMemsetAsync(st->d_nqc, 0, 64, hs));
+        HIPCHK(hipMemsetAsync(st->d_nqc, 0, skx::pass_counter_bytes(), hs));
         if (ranked) {
             HIPCHK(hipMemsetAsync(st->d_candmask, 0, (size_t)n_pad * 4, hs));
             skx::launch_cand_select(hs, ps.tab, n_pad, spc, (u32)n_sub, st->top_k, cap, ps.cand, st->d_candslot, ps.tabc, ps.ncand, st->d_cbad,
@@ -1874,7 +1892,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                 HIPCHK(hipMemset2DAsync(ps.smap, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
                 skx::launch_cand_sparse(hs, st->d_sslot, d_nd, q_bound, ref->rare_index(), st->d_candmask, st->d_candslot, n_pad, st->d_cbad, (u32)n_sub, st->d_nqc,
                                         ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords, rows_c, ps.rowany_c,
-                                        st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c);
+                                        st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c, walk_scale);
                 if (long_rows) {  // ... and the rows with a bit row: ANDed with the candidates' words
                     const u32 n_gw = n_pad / 64;
                     HIPCHK(hipMemsetAsync(st->d_cw, 0, (size_t)n_sub * n_gw * 8, hs));
@@ -1883,7 +1901,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                     skx::launch_cand_words(hs, ps.cand, st->n_pad_c, (u32)n_sub, n_gw, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl);
                     skx::launch_cand_long(hs, st->long_rows(), ref->rare_index(), d_nd, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl, st->n_pad_c,
                                           st->d_cbad, (u32)n_sub, st->d_nqc, ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords,
-                                          rows_c, ps.rowany_c, st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c);
+                                          rows_c, ps.rowany_c, st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c, walk_scale);
                 }
             }
         } else {
@@ -1922,6 +1940,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     (void)lean_used;
 
     // ---- the ranking chains are queued by queue_chains, once the pass's candidates are known
+    SKXCHK(queue_chains(st, false));  // (the pass before this one, if its candidates have been published by now)
     skx_stream::PassChains& pc = st->pcq[(st->pc_head + st->pc_n) & 1];
     st->pc_n += 1;
     pc.pending = true; pc.ranked = ranked; pc.has_cand = update_table;
@@ -2702,7 +2721,9 @@ static int pending_back(skx_stream* st, PendingBatch* younger) {
     // (a group that went batch by batch may fail at batch i: batches 0 .. i - 1 are scored, their rows must still reach the
     // host; the slots of the others are marked so that skx_stream_wait reports the loss instead of returning stale rows)
     int done = 0;
+    st->tail_pass = younger == nullptr;  // (a flush: nothing is sketched beside the group's pass)
     int rc = batch_back_group(st, g, n, younger, &done);
+    st->tail_pass = false;
     const std::string msg = rc != SKX_OK ? g_err : std::string();
     // (host-fed batches: the rows of the scored ones go back to the host behind their ranking chains -- queue_chains)
     for (int i = done; i < n; ++i) staged_drop(g[i].slot);
@@ -2727,7 +2748,10 @@ static int process_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     pb.d_topk_idx = d_topk_idx; pb.d_topk_sum = d_topk_sum;
     pb.h_shared = h_shared; pb.h_sketches = h_sketches; pb.h_sketch_len = h_sketch_len;
     SKXCHK(batch_front(st, pb));
-    return batch_back(st, pb, nullptr);
+    st->tail_pass = true;  // (a synchronous push: the batch's passes have the chip to themselves)
+    const int rc = batch_back(st, pb, nullptr);
+    st->tail_pass = false;
+    return rc;
 }
 // ... and with the halves of consecutive batches interleaved: front(i + 1), then back(i) -- or, when batches share passes,
 // front(i + 1) alone while the group of batch i has room left (its batches wait for their partners); the call that opens the

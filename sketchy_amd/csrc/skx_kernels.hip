@@ -48,6 +48,9 @@
 #ifndef SKX_SEGSUM_PRIO
 #define SKX_SEGSUM_PRIO 2
 #endif
+#ifndef SKX_MQ_NT
+#define SKX_MQ_NT 0
+#endif
 #ifndef SKX_RANK1_PRIO
 #define SKX_RANK1_PRIO 3
 #endif
@@ -1548,12 +1551,19 @@ __device__ __forceinline__ u32 upper_bound_u64(const u64* __restrict__ a, u32 n,
 }
 
 // qrow != NULL: the dictionary was split (classify kernels): position in Q -> row of the bit matrix
+// bbase / btot: the dictionary's bucket bases (dict_scan_a/b: still those of this pass's Q) -- a hash's bucket starts at
+// btot[bucket >> 10] + bbase[bucket] and holds a handful of keys in ascending order: two or three reads instead of the 19 dependent
+// ones of a binary search over 470 k keys (truth-strain pass: 0.19 ms of the front half, alone on the chip)
 __global__ void pair_q_kernel(const u64* __restrict__ pair_h, u32 n_pairs, const u64* __restrict__ q,
-                              const u32* __restrict__ n_q, u32* __restrict__ pair_q, const u32* __restrict__ qrow) {
+                              const u32* __restrict__ n_q, u32* __restrict__ pair_q, const u32* __restrict__ qrow,
+                              const u32* __restrict__ bbase, const u32* __restrict__ btot, u32 bshift) {
     __builtin_amdgcn_s_setprio(3);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n_pairs) {
-        const u32 pos = lower_bound_u64(q, *n_q, pair_h[p]);
+        const u64 h = pair_h[p];
+        const u32 nq = *n_q, b = dict_bucket(h, bshift);
+        u32 pos = btot[b >> 10] + bbase[b];
+        while (pos < nq && q[pos] < h) ++pos;  // (every pair's hash is in Q)
         pair_q[p] = qrow ? qrow[pos] : pos;
     }
 }
@@ -1650,6 +1660,7 @@ __global__ __launch_bounds__(256) void rare_fill_kernel(const u64* __restrict__ 
 // shared; but as BIT ROWS over the genomes (mlong[row][genome word]: 5 KB per hash at C2, 1.3 GB for its 263 k long lists) a pass
 // adds them up with bit-sliced counters -- coalesced 512-byte reads, no atomics (gain_long_kernel) -- and finds the candidates on a
 // row by ANDing its words with the candidates' (cand_long_kernel).
+constexpr u32 kCtrStride = 16;           // words between the per-batch counters of a pass (nlrow, nqc): one 64-byte line each
 constexpr u32 kShortList = 8;            // genomes a list may have to be walked by its row's lane alone
 constexpr u32 kLongFlag = 0x80000000u;   // sslot[2 i + 1]: the hash has a bit row, sslot[2 i] = its index
 __global__ __launch_bounds__(256) void mlong_build_kernel(const u32* __restrict__ lslot, u32 n_long, const u32* __restrict__ off,
@@ -1792,7 +1803,7 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict_
 // kShortList genomes.  Through M (sparse_fill_kernel + transpose_bits_kernel) a truth-strain pass of 469 k rows paid one scattered
 // atomic per posting (2.0 ms) and a transpose of 2.4 GB of mostly zeros (1.7 ms) whenever one of its batches ranked on everything.
 // Here: one block per 64 rows (= one word of rowany per group); thread (row, word of the group) walks the groups, copying or
-// zero-filling -- 512-byte runs per wave, 2 KB per block and group --, then the short rows' few words are written over their zeros.
+// zero-filling -- 512-byte runs per wave, 2 KB per block and group --, then writes the short rows' few words over its own zeros.
 // rowany[grp][word of these rows] is written for every group (plain stores), grp_any[grp] += rows of the group that hold a bit.
 constexpr u32 kRareGrpChunk = 512;  // groups per turn (rowany words of a block in LDS)
 __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
@@ -1853,23 +1864,26 @@ __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__
                     }
                 }
             }
-            __threadfence();   // (the zeros have arrived before the short rows' words follow them to the same addresses)
-            __syncthreads();
-            // short rows: thread (row, j) owns posting j -- the word it falls into gets every bit of the row's postings in that word
+            // short rows: the words their postings fall into are written once more, by the thread that wrote the zero (thread (row, word
+            // of the group) owns that word of every group: same thread, same address, program order -- no fence between the two stores)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const u32 rr = r + 32u * h, pj = lpost[rr][cw];
-                if (pj == 0xFFFFFFFFu) continue;
-                const u32 gw = pj >> 6, g = gw / kRankWords;
-                if (g < g0 || g >= g1) continue;
-                u64 val = 0;
+                const u32 rr = r + 32u * h;
+                if (lng[h] || np[h] == 0u) continue;
+                for (u32 j = 0; j < kShortList; ++j) {
+                    const u32 pj = lpost[rr][j];
+                    if (pj == 0xFFFFFFFFu) break;
+                    const u32 gw = pj >> 6, g = gw / kRankWords;
+                    if (gw % kRankWords != cw || g < g0 || g >= g1) continue;
+                    u64 val = 0;
 #pragma unroll
-                for (u32 k = 0; k < kShortList; ++k) {
-                    const u32 pk = lpost[rr][k];
-                    if (pk != 0xFFFFFFFFu && (pk >> 6) == gw) val |= 1ull << (pk & 63u);
+                    for (u32 k = 0; k < kShortList; ++k) {
+                        const u32 pk = lpost[rr][k];
+                        if (pk != 0xFFFFFFFFu && (pk >> 6) == gw) val |= 1ull << (pk & 63u);
+                    }
+                    mq[((size_t)g * nq_rows + row0 + rr) * kRankWords + cw] = val;
+                    atomicOr(&lany[g - g0], 1ull << rr);
                 }
-                mq[((size_t)g * nq_rows + row0 + rr) * kRankWords + gw % kRankWords] = val;
-                atomicOr(&lany[g - g0], 1ull << rr);
             }
             __syncthreads();
             for (u32 i = threadIdx.x; i < g1 - g0; i += 256u) {
@@ -2624,7 +2638,14 @@ __device__ __forceinline__ MaskVec gather_vec(const u64* __restrict__ mq_g, u32 
     MaskVec m;
 #pragma unroll
     for (int j = 0; j < kRankWords; ++j) m.w[j] = 0;
+#if SKX_MQ_NT  // (measurement: tools/build_variant.sh mqnt -DSKX_MQ_NT=1 -- non-temporal gathers of the ranking's rows)
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < kRankWords; ++j) m.w[j] = __builtin_nontemporal_load(mq_g + (size_t)q * kRankWords + j);
+    }
+#else
     if (on) m = *reinterpret_cast<const MaskVec*>(mq_g + (size_t)q * kRankWords);
+#endif
     return m;
 }
 
@@ -2734,7 +2755,11 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const u32* __restrict__ pa
     const char* const mq_base = reinterpret_cast<const char*>(mq + (size_t)grp * nq_rows * kRankWords);
     const char* const pq_base = reinterpret_cast<const char*>(pair_q);
     const u32 j8 = j * 8u;
+#if SKX_MQ_NT
+    auto row_at = [&](u32 q) -> u64 { return __builtin_nontemporal_load(reinterpret_cast<const u64*>(mq_base + (size_t)((q << 6) | j8))); };
+#else
     auto row_at = [&](u32 q) -> u64 { return *reinterpret_cast<const u64*>(mq_base + (size_t)((q << 6) | j8)); };
+#endif
     // one block: cnt <= kBlockPairs pairs, q_at(i) = the query row of its i-th pair (i < cnt)
     auto count_block = [&](u32 cnt, auto q_at) {
         u64 ones = 0, twos = 0, fours = 0;
@@ -3907,16 +3932,23 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
         if (__ballot(is_long)) {
             // rows with a bit row: listed per batch for gain_long_kernel / cand_long_kernel (one walk over the rare rows instead of two)
             if (lr.lrow) {
+                // (lane b asks for batch b's slots: ONE round trip for the eight counters -- one after the other, all in one cache line,
+                // they were 57 k serialised returning atomics per pass: the waves of this kernel spent 97 % of their cycles waiting for
+                // them, 0.73 ms alone on the chip.  The counters sit kCtrStride words apart.)
+                u64 bal[kPassBatchesMax];
+                u32 mine = 0;
 #pragma unroll
                 for (u32 b = 0; b < kPassBatchesMax; ++b) {
-                    if (b >= n_b) break;
-                    const bool in = is_long && c[b] != 0u;
-                    const u64 bal = __ballot(in);
-                    if (!bal) continue;
-                    u32 base = 0;
-                    if (lane == 0u) base = atomicAdd(&lr.nlrow[b], (u32)__popcll(bal));
-                    base = (u32)__shfl((int)base, 0);
-                    if (in) lr.lrow[(size_t)b * lr.lrow_stride + base + (u32)__popcll(bal & lanemask_lt())] = make_uint2(off, sr);
+                    bal[b] = __ballot(b < n_b && is_long && c[b] != 0u);
+                    if (lane == b) mine = (u32)__popcll(bal[b]);
+                }
+                u32 base = 0;
+                if (mine) base = atomicAdd(&lr.nlrow[lane * kCtrStride], mine);
+#pragma unroll
+                for (u32 b = 0; b < kPassBatchesMax; ++b) {
+                    const u32 bb = (u32)__shfl((int)base, (int)b);
+                    if ((bal[b] >> lane) & 1ull)
+                        lr.lrow[(size_t)b * lr.lrow_stride + bb + (u32)__popcll(bal[b] & lanemask_lt())] = make_uint2(off, sr);
                 }
             }
             if (is_long) np = 0;
@@ -3964,7 +3996,7 @@ __global__ __launch_bounds__(256) void long_rows_kernel(const u32* __restrict__ 
             const u64 bal = __ballot(in);
             if (!bal) continue;
             u32 base = 0;
-            if (lane == 0u) base = atomicAdd(&lr.nlrow[b], (u32)__popcll(bal));
+            if (lane == 0u) base = atomicAdd(&lr.nlrow[b * kCtrStride], (u32)__popcll(bal));
             base = (u32)__shfl((int)base, 0);
             if (in) lr.lrow[(size_t)b * lr.lrow_stride + base + (u32)__popcll(bal & lanemask_lt())] = make_uint2(e.x, sr);
         }
@@ -3994,7 +4026,7 @@ __global__ __launch_bounds__(256) void gain_long_kernel(LongRows lr, RareIndex r
     const u32 b = blockIdx.y, lane = lane_id(), wv = threadIdx.x >> 6;
     const u32 n_gw = ri.n_gw, wg = min(blockIdx.x * 64u + lane, n_gw - 1u);
     const bool mine = blockIdx.x * 64u + lane < n_gw;
-    const u32 nd64 = n_d[2], nr = lr.nlrow[b];
+    const u32 nd64 = n_d[2], nr = lr.nlrow[b * kCtrStride];
     const uint2* rows = lr.lrow + (size_t)b * lr.lrow_stride;
     const u32* cb = cnt + (size_t)b * row_stride + nd64;
     u64 pl[kGlPlanes];
@@ -4086,7 +4118,7 @@ __global__ __launch_bounds__(256) void cand_long_kernel(LongRows lr, RareIndex r
     __shared__ u64 pat[4][kPatWords];
     const u32 b = blockIdx.y, lane = lane_id(), wv = threadIdx.x >> 6;
     if (bad[b]) return;
-    const u32 nd64 = n_d[2], nr = lr.nlrow[b], n_gw = ri.n_gw, n_gw_c = n_grp_c * kRankWords;
+    const u32 nd64 = n_d[2], nr = lr.nlrow[b * kCtrStride], n_gw = ri.n_gw, n_gw_c = n_grp_c * kRankWords;
     const u32 nw = ncwl[b];
     if (nw == 0u) return;
     const uint2* rows = lr.lrow + (size_t)b * lr.lrow_stride;
@@ -4109,7 +4141,7 @@ __global__ __launch_bounds__(256) void cand_long_kernel(LongRows lr, RareIndex r
         if (!any) continue;
         u32 x = 0;
         if (lane == 0u) {
-            const u32 crow = nd64 + atomicAdd(&nqc[b], 1u);
+            const u32 crow = nd64 + atomicAdd(&nqc[b * kCtrStride], 1u);
             if (crow + 1u >= rows_c) { atomicOr(&bad[b], 2u); x = kCandNone; }
             else { smap[(size_t)b * smap_stride + e.y] = crow + 1u; x = crow; }
         }
@@ -4337,7 +4369,7 @@ __global__ __launch_bounds__(256) void cand_sparse_kernel(const u32* __restrict_
     };
     auto new_row = [&](u32 b, u32 sr) -> u32 {
         if (bad[b]) return kCandNone;
-        const u32 crow = nd64 + atomicAdd(&nqc[b], 1u);
+        const u32 crow = nd64 + atomicAdd(&nqc[b * kCtrStride], 1u);
         if (crow + 1u >= rows_c) { atomicOr(&bad[b], 2u); return kCandNone; }
         smap[(size_t)b * smap_stride + sr] = crow + 1u;  // (0 = not mapped)
         return crow;
@@ -4485,7 +4517,7 @@ __global__ void cand_publish_kernel(const u32* __restrict__ bad, u32 force_full,
         any |= full ? 1u : 0u;
         u32 mx = 0;
         for (u32 s_ = 0; s_ < n_sp; ++s_) mx = max(mx, ncand[b * n_sp + s_]);
-        nqc_total[b] = nd64 + nqc[b];   // rows of the compact problem (dense rows, padded to 64, + the mapped rare rows)
+        nqc_total[b] = nd64 + nqc[b * kCtrStride];   // rows of the compact problem (dense rows, padded to 64, + the mapped rare rows)
         h_pub[b] = full ? 0u : 1u;
         h_pub[kPassBatchesMax + b] = mx;
     }
@@ -4685,10 +4717,13 @@ void launch_dict_insert(hipStream_t st, const u64* sk, u32 sk_stride, const u32*
     hipLaunchKernelGGL(dict_insert_kernel, dim3(cdiv(r_end - r_begin, 256)), dim3(256), 0, st, sk, sk_stride, poff, r_begin,
                        r_end, p_base, pair_h, pair_r, ht, ht_slots - 1u, ctr, pair_cap, row_off, base);
 }
+static u32 dict_bshift(u64 max_ref) {
+    const u32 bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
+    return bits > 17u ? bits - 17u : 0u;  // hashes <= max_ref  =>  hash >> bshift < 2^17
+}
 void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* slot_off, u32* bcount, u32* bbase, u32* btot,
                       u32* ctr, u64* q, u32* n_q) {
-    const u32 bits = 64u - (u32)__builtin_clzll(max_ref | 1ull);
-    const u32 bshift = bits > 17u ? bits - 17u : 0u;  // hashes <= max_ref  =>  hash >> bshift < 2^17
+    const u32 bshift = dict_bshift(max_ref);
     const u32 walk = std::min<u32>(cdiv(ht_slots, 256), 8192u);
     hipLaunchKernelGGL(dict_count_kernel, dim3(walk), dim3(256), 0, st, ht, ht_slots, bshift, slot_off, bcount);
     hipLaunchKernelGGL(dict_scan_a_kernel, dim3(kDictBuckets / 1024u), dim3(256), 0, st, bcount, bbase, btot);
@@ -4697,9 +4732,10 @@ void launch_dict_rest(hipStream_t st, u64* ht, u32 ht_slots, u64 max_ref, u32* s
     hipLaunchKernelGGL(dict_bucket_sort_kernel, dim3(kDictBuckets / 256), dim3(256), 0, st, q, bbase, btot, ctr);
 }
 u32 dict_buckets() { return kDictBuckets; }
-void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q, const u32* qrow) {
+void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q, const u32* qrow, const u32* bbase,
+                   const u32* btot, u64 max_ref) {
     if (n_pairs == 0) return;
-    hipLaunchKernelGGL(pair_q_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pair_h, n_pairs, q, n_q, pair_q, qrow);
+    hipLaunchKernelGGL(pair_q_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pair_h, n_pairs, q, n_q, pair_q, qrow, bbase, btot, dict_bshift(max_ref));
 }
 void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow) {
     if (n_elems == 0) return;
@@ -4734,8 +4770,8 @@ void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, 
     if (n == 0) return;
     hipLaunchKernelGGL(pass_hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pair_q, pb, cnt, row_stride);
 }
-void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride,
-                      u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri, const LongRows* lr) {
+void launch_gain_dense(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride,
+                       u32 n_b, u32* gain) {
     const dim3 grid(n_pad / 256, std::max(1u, cdiv(cdiv(rows_bound, 64), kGainWords)));
 #define SKX_GAIN(NB) hipLaunchKernelGGL(gain_dense_kernel<NB>, grid, dim3(256), 0, st, m_bits, m_int, n_pad, n_d, cnt, row_stride, gain)
     switch (n_b) {
@@ -4743,13 +4779,17 @@ void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n
         case 5: SKX_GAIN(5); break; case 6: SKX_GAIN(6); break; case 7: SKX_GAIN(7); break; default: SKX_GAIN(8); break;
     }
 #undef SKX_GAIN
-    // (the walks over the genome lists are bound by the atomics they issue, not by their waves: a grid that fills the chip only keeps
-    // the other streams' kernels -- the next group's sketches -- out of the wave slots: 56 M reads/s with 1832 blocks, measured)
-    if (ri && sslot && gain_s)
-        hipLaunchKernelGGL(gain_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks))), dim3(256), 0, st, sslot, n_d, *ri, cnt,
-                           row_stride, n_b, n_pad, gain_s, lr ? *lr : LongRows{nullptr, nullptr, 0u});
+}
+// (the walks over the genome lists are bound by the latency of their dependent loads and atomics, not by their waves: a grid that fills
+// the chip only keeps the other streams' kernels -- the next group's sketches -- out of the wave slots: 56 M reads/s with 1832 blocks,
+// measured.  walk_scale: the caller knows that nothing runs beside this pass)
+void launch_gain_sparse(hipStream_t st, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride, u32 n_b, u32 n_pad, u32* gain_s,
+                        const u32* sslot, const RareIndex& ri, const LongRows* lr, u32 walk_scale) {
+    hipLaunchKernelGGL(gain_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks * std::max(1u, walk_scale)))), dim3(256), 0, st,
+                       sslot, n_d, ri, cnt, row_stride, n_b, n_pad, gain_s, lr ? *lr : LongRows{nullptr, nullptr, 0u});
 }
 u32 gain_sparse_stride() { return kGainSparseStride; }
+u32 pass_counter_bytes() { return kPassBatchesMax * kCtrStride * 4u; }
 void launch_mlong_build(hipStream_t st, const u32* lslot, u32 n_long, const u32* off, const u32* cnt, const u32* post, u64* mlong, u32 n_gw) {
     if (n_long == 0) return;
     hipLaunchKernelGGL(mlong_build_kernel, dim3(cdiv(n_long, 4)), dim3(256), 0, st, lslot, n_long, off, cnt, post, mlong, n_gw);
@@ -4758,16 +4798,18 @@ void launch_long_rows(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows
     hipLaunchKernelGGL(long_rows_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), (u32)env_int("SKX_G_LONGROWS", 1024)))), dim3(256), 0, st, sslot, n_d, cnt, row_stride, n_b, lr);
 }
 void launch_gain_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u32* cnt, u32 row_stride, u32 n_b, u32 n_pad,
-                      u32* gain_l) {
-    hipLaunchKernelGGL(gain_long_kernel, dim3(cdiv(ri.n_gw, 64), n_b, (u32)env_int("SKX_G_GAINLONG", 8)), dim3(256), 0, st, lr, ri, n_d, cnt, row_stride, n_pad, gain_l);
+                      u32* gain_l, u32 walk_scale) {
+    // (z: the batch's rows are split over this many workgroups -- 8 beside the other streams' kernels; alone on the chip 32 read the bit
+    // rows a third faster: one pass per batch 39 -> 47 M reads/s)
+    hipLaunchKernelGGL(gain_long_kernel, dim3(cdiv(ri.n_gw, 64), n_b, (u32)env_int("SKX_G_GAINLONG", 8) * std::min(4u, std::max(1u, walk_scale))), dim3(256), 0, st, lr, ri, n_d, cnt, row_stride, n_pad, gain_l);
 }
 void launch_cand_words(hipStream_t st, const u32* cand, u32 n_pad_c, u32 n_b, u32 n_gw, u64* cw, u32* cbase, u32* cwl, u32* ncwl) {
     hipLaunchKernelGGL(cand_words_kernel, dim3(n_b), dim3(1024), 0, st, cand, n_pad_c, n_gw, cw, cbase, cwl, ncwl);
 }
 void launch_cand_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u64* cw, const u32* cbase, const u32* cwl,
                       const u32* ncwl, u32 n_pad_c, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
-                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c) {
-    hipLaunchKernelGGL(cand_long_kernel, dim3((u32)env_int("SKX_G_CANDLONG", 192), n_b), dim3(256), 0, st, lr, ri, n_d, cw, cbase, cwl, ncwl, n_pad_c, bad, nqc, smap, smap_stride, mqc,
+                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale) {
+    hipLaunchKernelGGL(cand_long_kernel, dim3((u32)env_int("SKX_G_CANDLONG", 192) * std::min(4u, std::max(1u, walk_scale)), n_b), dim3(256), 0, st, lr, ri, n_d, cw, cbase, cwl, ncwl, n_pad_c, bad, nqc, smap, smap_stride, mqc,
                        mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
 }
 void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s, const u32* gain_l, u32 n_b, u32 n_pad, u64* tab) {
@@ -4787,8 +4829,8 @@ void launch_cand_gather_m(hipStream_t st, const u64* m_bits, const u64* m_int, u
 }
 void launch_cand_sparse(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const RareIndex& ri, const u32* candmask,
                         const u32* candslot, u32 n_pad, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
-                        u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c) {
-    hipLaunchKernelGGL(cand_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks))), dim3(256), 0, st, sslot, n_d, ri, candmask,
+                        u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale) {
+    hipLaunchKernelGGL(cand_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks * std::max(1u, walk_scale)))), dim3(256), 0, st, sslot, n_d, ri, candmask,
                        candslot, n_pad, bad, n_b, nqc, smap, smap_stride, mqc, mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
 }
 void launch_cand_publish(hipStream_t st, const u32* bad, u32 force_full, const u32* ncand, const u32* nqc, const u32* n_d, u32 n_b, u32 n_sp,

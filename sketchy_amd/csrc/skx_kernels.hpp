@@ -96,18 +96,19 @@ struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* po
                    // lid[key slot] = row (0xFFFFFFFF: none), lslot[row] = key slot.  NULL when there was no room for the rows.
                    const u64* mlong = nullptr; const u32* lid = nullptr; const u32* lslot = nullptr; u32 n_gw = 0; };
 // long-list rows of a pass, per batch: lrow[b][i] = {bit row, sparse row of the pass's matrix} (nlrow[b] of them, lrow_stride apart)
-struct LongRows { uint2* lrow; u32* nlrow; u32 lrow_stride; };
+struct LongRows { uint2* lrow; u32* nlrow; u32 lrow_stride; };  // (nlrow: one counter per batch, pass_counter_bytes() in all)
+u32 pass_counter_bytes();  // size of the per-batch counter arrays of a pass (nlrow, nqc: one cache line per batch)
 void launch_mlong_build(hipStream_t st, const u32* lslot, u32 n_long, const u32* off, const u32* cnt, const u32* post, u64* mlong, u32 n_gw);
 void launch_long_rows(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride, u32 n_b, const LongRows& lr);
 // gain_l[b][g] (zero on entry) += sum over batch b's long-list rows of cnt x bit: bit-sliced counters over the rows' 64-bit words
 void launch_gain_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u32* cnt, u32 row_stride, u32 n_b, u32 n_pad,
-                      u32* gain_l);
+                      u32* gain_l, u32 walk_scale = 1);
 // the candidates of every batch by genome word: cw[b][w] their bits, cbase[b][w] the slot of the word's first one, cwl[b][.] / ncwl[b] the
 // words that hold any (cw, ncwl zero on entry; cbase all-ones)
 void launch_cand_words(hipStream_t st, const u32* cand, u32 n_pad_c, u32 n_b, u32 n_gw, u64* cw, u32* cbase, u32* cwl, u32* ncwl);
 void launch_cand_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u64* cw, const u32* cbase, const u32* cwl,
                       const u32* ncwl, u32 n_pad_c, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
-                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c);
+                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale = 1);
 // build, two passes over the tiled matrix (n_elems = n_tiles * s * 256): count (key / cnt zeroed: all-ones / 0; *overflow raised when
 // the table is too small), then -- offsets from the counts, cursor zeroed -- fill
 void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow);
@@ -139,9 +140,12 @@ void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, 
 // gain[b][g] (zero on entry) += sum over rows of cnt[b][row] * (row's bit for g): dense rows from m_bits (BEFORE the transpose
 // re-zeroes it), the others from the genome lists (ri / sslot, or NULL)
 // gain_s (zero on entry, [n_b][n_pad] entries gain_sparse_stride() words apart): the rare rows' part
-void launch_pass_gain(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt,
-                      u32 row_stride, u32 n_b, u32* gain, u32* gain_s, const u32* sslot, const RareIndex* ri,
-                      const LongRows* lr = nullptr /* also lists the rows with a bit row per batch (nlrow zero on entry) */);
+void launch_gain_dense(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt,
+                       u32 row_stride, u32 n_b, u32* gain);
+// (lr: also lists the rows with a bit row per batch, nlrow zero on entry; walk_scale: multiplies the workgroups of the list walk --
+// a pass with nothing beside it may fill the chip)
+void launch_gain_sparse(hipStream_t st, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride, u32 n_b, u32 n_pad, u32* gain_s,
+                        const u32* sslot, const RareIndex& ri, const LongRows* lr, u32 walk_scale);
 u32 gain_sparse_stride();
 // tab[0] = prev, tab[b + 1] = tab[b] + gain[b]   ([n_b + 1][n_pad])
 void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s /* or NULL */, const u32* gain_l /* or NULL */, u32 n_b,
@@ -161,7 +165,7 @@ void launch_cand_gather_m(hipStream_t st, const u64* m_bits, const u64* m_int /*
 // their bits into mqc[b] / rowany_c[b] / grp_any_c[b] (all zero on entry); bad[b] |= 2 when they do not fit rows_c
 void launch_cand_sparse(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const RareIndex& ri, const u32* candmask,
                         const u32* candslot, u32 n_pad, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
-                        u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c);
+                        u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale = 1);
 // mode[b] = 1 compact / 0 everything, *any_full, nqc_total[b] = rows of the compact problem; h_pub (page-locked): [b] mode,
 // [8 + b] largest candidate count, [16] any_full, [18] = n_b, [17] = seq (written last)
 void launch_cand_publish(hipStream_t st, const u32* bad, u32 force_full, const u32* ncand, const u32* nqc, const u32* n_d, u32 n_b, u32 n_sp,
@@ -172,7 +176,8 @@ void launch_cand_rows_back(hipStream_t st, u32* out_idx, u32 n_reads, u32 n_sp, 
 
 // dictionary
 // qrow (launch_classify) != NULL: pair_q receives ROWS of the bit matrix instead of positions in q
-void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q, const u32* qrow = nullptr);
+void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q, const u32* n_q, u32* pair_q, const u32* qrow /* or NULL */,
+                   const u32* bbase, const u32* btot, u64 max_ref /* launch_dict_rest's, of the same pass */);
 // Dictionary of a pass, in two steps.  (1) launch_dict_insert gathers the pairs of reads [r_begin, r_end) (pair_h, pair_r)
 // and inserts every pair hash into the hash set -- one wave per read, no knowledge of the pair count needed: it can be
 // queued right behind the sketcher; if the reads have more than pair_cap pairs it does nothing.  (2) launch_dict_rest
