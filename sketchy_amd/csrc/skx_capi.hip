@@ -2383,10 +2383,12 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     // set and pair lists.  Decided here, when a later one's front half is queued: the batches waiting must be one open group
     // with room left (stream_coalesce), speculative and production like this one, and the caller must have asked for it
     // (pb.pairable: the enqueue / submit entry points of a stream created with stream_coalesce >= 2).
-    // (the FIRST group of a sample is kept to four batches: its pass ranks on everything -- nothing is known about the sample yet --, and
+    // (the FIRST group of a sample is kept to six batches: its pass ranks on everything -- nothing is known about the sample yet --, and
     // the sooner it has said what its candidates were, the sooner the passes behind it can rank compactly.  K = 20 batches: passes of
-    // 4 + 8 + 8 instead of 8 + 8 + 4, the same three scans)
-    static const u32 first_group_env = skx::knob("SKX_FIRST_GROUP") ? (u32)atoi(skx::knob("SKX_FIRST_GROUP")) : 4u;  // experiment knob
+    // 6 + 8 + 6 instead of 8 + 8 + 4, the same three scans.  Measured, reads/s from a fresh table, first group of 4 / 6 / 8 batches:
+    // truth-strain workload 104 / 102 / 97.5 M, ancestor workload -- no compact pass ever, but the shorter the LAST group, the
+    // shorter the tail of ranking chains behind the last sketch -- 129 / 133 / 134.5 M.)
+    static const u32 first_group_env = skx::knob("SKX_FIRST_GROUP") ? (u32)atoi(skx::knob("SKX_FIRST_GROUP")) : 6u;  // experiment knob
     // (... where a scan of the reference costs no more than the rankings it spares: the smaller first group can add one scan to the
     // sample -- K = 8 batches: 4 + 4 instead of 8.  Five species resident, 12 GB per scan: 36 M reads/s became 27 M.  Up to 6 GB.)
     const bool scan_is_cheap = (u64)ref->n_pad * ref->s * 8ull <= (6ull << 30);

@@ -1808,7 +1808,7 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict_
 constexpr u32 kRareGrpChunk = 512;  // groups per turn (rowany words of a block in LDS)
 __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
                                                          u64* __restrict__ mq, u32 nq_rows, u32 n_gw, u64* __restrict__ rowany,
-                                                         u32* __restrict__ grp_any, const u32* __restrict__ only_if) {
+                                                         u32* __restrict__ grp_any, const u32* __restrict__ only_if, u32 chunk) {
     __builtin_amdgcn_s_setprio(2);
     if (only_if && !*only_if) return;  // (no batch of the pass ranks on the full matrix)
     __shared__ u32 lpost[64][kShortList];
@@ -1836,8 +1836,8 @@ __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__
             lpost[r + 32u * h][cw] = mine;
         }
         const u32 row0 = nd64 + sr0;
-        for (u32 g0 = 0; g0 < n_grp; g0 += kRareGrpChunk) {
-            const u32 g1 = min(n_grp, g0 + kRareGrpChunk);
+        for (u32 g0 = 0; g0 < n_grp; g0 += chunk) {  // (chunk = kRareGrpChunk; the experiments build can force the turns on small references)
+            const u32 g1 = min(n_grp, g0 + chunk);
             for (u32 i = threadIdx.x; i < g1 - g0; i += 256u) lany[i] = 0ull;
             __syncthreads();
             // long rows: copy; short rows: zeros.  Four groups in flight per thread (the loads of a bit row are 64-byte pieces)
@@ -1889,7 +1889,7 @@ __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__
             for (u32 i = threadIdx.x; i < g1 - g0; i += 256u) {
                 const u64 a = lany[i];
                 rowany[(size_t)(g0 + i) * n_words + (row0 >> 6)] = a;
-                if (g0 == 0u && n_grp <= kRareGrpChunk && i == threadIdx.x) acc += (u32)__popcll(a);
+                if (g0 == 0u && n_grp <= chunk && i == threadIdx.x) acc += (u32)__popcll(a);
                 else if (a) atomicAdd(&grp_any[g0 + i], (u32)__popcll(a));
             }
             __syncthreads();  // (lany and lpost are reused)
@@ -4760,7 +4760,8 @@ void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const 
 void launch_rare_to_mq(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* mq, u32 nq_rows, u32 n_pad, u64* rowany,
                        u32* grp_any, u32 rows_bound, const u32* only_if) {
     const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 64), 1024u));
-    hipLaunchKernelGGL(rare_to_mq_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, mq, nq_rows, n_pad / 64, rowany, grp_any, only_if);
+    const u32 chunk = std::min(kRareGrpChunk, std::max(1u, (u32)env_int("SKX_RARE_CHUNK", (int)kRareGrpChunk)));  // experiment knob: groups per turn
+    hipLaunchKernelGGL(rare_to_mq_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, mq, nq_rows, n_pad / 64, rowany, grp_any, only_if, chunk);
 }
 void launch_nd_from_nq(hipStream_t st, const u32* n_q, u32* n_d, u32* h_words) {
     hipLaunchKernelGGL(nd_from_nq_kernel, dim3(1), dim3(1), 0, st, n_q, n_d, h_words);
