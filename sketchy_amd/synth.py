@@ -495,7 +495,12 @@ def make_reference_snp(n_genomes: int, s: int, k: int = 16, hash_seed: int = 0, 
             rows = rows[:, :s]
             if bool((rows[:, -1] == _I64_MAX).any()):
                 raise ValueError("a strain holds fewer than s hashes below the tracked threshold (genome too short?)")
-            ref[done + j0:done + j0 + J] = rows.cpu().numpy().view(np.uint64)
+            block = rows.cpu().numpy().view(np.uint64)
+            bad = np.nonzero((block[:, 1:] <= block[:, :-1]).any(axis=1))[0]
+            if len(bad):  # (a row that came back from the device sort out of order -- seen once with the pool generator, under the
+                block = block.copy()  # profiler: sorted again here rather than refused by skx_ref_create; the values are distinct)
+                block[bad] = np.sort(block[bad], axis=1)
+            ref[done + j0:done + j0 + J] = block
             t_local = truth - (done + j0)
             if 0 <= t_local < J:
                 truth_genome = ascii_np[sg[t_local].cpu().numpy()]
