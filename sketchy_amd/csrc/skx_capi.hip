@@ -266,9 +266,11 @@ struct skx_ref {
     u64 n_keys = 0, n_rare_keys = 0, n_postings = 0;  // distinct hashes (exact), of those rare, entries of their lists
     // long lists (more than 8 genomes) also as bit rows over the genomes (skx_kernels.hip, "long lists as bit rows")
     u64* d_mlong = nullptr;
+    u64* d_mlongT = nullptr;  // the bit rows transposed: [n_pad][n_lw] (or NULL: no room -- the candidates' rows are then found row by row)
     u32 *d_lid = nullptr, *d_lslot = nullptr;
     u64 n_long = 0;
-    skx::RareIndex rare_index() const { return skx::RareIndex{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask, d_mlong, d_lid, d_lslot, n_pad / 64}; }
+    u32 n_lw = 0;
+    skx::RareIndex rare_index() const { return skx::RareIndex{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask, d_mlong, d_lid, d_lslot, n_pad / 64, d_mlongT, n_lw}; }
     skx::KmerFilter kmer_filter() const { return skx::KmerFilter{d_kf, kf_shift}; }
     skx::Species species() const { return skx::Species{d_sp_g0, d_sp_n, d_grp_sp, n_species}; }
 };
@@ -280,7 +282,7 @@ static void ref_free(skx_ref* r) {
     (void)hipFree(r->d_exc_g); (void)hipFree(r->d_exc_h); (void)hipFree(r->d_filt); (void)hipFree(r->d_kf);
     (void)hipFree(r->d_sp_g0); (void)hipFree(r->d_sp_n); (void)hipFree(r->d_grp_sp); (void)hipFree(r->d_real2pad);
     (void)hipFree(r->d_kt_key); (void)hipFree(r->d_kt_cnt); (void)hipFree(r->d_kt_off); (void)hipFree(r->d_post);
-    (void)hipFree(r->d_mlong); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot);
+    (void)hipFree(r->d_mlong); (void)hipFree(r->d_mlongT); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot);
     delete r;
 }
 
@@ -524,6 +526,19 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                         lok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
                     }
                     if (lok) r->n_long = n_long;
+                    // ... and transposed (genome-major), when another eighth of what is free holds it
+                    static const int mlongt_env = skx::knob("SKX_LONG_ROWS_T") ? atoi(skx::knob("SKX_LONG_ROWS_T")) : 1;  // experiment knob
+                    if (lok && mlongt_env) {
+                        const u32 n_lw = (u32)((n_long + 63) / 64);
+                        const u64 t_bytes = (u64)r->n_pad * n_lw * 8;
+                        (void)hipMemGetInfo(&mem_free, &mem_total);
+                        if (t_bytes <= mem_free / 8 && hipMalloc(&r->d_mlongT, t_bytes) == hipSuccess) {
+                            skx::launch_mlong_transpose(nullptr, r->d_mlong, (u32)n_long, r->n_pad / 64, r->d_mlongT, n_lw);
+                            if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess) r->n_lw = n_lw;
+                            else { (void)hipFree(r->d_mlongT); r->d_mlongT = nullptr; }
+                        } else r->d_mlongT = nullptr;
+                        (void)hipGetLastError();
+                    }
                     else { (void)hipFree(r->d_mlong); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot); r->d_mlong = nullptr; r->d_lid = r->d_lslot = nullptr; (void)hipGetLastError(); }
                 }
             }
@@ -614,7 +629,7 @@ SKX_API int skx_ref_rare_index(const skx_ref* ref, uint64_t* n_keys, uint64_t* n
     if (n_keys) *n_keys = on ? ref->n_keys : 0;
     if (n_rare_keys) *n_rare_keys = on ? ref->n_rare_keys : 0;
     if (n_postings) *n_postings = on ? ref->n_postings : 0;
-    if (bytes) *bytes = on ? ((u64)ref->kt_mask + 1) * 16 + std::max<u64>(ref->n_postings, 1) * 4 + (ref->d_mlong ? ref->n_long * (ref->n_pad / 8 + 4) + ((u64)ref->kt_mask + 1) * 4 : 0) : 0;
+    if (bytes) *bytes = on ? ((u64)ref->kt_mask + 1) * 16 + std::max<u64>(ref->n_postings, 1) * 4 + (ref->d_mlong ? ref->n_long * (ref->n_pad / 8 + 4) + ((u64)ref->kt_mask + 1) * 4 : 0) + (ref->d_mlongT ? (u64)ref->n_pad * ref->n_lw * 8 : 0) : 0;
     return SKX_OK;
 }
 SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
@@ -763,7 +778,8 @@ struct skx_stream {
     uint2 *d_lrow = nullptr;     // [kPassBatchesMax][qcap + 128]
     u32 *d_nlrow = nullptr, *d_gain_l = nullptr, *d_cbase = nullptr, *d_cwl = nullptr, *d_ncwl = nullptr;
     u64 *d_cw = nullptr;
-    skx::LongRows long_rows() const { return skx::LongRows{d_lrow, d_nlrow, qcap + 128}; }
+    u64 *d_inb = nullptr, *d_hit = nullptr;  // [kPassBatchesMax][ref->n_lw]: the bit rows on a batch's list / those that hold a candidate of it
+    skx::LongRows long_rows() const { return skx::LongRows{d_lrow, d_nlrow, qcap + 128, d_inb, ref->n_lw}; }
     u32 *d_cbad = nullptr, *d_nqc = nullptr;  // [kPassBatchesMax] why a batch cannot rank compactly / mapped rare rows
     u32 *d_spc_g0 = nullptr, *d_spc_grp = nullptr;  // Species layout of the compact problems: kCandCap slots per species
     u32 n_pad_c = 0, n_grp_c = 0, cand_seq = 0;
@@ -958,7 +974,7 @@ static void stream_free(skx_stream* st) {
                     st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1],
                     st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum,
-                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_lrow, st->d_nlrow, st->d_gain_l, st->d_cbase, st->d_cwl, st->d_ncwl, st->d_cw, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp};
+                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_lrow, st->d_nlrow, st->d_gain_l, st->d_cbase, st->d_cwl, st->d_ncwl, st->d_cw, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp, st->d_inb, st->d_hit};
     for (auto& q : st->ps) {
         for (void* x : {(void*)q.tab, (void*)q.cand, (void*)q.tabc, (void*)q.ncand, (void*)q.mode, (void*)q.any_full, (void*)q.nqc_total, (void*)q.mc, (void*)q.mqc,
                         (void*)q.rowany_c, (void*)q.grp_any_c, (void*)q.smap, (void*)q.pair_qc, (void*)q.nd}) (void)hipFree(x);
@@ -1427,6 +1443,10 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
             SCHK(hipMalloc(&st->d_cbase, (size_t)nb * (n_pad / 64) * 4));
             SCHK(hipMalloc(&st->d_cwl, (size_t)nb * st->n_pad_c * 4));
             SCHK(hipMalloc(&st->d_ncwl, 64));
+            if (ref->d_mlongT) {
+                SCHK(hipMalloc(&st->d_inb, (size_t)nb * ref->n_lw * 8));
+                SCHK(hipMalloc(&st->d_hit, (size_t)nb * ref->n_lw * 8));
+            }
         }
         SCHK(hipMalloc(&st->d_cbad, 64));
         SCHK(hipMalloc(&st->d_nqc, skx::pass_counter_bytes()));
@@ -1802,6 +1822,10 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         if (split_dict) HIPCHK(hipMemsetAsync(st->d_gain_s, 0, (size_t)n_sub * n_pad * 4 * skx::gain_sparse_stride(), hs));
         if (long_rows) {  // the rows with a bit row: listed per batch (by the short lists' walk), added up with bit-sliced counters
             HIPCHK(hipMemsetAsync(st->d_nlrow, 0, skx::pass_counter_bytes(), hs));
+            if (st->d_inb) {
+                HIPCHK(hipMemsetAsync(st->d_inb, 0, (size_t)n_sub * ref->n_lw * 8, hs));
+                HIPCHK(hipMemsetAsync(st->d_hit, 0, (size_t)n_sub * ref->n_lw * 8, hs));
+            }
             HIPCHK(hipMemsetAsync(st->d_gain_l, 0, (size_t)n_sub * n_pad * 4, hs));
         }
         return SKX_OK;
@@ -1899,9 +1923,10 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                     HIPCHK(hipMemsetAsync(st->d_cbase, 0xFF, (size_t)n_sub * n_gw * 4, hs));
                     HIPCHK(hipMemsetAsync(st->d_ncwl, 0, 64, hs));
                     skx::launch_cand_words(hs, ps.cand, st->n_pad_c, (u32)n_sub, n_gw, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl);
+                    if (st->d_hit) skx::launch_cand_hit(hs, ps.cand, st->n_pad_c, (u32)n_sub, st->d_cbad, ref->rare_index(), st->d_inb, st->d_hit);
                     skx::launch_cand_long(hs, st->long_rows(), ref->rare_index(), d_nd, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl, st->n_pad_c,
                                           st->d_cbad, (u32)n_sub, st->d_nqc, ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords,
-                                          rows_c, ps.rowany_c, st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c, walk_scale);
+                                          rows_c, ps.rowany_c, st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c, walk_scale, st->d_hit);
                 }
             }
         } else {

@@ -1675,6 +1675,18 @@ __global__ __launch_bounds__(256) void mlong_build_kernel(const u32* __restrict_
     }
 }
 
+// the bit rows transposed (RareIndex::mlongT): one wave per (64 bit rows, genome word) -- lane = bit row on the way in, = genome on the
+// way out (transpose64 is defined further down)
+__device__ __forceinline__ u64 transpose64(u64 x, u32 lane);
+__global__ __launch_bounds__(256) void mlong_transpose_kernel(const u64* __restrict__ mlong, u32 n_long, u32 n_gw, u64* __restrict__ mlongT,
+                                                              u32 n_lw) {
+    const u32 lw = blockIdx.x, gw = blockIdx.y * 4u + (threadIdx.x >> 6), lane = lane_id();
+    if (gw >= n_gw) return;
+    const u32 row = lw * 64u + lane;
+    const u64 x = row < n_long ? mlong[(size_t)row * n_gw + gw] : 0ull;
+    const u64 y = transpose64(x, lane);
+    mlongT[((size_t)gw * 64u + lane) * n_lw + lw] = y;
+}
 // ---- a pass's dictionary, split.  classify_a: look every query hash up (qinfo[q] = its slot | kSlotNone; dense: bit 31 of qloc[q]),
 // block-local exclusive count of the dense ones; classify_b: one block scans the block totals, publishes nd / ns;
 // classify_c: Qd (the dense hashes, still ascending), qrow[q] = the hash's row of the bit matrix (dense rows first, in Qd order,
@@ -3947,19 +3959,25 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
 #pragma unroll
                 for (u32 b = 0; b < kPassBatchesMax; ++b) {
                     const u32 bb = (u32)__shfl((int)base, (int)b);
-                    if ((bal[b] >> lane) & 1ull)
+                    if ((bal[b] >> lane) & 1ull) {
                         lr.lrow[(size_t)b * lr.lrow_stride + bb + (u32)__popcll(bal[b] & lanemask_lt())] = make_uint2(off, sr);
+                        if (lr.inb) atomicOr(&lr.inb[(size_t)b * lr.n_lw + (off >> 6)], 1ull << (off & 63u));  // (off: the row's bit row)
+                    }
                 }
             }
             if (is_long) np = 0;
         }
         if (!any) np = 0;
         if (np && np <= 8u) {
-            for (u32 j = 0; j < np; ++j) {
-                const u32 g = ri.post[off + j];
+            u32 gs[kShortList];  // (all of the list requested at once: one round trip, not one per entry)
+#pragma unroll
+            for (u32 j = 0; j < kShortList; ++j) gs[j] = j < np ? ri.post[off + j] : 0u;
+#pragma unroll
+            for (u32 j = 0; j < kShortList; ++j) {
+                if (j >= np) break;
 #pragma unroll
                 for (u32 b = 0; b < kPassBatchesMax; ++b)
-                    if (c[b]) atomicAdd(&gain[((size_t)b * n_pad + g) * kGainSparseStride], c[b]);
+                    if (c[b]) atomicAdd(&gain[((size_t)b * n_pad + gs[j]) * kGainSparseStride], c[b]);
             }
         }
         u64 longs = __ballot(np > 8u);
@@ -4109,11 +4127,29 @@ __global__ __launch_bounds__(1024) void cand_words_kernel(const u32* __restrict_
 // the long-list rows of the compact problems: a row of batch b whose bit row meets b's candidates gets a row behind the dense ones
 // of b's compact matrix; its words are put together in LDS (candidate slot = the word's first slot + the rank of the bit among the
 // word's candidates) and written with plain stores.  grid: (blocks, batches)
+// which long-list rows of a batch hold one of its candidates: one wave per (batch, candidate slot)
+__global__ __launch_bounds__(256) void cand_hit_kernel(const u32* __restrict__ cand, u32 n_pad_c, const u32* __restrict__ bad, RareIndex ri,
+                                                       const u64* __restrict__ inb, u64* __restrict__ hit) {
+    __builtin_amdgcn_s_setprio(2);
+    const u32 b = blockIdx.y, c = blockIdx.x * 4u + (threadIdx.x >> 6), lane = lane_id();
+    if (c >= n_pad_c || bad[b]) return;
+    const u32 g = cand[(size_t)b * n_pad_c + c];
+    if (g == kCandNone) return;
+    const u64* col = ri.mlongT + (size_t)g * ri.n_lw;
+    const u64* in = inb + (size_t)b * ri.n_lw;
+    u64* out = hit + (size_t)b * ri.n_lw;
+    for (u32 w = lane; w < ri.n_lw; w += 64u) {
+        const u64 x = col[w] & in[w];
+        if (x) atomicOr(&out[w], x);
+    }
+}
+
 __global__ __launch_bounds__(256) void cand_long_kernel(LongRows lr, RareIndex ri, const u32* __restrict__ n_d, const u64* __restrict__ cw,
                                                         const u32* __restrict__ cbase, const u32* __restrict__ cwl, const u32* __restrict__ ncwl,
                                                         u32 n_pad_c, u32* __restrict__ bad, u32* __restrict__ nqc, u32* __restrict__ smap,
                                                         u32 smap_stride, u64* __restrict__ mqc, size_t mqc_stride, u32 rows_c,
-                                                        u64* __restrict__ rowany_c, u32 rowany_stride, u32* __restrict__ grp_any_c, u32 n_grp_c) {
+                                                        u64* __restrict__ rowany_c, u32 rowany_stride, u32* __restrict__ grp_any_c, u32 n_grp_c,
+                                                        const u64* __restrict__ hit) {
     __builtin_amdgcn_s_setprio(2);
     __shared__ u64 pat[4][kPatWords];
     const u32 b = blockIdx.y, lane = lane_id(), wv = threadIdx.x >> 6;
@@ -4129,6 +4165,9 @@ __global__ __launch_bounds__(256) void cand_long_kernel(LongRows lr, RareIndex r
     const bool in_lds = n_gw_c <= kPatWords;
     for (u32 i = blockIdx.x * 4u + wv; i < nr; i += gridDim.x * 4u) {
         const uint2 e = rows[i];
+        // (cand_hit_kernel has the answer for every row of the batch at once: 45 k rows x ~180 scattered words each were 35 M L2 requests
+        // per pass, 0.58 ms; the candidates' rows of the transposed matrix ANDed with the batch's row mask are 53 MB of coalesced reads)
+        if (hit && !((hit[(size_t)b * ri.n_lw + (e.x >> 6)] >> (e.x & 63u)) & 1ull)) continue;
         const u64* mrow = ri.mlong + (size_t)e.x * n_gw;
         // does the row meet any candidate at all?  (almost never: the hash of some other clade)
         u64 any = 0ull;
@@ -4383,9 +4422,16 @@ __global__ __launch_bounds__(256) void cand_sparse_kernel(const u32* __restrict_
             u32 crow[kPassBatchesMax];
 #pragma unroll
             for (u32 b = 0; b < kPassBatchesMax; ++b) crow[b] = kCandNone;
-            for (u32 j = 0; j < np; ++j) {
-                const u32 g = ri.post[off + j];
-                u32 m = candmask[g];
+            u32 gs[kShortList], ms[kShortList];  // (the list, then its genomes' candidate masks: two round trips, not two per entry)
+#pragma unroll
+            for (u32 j = 0; j < kShortList; ++j) gs[j] = j < np ? ri.post[off + j] : 0u;
+#pragma unroll
+            for (u32 j = 0; j < kShortList; ++j) ms[j] = j < np ? candmask[gs[j]] : 0u;
+#pragma unroll
+            for (u32 j = 0; j < kShortList; ++j) {
+                if (j >= np) break;
+                const u32 g = gs[j];
+                u32 m = ms[j];
                 while (m) {
                     const u32 b = (u32)__builtin_ctz(m);
                     m &= m - 1u;
@@ -4804,14 +4850,21 @@ void launch_gain_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, c
     // rows a third faster: one pass per batch 39 -> 47 M reads/s)
     hipLaunchKernelGGL(gain_long_kernel, dim3(cdiv(ri.n_gw, 64), n_b, (u32)env_int("SKX_G_GAINLONG", 8) * std::min(4u, std::max(1u, walk_scale))), dim3(256), 0, st, lr, ri, n_d, cnt, row_stride, n_pad, gain_l);
 }
+void launch_mlong_transpose(hipStream_t st, const u64* mlong, u32 n_long, u32 n_gw, u64* mlongT, u32 n_lw) {
+    if (n_long == 0) return;
+    hipLaunchKernelGGL(mlong_transpose_kernel, dim3(n_lw, cdiv(n_gw, 4)), dim3(256), 0, st, mlong, n_long, n_gw, mlongT, n_lw);
+}
+void launch_cand_hit(hipStream_t st, const u32* cand, u32 n_pad_c, u32 n_b, const u32* bad, const RareIndex& ri, const u64* inb, u64* hit) {
+    hipLaunchKernelGGL(cand_hit_kernel, dim3(cdiv(n_pad_c, 4), n_b), dim3(256), 0, st, cand, n_pad_c, bad, ri, inb, hit);
+}
 void launch_cand_words(hipStream_t st, const u32* cand, u32 n_pad_c, u32 n_b, u32 n_gw, u64* cw, u32* cbase, u32* cwl, u32* ncwl) {
     hipLaunchKernelGGL(cand_words_kernel, dim3(n_b), dim3(1024), 0, st, cand, n_pad_c, n_gw, cw, cbase, cwl, ncwl);
 }
 void launch_cand_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u64* cw, const u32* cbase, const u32* cwl,
                       const u32* ncwl, u32 n_pad_c, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
-                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale) {
+                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale, const u64* hit) {
     hipLaunchKernelGGL(cand_long_kernel, dim3((u32)env_int("SKX_G_CANDLONG", 192) * std::min(4u, std::max(1u, walk_scale)), n_b), dim3(256), 0, st, lr, ri, n_d, cw, cbase, cwl, ncwl, n_pad_c, bad, nqc, smap, smap_stride, mqc,
-                       mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
+                       mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c, hit);
 }
 void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s, const u32* gain_l, u32 n_b, u32 n_pad, u64* tab) {
     hipLaunchKernelGGL(pass_tables_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, st, prev, gain, gain_s, gain_l, n_b, n_pad, tab);

@@ -94,9 +94,13 @@ void launch_count_scan(hipStream_t st, const u32* in, u32* out, u32 n, u32* bsum
 struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* post; u32 mask;
                    // long lists (more than 8 genomes) also as BIT ROWS: mlong[lid][n_gw] u64, bit g of a row = genome g holds the hash;
                    // lid[key slot] = row (0xFFFFFFFF: none), lslot[row] = key slot.  NULL when there was no room for the rows.
-                   const u64* mlong = nullptr; const u32* lid = nullptr; const u32* lslot = nullptr; u32 n_gw = 0; };
+                   const u64* mlong = nullptr; const u32* lid = nullptr; const u32* lslot = nullptr; u32 n_gw = 0;
+                   // ... and the same bits TRANSPOSED: mlongT[genome][n_lw] u64, bit r of a genome's row = bit row r holds the genome
+                   // (n_lw = ceil(rows / 64) words; NULL when there was no room): which of a batch's long-list rows meet a candidate is
+                   // then an AND of the candidate's row with the batch's row mask, not a walk over every row (launch_cand_hit)
+                   const u64* mlongT = nullptr; u32 n_lw = 0; };
 // long-list rows of a pass, per batch: lrow[b][i] = {bit row, sparse row of the pass's matrix} (nlrow[b] of them, lrow_stride apart)
-struct LongRows { uint2* lrow; u32* nlrow; u32 lrow_stride; };  // (nlrow: one counter per batch, pass_counter_bytes() in all)
+struct LongRows { uint2* lrow; u32* nlrow; u32 lrow_stride; u64* inb = nullptr; u32 n_lw = 0; };  // inb[b][n_lw] (or NULL; zero on entry): bit r = bit row r is on batch b's list  // (nlrow: one counter per batch, pass_counter_bytes() in all)
 u32 pass_counter_bytes();  // size of the per-batch counter arrays of a pass (nlrow, nqc: one cache line per batch)
 void launch_mlong_build(hipStream_t st, const u32* lslot, u32 n_long, const u32* off, const u32* cnt, const u32* post, u64* mlong, u32 n_gw);
 void launch_long_rows(hipStream_t st, const u32* sslot, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride, u32 n_b, const LongRows& lr);
@@ -105,10 +109,14 @@ void launch_gain_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, c
                       u32* gain_l, u32 walk_scale = 1);
 // the candidates of every batch by genome word: cw[b][w] their bits, cbase[b][w] the slot of the word's first one, cwl[b][.] / ncwl[b] the
 // words that hold any (cw, ncwl zero on entry; cbase all-ones)
+void launch_mlong_transpose(hipStream_t st, const u64* mlong, u32 n_long, u32 n_gw, u64* mlongT, u32 n_lw);
+// hit[b][n_lw] (zero on entry) |= (row of candidate g in the transposed bit rows) & inb[b], for every candidate of every batch: the
+// long-list rows of batch b that hold any of its candidates -- cand_long_kernel then only looks at those
+void launch_cand_hit(hipStream_t st, const u32* cand, u32 n_pad_c, u32 n_b, const u32* bad, const RareIndex& ri, const u64* inb, u64* hit);
 void launch_cand_words(hipStream_t st, const u32* cand, u32 n_pad_c, u32 n_b, u32 n_gw, u64* cw, u32* cbase, u32* cwl, u32* ncwl);
 void launch_cand_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, const u32* n_d, const u64* cw, const u32* cbase, const u32* cwl,
                       const u32* ncwl, u32 n_pad_c, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, u64* mqc, size_t mqc_stride,
-                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale = 1);
+                      u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale = 1, const u64* hit = nullptr /* launch_cand_hit's, or NULL: every listed row is tested */);
 // build, two passes over the tiled matrix (n_elems = n_tiles * s * 256): count (key / cnt zeroed: all-ones / 0; *overflow raised when
 // the table is too small), then -- offsets from the counts, cursor zeroed -- fill
 void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow);

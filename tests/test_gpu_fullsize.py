@@ -203,7 +203,8 @@ def test_forced_scan_kernel_variants(gpu, split, big):
                                    {"SKX_CAND": "0"}, {"SKX_CAND": "0", "SKX_PASS_READS": "64"}, {"SKX_RARE_MAX": "0"}, {"SKX_RARE_MAX": "3"},
                                    {"SKX_RARE_MAX": "0", "SKX_CAND": "0"}, {"SKX_TABLE_LEGACY": "0"}, {"SKX_TABLE_LEGACY": "100"},
                                    {"SKX_RARE_MAX": "100000"}, {"SKX_RARE_MAX": "100000", "SKX_RARE_CHUNK": "1"}, {"SKX_RARE_DIRECT": "0"},
-                                   {"SKX_RARE_MAX": "100000", "SKX_RARE_DIRECT": "0"}, {"SKX_TAIL_SCALE": "1"}, {"SKX_FIRST_GROUP": "1"}])
+                                   {"SKX_RARE_MAX": "100000", "SKX_RARE_DIRECT": "0"}, {"SKX_TAIL_SCALE": "1"}, {"SKX_FIRST_GROUP": "1"},
+                                   {"SKX_RARE_MAX": "100000", "SKX_LONG_ROWS_T": "0"}])
 def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     """Several passes per push (the path that needs the per-read pair offsets on the host), the pipeline depths, the
     unfiltered dictionary, the ranking without its per-word live flags, the ranking lanes forced to one / four, the
@@ -212,7 +213,7 @@ def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     probe), and round 5's machinery switched off or forced -- no compact ranking on the candidates (SKX_CAND=0), no rare-hash index or
     one for nearly every hash (SKX_RARE_MAX), the table always / never out of the ranking chains (SKX_TABLE_LEGACY), the rare rows into the
     group-major matrix one rank group per turn (SKX_RARE_CHUNK=1) or through M and the transpose as before (SKX_RARE_DIRECT=0), the list
-    walks of a closing pass at their ordinary size (SKX_TAIL_SCALE=1), first groups of one batch -- all give the oracle's rows."""
+    walks of a closing pass at their ordinary size (SKX_TAIL_SCALE=1), first groups of one batch, no transposed bit rows (SKX_LONG_ROWS_T=0: the candidates' long-list rows found row by row) -- all give the oracle's rows."""
     from helpers import exp_env
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=exp_env(**knobs),
                          capture_output=True, text=True)
