@@ -3969,15 +3969,11 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
         }
         if (!any) np = 0;
         if (np && np <= 8u) {
-            u32 gs[kShortList];  // (all of the list requested at once: one round trip, not one per entry)
-#pragma unroll
-            for (u32 j = 0; j < kShortList; ++j) gs[j] = j < np ? ri.post[off + j] : 0u;
-#pragma unroll
-            for (u32 j = 0; j < kShortList; ++j) {
-                if (j >= np) break;
+            for (u32 j = 0; j < np; ++j) {
+                const u32 g = ri.post[off + j];
 #pragma unroll
                 for (u32 b = 0; b < kPassBatchesMax; ++b)
-                    if (c[b]) atomicAdd(&gain[((size_t)b * n_pad + gs[j]) * kGainSparseStride], c[b]);
+                    if (c[b]) atomicAdd(&gain[((size_t)b * n_pad + g) * kGainSparseStride], c[b]);
             }
         }
         u64 longs = __ballot(np > 8u);
@@ -4422,16 +4418,11 @@ __global__ __launch_bounds__(256) void cand_sparse_kernel(const u32* __restrict_
             u32 crow[kPassBatchesMax];
 #pragma unroll
             for (u32 b = 0; b < kPassBatchesMax; ++b) crow[b] = kCandNone;
-            u32 gs[kShortList], ms[kShortList];  // (the list, then its genomes' candidate masks: two round trips, not two per entry)
-#pragma unroll
-            for (u32 j = 0; j < kShortList; ++j) gs[j] = j < np ? ri.post[off + j] : 0u;
-#pragma unroll
-            for (u32 j = 0; j < kShortList; ++j) ms[j] = j < np ? candmask[gs[j]] : 0u;
-#pragma unroll
-            for (u32 j = 0; j < kShortList; ++j) {
-                if (j >= np) break;
-                const u32 g = gs[j];
-                u32 m = ms[j];
+            // (tried: the list and its genomes' candidate masks requested at once instead of entry by entry -- the kernels 5 % shorter, the
+            // stream not: 103.8 M reads/s either way)
+            for (u32 j = 0; j < np; ++j) {
+                const u32 g = ri.post[off + j];
+                u32 m = candmask[g];
                 while (m) {
                     const u32 b = (u32)__builtin_ctz(m);
                     m &= m - 1u;
