@@ -4,7 +4,7 @@ issues, per kernel of this library, from the per-kernel SQ_INSTS_VALU means of t
 profiles/valu_insts.json (what bench.py's roofline_valu block quotes).
 
 A step launches the main sketch kernel (sketch_wave_kernel<k, HCAP, true> with the smallest HCAP) exactly once, so a kernel's launches per step = its dispatches / that
-kernel's dispatches (set-up kernels -- ref_tile, band_bounds, filter_build -- are left out: they run once per reference)."""
+kernel's dispatches (set-up kernels -- ref_tile, band_bounds, filter_build, the rare-hash index's -- are left out: they run once per reference)."""
 import csv
 import json
 import os
@@ -14,7 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sketchy_amd.build import source_sha  # noqa: E402
-SETUP = ("ref_tile_kernel", "band_bounds_kernel", "filter_build_kernel")
+SETUP = ("ref_tile_kernel", "band_bounds_kernel", "filter_build_kernel", "rare_count_kernel", "rare_fill_kernel", "mlong_build_kernel",
+         "mlong_transpose_kernel")  # (round 5: the rare-hash index is built with the reference too)
 src, key, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 sha = sys.argv[4] if len(sys.argv) > 4 else source_sha()   # (argv[4]: re-deriving the JSON from a CSV of an earlier tree)
 rows = {}
