@@ -142,6 +142,13 @@ int skx_ref_kmer_filter(const skx_ref *ref, uint64_t *n_keys, uint64_t *table_by
  * dictionary then holds the hashes many genomes share); results are the same with and without it.  All zero: none was built.
  */
 int skx_ref_rare_index(const skx_ref *ref, uint64_t *n_keys, uint64_t *n_rare_keys, uint64_t *n_postings, uint64_t *bytes);
+/*
+ * ... and how its long genome lists (more than 8 genomes) are stored: n_long_lists of them have a bit row over the genomes;
+ * n_pattern_lists of those are ALSO written as one of n_patterns shared patterns plus at most 14 exceptions (the lineage-level hashes
+ * of a clonal collection: "the lineage's strains minus the odd one") -- a pass adds such rows up per pattern instead of per row; bytes =
+ * the device memory of the records and the pattern matrix.  Exact either way; all zero: no bit rows / no patterns.
+ */
+int skx_ref_patterns(const skx_ref *ref, uint64_t *n_long_lists, uint64_t *n_patterns, uint64_t *n_pattern_lists, uint64_t *bytes);
 /* bytes of reference hashes one scoring pass streams from HBM (8*stride*n_genomes) */
 int skx_ref_pass_bytes(const skx_ref *ref, uint64_t *bytes);
 void skx_ref_destroy(skx_ref *ref);

@@ -32,6 +32,7 @@ SYMBOLS = [
     ("skx_get_option", _i, [C.c_char_p, C.POINTER(_u64)]),
     ("skx_ref_kmer_filter", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("skx_ref_rare_index", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    ("skx_ref_patterns", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     ("skx_ref_create", _i, [_pp, _i, _u32, _u64, _u32, _u32, _u32, _vp, _vp]),
     ("skx_ref_create_multi", _i, [_pp, _i, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _vp]),
     ("skx_ref_sketch_size", _i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),

@@ -114,6 +114,14 @@ class ReferenceSketch:
         return dict(zip(("keys", "rare_keys", "postings", "bytes"), [x.value for x in v]))
 
     @property
+    def patterns(self):
+        """dict(long_lists, patterns, pattern_lists, bytes): the long genome lists of the rare-hash index and how many of them are stored
+        as a shared pattern + exceptions (all 0: none)"""
+        v = [C.c_uint64(0) for _ in range(4)]
+        _lib.check(_lib.load().skx_ref_patterns(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("long_lists", "patterns", "pattern_lists", "bytes"), [x.value for x in v]))
+
+    @property
     def pass_bytes(self) -> int:
         b = C.c_uint64(0)
         _lib.check(_lib.load().skx_ref_pass_bytes(self._h, C.byref(b)))

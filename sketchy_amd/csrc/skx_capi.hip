@@ -24,6 +24,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "sketchy_hip.h"
@@ -270,7 +271,16 @@ struct skx_ref {
     u32 *d_lid = nullptr, *d_lslot = nullptr;
     u64 n_long = 0;
     u32 n_lw = 0;
-    skx::RareIndex rare_index() const { return skx::RareIndex{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask, d_mlong, d_lid, d_lslot, n_pad / 64, d_mlongT, n_lw}; }
+    // most long lists as (pattern, exceptions) (skx_kernels.hip, "long lists as (pattern, exceptions)"; build_patterns below)
+    u32 *d_prec = nullptr, *d_pat_rep = nullptr, *d_npat = nullptr;
+    u64* d_pm = nullptr;
+    u32 n_pat = 0;
+    u64 n_pat_lists = 0;  // long lists stored as a pattern + at most 14 exceptions
+    skx::RareIndex rare_index() const {
+        skx::RareIndex ri{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask, d_mlong, d_lid, d_lslot, n_pad / 64, d_mlongT, n_lw};
+        ri.prec = d_prec; ri.pat_rep = d_pat_rep; ri.pm = d_pm; ri.d_npat = d_npat; ri.n_pat = n_pat;
+        return ri;
+    }
     skx::KmerFilter kmer_filter() const { return skx::KmerFilter{d_kf, kf_shift}; }
     skx::Species species() const { return skx::Species{d_sp_g0, d_sp_n, d_grp_sp, n_species}; }
 };
@@ -283,10 +293,92 @@ static void ref_free(skx_ref* r) {
     (void)hipFree(r->d_sp_g0); (void)hipFree(r->d_sp_n); (void)hipFree(r->d_grp_sp); (void)hipFree(r->d_real2pad);
     (void)hipFree(r->d_kt_key); (void)hipFree(r->d_kt_cnt); (void)hipFree(r->d_kt_off); (void)hipFree(r->d_post);
     (void)hipFree(r->d_mlong); (void)hipFree(r->d_mlongT); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot);
+    (void)hipFree(r->d_prec); (void)hipFree(r->d_pat_rep); (void)hipFree(r->d_npat); (void)hipFree(r->d_pm);
     delete r;
 }
 
 static const u32 kGroupGenomes = skx::kRankWords * 64u;  // 512: a species starts on a rank-group boundary
+
+// Most long lists of a clonal collection as (pattern, exceptions) -- skx_kernels.hip, "long lists as (pattern, exceptions)".  Needs the
+// bit rows (the exceptions are the XOR of two of them); anything that goes wrong leaves the reference without patterns: every long list
+// keeps its bit row, as in round 5.  Host work: one 12-byte record per long list (C2's SNP tree: 263 k).
+static const u32 kPatMax = 16384;        // patterns of a reference (rows of the compact matrices, words of the pattern matrix)
+static const u32 kPatGroupMin = 4;       // lists a signature group must hold to get a pattern
+static void build_patterns(skx_ref* r) {
+    static const int pat_env = skx::knob("SKX_PATTERNS") ? atoi(skx::knob("SKX_PATTERNS")) : 1;  // experiment knob: 0 = bit rows only
+    if (!pat_env || !r->d_mlong || r->n_long < 64 || r->n_long >= 0x7FFFFFFFull) return;
+    const u32 n_long = (u32)r->n_long, n_gw = r->n_pad / 64;
+    u32 *d_sig = nullptr, *d_pat_of = nullptr, *d_done = nullptr;
+    u64* d_content = nullptr;
+    auto drop = [&]() {
+        (void)hipFree(r->d_prec); (void)hipFree(r->d_pat_rep); (void)hipFree(r->d_npat); (void)hipFree(r->d_pm);
+        r->d_prec = r->d_pat_rep = r->d_npat = nullptr; r->d_pm = nullptr; r->n_pat = 0; r->n_pat_lists = 0;
+        (void)hipGetLastError();
+    };
+    bool ok = hipMalloc(&d_sig, (size_t)n_long * 4) == hipSuccess && hipMalloc(&d_content, (size_t)n_long * 8) == hipSuccess;
+    try {
+        std::vector<u32> sig(n_long), pat_of(n_long, 0xFFFFFFFFu), rep;
+        std::vector<u64> content(n_long);
+        if (ok) {
+            skx::launch_list_sig(nullptr, r->d_lslot, n_long, r->d_kt_off, r->d_kt_cnt, r->d_post, d_sig, d_content);
+            ok = hipGetLastError() == hipSuccess && hipMemcpy(sig.data(), d_sig, (size_t)n_long * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(content.data(), d_content, (size_t)n_long * 8, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (ok) {
+            // the most frequent exact list of every signature group (ties: the lower bit row), groups by size
+            struct Exact { u32 count = 0, first = 0, sig = 0; };
+            struct Group { u32 size = 0, best_count = 0, best_first = 0; };
+            std::unordered_map<u64, Exact> exact;
+            std::unordered_map<u32, Group> groups;
+            exact.reserve(n_long);
+            for (u32 i = 0; i < n_long; ++i) {
+                Exact& e = exact[content[i] ^ ((u64)sig[i] * 0xD6E8FEB86659FD93ull)];
+                if (!e.count) { e.first = i; e.sig = sig[i]; }
+                e.count += 1;
+                groups[sig[i]].size += 1;
+            }
+            for (const auto& kv : exact) {
+                const Exact& e = kv.second;
+                Group& g = groups[e.sig];
+                if (e.count > g.best_count || (e.count == g.best_count && e.first < g.best_first)) { g.best_count = e.count; g.best_first = e.first; }
+            }
+            std::vector<std::pair<u32, u32>> order;  // (size, signature)
+            for (const auto& kv : groups) if (kv.second.size >= kPatGroupMin) order.push_back({kv.second.size, kv.first});
+            std::sort(order.begin(), order.end(), [](const std::pair<u32, u32>& a, const std::pair<u32, u32>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+            if (order.size() > kPatMax) order.resize(kPatMax);
+            std::unordered_map<u32, u32> pat_of_sig;
+            for (const auto& o : order) { pat_of_sig[o.second] = (u32)rep.size(); rep.push_back(groups[o.second].best_first); }
+            for (u32 i = 0; i < n_long; ++i) { const auto it = pat_of_sig.find(sig[i]); if (it != pat_of_sig.end()) pat_of[i] = it->second; }
+            ok = !rep.empty();
+        }
+        const u32 n_pat = (u32)rep.size(), n_pw = (n_pat + 63) / 64;
+        size_t mem_free = 0, mem_total = 0;
+        (void)hipMemGetInfo(&mem_free, &mem_total);
+        ok = ok && ((size_t)n_long * skx::pat_record_words() * 4 + (size_t)n_pw * r->n_pad * 8) <= mem_free / 8;
+        ok = ok && hipMalloc(&d_pat_of, (size_t)n_long * 4) == hipSuccess && hipMalloc(&d_done, 4) == hipSuccess &&
+             hipMalloc(&r->d_pat_rep, (size_t)n_pat * 4) == hipSuccess && hipMalloc(&r->d_npat, 16) == hipSuccess &&
+             hipMalloc(&r->d_prec, (size_t)n_long * skx::pat_record_words() * 4) == hipSuccess &&
+             hipMalloc(&r->d_pm, (size_t)n_pw * r->n_pad * 8) == hipSuccess &&
+             hipMemcpy(d_pat_of, pat_of.data(), (size_t)n_long * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(r->d_pat_rep, rep.data(), (size_t)n_pat * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemset(d_done, 0, 4) == hipSuccess;
+        if (ok) {
+            const u32 words[4] = {n_pat, 0u, (n_pat + 63u) & ~63u, n_pat};
+            ok = hipMemcpy(r->d_npat, words, 16, hipMemcpyHostToDevice) == hipSuccess;
+        }
+        if (ok) {
+            skx::launch_pat_exceptions(nullptr, r->d_mlong, n_gw, n_long, d_pat_of, r->d_pat_rep, r->d_prec, d_done);
+            skx::launch_pat_matrix(nullptr, r->d_mlong, r->d_pat_rep, n_pat, n_gw, r->d_pm, r->n_pad);
+            u32 done = 0;
+            ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipMemcpy(&done, d_done, 4, hipMemcpyDeviceToHost) == hipSuccess;
+            // (a collection whose long lists do not cluster: the pattern machinery would only add launches)
+            ok = ok && (u64)done * 8 >= n_long;
+            if (ok) { r->n_pat = n_pat; r->n_pat_lists = done; }
+        }
+    } catch (const std::bad_alloc&) { ok = false; }
+    (void)hipFree(d_sig); (void)hipFree(d_content); (void)hipFree(d_pat_of); (void)hipFree(d_done);
+    if (!ok) drop();
+}
 
 SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s_read, uint32_t stride,
                                  uint32_t n_species, const uint32_t* n_genomes, const uint64_t* const* hashes,
@@ -489,7 +581,7 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                 drop();  // (the distinct count was an estimate: twice the slots)
                 if (attempt == 3) ok = false;
             }
-            if (ok && r->d_kt_key) {
+            if (ok && r->d_kt_key) try {
                 std::vector<u32> cnt(slots), off(slots);
                 ok = hipMemcpy(cnt.data(), r->d_kt_cnt, slots * 4, hipMemcpyDeviceToHost) == hipSuccess;
                 u64 total = 0, keys = 0, rare = 0;
@@ -539,8 +631,16 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                         } else r->d_mlongT = nullptr;
                         (void)hipGetLastError();
                     }
-                    else { (void)hipFree(r->d_mlong); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot); r->d_mlong = nullptr; r->d_lid = r->d_lslot = nullptr; (void)hipGetLastError(); }
+                    else if (!lok) { (void)hipFree(r->d_mlong); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot); r->d_mlong = nullptr; r->d_lid = r->d_lslot = nullptr; r->n_long = 0; (void)hipGetLastError(); }
+                    if (lok) build_patterns(r);
                 }
+            } catch (const std::bad_alloc&) {
+                // (the host-side offsets of a very large key table did not fit the host's memory: no index, every hash goes to the scan)
+                (void)hipFree(r->d_mlong); (void)hipFree(r->d_mlongT); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot);
+                r->d_mlong = r->d_mlongT = nullptr; r->d_lid = r->d_lslot = nullptr; r->n_long = 0; r->n_lw = 0;
+                (void)hipFree(r->d_prec); (void)hipFree(r->d_pat_rep); (void)hipFree(r->d_npat); (void)hipFree(r->d_pm);
+                r->d_prec = r->d_pat_rep = r->d_npat = nullptr; r->d_pm = nullptr; r->n_pat = 0; r->n_pat_lists = 0;
+                ok = false;
             }
             (void)hipFree(d_over); (void)hipFree(d_cursor);
             if (!ok) drop();
@@ -630,6 +730,14 @@ SKX_API int skx_ref_rare_index(const skx_ref* ref, uint64_t* n_keys, uint64_t* n
     if (n_rare_keys) *n_rare_keys = on ? ref->n_rare_keys : 0;
     if (n_postings) *n_postings = on ? ref->n_postings : 0;
     if (bytes) *bytes = on ? ((u64)ref->kt_mask + 1) * 16 + std::max<u64>(ref->n_postings, 1) * 4 + (ref->d_mlong ? ref->n_long * (ref->n_pad / 8 + 4) + ((u64)ref->kt_mask + 1) * 4 : 0) + (ref->d_mlongT ? (u64)ref->n_pad * ref->n_lw * 8 : 0) : 0;
+    return SKX_OK;
+}
+SKX_API int skx_ref_patterns(const skx_ref* ref, uint64_t* n_long_lists, uint64_t* n_patterns, uint64_t* n_pattern_lists, uint64_t* bytes) {
+    if (!ref) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (n_long_lists) *n_long_lists = ref->d_mlong ? ref->n_long : 0;
+    if (n_patterns) *n_patterns = ref->d_prec ? ref->n_pat : 0;
+    if (n_pattern_lists) *n_pattern_lists = ref->d_prec ? ref->n_pat_lists : 0;
+    if (bytes) *bytes = ref->d_prec ? ref->n_long * skx::pat_record_words() * 4 + (u64)((ref->n_pat + 63) / 64) * ref->n_pad * 8 + (u64)ref->n_pat * 4 : 0;
     return SKX_OK;
 }
 SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
@@ -764,6 +872,11 @@ struct skx_stream {
     // for, position in Q -> row, key-table slots of the other rows, scratch of the classify kernels; d_nd = {dense rows, other rows}
     u64* d_qd = nullptr;
     u32 *d_qrow = nullptr, *d_sslot = nullptr, *d_qinfo = nullptr, *d_qloc = nullptr, *d_cls_bsum = nullptr;
+    // {dense rows, other rows, first other row, rows in all} of the pass whose FRONT HALF is on the scan stream: scan-stream scratch, one
+    // copy.  The ranking chains read the per-set copy ps[b].nd, which a pass writes only behind its wait for the chains that last used the
+    // set (wait_back) -- round 5 let the dictionary stage write ps[b].nd directly, ahead of that wait: a chain of the pass two back that was
+    // still running could have seen the new pass's counts.
+    u32* d_nd_hs = nullptr;
     u32* h_lcount = nullptr;   // page-locked: {candidates the latest batch of a legacy pass would have had, its sequence number}
     u32 lcount_seq = 0, lcount_seen = 0, lcount_floor = 0;  // (floor: counts older than the last reset do not count)
     u32* h_nq_sink = nullptr;  // page-locked: where the live sample of a compact chain goes (nobody reads it)
@@ -780,6 +893,14 @@ struct skx_stream {
     u64 *d_cw = nullptr;
     u64 *d_inb = nullptr, *d_hit = nullptr;  // [kPassBatchesMax][ref->n_lw]: the bit rows on a batch's list / those that hold a candidate of it
     skx::LongRows long_rows() const { return skx::LongRows{d_lrow, d_nlrow, qcap + 128, d_inb, ref->n_lw}; }
+    // rows whose list is a pattern + exceptions (references with patterns; a stream whose compact problems are wider than the pattern
+    // kernels' LDS rows -- more than eight species -- does without: its dictionaries never flag a row)
+    bool use_pat = false;
+    u32 *d_hist = nullptr, *d_nprow = nullptr;  // [kPassBatchesMax][npat_pad] occurrences of every pattern per batch; rows listed per batch
+    u64* d_pcw = nullptr;                        // [kPassBatchesMax][n_pat][n_grp_c * 8] the patterns at every batch's candidates
+    u32 npat_pad = 0;
+    skx::PatRows pat_rows() const { return skx::PatRows{d_hist, npat_pad, d_gain_l, d_nprow}; }
+    skx::RareIndex rare_index() const { skx::RareIndex ri = ref->rare_index(); if (!use_pat) { ri.prec = nullptr; ri.n_pat = 0; } return ri; }
     u32 *d_cbad = nullptr, *d_nqc = nullptr;  // [kPassBatchesMax] why a batch cannot rank compactly / mapped rare rows
     u32 *d_spc_g0 = nullptr, *d_spc_grp = nullptr;  // Species layout of the compact problems: kCandCap slots per species
     u32 n_pad_c = 0, n_grp_c = 0, cand_seq = 0;
@@ -973,8 +1094,8 @@ static void stream_free(skx_stream* st) {
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1],
                     st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1],
-                    st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum,
-                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_lrow, st->d_nlrow, st->d_gain_l, st->d_cbase, st->d_cwl, st->d_ncwl, st->d_cw, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp, st->d_inb, st->d_hit};
+                    st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_nd_hs,
+                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_lrow, st->d_nlrow, st->d_gain_l, st->d_cbase, st->d_cwl, st->d_ncwl, st->d_cw, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp, st->d_inb, st->d_hit, st->d_hist, st->d_nprow, st->d_pcw};
     for (auto& q : st->ps) {
         for (void* x : {(void*)q.tab, (void*)q.cand, (void*)q.tabc, (void*)q.ncand, (void*)q.mode, (void*)q.any_full, (void*)q.nqc_total, (void*)q.mc, (void*)q.mqc,
                         (void*)q.rowany_c, (void*)q.grp_any_c, (void*)q.smap, (void*)q.pair_qc, (void*)q.nd}) (void)hipFree(x);
@@ -1417,6 +1538,8 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipHostMalloc((void**)&st->h_nq_sink, 4 * 4, hipHostMallocCoherent));
     SCHK(hipHostMalloc((void**)&st->h_lcount, 4 * 4, hipHostMallocCoherent));
     memset(st->h_lcount, 0, 4 * 4);
+    SCHK(hipMalloc(&st->d_nd_hs, 64));
+    SCHK(hipMemset(st->d_nd_hs, 0, 64));
     if (ref->d_kt_key) {  // the split dictionary of a pass (rare-hash index)
         SCHK(hipMalloc(&st->d_qd, (size_t)st->pcap * 8));
         SCHK(hipMalloc(&st->d_qrow, (size_t)st->pcap * 4));
@@ -1446,6 +1569,13 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
             if (ref->d_mlongT) {
                 SCHK(hipMalloc(&st->d_inb, (size_t)nb * ref->n_lw * 8));
                 SCHK(hipMalloc(&st->d_hit, (size_t)nb * ref->n_lw * 8));
+            }
+            if (ref->d_prec && ref->n_pat && st->n_grp_c * skx::kRankWords <= skx::pat_words_max()) {
+                st->use_pat = true;
+                st->npat_pad = (ref->n_pat + 63u) & ~63u;
+                SCHK(hipMalloc(&st->d_hist, (size_t)nb * st->npat_pad * 4));
+                SCHK(hipMalloc(&st->d_nprow, skx::pass_counter_bytes()));
+                SCHK(hipMalloc(&st->d_pcw, (size_t)nb * ref->n_pat * st->n_grp_c * skx::kRankWords * 8));
             }
         }
         SCHK(hipMalloc(&st->d_cbad, 64));
@@ -1656,7 +1786,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     u64 *d_mq = st->d_mq[b], *d_q = st->d_q[b];
     u32* d_grp_any = st->d_grp_any[b];
     skx_stream::PassSet& ps = st->ps[b];
-    u32* const d_nd = ps.nd;
+    u32* const d_nd = st->d_nd_hs;  // (scan-stream scratch; ps.nd, the copy the chains read, is written in wait_back)
     const u32 qstride = st->qcap + 128;         // rows per batch of the per-row arrays (d_cnt, smap)
 
     // |Q| per pair from the latest pass whose dictionary is known to be complete (split dictionaries: also the dense share)
@@ -1720,7 +1850,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                               st->d_dict_ctr[b], d_q, d_nq);
         if (split_dict) {
             // dense hashes -> rows [0, nd), what the scan looks for; the others -> the rows behind, filled from the genome lists
-            skx::launch_classify(hs, d_q, d_nq, q_bound, ref->rare_index(), st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_qd, d_nd,
+            skx::launch_classify(hs, d_q, d_nq, q_bound, st->rare_index(), st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_qd, d_nd,
                                  st->d_qrow, st->d_sslot, st->h_nd + 2 * b);
             scan_q = st->d_qd; scan_nq = d_nd;
         } else {
@@ -1761,6 +1891,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // the ranking two passes back reads this set's pair -> query index, Mq and group flags: from here on they are rewritten
     auto wait_back = [&]() -> int {
         if (st->back_pending[b]) { HIPCHK(hipStreamWaitEvent(hs, st->ev_back[b], 0)); st->back_pending[b] = false; }
+        HIPCHK(hipMemcpyAsync(ps.nd, d_nd, 16, hipMemcpyDeviceToDevice, hs));  // (the counts this pass's chains will read)
         HIPCHK(hipMemsetAsync(d_grp_any, 0, (size_t)n_grp_all * 4, hs));  // raised by the transpose
         if (P > 0) {
             skx::launch_pair_q(hs, st->d_pair_h[b], P, d_q, d_nq, d_pair_q, split_dict ? st->d_qrow : nullptr, st->d_bbase, st->d_btot, ref->max_ref);
@@ -1809,10 +1940,15 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     for (int i = 0; i < n_sub; ++i) pbt.p_off[i] = subs[i].p_off;
     pbt.p_off[n_sub] = P;
     auto rare_gains = [&](hipStream_t on) -> int {  // row counts known: the short lists' adds, the bit rows' bit-sliced sums
-        const skx::RareIndex ri = ref->rare_index();
+        const skx::RareIndex ri = st->rare_index();
         const skx::LongRows lrows = st->long_rows();
-        skx::launch_gain_sparse(on, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_s, st->d_sslot, ri, long_rows ? &lrows : nullptr, walk_scale);
+        const skx::PatRows prows = st->pat_rows();
+        skx::launch_gain_sparse(on, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_s, st->d_sslot, ri, long_rows ? &lrows : nullptr, walk_scale,
+                                (long_rows && st->use_pat) ? &prows : nullptr);
         if (long_rows) skx::launch_gain_long(on, lrows, ri, d_nd, st->d_rowcnt, qstride, (u32)n_sub, n_pad, st->d_gain_l, walk_scale);
+        // the pattern rows' part: gain_l[b][g] += sum over the patterns of hist[b][p] x PM[p][g] -- the dense rows' kernel on the pattern matrix
+        if (long_rows && st->use_pat)
+            skx::launch_gain_dense(on, ri.pm, nullptr, n_pad, ri.d_npat, ri.n_pat, st->d_hist, st->npat_pad, (u32)n_sub, st->d_gain_l);
         HIPCHK(hipGetLastError());
         return SKX_OK;
     };
@@ -1827,6 +1963,10 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                 HIPCHK(hipMemsetAsync(st->d_hit, 0, (size_t)n_sub * ref->n_lw * 8, hs));
             }
             HIPCHK(hipMemsetAsync(st->d_gain_l, 0, (size_t)n_sub * n_pad * 4, hs));
+            if (st->use_pat) {
+                HIPCHK(hipMemsetAsync(st->d_hist, 0, (size_t)n_sub * st->npat_pad * 4, hs));
+                HIPCHK(hipMemsetAsync(st->d_nprow, 0, skx::pass_counter_bytes(), hs));
+            }
         }
         return SKX_OK;
     };
@@ -1905,6 +2045,8 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         for (int i = 0; i < n_sub; ++i) if (subs[i].d_shared) force_full |= 1u << i;
         HIPCHK(hipMemsetAsync(st->d_cbad, 0, 64, hs));
         HIPCHK(hipMemsetAsync(st->d_nqc, 0, skx::pass_counter_bytes(), hs));
+        const bool pat_rows = st->use_pat && long_rows && ranked && P > 0 && !all_forced;
+        if (pat_rows) skx::launch_pat_nqc_init(hs, st->d_nqc, st->npat_pad);  // (the mapped rare rows come behind the patterns' rows)
         if (ranked) {
             HIPCHK(hipMemsetAsync(st->d_candmask, 0, (size_t)n_pad * 4, hs));
             skx::launch_cand_select(hs, ps.tab, n_pad, spc, (u32)n_sub, st->top_k, cap, ps.cand, st->d_candslot, ps.tabc, ps.ncand, st->d_cbad,
@@ -1914,7 +2056,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                 HIPCHK(hipMemsetAsync(ps.mqc, 0, (size_t)n_sub * st->n_grp_c * rows_c * skx::kRankWords * 8, hs));
                 HIPCHK(hipMemsetAsync(ps.rowany_c, 0, (size_t)n_sub * st->n_grp_c * (rows_c / 64) * 8, hs));
                 HIPCHK(hipMemset2DAsync(ps.smap, (size_t)qstride * 4, 0, (size_t)nq_rows * 4, (size_t)n_sub, hs));
-                skx::launch_cand_sparse(hs, st->d_sslot, d_nd, q_bound, ref->rare_index(), st->d_candmask, st->d_candslot, n_pad, st->d_cbad, (u32)n_sub, st->d_nqc,
+                skx::launch_cand_sparse(hs, st->d_sslot, d_nd, q_bound, st->rare_index(), st->d_candmask, st->d_candslot, n_pad, st->d_cbad, (u32)n_sub, st->d_nqc,
                                         ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords, rows_c, ps.rowany_c,
                                         st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c, walk_scale);
                 if (long_rows) {  // ... and the rows with a bit row: ANDed with the candidates' words
@@ -1923,10 +2065,19 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
                     HIPCHK(hipMemsetAsync(st->d_cbase, 0xFF, (size_t)n_sub * n_gw * 4, hs));
                     HIPCHK(hipMemsetAsync(st->d_ncwl, 0, 64, hs));
                     skx::launch_cand_words(hs, ps.cand, st->n_pad_c, (u32)n_sub, n_gw, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl);
-                    if (st->d_hit) skx::launch_cand_hit(hs, ps.cand, st->n_pad_c, (u32)n_sub, st->d_cbad, ref->rare_index(), st->d_inb, st->d_hit);
-                    skx::launch_cand_long(hs, st->long_rows(), ref->rare_index(), d_nd, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl, st->n_pad_c,
+                    if (st->d_hit) skx::launch_cand_hit(hs, ps.cand, st->n_pad_c, (u32)n_sub, st->d_cbad, st->rare_index(), st->d_inb, st->d_hit);
+                    skx::launch_cand_long(hs, st->long_rows(), st->rare_index(), d_nd, st->d_cw, st->d_cbase, st->d_cwl, st->d_ncwl, st->n_pad_c,
                                           st->d_cbad, (u32)n_sub, st->d_nqc, ps.smap, qstride, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords,
                                           rows_c, ps.rowany_c, st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c, walk_scale, st->d_hit);
+                }
+                if (pat_rows) {  // ... and the rows that are a pattern + exceptions: the pattern's row, or the pattern's words with a few bits flipped
+                    const skx::RareIndex ri = st->rare_index();
+                    skx::launch_cand_pat_rows(hs, ri, d_nd, st->d_candmask, st->d_candslot, n_pad, st->d_cbad, (u32)n_sub, st->d_pcw, ps.mqc,
+                                              (size_t)st->n_grp_c * rows_c * skx::kRankWords, rows_c, ps.rowany_c, st->n_grp_c * (rows_c / 64), ps.grp_any_c,
+                                              st->n_grp_c);
+                    skx::launch_cand_pat_map(hs, st->long_rows(), st->pat_rows(), ri, d_nd, st->d_candmask, st->d_candslot, n_pad, st->d_cbad, (u32)n_sub,
+                                             st->d_nqc, ps.smap, qstride, st->d_pcw, ps.mqc, (size_t)st->n_grp_c * rows_c * skx::kRankWords, rows_c,
+                                             ps.rowany_c, st->n_grp_c * (rows_c / 64), ps.grp_any_c, st->n_grp_c, q_bound, walk_scale);
                 }
             }
         } else {
@@ -1948,14 +2099,14 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         const bool direct_rare = split_dict && ref->d_mlong != nullptr && direct_env != 0;
         if (split_dict && !direct_rare) {
             Span sp(st, 1, hs);
-            skx::launch_sparse_fill(hs, st->d_sslot, d_nd, ref->rare_index(), st->d_m, n_pad, d_mdirty, q_bound, only_if);
+            skx::launch_sparse_fill(hs, st->d_sslot, d_nd, st->rare_index(), st->d_m, n_pad, d_mdirty, q_bound, only_if);
         }
         {
             Span sp(st, 3, hs);
             skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, direct_rare ? d_nd + 2 : d_nd + 3, d_grp_any,
                                        nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, direct_rare ? nd_est : nq_est, st->d_rowany[b], only_if);
             if (direct_rare)
-                skx::launch_rare_to_mq(hs, st->d_sslot, d_nd, ref->rare_index(), d_mq, nq_rows, n_pad, st->d_rowany[b], d_grp_any, q_bound, only_if);
+                skx::launch_rare_to_mq(hs, st->d_sslot, d_nd, st->rare_index(), d_mq, nq_rows, n_pad, st->d_rowany[b], d_grp_any, q_bound, only_if);
             if (only_if) skx::launch_m_clear(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, d_nd, only_if);
         }
     }

@@ -1687,6 +1687,91 @@ __global__ __launch_bounds__(256) void mlong_transpose_kernel(const u64* __restr
     const u64 y = transpose64(x, lane);
     mlongT[((size_t)gw * 64u + lane) * n_lw + lw] = y;
 }
+// ---- long lists as (pattern, exceptions) (round 6).  The long lists of a clonal collection are near-duplicates: every lineage-level hash of a
+// lineage is held by the lineage's ~200 strains minus the odd strain whose own SNP removed it (SURVEY 8(d)'s tree at C2: 263 k long lists,
+// 258 k of them distinct -- and 97 % within 14 genomes of the most frequent list of their lineage, median 2: tools/diag_patterns.py).
+// skx_ref_create groups the long lists by a MinHash signature of the list (list_sig_kernel; two lists of Jaccard similarity J share it
+// with probability J), takes the most frequent exact list of a group as the group's PATTERN (host: a few hundred thousand 12-byte
+// records), and writes every list of the group as that pattern plus its symmetric difference (pat_exceptions_kernel: XOR of two bit rows)
+// when that is at most kPatExcMax genomes: prec[lid] = {pattern, n, n x (genome | in the pattern but NOT on the list << 31)}.  The patterns'
+// bits transposed form a small matrix PM[word of 64 patterns][genome] laid out like M.  For such a row a pass needs neither the bit row
+// nor the list:  gain_b[g] = sum_p hist_b[p] * PM[p][g]  (hist_b[p] = occurrences of the pattern's rows among batch b's pairs: the same
+// kernel that adds up the dense rows of M, on ~200 rows instead of 130 k bit rows of 5 KB)  +/- the count at the row's exceptions; and
+// a compact ranking maps the row to its pattern's row of the compact matrix unless one of the exceptions is a candidate.  Whatever the
+// grouping finds, rows and table are exact: a list is stored as EXACTLY pattern xor exceptions, or left to its bit row.
+constexpr u32 kPatFlag = 0x40000000u;    // sslot[2 i + 1], with kLongFlag: the row's list is a pattern + exceptions (prec[bit row])
+constexpr u32 kLenMask = 0x3FFFFFFFu;    // ... the list's length
+constexpr u32 kPatNone = 0xFFFFFFFFu;
+constexpr u32 kPatRec = 16;              // u32 words of a record: pattern, exceptions, the exceptions
+constexpr u32 kPatExcMax = kPatRec - 2u;
+__device__ __forceinline__ u32 mix32(u32 x) {
+    x = (x ^ (x >> 16)) * 0x7FEB352Du;
+    x = (x ^ (x >> 15)) * 0x846CA68Bu;
+    return x ^ (x >> 16);
+}
+// sig[row] = min over the list of mix32(genome), content[row] = an order-independent 64-bit digest of the list: one wave per bit row
+__global__ __launch_bounds__(256) void list_sig_kernel(const u32* __restrict__ lslot, u32 n_long, const u32* __restrict__ off,
+                                                       const u32* __restrict__ cnt, const u32* __restrict__ post, u32* __restrict__ sig,
+                                                       u64* __restrict__ content) {
+    const u32 w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = lane_id();
+    if (w >= n_long) return;
+    const u32 slot = lslot[w], o = off[slot], n = cnt[slot];
+    u32 m = 0xFFFFFFFFu;
+    u64 c = 0;
+    for (u32 j = lane; j < n; j += 64u) {
+        const u32 g = post[o + j], x = mix32(g);
+        m = min(m, x);
+        c += ((u64)x * 0x9E3779B97F4A7C15ull) ^ ((u64)g << 32);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { m = min(m, (u32)__shfl_xor((int)m, d, 64)); c += shfl_xor64(c, d); }
+    if (lane == 0u) { sig[w] = m; content[w] = c; }
+}
+// prec[row] = the row's list as its pattern (pat_of[row], or none) + exceptions: one wave per bit row XORs it with the pattern's
+__global__ __launch_bounds__(256) void pat_exceptions_kernel(const u64* __restrict__ mlong, u32 n_gw, u32 n_long, const u32* __restrict__ pat_of,
+                                                             const u32* __restrict__ pat_rep, u32* __restrict__ prec, u32* __restrict__ n_done) {
+    const u32 w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = lane_id();
+    if (w >= n_long) return;
+    u32* rec = prec + (size_t)w * kPatRec;
+    const u32 pat = pat_of[w];
+    if (pat == kPatNone) { if (lane == 0u) rec[0] = kPatNone; return; }
+    const u64* a = mlong + (size_t)w * n_gw;
+    const u64* b = mlong + (size_t)pat_rep[pat] * n_gw;
+    u32 total = 0;
+    for (u32 i = lane; i < n_gw; i += 64u) total += (u32)__popcll(a[i] ^ b[i]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) total += (u32)__shfl_xor((int)total, d, 64);
+    if (total > kPatExcMax) { if (lane == 0u) rec[0] = kPatNone; return; }
+    u32 at = 0;
+    for (u32 i0 = 0; i0 < n_gw; i0 += 64u) {
+        const u32 i = i0 + lane;
+        const u64 bw = i < n_gw ? b[i] : 0ull;
+        u64 x = i < n_gw ? (a[i] ^ bw) : 0ull;
+        u64 bal = __ballot(x != 0ull);
+        while (bal) {  // (a handful of words of the row differ at all)
+            const u32 src = (u32)__builtin_ctzll(bal);
+            bal &= bal - 1ull;
+            u64 xs = readlane64(x, (int)src);
+            const u64 bs = readlane64(bw, (int)src);
+            while (xs) {
+                const u32 bit = (u32)__builtin_ctzll(xs);
+                xs &= xs - 1ull;
+                if (lane == 0u) rec[2u + at] = ((i0 + src) * 64u + bit) | (((bs >> bit) & 1ull) ? 0x80000000u : 0u);
+                ++at;
+            }
+        }
+    }
+    if (lane == 0u) { rec[0] = pat; rec[1] = total; atomicAdd(n_done, 1u); }
+}
+// PM[w][g] bit j = pattern 64 w + j holds genome g (the patterns' bit rows transposed, in M's layout): one wave per (64 patterns, genome word)
+__global__ __launch_bounds__(256) void pat_matrix_kernel(const u64* __restrict__ mlong, const u32* __restrict__ pat_rep, u32 n_pat, u32 n_gw,
+                                                         u64* __restrict__ pm, u32 n_pad) {
+    const u32 pw = blockIdx.x, gw = blockIdx.y * 4u + (threadIdx.x >> 6), lane = lane_id();
+    if (gw >= n_gw) return;
+    const u32 p = pw * 64u + lane;
+    const u64 x = p < n_pat ? mlong[(size_t)pat_rep[p] * n_gw + gw] : 0ull;
+    pm[(size_t)pw * n_pad + gw * 64u + lane] = transpose64(x, lane);
+}
 // ---- a pass's dictionary, split.  classify_a: look every query hash up (qinfo[q] = its slot | kSlotNone; dense: bit 31 of qloc[q]),
 // block-local exclusive count of the dense ones; classify_b: one block scans the block totals, publishes nd / ns;
 // classify_c: Qd (the dense hashes, still ascending), qrow[q] = the hash's row of the bit matrix (dense rows first, in Qd order,
@@ -1761,8 +1846,10 @@ __global__ __launch_bounds__(256) void classify_c_kernel(const u64* __restrict__
         qrow[i] = nd64 + sr;
         const u32 np = slot != kSlotNone ? ri.cnt[slot] : 0u;
         const bool lng = ri.mlong != nullptr && np > kShortList;  // (a long list: the row carries the index of its bit row instead)
-        sslot[2u * sr] = slot == kSlotNone ? 0u : lng ? ri.lid[slot] : ri.off[slot];
-        sslot[2u * sr + 1u] = lng ? (np | kLongFlag) : np;
+        const u32 lid = lng ? ri.lid[slot] : 0u;
+        const bool pat = lng && ri.prec != nullptr && ri.prec[(size_t)lid * kPatRec] != kPatNone;  // (... which is a pattern + exceptions)
+        sslot[2u * sr] = slot == kSlotNone ? 0u : lng ? lid : ri.off[slot];
+        sslot[2u * sr + 1u] = lng ? (np | kLongFlag | (pat ? kPatFlag : 0u)) : np;
     }
 }
 // a reference without the index: every hash is the scan's, rows = positions in Q
@@ -1787,7 +1874,7 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict_
         if (sr < ns) {
             const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr];
             off = e.x; cnt = e.y;
-            if (cnt & kLongFlag) { cnt &= ~kLongFlag; off = ri.off[ri.lslot[off]]; }  // (a bit row: M wants the list)
+            if (cnt & kLongFlag) { cnt &= kLenMask; off = ri.off[ri.lslot[off]]; }  // (a bit row: M wants the list)
         }
         const u32 row = nd + sr;
         u64* const mrow = m_bits + (size_t)(row >> 6) * n_pad;
@@ -1841,7 +1928,7 @@ __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__
             if (sr < ns) {
                 const uint2 e = reinterpret_cast<const uint2*>(sslot)[sr];
                 lng[h] = (e.y & kLongFlag) != 0u;
-                np[h] = e.y & ~kLongFlag;
+                np[h] = e.y & kLenMask;
                 lid[h] = e.x;
                 if (!lng[h] && cw < np[h]) mine = ri.post[e.x + cw];
             }
@@ -3920,7 +4007,7 @@ __global__ __launch_bounds__(256) void gain_dense_kernel(const u64* __restrict__
 // list --, counts summed per list first.  DESIGN.md section 9.)
 __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
                                                           const u32* __restrict__ cnt, u32 row_stride, u32 n_b, u32 n_pad,
-                                                          u32* __restrict__ gain, LongRows lr) {
+                                                          u32* __restrict__ gain, LongRows lr, PatRows pr) {
     __builtin_amdgcn_s_setprio(2);
     const u32 nd64 = n_d[2], ns = n_d[1], lane = lane_id();
     const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
@@ -3940,7 +4027,45 @@ __global__ __launch_bounds__(256) void gain_sparse_kernel(const u32* __restrict_
                     if (b < n_b) { c[b] = cnt[(size_t)b * row_stride + nd64 + sr]; any |= c[b]; }
             }
         }
-        const bool is_long = (np & kLongFlag) != 0u;
+        // rows whose list is a pattern + exceptions (prec): the pattern's count goes up by the row's, the exceptions take the difference
+        // (gain_x: wrapping adds -- the pattern's part, added by the dense-rows kernel on PM, makes every entry a true count again);
+        // listed per batch from the END of the bit rows' region for cand_pat_map_kernel
+        const bool is_pat = pr.hist != nullptr && (np & (kLongFlag | kPatFlag)) == (kLongFlag | kPatFlag);
+        if (__ballot(is_pat)) {
+            u64 bal[kPassBatchesMax];
+            u32 mine = 0;
+#pragma unroll
+            for (u32 b = 0; b < kPassBatchesMax; ++b) {
+                bal[b] = __ballot(b < n_b && is_pat && c[b] != 0u);
+                if (lane == b) mine = (u32)__popcll(bal[b]);
+            }
+            u32 base = 0;
+            if (mine) base = atomicAdd(&pr.nprow[lane * kCtrStride], mine);
+#pragma unroll
+            for (u32 b = 0; b < kPassBatchesMax; ++b) {
+                const u32 bb = (u32)__shfl((int)base, (int)b);
+                if ((bal[b] >> lane) & 1ull)
+                    lr.lrow[(size_t)b * lr.lrow_stride + (lr.lrow_stride - 1u - (bb + (u32)__popcll(bal[b] & lanemask_lt())))] = make_uint2(off, sr);
+            }
+            if (is_pat && any) {
+                const u32* rec = ri.prec + (size_t)off * kPatRec;
+                const uint4 r0 = *reinterpret_cast<const uint4*>(rec);  // {pattern, exceptions, first two of them}
+                const u32 pat = r0.x, n_exc = r0.y;
+#pragma unroll
+                for (u32 b = 0; b < kPassBatchesMax; ++b)
+                    if (c[b]) atomicAdd(&pr.hist[(size_t)b * pr.hist_stride + pat], c[b]);
+                for (u32 j = 0; j < n_exc; ++j) {
+                    const u32 e = j == 0u ? r0.z : j == 1u ? r0.w : rec[2u + j];
+                    const u32 g = e & 0x7FFFFFFFu;
+                    const bool neg = (e >> 31) != 0u;
+#pragma unroll
+                    for (u32 b = 0; b < kPassBatchesMax; ++b)
+                        if (c[b]) atomicAdd(&pr.gain_x[(size_t)b * n_pad + g], neg ? 0u - c[b] : c[b]);
+                }
+            }
+        }
+        const bool is_long = (np & kLongFlag) != 0u && !is_pat;
+        if (is_pat) np = 0;
         if (__ballot(is_long)) {
             // rows with a bit row: listed per batch for gain_long_kernel / cand_long_kernel (one walk over the rare rows instead of two)
             if (lr.lrow) {
@@ -4229,10 +4354,109 @@ __global__ __launch_bounds__(256) void cand_long_kernel(LongRows lr, RareIndex r
         }
     }
 }
+// ---- pattern rows of the compact problems (round 6).  Row nd64 + p of batch b's compact matrix = pattern p's bits at b's candidates
+// (one wave per (pattern, batch) walks the pattern's list -- its representative's genome list -- once per pass; pcw[b][p][word] keeps the
+// words for the rows below).  A row of the pass whose list is pattern + exceptions then needs no row of its own unless one of its
+// exceptions is a candidate of the batch: smap -> the pattern's row; else a new row = the pattern's words with those bits flipped.
+// The mapped rows start behind the patterns': the pass's nqc counters start at n_pat rounded up to 64 (pat_nqc_init_kernel).
+__global__ void pat_nqc_init_kernel(u32* __restrict__ nqc, u32 v) {
+    if (threadIdx.x < kPassBatchesMax) nqc[threadIdx.x * kCtrStride] = v;
+}
+__global__ __launch_bounds__(256) void cand_pat_rows_kernel(RareIndex ri, const u32* __restrict__ n_d, const u32* __restrict__ candmask,
+                                                            const u32* __restrict__ candslot, u32 n_pad, u32* __restrict__ bad,
+                                                            u64* __restrict__ pcw, u64* __restrict__ mqc, size_t mqc_stride, u32 rows_c,
+                                                            u64* __restrict__ rowany_c, u32 rowany_stride, u32* __restrict__ grp_any_c,
+                                                            u32 n_grp_c) {
+    __builtin_amdgcn_s_setprio(2);
+    __shared__ u64 pat[4][kPatWords];
+    const u32 b = blockIdx.y, lane = lane_id(), wv = threadIdx.x >> 6, p = blockIdx.x * 4u + wv;
+    if (p >= ri.n_pat || bad[b]) return;
+    const u32 nd64 = n_d[2], n_gw_c = n_grp_c * kRankWords, npat64 = (ri.n_pat + 63u) & ~63u;
+    if (nd64 + npat64 + 64u >= rows_c) { if (lane == 0u) atomicOr(&bad[b], 2u); return; }  // (no room for the patterns' rows: the batch ranks on everything)
+    const u32 cr = nd64 + p;
+    u64* pw = pat[wv];
+    for (u32 w = lane; w < n_gw_c; w += 64u) pw[w] = 0ull;
+    wave_sync();
+    const u32 slot = ri.lslot[ri.pat_rep[p]], o = ri.off[slot], n = ri.cnt[slot];
+    for (u32 j = lane; j < n; j += 64u) {
+        const u32 g = ri.post[o + j];
+        if ((candmask[g] >> b) & 1u) {
+            const u32 s_ = candslot[(size_t)b * n_pad + g];
+            atomicOr(&pw[s_ >> 6], 1ull << (s_ & 63u));
+        }
+    }
+    wave_sync();
+    u64* out = pcw + ((size_t)b * ri.n_pat + p) * n_gw_c;
+    for (u32 w0 = 0; w0 < n_gw_c; w0 += 64u) {
+        const u32 w = w0 + lane;
+        const u64 v = w < n_gw_c ? pw[w] : 0ull;
+        if (w < n_gw_c) out[w] = v;
+        if (v) mqc[(size_t)b * mqc_stride + mq_index(w, cr, rows_c)] = v;
+        const u64 nzw = __ballot(v != 0ull);
+        const u32 l0 = (lane / kRankWords) * kRankWords;
+        if (lane == l0 && w < n_gw_c && ((nzw >> l0) & ((1ull << kRankWords) - 1ull)) != 0ull) {
+            const u32 grp = w / kRankWords;
+            atomicOr(&rowany_c[(size_t)b * rowany_stride + (size_t)grp * (rows_c >> 6) + (cr >> 6)], 1ull << (cr & 63u));
+            u32* ga = grp_any_c + (size_t)b * n_grp_c + grp;
+            if (*ga == 0u) atomicOr(ga, 1u);
+        }
+    }
+}
+// one THREAD per listed pattern row of a batch (grid: (blocks, batches))
+__global__ __launch_bounds__(256) void cand_pat_map_kernel(LongRows lr, PatRows pr, RareIndex ri, const u32* __restrict__ n_d,
+                                                           const u32* __restrict__ candmask, const u32* __restrict__ candslot, u32 n_pad,
+                                                           u32* __restrict__ bad, u32* __restrict__ nqc, u32* __restrict__ smap, u32 smap_stride,
+                                                           const u64* __restrict__ pcw, u64* __restrict__ mqc, size_t mqc_stride, u32 rows_c,
+                                                           u64* __restrict__ rowany_c, u32 rowany_stride, u32* __restrict__ grp_any_c,
+                                                           u32 n_grp_c) {
+    __builtin_amdgcn_s_setprio(2);
+    const u32 b = blockIdx.y;
+    if (bad[b]) return;
+    const u32 nd64 = n_d[2], nr = pr.nprow[b * kCtrStride], n_gw_c = n_grp_c * kRankWords;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < nr; i += gridDim.x * 256u) {
+        const uint2 e = lr.lrow[(size_t)b * lr.lrow_stride + (lr.lrow_stride - 1u - i)];
+        const u32* rec = ri.prec + (size_t)e.x * kPatRec;
+        const u32 p = rec[0], n_exc = rec[1];
+        u32 fl[kPatExcMax];
+        u32 nf = 0;
+#pragma unroll
+        for (u32 j = 0; j < kPatExcMax; ++j) {
+            fl[j] = kCandNone;
+            if (j < n_exc) {
+                const u32 g = rec[2u + j] & 0x7FFFFFFFu;
+                if ((candmask[g] >> b) & 1u) { fl[j] = candslot[(size_t)b * n_pad + g]; ++nf; }
+            }
+        }
+        if (nf == 0u) { smap[(size_t)b * smap_stride + e.y] = nd64 + p + 1u; continue; }
+        const u32 cr = nd64 + atomicAdd(&nqc[b * kCtrStride], 1u);
+        if (cr + 1u >= rows_c) { atomicOr(&bad[b], 2u); continue; }  // (the batch's matrix is full: it ranks on everything)
+        smap[(size_t)b * smap_stride + e.y] = cr + 1u;
+        const u64* src = pcw + ((size_t)b * ri.n_pat + p) * n_gw_c;
+        for (u32 grp = 0; grp < n_grp_c; ++grp) {
+            u64 any = 0ull;
+#pragma unroll
+            for (u32 k = 0; k < kRankWords; ++k) {
+                const u32 w = grp * kRankWords + k;
+                u64 v = src[w];
+#pragma unroll
+                for (u32 j = 0; j < kPatExcMax; ++j) v ^= (fl[j] >> 6) == w ? 1ull << (fl[j] & 63u) : 0ull;  // (kCandNone >> 6 is no word)
+                if (v) mqc[(size_t)b * mqc_stride + mq_index(w, cr, rows_c)] = v;
+                any |= v;
+            }
+            if (any) {
+                atomicOr(&rowany_c[(size_t)b * rowany_stride + (size_t)grp * (rows_c >> 6) + (cr >> 6)], 1ull << (cr & 63u));
+                u32* ga = grp_any_c + (size_t)b * n_grp_c + grp;
+                if (*ga == 0u) atomicOr(ga, 1u);
+            }
+        }
+    }
+}
 // gain_s (or NULL): the rare rows' part, one entry per kGainSparseStride words (gain_sparse_kernel)
-__global__ __launch_bounds__(256) void pass_tables_kernel(const u64* __restrict__ prev, const u32* __restrict__ gain,
+// (prev may lie INSIDE tab -- the table a pass on the same buffer set left as its last row: every thread reads prev[g] before it writes
+// column g and touches no other column, so the in-place case is well defined; hence no __restrict__ on the two)
+__global__ __launch_bounds__(256) void pass_tables_kernel(const u64* prev, const u32* __restrict__ gain,
                                                           const u32* __restrict__ gain_s, const u32* __restrict__ gain_l, u32 n_b, u32 n_pad,
-                                                          u64* __restrict__ tab) {
+                                                          u64* tab) {
     __builtin_amdgcn_s_setprio(3);
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     if (g >= n_pad) return;
@@ -4275,7 +4499,9 @@ __device__ __forceinline__ u64 species_theta(const u64* __restrict__ t0, u32 g0,
     u64 theta = 0, prev = 0;
     u32 remaining = max(top_k, 1u);
     bool first = true;
-    for (u32 round = 0; round < 64u; ++round) {
+    // (every round settles at least one of the top_k places: at most top_k rounds -- round 5 stopped after 64 and returned 0 for larger
+    // top_k with distinct values: exact still, but every genome a candidate for ever)
+    for (u32 round = 0, n_rounds = max(top_k, 1u); round < n_rounds; ++round) {
         u64 m = 0;
         u32 any = 0;
         for (u32 g = g0 + tid; g < g0 + n; g += 1024u) {
@@ -4822,9 +5048,38 @@ void launch_gain_dense(hipStream_t st, const u64* m_bits, const u64* m_int, u32 
 // the chip only keeps the other streams' kernels -- the next group's sketches -- out of the wave slots: 56 M reads/s with 1832 blocks,
 // measured.  walk_scale: the caller knows that nothing runs beside this pass)
 void launch_gain_sparse(hipStream_t st, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride, u32 n_b, u32 n_pad, u32* gain_s,
-                        const u32* sslot, const RareIndex& ri, const LongRows* lr, u32 walk_scale) {
+                        const u32* sslot, const RareIndex& ri, const LongRows* lr, u32 walk_scale, const PatRows* pr) {
     hipLaunchKernelGGL(gain_sparse_kernel, dim3(std::max(1u, std::min(cdiv(rows_bound, 256), kWalkBlocks * std::max(1u, walk_scale)))), dim3(256), 0, st,
-                       sslot, n_d, ri, cnt, row_stride, n_b, n_pad, gain_s, lr ? *lr : LongRows{nullptr, nullptr, 0u});
+                       sslot, n_d, ri, cnt, row_stride, n_b, n_pad, gain_s, lr ? *lr : LongRows{nullptr, nullptr, 0u},
+                       (pr && lr && ri.prec) ? *pr : PatRows{nullptr, 0u, nullptr, nullptr});
+}
+void launch_list_sig(hipStream_t st, const u32* lslot, u32 n_long, const u32* off, const u32* cnt, const u32* post, u32* sig, u64* content) {
+    if (n_long == 0) return;
+    hipLaunchKernelGGL(list_sig_kernel, dim3(cdiv(n_long, 4)), dim3(256), 0, st, lslot, n_long, off, cnt, post, sig, content);
+}
+void launch_pat_exceptions(hipStream_t st, const u64* mlong, u32 n_gw, u32 n_long, const u32* pat_of, const u32* pat_rep, u32* prec, u32* n_done) {
+    if (n_long == 0) return;
+    hipLaunchKernelGGL(pat_exceptions_kernel, dim3(cdiv(n_long, 4)), dim3(256), 0, st, mlong, n_gw, n_long, pat_of, pat_rep, prec, n_done);
+}
+void launch_pat_matrix(hipStream_t st, const u64* mlong, const u32* pat_rep, u32 n_pat, u32 n_gw, u64* pm, u32 n_pad) {
+    if (n_pat == 0) return;
+    hipLaunchKernelGGL(pat_matrix_kernel, dim3(cdiv(n_pat, 64), cdiv(n_gw, 4)), dim3(256), 0, st, mlong, pat_rep, n_pat, n_gw, pm, n_pad);
+}
+u32 pat_record_words() { return kPatRec; }
+u32 pat_words_max() { return kPatWords; }
+void launch_pat_nqc_init(hipStream_t st, u32* nqc, u32 v) { hipLaunchKernelGGL(pat_nqc_init_kernel, dim3(1), dim3(64), 0, st, nqc, v); }
+void launch_cand_pat_rows(hipStream_t st, const RareIndex& ri, const u32* n_d, const u32* candmask, const u32* candslot, u32 n_pad, u32* bad, u32 n_b,
+                          u64* pcw, u64* mqc, size_t mqc_stride, u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c) {
+    if (ri.n_pat == 0) return;
+    hipLaunchKernelGGL(cand_pat_rows_kernel, dim3(cdiv(ri.n_pat, 4), n_b), dim3(256), 0, st, ri, n_d, candmask, candslot, n_pad, bad, pcw, mqc, mqc_stride,
+                       rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
+}
+void launch_cand_pat_map(hipStream_t st, const LongRows& lr, const PatRows& pr, const RareIndex& ri, const u32* n_d, const u32* candmask,
+                         const u32* candslot, u32 n_pad, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, const u64* pcw, u64* mqc,
+                         size_t mqc_stride, u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 rows_bound, u32 walk_scale) {
+    const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 256), 64u * std::max(1u, walk_scale)));
+    hipLaunchKernelGGL(cand_pat_map_kernel, dim3(blocks, n_b), dim3(256), 0, st, lr, pr, ri, n_d, candmask, candslot, n_pad, bad, nqc, smap, smap_stride,
+                       pcw, mqc, mqc_stride, rows_c, rowany_c, rowany_stride, grp_any_c, n_grp_c);
 }
 u32 gain_sparse_stride() { return kGainSparseStride; }
 u32 pass_counter_bytes() { return kPassBatchesMax * kCtrStride * 4u; }

@@ -98,7 +98,19 @@ struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* po
                    // ... and the same bits TRANSPOSED: mlongT[genome][n_lw] u64, bit r of a genome's row = bit row r holds the genome
                    // (n_lw = ceil(rows / 64) words; NULL when there was no room): which of a batch's long-list rows meet a candidate is
                    // then an AND of the candidate's row with the batch's row mask, not a walk over every row (launch_cand_hit)
-                   const u64* mlongT = nullptr; u32 n_lw = 0; };
+                   const u64* mlongT = nullptr; u32 n_lw = 0;
+                   // ... and most long lists as (pattern, exceptions) (round 6; skx_kernels.hip, "long lists as (pattern, exceptions)"):
+                   // prec[bit row][pat_record_words()] = {pattern or 0xFFFFFFFF, n, n x (genome | not-on-the-list << 31)}; pat_rep[pattern] =
+                   // the bit row whose list IS the pattern; pm[word of 64 patterns][n_pad] the patterns' bits in M's layout; d_npat[0] = n_pat
+                   const u32* prec = nullptr; const u32* pat_rep = nullptr; const u64* pm = nullptr; const u32* d_npat = nullptr; u32 n_pat = 0; };
+// pattern rows of a pass: hist[b][hist_stride] = occurrences of every pattern among batch b's pairs, gain_x[b][n_pad] += / -= the rows'
+// counts at their exceptions (wrapping), nprow[b] (one counter per batch, like LongRows::nlrow) rows listed from the END of lrow[b]
+struct PatRows { u32* hist; u32 hist_stride; u32* gain_x; u32* nprow; };
+void launch_list_sig(hipStream_t st, const u32* lslot, u32 n_long, const u32* off, const u32* cnt, const u32* post, u32* sig, u64* content);
+void launch_pat_exceptions(hipStream_t st, const u64* mlong, u32 n_gw, u32 n_long, const u32* pat_of, const u32* pat_rep, u32* prec, u32* n_done);
+void launch_pat_matrix(hipStream_t st, const u64* mlong, const u32* pat_rep, u32 n_pat, u32 n_gw, u64* pm, u32 n_pad);
+u32 pat_record_words();
+u32 pat_words_max();  // genome words of a compact problem the pattern path handles (more species than that: the stream does not use the patterns)
 // long-list rows of a pass, per batch: lrow[b][i] = {bit row, sparse row of the pass's matrix} (nlrow[b] of them, lrow_stride apart)
 struct LongRows { uint2* lrow; u32* nlrow; u32 lrow_stride; u64* inb = nullptr; u32 n_lw = 0; };  // inb[b][n_lw] (or NULL; zero on entry): bit r = bit row r is on batch b's list  // (nlrow: one counter per batch, pass_counter_bytes() in all)
 u32 pass_counter_bytes();  // size of the per-batch counter arrays of a pass (nlrow, nqc: one cache line per batch)
@@ -152,8 +164,19 @@ void launch_gain_dense(hipStream_t st, const u64* m_bits, const u64* m_int /* or
                        u32 row_stride, u32 n_b, u32* gain);
 // (lr: also lists the rows with a bit row per batch, nlrow zero on entry; walk_scale: multiplies the workgroups of the list walk --
 // a pass with nothing beside it may fill the chip)
+// (pr: the rows whose list is pattern + exceptions add to hist / gain_x and are listed for launch_cand_pat_map; hist, gain_x, nprow zero on entry)
 void launch_gain_sparse(hipStream_t st, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride, u32 n_b, u32 n_pad, u32* gain_s,
-                        const u32* sslot, const RareIndex& ri, const LongRows* lr, u32 walk_scale);
+                        const u32* sslot, const RareIndex& ri, const LongRows* lr, u32 walk_scale, const PatRows* pr = nullptr);
+// pattern rows of the compact problems: nqc starts at n_pat rounded up to 64 (the mapped rows come behind the patterns' rows);
+// launch_cand_pat_rows: row n_d[2] + p of mqc[b] = pattern p at batch b's candidates, pcw[b][p][n_grp_c * 8] the same words;
+// launch_cand_pat_map: smap of every listed pattern row -> its pattern's row, or a new row (pattern's words with the exceptions that are
+// candidates flipped)
+void launch_pat_nqc_init(hipStream_t st, u32* nqc, u32 v);
+void launch_cand_pat_rows(hipStream_t st, const RareIndex& ri, const u32* n_d, const u32* candmask, const u32* candslot, u32 n_pad, u32* bad, u32 n_b,
+                          u64* pcw, u64* mqc, size_t mqc_stride, u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c);
+void launch_cand_pat_map(hipStream_t st, const LongRows& lr, const PatRows& pr, const RareIndex& ri, const u32* n_d, const u32* candmask,
+                         const u32* candslot, u32 n_pad, u32* bad, u32 n_b, u32* nqc, u32* smap, u32 smap_stride, const u64* pcw, u64* mqc,
+                         size_t mqc_stride, u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 rows_bound, u32 walk_scale = 1);
 u32 gain_sparse_stride();
 // tab[0] = prev, tab[b + 1] = tab[b] + gain[b]   ([n_b + 1][n_pad])
 void launch_pass_tables(hipStream_t st, const u64* prev, const u32* gain, const u32* gain_s /* or NULL */, const u32* gain_l /* or NULL */, u32 n_b,
