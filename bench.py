@@ -453,6 +453,8 @@ def main():
                                           "queueing the last batch's passes and waiting for them)"),
                    "api": "skx_stream_enqueue_device + final sync" if args.api == "enqueue" else "skx_stream_push_device + final sync",
                    "kmer_prefilter": dict(zip(("keys", "table_bytes"), R.kmer_filter)),
+                   "rare_index": R.rare_index, "long_lists": R.patterns,
+                   "static_dense_dictionary": dict(zip(("on", "hashes"), R.static_dense)),
                    "batches_per_pass": (f"up to {coalesce_policy} (option stream_coalesce: batches enqueued back to back share one scan of "
                                         f"the reference; {stats['passes_shared']} shared passes so far on this stream)") if args.api == "enqueue" else "1",
                    "parallelism": f"reads sharded x{world}, reference replicated, final table all-reduce via {reducer.how}"},
@@ -560,7 +562,15 @@ def main():
         cold_s = shard.max_over_ranks(float(np.median(cold)))
         cold_prof = S.profile() if not args.no_profile else None
         S.set_profiling(False)
-        if rank == 0 and cold_prof and cold_prof["scan"]["launches"] and "roofline" in out:
+        sd_static, sd_n = R.static_dense
+        if rank == 0 and "roofline" in out and sd_static and sd_n:
+            # (static dense dictionary: a pass's scan is queued beside its first batch's sketch -- the synchronised pushes of value_cold no
+            # longer show the kernel by itself; skx_stream_scan_alone does)
+            ms_alone = S.scan_alone(5)
+            ach = R.pass_bytes / (ms_alone * 1e-3) / 1e9
+            out["roofline"]["isolated"] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_alone,
+                                           "note": "scan kernel alone on the GPU (skx_stream_scan_alone: 5 launches back to back behind a synchronisation)"}
+        elif rank == 0 and cold_prof and cold_prof["scan"]["launches"] and "roofline" in out:
             # the same kernel with nothing beside it (these pushes are synchronised one by one): its own quality, whereas
             # the timed region's figure is stretched by the sketch of the next batch sharing the CUs on purpose
             ms_alone = cold_prof["scan"]["ms"] / cold_prof["scan"]["launches"]

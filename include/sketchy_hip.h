@@ -149,6 +149,14 @@ int skx_ref_rare_index(const skx_ref *ref, uint64_t *n_keys, uint64_t *n_rare_ke
  * the device memory of the records and the pattern matrix.  Exact either way; all zero: no bit rows / no patterns.
  */
 int skx_ref_patterns(const skx_ref *ref, uint64_t *n_long_lists, uint64_t *n_patterns, uint64_t *n_pattern_lists, uint64_t *bytes);
+/*
+ * The static dense dictionary: with the rare-hash index the scan is only ever asked for hashes held by more genomes than the index
+ * lists, and which hashes those are depends on the reference alone -- n_hashes of them (0 with *is_static set: every hash is rare,
+ * nothing is ever scanned for).  Their rows of the bit matrix are fixed, a pass needs no dictionary sort or windows for them, and its
+ * scan is queued with its first batch's sketch instead of behind its dictionary.  *is_static = 0: per-pass dictionaries (no index, too
+ * many dense hashes for the scan kernel's slices, or long lists without bit rows).
+ */
+int skx_ref_static_dense(const skx_ref *ref, int *is_static, uint64_t *n_hashes);
 /* bytes of reference hashes one scoring pass streams from HBM (8*stride*n_genomes) */
 int skx_ref_pass_bytes(const skx_ref *ref, uint64_t *bytes);
 void skx_ref_destroy(skx_ref *ref);
@@ -281,6 +289,13 @@ void skx_stream_destroy(skx_stream *st);
 int skx_stream_set_profiling(skx_stream *st, int enabled);
 /* ms[SKX_N_STAGES] accumulated milliseconds, launches[SKX_N_STAGES] timed intervals; resets the counters */
 int skx_stream_profile(skx_stream *st, double *ms, uint64_t *launches);
+/*
+ * The reference scan ALONE on the device: `reps` launches back to back behind a synchronisation, their average in milliseconds.
+ * (References with a static dense dictionary -- the hashes the scan can be asked for are a property of the reference; see
+ * skx_ref_static_dense -- have their scans queued beside the sketches of the batches they serve, so no other entry point times one
+ * by itself.)  SKX_ERR_INVALID for a stream that builds its scan's dictionary per pass.
+ */
+int skx_stream_scan_alone(skx_stream *st, uint32_t reps, double *ms_avg);
 
 /* ---- stand-alone operators (parity / `shared` subcommand) --------------------------- */
 /* sketch n_reads reads with (k, seed, s); outputs as in skx_stream_push (host arrays) */

@@ -33,6 +33,7 @@ SYMBOLS = [
     ("skx_ref_kmer_filter", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     ("skx_ref_rare_index", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     ("skx_ref_patterns", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    ("skx_ref_static_dense", _i, [_vp, C.POINTER(C.c_int), C.POINTER(_u64)]),
     ("skx_ref_create", _i, [_pp, _i, _u32, _u64, _u32, _u32, _u32, _vp, _vp]),
     ("skx_ref_create_multi", _i, [_pp, _i, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _vp]),
     ("skx_ref_sketch_size", _i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
@@ -62,6 +63,7 @@ SYMBOLS = [
     ("skx_stream_destroy", None, [_vp]),
     ("skx_stream_set_profiling", _i, [_vp, _i]),
     ("skx_stream_profile", _i, [_vp, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    ("skx_stream_scan_alone", _i, [_vp, C.c_uint32, C.POINTER(C.c_double)]),
     ("skx_sketch_reads", _i, [_i, _u32, _u64, _u32, _vp, _vp, _u32, _vp, _vp]),
     ("skx_common_hashes", _i, [_vp, _vp, _vp, _u32, _u32, _vp]),
     ("skx_comm_unique_id", _i, [_vp]),

@@ -122,6 +122,13 @@ class ReferenceSketch:
         return dict(zip(("long_lists", "patterns", "pattern_lists", "bytes"), [x.value for x in v]))
 
     @property
+    def static_dense(self):
+        """(is_static, n_hashes): does the reference have a static dense dictionary, and how many hashes the scan can be asked for"""
+        f, n = C.c_int(0), C.c_uint64(0)
+        _lib.check(_lib.load().skx_ref_static_dense(self._h, C.byref(f), C.byref(n)))
+        return bool(f.value), n.value
+
+    @property
     def pass_bytes(self) -> int:
         b = C.c_uint64(0)
         _lib.check(_lib.load().skx_ref_pass_bytes(self._h, C.byref(b)))
@@ -255,6 +262,12 @@ class SumOfSharedHashes:
         n = (C.c_uint64 * _lib.N_STAGES)()
         _lib.check(_lib.load().skx_stream_profile(self._h, ms, n))
         return {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.STAGE_NAMES)}
+
+    def scan_alone(self, reps=3) -> float:
+        """average milliseconds of `reps` reference scans with nothing beside them (streams on a reference with a static dense dictionary)"""
+        ms = C.c_double(0)
+        _lib.check(_lib.load().skx_stream_scan_alone(self._h, int(reps), C.byref(ms)))
+        return ms.value
 
     def allreduce(self, comm):
         _lib.check(_lib.load().skx_stream_allreduce(self._h, comm._h))

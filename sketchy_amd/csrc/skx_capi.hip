@@ -276,9 +276,18 @@ struct skx_ref {
     u64* d_pm = nullptr;
     u32 n_pat = 0;
     u64 n_pat_lists = 0;  // long lists stored as a pattern + at most 14 exceptions
+    // every rare hash's bits come from its list or bit row WITHOUT M (rare_to_mq): all long lists have a bit row, or there is no long list
+    bool rare_direct = false;
+    // the static dense dictionary (build_static_dense): the hashes the scan can be asked for are a property of the REFERENCE
+    u64* d_qs = nullptr;      // [n_sd] ascending
+    u32* d_nsd = nullptr;     // {n_sd, 0, n_sd rounded up to 64, n_sd}: what the kernels take as n_q / n_d of the static rows
+    u32* d_win_s = nullptr;   // [n_bands * n_tiles][2] its slice per (band, tile)
+    u32 n_sd = 0;
+    bool static_dense = false;
     skx::RareIndex rare_index() const {
         skx::RareIndex ri{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask, d_mlong, d_lid, d_lslot, n_pad / 64, d_mlongT, n_lw};
         ri.prec = d_prec; ri.pat_rep = d_pat_rep; ri.pm = d_pm; ri.d_npat = d_npat; ri.n_pat = n_pat;
+        if (static_dense) { ri.qs = d_qs; ri.n_sd = n_sd; }
         return ri;
     }
     skx::KmerFilter kmer_filter() const { return skx::KmerFilter{d_kf, kf_shift}; }
@@ -294,6 +303,7 @@ static void ref_free(skx_ref* r) {
     (void)hipFree(r->d_kt_key); (void)hipFree(r->d_kt_cnt); (void)hipFree(r->d_kt_off); (void)hipFree(r->d_post);
     (void)hipFree(r->d_mlong); (void)hipFree(r->d_mlongT); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot);
     (void)hipFree(r->d_prec); (void)hipFree(r->d_pat_rep); (void)hipFree(r->d_npat); (void)hipFree(r->d_pm);
+    (void)hipFree(r->d_qs); (void)hipFree(r->d_nsd); (void)hipFree(r->d_win_s);
     delete r;
 }
 
@@ -378,6 +388,64 @@ static void build_patterns(skx_ref* r) {
     } catch (const std::bad_alloc&) { ok = false; }
     (void)hipFree(d_sig); (void)hipFree(d_content); (void)hipFree(d_pat_of); (void)hipFree(d_done);
     if (!ok) drop();
+}
+
+// The static dense dictionary.  With the rare-hash index a pass asks the scan only for hashes held by more genomes than the index
+// lists -- and WHICH hashes those are is a property of the reference (C2: 10 140 of 893 260 keys).  So the scan's dictionary, its
+// slice per (band, tile) and the rows of the bit matrix they get are built here, once: a pass maps its dense query hashes onto
+// those fixed rows (launch_classify), needs no sorted dictionary, windows or row compaction for them, and -- the point -- its scan
+// no longer depends on the batch at all: it is queued when the pass's first batch is (batch_front), beside the sketches.  A lone
+// batch used to run sketch -> dictionary -> scan -> ranking strictly one after the other.  The scan still streams 8 x s x N bytes
+// per pass.  Needs: the index; every rare row's bits obtainable without M (rare_direct); few enough dense hashes for the lean scan
+// kernel's slices.  Else the reference keeps per-pass dictionaries, as in rounds 1-5.
+static void build_static_dense(skx_ref* r, const std::vector<u64>& exc_h) {
+    static const int sd_env = skx::knob("SKX_STATIC_DENSE") ? atoi(skx::knob("SKX_STATIC_DENSE")) : 1;  // experiment knob: 0 = per-pass dictionaries
+    if (!sd_env || !r->d_kt_key || !r->rare_direct) return;
+    const u64 slots = (u64)r->kt_mask + 1;
+    // (the lean kernel's one-pass probe takes slices of 254 entries; a (band, tile) slice holds ~3.1 x rows per band x |Q| / s of them.
+    // Beyond ~190 entries per band's worth the host would pick the split / big-table variants: such references keep per-pass dictionaries)
+    const u64 cap = std::min<u64>(65536, (u64)191 * r->s / std::max<u32>(r->rb, 1u));
+    u64* d_keys = nullptr;
+    u32* d_n = nullptr;
+    bool ok = cap >= 1 && hipMalloc(&d_keys, (cap + 1) * 8) == hipSuccess && hipMalloc(&d_n, 4) == hipSuccess && hipMemset(d_n, 0, 4) == hipSuccess;
+    u32 n = 0;
+    if (ok) {
+        skx::launch_collect_dense(nullptr, r->d_kt_key, r->d_kt_off, slots, d_keys, d_n, (u32)cap);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    std::vector<u64> qs;
+    if (ok) {
+        std::vector<u64> ex(exc_h);  // the lifted hashes ride with the dense rows (exceptions_kernel sets their bits)
+        std::sort(ex.begin(), ex.end());
+        ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
+        ok = (u64)n + ex.size() <= cap;
+        if (ok) {
+            qs.resize(n);
+            ok = n == 0 || hipMemcpy(qs.data(), d_keys, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess;
+            qs.insert(qs.end(), ex.begin(), ex.end());
+            std::sort(qs.begin(), qs.end());
+        }
+    }
+    (void)hipFree(d_keys); (void)hipFree(d_n);
+    if (!ok) { (void)hipGetLastError(); return; }
+    const u32 n_sd = (u32)qs.size(), n_bt = r->n_bands * r->n_tiles;
+    const u32 words[4] = {n_sd, 0u, (n_sd + 63u) & ~63u, n_sd};
+    ok = hipMalloc(&r->d_qs, std::max<size_t>(n_sd, 1) * 8) == hipSuccess && hipMalloc(&r->d_nsd, 16) == hipSuccess &&
+         hipMalloc(&r->d_win_s, (size_t)n_bt * 8) == hipSuccess &&
+         (n_sd == 0 || hipMemcpy(r->d_qs, qs.data(), (size_t)n_sd * 8, hipMemcpyHostToDevice) == hipSuccess) &&
+         hipMemcpy(r->d_nsd, words, 16, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        skx::launch_window(nullptr, r->d_lo, r->d_hi, n_bt, r->d_qs, r->d_nsd, r->d_win_s, nullptr);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipFree(r->d_qs); (void)hipFree(r->d_nsd); (void)hipFree(r->d_win_s);
+        r->d_qs = nullptr; r->d_nsd = r->d_win_s = nullptr;
+        (void)hipGetLastError();
+        return;
+    }
+    r->n_sd = n_sd;
+    r->static_dense = true;
 }
 
 SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s_read, uint32_t stride,
@@ -584,9 +652,9 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
             if (ok && r->d_kt_key) try {
                 std::vector<u32> cnt(slots), off(slots);
                 ok = hipMemcpy(cnt.data(), r->d_kt_cnt, slots * 4, hipMemcpyDeviceToHost) == hipSuccess;
-                u64 total = 0, keys = 0, rare = 0;
+                u64 total = 0, keys = 0, rare = 0, long_keys = 0;
                 for (u64 i = 0; ok && i < slots; ++i) {
-                    if (cnt[i] && cnt[i] <= rare_max) { off[i] = (u32)total; total += cnt[i]; ++rare; }
+                    if (cnt[i] && cnt[i] <= rare_max) { off[i] = (u32)total; total += cnt[i]; ++rare; long_keys += cnt[i] > 8u ? 1 : 0; }
                     else off[i] = 0xFFFFFFFFu;
                     keys += cnt[i] ? 1 : 0;
                 }
@@ -634,16 +702,19 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                     else if (!lok) { (void)hipFree(r->d_mlong); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot); r->d_mlong = nullptr; r->d_lid = r->d_lslot = nullptr; r->n_long = 0; (void)hipGetLastError(); }
                     if (lok) build_patterns(r);
                 }
+                r->rare_direct = ok && (r->d_mlong != nullptr || long_keys == 0);
             } catch (const std::bad_alloc&) {
                 // (the host-side offsets of a very large key table did not fit the host's memory: no index, every hash goes to the scan)
                 (void)hipFree(r->d_mlong); (void)hipFree(r->d_mlongT); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot);
                 r->d_mlong = r->d_mlongT = nullptr; r->d_lid = r->d_lslot = nullptr; r->n_long = 0; r->n_lw = 0;
                 (void)hipFree(r->d_prec); (void)hipFree(r->d_pat_rep); (void)hipFree(r->d_npat); (void)hipFree(r->d_pm);
                 r->d_prec = r->d_pat_rep = r->d_npat = nullptr; r->d_pm = nullptr; r->n_pat = 0; r->n_pat_lists = 0;
+                r->rare_direct = false;
                 ok = false;
             }
             (void)hipFree(d_over); (void)hipFree(d_cursor);
-            if (!ok) drop();
+            if (!ok) { drop(); r->rare_direct = false; }
+            else build_static_dense(r, exc_h);
         }
     }
     const u32 pf_mode = skx::knob("SKX_KMER_PREFILTER") ? (u32)atoi(skx::knob("SKX_KMER_PREFILTER")) : g_kmer_prefilter.load();  // (experiment knob overrides the policy)
@@ -738,6 +809,12 @@ SKX_API int skx_ref_patterns(const skx_ref* ref, uint64_t* n_long_lists, uint64_
     if (n_patterns) *n_patterns = ref->d_prec ? ref->n_pat : 0;
     if (n_pattern_lists) *n_pattern_lists = ref->d_prec ? ref->n_pat_lists : 0;
     if (bytes) *bytes = ref->d_prec ? ref->n_long * skx::pat_record_words() * 4 + (u64)((ref->n_pat + 63) / 64) * ref->n_pad * 8 + (u64)ref->n_pat * 4 : 0;
+    return SKX_OK;
+}
+SKX_API int skx_ref_static_dense(const skx_ref* ref, int* is_static, uint64_t* n_hashes) {
+    if (!ref) return fail(SKX_ERR_INVALID, "NULL argument");
+    if (is_static) *is_static = ref->static_dense ? 1 : 0;
+    if (n_hashes) *n_hashes = ref->static_dense ? ref->n_sd : 0;
     return SKX_OK;
 }
 SKX_API int skx_ref_pass_bytes(const skx_ref* ref, uint64_t* bytes) {
@@ -900,7 +977,12 @@ struct skx_stream {
     u64* d_pcw = nullptr;                        // [kPassBatchesMax][n_pat][n_grp_c * 8] the patterns at every batch's candidates
     u32 npat_pad = 0;
     skx::PatRows pat_rows() const { return skx::PatRows{d_hist, npat_pad, d_gain_l, d_nprow}; }
-    skx::RareIndex rare_index() const { skx::RareIndex ri = ref->rare_index(); if (!use_pat) { ri.prec = nullptr; ri.n_pat = 0; } return ri; }
+    skx::RareIndex rare_index() const {
+        skx::RareIndex ri = ref->rare_index();
+        if (!use_pat) { ri.prec = nullptr; ri.n_pat = 0; }
+        if (!static_dense) { ri.qs = nullptr; ri.n_sd = 0; }
+        return ri;
+    }
     u32 *d_cbad = nullptr, *d_nqc = nullptr;  // [kPassBatchesMax] why a batch cannot rank compactly / mapped rare rows
     u32 *d_spc_g0 = nullptr, *d_spc_grp = nullptr;  // Species layout of the compact problems: kCandCap slots per species
     u32 n_pad_c = 0, n_grp_c = 0, cand_seq = 0;
@@ -969,6 +1051,15 @@ struct skx_stream {
     u32 *d_nq[2] = {nullptr, nullptr}, *d_win[2] = {nullptr, nullptr};
     u32 *d_pair_r[3] = {nullptr, nullptr, nullptr}, *d_pair_q[2] = {nullptr, nullptr}, *d_poff_pass[3] = {nullptr, nullptr, nullptr};
     u64 *d_m = nullptr, *d_mint = nullptr, *d_mq[2] = {nullptr, nullptr};
+    // static dense dictionary (skx_ref::static_dense; build_static_dense): M holds the reference's static dense rows only -- two copies,
+    // one per buffer set --, and the scan that fills set b's is queued as soon as the pass that will use set b is known to come
+    // (queue_static_scan: when its first batch is sketched), not behind that pass's dictionary
+    bool static_dense = false;
+    u64* d_ms[2] = {nullptr, nullptr};
+    bool m_ready[2] = {false, false};  // a scan into d_ms[b] is queued (or done) and nobody has consumed it yet
+    u32* d_mdirty_s = nullptr;         // (a word for the early scan's "M was written" flag: nobody reads it)
+    u32 sd64 = 0;                      // static dense rows, rounded up to 64: the rare rows of a pass start there
+    u32 qhash_cap() const { return qcap - sd64; }  // distinct query hashes a pass's matrices hold beside the static rows
     // RANKING LANES (round 4).  The ranking of a batch is a chain of nine short, latency-bound kernels (counts, three prefix /
     // leader kernels, per-read arg-max, merge): alone it takes ~0.37 ms and leaves most of the chip idle, and the chains of
     // consecutive batches depend on each other through ONE thing only -- the table a batch starts from, which the previous
@@ -1095,7 +1186,7 @@ static void stream_free(skx_stream* st) {
                     st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
                     st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1],
                     st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_nd_hs,
-                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_lrow, st->d_nlrow, st->d_gain_l, st->d_cbase, st->d_cwl, st->d_ncwl, st->d_cw, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp, st->d_inb, st->d_hit, st->d_hist, st->d_nprow, st->d_pcw};
+                    st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_lrow, st->d_nlrow, st->d_gain_l, st->d_cbase, st->d_cwl, st->d_ncwl, st->d_cw, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp, st->d_inb, st->d_hit, st->d_hist, st->d_nprow, st->d_pcw, st->d_ms[0], st->d_ms[1], st->d_mdirty_s};
     for (auto& q : st->ps) {
         for (void* x : {(void*)q.tab, (void*)q.cand, (void*)q.tabc, (void*)q.ncand, (void*)q.mode, (void*)q.any_full, (void*)q.nqc_total, (void*)q.mc, (void*)q.mqc,
                         (void*)q.rowany_c, (void*)q.grp_any_c, (void*)q.smap, (void*)q.pair_qc, (void*)q.nd}) (void)hipFree(x);
@@ -1452,8 +1543,21 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         SCHK(hipMalloc(&st->d_win[i], (size_t)n_bt * 8));
     }
     // (rows: qcap + 128 -- the rows behind the dense ones start on a word boundary, a pass of qcap hashes can reach 63 rows further)
-    SCHK(hipMalloc(&st->d_m, (size_t)(st->qcap / 64 + 2) * n_pad * 8));
-    SCHK(hipMemset(st->d_m, 0, (size_t)(st->qcap / 64 + 2) * n_pad * 8));      // kept all-zero between passes
+    {
+        const u32 sd64 = (ref->n_sd + 63u) & ~63u;
+        st->static_dense = ref->static_dense && (u64)2 * sd64 + 128 <= st->qcap;
+        if (st->static_dense) {
+            st->sd64 = sd64;
+            for (int i = 0; i < 2; ++i) {
+                SCHK(hipMalloc(&st->d_ms[i], (size_t)(sd64 / 64 + 2) * n_pad * 8));
+                SCHK(hipMemset(st->d_ms[i], 0, (size_t)(sd64 / 64 + 2) * n_pad * 8));  // all-zero until a scan fills it; the pass that consumes it zeroes it again
+            }
+            SCHK(hipMalloc(&st->d_mdirty_s, 64));
+        } else {
+            SCHK(hipMalloc(&st->d_m, (size_t)(st->qcap / 64 + 2) * n_pad * 8));
+            SCHK(hipMemset(st->d_m, 0, (size_t)(st->qcap / 64 + 2) * n_pad * 8));      // kept all-zero between passes
+        }
+    }
     // (d_mint, the second word array of the split scan variant, is allocated by the first pass that wants it)
     for (int i = 0; i < 2; ++i)
         SCHK(hipMalloc(&st->d_mq[i], ((size_t)st->qcap + 128) * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
@@ -1633,6 +1737,7 @@ SKX_API void skx_stream_destroy(skx_stream* st) { stream_free(st); }
 
 // ---- profiling spans
 static int flush_pending(skx_stream* st);
+SKX_API int skx_stream_sync(skx_stream* st);
 static hipEvent_t get_event(skx_stream* st) {
     if (!st->ev_pool.empty()) { hipEvent_t ev = st->ev_pool.back(); st->ev_pool.pop_back(); return ev; }
     hipEvent_t ev = nullptr;
@@ -1720,8 +1825,9 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     for (int i = 1; i < st->n_lanes; ++i) if (st->lane[i].s) HIPCHK(hipStreamSynchronize(st->lane[i].s));
     size_t mem_free = 0, mem_total = 0;
     HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
-    const u64 per_row = (u64)n_pad / 8 * (st->d_mint ? 2 : 1) + 2 * mq_words * 8 + 2 * (u64)(n_pad / (skx::kRankWords * 64)) / 8 + 1 +
+    const u64 per_row = (st->static_dense ? 0 : (u64)n_pad / 8 * (st->d_mint ? 2 : 1)) + 2 * mq_words * 8 + 2 * (u64)(n_pad / (skx::kRankWords * 64)) / 8 + 1 +
                         5ull * skx::kPassBatchesMax * 4;  // (+ the per-batch row counters, the two rare-row maps, the long-row lists)
+    want_rows += st->sd64;  // (the caller counts distinct query hashes: the static dense rows come on top)
     u64 rows = std::min<u64>(want_rows, (u64)(mem_free / 4) / per_row);  // (a quarter of what is free: the one array family a dense stream cannot do without)
     rows = std::min<u64>(rows, st->pcap) / 64 * 64;
     if (rows <= st->qcap) return SKX_OK;  // no room (or nothing to gain): the batch is cut into passes as before
@@ -1729,7 +1835,7 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     u32 *wb[2] = {nullptr, nullptr}, *cnt = nullptr, *sm[2] = {nullptr, nullptr};
     uint2* lrow = nullptr;
     auto undo = [&]() { for (void* q : {(void*)m, (void*)mint, (void*)mq[0], (void*)mq[1], (void*)ra[0], (void*)ra[1], (void*)wb[0], (void*)wb[1], (void*)cnt, (void*)sm[0], (void*)sm[1], (void*)lrow}) if (q) (void)hipFree(q); (void)hipGetLastError(); };
-    hipError_t e = hipMalloc(&m, (size_t)(rows / 64 + 2) * n_pad * 8);
+    hipError_t e = st->static_dense ? hipSuccess : hipMalloc(&m, (size_t)(rows / 64 + 2) * n_pad * 8);  // (static dense rows: M does not grow)
     if (e == hipSuccess && st->d_mint) e = hipMalloc(&mint, (size_t)(rows / 64 + 2) * n_pad * 8);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&mq[i], ((size_t)rows + 128) * mq_words * 8);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&ra[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (rows / 64 + 2) * 8);
@@ -1737,11 +1843,11 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     if (e == hipSuccess) e = hipMalloc(&cnt, (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 4);
     if (e == hipSuccess && st->d_lrow) e = hipMalloc(&lrow, (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 8);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&sm[i], (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 4);
-    if (e == hipSuccess) e = hipMemset(m, 0, (size_t)(rows / 64 + 2) * n_pad * 8);  // (M is all-zero between passes)
+    if (e == hipSuccess && m) e = hipMemset(m, 0, (size_t)(rows / 64 + 2) * n_pad * 8);  // (M is all-zero between passes)
     if (e == hipSuccess && mint) e = hipMemset(mint, 0, (size_t)(rows / 64 + 2) * n_pad * 8);
     if (e == hipSuccess) e = hipDeviceSynchronize();  // (the zero-fills ran on the null stream)
     if (e != hipSuccess) { undo(); return SKX_OK; }   // (no memory for it: as before)
-    (void)hipFree(st->d_m); st->d_m = m;
+    if (m) { (void)hipFree(st->d_m); st->d_m = m; }
     if (mint) { (void)hipFree(st->d_mint); st->d_mint = mint; }
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(st->d_mq[i]); st->d_mq[i] = mq[i];
@@ -1756,6 +1862,29 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     return SKX_OK;
 }
 
+// The scan of the reference for the pass that will use buffer set b (static dense dictionary only): M_s[b] = membership of the static
+// dense hashes.  Independent of every batch, so it is queued as early as the pass is known to come -- batch_front, when the pass's
+// first batch is sketched: an HBM-bound kernel beside the VALU-bound sketches -- or, failing that, by the pass itself.  M_s[b] is
+// all-zero here: zeroed at creation, and whoever consumed it last (transpose / m_clear of the pass two back, queued on this stream
+// before) zeroed what it read.
+static int queue_static_scan(skx_stream* st, int b) {
+    if (!st->static_dense || st->m_ready[b]) return SKX_OK;
+    const skx_ref* ref = st->ref;
+    st->m_ready[b] = true;
+    if (ref->n_sd == 0) return SKX_OK;  // (every hash of the reference is rare: nothing to scan for)
+    {
+        Span sp(st, 2, st->hs);
+        skx::launch_scan(st->hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, ref->d_qs, ref->d_win_s, st->d_ms[b], nullptr, ref->n_pad,
+                         false, true, nullptr, st->d_mdirty_s, true, 0u, false);
+    }
+    {
+        Span sp(st, 1, st->hs);
+        skx::launch_exceptions(st->hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, ref->d_qs, ref->d_nsd, st->d_ms[b], ref->n_pad, st->d_mdirty_s, nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    return SKX_OK;
+}
+
 static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_table, bool inserted, u32 q_rows) {
     const skx_ref* ref = st->ref;
     hipStream_t hs0 = st->hs0, hs = st->hs;
@@ -1767,10 +1896,11 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     if (!inserted && n_sub != 1) return fail(SKX_ERR_HIP, "internal: a shared pass needs its pairs gathered by the front halves");
     const u32 n_bt = ref->n_bands * ref->n_tiles;
     const u32 q_bound = std::min(P, q_rows);
-    if (q_bound > st->qcap) return fail(SKX_ERR_HIP, "internal: pass of %u query rows exceeds the matrices' %u", q_bound, st->qcap);
+    if (q_bound > st->qhash_cap()) return fail(SKX_ERR_HIP, "internal: pass of %u query rows exceeds the matrices' %u", q_bound, st->qhash_cap());
     // rows per group of the group-major bit matrix of this pass (the rows behind the dense ones start on a word boundary: up to 63 more
     // than the dictionary has hashes)
-    const u32 nq_rows = ((q_bound + 63) / 64) * 64 + 64;
+    const bool sdm = st->static_dense;  // the dense rows are the reference's static ones: rows [0, sd64), the pass's rare rows behind
+    const u32 nq_rows = st->sd64 + ((q_bound + 63) / 64) * 64 + 64;
     // the ranking of earlier passes whose candidates have been published by now; the pass TWO back (it used this pass's buffer set)
     // must be through -- the one before this may still be waiting for its scan
     // (the pass ONE back is queued BEHIND this pass's front half, further down: its eight chains are a hundred launches, 0.3-0.4 ms of
@@ -1784,6 +1914,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     u32 *d_pair_r = st->d_pair_r[slot], *d_pair_q = st->d_pair_q[b], *d_poff = st->d_poff_pass[slot];
     u32 *d_nq = st->d_nq[b], *d_win = st->d_win[b];
     u64 *d_mq = st->d_mq[b], *d_q = st->d_q[b];
+    u64* const d_m = sdm ? st->d_ms[b] : st->d_m;  // the pass's M: the static rows' (filled by queue_static_scan), or all of its dictionary's
     u32* d_grp_any = st->d_grp_any[b];
     skx_stream::PassSet& ps = st->ps[b];
     u32* const d_nd = st->d_nd_hs;  // (scan-stream scratch; ps.nd, the copy the chains read, is written in wait_back)
@@ -1830,6 +1961,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // further down, right before those are overwritten.
     (void)hs0;
     SKX_MARK("pass: begin, subs", n_sub);
+    if (sdm && P > 0) SKXCHK(queue_static_scan(st, b));  // (normally queued long since: batch_front of the pass's first batch)
     for (int i = 0; i < n_sub; ++i) HIPCHK(hipStreamWaitEvent(hs, st->ev_sketch[subs[i].side], 0));  // the batches' sketches and pair offsets
     st->front_pending[b] = false;  // (this stream recorded it)
     // (inserted: the sketch stream also copied the pass's pair offsets -- this stream then never touches the sketch buffers,
@@ -1856,7 +1988,9 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         } else {
             skx::launch_nd_from_nq(hs, d_nq, d_nd, st->h_nd + 2 * b);
         }
-        if (st->d_hbuf && !into_m) {  // (round 3's slab form only: windows + word -> bands in one launch; also hands |Q| to the host)
+        if (sdm) {
+            // (the scan's dictionary and its windows are the reference's)
+        } else if (st->d_hbuf && !into_m) {  // (round 3's slab form only: windows + word -> bands in one launch; also hands |Q| to the host)
             skx::launch_word_bands(hs, d_win, ref->n_tiles, ref->n_bands, scan_nq, st->d_wb[b], ref->d_lo, ref->d_hi, scan_q, split_dict ? nullptr : &st->h_nq[b]);
         } else {
             skx::launch_window(hs, ref->d_lo, ref->d_hi, n_bt, scan_q, scan_nq, d_win, split_dict ? nullptr : &st->h_nq[b]);
@@ -1873,14 +2007,14 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
 
     // the very first pass of a stream has no hint: wait for its dictionary once rather than run the heaviest variant
     // (split dictionaries: until a pass has told which share of the hashes is dense, every pass is worth that wait once)
-    if ((!st->have_hint && !nq_known && P > 0) || (split_dict && !st->have_split_hint && P > 0)) {
+    if (!sdm && ((!st->have_hint && !nq_known && P > 0) || (split_dict && !st->have_split_hint && P > 0))) {
         HIPCHK(hipStreamSynchronize(hs));
         take_hint(b, P);
         st->have_split_hint = true;
         if (!nq_known) nq_est = std::max<u64>(1, hint_nq(b));
     }
     // what the SCAN looks for: the dense part of the dictionary
-    const u64 nd_est = split_dict ? std::max<u64>(1, (u64)((double)nq_est * st->nd_frac * 1.1) + 64) : nq_est;
+    const u64 nd_est = sdm ? std::max<u32>(1u, ref->n_sd) : split_dict ? std::max<u64>(1, (u64)((double)nq_est * st->nd_frac * 1.1) + 64) : nq_est;
 
     // ---- scan + transpose (same stream, HBM-bound)
     const u32 n_grp_all = n_pad / (skx::kRankWords * 64);
@@ -1972,7 +2106,10 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     };
     const u32 n_words = nq_rows / 64;
     bool split = false, lean_used = false;
-    if (P > 0) {
+    if (P > 0 && sdm) {
+        st->total_passes += 1; st->lean_passes += 1;
+        SKXCHK(wait_back());  // (the scan was queued with the pass's first batch, or at the top of this function)
+    } else if (P > 0) {
         // many query words per band (dense batches): most flushed words are interior -> split arrays pay off
         static const int split_env = skx::knob("SKX_SCAN_SPLIT") ? atoi(skx::knob("SKX_SCAN_SPLIT")) : -1;
         split = split_env >= 0 ? split_env != 0 : (nd_est * ref->rb / ref->s >= 192);
@@ -2005,14 +2142,14 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             Span sp(st, 2, hs);
             // sparse dictionaries: the lean kernel with its single-owner slabs; dense ones: scan_kernel's variants into M
             // d_m / d_mint are all zero here: zeroed at creation, and the transpose of every pass zeroes what it read
-            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, scan_q, d_win, st->d_m,
+            skx::launch_scan(hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, scan_q, d_win, d_m,
                              split ? st->d_mint : nullptr, n_pad, big, lean && !run_scan, (lean && !run_scan) ? st->d_hbuf : nullptr, d_mdirty, into_m,
                              run_scan ? scan_run : 0u, big_slices);
         }
         {
             Span sp(st, 1, hs);
             // (after the scan: its persistent form writes complete words with plain stores, these OR single bits in)
-            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, st->d_m, n_pad, d_mdirty, split_dict ? st->d_qrow : nullptr);
+            skx::launch_exceptions(hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, d_q, d_nq, d_m, n_pad, d_mdirty, split_dict ? st->d_qrow : nullptr);
         }
         SKXCHK(wait_back());
     }
@@ -2029,7 +2166,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         HIPCHK(hipMemsetAsync(st->d_gain, 0, (size_t)n_sub * n_pad * 4, hs));
         if (P > 0) {
             SKXCHK(row_counts());
-            skx::launch_gain_dense(hs, st->d_m, m_int, n_pad, d_nd, q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain);
+            skx::launch_gain_dense(hs, d_m, m_int, n_pad, d_nd, sdm ? ref->n_sd : q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain);
             if (split_dict) SKXCHK(rare_gains(hs));
         }
         skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (split_dict && P > 0) ? st->d_gain_s : nullptr,
@@ -2087,7 +2224,7 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         skx::launch_cand_publish(hs, st->d_cbad, force_full, ps.ncand, st->d_nqc, d_nd, (u32)n_sub, n_sp, rows_c, ps.mode, ps.any_full,
                                  ps.nqc_total, ps.h_pub, seq);
         if (ranked && P > 0 && !all_forced)
-            skx::launch_cand_gather_m(hs, st->d_m, m_int, n_pad, d_nd, q_bound, ps.cand, st->n_pad_c, st->d_cbad, (u32)n_sub, ps.mc, rows_c / 64);
+            skx::launch_cand_gather_m(hs, d_m, m_int, n_pad, d_nd, sdm ? ref->n_sd : q_bound, ps.cand, st->n_pad_c, st->d_cbad, (u32)n_sub, ps.mc, rows_c / 64);
         only_if = ps.any_full;
         HIPCHK(hipGetLastError());
     }
@@ -2096,19 +2233,20 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         // more than eight genomes they go straight into the group-major matrix (rare_to_mq_kernel) and M -- hence the transpose --
         // holds the dense rows only; without (no room for the bit rows): bits from the genome lists into M, as the scan's.
         static const int direct_env = skx::knob("SKX_RARE_DIRECT") ? atoi(skx::knob("SKX_RARE_DIRECT")) : 1;  // experiment knob: 0 = through M
-        const bool direct_rare = split_dict && ref->d_mlong != nullptr && direct_env != 0;
+        const bool direct_rare = split_dict && ref->rare_direct && (direct_env != 0 || sdm);
         if (split_dict && !direct_rare) {
             Span sp(st, 1, hs);
-            skx::launch_sparse_fill(hs, st->d_sslot, d_nd, st->rare_index(), st->d_m, n_pad, d_mdirty, q_bound, only_if);
+            skx::launch_sparse_fill(hs, st->d_sslot, d_nd, st->rare_index(), d_m, n_pad, d_mdirty, q_bound, only_if);
         }
         {
             Span sp(st, 3, hs);
-            skx::launch_transpose_bits(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, direct_rare ? d_nd + 2 : d_nd + 3, d_grp_any,
+            skx::launch_transpose_bits(hs, d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, direct_rare ? d_nd + 2 : d_nd + 3, d_grp_any,
                                        nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, direct_rare ? nd_est : nq_est, st->d_rowany[b], only_if);
             if (direct_rare)
                 skx::launch_rare_to_mq(hs, st->d_sslot, d_nd, st->rare_index(), d_mq, nq_rows, n_pad, st->d_rowany[b], d_grp_any, q_bound, only_if);
-            if (only_if) skx::launch_m_clear(hs, st->d_m, split ? st->d_mint : nullptr, n_pad, d_nd, only_if);
+            if (only_if) skx::launch_m_clear(hs, d_m, split ? st->d_mint : nullptr, n_pad, d_nd, only_if);
         }
+        if (sdm) st->m_ready[b] = false;  // (consumed: transposed -- which zeroes what it reads -- or cleared)
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(st->ev_front[b], hs));
@@ -2400,7 +2538,7 @@ static int run_pass(skx_stream* st, u32 ra, u32 rb, u32 p_base, u32 P, u32* d_to
 template <class F>
 static int for_each_pass(skx_stream* st, u32 n_reads, u32 max_pass_reads, F fn) {
     const u32 cap = std::max<u32>(1u, std::min<u32>(st->rpass, max_pass_reads));
-    const u32 pair_cap = std::min(st->pcap, st->qcap);
+    const u32 pair_cap = std::min(st->pcap, st->qhash_cap());
     u32 ra = 0;
     while (ra < n_reads) {
         u32 rb = ra;
@@ -2575,7 +2713,7 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         u64 reads = pb.n_reads;
         for (int i = 0; i < st->n_pend; ++i) reads += st->pend[i].n_reads;
         // (distinct hashes: what the matrices can GROW to counts -- batch_back_group makes the room when the group closes)
-        joins = reads * st->ppr_est * 1.25 <= (double)st->pcap && reads * st->qpr_est * 1.25 <= (double)std::max(st->qcap, st->qcap_max);
+        joins = reads * st->ppr_est * 1.25 <= (double)st->pcap && reads * st->qpr_est * 1.25 <= (double)(std::max(st->qcap, st->qcap_max) - st->sd64);
     }
     for (int i = 0; joins && i < st->n_pend; ++i) {
         const PendingBatch& q = st->pend[i];
@@ -2590,6 +2728,14 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         pb.gi = 0;
         pb.spec_set = st->buf ^ (st->n_pend ? 1 : 0);
         pb.spec_slot = (st->pslot + (st->n_pend ? 1 : 0)) % 3;
+    }
+    // static dense dictionary: the scan of the pass this batch opens depends on no batch -- queue it NOW, ahead of the sketch: the
+    // HBM-bound scan then runs beside the VALU-bound sketches of its own group (a lone batch: beside its own sketch) instead of behind
+    // their dictionary
+    bool early_scan = false;
+    if (st->static_dense && pb.gi == 0 && ref->n_sd && !st->m_ready[pb.spec_set]) {
+        SKXCHK(queue_static_scan(st, pb.spec_set));
+        early_scan = true;
     }
     if (st->chk_dirty[pb.side]) {  // the batch that last used this set failed between arming and publishing: nothing re-armed its counters
         HIPCHK(hipMemsetAsync(st->d_chk, 0, (size_t)skx::chk_words() * 4, hs));  // (the whole block: the pool's bump counters sit behind word 16)
@@ -2627,6 +2773,9 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
         const bool opens_behind_a_group = st->n_pend && !joins;
         if (st->n_pend && (!room_lazy_env || opens_behind_a_group || pass_in_flight)) leave_room = ranking_light ? 1 : 2;
         else if (scan_in_flight) leave_room = 1;
+        // (experiment knob SKX_EARLY_ROOM: the pad of a sketch whose pass's scan was queued just ahead of it; default 1 = the smaller pad)
+        static const int early_room_env = skx::knob("SKX_EARLY_ROOM") ? atoi(skx::knob("SKX_EARLY_ROOM")) : 1;
+        if (early_scan && leave_room < early_room_env) leave_room = early_room_env;
     }
     {
         SKX_T0();
@@ -2736,13 +2885,13 @@ static int batch_back(skx_stream* st, PendingBatch& pb, PendingBatch* younger) {
     // speculative gather ran (it counts its new keys; it did nothing when the pairs exceed a pass), else bounded by the pairs
     const u32 spec_keys = pb.spec_insert ? st->h_chk[10] : 0xFFFFFFFFu;
     const u32 q_rows = spec_keys != 0xFFFFFFFFu ? spec_keys : total_pairs;
-    if (spec_keys != 0xFFFFFFFFu && q_rows > st->qcap && total_pairs <= st->pcap) {
+    if (spec_keys != 0xFFFFFFFFu && q_rows > st->qhash_cap() && total_pairs <= st->pcap) {
         // more distinct hashes than the pass's matrices have rows: make room for a group of such batches (see grow_query_rows)
         // (enqueued batches share passes: room for a group of them; a stream that is pushed to needs one batch's worth)
         const u64 per_batch = (u64)q_rows + q_rows / 4;
         SKXCHK(grow_query_rows(st, pb.pairable ? std::max<u64>(per_batch, per_batch * std::min<u32>(st->coalesce, 8u) * 3 / 4) : per_batch));
     }
-    const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap && q_rows <= st->qcap;
+    const bool single = n_reads <= std::min(st->rpass, pb.dbg_cap) && total_pairs <= st->pcap && q_rows <= st->qhash_cap();
 #ifdef SKX_EXPERIMENTS
     if (skx::knob("SKX_DEBUG_PASS"))
         fprintf(stderr, "[skx pass] reads %u rpass %u dbg_cap %u pairs %u pcap %u spec_insert %d spec_keys %u q_rows %u qcap %u single %d gi %d\n",
@@ -2829,10 +2978,10 @@ static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch
     }
     const u32 q_rows = (st->h_chk_base + 16 * g[n - 1].side)[10];  // (the last summary counts the keys of the joint set)
     const bool clean = fits;
-    if (clean && q_rows != 0xFFFFFFFFu && q_rows > st->qcap && pairs <= st->pcap)
+    if (clean && q_rows != 0xFFFFFFFFu && q_rows > st->qhash_cap() && pairs <= st->pcap)
         // (the joint set of the group, scaled to a full group when this one was smaller: see grow_query_rows)
         SKXCHK(grow_query_rows(st, ((u64)q_rows + q_rows / 4) * std::max<u32>(1u, (st->coalesce + (u32)n - 1) / (u32)n)));
-    fits = fits && pairs <= st->pcap && q_rows != 0xFFFFFFFFu && q_rows <= st->qcap;
+    fits = fits && pairs <= st->pcap && q_rows != 0xFFFFFFFFu && q_rows <= st->qhash_cap();
     u64 reads = 0;
     for (int i = 0; i < n; ++i) reads += g[i].n_reads;
     if (clean && q_rows != 0xFFFFFFFFu && reads) {
@@ -2843,7 +2992,7 @@ static int batch_back_group(skx_stream* st, PendingBatch* g, int n, PendingBatch
     if (clean && !fits) {  // too much for one pass: smaller groups from here on
         u64 acc = 0;
         int m = 0;
-        while (m < n && acc + P[m] <= st->pcap / 10 * 9 && (double)(acc + P[m]) / std::max<u64>(pairs, 1) * q_rows <= st->qcap / 10 * 9) acc += P[m++];
+        while (m < n && acc + P[m] <= st->pcap / 10 * 9 && (double)(acc + P[m]) / std::max<u64>(pairs, 1) * q_rows <= st->qhash_cap() / 10 * 9) acc += P[m++];
         st->group_cap = (u32)std::max(1, std::min(m, n - 1));
         st->clean_groups = 0;
     } else if (fits && ++st->clean_groups >= 64 && st->group_cap < st->coalesce) {
@@ -3288,6 +3437,35 @@ SKX_API uint64_t skx_pack_line(const uint8_t* ascii, uint64_t n, uint8_t* packed
 SKX_API uint64_t skx_pack_bases(const uint8_t*, uint64_t, uint8_t*, uint64_t);
 SKX_API uint64_t skx_pack_line(const uint8_t*, uint64_t, uint8_t*, uint64_t, uint64_t*);
 #endif
+// the reference scan ALONE on the device (profiling aid: with the static dense dictionary a stream's scans run beside its sketches,
+// so no entry point times one by itself any more): `reps` launches back to back behind a synchronisation, average milliseconds.
+// The membership bits it leaves are the ones any pass of the stream needs (they depend on the reference only): kept for the next pass.
+SKX_API int skx_stream_scan_alone(skx_stream* st, uint32_t reps, double* ms_avg) {
+    if (!st || !ms_avg) return fail(SKX_ERR_INVALID, "NULL argument");
+    *ms_avg = 0.0;
+    SKXCHK(skx_stream_sync(st));
+    if (!st->static_dense || st->ref->n_sd == 0 || reps == 0)
+        return fail(SKX_ERR_INVALID, "this stream builds its scan's dictionary per pass (or the reference has no dense hash): time a synchronous push instead");
+    const skx_ref* ref = st->ref;
+    const int b = st->buf;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, st->hs));
+    for (uint32_t i = 0; i < reps; ++i)
+        skx::launch_scan(st->hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, ref->d_qs, ref->d_win_s, st->d_ms[b], nullptr, ref->n_pad,
+                         false, true, nullptr, st->d_mdirty_s, true, 0u, false);
+    HIPCHK(hipEventRecord(e1, st->hs));
+    skx::launch_exceptions(st->hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, ref->d_qs, ref->d_nsd, st->d_ms[b], ref->n_pad, st->d_mdirty_s, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st->hs));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    st->m_ready[b] = true;
+    *ms_avg = (double)ms / reps;
+    return SKX_OK;
+}
 SKX_API int skx_stream_sync(skx_stream* st) {
     if (!st) return fail(SKX_ERR_INVALID, "NULL stream");
     SKXCHK(use_device(st->device));

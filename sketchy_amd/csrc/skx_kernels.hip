@@ -1654,6 +1654,16 @@ __global__ __launch_bounds__(256) void rare_fill_kernel(const u64* __restrict__ 
     }
 }
 
+// the keys the scan has to find (held by more genomes than the index lists): out[0 .. *n) in no particular order; *n may exceed cap
+__global__ __launch_bounds__(256) void collect_dense_kernel(const u64* __restrict__ key, const u32* __restrict__ off, u64 slots,
+                                                            u64* __restrict__ out, u32* __restrict__ n, u32 cap) {
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < slots; i += (u64)gridDim.x * 256u) {
+        const u64 k = key[i];
+        if (k == kPad || off[i] != kRareDense) continue;
+        const u32 at = atomicAdd(n, 1u);
+        if (at < cap) out[at] = k;
+    }
+}
 // ---- long lists as bit rows.  A hash held by more than kShortList genomes (a lineage's: ~200) costs a pass one atomic per genome
 // on its list and batch -- 8.7 M per C2 pass of the SNP workload, 3.9 ms at the ~2.3 G/s scattered device-scope atomics reach.  The
 // lists themselves differ from hash to hash (a strain's own SNP removes a lineage hash from that one strain), so they cannot be
@@ -1807,8 +1817,9 @@ __global__ __launch_bounds__(256) void classify_a_kernel(const u64* __restrict__
         if (q0 + j < nq) { qinfo[q0 + j] = info[j]; qloc[q0 + j] = e[j] | (c[j] << 31); }
     if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
+constexpr u32 kNoStatic = 0xFFFFFFFFu;
 __global__ __launch_bounds__(1024) void classify_b_kernel(u32* __restrict__ bsum, const u32* __restrict__ n_q, u32* __restrict__ n_d,
-                                                          volatile u32* __restrict__ h_words) {
+                                                          volatile u32* __restrict__ h_words, u32 static_nd) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ u32 part[1024];
     const u32 nq = *n_q, nb = (nq + 1023u) / 1024u, t = threadIdx.x;
@@ -1826,9 +1837,10 @@ __global__ __launch_bounds__(1024) void classify_b_kernel(u32* __restrict__ bsum
     u32 run = part[t] - mine;
     for (u32 i = 0; i < per; ++i) { const u32 b = t * per + i; if (b < nb) { const u32 v = bsum[b]; bsum[b] = run; run += v; } }
     if (t == 1023u) {
-        const u32 nd = part[t], nd64 = (nd + 63u) & ~63u;
-        n_d[0] = nd; n_d[1] = nq - nd; n_d[2] = nd64; n_d[3] = nd64 + (nq - nd);  // dense rows, other rows, first other row, rows in all
-        if (h_words) { h_words[0] = nq; h_words[1] = nd; __threadfence_system(); }
+        // (static_nd: the reference's STATIC dense dictionary -- the dense rows are its rows, whichever of them this pass asks for)
+        const u32 nd_pass = part[t], nd = static_nd != kNoStatic ? static_nd : nd_pass, nd64 = (nd + 63u) & ~63u;
+        n_d[0] = nd; n_d[1] = nq - nd_pass; n_d[2] = nd64; n_d[3] = nd64 + (nq - nd_pass);  // dense rows, other rows, first other row, rows in all
+        if (h_words) { h_words[0] = nq; h_words[1] = nd_pass; __threadfence_system(); }
     }
 }
 __global__ __launch_bounds__(256) void classify_c_kernel(const u64* __restrict__ q, const u32* __restrict__ n_q,
@@ -1839,7 +1851,10 @@ __global__ __launch_bounds__(256) void classify_c_kernel(const u64* __restrict__
     const u32 nq = *n_q, i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nq) return;
     const u32 loc = qloc[i], dr = bsum[i >> 10] + (loc & 0x7FFFFFFFu), nd64 = n_d[2];
-    if (loc >> 31) { qd[dr] = q[i]; qrow[i] = dr; }
+    if (loc >> 31) {
+        if (ri.qs) qrow[i] = lower_bound_u64(ri.qs, ri.n_sd, q[i]);  // (its row of the static dictionary: every dense hash is in it)
+        else { qd[dr] = q[i]; qrow[i] = dr; }
+    }
     else {  // (the other rows start on a word boundary; sslot[2 sr], [2 sr + 1] = start and length of the hash's genome list -- or, length with
         // kLongFlag: the index of its bit row)
         const u32 sr = i - dr, slot = qinfo[i];
@@ -5008,11 +5023,14 @@ void launch_rare_fill(hipStream_t st, const u64* mat, u64 n_elems, u32 s, const 
     if (n_elems == 0) return;
     hipLaunchKernelGGL(rare_fill_kernel, dim3((u32)std::min<u64>((n_elems + 255) / 256, 1u << 16)), dim3(256), 0, st, mat, n_elems, s, key, off, cursor, post, mask);
 }
+void launch_collect_dense(hipStream_t st, const u64* key, const u32* off, u64 slots, u64* out, u32* n, u32 cap) {
+    hipLaunchKernelGGL(collect_dense_kernel, dim3((u32)std::min<u64>((slots + 255) / 256, 4096)), dim3(256), 0, st, key, off, slots, out, n, cap);
+}
 void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, const RareIndex& ri, u32* qinfo, u32* qloc, u32* bsum,
                      u64* qd, u32* n_d, u32* qrow, u32* sslot, u32* h_words) {
     const u32 nb = std::max(1u, cdiv(q_bound, 1024));
     hipLaunchKernelGGL(classify_a_kernel, dim3(nb), dim3(256), 0, st, q, n_q, ri, qinfo, qloc, bsum);
-    hipLaunchKernelGGL(classify_b_kernel, dim3(1), dim3(1024), 0, st, bsum, n_q, n_d, h_words);
+    hipLaunchKernelGGL(classify_b_kernel, dim3(1), dim3(1024), 0, st, bsum, n_q, n_d, h_words, ri.qs ? ri.n_sd : kNoStatic);
     hipLaunchKernelGGL(classify_c_kernel, dim3(std::max(1u, cdiv(q_bound, 256))), dim3(256), 0, st, q, n_q, qinfo, qloc, bsum, n_d, qd, qrow, sslot, ri);
 }
 void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* m_bits, u32 n_pad, u32* m_dirty, u32 rows_bound,

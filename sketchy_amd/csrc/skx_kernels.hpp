@@ -102,7 +102,11 @@ struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* po
                    // ... and most long lists as (pattern, exceptions) (round 6; skx_kernels.hip, "long lists as (pattern, exceptions)"):
                    // prec[bit row][pat_record_words()] = {pattern or 0xFFFFFFFF, n, n x (genome | not-on-the-list << 31)}; pat_rep[pattern] =
                    // the bit row whose list IS the pattern; pm[word of 64 patterns][n_pad] the patterns' bits in M's layout; d_npat[0] = n_pat
-                   const u32* prec = nullptr; const u32* pat_rep = nullptr; const u64* pm = nullptr; const u32* d_npat = nullptr; u32 n_pat = 0; };
+                   const u32* prec = nullptr; const u32* pat_rep = nullptr; const u64* pm = nullptr; const u32* d_npat = nullptr; u32 n_pat = 0;
+                   // the STATIC dense dictionary (round 6): qs[0 .. n_sd) = every hash the scan can be asked for (held by more genomes than
+                   // the index lists, + the lifted hashes), ascending; a pass's dense rows are ITS rows (launch_classify); NULL: per-pass dictionaries
+                   const u64* qs = nullptr; u32 n_sd = 0; };
+void launch_collect_dense(hipStream_t st, const u64* key, const u32* off, u64 slots, u64* out, u32* n, u32 cap);
 // pattern rows of a pass: hist[b][hist_stride] = occurrences of every pattern among batch b's pairs, gain_x[b][n_pad] += / -= the rows'
 // counts at their exceptions (wrapping), nprow[b] (one counter per batch, like LongRows::nlrow) rows listed from the END of lrow[b]
 struct PatRows { u32* hist; u32 hist_stride; u32* gain_x; u32* nprow; };

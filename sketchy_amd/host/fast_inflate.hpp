@@ -1,0 +1,327 @@
+// fast_inflate.hpp -- a raw DEFLATE (RFC 1951) decoder for members that sit in memory whole, written for the BGZF front-end
+// (formats.hpp, MappedFile::open_bgzf): input and output buffers are complete and the output size is known from the member's trailer,
+// so the hot loop needs no streaming state -- a 64-bit bit buffer refilled eight bytes at a time, an 11-bit primary table for the
+// literal / length code whose entries carry base value and extra-bit count (one lookup per symbol, two for the rare long codes), an
+// 8-bit one for the distances, word-wise match copies.  zlib's inflate() does 0.14 GB/s per thread on FASTQ with noisy quality strings
+// (DESIGN.md section 8); this does 3-4 x that.  Nothing is trusted: every table entry, distance and length is checked against the
+// buffers, a corrupt member makes inflate_raw return false (tests/test_host_cpu.py runs it under ASan + UBSan on mutated members).
+// The reference reads gzip through needletail / flate2 (src/sketchy.rs:89-92); the bytes that come out are the same.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+namespace sketchy {
+
+class FastInflate {
+  public:
+    // true: `in` held exactly one complete raw-deflate stream (final block seen) that inflated to exactly out_len bytes
+    bool inflate_raw(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len) {
+        const uint8_t* const in_end = in + in_len;
+        uint8_t* const out0 = out;
+        uint8_t* const out_end = out + out_len;
+        uint64_t bb = 0;  // bit buffer, LSB first
+        int bc = 0;       // valid bits in it
+        // careful refill: byte-wise, never past in_end (missing bits read as zero and are caught by `bc < 0` after they are consumed)
+#define SKX_REFILL_SAFE() do { while (bc <= 56 && in < in_end) { bb |= (uint64_t)*in++ << bc; bc += 8; } } while (0)
+#define SKX_TAKE(n) do { bb >>= (n); bc -= (int)(n); } while (0)
+        for (;;) {
+            SKX_REFILL_SAFE();
+            const unsigned final = (unsigned)bb & 1u, type = ((unsigned)bb >> 1) & 3u;
+            SKX_TAKE(3);
+            if (bc < 0) return false;
+            if (type == 0) {  // stored: skip to the byte boundary, LEN, NLEN
+                SKX_TAKE(bc & 7);
+                SKX_REFILL_SAFE();
+                if (bc < 32) return false;
+                const unsigned len = (unsigned)bb & 0xFFFFu, nlen = ((unsigned)(bb >> 16)) & 0xFFFFu;
+                SKX_TAKE(32);
+                if ((len ^ nlen) != 0xFFFFu) return false;
+                // (the bytes still in the bit buffer belong to the block: hand them back)
+                in -= bc >> 3; bb = 0; bc = 0;
+                if ((size_t)(in_end - in) < len || (size_t)(out_end - out) < len) return false;
+                memcpy(out, in, len);
+                in += len; out += len;
+            } else if (type == 3) {
+                return false;
+            } else {
+                if (type == 1) {
+                    if (!fixed_ready) { build_fixed(); }
+                    lit = fixed_lit; off = fixed_off; pack = fixed_pack;
+                } else {
+                    // dynamic: HLIT, HDIST, HCLEN, the code-length code, then the two codes' lengths run-length coded with it
+                    SKX_REFILL_SAFE();
+                    const unsigned hlit = ((unsigned)bb & 31u) + 257u, hdist = (((unsigned)bb >> 5) & 31u) + 1u, hclen = (((unsigned)bb >> 10) & 15u) + 4u;
+                    SKX_TAKE(14);
+                    if (bc < 0 || hlit > 286u || hdist > 30u) return false;
+                    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                    uint8_t pl[19];
+                    memset(pl, 0, sizeof pl);
+                    for (unsigned i = 0; i < hclen; ++i) {
+                        SKX_REFILL_SAFE();
+                        pl[order[i]] = (uint8_t)(bb & 7u);
+                        SKX_TAKE(3);
+                    }
+                    if (bc < 0) return false;
+                    if (!build(pl, 19, pre_tab, kPreBits, kPreSize, kKindPre)) return false;
+                    uint8_t lens[286 + 30 + 138];
+                    unsigned n = 0;
+                    const unsigned total = hlit + hdist;
+                    while (n < total) {
+                        SKX_REFILL_SAFE();
+                        const uint32_t e = pre_tab[bb & ((1u << kPreBits) - 1u)];
+                        const unsigned l = e & 0xFFu;
+                        if (l == 0) return false;
+                        SKX_TAKE(l);
+                        const unsigned sym = e >> 16;
+                        if (sym < 16) { lens[n++] = (uint8_t)sym; }
+                        else {
+                            unsigned rep, val = 0;
+                            if (sym == 16) { if (n == 0) return false; val = lens[n - 1]; rep = 3u + ((unsigned)bb & 3u); SKX_TAKE(2); }
+                            else if (sym == 17) { rep = 3u + ((unsigned)bb & 7u); SKX_TAKE(3); }
+                            else { rep = 11u + ((unsigned)bb & 127u); SKX_TAKE(7); }
+                            if (n + rep > total) return false;
+                            memset(lens + n, (int)val, rep);
+                            n += rep;
+                        }
+                        if (bc < 0) return false;
+                    }
+                    if (lens[256] == 0) return false;  // (no end-of-block code)
+                    if (!build(lens, hlit, dyn_lit, kLitBits, kLitSize, kKindLit)) return false;
+                    if (!build(lens + hlit, hdist, dyn_off, kOffBits, kOffSize, kKindOff)) return false;
+                    build_pack(dyn_lit, dyn_pack);
+                    lit = dyn_lit; off = dyn_off; pack = dyn_pack;
+                }
+                // ---- the block's symbols
+                bool done = false;
+                while (!done) {
+                    // fast loop: eight-byte refills and word copies need slack on both sides
+                    if ((size_t)(in_end - in) >= 32 && (size_t)(out_end - out) >= 320) {
+                        const uint8_t* const in_fast = in_end - 32;
+                        uint8_t* const out_fast = out_end - 320;
+                        // (the careful refill leaves exact counts; the fast one keeps bc in 56..63 with valid data above it)
+#define SKX_REFILL_FAST() do { uint64_t w_; memcpy(&w_, in, 8); bb |= w_ << bc; in += (63 - bc) >> 3; bc |= 56; } while (0)
+                        do {
+                            SKX_REFILL_FAST();
+                            // runs of literals: one lookup yields up to four of them (every literal whose whole code lies inside the
+                            // 11 index bits -- four bases, two quality values), written as one word; four lookups per refill
+                            uint64_t pk = pack[bb & ((1u << kLitBits) - 1u)];
+                            if (pk & 0xFF00u) {
+#define SKX_PACKED() do { const uint32_t w4_ = (uint32_t)(pk >> 16); memcpy(out, &w4_, 4); out += (pk >> 8) & 0xFFu; SKX_TAKE(pk & 0xFFu); pk = pack[bb & ((1u << kLitBits) - 1u)]; } while (0)
+                                SKX_PACKED();
+                                if (pk & 0xFF00u) {
+                                    SKX_PACKED();
+                                    if (pk & 0xFF00u) {
+                                        SKX_PACKED();
+                                        if (pk & 0xFF00u) { SKX_PACKED(); continue; }
+                                    }
+                                }
+#undef SKX_PACKED
+                                SKX_REFILL_FAST();
+                            }
+                            uint32_t e = lit[bb & ((1u << kLitBits) - 1u)];
+                            if (e & kSubtable) {
+                                SKX_TAKE(kLitBits);
+                                e = lit[((e >> 16) & 0x1FFFu) + (bb & ((1u << ((e >> 8) & 0xFu)) - 1u))];
+                                if (e & kLiteral) { SKX_TAKE(e & 0xFFu); *out++ = (uint8_t)(e >> 16); continue; }
+                            }
+                            if ((e & 0xFFu) == 0) return false;  // (a code the block's table does not hold)
+                            SKX_TAKE(e & 0xFFu);
+                            if (e & kEndOfBlock) { done = true; break; }
+                            const unsigned xl = (e >> 8) & 0x1Fu;
+                            unsigned len = (e >> 16) + ((unsigned)bb & ((1u << xl) - 1u));
+                            SKX_TAKE(xl);
+                            SKX_REFILL_FAST();
+                            uint32_t d = off[bb & ((1u << kOffBits) - 1u)];
+                            if (d & kOffSubtable) {
+                                SKX_TAKE(kOffBits);
+                                d = off[((d >> 16) & 0x1FFFu) + (bb & ((1u << ((d >> 8) & 0xFu)) - 1u))];
+                            }
+                            if ((d & 0xFFu) == 0) return false;
+                            SKX_TAKE(d & 0xFFu);
+                            const unsigned xd = (d >> 8) & 0xFu;
+                            const size_t dist = ((d >> 16) & 0x7FFFu) + (size_t)(bb & ((1ull << xd) - 1ull));
+                            SKX_TAKE(xd);
+                            if (dist > (size_t)(out - out0)) return false;
+                            const uint8_t* src = out - dist;
+                            uint8_t* dst = out;
+                            out += len;
+                            if (dist >= 8) {  // (word copies may run up to 7 bytes past the match: the slack covers it)
+                                do { uint64_t w_; memcpy(&w_, src, 8); memcpy(dst, &w_, 8); src += 8; dst += 8; } while (dst < out);
+                            } else if (dist == 1) {
+                                uint64_t w_ = 0x0101010101010101ull * src[0];
+                                do { memcpy(dst, &w_, 8); dst += 8; } while (dst < out);
+                            } else {
+                                do { *dst++ = *src++; } while (dst < out);
+                            }
+                        } while (in <= in_fast && out <= out_fast);
+                        // back to exact bit accounting
+                        bb &= bc >= 64 ? ~0ull : ((1ull << bc) - 1ull);
+                        if (done) break;
+                    }
+                    // careful loop: one symbol at a time, every access checked
+                    SKX_REFILL_SAFE();
+                    uint32_t e = lit[bb & ((1u << kLitBits) - 1u)];
+                    if (e & kSubtable) {
+                        SKX_TAKE(kLitBits);
+                        e = lit[((e >> 16) & 0x1FFFu) + (bb & ((1u << ((e >> 8) & 0xFu)) - 1u))];
+                    }
+                    if ((e & 0xFFu) == 0) return false;
+                    SKX_TAKE(e & 0xFFu);
+                    if (bc < 0) return false;
+                    if (e & kLiteral) {
+                        if (out == out_end) return false;
+                        *out++ = (uint8_t)(e >> 16);
+                        continue;
+                    }
+                    if (e & kEndOfBlock) break;
+                    const unsigned xl = (e >> 8) & 0x1Fu;
+                    const unsigned len = (e >> 16) + ((unsigned)bb & ((1u << xl) - 1u));
+                    SKX_TAKE(xl);
+                    SKX_REFILL_SAFE();
+                    uint32_t d = off[bb & ((1u << kOffBits) - 1u)];
+                    if (d & kOffSubtable) {
+                        SKX_TAKE(kOffBits);
+                        d = off[((d >> 16) & 0x1FFFu) + (bb & ((1u << ((d >> 8) & 0xFu)) - 1u))];
+                    }
+                    if ((d & 0xFFu) == 0) return false;
+                    SKX_TAKE(d & 0xFFu);
+                    const unsigned xd = (d >> 8) & 0xFu;
+                    const size_t dist = ((d >> 16) & 0x7FFFu) + (size_t)(bb & ((1ull << xd) - 1ull));
+                    SKX_TAKE(xd);
+                    if (bc < 0 || dist > (size_t)(out - out0) || len > (size_t)(out_end - out)) return false;
+                    const uint8_t* src = out - dist;
+                    for (unsigned i = 0; i < len; ++i) out[i] = src[i];
+                    out += len;
+                }
+            }
+            if (final) break;
+        }
+#undef SKX_REFILL_FAST
+#undef SKX_REFILL_SAFE
+#undef SKX_TAKE
+        return out == out_end;  // (bytes behind the stream's last block, if any, are the caller's: a gzip trailer, padding)
+    }
+
+  private:
+    // table entries (u32): bits 0-7 = bits to consume (0: no such code), 8-12 = extra bits (lengths, distances) or the subtable's index bits,
+    // 16-.. = literal / length base / distance base / subtable start; flags below
+    // (literal / length table: literal bit 31, end of block bit 30, subtable bit 29 -- start in bits 16-28; distance table: the base takes
+    // bits 16-30, its subtable flag is bit 31)
+    static constexpr uint32_t kLiteral = 0x80000000u, kEndOfBlock = 0x40000000u, kSubtable = 0x20000000u, kOffSubtable = 0x80000000u;
+    static constexpr unsigned kLitBits = 11, kOffBits = 8, kPreBits = 7;
+    static constexpr unsigned kLitSize = (1u << kLitBits) + 288u * 16u, kOffSize = (1u << kOffBits) + 32u * 128u, kPreSize = 1u << kPreBits;
+    enum Kind { kKindLit, kKindOff, kKindPre };
+    uint32_t dyn_lit[kLitSize], dyn_off[kOffSize], fixed_lit[kLitSize], fixed_off[kOffSize], pre_tab[kPreSize];
+    uint64_t dyn_pack[1u << kLitBits], fixed_pack[1u << kLitBits];  // bits 0-7 = bits of the run, 8-15 = literals in it (0: none), 16-47 = the literals
+    const uint32_t* lit = nullptr;
+    const uint32_t* off = nullptr;
+    const uint64_t* pack = nullptr;
+    bool fixed_ready = false;
+
+    static uint32_t symbol_entry(Kind kind, unsigned sym) {
+        static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+        static const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+        if (kind == kKindPre) return (uint32_t)sym << 16;
+        if (kind == kKindOff) return sym < 30 ? ((uint32_t)dist_base[sym] << 16) | ((uint32_t)dist_extra[sym] << 8) : 0xFFFFFFFFu;
+        if (sym < 256) return kLiteral | ((uint32_t)sym << 16);
+        if (sym == 256) return kEndOfBlock;
+        if (sym < 286) return ((uint32_t)len_base[sym - 257] << 16) | ((uint32_t)len_extra[sym - 257] << 8);
+        return 0xFFFFFFFFu;  // (286, 287: in the fixed code's alphabet, never valid in data)
+    }
+    static unsigned reverse_bits(unsigned code, unsigned len) {
+        unsigned r = 0;
+        for (unsigned i = 0; i < len; ++i) { r = (r << 1) | (code & 1u); code >>= 1; }
+        return r;
+    }
+    // canonical Huffman code of lens[0 .. n) -> lookup table (primary `bits` wide + subtables); false: over-subscribed / no code at all
+    static bool build(const uint8_t* lens, unsigned n, uint32_t* tab, unsigned bits, unsigned size, Kind kind) {
+        unsigned count[16];
+        memset(count, 0, sizeof count);
+        for (unsigned i = 0; i < n; ++i) { if (lens[i] > 15) return false; count[lens[i]]++; }
+        unsigned next_code[16];
+        unsigned code = 0, left = 1;
+        count[0] = 0;
+        for (unsigned l = 1; l <= 15; ++l) {
+            left <<= 1;
+            if (count[l] > left) return false;  // over-subscribed
+            left -= count[l];
+            code = (code + count[l - 1]) << 1;
+            next_code[l] = code;
+        }
+        // (incomplete codes are legal for a distance code with one symbol -- and tolerated in general: codes that do not exist decode
+        // to an entry of length 0, which the decoder refuses)
+        memset(tab, 0, (size_t)size * sizeof(uint32_t));
+        uint8_t sub_max[1u << 11];
+        bool any_long = false;
+        // pass 1: short codes into the primary table; the longest code behind every primary prefix
+        unsigned codes[320];
+        for (unsigned s = 0; s < n; ++s) {
+            const unsigned l = lens[s];
+            if (!l) continue;
+            const unsigned r = reverse_bits(next_code[l]++, l);
+            codes[s] = r;
+            const uint32_t ent = symbol_entry(kind, s);
+            if (l <= bits) {
+                if (ent == 0xFFFFFFFFu) continue;  // (a code for a symbol that must not occur: left out, refused when met)
+                for (unsigned i = r; i < (1u << bits); i += 1u << l) tab[i] = ent | l;
+            } else {
+                if (!any_long) { memset(sub_max, 0, sizeof sub_max); any_long = true; }
+                const unsigned p = r & ((1u << bits) - 1u);
+                if (l > sub_max[p]) sub_max[p] = (uint8_t)l;
+            }
+        }
+        if (!any_long) return true;
+        // pass 2: a subtable per prefix with long codes, then the long codes into them
+        unsigned next = 1u << bits;
+        for (unsigned p = 0; p < (1u << bits); ++p) {
+            if (!sub_max[p]) continue;
+            const unsigned sb = sub_max[p] - bits;
+            if (next + (1u << sb) > size) return false;
+            tab[p] = (kind == kKindOff ? kOffSubtable : kSubtable) | ((uint32_t)next << 16) | (sb << 8) | bits;
+            next += 1u << sb;
+        }
+        for (unsigned s = 0; s < n; ++s) {
+            const unsigned l = lens[s];
+            if (l <= bits) continue;
+            const uint32_t ent = symbol_entry(kind, s);
+            if (ent == 0xFFFFFFFFu) continue;
+            const unsigned r = codes[s], p = r & ((1u << bits) - 1u);
+            const uint32_t pe = tab[p];
+            const unsigned start = (pe >> 16) & 0x1FFFu, sb = (pe >> 8) & 0xFu;
+            for (unsigned i = r >> bits; i < (1u << sb); i += 1u << (l - bits)) tab[start + i] = ent | (l - bits);
+        }
+        return true;
+    }
+    // pk[i] = the literals whose codes lie completely inside the index bits i (at most four), from the primary table
+    static void build_pack(const uint32_t* tab, uint64_t* pk) {
+        for (unsigned idx = 0; idx < (1u << kLitBits); ++idx) {
+            unsigned v = idx, avail = kLitBits, bits = 0, n = 0;
+            uint64_t payload = 0;
+            while (n < 4) {
+                const uint32_t e = tab[v];  // (the bits above `avail` are zero: right for every code of at most `avail` bits)
+                const unsigned l = e & 0xFFu;
+                if (!(e & kLiteral) || l > avail) break;
+                payload |= (uint64_t)((e >> 16) & 0xFFu) << (8 * n);
+                ++n; bits += l; v >>= l; avail -= l;
+            }
+            pk[idx] = n ? (payload << 16) | ((uint64_t)n << 8) | bits : 0ull;
+        }
+    }
+    void build_fixed() {
+        uint8_t l[288 + 32];
+        for (unsigned i = 0; i < 144; ++i) l[i] = 8;
+        for (unsigned i = 144; i < 256; ++i) l[i] = 9;
+        for (unsigned i = 256; i < 280; ++i) l[i] = 7;
+        for (unsigned i = 280; i < 288; ++i) l[i] = 8;
+        for (unsigned i = 0; i < 32; ++i) l[288 + i] = 5;
+        (void)build(l, 288, fixed_lit, kLitBits, kLitSize, kKindLit);
+        (void)build(l + 288, 32, fixed_off, kOffBits, kOffSize, kKindOff);
+        build_pack(fixed_lit, fixed_pack);
+        fixed_ready = true;
+    }
+};
+
+}  // namespace sketchy

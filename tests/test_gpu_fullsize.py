@@ -185,9 +185,10 @@ def test_c2_footprint_and_four_streams_on_one_reference(c2):
 @pytest.mark.parametrize("split,big", [("0", "0"), ("1", "0"), ("1", "1")])
 def test_forced_scan_kernel_variants(gpu, split, big):
     """The split-array and big-table scan variants are picked automatically only for dense full-size passes;
-    force each of them (env, read once per process) on small ragged inputs and compare with the oracle."""
+    force each of them (env, read once per process) on small ragged inputs and compare with the oracle.
+    (SKX_RARE_MAX=0: no rare-hash index, so every query hash of these small panels really goes through the scan.)"""
     from helpers import exp_env
-    env = exp_env(SKX_SCAN_SPLIT=split, SKX_SCAN_BIG=big)
+    env = exp_env(SKX_SCAN_SPLIT=split, SKX_SCAN_BIG=big, SKX_RARE_MAX=0)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=env, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "variant ok" in out.stdout
@@ -204,7 +205,9 @@ def test_forced_scan_kernel_variants(gpu, split, big):
                                    {"SKX_RARE_MAX": "0", "SKX_CAND": "0"}, {"SKX_TABLE_LEGACY": "0"}, {"SKX_TABLE_LEGACY": "100"},
                                    {"SKX_RARE_MAX": "100000"}, {"SKX_RARE_MAX": "100000", "SKX_RARE_CHUNK": "1"}, {"SKX_RARE_DIRECT": "0"},
                                    {"SKX_RARE_MAX": "100000", "SKX_RARE_DIRECT": "0"}, {"SKX_TAIL_SCALE": "1"}, {"SKX_FIRST_GROUP": "1"},
-                                   {"SKX_RARE_MAX": "100000", "SKX_LONG_ROWS_T": "0"}])
+                                   {"SKX_RARE_MAX": "100000", "SKX_LONG_ROWS_T": "0"}, {"SKX_STATIC_DENSE": "0"},
+                                   {"SKX_STATIC_DENSE": "0", "SKX_PASS_READS": "64"}, {"SKX_RARE_MAX": "3", "SKX_STATIC_DENSE": "0"},
+                                   {"SKX_RARE_MAX": "3", "SKX_PASS_READS": "37"}, {"SKX_PATTERNS": "0"}, {"SKX_LONG_ROWS": "0"}])
 def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     """Several passes per push (the path that needs the per-read pair offsets on the host), the pipeline depths, the
     unfiltered dictionary, the ranking without its per-word live flags, the ranking lanes forced to one / four, the
@@ -213,7 +216,9 @@ def test_forced_pass_partition_and_pipeline_depth(gpu, knobs):
     probe), and round 5's machinery switched off or forced -- no compact ranking on the candidates (SKX_CAND=0), no rare-hash index or
     one for nearly every hash (SKX_RARE_MAX), the table always / never out of the ranking chains (SKX_TABLE_LEGACY), the rare rows into the
     group-major matrix one rank group per turn (SKX_RARE_CHUNK=1) or through M and the transpose as before (SKX_RARE_DIRECT=0), the list
-    walks of a closing pass at their ordinary size (SKX_TAIL_SCALE=1), first groups of one batch, no transposed bit rows (SKX_LONG_ROWS_T=0: the candidates' long-list rows found row by row) -- all give the oracle's rows."""
+    walks of a closing pass at their ordinary size (SKX_TAIL_SCALE=1), first groups of one batch, no transposed bit rows (SKX_LONG_ROWS_T=0: the candidates' long-list rows found row by row),
+    round 6's static dense dictionary off (SKX_STATIC_DENSE=0: per-pass dictionaries, the scan behind them) or with nearly every hash in it
+    (SKX_RARE_MAX=3), no patterns, no bit rows at all -- all give the oracle's rows."""
     from helpers import exp_env
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=exp_env(**knobs),
                          capture_output=True, text=True)

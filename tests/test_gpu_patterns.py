@@ -6,30 +6,53 @@ minus the odd one", so skx_ref_create stores them as a shared pattern plus a few
 the oracle's (src/sketchy.rs:337-349, :425-438) -- with the sample's own lineage as the candidates (its strains ARE the exceptions of
 its lineage-level hashes), for top-1 and top-3, through shared passes and through synchronous pushes."""
 import os
+import subprocess
+import sys
+import tempfile
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 N, S_, B, NB = 6000, 2000, 16384, 14
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _generate(d):
+    # (in a child: torch's bundled HIP runtime and the library's do not share a process, as in the other GPU tests)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from sketchy_amd import synth\n"
+        "ref = synth.make_reference(%d, %d, rng_seed=3, device='cuda', mode='snp', n_lineages=30)\n"
+        "src = torch.from_numpy(ref['truth_genome']).to('cuda')\n"
+        "parts, lens = [], []\n"
+        "for i in range(%d):\n"
+        "    b, o = synth.make_reads_torch(src, %d, 1500, rng_seed=4100 + i, device='cuda')\n"
+        "    parts.append(b.cpu().numpy()); lens.append(np.diff(o.cpu().numpy().astype(np.int64)))\n"
+        "bases = np.concatenate(parts); offsets = np.zeros(1 + sum(len(x) for x in lens), np.uint64)\n"
+        "offsets[1:] = np.cumsum(np.concatenate(lens)).astype(np.uint64)\n"
+        "np.save(%r + '/ref.npy', ref['ref']); np.save(%r + '/bases.npy', bases); np.save(%r + '/offsets.npy', offsets)\n"
+        "np.save(%r + '/truth.npy', np.array([ref['truth_index']]))\n"
+    ) % (ROOT, N, S_, NB, B, d, d, d, d)
+    subprocess.check_call([sys.executable, "-c", code])
 
 
 @pytest.fixture(scope="module")
 def snp(gpu):
-    from sketchy_amd import api, synth
-    ref = synth.make_reference(N, S_, rng_seed=3, device="cuda", mode="snp", n_lineages=30)
-    import torch
-    src = torch.from_numpy(ref["truth_genome"]).to("cuda")
-    parts, lens = [], []
-    for i in range(NB):
-        b, o = synth.make_reads_torch(src, B, 1500, rng_seed=4100 + i, device="cuda")
-        parts.append(b.cpu().numpy()); lens.append(np.diff(o.cpu().numpy().astype(np.int64)))
-    bases = np.concatenate(parts)
-    offsets = np.zeros(1 + NB * B, np.uint64)
-    offsets[1:] = np.cumsum(np.concatenate(lens)).astype(np.uint64)
-    R = api.ReferenceSketch(ref["ref"])
-    yield dict(ref=ref["ref"], truth=ref["truth_index"], bases=bases, offsets=offsets, R=R)
-    R.close()
+    d = tempfile.mkdtemp(prefix="skx_pat_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        _generate(d)
+        out = dict(ref=np.load(d + "/ref.npy"), bases=np.load(d + "/bases.npy"), offsets=np.load(d + "/offsets.npy"),
+                   truth=int(np.load(d + "/truth.npy")[0]))
+    finally:
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))
+        os.rmdir(d)
+    from sketchy_amd import api
+    out["R"] = api.ReferenceSketch(out["ref"])
+    yield out
+    out["R"].close()
 
 
 def test_most_long_lists_are_stored_as_patterns(snp):
@@ -88,7 +111,7 @@ def test_rows_and_shared_counts_through_pushes(snp):
     n = 300
     S = api.SumOfSharedHashes(R, top=2, max_batch_reads=n, max_batch_bases=int(offsets[n] - offsets[0]))
     got = S.push(bases, offsets[:n + 1], want_shared=True)
-    e = orc.stream(16, 0, S_, ref, None, bases[:int(offsets[n])], offsets[:n + 1], top_k=2, want_shared=True)
+    e = orc.stream(16, 0, S_, ref, np.full(N, S_, np.uint32), bases[:int(offsets[n])], offsets[:n + 1], top_k=2, want_shared=True)
     np.testing.assert_array_equal(got["shared"], e["shared"])
     np.testing.assert_array_equal(got["topk_sum"], e["topk_sum"])
     np.testing.assert_array_equal(got["topk_idx"], e["topk_idx"])
@@ -111,9 +134,7 @@ def test_rows_and_shared_counts_through_pushes(snp):
 
 def test_same_rows_without_the_patterns(snp):
     """the experiments build with SKX_PATTERNS=0 (bit rows only, round 5's path) gives the same rows: run as a child so the knob is read"""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = ROOT
     code = (
         "import sys, numpy as np, hashlib; sys.path.insert(0, %r)\n"
         "import torch\n"
