@@ -40,7 +40,7 @@ class FastInflate {
                 // (the bytes still in the bit buffer belong to the block: hand them back)
                 in -= bc >> 3; bb = 0; bc = 0;
                 if ((size_t)(in_end - in) < len || (size_t)(out_end - out) < len) return false;
-                memcpy(out, in, len);
+                if (len) memcpy(out, in, len);
                 in += len; out += len;
             } else if (type == 3) {
                 return false;
@@ -324,4 +324,79 @@ class FastInflate {
     }
 };
 
+}  // namespace sketchy
+
+// ---- CRC-32 (the gzip polynomial) of a member's inflated bytes.  zlib's table-driven crc32() runs at ~1 GB/s per thread -- a third of the
+// time of the decoder above; carry-less multiplication folds 64 bytes per step (Gopal et al., "Fast CRC Computation for Generic
+// Polynomials Using PCLMULQDQ", the constants are those of the reflected polynomial 0xEDB88320): ~10 GB/s.  Run-time dispatch; the head
+// that is not a multiple of 16 bytes (and machines without the instruction) go through zlib.
+#include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+namespace sketchy {
+__attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_clmul_blocks(const uint8_t* buf, size_t len /* multiple of 16, >= 64 */, uint32_t state) {
+    alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+    alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+    alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+    alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i*)(buf + 0x00));
+    x2 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i*)(buf + 0x20));
+    x4 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)state));
+    x0 = _mm_load_si128((const __m128i*)k1k2);
+    buf += 64; len -= 64;
+    while (len >= 64) {
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i*)(buf + 0x00)); y6 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i*)(buf + 0x20)); y8 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64; len -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i*)k3k4);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) {
+        x2 = _mm_loadu_si128((const __m128i*)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i*)k5k0);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_load_si128((const __m128i*)poly);
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+inline bool crc32_have_clmul() { static const bool have = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1"); return have; }
+}  // namespace sketchy
+#endif
+namespace sketchy {
+// crc32 of buf[0 .. len) as zlib's crc32(0, buf, len)
+inline uint32_t crc32_fast(const uint8_t* buf, size_t len) {
+#if defined(__x86_64__)
+    if (len >= 80 && crc32_have_clmul()) {
+        const size_t head = len & 15u;                      // (zlib for the odd head, folds for the rest: a multiple of 16, at least 64)
+        uint32_t c = head ? (uint32_t)crc32(0L, buf, (uInt)head) : 0u;
+        return ~crc32_clmul_blocks(buf + head, len - head, ~c);
+    }
+#endif
+    return (uint32_t)crc32(0L, buf, (uInt)len);
+}
 }  // namespace sketchy

@@ -275,6 +275,8 @@ class Sketchy {
         // (a BGZF file -- gzip members with their sizes in the header -- is inflated by all threads at once and then cut and parsed
         // like an uncompressed one; plain gzip is one sequential stream)
         const bool mapped = map.open(path) || map.open_bgzf(path, config.threads ? (unsigned)config.threads : std::min(usable_threads(), 22u));
+        if (mapped && map.inflated() && !map.eof_marker)
+            fprintf(stderr, "sketchy-hip: warning: %s does not end with BGZF's end-of-file block (truncated at a block boundary?)\n", path.c_str());
         const char *fbegin = mapped ? map.data() : nullptr, *fend = mapped ? map.data() + map.size() : nullptr;
         bool fastq = false;
         size_t chunk_bytes = 0;

@@ -169,6 +169,48 @@ def test_stream_rows_from_bgzf_inflated_in_parallel(asan_bin, tmp_path):
     assert rc in (0, 1) and "Sanitizer" not in err   # (a truncated tail: either the streaming reader's error or the reads that were whole)
 
 
+def test_fast_inflate_against_zlib_under_sanitizers():
+    """sketchy_amd/host/fast_inflate.hpp: stored / fixed / dynamic blocks of every zlib strategy and level, sizes around the fast loop's
+    margins, skewed alphabets (15-bit codes, subtables) -- byte-identical to the input, wrong output sizes refused; 20 000 mutated
+    and truncated members end in `false` or garbage of the right length (the CRC catches that), never in a sanitizer report;
+    crc32_fast == zlib's crc32 for every length class."""
+    exe = os.path.join(ROOT, "tests", "stub", "inflate-check-asan")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "stub"), exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    p = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=900)
+    assert p.returncode == 0 and " fails 0;" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_bgzf_members_are_checked_against_their_crc(asan_bin, tmp_path):
+    """A BGZF member whose bytes were damaged but still inflate to the right length is refused (CRC32 of the member's trailer; needletail /
+    flate2 do the same, src/sketchy.rs:89-92); a file without BGZF's empty end-of-file member is scored with a warning; members written
+    at other compression levels (stored blocks at level 0, longer matches at 9) give the same rows."""
+    from helpers import write_bgzf
+    names, geno, msh, tsv = _reference(tmp_path)
+    reads = _reads(400, 1, 2000, seed=33)
+    want = _expected(reads, names, geno, top=1)
+    fq = str(tmp_path / "r.fq")
+    _fastq(fq, reads)
+    raw = open(fq, "rb").read()
+    bg = str(tmp_path / "r.fq.gz")
+    for level in (0, 6, 9):
+        write_bgzf(bg, raw, block=20000, level=level)
+        rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", bg, "-s", "-b", "32", "-j", "4")
+        assert rc == 0 and out == want, (level, err)
+    write_bgzf(bg, raw, block=20000, level=0)   # stored blocks: a flipped payload byte still "inflates"
+    data = bytearray(open(bg, "rb").read())
+    data[200] ^= 0x01
+    bad = str(tmp_path / "bad.fq.gz")
+    open(bad, "wb").write(bytes(data))
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", bad, "-s", "-b", "32")
+    assert rc == 1 and "CRC" in err and "Sanitizer" not in err, (rc, err)
+    noeof = str(tmp_path / "noeof.fq.gz")
+    write_bgzf(bg, raw, block=20000, level=6)
+    open(noeof, "wb").write(open(bg, "rb").read()[:-28])
+    rc, out, err = _run("predict", "-r", msh, "-g", tsv, "-i", noeof, "-s", "-b", "32")
+    assert rc == 0 and out == want and "end-of-file block" in err, err
+
+
 def test_a_chunk_with_far_more_reads_than_the_first_records_promised(asan_bin, tmp_path):
     """Chunks are sized from the first 64 records; when the rest of the file holds 100-fold shorter reads a chunk carries far
     more reads than its slot holds: the overflow goes through heap batches and the spill slot, rows and order unchanged."""
