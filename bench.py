@@ -53,14 +53,20 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CHECK_CUT = 4096       # reads per push of the verification stream
 
 
-def _pmc_traffic(config, batch):
+def _profile_key(config, batch, workload):
+    """key of a committed profile in profiles/scan_traffic.json / valu_insts.json: per config, batch AND workload (round 5 quoted the
+    truth-strain run's traffic beside the ancestor stream's line)"""
+    return f"{config}{'truth' if workload == 'truth' else ''}_b{batch}"
+
+
+def _pmc_traffic(config, batch, workload="truth"):
     """HBM bytes per scan_kernel launch from the COMMITTED rocprofv3 PMC passes (profiles/scan_traffic.json; FETCH_SIZE
     x 1024 x 2 [gfx950 counts wide streaming reads at half their bytes] + WRITE_SIZE x 1024) for the same config and
     batch -- not measured in this run; (None, None) when no matching profile is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "scan_traffic.json")) as f:
             t = json.load(f)
-        key = f"{config}_b{batch}"
+        key = _profile_key(config, batch, workload)
         e = t.get(key)
         if e:
             return (e.get("bytes_per_launch"), f"profiles/scan_traffic.json:{key} ({e.get('profile', 'committed rocprofv3 --pmc passes')}; not measured in this run)",
@@ -81,15 +87,15 @@ VALU_CYCLES_PER_WAVE_INST = 4  # a wave64 VALU instruction occupies its SIMD (16
 CLOCK_GHZ = 2.4
 
 
-def _valu_insts(config, batch):
+def _valu_insts(config, batch, workload="truth"):
     """VALU wave instructions one step issues, from the COMMITTED per-kernel SQ_INSTS_VALU profile (profiles/valu_insts.json,
     written from tools/pmc_all.sh output) -- not measured in this run; None when no matching profile is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "valu_insts.json")) as f:
-            e = json.load(f).get(f"{config}_b{batch}")
+            e = json.load(f).get(_profile_key(config, batch, workload))
         if e:
             return {"wave_insts_per_step": e["wave_insts_per_step"], "per_kernel": e.get("per_kernel"), "source_sha": e.get("source_sha"),
-                    "source": f"profiles/valu_insts.json:{config}_b{batch} ({e.get('profile', 'committed rocprofv3 --pmc SQ_INSTS_VALU pass')}; "
+                    "source": f"profiles/valu_insts.json:{_profile_key(config, batch, workload)} ({e.get('profile', 'committed rocprofv3 --pmc SQ_INSTS_VALU pass')}; "
                               "not measured in this run)"}
     except (OSError, ValueError, KeyError):
         pass
@@ -292,11 +298,12 @@ def main():
     ap.add_argument("--e2e-args", default="", help="experiment: extra arguments for the sketchy-hip command of the value_end_to_end leg, e.g. '-b 65536 --pin'")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the value_end_to_end leg (FASTQ file -> sketchy-hip predict -s -> rows file)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity checks of the timed steps (profiling runs only)")
-    ap.add_argument("--workload", default="ancestor", choices=["ancestor", "truth"],
-                    help="ancestor (default, `value`): random-hash clone tree, every read drawn from the tree's common ancestor -- a 40 000-way "
-                         "near-tie, the conservative case; truth: SURVEY.md 8(d)'s generator -- SNP clone tree with real 16-mer hashes, reads from ONE "
-                         "truth strain (a leader emerges, as in a real sample).  The default run reports the second as `value_truth_strain`")
-    ap.add_argument("--no-truth-leg", action="store_true", help="skip the value_truth_strain leg (a child run of this script with --workload truth)")
+    ap.add_argument("--workload", default="truth", choices=["ancestor", "truth"],
+                    help="truth (default, `value`): SURVEY.md 8(d)'s generator -- SNP clone tree with real 16-mer hashes, reads sampled from ONE "
+                         "truth strain (a leader emerges, as in a real sample); ancestor: rounds 1-4's -- random-hash clone tree, every read drawn from "
+                         "the tree's common ancestor, a 40 000-way near-tie.  The default run reports the second as `value_ancestor`")
+    ap.add_argument("--no-truth-leg", "--no-other-workload-leg", dest="no_truth_leg", action="store_true",
+                    help="skip the leg of the OTHER workload (a child run of this script: value_ancestor by default, value_truth_strain under --workload ancestor)")
     ap.add_argument("--oracle-steps", default="first,last", help="timed steps whose EVERY row is compared with the CPU oracle (fast checker); "
                     "'none' skips the whole-step oracle check")
     ap.add_argument("--no-shuffle", action="store_true", help="experiment: keep genomes grouped by lineage")
@@ -443,7 +450,7 @@ def main():
                    "workload_kind": ("SURVEY 8(d): SNP clone tree (lineage divergence 1 %, strain 0.05 %), sketches = bottom-s of the strains' REAL 16-mer "
                                      "hashes, reads sampled from ONE truth strain per species, 5 % substitution errors") if truth else
                                     ("random-hash clone tree, reads sampled from the tree's common ancestor, 5 % substitution errors "
-                                     "(a near-tie of all genomes: the conservative case; `value_truth_strain` is the other)"),
+                                     "(rounds 1-4's stream: a near-tie of all genomes; NOT SURVEY 8(d)'s)"),
                    "stream": f"{K} distinct batches = the first {K * B} reads of a sample per GPU, table fresh at the first timed step",
                    "reads_per_step": B, "read_len": read_len, "read_len_lognormal_sigma": sigma,
                    "mean_read_len": round(float(np.mean(batch_bases)) / B, 1), "n_species": n_sp, "n_genomes": species, "s": s, "k": k,
@@ -506,7 +513,7 @@ def main():
         if prof and prof["scan"]["launches"]:
             scan_ms = prof["scan"]["ms"] / prof["scan"]["launches"]
             achieved = pass_bytes / (scan_ms * 1e-3) / 1e9
-            traffic, traffic_src, traffic_sha = _pmc_traffic(args.config, B)
+            traffic, traffic_src, traffic_sha = _pmc_traffic(args.config, B, args.workload)
             launches_per_step = prof["scan"]["launches"] / (K * reps)
             step_gbs = pass_bytes * launches_per_step / (elapsed / K) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -527,7 +534,7 @@ def main():
                                               "note": "algorithmic bytes x launches_per_step over the whole step time (sketch, dictionary, ranking "
                                                       "included): what the step needs from HBM for the reference, not a quality figure -- it "
                                                       "falls as batches share scans while the reads/s go up"}}
-        vi = _valu_insts(args.config, B)
+        vi = _valu_insts(args.config, B, args.workload)
         if vi:
             floor_ms = vi["wave_insts_per_step"] * VALU_CYCLES_PER_WAVE_INST / (N_SIMDS * CLOCK_GHZ * 1e9) * 1e3
             out["roofline_valu"] = {"bound": "valu_issue", "wave_insts_per_step": vi["wave_insts_per_step"],
@@ -919,10 +926,12 @@ def main():
         if table_ok is False:
             err = err or "the final table of the timed stream differs from the CPU oracle's (orc_stream_fast)"
 
-    # ---- value_truth_strain: the same bench on SURVEY.md 8(d)'s generator (SNP clone tree, reads from ONE truth strain), as a child
+    # ---- the OTHER workload (value_ancestor: rounds 1-4's near-tie stream; under --workload ancestor: value_truth_strain), as a child
     # run of this script (its own reference, stream, timed region from a fresh table, whole-step oracle check); not `value`
-    if rank == 0 and world == 1 and args.workload == "ancestor" and not args.no_truth_leg and not args.no_extra_legs:
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "truth", "--config", args.config, "--steps", str(K), "--warmup", str(W),
+    other = "ancestor" if args.workload == "truth" else "truth"
+    other_key = "value_ancestor" if other == "ancestor" else "value_truth_strain"
+    if rank == 0 and world == 1 and not args.no_truth_leg and not args.no_extra_legs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", other, "--config", args.config, "--steps", str(K), "--warmup", str(W),
                "--batch", str(B), "--top", str(top), "--reps", str(min(reps, 5)), "--no-extra-legs", "--cpu-seconds", "0", "--api", args.api,
                "--oracle-steps", args.oracle_steps] + (["--no-check"] if args.no_check else [])
         try:
@@ -931,18 +940,18 @@ def main():
             child = json.loads(line[-1]) if line else None
         except Exception as e:  # noqa: BLE001
             p, child = None, None
-            out["value_truth_strain"] = {"error": f"{type(e).__name__}: {e}"[:300], "not_run": True}
+            out[other_key] = {"error": f"{type(e).__name__}: {e}"[:300], "not_run": True}
         if child:
             keep = ("value", "unit", "ms_per_step", "values_all", "reps", "steps", "parity", "oracle_whole_steps", "pass_stats", "parity_error")
             tl = {k_: child[k_] for k_ in keep if k_ in child}
             if "roofline" in child:
                 tl["scan"] = {k_: child["roofline"].get(k_) for k_ in ("achieved", "frac", "avg_launch_ms", "launches_per_step")}
             tl["workload"] = child["config"]["workload_kind"]
-            out["value_truth_strain"] = tl
+            out[other_key] = tl
             if child.get("parity_error"):
-                err = err or "value_truth_strain: " + child["parity_error"]
+                err = err or other_key + ": " + child["parity_error"]
         elif p is not None:
-            out["value_truth_strain"] = {"error": f"child run failed (rc {p.returncode}): {p.stderr[-400:]}", "not_run": True}
+            out[other_key] = {"error": f"child run failed (rc {p.returncode}): {p.stderr[-400:]}", "not_run": True}
 
     # every rank's verdict decides the exit code
     n_bad = shard.sum_over_ranks_int(1 if err else 0)

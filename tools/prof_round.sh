@@ -11,7 +11,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 grep -E "skx::|^kernel" $P/${TAG}_kernel_stats.csv | cut -c1-120; cat $P/${TAG}_pmc_FETCH_SIZE.csv $P/${TAG}_pmc_WRITE_SIZE.csv | grep -E "scan_lean|scan_kernel|transpose"
 # HBM bytes per scan launch -> profiles/scan_traffic.json (with the sha of the sources profiled); a copy travels back in gpurun_out/
-CFG=c2; B=98304; prev=""; for a in "$@"; do [ "$prev" = "--config" ] && CFG=$a; [ "$prev" = "--batch" ] && B=$a; prev=$a; done
+# (key: <config>[truth]_b<batch> -- bench.py's _profile_key: the workload belongs to the key; truth is bench.py's default)
+CFG=c2; B=98304; WL=truth; prev=""; for a in "$@"; do [ "$prev" = "--config" ] && CFG=$a; [ "$prev" = "--batch" ] && B=$a; [ "$prev" = "--workload" ] && WL=$a; prev=$a; done
+[ "$WL" = "truth" ] && CFG=${CFG}truth
 # (a dense dictionary -- C4's mixed stream -- is scanned by scan_kernel's split-array variant instead of the lean kernel)
 KPAT=scan_lean_kernel; grep -q scan_lean_kernel $P/${TAG}_pmc_FETCH_SIZE.csv || KPAT="scan_kernel<"
 python3 tools/scan_traffic.py $P/${TAG}_pmc_FETCH_SIZE.csv $P/${TAG}_pmc_WRITE_SIZE.csv ${CFG}_b$B $TAG "$KPAT" && cp profiles/scan_traffic.json $P/${TAG}_scan_traffic.json

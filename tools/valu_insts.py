@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sketchy_amd.build import source_sha  # noqa: E402
 SETUP = ("ref_tile_kernel", "band_bounds_kernel", "filter_build_kernel", "rare_count_kernel", "rare_fill_kernel", "mlong_build_kernel",
-         "mlong_transpose_kernel")  # (round 5: the rare-hash index is built with the reference too)
+         "mlong_transpose_kernel", "list_sig_kernel", "pat_exceptions_kernel", "pat_matrix_kernel",
+         "collect_dense_kernel")  # (the rare-hash index, the patterns and the static dictionary are built with the reference)
 src, key, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 sha = sys.argv[4] if len(sys.argv) > 4 else source_sha()   # (argv[4]: re-deriving the JSON from a CSV of an earlier tree)
 rows = {}
