@@ -631,6 +631,53 @@ def main():
                                                    "what": "the same K batches on a stream created with option stream_coalesce = 1: one "
                                                            "scan of the reference per batch"}
             S1.close()
+        # value_membership_reused: the timed stream once more on a stream created with the policy "reuse_membership" = 1 (references with a
+        # static dense dictionary: the bits the scan finds depend on the reference alone -- this stream scans once per buffer set and keeps
+        # them).  NOT `value`: the contract's pass streams the reference every time.  Rows must be identical.
+        if args.api == "enqueue" and R.static_dense[0] and R.static_dense[1]:
+            api.set_option("reuse_membership", 1)
+            try:
+                Sr = api.SumOfSharedHashes(R, top=top, max_batch_reads=B, max_batch_bases=max(batch_bases))
+            finally:
+                api.set_option("reuse_membership", 0)
+            for i in range(min(W, 2)):
+                step(i, slot=0, call=Sr.enqueue_device)
+            Sr.sync()
+            t_r = []
+            for rep in range(3):
+                Sr.reset()
+                shard.barrier()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for i in range(W, W + K):
+                    step(i, slot=0 if i < W + K - 1 else W + K - 1, call=Sr.enqueue_device)
+                Sr.sync()
+                t_r.append(shard.max_over_ranks(time.perf_counter() - tc))
+            reuse_ok = None
+            if not args.no_check and top:
+                reuse_ok = bool(np.array_equal(d_ti[W + K - 1].cpu().numpy().view(np.uint32), ti_last) and
+                                np.array_equal(d_ts[W + K - 1].cpu().numpy().view(np.uint64), ts_last))
+                if not reuse_ok:
+                    err = err or "rows of the last timed step differ when the static dense rows are kept between passes"
+            Sr.reset()
+            torch.cuda.synchronize()
+            tcold = []
+            for rep in range(5):
+                Sr.reset()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                step(W, slot=0, call=Sr.enqueue_device)
+                Sr.sync()
+                tcold.append(time.perf_counter() - tc)
+            if rank == 0:
+                tr = float(np.median(t_r))
+                out["value_membership_reused"] = {"value": K * B * world / tr, "unit": "reads/s", "ms_per_step": 1e3 * tr / K, "median_of": 3,
+                                                  "value_cold": B * world / float(np.median(tcold)), "rows_match_timed_run": reuse_ok,
+                                                  "what": "the same K batches from a fresh table on a stream created with option reuse_membership = 1: the "
+                                                          "membership bits of the reference's static dense hashes are scanned for once and kept -- "
+                                                          "no pass streams the reference again (a side leg: `value` scans every pass, as the contract's "
+                                                          "roofline figure assumes)"}
+            Sr.close()
         # value_steady_state: the same stream far from its start (no reset, batches cycled), three regions of >= 0.5 s
         n_long = max(32, int(0.5 / (elapsed / K)))
         S.reset()

@@ -92,6 +92,11 @@ int skx_device_pci_bus_id(int device, char *bus_id, size_t cap);
  *                     each with its own scratch (the table a batch starts from is all a chain needs of the one before it: it waits
  *                     for that chain's second kernel, not for its end).  C2, 20 batches from a fresh table: 131 M reads/s on one
  *                     lane, 134 M on two, 129-131 M on three / four; ~0.6 GB of scratch per lane at C2, 2.3 GB at C4.
+ *   "rare_hash_genomes"  0 (no rare-hash index) .. 2^20 (default 1024): see skx_ref_rare_index.
+ *   "reuse_membership"  0 (default) / 1: references with a static dense dictionary (skx_ref_static_dense) -- the bits the scan finds
+ *                     for them depend on the reference alone.  0: every scoring pass streams the reference once (8 x stride x genomes
+ *                     bytes: the pass SURVEY 8(d)'s roofline figure is defined on).  1: a stream scans the reference once per buffer set
+ *                     and keeps the rows; later passes read the 52 MB (C2) of kept bits instead of the 3.2 GB of hashes.
  *   "comm_timeout_ms" 0 (default: no watchdog) .. 86 400 000: skx_comm_create (ncclCommInitRank) and skx_stream_allreduce
  *                     (ncclAllReduce + its stream synchronisation) block for ever when a peer never arrives.  With a
  *                     timeout set, a call that has not returned in time prints which rank was stuck in what to stderr and

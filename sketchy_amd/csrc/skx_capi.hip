@@ -180,6 +180,7 @@ static std::atomic<u32> g_stream_coalesce{8};         // batches of skx_stream_e
 static const int kRankLanesMax = 4;
 static std::atomic<u32> g_rank_lanes{2};   // ranking lanes of a stream that enqueues (1 .. 4): chains of consecutive batches that run side by side
 static std::atomic<u32> g_rare_hash_genomes{1024};   // rare-hash index of a reference: hashes held by at most this many genomes get genome lists (0 = no index)
+static std::atomic<u32> g_reuse_membership{0};   // references with a static dense dictionary: 1 = a stream scans the reference ONCE per buffer set and keeps the rows
 static std::atomic<u64> g_comm_timeout_ms{0};  // watchdog of skx_comm_create / skx_stream_allreduce: 0 = none (block for ever, as RCCL does)
 
 SKX_API int skx_set_option(const char* name, uint64_t value) {
@@ -214,6 +215,11 @@ SKX_API int skx_set_option(const char* name, uint64_t value) {
         g_rare_hash_genomes = (u32)value;
         return SKX_OK;
     }
+    if (!strcmp(name, "reuse_membership")) {
+        if (value > 1) return fail(SKX_ERR_INVALID, "reuse_membership must be 0 (every pass scans the reference) or 1 (static dense rows are kept)");
+        g_reuse_membership = (u32)value;
+        return SKX_OK;
+    }
     if (!strcmp(name, "comm_timeout_ms")) {
         if (value > 86400000ull) return fail(SKX_ERR_INVALID, "comm_timeout_ms must be 0 (no watchdog) .. 86400000");
         g_comm_timeout_ms = value;
@@ -230,6 +236,7 @@ SKX_API int skx_get_option(const char* name, uint64_t* value) {
     if (!strcmp(name, "comm_timeout_ms")) { *value = g_comm_timeout_ms; return SKX_OK; }
     if (!strcmp(name, "rank_lanes")) { *value = g_rank_lanes; return SKX_OK; }
     if (!strcmp(name, "rare_hash_genomes")) { *value = g_rare_hash_genomes; return SKX_OK; }
+    if (!strcmp(name, "reuse_membership")) { *value = g_reuse_membership; return SKX_OK; }
     return fail(SKX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -1057,6 +1064,11 @@ struct skx_stream {
     bool static_dense = false;
     u64* d_ms[2] = {nullptr, nullptr};
     bool m_ready[2] = {false, false};  // a scan into d_ms[b] is queued (or done) and nobody has consumed it yet
+    // policy "reuse_membership" (off by default): the static dense rows of M depend on the reference alone, so a stream may scan the
+    // reference once per buffer set and keep them -- no pass streams the 8 x s x N bytes again.  NOT what SURVEY 8(d)'s roofline figure
+    // assumes (one scan of the reference per scoring pass): bench.py reports it as a side leg, `value` keeps scanning every pass.
+    bool reuse_m = false;
+    bool m_filled[2] = {false, false};
     u32* d_mdirty_s = nullptr;         // (a word for the early scan's "M was written" flag: nobody reads it)
     u32 sd64 = 0;                      // static dense rows, rounded up to 64: the rare rows of a pass start there
     u32 qhash_cap() const { return qcap - sd64; }  // distinct query hashes a pass's matrices hold beside the static rows
@@ -1553,6 +1565,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
                 SCHK(hipMemset(st->d_ms[i], 0, (size_t)(sd64 / 64 + 2) * n_pad * 8));  // all-zero until a scan fills it; the pass that consumes it zeroes it again
             }
             SCHK(hipMalloc(&st->d_mdirty_s, 64));
+            st->reuse_m = g_reuse_membership.load() != 0;
         } else {
             SCHK(hipMalloc(&st->d_m, (size_t)(st->qcap / 64 + 2) * n_pad * 8));
             SCHK(hipMemset(st->d_m, 0, (size_t)(st->qcap / 64 + 2) * n_pad * 8));      // kept all-zero between passes
@@ -1872,6 +1885,8 @@ static int queue_static_scan(skx_stream* st, int b) {
     const skx_ref* ref = st->ref;
     st->m_ready[b] = true;
     if (ref->n_sd == 0) return SKX_OK;  // (every hash of the reference is rare: nothing to scan for)
+    if (st->reuse_m && st->m_filled[b]) return SKX_OK;  // (policy reuse_membership: the rows of an earlier scan were kept)
+    st->m_filled[b] = true;
     {
         Span sp(st, 2, st->hs);
         skx::launch_scan(st->hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, ref->d_qs, ref->d_win_s, st->d_ms[b], nullptr, ref->n_pad,
@@ -2241,10 +2256,11 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         {
             Span sp(st, 3, hs);
             skx::launch_transpose_bits(hs, d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, direct_rare ? d_nd + 2 : d_nd + 3, d_grp_any,
-                                       nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, direct_rare ? nd_est : nq_est, st->d_rowany[b], only_if);
+                                       nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, direct_rare ? nd_est : nq_est, st->d_rowany[b], only_if,
+                                       sdm && st->reuse_m);
             if (direct_rare)
                 skx::launch_rare_to_mq(hs, st->d_sslot, d_nd, st->rare_index(), d_mq, nq_rows, n_pad, st->d_rowany[b], d_grp_any, q_bound, only_if);
-            if (only_if) skx::launch_m_clear(hs, d_m, split ? st->d_mint : nullptr, n_pad, d_nd, only_if);
+            if (only_if && !(sdm && st->reuse_m)) skx::launch_m_clear(hs, d_m, split ? st->d_mint : nullptr, n_pad, d_nd, only_if);
         }
         if (sdm) st->m_ready[b] = false;  // (consumed: transposed -- which zeroes what it reads -- or cleared)
     }
@@ -2734,8 +2750,8 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     // their dictionary
     bool early_scan = false;
     if (st->static_dense && pb.gi == 0 && ref->n_sd && !st->m_ready[pb.spec_set]) {
+        early_scan = !(st->reuse_m && st->m_filled[pb.spec_set]);  // (a scan really goes out beside this sketch)
         SKXCHK(queue_static_scan(st, pb.spec_set));
-        early_scan = true;
     }
     if (st->chk_dirty[pb.side]) {  // the batch that last used this set failed between arming and publishing: nothing re-armed its counters
         HIPCHK(hipMemsetAsync(st->d_chk, 0, (size_t)skx::chk_words() * 4, hs));  // (the whole block: the pool's bump counters sit behind word 16)
@@ -3462,7 +3478,7 @@ SKX_API int skx_stream_scan_alone(skx_stream* st, uint32_t reps, double* ms_avg)
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    st->m_ready[b] = true;
+    st->m_ready[b] = true; st->m_filled[b] = true;
     *ms_avg = (double)ms / reps;
     return SKX_OK;
 }

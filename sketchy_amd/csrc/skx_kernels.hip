@@ -2643,7 +2643,7 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
                                                              const u64* __restrict__ hbuf, const u32* __restrict__ wb,
                                                              const u32* __restrict__ win, u32 n_tiles,
                                                              const u32* __restrict__ m_dirty, u64* __restrict__ rowany,
-                                                             const u32* __restrict__ only_if) {
+                                                             const u32* __restrict__ only_if, u32 keep_m) {
     __builtin_amdgcn_s_setprio(2);  // short / latency-bound link of a chain: do not queue behind the VALU-bound kernels beside it
     if (only_if && !*only_if) return;  // (every batch of the pass ranks on its candidates' compact matrix: nobody reads this one)
     __shared__ u64 tile[2][64][kRankWords + 1];
@@ -2670,7 +2670,7 @@ __global__ __launch_bounds__(256) void transpose_bits_kernel(u64* __restrict__ m
         u64 x = 0;
         if (read_m) {
             x = m_bits[(size_t)w * n_pad + col];
-            if (x) m_bits[(size_t)w * n_pad + col] = 0;
+            if (x && !keep_m) m_bits[(size_t)w * n_pad + col] = 0;  // (keep_m: the static dense rows, kept for the passes to come)
             if (m_int) {
                 const u64 y = m_int[(size_t)w * n_pad + col];
                 if (y) { m_int[(size_t)w * n_pad + col] = 0; x |= y; }
@@ -5269,14 +5269,14 @@ void launch_scan(hipStream_t st, const u64* mat, u32 s, u32 n_tiles, u32 rb, u32
 }
 void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u32 n_words, u64* mq, const u32* n_q, u32* grp_any,
                            const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles, const u32* m_dirty, u64 nq_est, u64* rowany,
-                           const u32* only_if) {
+                           const u32* only_if, bool keep_m) {
     if (n_words == 0) return;
     const u32 n_gw = n_pad / 64;
     // y extent: twice the estimated dictionary size (the blocks stride, see the kernel), at most what the pairs allow
     const u32 y_all = cdiv(n_words, kWordsPerBlock);
     const u32 y_est = (u32)std::min<u64>(y_all, std::max<u64>(16, cdiv((u32)std::min<u64>(2 * nq_est / 64 + 1, 0xFFFFFFF0u), kWordsPerBlock)));
     hipLaunchKernelGGL(transpose_bits_kernel, dim3(cdiv(n_gw, kRankWords), std::min(y_est, 65535u)), dim3(256), 0, st,
-                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty, rowany, only_if);
+                       m_bits, m_int, n_pad, n_words, mq, n_gw, n_q, grp_any, hbuf, wb, win, n_tiles, m_dirty, rowany, only_if, keep_m ? 1u : 0u);
 }
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_bases, u32* chk, u32* cnt_tail, const LongReads* long_reads) {
     const LongReads lr = long_reads ? *long_reads : LongReads{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};

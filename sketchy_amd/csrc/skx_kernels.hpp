@@ -265,7 +265,8 @@ void launch_transpose_bits(hipStream_t st, u64* m_bits, u64* m_int, u32 n_pad, u
                            const u32* n_q, u32* grp_any, const u64* hbuf, const u32* wb, const u32* win, u32 n_tiles,
                            const u32* m_dirty, u64 nq_est /* the host's estimate of the dictionary size: sizes the grid */,
                            u64* rowany /* [rank groups][n_words]: bit r of word w = row 64 w + r holds a bit in the group; or NULL */,
-                           const u32* only_if = nullptr /* device flag: run only when it is non-zero */);
+                           const u32* only_if = nullptr /* device flag: run only when it is non-zero */,
+                           bool keep_m = false /* do NOT re-zero m_bits (static dense rows kept for later passes: policy reuse_membership) */);
 // chk[0..5], [9] (zero on entry): non-monotonic marker, long-read count, offsets[0], offsets[n_reads], segment count;
 // long_reads != NULL: also lists the batch's long reads and their segments (chk[6] |= 2 if they do not fit the tables)
 void launch_batch_check(hipStream_t st, const u64* offsets, u32 n_reads, u64 n_bases, u32* chk, u32* cnt_tail /* zeroed */,

@@ -71,9 +71,11 @@ def test_every_row_of_full_batches_at_the_head_and_mid_stream(c2):
     from oracle import oracle as orc
     from sketchy_amd import api
     R, ref, bases, offsets = c2["R"], c2["ref"], c2["bases"], c2["offsets"]
+    free0, _ = api.device_mem(0)
     S = api.SumOfSharedHashes(R, top=1, max_batch_reads=B, max_batch_bases=int(np.max(offsets[B::B] - offsets[:-B:B])))
     d_b = api.DeviceBuffer.from_numpy(bases)
     bufs = []
+    stream_bytes = None
     try:
         for i in range(N_BATCHES):
             a = i * B
@@ -84,6 +86,10 @@ def test_every_row_of_full_batches_at_the_head_and_mid_stream(c2):
         S.sync()
         st = S.stats()
         assert st["passes_shared"] >= 2 and st["groups_unshared"] == 0, st     # the batches really shared their passes
+        # footprint of the stream after its matrices have grown to what this workload needs (the buffers of this test are not the stream's)
+        free1, _ = api.device_mem(0)
+        own = len(bases) + sum(x.nbytes for t in bufs for x in t)
+        stream_bytes = free0 - free1 - own
         got = {i: (bufs[i][1].to_numpy(np.uint32, (B, 1)), bufs[i][2].to_numpy(np.uint64, (B, 1))) for i in ROW_BATCHES}
         table = S.table()
     finally:
@@ -92,6 +98,17 @@ def test_every_row_of_full_batches_at_the_head_and_mid_stream(c2):
             for x in t:
                 x.free()
         S.close()
+    # Footprint at C2 (SURVEY 8(d) reference: 893 k distinct hashes, 161 k distinct query hashes per batch -- the matrices' rows grow to ~1 M):
+    # reference = the 3.2 GB matrix + the rare-hash index (lists, bit rows, their transpose, patterns); stream: round 5 held M (7.6 GB at
+    # 1.2 M rows) + 2 x Mq + per-row arrays, ~25-30 GB with the index.  Since round 6 M holds the reference's static dense rows only
+    # (2 x 52 MB): the stream's bound is the two group-major matrices.  Stated bounds: index + patterns <= 3.5 GB, one stream <= 16 GB
+    # (SNP reference) / 8 GB (pool reference).
+    ri, pt = R.rare_index, R.patterns
+    print(f"{c2['mode']}: footprint: matrix {R.pass_bytes / 2**30:.2f} GiB, rare-hash index {ri['bytes'] / 2**30:.2f} GiB, patterns "
+          f"{pt['bytes'] / 2**30:.3f} GiB ({pt['pattern_lists']} of {pt['long_lists']} long lists, {pt['patterns']} patterns), static dense "
+          f"{R.static_dense}, stream {stream_bytes / 2**30:.2f} GiB, query rows {st['query_rows']}")
+    assert ri["bytes"] + pt["bytes"] <= 3.5 * 2**30
+    assert stream_bytes <= (16 if c2["mode"] == "snp" else 8) * 2**30, stream_bytes
     cum = None
     pairs = 0
     for i in range(N_BATCHES):

@@ -63,12 +63,18 @@ def test_most_long_lists_are_stored_as_patterns(snp):
     assert p["pattern_lists"] >= 0.8 * p["long_lists"]    # tools/diag_patterns.py: 97 % within 14 genomes of their lineage's list
 
 
-@pytest.mark.parametrize("top", [1, 3])
-def test_rows_and_table_through_shared_passes(snp, top):
+@pytest.mark.parametrize("top,reuse", [(1, 0), (3, 0), (1, 1)])
+def test_rows_and_table_through_shared_passes(snp, top, reuse):
+    """(reuse = 1: policy "reuse_membership" -- the static dense rows of M are scanned for once per buffer set and kept)"""
     from oracle import oracle as orc
     from sketchy_amd import api
     R, ref, bases, offsets = snp["R"], snp["ref"], snp["bases"], snp["offsets"]
-    S = api.SumOfSharedHashes(R, top=top, max_batch_reads=B, max_batch_bases=int(np.max(offsets[B::B] - offsets[:-B:B])))
+    assert R.static_dense[0] and R.static_dense[1] > 100     # 6 000 genomes: the hashes of the common ancestor are held by more than 1 024
+    api.set_option("reuse_membership", reuse)
+    try:
+        S = api.SumOfSharedHashes(R, top=top, max_batch_reads=B, max_batch_bases=int(np.max(offsets[B::B] - offsets[:-B:B])))
+    finally:
+        api.set_option("reuse_membership", 0)
     d_b = api.DeviceBuffer.from_numpy(bases)
     bufs = []
     try:
