@@ -1887,10 +1887,13 @@ static int queue_static_scan(skx_stream* st, int b) {
     if (ref->n_sd == 0) return SKX_OK;  // (every hash of the reference is rare: nothing to scan for)
     if (st->reuse_m && st->m_filled[b]) return SKX_OK;  // (policy reuse_membership: the rows of an earlier scan were kept)
     st->m_filled[b] = true;
+    // (experiment knob SKX_SCAN_BIGSLICE=1, with SKX_RB=128: the lean kernel's instance for slices of up to 510 entries over bands of 128
+    // rows = TWO of the default bands per workgroup, one result tile, every word flushed once per pair of bands)
+    static const bool big_slices = skx::knob("SKX_SCAN_BIGSLICE") && atoi(skx::knob("SKX_SCAN_BIGSLICE")) != 0;
     {
         Span sp(st, 2, st->hs);
         skx::launch_scan(st->hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, ref->d_qs, ref->d_win_s, st->d_ms[b], nullptr, ref->n_pad,
-                         false, true, nullptr, st->d_mdirty_s, true, 0u, false);
+                         false, true, nullptr, st->d_mdirty_s, true, 0u, big_slices);
     }
     {
         Span sp(st, 1, st->hs);
@@ -3468,9 +3471,10 @@ SKX_API int skx_stream_scan_alone(skx_stream* st, uint32_t reps, double* ms_avg)
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, st->hs));
+    static const bool big_slices = skx::knob("SKX_SCAN_BIGSLICE") && atoi(skx::knob("SKX_SCAN_BIGSLICE")) != 0;  // (experiment knob, as queue_static_scan)
     for (uint32_t i = 0; i < reps; ++i)
         skx::launch_scan(st->hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, ref->d_qs, ref->d_win_s, st->d_ms[b], nullptr, ref->n_pad,
-                         false, true, nullptr, st->d_mdirty_s, true, 0u, false);
+                         false, true, nullptr, st->d_mdirty_s, true, 0u, big_slices);
     HIPCHK(hipEventRecord(e1, st->hs));
     skx::launch_exceptions(st->hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, ref->d_qs, ref->d_nsd, st->d_ms[b], ref->n_pad, st->d_mdirty_s, nullptr);
     HIPCHK(hipGetLastError());
