@@ -291,10 +291,17 @@ struct skx_ref {
     u32* d_win_s = nullptr;   // [n_bands * n_tiles][2] its slice per (band, tile)
     u32 n_sd = 0;
     bool static_dense = false;
+    // (several species: the dictionary is the species' sorted segments one after the other -- a tile of species A only needs A's hashes:
+    // slices of ~200 entries again instead of ~1 000, the lean scan kernel instead of the dense-dictionary one)
+    u32* d_srow = nullptr;    // [key-table slots] row of a dense hash
+    u32* d_seg = nullptr;     // [2 n_species] first row / hashes of every species' segment
+    u32* d_segw = nullptr;    // [2 n_species] the words of M that hold them
+    u32 sd_tail0 = 0;         // first row of the lifted hashes (sorted tail)
+    u64 n_forced_rare = 0;    // hashes held by more genomes than rare_hash_genomes that got a list anyway: they occur in several species
     skx::RareIndex rare_index() const {
         skx::RareIndex ri{d_kt_key, d_kt_off, d_kt_cnt, d_post, kt_mask, d_mlong, d_lid, d_lslot, n_pad / 64, d_mlongT, n_lw};
         ri.prec = d_prec; ri.pat_rep = d_pat_rep; ri.pm = d_pm; ri.d_npat = d_npat; ri.n_pat = n_pat;
-        if (static_dense) { ri.qs = d_qs; ri.n_sd = n_sd; }
+        if (static_dense) { ri.qs = d_qs; ri.n_sd = n_sd; ri.srow = d_srow; ri.tail0 = sd_tail0; }
         return ri;
     }
     skx::KmerFilter kmer_filter() const { return skx::KmerFilter{d_kf, kf_shift}; }
@@ -311,6 +318,7 @@ static void ref_free(skx_ref* r) {
     (void)hipFree(r->d_mlong); (void)hipFree(r->d_mlongT); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot);
     (void)hipFree(r->d_prec); (void)hipFree(r->d_pat_rep); (void)hipFree(r->d_npat); (void)hipFree(r->d_pm);
     (void)hipFree(r->d_qs); (void)hipFree(r->d_nsd); (void)hipFree(r->d_win_s);
+    (void)hipFree(r->d_srow); (void)hipFree(r->d_seg); (void)hipFree(r->d_segw);
     delete r;
 }
 
@@ -405,54 +413,82 @@ static void build_patterns(skx_ref* r) {
 // batch used to run sketch -> dictionary -> scan -> ranking strictly one after the other.  The scan still streams 8 x s x N bytes
 // per pass.  Needs: the index; every rare row's bits obtainable without M (rare_direct); few enough dense hashes for the lean scan
 // kernel's slices.  Else the reference keeps per-pass dictionaries, as in rounds 1-5.
-static void build_static_dense(skx_ref* r, const std::vector<u64>& exc_h) {
+static void build_static_dense(skx_ref* r, const std::vector<u64>& exc_h, const std::vector<u64>* spmask) {
     static const int sd_env = skx::knob("SKX_STATIC_DENSE") ? atoi(skx::knob("SKX_STATIC_DENSE")) : 1;  // experiment knob: 0 = per-pass dictionaries
     if (!sd_env || !r->d_kt_key || !r->rare_direct) return;
     const u64 slots = (u64)r->kt_mask + 1;
-    // (the lean kernel's one-pass probe takes slices of 254 entries; a (band, tile) slice holds ~3.1 x rows per band x |Q| / s of them.
-    // Beyond ~190 entries per band's worth the host would pick the split / big-table variants: such references keep per-pass dictionaries)
-    const u64 cap = std::min<u64>(65536, (u64)191 * r->s / std::max<u32>(r->rb, 1u));
+    const u32 n_sp = r->n_species;
+    // (the lean kernel's one-pass probe takes slices of 254 entries; a (band, tile) slice holds ~3.1 x rows per band x |Q of its species| / s
+    // of them.  Beyond ~190 entries per band's worth the host would pick the split / big-table variants: such references keep per-pass
+    // dictionaries)
+    const u64 cap_sp = (u64)191 * r->s / std::max<u32>(r->rb, 1u), cap = std::min<u64>(131072, cap_sp * n_sp);
     u64* d_keys = nullptr;
-    u32* d_n = nullptr;
-    bool ok = cap >= 1 && hipMalloc(&d_keys, (cap + 1) * 8) == hipSuccess && hipMalloc(&d_n, 4) == hipSuccess && hipMemset(d_n, 0, 4) == hipSuccess;
+    u32 *d_slots = nullptr, *d_n = nullptr;
+    bool ok = cap >= 1 && hipMalloc(&d_keys, (cap + 1) * 8) == hipSuccess && hipMalloc(&d_slots, (cap + 1) * 4) == hipSuccess &&
+              hipMalloc(&d_n, 4) == hipSuccess && hipMemset(d_n, 0, 4) == hipSuccess;
     u32 n = 0;
     if (ok) {
-        skx::launch_collect_dense(nullptr, r->d_kt_key, r->d_kt_off, slots, d_keys, d_n, (u32)cap);
-        ok = hipGetLastError() == hipSuccess && hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost) == hipSuccess;
+        skx::launch_collect_dense(nullptr, r->d_kt_key, r->d_kt_off, slots, d_keys, d_slots, d_n, (u32)cap);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost) == hipSuccess && n <= cap;
     }
-    std::vector<u64> qs;
-    if (ok) {
-        std::vector<u64> ex(exc_h);  // the lifted hashes ride with the dense rows (exceptions_kernel sets their bits)
+    std::vector<u64> keys(n);
+    std::vector<u32> kslot(n);
+    ok = ok && (n == 0 || (hipMemcpy(keys.data(), d_keys, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                           hipMemcpy(kslot.data(), d_slots, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess));
+    (void)hipFree(d_keys); (void)hipFree(d_slots); (void)hipFree(d_n);
+    if (!ok) { (void)hipGetLastError(); return; }
+    try {
+        // every dense hash into its species' segment (a hash that several species hold was given a list by the index build: none is left here)
+        std::vector<std::vector<std::pair<u64, u32>>> per(n_sp);
+        for (u32 i = 0; i < n; ++i) {
+            u32 sp = 0;
+            if (n_sp > 1) {
+                const u64 m = spmask ? (*spmask)[kslot[i]] : 0;
+                if (m == 0 || (m & (m - 1)) != 0) return;  // (held by several species and too widely for a list: per-pass dictionaries)
+                sp = (u32)__builtin_ctzll(m);
+            }
+            per[sp].push_back({keys[i], kslot[i]});
+        }
+        std::vector<u64> ex(exc_h);  // the lifted hashes ride with the dense rows (exceptions_kernel sets their bits): sorted tail
         std::sort(ex.begin(), ex.end());
         ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
-        ok = (u64)n + ex.size() <= cap;
-        if (ok) {
-            qs.resize(n);
-            ok = n == 0 || hipMemcpy(qs.data(), d_keys, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess;
-            qs.insert(qs.end(), ex.begin(), ex.end());
-            std::sort(qs.begin(), qs.end());
+        std::vector<u32> seg(2 * n_sp), segw(2 * n_sp);
+        u32 row = 0;
+        for (u32 sp = 0; sp < n_sp; ++sp) {
+            if (per[sp].size() > cap_sp) return;
+            std::sort(per[sp].begin(), per[sp].end());
+            seg[2 * sp] = row; seg[2 * sp + 1] = (u32)per[sp].size();
+            segw[2 * sp] = row / 64; segw[2 * sp + 1] = (row + (u32)per[sp].size() + 63) / 64;
+            row = (row + (u32)per[sp].size() + 63u) & ~63u;
         }
-    }
-    (void)hipFree(d_keys); (void)hipFree(d_n);
-    if (!ok) { (void)hipGetLastError(); return; }
-    const u32 n_sd = (u32)qs.size(), n_bt = r->n_bands * r->n_tiles;
-    const u32 words[4] = {n_sd, 0u, (n_sd + 63u) & ~63u, n_sd};
-    ok = hipMalloc(&r->d_qs, std::max<size_t>(n_sd, 1) * 8) == hipSuccess && hipMalloc(&r->d_nsd, 16) == hipSuccess &&
-         hipMalloc(&r->d_win_s, (size_t)n_bt * 8) == hipSuccess &&
-         (n_sd == 0 || hipMemcpy(r->d_qs, qs.data(), (size_t)n_sd * 8, hipMemcpyHostToDevice) == hipSuccess) &&
-         hipMemcpy(r->d_nsd, words, 16, hipMemcpyHostToDevice) == hipSuccess;
-    if (ok) {
-        skx::launch_window(nullptr, r->d_lo, r->d_hi, n_bt, r->d_qs, r->d_nsd, r->d_win_s, nullptr);
-        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-    }
+        // (the tail starts on the word boundary behind the last segment; without lifted hashes the dictionary ends with the last segment's last hash)
+        const u32 t0 = row, n_sd = ex.empty() ? (n_sp ? seg[2 * (n_sp - 1)] + seg[2 * (n_sp - 1) + 1] : 0u) : t0 + (u32)ex.size();
+        std::vector<u64> qs(std::max<u32>(n_sd, 1u), 0xFFFFFFFFFFFFFFFFull);   // (padding between the segments: all-ones, inside no window)
+        std::vector<u32> srow(slots, 0xFFFFFFFFu);
+        for (u32 sp = 0; sp < n_sp; ++sp)
+            for (u32 i = 0; i < per[sp].size(); ++i) { qs[seg[2 * sp] + i] = per[sp][i].first; srow[per[sp][i].second] = seg[2 * sp] + i; }
+        for (u32 i = 0; i < ex.size(); ++i) qs[t0 + i] = ex[i];
+        const u32 n_bt = r->n_bands * r->n_tiles;
+        const u32 words[4] = {n_sd, 0u, (n_sd + 63u) & ~63u, n_sd};
+        ok = hipMalloc(&r->d_qs, (size_t)qs.size() * 8) == hipSuccess && hipMalloc(&r->d_nsd, 16) == hipSuccess &&
+             hipMalloc(&r->d_win_s, (size_t)n_bt * 8) == hipSuccess && hipMalloc(&r->d_srow, (size_t)slots * 4) == hipSuccess &&
+             hipMalloc(&r->d_seg, (size_t)2 * n_sp * 4) == hipSuccess && hipMalloc(&r->d_segw, (size_t)2 * n_sp * 4) == hipSuccess &&
+             hipMemcpy(r->d_qs, qs.data(), qs.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(r->d_srow, srow.data(), (size_t)slots * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(r->d_seg, seg.data(), (size_t)2 * n_sp * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(r->d_segw, segw.data(), (size_t)2 * n_sp * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(r->d_nsd, words, 16, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) {
+            skx::launch_window_seg(nullptr, r->d_lo, r->d_hi, n_bt, r->n_tiles, r->d_qs, r->d_seg, r->d_grp_sp, r->d_win_s);
+            ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        }
+        if (ok) { r->n_sd = n_sd; r->sd_tail0 = t0; r->static_dense = true; }
+    } catch (const std::bad_alloc&) { ok = false; }
     if (!ok) {
-        (void)hipFree(r->d_qs); (void)hipFree(r->d_nsd); (void)hipFree(r->d_win_s);
-        r->d_qs = nullptr; r->d_nsd = r->d_win_s = nullptr;
+        (void)hipFree(r->d_qs); (void)hipFree(r->d_nsd); (void)hipFree(r->d_win_s); (void)hipFree(r->d_srow); (void)hipFree(r->d_seg); (void)hipFree(r->d_segw);
+        r->d_qs = nullptr; r->d_nsd = r->d_win_s = r->d_srow = r->d_seg = r->d_segw = nullptr;
         (void)hipGetLastError();
-        return;
     }
-    r->n_sd = n_sd;
-    r->static_dense = true;
 }
 
 SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t seed, uint32_t s_read, uint32_t stride,
@@ -637,6 +673,7 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
             while (slots < (u64)((double)r->n_distinct * 1.6) + 1024) slots <<= 1;
             u32* d_over = nullptr;
             u32* d_cursor = nullptr;
+            u64* d_spm = nullptr;
             auto drop = [&]() {
                 (void)hipFree(r->d_kt_key); (void)hipFree(r->d_kt_cnt); (void)hipFree(r->d_kt_off); (void)hipFree(r->d_post);
                 r->d_kt_key = nullptr; r->d_kt_cnt = r->d_kt_off = r->d_post = nullptr;
@@ -648,23 +685,33 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                 ok = hipMalloc(&r->d_kt_key, slots * 8) == hipSuccess && hipMalloc(&r->d_kt_cnt, slots * 4) == hipSuccess &&
                      hipMemset(r->d_kt_key, 0xFF, slots * 8) == hipSuccess && hipMemset(r->d_kt_cnt, 0, slots * 4) == hipSuccess &&
                      hipMemset(d_over, 0, 4) == hipSuccess;
+                // (several species: which of them hold a key -- a hash many genomes of SEVERAL species hold gets a list whatever its
+                // count, so that every hash left to the scan belongs to one species: build_static_dense)
+                if (ok && n_species > 1) ok = hipMalloc(&d_spm, slots * 8) == hipSuccess && hipMemset(d_spm, 0, slots * 8) == hipSuccess;
                 if (!ok) break;
-                skx::launch_rare_count(nullptr, r->d_mat, mat_elems, r->d_kt_key, r->d_kt_cnt, (u32)(slots - 1), d_over);
+                skx::launch_rare_count(nullptr, r->d_mat, mat_elems, r->d_kt_key, r->d_kt_cnt, (u32)(slots - 1), d_over, d_spm, r->d_grp_sp, s);
                 u32 over = 0;
                 ok = hipGetLastError() == hipSuccess && hipMemcpy(&over, d_over, 4, hipMemcpyDeviceToHost) == hipSuccess;
                 if (ok && !over) break;
                 drop();  // (the distinct count was an estimate: twice the slots)
+                (void)hipFree(d_spm); d_spm = nullptr;
                 if (attempt == 3) ok = false;
             }
+            std::vector<u64> spm;
             if (ok && r->d_kt_key) try {
                 std::vector<u32> cnt(slots), off(slots);
                 ok = hipMemcpy(cnt.data(), r->d_kt_cnt, slots * 4, hipMemcpyDeviceToHost) == hipSuccess;
-                u64 total = 0, keys = 0, rare = 0, long_keys = 0;
+                if (ok && d_spm) { spm.resize(slots); ok = hipMemcpy(spm.data(), d_spm, slots * 8, hipMemcpyDeviceToHost) == hipSuccess; }
+                (void)hipFree(d_spm); d_spm = nullptr;
+                u64 total = 0, keys = 0, rare = 0, long_keys = 0, forced = 0;
                 for (u64 i = 0; ok && i < slots; ++i) {
-                    if (cnt[i] && cnt[i] <= rare_max) { off[i] = (u32)total; total += cnt[i]; ++rare; long_keys += cnt[i] > 8u ? 1 : 0; }
+                    // (a hash of several species: listed up to 2^18 genomes; a handful at k = 16 -- unrelated species share ~0.1 % of their k-mers)
+                    const bool multi = !spm.empty() && (spm[i] & (spm[i] - 1)) != 0 && cnt[i] > rare_max && cnt[i] <= (1u << 18);
+                    if (cnt[i] && (cnt[i] <= rare_max || multi)) { off[i] = (u32)total; total += cnt[i]; ++rare; long_keys += cnt[i] > 8u ? 1 : 0; forced += multi ? 1 : 0; }
                     else off[i] = 0xFFFFFFFFu;
                     keys += cnt[i] ? 1 : 0;
                 }
+                r->n_forced_rare = forced;
                 ok = ok && total < 0xFFFFFFF0ull;
                 ok = ok && hipMalloc(&r->d_kt_off, slots * 4) == hipSuccess && hipMalloc(&r->d_post, std::max<u64>(total, 1) * 4) == hipSuccess &&
                      hipMalloc(&d_cursor, slots * 4) == hipSuccess && hipMemset(d_cursor, 0, slots * 4) == hipSuccess &&
@@ -720,8 +767,9 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                 ok = false;
             }
             (void)hipFree(d_over); (void)hipFree(d_cursor);
+            (void)hipFree(d_spm);
             if (!ok) { drop(); r->rare_direct = false; }
-            else build_static_dense(r, exc_h);
+            else build_static_dense(r, exc_h, spm.empty() ? nullptr : &spm);
         }
     }
     const u32 pf_mode = skx::knob("SKX_KMER_PREFILTER") ? (u32)atoi(skx::knob("SKX_KMER_PREFILTER")) : g_kmer_prefilter.load();  // (experiment knob overrides the policy)
@@ -1418,6 +1466,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     st->pcap = (u32)pc;
     const u32 rows_policy = g_stream_query_rows.load();
     u64 qc = rows_policy ? rows_policy : 65536;
+    if (!rows_policy && ref->static_dense) qc += (ref->n_sd + 63u) & ~63u;  // (the static dense rows come on top of the distinct hashes of a pass)
     if (dense_queries) {
         size_t mem_free = 0, mem_total = 0;
         (void)hipMemGetInfo(&mem_free, &mem_total);
@@ -1557,7 +1606,7 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     // (rows: qcap + 128 -- the rows behind the dense ones start on a word boundary, a pass of qcap hashes can reach 63 rows further)
     {
         const u32 sd64 = (ref->n_sd + 63u) & ~63u;
-        st->static_dense = ref->static_dense && (u64)2 * sd64 + 128 <= st->qcap;
+        st->static_dense = ref->static_dense && (u64)sd64 + 1024 <= st->qcap;
         if (st->static_dense) {
             st->sd64 = sd64;
             for (int i = 0; i < 2; ++i) {
@@ -1897,7 +1946,8 @@ static int queue_static_scan(skx_stream* st, int b) {
     }
     {
         Span sp(st, 1, st->hs);
-        skx::launch_exceptions(st->hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, ref->d_qs, ref->d_nsd, st->d_ms[b], ref->n_pad, st->d_mdirty_s, nullptr);
+        skx::launch_exceptions(st->hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, ref->d_qs + ref->sd_tail0, nullptr, st->d_ms[b], ref->n_pad, st->d_mdirty_s, nullptr,
+                               ref->sd_tail0, ref->n_sd - ref->sd_tail0);
     }
     HIPCHK(hipGetLastError());
     return SKX_OK;
@@ -2071,7 +2121,10 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     static const int cand_env0 = skx::knob("SKX_CAND") ? atoi(skx::knob("SKX_CAND")) : 1;
     // (... and the FIRST pass of a sample: on a table of zeros every genome of a species is a candidate of the first batch, whatever
     // follows -- with more genomes than a compact ranking takes, the pass that would only find that out is not worth its wait)
-    const bool fresh_overflow = st->fresh_table && ref->max_species > skx::kCandCap;
+    // (top_k >= 2: the full top-k ranking of a batch costs several times the top-1's -- there the pass that finds out that batches 3, 4, ...
+    // of a sample already have a leader is worth its wait: --top 16 on the truth-strain stream 34.1 -> 41.8 M reads/s from a fresh table,
+    // top-1 100.8 against 101.3 M)
+    const bool fresh_overflow = st->fresh_table && ref->max_species > skx::kCandCap && st->top_k <= 1;
     // (the SECOND pass of a sample goes by a count from the second half of the first pass -- the first batches of ANY sample say
     // "everything" -- and looks for itself when none has arrived yet)
     const bool second_blind = st->passes_since_fresh == 1 && !((int)(st->lcount_seen - st->lcount_floor) > 0);
@@ -2184,7 +2237,8 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
         HIPCHK(hipMemsetAsync(st->d_gain, 0, (size_t)n_sub * n_pad * 4, hs));
         if (P > 0) {
             SKXCHK(row_counts());
-            skx::launch_gain_dense(hs, d_m, m_int, n_pad, d_nd, sdm ? ref->n_sd : q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain);
+            skx::launch_gain_dense(hs, d_m, m_int, n_pad, d_nd, sdm ? ref->n_sd : q_bound, st->d_rowcnt, qstride, (u32)n_sub, st->d_gain,
+                                   (sdm && ref->n_species > 1) ? ref->d_segw : nullptr, ref->d_grp_sp);
             if (split_dict) SKXCHK(rare_gains(hs));
         }
         skx::launch_pass_tables(hs, st->d_cum, st->d_gain, (split_dict && P > 0) ? st->d_gain_s : nullptr,
@@ -3476,7 +3530,8 @@ SKX_API int skx_stream_scan_alone(skx_stream* st, uint32_t reps, double* ms_avg)
         skx::launch_scan(st->hs, ref->d_mat, ref->s, ref->n_tiles, ref->rb, ref->n_bands, ref->d_qs, ref->d_win_s, st->d_ms[b], nullptr, ref->n_pad,
                          false, true, nullptr, st->d_mdirty_s, true, 0u, big_slices);
     HIPCHK(hipEventRecord(e1, st->hs));
-    skx::launch_exceptions(st->hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, ref->d_qs, ref->d_nsd, st->d_ms[b], ref->n_pad, st->d_mdirty_s, nullptr);
+    skx::launch_exceptions(st->hs, ref->d_exc_g, ref->d_exc_h, ref->n_exc, ref->d_qs + ref->sd_tail0, nullptr, st->d_ms[b], ref->n_pad, st->d_mdirty_s, nullptr,
+                           ref->sd_tail0, ref->n_sd - ref->sd_tail0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st->hs));
     float ms = 0;

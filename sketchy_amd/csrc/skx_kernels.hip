@@ -1589,12 +1589,13 @@ __global__ void window_kernel(const u64* __restrict__ lo, const u64* __restrict_
 // markers); set their bits here.  exc_g / exc_h: (genome, hash) pairs.
 __global__ void exceptions_kernel(const u32* __restrict__ exc_g, const u64* __restrict__ exc_h, u32 n_exc,
                                   const u64* __restrict__ q, const u32* __restrict__ n_q, u64* __restrict__ m_bits,
-                                  u32 n_pad, u32* __restrict__ m_dirty, const u32* __restrict__ qrow) {
+                                  u32 n_pad, u32* __restrict__ m_dirty, const u32* __restrict__ qrow, u32 row0, u32 n_fixed) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_exc) return;
-    const u32 nq = *n_q;
+    const u32 nq = n_q ? *n_q : n_fixed;  // (static dictionary: q = its tail of lifted hashes, n_fixed of them, rows from row0 on)
     u32 pos = lower_bound_u64(q, nq, exc_h[e]);
     if (pos < nq && q[pos] == exc_h[e]) {
+        pos += row0;
         if (qrow) pos = qrow[pos];
         atomicOr(&m_bits[(size_t)(pos >> 6) * n_pad + exc_g[e]], 1ull << (pos & 63u));
         if (m_dirty) *m_dirty = 1u;  // (the transpose must look at M)
@@ -1622,8 +1623,11 @@ constexpr u32 kSlotNone = 0xFFFFFFFFu;    // sslot of a query hash that no genom
 __device__ __forceinline__ u32 kt_start(u64 key, u32 mask) { return (u32)((key ^ (key >> 29)) * 0x9E3779B1u) & mask; }
 
 // every real hash of the tiled matrix: insert its key, count the genomes that hold it (columns hold distinct hashes)
+// spmask (several species resident, or NULL): bit sp of spmask[slot] = some genome of species sp holds the key (grp_sp: species of a
+// rank group of 512 genomes; per_tile = s x 256 elements of the tiled matrix per tile of 256 genomes)
 __global__ __launch_bounds__(256) void rare_count_kernel(const u64* __restrict__ mat, u64 n_elems, u64* __restrict__ key,
-                                                         u32* __restrict__ cnt, u32 mask, u32* __restrict__ overflow) {
+                                                         u32* __restrict__ cnt, u32 mask, u32* __restrict__ overflow,
+                                                         unsigned long long* __restrict__ spmask, const u32* __restrict__ grp_sp, u64 per_tile) {
     for (u64 e = (u64)blockIdx.x * 256u + threadIdx.x; e < n_elems; e += (u64)gridDim.x * 256u) {
         const u64 h = mat[e];
         if (h >= kEmpty) continue;  // padding; hashes >= kEmpty were lifted into the exception list and stay with the scan path
@@ -1631,7 +1635,14 @@ __global__ __launch_bounds__(256) void rare_count_kernel(const u64* __restrict__
         for (;;) {
             u64 prev = key[slot];
             if (prev == kPad) prev = atomicCAS(&key[slot], kPad, h);
-            if (prev == kPad || prev == h) { atomicAdd(&cnt[slot], 1u); break; }
+            if (prev == kPad || prev == h) {
+                atomicAdd(&cnt[slot], 1u);
+                if (spmask) {
+                    const unsigned long long bit = 1ull << grp_sp[(u32)(e / per_tile) / (kRankWords * 64u / kTileGenomes)];
+                    if (!(spmask[slot] & bit)) atomicOr(&spmask[slot], bit);
+                }
+                break;
+            }
             slot = (slot + 1u) & mask;
             if (++tries > mask) { *overflow = 1u; break; }
         }
@@ -1656,13 +1667,26 @@ __global__ __launch_bounds__(256) void rare_fill_kernel(const u64* __restrict__ 
 
 // the keys the scan has to find (held by more genomes than the index lists): out[0 .. *n) in no particular order; *n may exceed cap
 __global__ __launch_bounds__(256) void collect_dense_kernel(const u64* __restrict__ key, const u32* __restrict__ off, u64 slots,
-                                                            u64* __restrict__ out, u32* __restrict__ n, u32 cap) {
+                                                            u64* __restrict__ out, u32* __restrict__ out_slot, u32* __restrict__ n, u32 cap) {
     for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < slots; i += (u64)gridDim.x * 256u) {
         const u64 k = key[i];
         if (k == kPad || off[i] != kRareDense) continue;
         const u32 at = atomicAdd(n, 1u);
-        if (at < cap) out[at] = k;
+        if (at < cap) { out[at] = k; out_slot[at] = (u32)i; }
     }
+}
+// the static dictionary's slice per (band, tile): several species resident -> the dictionary is the species' sorted segments one after
+// the other (seg[2 sp], seg[2 sp + 1] = first row and number of hashes of species sp's), and a tile looks in ITS species' segment only
+__global__ void window_seg_kernel(const u64* __restrict__ lo, const u64* __restrict__ hi, u32 n_bt, u32 n_tiles,
+                                  const u64* __restrict__ q, const u32* __restrict__ seg, const u32* __restrict__ grp_sp, u32* __restrict__ win) {
+    const u32 bt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bt >= n_bt) return;
+    const u32 sp = grp_sp[(bt % n_tiles) / (kRankWords * 64u / kTileGenomes)];
+    const u32 a = seg[2u * sp], n = seg[2u * sp + 1u];
+    u32 qa = a + n, qb = a + n;
+    if (lo[bt] <= hi[bt]) { qa = a + lower_bound_u64(q + a, n, lo[bt]); qb = a + upper_bound_u64(q + a, n, hi[bt]); }
+    win[2 * bt] = qa;
+    win[2 * bt + 1] = qb;
 }
 // ---- long lists as bit rows.  A hash held by more than kShortList genomes (a lineage's: ~200) costs a pass one atomic per genome
 // on its list and batch -- 8.7 M per C2 pass of the SNP workload, 3.9 ms at the ~2.3 G/s scattered device-scope atomics reach.  The
@@ -1852,7 +1876,10 @@ __global__ __launch_bounds__(256) void classify_c_kernel(const u64* __restrict__
     if (i >= nq) return;
     const u32 loc = qloc[i], dr = bsum[i >> 10] + (loc & 0x7FFFFFFFu), nd64 = n_d[2];
     if (loc >> 31) {
-        if (ri.qs) qrow[i] = lower_bound_u64(ri.qs, ri.n_sd, q[i]);  // (its row of the static dictionary: every dense hash is in it)
+        if (ri.qs) {  // its row of the static dictionary (every dense hash is in it): by key slot, the lifted hashes by search in their tail
+            const u32 slot = qinfo[i];
+            qrow[i] = slot != kSlotNone ? ri.srow[slot] : ri.tail0 + lower_bound_u64(ri.qs + ri.tail0, ri.n_sd - ri.tail0, q[i]);
+        }
         else { qd[dr] = q[i]; qrow[i] = dr; }
     }
     else {  // (the other rows start on a word boundary; sslot[2 sr], [2 sr + 1] = start and length of the hash's genome list -- or, length with
@@ -3984,16 +4011,23 @@ __global__ __launch_bounds__(256) void pass_hist_kernel(const u32* __restrict__ 
 // grid: (n_pad / 256, word chunks); M is read before the transpose re-zeroes it.
 constexpr u32 kGainWords = 8;  // query words per block
 constexpr u32 kGainSparseStride = SKX_GAIN_SPARSE_STRIDE;  // u32 words between two genomes' entries of the rare rows' gain array
+// segw (or NULL; static dictionaries of several species): segw[2 sp], [2 sp + 1] = the words that hold species sp's rows -- a block
+// of 256 genomes belongs to one species (grp_sp) and reads no other species' words (all zero for its genomes)
 template <u32 NB>
 __global__ __launch_bounds__(256) void gain_dense_kernel(const u64* __restrict__ m_bits, const u64* __restrict__ m_int, u32 n_pad,
                                                          const u32* __restrict__ n_d, const u32* __restrict__ cnt, u32 row_stride,
-                                                         u32* __restrict__ gain) {
+                                                         u32* __restrict__ gain, const u32* __restrict__ segw, const u32* __restrict__ grp_sp) {
     __builtin_amdgcn_s_setprio(2);
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     const u32 nd = n_d[0], n_words = (nd + 63u) >> 6;
-    const u32 w0 = blockIdx.y * kGainWords;
+    u32 w0 = blockIdx.y * kGainWords;
     if (w0 >= n_words) return;
-    const u32 w1 = min(n_words, w0 + kGainWords);
+    u32 w1 = min(n_words, w0 + kGainWords);
+    if (segw) {
+        const u32 sp = grp_sp[blockIdx.x / (kRankWords * 64u / 256u)];
+        w0 = max(w0, segw[2u * sp]); w1 = min(w1, segw[2u * sp + 1u]);
+        if (w0 >= w1) return;
+    }
     u32 acc[NB];
 #pragma unroll
     for (u32 b = 0; b < NB; ++b) acc[b] = 0;
@@ -5015,16 +5049,20 @@ void launch_pair_q(hipStream_t st, const u64* pair_h, u32 n_pairs, const u64* q,
     if (n_pairs == 0) return;
     hipLaunchKernelGGL(pair_q_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, st, pair_h, n_pairs, q, n_q, pair_q, qrow, bbase, btot, dict_bshift(max_ref));
 }
-void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow) {
+void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow, u64* spmask, const u32* grp_sp, u32 s) {
     if (n_elems == 0) return;
-    hipLaunchKernelGGL(rare_count_kernel, dim3((u32)std::min<u64>((n_elems + 255) / 256, 1u << 16)), dim3(256), 0, st, mat, n_elems, key, cnt, mask, overflow);
+    hipLaunchKernelGGL(rare_count_kernel, dim3((u32)std::min<u64>((n_elems + 255) / 256, 1u << 16)), dim3(256), 0, st, mat, n_elems, key, cnt, mask, overflow,
+                       spmask, grp_sp, (u64)s * kTileGenomes);
 }
 void launch_rare_fill(hipStream_t st, const u64* mat, u64 n_elems, u32 s, const u64* key, const u32* off, u32* cursor, u32* post, u32 mask) {
     if (n_elems == 0) return;
     hipLaunchKernelGGL(rare_fill_kernel, dim3((u32)std::min<u64>((n_elems + 255) / 256, 1u << 16)), dim3(256), 0, st, mat, n_elems, s, key, off, cursor, post, mask);
 }
-void launch_collect_dense(hipStream_t st, const u64* key, const u32* off, u64 slots, u64* out, u32* n, u32 cap) {
-    hipLaunchKernelGGL(collect_dense_kernel, dim3((u32)std::min<u64>((slots + 255) / 256, 4096)), dim3(256), 0, st, key, off, slots, out, n, cap);
+void launch_collect_dense(hipStream_t st, const u64* key, const u32* off, u64 slots, u64* out, u32* out_slot, u32* n, u32 cap) {
+    hipLaunchKernelGGL(collect_dense_kernel, dim3((u32)std::min<u64>((slots + 255) / 256, 4096)), dim3(256), 0, st, key, off, slots, out, out_slot, n, cap);
+}
+void launch_window_seg(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, u32 n_tiles, const u64* q, const u32* seg, const u32* grp_sp, u32* win) {
+    hipLaunchKernelGGL(window_seg_kernel, dim3(cdiv(n_bt, 256)), dim3(256), 0, st, lo, hi, n_bt, n_tiles, q, seg, grp_sp, win);
 }
 void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, const RareIndex& ri, u32* qinfo, u32* qloc, u32* bsum,
                      u64* qd, u32* n_d, u32* qrow, u32* sslot, u32* h_words) {
@@ -5053,9 +5091,9 @@ void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, 
     hipLaunchKernelGGL(pass_hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pair_q, pb, cnt, row_stride);
 }
 void launch_gain_dense(hipStream_t st, const u64* m_bits, const u64* m_int, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt, u32 row_stride,
-                       u32 n_b, u32* gain) {
+                       u32 n_b, u32* gain, const u32* segw, const u32* grp_sp) {
     const dim3 grid(n_pad / 256, std::max(1u, cdiv(cdiv(rows_bound, 64), kGainWords)));
-#define SKX_GAIN(NB) hipLaunchKernelGGL(gain_dense_kernel<NB>, grid, dim3(256), 0, st, m_bits, m_int, n_pad, n_d, cnt, row_stride, gain)
+#define SKX_GAIN(NB) hipLaunchKernelGGL(gain_dense_kernel<NB>, grid, dim3(256), 0, st, m_bits, m_int, n_pad, n_d, cnt, row_stride, gain, segw, grp_sp)
     switch (n_b) {
         case 1: SKX_GAIN(1); break; case 2: SKX_GAIN(2); break; case 3: SKX_GAIN(3); break; case 4: SKX_GAIN(4); break;
         case 5: SKX_GAIN(5); break; case 6: SKX_GAIN(6); break; case 7: SKX_GAIN(7); break; default: SKX_GAIN(8); break;
@@ -5172,10 +5210,10 @@ void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const
     hipLaunchKernelGGL(window_kernel, dim3(cdiv(n_bt, 256)), dim3(256), 0, st, lo, hi, n_bt, q, n_q, win, h_nq);
 }
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
-                       u64* m_bits, u32 n_pad, u32* m_dirty, const u32* qrow) {
+                       u64* m_bits, u32 n_pad, u32* m_dirty, const u32* qrow, u32 row0, u32 n_fixed) {
     if (n_exc == 0) return;
     hipLaunchKernelGGL(exceptions_kernel, dim3(cdiv(n_exc, 256)), dim3(256), 0, st, exc_g, exc_h, n_exc, q, n_q,
-                       m_bits, n_pad, m_dirty, qrow);
+                       m_bits, n_pad, m_dirty, qrow, row0, n_fixed);
 }
 
 bool scan_lean_wants_slabs();

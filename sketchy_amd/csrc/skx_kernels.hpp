@@ -105,8 +105,11 @@ struct RareIndex { const u64* key; const u32* off; const u32* cnt; const u32* po
                    const u32* prec = nullptr; const u32* pat_rep = nullptr; const u64* pm = nullptr; const u32* d_npat = nullptr; u32 n_pat = 0;
                    // the STATIC dense dictionary (round 6): qs[0 .. n_sd) = every hash the scan can be asked for (held by more genomes than
                    // the index lists, + the lifted hashes), ascending; a pass's dense rows are ITS rows (launch_classify); NULL: per-pass dictionaries
-                   const u64* qs = nullptr; u32 n_sd = 0; };
-void launch_collect_dense(hipStream_t st, const u64* key, const u32* off, u64 slots, u64* out, u32* n, u32 cap);
+                   // (several species: the species' sorted segments one after the other, each starting on a multiple of 64 rows, padded with
+                   // all-ones; srow[key slot] = the hash's row; the lifted hashes sorted in the tail [tail0, n_sd))
+                   const u64* qs = nullptr; u32 n_sd = 0; const u32* srow = nullptr; u32 tail0 = 0; };
+void launch_collect_dense(hipStream_t st, const u64* key, const u32* off, u64 slots, u64* out, u32* out_slot, u32* n, u32 cap);
+void launch_window_seg(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, u32 n_tiles, const u64* q, const u32* seg, const u32* grp_sp, u32* win);
 // pattern rows of a pass: hist[b][hist_stride] = occurrences of every pattern among batch b's pairs, gain_x[b][n_pad] += / -= the rows'
 // counts at their exceptions (wrapping), nprow[b] (one counter per batch, like LongRows::nlrow) rows listed from the END of lrow[b]
 struct PatRows { u32* hist; u32 hist_stride; u32* gain_x; u32* nprow; };
@@ -135,7 +138,8 @@ void launch_cand_long(hipStream_t st, const LongRows& lr, const RareIndex& ri, c
                       u32 rows_c, u64* rowany_c, u32 rowany_stride, u32* grp_any_c, u32 n_grp_c, u32 walk_scale = 1, const u64* hit = nullptr /* launch_cand_hit's, or NULL: every listed row is tested */);
 // build, two passes over the tiled matrix (n_elems = n_tiles * s * 256): count (key / cnt zeroed: all-ones / 0; *overflow raised when
 // the table is too small), then -- offsets from the counts, cursor zeroed -- fill
-void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow);
+void launch_rare_count(hipStream_t st, const u64* mat, u64 n_elems, u64* key, u32* cnt, u32 mask, u32* overflow,
+                       u64* spmask = nullptr /* [slots], zero on entry: bit sp = a genome of species sp holds the key */, const u32* grp_sp = nullptr, u32 s = 0);
 void launch_rare_fill(hipStream_t st, const u64* mat, u64 n_elems, u32 s, const u64* key, const u32* off, u32* cursor, u32* post, u32 mask);
 // a pass's dictionary split into the hashes the scan looks for (qd ascending, n_d[0] of them: rows [0, n_d[0]) of the bit matrix)
 // and the others (n_d[1]; rows from n_d[2] on, sslot[2 i], [2 i + 1] = start and length of row i's genome list); qrow[position in q] = row.
@@ -165,7 +169,8 @@ void launch_pass_hist(hipStream_t st, const u32* pair_q, const PassBatches& pb, 
 // re-zeroes it), the others from the genome lists (ri / sslot, or NULL)
 // gain_s (zero on entry, [n_b][n_pad] entries gain_sparse_stride() words apart): the rare rows' part
 void launch_gain_dense(hipStream_t st, const u64* m_bits, const u64* m_int /* or NULL */, u32 n_pad, const u32* n_d, u32 rows_bound, const u32* cnt,
-                       u32 row_stride, u32 n_b, u32* gain);
+                       u32 row_stride, u32 n_b, u32* gain, const u32* segw = nullptr /* [2 n_sp] word range of every species' rows (static dictionary) */,
+                       const u32* grp_sp = nullptr);
 // (lr: also lists the rows with a bit row per batch, nlrow zero on entry; walk_scale: multiplies the workgroups of the list walk --
 // a pass with nothing beside it may fill the chip)
 // (pr: the rows whose list is pattern + exceptions add to hist / gain_x and are listed for launch_cand_pat_map; hist, gain_x, nprow zero on entry)
@@ -234,7 +239,8 @@ u32 dict_buckets();
 void launch_window(hipStream_t st, const u64* lo, const u64* hi, u32 n_bt, const u64* q, const u32* n_q, u32* win,
                    u32* h_nq /* page-locked host word that receives *n_q, or NULL */);
 void launch_exceptions(hipStream_t st, const u32* exc_g, const u64* exc_h, u32 n_exc, const u64* q, const u32* n_q,
-                       u64* m_bits, u32 n_pad, u32* m_dirty /* raised when a bit was set, or NULL */, const u32* qrow = nullptr);
+                       u64* m_bits, u32 n_pad, u32* m_dirty /* raised when a bit was set, or NULL */, const u32* qrow = nullptr,
+                       u32 row0 = 0 /* q[0]'s row */, u32 n_fixed = 0 /* n_q == NULL: entries of q */);
 
 // scan + transpose
 // lean: scan_lean_kernel (sparse dictionaries: every production pass) -- every (band, tile) block ORs the words of its slice into
