@@ -740,9 +740,13 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                         lok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
                     }
                     if (lok) r->n_long = n_long;
-                    // ... and transposed (genome-major), when another eighth of what is free holds it
-                    static const int mlongt_env = skx::knob("SKX_LONG_ROWS_T") ? atoi(skx::knob("SKX_LONG_ROWS_T")) : 1;  // experiment knob
-                    if (lok && mlongt_env) {
+                    // most of them as (pattern, exceptions): such rows need no transposed bit rows (their candidates come from the pattern)
+                    if (lok) build_patterns(r);
+                    const bool mostly_patterns = lok && r->d_prec && r->n_pat_lists * 10 >= n_long * 9;
+                    // ... and transposed (genome-major), when another eighth of what is free holds it -- unless nine lists in ten are patterns:
+                    // the few bit rows a batch then lists are tested against the candidates row by row (C4's pool reference: 24 GB less)
+                    static const int mlongt_env = skx::knob("SKX_LONG_ROWS_T") ? atoi(skx::knob("SKX_LONG_ROWS_T")) : 1;  // experiment knob (2: always)
+                    if (lok && mlongt_env && (!mostly_patterns || mlongt_env == 2)) {
                         const u32 n_lw = (u32)((n_long + 63) / 64);
                         const u64 t_bytes = (u64)r->n_pad * n_lw * 8;
                         (void)hipMemGetInfo(&mem_free, &mem_total);
@@ -754,7 +758,6 @@ SKX_API int skx_ref_create_multi(skx_ref** out, int device, uint32_t k, uint64_t
                         (void)hipGetLastError();
                     }
                     else if (!lok) { (void)hipFree(r->d_mlong); (void)hipFree(r->d_lid); (void)hipFree(r->d_lslot); r->d_mlong = nullptr; r->d_lid = r->d_lslot = nullptr; r->n_long = 0; (void)hipGetLastError(); }
-                    if (lok) build_patterns(r);
                 }
                 r->rare_direct = ok && (r->d_mlong != nullptr || long_keys == 0);
             } catch (const std::bad_alloc&) {
