@@ -189,7 +189,7 @@ def _end_to_end(refs, batches, batch_bases, B, read_len, top, n_use, S, step_row
         gz = {}
         try:
             import zlib
-            n_gz = min(n_use, 2)
+            n_gz = min(n_use, 4)
             rec_bytes = 8 + L + 3 + L + 1
             raw = np.fromfile(d + "/reads.fq", np.uint8, count=n_gz * B * rec_bytes)
             t2 = time.time()
@@ -213,13 +213,19 @@ def _end_to_end(refs, batches, batch_bases, B, read_len, top, n_use, S, step_row
                         gz[kind] = {"error": f"rc {p.returncode}: {p.stderr[-300:]}"}
                         break
                     tmg = json.loads(m.group(0))["sketchy_hip_timing"]
-                    # (seconds_stream: from the moment the input is opened -- a BGZF file is inflated BEFORE the parser threads start)
+                    # (a BGZF file is inflated BEFORE the parser threads start -- seconds_open_input --; a plain gzip stream inside the parse
+                    # loop.  value = reads / (opening + inflating the input + parser start to last row): what value_end_to_end counts, plus the
+                    # inflate.  seconds_stream also holds the one-time set-up of the stream and its page-locked slots (0.4 s: more than
+                    # everything else for a sample of a few batches; round 5 quoted that figure)
+                    tmg["rate"] = tmg["reads"] / max(tmg.get("seconds_open_input", 0.0) + tmg["seconds_parse_start_to_last_row"], 1e-9)
                     tmg["rate_from_open"] = tmg["reads"] / max(tmg["seconds_stream"], 1e-9)
-                    if best is None or tmg["rate_from_open"] > best["rate_from_open"]:
+                    if best is None or tmg["rate"] > best["rate"]:
                         best = tmg
                 if best:
-                    gz[kind] = {"value": best["rate_from_open"], "unit": "reads/s", "reads": best["reads"], "input": best.get("input"),
-                                "seconds_from_open_to_last_row": best["seconds_stream"], "parse_threads": best.get("parse_threads"),
+                    gz[kind] = {"value": best["rate"], "unit": "reads/s", "reads": best["reads"], "input": best.get("input"),
+                                "seconds_open_and_inflate": best.get("seconds_open_input"), "seconds_parse_start_to_last_row": best["seconds_parse_start_to_last_row"],
+                                "seconds_from_open_to_last_row_with_setup": best["seconds_stream"], "value_with_setup": best["rate_from_open"],
+                                "parse_threads": best.get("parse_threads"),
                                 "compressed_GB": round(os.path.getsize(d + f"/reads.{kind}.fq.gz") / 1e9, 3),
                                 "best_of": 2}
             gz["compress_s"] = round(t_comp, 1)
@@ -853,9 +859,10 @@ def main():
             out["value_end_to_end"] = e2e
             g = e2e.get("gz") or {}
             out["value_end_to_end_gz"] = {"bgzf": g.get("bgzf"), "plain_gzip": g.get("plain"), "compress_s": g.get("compress_s"), "error": g.get("error"),
-                                          "what": "the same FASTQ (its first two batches) compressed: BGZF -- gzip members of 64 KB whose sizes are in "
+                                          "what": "the same FASTQ (its first four batches) compressed: BGZF -- gzip members of 64 KB whose sizes are in "
                                                   "their headers, inflated by all host threads at once -- and plain single-member gzip (one "
-                                                  "sequential inflate thread); sketchy-hip predict -s, timed by the host as above"}
+                                                  "sequential inflate thread); sketchy-hip predict -s; value = reads / (opening + inflating the input + "
+                                                  "parser start to last row), value_with_setup also counts creating the stream and its page-locked slots"}
             for kind in ("bgzf", "plain"):
                 if isinstance(g.get(kind), dict) and g[kind].get("rows_match_device_path") is False:
                     err = err or f"rows printed from the {kind} gzip input differ from the device-resident path's rows"

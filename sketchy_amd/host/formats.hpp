@@ -339,6 +339,7 @@ class FastxReader {
 // An uncompressed regular file is mapped and cut into CHUNKS at record boundaries; every chunk is parsed by whichever thread
 // picks it up (sketchy_host.cpp).  needletail reads one record at a time on the thread that scores it (src/sketchy.rs:328-333);
 // the records, their order and their bytes are the same.
+bool& bgzf_force_zlib();
 class MappedFile {
   public:
     MappedFile() = default;
@@ -410,6 +411,8 @@ inline bool sketchy::MappedFile::open(const std::string& path) {
     base = static_cast<const char*>(m); len = (size_t)st.st_size;
     return true;
 }
+// (measurement aid of tools/bgzf_rate.cpp: every member through zlib, as in round 5)
+inline bool& sketchy::bgzf_force_zlib() { static bool f = false; return f; }
 inline bool sketchy::MappedFile::open_bgzf(const std::string& path, unsigned threads) {
     if (path == "-") return false;
     const int fd = ::open(path.c_str(), O_RDONLY);
@@ -481,7 +484,7 @@ inline bool sketchy::MappedFile::open_bgzf(const std::string& path, unsigned thr
                 const Block& k = blocks[b];
                 if (k.usize == 0) continue;
                 unsigned char* dst = reinterpret_cast<unsigned char*>(u + k.uoff);
-                if (!fi->inflate_raw(c + k.coff, k.csize, dst, k.usize)) {
+                if (bgzf_force_zlib() || !fi->inflate_raw(c + k.coff, k.csize, dst, k.usize)) {
                     inflateReset(&z);
                     z.next_in = const_cast<unsigned char*>(c + k.coff); z.avail_in = (unsigned)k.csize;
                     z.next_out = dst; z.avail_out = (unsigned)k.usize;

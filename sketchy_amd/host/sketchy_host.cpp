@@ -275,6 +275,7 @@ class Sketchy {
         // (a BGZF file -- gzip members with their sizes in the header -- is inflated by all threads at once and then cut and parsed
         // like an uncompressed one; plain gzip is one sequential stream)
         const bool mapped = map.open(path) || map.open_bgzf(path, config.threads ? (unsigned)config.threads : std::min(usable_threads(), 22u));
+        const double open_s = std::chrono::duration<double>(clock::now() - t_begin).count();  // mapping the input (BGZF: inflating all of it)
         if (mapped && map.inflated() && !map.eof_marker)
             fprintf(stderr, "sketchy-hip: warning: %s does not end with BGZF's end-of-file block (truncated at a block boundary?)\n", path.c_str());
         const char *fbegin = mapped ? map.data() : nullptr, *fend = mapped ? map.data() + map.size() : nullptr;
@@ -632,10 +633,10 @@ class Sketchy {
             // seconds_parse_start_to_last_row: from the moment the parser threads start (stream and page-locked slots exist) until
             // the last row is written; seconds_stream adds that set-up.  device thread: waiting for parsed chunks / inside
             // skx_stream_submit (it blocks when the library's staging slots are all in flight) / final drain + hand-over
-            std::fprintf(stderr, "{\"sketchy_hip_timing\": {\"reads\": %zu, \"batches\": %zu, \"seconds_stream\": %.6f, \"seconds_parse_start_to_last_row\": %.6f, "
+            std::fprintf(stderr, "{\"sketchy_hip_timing\": {\"reads\": %zu, \"batches\": %zu, \"seconds_stream\": %.6f, \"seconds_open_input\": %.6f, \"seconds_parse_start_to_last_row\": %.6f, "
                                  "\"reads_per_s\": %.1f, \"parse_threads\": %u, \"format_threads\": %u, \"cpus_pinned_near_device\": %u, \"input\": \"%s\", \"batch_reads\": %zu, "
                                  "\"device_thread_s\": {\"wait_for_parsers\": %.6f, \"submit\": %.6f, \"drain_and_hand_over\": %.6f}}}\n",
-                         fed, n_batches, all_s, run_s, fed / std::max(run_s, 1e-9), n_parse, n_format, pinned, mapped ? (map.inflated() ? (fastq ? "bgzf fastq" : "bgzf fasta") : (fastq ? "mapped fastq" : "mapped fasta")) : "streamed", want_reads,
+                         fed, n_batches, all_s, open_s, run_s, fed / std::max(run_s, 1e-9), n_parse, n_format, pinned, mapped ? (map.inflated() ? (fastq ? "bgzf fastq" : "bgzf fasta") : (fastq ? "mapped fastq" : "mapped fasta")) : "streamed", want_reads,
                          s_wait_parse, s_submit, s_retire);
         }
     }
