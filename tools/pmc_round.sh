@@ -3,7 +3,7 @@
 # (keys as bench.py's _profile_key: c2truth_b98304 = the default workload, SURVEY 8(d)'s; c2_b98304 = the ancestor stream), and the multiply micro-benchmark
 TAG=$1
 mkdir -p gpurun_out/prof
-for V in "c2truth --workload truth" "c2 --workload ancestor" "c4truth --config c4 --workload truth"; do
+for V in "c2truth --workload truth" "c2 --workload ancestor" "c4 --config c4 --workload ancestor" "c4truth --config c4 --workload truth"; do
   set -- $V; K=$1; shift
   tools/pmc_all.sh "$@" > gpurun_out/prof/${TAG}_${K}_insts.txt 2>&1
   cp gpurun_out/prof/pmc_all_summary.csv gpurun_out/prof/${TAG}_${K}_insts_per_kernel.csv
