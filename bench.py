@@ -985,6 +985,14 @@ def main():
     other = "ancestor" if args.workload == "truth" else "truth"
     other_key = "value_ancestor" if other == "ancestor" else "value_truth_strain"
     if rank == 0 and world == 1 and not args.no_truth_leg and not args.no_extra_legs:
+        # (the child builds its own reference: this process's stream, reference and batches are released first -- at C4 the parent's
+        # ~70 GB left the child's reference without room for its bit rows, and with them without its static dictionary: the child of
+        # round 6's first c4 line ran the dense-dictionary scan at 32.5 M reads/s where the same command on its own does 42 M)
+        S.close()
+        reducer.close()
+        R.close()
+        del d_ti, d_ts, batches, sources, genome_t
+        torch.cuda.empty_cache()
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", other, "--config", args.config, "--steps", str(K), "--warmup", str(W),
                "--batch", str(B), "--top", str(top), "--reps", str(min(reps, 5)), "--no-extra-legs", "--cpu-seconds", "0", "--api", args.api,
                "--oracle-steps", args.oracle_steps] + (["--no-check"] if args.no_check else [])
