@@ -2808,8 +2808,13 @@ static int batch_front(skx_stream* st, PendingBatch& pb) {
     // static dense dictionary: the scan of the pass this batch opens depends on no batch -- queue it NOW, ahead of the sketch: the
     // HBM-bound scan then runs beside the VALU-bound sketches of its own group (a lone batch: beside its own sketch) instead of behind
     // their dictionary
+    // WHEN (policy of this build, experiment knob SKX_EARLY_SCAN): 1 = always here; 2 (default) = here only when no group is waiting for its
+    // pass (the first group of a sample, a lone batch) -- else right BEHIND the waiting group's front half (enqueue_batch): the scan of
+    // group k + 1 then runs beside that group's padded sketches in mid-stream instead of beside the unpadded first sketches of the sample;
+    // 0 = never early (the pass launches it itself, as in round 5)
+    static const int early_env = skx::knob("SKX_EARLY_SCAN") ? atoi(skx::knob("SKX_EARLY_SCAN")) : 2;
     bool early_scan = false;
-    if (st->static_dense && pb.gi == 0 && ref->n_sd && !st->m_ready[pb.spec_set]) {
+    if (st->static_dense && pb.gi == 0 && ref->n_sd && !st->m_ready[pb.spec_set] && (early_env == 1 || (early_env == 2 && st->n_pend == 0))) {
         early_scan = !(st->reuse_m && st->m_filled[pb.spec_set]);  // (a scan really goes out beside this sketch)
         SKXCHK(queue_static_scan(st, pb.spec_set));
     }
@@ -3176,7 +3181,13 @@ static int enqueue_batch(skx_stream* st, const uint8_t* d_bases, const u64* d_of
     }
     SKX_MARK("enqueue: front queued, gi", nw.gi);
     int rc = SKX_OK;
+    const bool had_pending = st->n_pend > 0;
     if (nw.gi == 0) rc = pending_back(st, &nw);  // (it joined nobody: the batches waiting are complete)
+    if (rc == SKX_OK && nw.gi == 0 && had_pending && st->static_dense && st->ref->n_sd) {
+        // (the new group's scan: behind the front half of the group that has just been queued -- see batch_front)
+        static const int early_env = skx::knob("SKX_EARLY_SCAN") ? atoi(skx::knob("SKX_EARLY_SCAN")) : 2;
+        if (early_env == 2 && !st->m_ready[nw.spec_set]) rc = queue_static_scan(st, nw.spec_set);
+    }
     if (rc != SKX_OK) {
         const std::string msg = g_err;
         (void)cancel_speculation(st, nw);
