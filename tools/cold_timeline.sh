@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (GPU box): tools/cold_timeline.sh <tag>  -- the kernels of ONE lone first batch (tools/diag_cold.py) with their start offsets
+# usage (GPU box): tools/cold_timeline.sh <tag> [ancestor|truth]  -- the kernels of ONE lone first batch (tools/diag_cold.py) with their start offsets
 TAG=$1
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 P=gpurun_out/prof; mkdir -p $P
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $P/kt_$TAG -o kt -- python3 tools/diag_cold.py 8 > $P/${TAG}_cold.txt 2> $P/${TAG}_cold.err
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $P/kt_$TAG -o kt -- python3 tools/diag_cold.py 8 ${2:-ancestor} > $P/${TAG}_cold.txt 2> $P/${TAG}_cold.err
 python3 - $(find $P/kt_$TAG -name "*kernel_trace.csv" | head -1) > $P/${TAG}_cold_timeline.txt <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "skx::" in r["Kernel_Name"]]

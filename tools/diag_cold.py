@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/diag_cold.py [n_cold] (GPU box): the cold leg alone -- table reset, ONE enqueue of a C2 batch, sync -- for a kernel
+"""tools/diag_cold.py [n_cold] [ancestor|truth] (GPU box): the cold leg alone -- table reset, ONE enqueue of a C2 batch, sync -- for a kernel
 trace of a lone first batch (rocprofv3 --kernel-trace --stats -- python3 tools/diag_cold.py)."""
 import sys
 import time
@@ -12,9 +12,10 @@ from sketchy_amd import api, synth  # noqa: E402
 
 B = 98304
 n_cold = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+workload = sys.argv[2] if len(sys.argv) > 2 else "ancestor"
 tdev = "cuda:0"
-ref = synth.make_reference(40000, 10000, k=16, hash_seed=0, rng_seed=1, device=tdev)
-genome_t = torch.from_numpy(ref["genome"]).to(tdev)
+ref = synth.make_reference(40000, 10000, k=16, hash_seed=0, rng_seed=1, device=tdev, mode="snp" if workload == "truth" else "pool")
+genome_t = torch.from_numpy(ref["truth_genome"] if workload == "truth" else ref["genome"]).to(tdev)
 batches = [synth.make_reads_torch(genome_t, B, 1500, err=0.05, rng_seed=1000 + i, lognormal_sigma=0.0, device=tdev) for i in range(2)]
 nb = [int(o[-1].item()) for _, o in batches]
 R = api.ReferenceSketch([ref["ref"]], [ref["col_len"]], k=16, seed=0, device=0)
