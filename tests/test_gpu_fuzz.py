@@ -7,17 +7,23 @@ import os
 import numpy as np
 import pytest
 
-from helpers import workload
+from helpers import workload, workload_snp
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
 
-def _walk(seed):
+def _walk(seed, tree=False):
     from sketchy_amd import api
     rng = np.random.default_rng(seed)
     n, s, top = int(rng.choice([130, 600, 1100])), int(rng.choice([100, 300])), int(rng.choice([1, 1, 3]))
-    ref, bases, offsets = workload(n, s, 4000, read_len=int(rng.choice([200, 500])), rng_seed=int(rng.integers(1, 10 ** 6)))
+    if tree:
+        # a SURVEY 8(d) clone tree with more than 1 024 genomes: the reference gets its rare-hash index, the lists' patterns and the
+        # static dense dictionary -- the walk then also crosses the deferred passes' candidate paths
+        n, s = int(rng.choice([1500, 2600])), 300
+        ref, bases, offsets = workload_snp(n, s, 4000, read_len=int(rng.choice([200, 500])), rng_seed=3 + seed % 2, n_lineages=13)
+    else:
+        ref, bases, offsets = workload(n, s, 4000, read_len=int(rng.choice([200, 500])), rng_seed=int(rng.integers(1, 10 ** 6)))
     col_len = np.full(n, s, np.uint32)
     packed, poff = api.pack_reads(bases, offsets)
     R = api.ReferenceSketch(ref["ref"])
@@ -28,11 +34,13 @@ def _walk(seed):
         api.set_option("stream_coalesce", int(rng.choice([1, 2, 3, 5, 8, 8])))
         api.set_option("stream_query_rows", int(rng.choice([0, 0, 0, 64])))
         api.set_option("rank_lanes", int(rng.choice([1, 2, 2, 2, 3, 4])))
+        api.set_option("reuse_membership", int(rng.choice([0, 0, 1])) if tree else 0)
         S = api.SumOfSharedHashes(R, top=top, max_batch_reads=400, max_batch_bases=400 * 700)
     finally:
         api.set_option("stream_coalesce", before)
         api.set_option("stream_query_rows", 0)
         api.set_option("rank_lanes", lanes_before)
+        api.set_option("reuse_membership", 0)
     d_ascii, d_packed = api.DeviceBuffer.from_numpy(bases), api.DeviceBuffer.from_numpy(packed)
     h_ascii, h_packed = api.HostBuffer(len(bases)), api.HostBuffer(len(packed))
     h_ascii.view(np.uint8)[:] = bases
@@ -131,6 +139,10 @@ def _walk(seed):
     resolve()
     assert pos > 0
     np.testing.assert_array_equal(S.table(), cum if cum is not None else np.zeros(n, np.uint64))
+    if tree:
+        st = S.stats()
+        print("walk", seed, "n", n, "top", top, "static", R.static_dense, "patterns", R.patterns["pattern_lists"], "passes", st["passes"],
+              "shared", st["passes_shared"], "compact", st["batches_compact"], "full", st["batches_full"])
     for d in keep:
         d.free()
     h_ascii.free(); h_packed.free()
@@ -141,3 +153,11 @@ def test_random_walks_over_the_stream_api(gpu):
     base = int(os.environ.get("SKX_TEST_SEED", "5"))
     total = sum(_walk(1000 * base + i) for i in range(6))
     assert total > 3000  # (the walks really pushed reads through)
+
+
+def test_random_walks_on_a_clone_tree_reference(gpu):
+    """the same walks where skx_ref_create has built everything it builds for a large collection (rare-hash index, patterns, static
+    dense dictionary), with and without the `reuse_membership` policy"""
+    base = int(os.environ.get("SKX_TEST_SEED", "5"))
+    total = sum(_walk(2000 * base + i, tree=True) for i in range(5))
+    assert total > 2500
