@@ -3370,34 +3370,43 @@ __global__ __launch_bounds__(256) void rank_seg_kernel(const u32* __restrict__ p
 // Candidates of read r: cand[(r * n_units + u) * top_k + j], u = rank group (pruned path, per_grp = 1) or genome word
 // (generic path, per_grp = kRankWords); a species owns the units of its rank groups.  Output rows hold genome indices
 // LOCAL to the species: out[((out_r0 + r) * n_sp + sp) * top_k + j].
+// Every unit's list is in rank order with its "none" entries at the end (rank_seg_topk_kernel / rank_seg_kernel write them so), so
+// this is a k-way merge: a unit takes part with the HEAD of its list only -- next[u], one byte of LDS per unit, owned by the lane
+// that walks the unit -- and a round costs one entry per unit, not top_k.  (Until round 6 every round walked all top_k entries of
+// every unit: 16 x 1 264 entries x 98 304 reads for a full top-16 ranking at C2, 4-9 ms; profiles/r06_topk.txt.)
 __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__ cand_sum,
                                                          const u32* __restrict__ cand_idx, u32 n_reads, u32 n_units,
                                                          u32 per_grp, u32 top_k, u32* __restrict__ out_idx,
                                                          u64* __restrict__ out_sum, u32 out_r0, Species sp,
-                                                         const unsigned char* __restrict__ has /* [seg][n_units] or NULL */) {
+                                                         const unsigned char* __restrict__ has /* [seg][n_units] or NULL */,
+                                                         u32 next_stride) {
+    extern __shared__ unsigned char s_next[];  // [4 waves][next_stride]
     const u32 w = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = lane_id();
     const u32 r = w / sp.n_sp, spi = w % sp.n_sp;
     if (r >= n_reads) return;
     const u32 g_lo = sp.g0[spi], grp0 = g_lo / (kRankWords * 64u), grp1 = (g_lo + sp.n[spi] + kRankWords * 64u - 1u) / (kRankWords * 64u);
-    const u32 n_cand = (grp1 - grp0) * per_grp * top_k;
+    const u32 n_u = (grp1 - grp0) * per_grp;
     const u64* cs = cand_sum + ((size_t)r * n_units + (size_t)grp0 * per_grp) * top_k;
     const u32* ci = cand_idx + ((size_t)r * n_units + (size_t)grp0 * per_grp) * top_k;
-    u64 ps = 0; u32 pi = 0; bool first = true;
+    unsigned char* next = s_next + (threadIdx.x >> 6) * next_stride;
+    // (a unit the pruned ranking reported nothing for -- its entries were not even written -- starts exhausted; has: unit = rank group)
+    for (u32 u = lane; u < n_u; u += 64u) next[u] = (unsigned char)((has && !has[(size_t)(r >> 6) * n_units + grp0 + u]) ? top_k : 0u);
     for (u32 j = 0; j < top_k; ++j) {
-        u64 bs = 0; u32 bi = 0xFFFFFFFFu;
-        for (u32 c = lane; c < n_cand; c += 64u) {
-            if (has && !has[(size_t)(r >> 6) * n_units + grp0 + c / top_k]) continue;  // (pruned path: unit = rank group)
-            const u64 s_ = cs[c]; const u32 i_ = ci[c];
-            if (i_ == 0xFFFFFFFFu) continue;
-            if (!first && !ranks_before(ps, pi, s_, i_)) continue;
-            if (bi == 0xFFFFFFFFu || ranks_before(s_, i_, bs, bi)) { bs = s_; bi = i_; }
+        u64 bs = 0; u32 bi = 0xFFFFFFFFu, bu = 0;
+        for (u32 u = lane; u < n_u; u += 64u) {  // (lane l owns units l, l + 64, ...: no other lane reads or writes their next[])
+            const u32 nx = next[u];
+            if (nx >= top_k) continue;
+            const u64 s_ = cs[(size_t)u * top_k + nx]; const u32 i_ = ci[(size_t)u * top_k + nx];
+            if (i_ == 0xFFFFFFFFu) { next[u] = (unsigned char)top_k; continue; }
+            if (bi == 0xFFFFFFFFu || ranks_before(s_, i_, bs, bi)) { bs = s_; bi = i_; bu = u; }
         }
+        const u32 mine = bi;
         wave_best(bs, bi, bi != 0xFFFFFFFFu);
-        if (lane == 0) {
+        if (bi != 0xFFFFFFFFu && mine == bi) next[bu] += 1;  // (genome indices are unique: one lane)
+        if (lane == 0) {  // (nothing left: index "none" - g_lo and sum 0, as the rows of a species with fewer genomes than top_k always were)
             out_idx[((size_t)(out_r0 + r) * sp.n_sp + spi) * top_k + j] = bi - g_lo;
             out_sum[((size_t)(out_r0 + r) * sp.n_sp + spi) * top_k + j] = bs;
         }
-        ps = bs; pi = bi; first = false;
     }
 }
 
@@ -3725,6 +3734,8 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
 // and every read takes k rounds of "largest key below the previous winner" over the group's candidates.
 // Non-candidates never take part.  Output: cand_sum / cand_idx[(r * n_grp + grp) * top_k + j], idx 0xFFFFFFFF = none.
 constexpr u32 kTopkFast = 16;
+constexpr u32 kFewCands = 8;  // a group with at most this many candidates counts them one by one instead of replaying the segment
+static_assert(kFewCands <= kTopkFast, "res[] holds the few-candidates path's rows");
 static_assert(kTopkFast == kTopkFastMax, "chunk_leader_merge_kernel's LDS copy of the leaders");
 __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restrict__ pair_q, const u32* __restrict__ pair_r,
                                                             const u32* __restrict__ poff, u32 p_base, u32 r_begin,
@@ -3815,6 +3826,65 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
             cnt += (u32)__popcll(hm & lm);
         }
         if (lane < rz - ra) res[0] = ((start + cnt + 1ull) << SH) | ((u64)(NW - 1 - wc) << 6) | (u64)(63u - lc);
+    } else if (n_cands >= 2u && n_cands <= kFewCands) {
+        // A handful of candidates in the group (a full ranking of a clone-tree sample: the leading lineage's strains are spread over
+        // all the rank groups, two or three to each): the same count as above per candidate -- every lane ends up with the values of
+        // all of them after ITS read -- and the read's order is a selection among <= kFewCands keys in registers.  No read-by-read
+        // replay with its wave-wide maxima: ~4 k instructions per wave instead of ~28 k (profiles/r06_topk.txt).
+        u64 bal[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bal[w] = __ballot(cand[w]);
+        u32 cw[kFewCands], cl[kFewCands];
+        u64 cst[kFewCands];
+#pragma unroll
+        for (u32 c = 0; c < kFewCands; ++c) {  // candidate c in (word, lane) order; everything here is wave-uniform
+            u32 fw = (u32)NW;
+#pragma unroll
+            for (int w = NW - 1; w >= 0; --w) if (bal[w]) fw = (u32)w;
+            u64 b_ = 0, sv = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) if ((u32)w == fw) { b_ = bal[w]; sv = sum[w]; }
+            const u32 l = b_ ? (u32)__builtin_ctzll(b_) : 0u;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) if ((u32)w == fw) bal[w] = b_ & (b_ - 1ull);
+            cw[c] = fw < (u32)NW ? fw : 0u;
+            cl[c] = l;
+            cst[c] = readlane64(sv, (int)l);
+        }
+        const u32 pe = lane < rz - ra ? poff[r_begin + ra + lane + 1u] - p_base - pa : 0u;  // the segment's pairs up to and including this lane's read
+        u32 cnt[kFewCands];
+#pragma unroll
+        for (u32 c = 0; c < kFewCands; ++c) cnt[c] = 0;
+        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+            const u32 p = p0 + lane;
+            const bool v = p < pz;
+            const u64* row = mq_g + (size_t)(v ? pair_q[p] : 0u) * NW;
+            const u32 off = p0 - pa, nlow = pe > off ? min(64u, pe - off) : 0u;
+            const u64 lm = nlow >= 64u ? ~0ull : ((1ull << nlow) - 1ull);
+#pragma unroll
+            for (u32 c = 0; c < kFewCands; ++c) {
+                if (c < n_cands) {
+                    const u64 word = v ? row[cw[c]] : 0ull;
+                    const u64 hm = __ballot(v && ((word >> cl[c]) & 1ull));
+                    cnt[c] += (u32)__popcll(hm & lm);
+                }
+            }
+        }
+        u64 key[kFewCands];
+#pragma unroll
+        for (u32 c = 0; c < kFewCands; ++c)
+            key[c] = c < n_cands ? (((cst[c] + cnt[c] + 1ull) << SH) | ((u64)((u32)NW - 1u - cw[c]) << 6) | (u64)(63u - cl[c])) : 0ull;
+        u64 prev = ~0ull;
+#pragma unroll
+        for (u32 j = 0; j < kFewCands; ++j) {
+            if (j < top_k) {
+                u64 best = 0;
+#pragma unroll
+                for (u32 c = 0; c < kFewCands; ++c) if (key[c] < prev) best = max(best, key[c]);
+                res[j] = best;  // (keys are distinct; 0 = fewer than j + 1 candidates: nothing is below 0)
+                prev = best;
+            }
+        }
     } else if (wmask != 0) {
         u32 cur = ra;
         auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
@@ -5433,8 +5503,9 @@ void launch_top1_merge(hipStream_t st, const u64* best_sum, const u32* best_idx,
 void launch_topk_merge(hipStream_t st, const u64* cand_sum, const u32* cand_idx, u32 n_reads, u32 n_units, u32 per_grp,
                        u32 top_k, u32* out_idx, u64* out_sum, u32 out_r0, const Species& sp, const unsigned char* has) {
     if (n_reads == 0) return;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(cdiv((u64)n_reads * sp.n_sp, 4)), dim3(256), 0, st, cand_sum, cand_idx, n_reads,
-                       n_units, per_grp, top_k, out_idx, out_sum, out_r0, sp, has);
+    const u32 next_stride = (n_units + 3u) & ~3u;  // (a species owns at most all of the units)
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(cdiv((u64)n_reads * sp.n_sp, 4)), dim3(256), 4u * next_stride, st, cand_sum, cand_idx, n_reads,
+                       n_units, per_grp, top_k, out_idx, out_sum, out_r0, sp, has, next_stride);
 }
 void launch_rank_table(hipStream_t st, const u64* cum, const Species& sp, u32 top_k, u32* out_idx, u64* out_sum) {
     hipLaunchKernelGGL(rank_table_kernel, dim3(sp.n_sp), dim3(1024), 0, st, cum, sp, top_k, out_idx, out_sum);
