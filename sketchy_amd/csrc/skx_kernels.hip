@@ -3388,6 +3388,27 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const u64* __restrict__
     const u32 n_u = (grp1 - grp0) * per_grp;
     const u64* cs = cand_sum + ((size_t)r * n_units + (size_t)grp0 * per_grp) * top_k;
     const u32* ci = cand_idx + ((size_t)r * n_units + (size_t)grp0 * per_grp) * top_k;
+    if (n_u * top_k <= 64u) {
+        // Few enough entries for one per lane (the candidates' compact problems: two rank groups per species): an entry's place in the row
+        // is the number of entries that rank before it -- one load, no rounds.
+        const u32 u = lane / top_k;
+        bool ok = lane < n_u * top_k && !(has && !has[(size_t)(r >> 6) * n_units + grp0 + u]);
+        u64 s_ = 0; u32 i_ = 0xFFFFFFFFu;
+        if (ok) { s_ = cs[lane]; i_ = ci[lane]; }
+        ok = ok && i_ != 0xFFFFFFFFu;
+        const u64 okm = __ballot(ok);
+        u32 before = 0;
+        for (u64 m = okm; m; m &= m - 1ull) {
+            const int e = __builtin_ctzll(m);
+            const u64 se = readlane64(s_, e); const u32 ie = __builtin_amdgcn_readlane(i_, e);
+            before += ranks_before(se, ie, s_, i_) ? 1u : 0u;
+        }
+        const size_t o = ((size_t)(out_r0 + r) * sp.n_sp + spi) * top_k;
+        if (ok && before < top_k) { out_idx[o + before] = i_ - g_lo; out_sum[o + before] = s_; }
+        const u32 n_ok = (u32)__popcll(okm);
+        if (lane >= n_ok && lane < top_k) { out_idx[o + lane] = 0xFFFFFFFFu - g_lo; out_sum[o + lane] = 0; }  // (nothing left: see below)
+        return;
+    }
     unsigned char* next = s_next + (threadIdx.x >> 6) * next_stride;
     // (a unit the pruned ranking reported nothing for -- its entries were not even written -- starts exhausted; has: unit = rank group)
     for (u32 u = lane; u < n_u; u += 64u) next[u] = (unsigned char)((has && !has[(size_t)(r >> 6) * n_units + grp0 + u]) ? top_k : 0u);
@@ -3885,6 +3906,77 @@ __global__ __launch_bounds__(256) void rank_seg_topk_kernel(const u32* __restric
                 prev = best;
             }
         }
+    } else if (n_cands > kFewCands && n_cands <= 64u) {
+        // At most one candidate per lane (a leader has emerged: the compact problems of a clone-tree sample carry 20-60): the candidates
+        // move to lanes 0 .. n_cands-1 in (word, lane) order, the replay keeps ONE sum per lane, and a read's order is each candidate's
+        // count of the candidates ahead of it (n_cands independent compares) instead of top_k dependent wave-wide maxima; the rows are
+        // stored as they are made.  ~5 n_cands + 30 instructions per read instead of ~45 top_k (profiles/r06_topk.txt).
+        __shared__ u32 s_cid[4][64];
+        const u32 wv = threadIdx.x >> 6;
+        {
+            u32 base = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const u64 b_ = __ballot(cand[w]);
+                if (cand[w]) s_cid[wv][base + (u32)__popcll(b_ & lanemask_lt())] = ((u32)w << 6) | lane;
+                base += (u32)__popcll(b_);
+            }
+        }
+        wave_sync();
+        const bool isc = lane < n_cands;
+        const u32 cid = isc ? s_cid[wv][lane] : 0u;
+        const u32 wc_ = cid >> 6, lc_ = cid & 63u;
+        auto pick = [&](const u64 (&v)[NW]) -> u64 {  // v[wc_] of lane lc_
+            u64 out = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if ((wmask >> w) & 1u) {
+                    const u32 lo = (u32)__shfl((int)(u32)v[w], (int)lc_, 64), hi = (u32)__shfl((int)(u32)(v[w] >> 32), (int)lc_, 64);
+                    if (wc_ == (u32)w) out = make_u64(lo, hi);
+                }
+            }
+            return out;
+        };
+        u64 sumc = pick(sum);
+        const u32 gidx = (grp * NW + wc_) * 64u + lc_;
+        const u64 tie = ((u64)((u32)NW - 1u - wc_) << 6) | (u64)(63u - lc_);
+        u32 cur = ra;
+        auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
+            if (cur >= r_stop) return;
+            const u64 key = isc ? (((sumc + 1ull) << SH) | tie) : 0ull;
+            u32 ahead = 0;
+            for (u32 e = 0; e < n_cands; ++e) ahead += readlane64(key, (int)e) > key ? 1u : 0u;
+            for (u32 r = cur; r < r_stop; ++r) {
+                const size_t o = ((size_t)r * n_grp + grp) * top_k;
+                if (isc) { if (ahead < top_k) { cand_sum[o + ahead] = sumc; cand_idx[o + ahead] = gidx; } }
+                else if (lane < top_k) { cand_sum[o + lane] = 0; cand_idx[o + lane] = 0xFFFFFFFFu; }  // (fewer than top_k candidates)
+            }
+            cur = r_stop;
+        };
+        MaskVec nxt = gather_vec(mq_g, (pa + lane < pz) ? pair_q[pa + lane] : 0u, pa + lane < pz);
+        u32 rnxt = (pa + lane < pz) ? pair_r[pa + lane] : 0u;
+        for (u32 p0 = pa; p0 < pz; p0 += 64u) {
+            const u32 n = min(64u, pz - p0);
+            const MaskVec cur_m = nxt;
+            const u32 rv = rnxt;
+            const u32 pn = p0 + 64u + lane;
+            nxt = gather_vec(mq_g, pn < pz ? pair_q[pn] : 0u, pn < pz);
+            rnxt = pn < pz ? pair_r[pn] : 0u;
+            u64 x[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) x[j] = (wmask >> j & 1u) ? transpose64(cur_m.w[j], lane) : 0;  // live words only
+            const u64 xc = pick(x);  // this lane's candidate across the chunk's pairs
+            for (u32 j = 0; j < n;) {
+                const u32 rd = __builtin_amdgcn_readlane(rv, (int)j);
+                emit_upto(rd);                                   // reads before rd see the state without rd's pairs
+                const u64 m = __ballot(lane < n && rv == rd);    // rd's pairs inside this chunk (contiguous from j)
+                sumc += (u64)__popcll(xc & m);
+                j += __popcll(m);
+            }
+        }
+        emit_upto(rz);
+        if (lane == 0) has[(size_t)seg * n_grp + grp] = 1;
+        return;
     } else if (wmask != 0) {
         u32 cur = ra;
         auto emit_upto = [&](u32 r_stop) {  // reads [cur, r_stop) all see the current state
