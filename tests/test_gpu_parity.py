@@ -684,6 +684,26 @@ def test_topk_fast_and_generic_paths(gpu, top):
     check(hashes, bases, offsets, top=top, batches=2, want_shared=False, want_sketches=False)
 
 
+@pytest.mark.parametrize("top", [2, 16])
+@pytest.mark.parametrize("n_lead,spread", [(2, 0), (5, 1), (8, 0), (9, 1), (16, 0), (40, 0), (64, 0), (65, 0), (130, 1), (130, 0)])
+def test_topk_with_a_given_number_of_leaders(gpu, top, n_lead, spread):
+    """The pruned top-k ranking (rank_seg_topk_kernel) orders a rank group's candidates in one of four ways -- one candidate, up to eight
+    (counted one by one), up to 64 (one per lane), more (read-by-read replay) -- and topk_merge_kernel merges the groups' lists in one of
+    two.  Here n_lead variants of a SECOND ancestor sit among 1 100 variants of the first, packed into one rank group or spread over all
+    three; the reads come from the second ancestor, so after the first batch exactly those n_lead genomes are ahead (with exact ties among
+    them), and batches two and three rank them through the path their number selects (src/sketchy.rs:348, :389-400: sum desc, index asc)."""
+    if n_lead < top:
+        pytest.skip("fewer leaders than rows: the zero genomes tie for the rest and everything is a candidate")
+    ref, _, _ = workload(1100, 160, 10, read_len=700, rng_seed=91)
+    lead, bases, offsets = workload(n_lead, 160, 600, read_len=700, rng_seed=92)
+    hashes = ref["ref"].copy()
+    pos = (np.arange(n_lead) * (1100 // n_lead if spread else 1) + 7) % 1100
+    hashes[pos] = lead["ref"]
+    if n_lead >= 3:
+        hashes[pos[-1]] = hashes[pos[0]]   # an exact tie between the lowest and the highest index
+    check(hashes, bases, offsets, top=top, batches=3, want_shared=False, want_sketches=False)
+
+
 def test_common_hashes_extreme_query_values(gpu):
     """Arbitrary query hashes reach the dictionary builder through `shared`: 0, the all-ones value (the hash set's
     empty marker), the table markers, heavy duplication across queries, and a query the reference never meets."""

@@ -63,7 +63,7 @@ def test_most_long_lists_are_stored_as_patterns(snp):
     assert p["pattern_lists"] >= 0.8 * p["long_lists"]    # tools/diag_patterns.py: 97 % within 14 genomes of their lineage's list
 
 
-@pytest.mark.parametrize("top,reuse", [(1, 0), (3, 0), (1, 1)])
+@pytest.mark.parametrize("top,reuse", [(1, 0), (3, 0), (16, 0), (1, 1)])
 def test_rows_and_table_through_shared_passes(snp, top, reuse):
     """(reuse = 1: policy "reuse_membership" -- the static dense rows of M are scanned for once per buffer set and kept)"""
     from oracle import oracle as orc

@@ -80,7 +80,7 @@ def test_the_two_trees_share_their_ancestors_hashes(kin):
     assert kin["R"].rare_index["postings"] > int(ca[np.isin(ua, both)].sum())   # ... and their lists are in the index, whatever their length
 
 
-@pytest.mark.parametrize("top,reuse", [(1, 0), (4, 0), (1, 1)])
+@pytest.mark.parametrize("top,reuse", [(1, 0), (4, 0), (9, 0), (1, 1)])
 def test_rows_and_tables_through_shared_passes(kin, top, reuse):
     from oracle import oracle as orc
     from sketchy_amd import api
