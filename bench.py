@@ -684,6 +684,45 @@ def main():
                                                           "no pass streams the reference again (a side leg: `value` scans every pass, as the contract's "
                                                           "roofline figure assumes)"}
             Sr.close()
+        # value_top16: the same K batches from a fresh table with SIXTEEN rows after every read (`sketchy predict -t 16`,
+        # src/cli.rs:118-119, src/sketchy.rs:348) -- a side leg of the top-1 line.  Its first row of every read of the last batch must be the
+        # timed run's row (rank 0 of 16 = the top-1); all sixteen rows against the oracle: tests/test_gpu_patterns.py, `--top 16` itself.
+        if args.api == "enqueue" and top == 1 and n_sp == 1 and not args.no_large_batch:
+            S16 = api.SumOfSharedHashes(R, top=16, max_batch_reads=B, max_batch_bases=max(batch_bases))
+            d16_i = torch.zeros((2, B, 16), dtype=torch.int32, device=tdev)
+            d16_s = torch.zeros((2, B, 16), dtype=torch.int64, device=tdev)
+
+            def step16(i, slot=0):
+                bb, oo = batches[i % n_distinct]
+                S16.enqueue_device(bb.data_ptr(), oo.data_ptr(), B, batch_bases[i % n_distinct], d16_i[slot].data_ptr(), d16_s[slot].data_ptr())
+            for i in range(min(W, 2)):
+                step16(i)
+            S16.sync()
+            t16 = []
+            for rep in range(3):
+                S16.reset()
+                shard.barrier()
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                for i in range(W, W + K):
+                    step16(i, slot=1 if i == W + K - 1 else 0)
+                S16.sync()
+                t16.append(shard.max_over_ranks(time.perf_counter() - tc))
+            ok16 = None
+            if not args.no_check:
+                ok16 = bool(np.array_equal(d16_i[1, :, 0].cpu().numpy().view(np.uint32), ti_last.reshape(B, -1)[:, 0]) and
+                            np.array_equal(d16_s[1, :, 0].cpu().numpy().view(np.uint64), ts_last.reshape(B, -1)[:, 0]))
+                s16 = d16_s[1].cpu().numpy().view(np.uint64)
+                ok16 = ok16 and bool((s16[:, :-1] >= s16[:, 1:]).all())   # rows in rank order
+                if not ok16:
+                    err = err or "the first of sixteen rows differs from the top-1 row of the last timed step"
+            if rank == 0:
+                tt = float(np.median(t16))
+                out["value_top16"] = {"value": K * B * world / tt, "unit": "reads/s", "ms_per_step": 1e3 * tt / K, "median_of": 3,
+                                      "first_row_matches_timed_run": ok16,
+                                      "what": "the same K batches from a fresh table on a stream created with top = 16: sixteen ranked rows after every read"}
+            S16.close()
+            del d16_i, d16_s
         # value_steady_state: the same stream far from its start (no reset, batches cycled), three regions of >= 0.5 s
         n_long = max(32, int(0.5 / (elapsed / K)))
         S.reset()

@@ -25,6 +25,9 @@ rows = [
     ("C2", "`value_membership_reused` (policy `reuse_membership`: the static dense rows scanned for once and kept -- a side leg), 20 batches / a lone batch",
      f"{M(g(d, 'value_membership_reused', 'value'))} / {M(g(d, 'value_membership_reused', 'value_cold'))}", f"{g(d, 'value_membership_reused', 'ms_per_step') or 0:.3f}", "no scan in the timed region", "",
      f"rows = the timed run's: {g(d, 'value_membership_reused', 'rows_match_timed_run')}"),
+    ("C2", "`value_top16` (sixteen rows after every read, `-t 16`, truth strain; all K and both workloads: `profiles/r06_topk.txt`), 20 batches from a fresh table",
+     f"{M(g(d, 'value_top16', 'value'))}", f"{g(d, 'value_top16', 'ms_per_step') or 0:.3f}", "", "",
+     f"first row = the timed run's: {g(d, 'value_top16', 'first_row_matches_timed_run')}"),
     ("C2", "`value_host_fed` / `value_host_fed_packed` (PCIe-bound)", f"{M(g(d, 'value_host_fed', 'value'))} / {M(g(d, 'value_host_fed_packed', 'value'))}", "", "", "", ""),
     ("C2", "**`value_end_to_end`**: `sketchy-hip predict -s` on a 4.7 GB FASTQ file (host-bound: 16 usable CPUs of a shared box)",
      f"**{M(g(d, 'value_end_to_end', 'value'))}** (runs {' / '.join(f'{v / 1e6:.1f}' for v in (g(d, 'value_end_to_end', 'runs_reads_per_s') or []))})", "", "", "",
