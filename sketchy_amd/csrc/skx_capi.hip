@@ -1186,6 +1186,8 @@ struct skx_stream {
     u32 pub_seq = 0;         // sequence number of the latest publish
     bool chk_dirty[kSides] = {};  // per set: a push failed between arming and publishing -- re-zero the set's device-side counters before its next batch
     u64* d_rowany[2] = {nullptr, nullptr};   // [rank groups][qcap / 64] per buffer set: which query rows hold a bit for the group
+    u32* d_mqext = nullptr;                  // per buffer set {row stride, clean rows} of (d_mq, d_rowany): rare_to_mq_kernel writes only what changed
+    u32 mq_stride[2] = {0, 0};               // the row stride the set's last pass used (kept while it fits: the same stride = sparse writes)
     u32* d_grp_any[2] = {nullptr, nullptr};  // [rank groups + 1] per buffer set: the group's slice of the bit matrix holds any
                                              // bit; last word = "M itself was written this pass" (m_dirty)
     u64* d_hbuf = nullptr;                   // slabs of the lean scan kernel, [bands * tiles][scan_lean_words()][256]
@@ -1247,7 +1249,7 @@ static void stream_free(skx_stream* st) {
                     st->d_q[0], st->d_q[1], st->d_pair_r[0], st->d_pair_r[1], st->d_pair_q[0], st->d_pair_q[1],
                     st->d_poff_pass[0], st->d_poff_pass[1], st->d_poff_pass[2], st->d_pair_r[2], st->d_nq[0], st->d_nq[1], st->d_win[0], st->d_win[1], st->d_m, st->d_mint, st->d_mq[0], st->d_mq[1],
                     st->d_topk_idx, st->d_topk_sum, st->d_tab_tmp, st->d_rank_idx, st->d_rank_sum, st->d_bsum, st->d_grp_any[0],
-                    st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1],
+                    st->d_grp_any[1], st->d_hbuf, st->d_wb[0], st->d_wb[1], st->d_rowany[0], st->d_rowany[1], st->d_mqext,
                     st->d_qd, st->d_qrow, st->d_sslot, st->d_qinfo, st->d_qloc, st->d_cls_bsum, st->d_nd_hs,
                     st->d_rowcnt, st->d_gain, st->d_gain_s, st->d_candslot, st->d_candmask, st->d_lrow, st->d_nlrow, st->d_gain_l, st->d_cbase, st->d_cwl, st->d_ncwl, st->d_cw, st->d_cbad, st->d_nqc, st->d_spc_g0, st->d_spc_grp, st->d_inb, st->d_hit, st->d_hist, st->d_nprow, st->d_pcw, st->d_ms[0], st->d_ms[1], st->d_mdirty_s};
     for (auto& q : st->ps) {
@@ -1624,8 +1626,16 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
         }
     }
     // (d_mint, the second word array of the split scan variant, is allocated by the first pass that wants it)
-    for (int i = 0; i < 2; ++i)
-        SCHK(hipMalloc(&st->d_mq[i], ((size_t)st->qcap + 128) * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8));
+    for (int i = 0; i < 2; ++i) {
+        const size_t bytes = ((size_t)st->qcap + 128) * ((n_gw + skx::kRankWords - 1) / skx::kRankWords * skx::kRankWords) * 8;
+        SCHK(hipMalloc(&st->d_mq[i], bytes));
+        SCHK(hipMemset(st->d_mq[i], 0, bytes));  // (zero + zero flags = clean under any row stride: d_mqext)
+    }
+    {
+        const u32 any[4] = {skx::mq_any_stride(), 0xFFFFFFFFu, skx::mq_any_stride(), 0xFFFFFFFFu};
+        SCHK(hipMalloc(&st->d_mqext, sizeof(any)));
+        SCHK(hipMemcpy(st->d_mqext, any, sizeof(any), hipMemcpyHostToDevice));
+    }
     st->n_cand_units = n_cand_units;
     {
         // ranking lanes: the second one only for streams that enqueue (batches back to back are what it overlaps); experiment
@@ -1675,7 +1685,10 @@ static int stream_create_internal(skx_stream** out, const skx_ref* ref, u32 top_
     SCHK(hipMalloc(&st->d_rank_sum, (size_t)st->rank_cap * 8));
     SCHK(hipMalloc(&st->d_bsum, ((size_t)max_reads / 1024 + 2) * 4));
     for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_grp_any[i], (size_t)(n_pad / (skx::kRankWords * 64) + 1) * 4));
-    for (int i = 0; i < 2; ++i) SCHK(hipMalloc(&st->d_rowany[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (st->qcap / 64 + 2) * 8));
+    for (int i = 0; i < 2; ++i) {
+        SCHK(hipMalloc(&st->d_rowany[i], (size_t)(n_pad / (skx::kRankWords * 64)) * (st->qcap / 64 + 2) * 8));
+        SCHK(hipMemset(st->d_rowany[i], 0, (size_t)(n_pad / (skx::kRankWords * 64)) * (st->qcap / 64 + 2) * 8));
+    }
     // (the slabs of round 3's form of the lean kernel, 252 MB at C2, 0.94 GB at C4: experiments build, when a knob asks for that form)
     if (skx::scan_lean_wants_slabs() && skx::scan_lean_applies(ref->n_bands, false, false)) {
         SCHK(hipMalloc(&st->d_hbuf, (size_t)n_bt * skx::scan_lean_words() * skx::kTileGenomes * 8));
@@ -1893,7 +1906,8 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     const u64 per_row = (st->static_dense ? 0 : (u64)n_pad / 8 * (st->d_mint ? 2 : 1)) + 2 * mq_words * 8 + 2 * (u64)(n_pad / (skx::kRankWords * 64)) / 8 + 1 +
                         5ull * skx::kPassBatchesMax * 4;  // (+ the per-batch row counters, the two rare-row maps, the long-row lists)
     want_rows += st->sd64;  // (the caller counts distinct query hashes: the static dense rows come on top)
-    u64 rows = std::min<u64>(want_rows, (u64)(mem_free / 4) / per_row);  // (a quarter of what is free: the one array family a dense stream cannot do without)
+    static const int grow_div = skx::knob("SKX_GROW_DIV") ? std::max(1, atoi(skx::knob("SKX_GROW_DIV"))) : 4;  // experiment knob
+    u64 rows = std::min<u64>(want_rows, (u64)(mem_free / grow_div) / per_row);  // (a quarter of what is free: the one array family a dense stream cannot do without)
     rows = std::min<u64>(rows, st->pcap) / 64 * 64;
     if (rows <= st->qcap) return SKX_OK;  // no room (or nothing to gain): the batch is cut into passes as before
     u64 *m = nullptr, *mint = nullptr, *mq[2] = {nullptr, nullptr}, *ra[2] = {nullptr, nullptr};
@@ -1909,6 +1923,13 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     if (e == hipSuccess && st->d_lrow) e = hipMalloc(&lrow, (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 8);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(&sm[i], (size_t)skx::kPassBatchesMax * ((size_t)rows + 128) * 4);
     if (e == hipSuccess && m) e = hipMemset(m, 0, (size_t)(rows / 64 + 2) * n_pad * 8);  // (M is all-zero between passes)
+    // (the group-major matrices and their row flags start all-zero: clean under any row stride -- d_mqext below)
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMemset(mq[i], 0, ((size_t)rows + 128) * mq_words * 8);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMemset(ra[i], 0, (size_t)(n_pad / (skx::kRankWords * 64)) * (rows / 64 + 2) * 8);
+    if (e == hipSuccess) {
+        const u32 any[4] = {skx::mq_any_stride(), 0xFFFFFFFFu, skx::mq_any_stride(), 0xFFFFFFFFu};
+        e = hipMemcpy(st->d_mqext, any, sizeof(any), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && mint) e = hipMemset(mint, 0, (size_t)(rows / 64 + 2) * n_pad * 8);
     if (e == hipSuccess) e = hipDeviceSynchronize();  // (the zero-fills ran on the null stream)
     if (e != hipSuccess) { undo(); return SKX_OK; }   // (no memory for it: as before)
@@ -1923,6 +1944,7 @@ static int grow_query_rows(skx_stream* st, u64 want_rows) {
     (void)hipFree(st->d_rowcnt); st->d_rowcnt = cnt;
     if (lrow) { (void)hipFree(st->d_lrow); st->d_lrow = lrow; }
     st->qcap = (u32)rows;
+    st->mq_stride[0] = st->mq_stride[1] = 0;
     st->qrows_grown += 1;
     return SKX_OK;
 }
@@ -1971,7 +1993,14 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
     // rows per group of the group-major bit matrix of this pass (the rows behind the dense ones start on a word boundary: up to 63 more
     // than the dictionary has hashes)
     const bool sdm = st->static_dense;  // the dense rows are the reference's static ones: rows [0, sd64), the pass's rare rows behind
-    const u32 nq_rows = st->sd64 + ((q_bound + 63) / 64) * 64 + 64;
+    // (... and a buffer set keeps the stride of its last pass while that is large enough and not more than twice what this pass needs:
+    // under an unchanged stride rare_to_mq_kernel writes only the words that changed -- d_mqext; a new stride is taken a quarter larger
+    // than needed, so that the next passes fit it)
+    const u32 nq_need = st->sd64 + ((q_bound + 63) / 64) * 64 + 64;
+    const u32 nq_max = st->sd64 + ((st->qhash_cap() + 63) / 64) * 64 + 64;
+    u32& nq_keep = st->mq_stride[st->buf];
+    if (!(nq_keep >= nq_need && nq_keep <= 2 * nq_need + 4096)) nq_keep = std::min(nq_max, (nq_need + nq_need / 4 + 63) / 64 * 64);
+    const u32 nq_rows = nq_keep;
     // the ranking of earlier passes whose candidates have been published by now; the pass TWO back (it used this pass's buffer set)
     // must be through -- the one before this may still be waiting for its scan
     // (the pass ONE back is queued BEHIND this pass's front half, further down: its eight chains are a hundred launches, 0.3-0.4 ms of
@@ -2313,13 +2342,15 @@ static int run_pass_multi(skx_stream* st, SubPass* subs, int n_sub, bool update_
             Span sp(st, 1, hs);
             skx::launch_sparse_fill(hs, st->d_sslot, d_nd, st->rare_index(), d_m, n_pad, d_mdirty, q_bound, only_if);
         }
+        if (!direct_rare) HIPCHK(hipMemsetAsync(st->d_mqext + 2 * b, 0, 8, hs));  // (the transpose alone writes the set: nothing is known about it afterwards)
         {
             Span sp(st, 3, hs);
             skx::launch_transpose_bits(hs, d_m, split ? st->d_mint : nullptr, n_pad, n_words, d_mq, direct_rare ? d_nd + 2 : d_nd + 3, d_grp_any,
                                        nullptr, st->d_wb[b], d_win, ref->n_tiles, d_mdirty, direct_rare ? nd_est : nq_est, st->d_rowany[b], only_if,
                                        sdm && st->reuse_m);
             if (direct_rare)
-                skx::launch_rare_to_mq(hs, st->d_sslot, d_nd, st->rare_index(), d_mq, nq_rows, n_pad, st->d_rowany[b], d_grp_any, q_bound, only_if);
+                skx::launch_rare_to_mq(hs, st->d_sslot, d_nd, st->rare_index(), d_mq, nq_rows, n_pad, st->d_rowany[b], d_grp_any, q_bound, only_if,
+                                       st->d_mqext + 2 * b);
             if (only_if && !(sdm && st->reuse_m)) skx::launch_m_clear(hs, d_m, split ? st->d_mint : nullptr, n_pad, d_nd, only_if);
         }
         if (sdm) st->m_ready[b] = false;  // (consumed: transposed -- which zeroes what it reads -- or cleared)

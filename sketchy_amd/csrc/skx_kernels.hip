@@ -1946,14 +1946,26 @@ __global__ __launch_bounds__(256) void sparse_fill_kernel(const u32* __restrict_
 // Here: one block per 64 rows (= one word of rowany per group); thread (row, word of the group) walks the groups, copying or
 // zero-filling -- 512-byte runs per wave, 2 KB per block and group --, then writes the short rows' few words over its own zeros.
 // rowany[grp][word of these rows] is written for every group (plain stores), grp_any[grp] += rows of the group that hold a bit.
+//
+// Zero-filling is most of that: a truth-strain pass's rows are almost all short lists (somebody's private SNP hash met by a sequencing
+// error: eight genomes at most), 381 k rows x 293 groups x 64 B at C4 = 7 GB of zeros per batch.  `ext` = {row stride, clean rows} of
+// this buffer set's (Mq, rowany) pair says where that is not needed: under the SAME row stride as the passes before, a row below
+// `clean` holds bits for a group only if the set's rowany -- still the previous pass's here -- says so (the transposes and this kernel
+// keep it so: a row's words are written whenever its old or its new flag is set).  Such a block of 64 rows writes only the words that
+// are non-zero now or were flagged before; the other blocks (a new stride, rows never written under it) are written in full as before.
+// stride 0xFFFFFFFF = arrays zeroed at allocation: clean under any stride.  mq_extent_kernel, behind this kernel, brings `ext` up to date.
 constexpr u32 kRareGrpChunk = 512;  // groups per turn (rowany words of a block in LDS)
+constexpr u32 kAnyStride = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__ sslot, const u32* __restrict__ n_d, RareIndex ri,
                                                          u64* __restrict__ mq, u32 nq_rows, u32 n_gw, u64* __restrict__ rowany,
-                                                         u32* __restrict__ grp_any, const u32* __restrict__ only_if, u32 chunk) {
+                                                         u32* __restrict__ grp_any, const u32* __restrict__ only_if, u32 chunk,
+                                                         const u32* __restrict__ ext) {
     __builtin_amdgcn_s_setprio(2);
     if (only_if && !*only_if) return;  // (no batch of the pass ranks on the full matrix)
     __shared__ u32 lpost[64][kShortList];
     __shared__ unsigned long long lany[kRareGrpChunk];
+    __shared__ unsigned long long lold[kRareGrpChunk];  // the rows' flags before this pass (all ones: write every word)
+    const u32 clean = (ext && (ext[0] == kAnyStride || ext[0] == nq_rows)) ? ext[1] : 0u;
     const u32 nd64 = n_d[2], ns = n_d[1], n_grp = n_gw / kRankWords, n_words = nq_rows >> 6;
     const u32 r = threadIdx.x >> 3, cw = threadIdx.x & 7u, lane = lane_id();
     static_assert(kRankWords == 8 && kShortList == 8, "thread = (row, word of the group) = (row, posting)");
@@ -1977,9 +1989,13 @@ __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__
             lpost[r + 32u * h][cw] = mine;
         }
         const u32 row0 = nd64 + sr0;
+        const bool known = row0 + 64u <= clean;  // (block-uniform)
         for (u32 g0 = 0; g0 < n_grp; g0 += chunk) {  // (chunk = kRareGrpChunk; the experiments build can force the turns on small references)
             const u32 g1 = min(n_grp, g0 + chunk);
-            for (u32 i = threadIdx.x; i < g1 - g0; i += 256u) lany[i] = 0ull;
+            for (u32 i = threadIdx.x; i < g1 - g0; i += 256u) {
+                lany[i] = 0ull;
+                lold[i] = known ? rowany[(size_t)(g0 + i) * n_words + (row0 >> 6)] : ~0ull;
+            }
             __syncthreads();
             // long rows: copy; short rows: zeros.  Four groups in flight per thread (the loads of a bit row are 64-byte pieces)
             for (u32 g = g0; g < g1; g += 4u) {
@@ -1994,7 +2010,8 @@ __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__
                     if (g + u >= g1) break;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        mq[((size_t)(g + u) * nq_rows + row0 + r + 32u * h) * kRankWords + cw] = v[u][h];
+                        if (v[u][h] != 0ull || ((lold[g + u - g0] >> (r + 32u * h)) & 1ull))
+                            mq[((size_t)(g + u) * nq_rows + row0 + r + 32u * h) * kRankWords + cw] = v[u][h];
                         // rows of this wave (8 of them: 8 lanes each) that hold a bit for the group
                         u64 m = __ballot(v[u][h] != 0ull);
                         if (m) {
@@ -2037,6 +2054,14 @@ __global__ __launch_bounds__(256) void rare_to_mq_kernel(const u32* __restrict__
         }
     }
     if (acc) atomicAdd(&grp_any[threadIdx.x], acc);
+}
+
+// {row stride, clean rows} of a buffer set's (Mq, rowany) pair after a pass that wrote it through the transposes + rare_to_mq_kernel
+__global__ void mq_extent_kernel(u32* __restrict__ ext, u32 nq_rows, const u32* __restrict__ n_d, const u32* __restrict__ only_if) {
+    if (only_if && !*only_if) return;
+    const u32 rows = n_d[2] + ((n_d[1] + 63u) & ~63u);
+    if (ext[0] == kAnyStride || ext[0] == nq_rows) { ext[0] = nq_rows; ext[1] = max(ext[1], rows); }
+    else { ext[0] = nq_rows; ext[1] = rows; }  // (a new stride: what lies behind these rows belongs to the old layout)
 }
 
 // =====================================================================================
@@ -5239,11 +5264,15 @@ void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const 
     hipLaunchKernelGGL(sparse_fill_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, m_bits, n_pad, m_dirty, only_if);
 }
 void launch_rare_to_mq(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* mq, u32 nq_rows, u32 n_pad, u64* rowany,
-                       u32* grp_any, u32 rows_bound, const u32* only_if) {
+                       u32* grp_any, u32 rows_bound, const u32* only_if, u32* ext) {
     const u32 blocks = std::max(1u, std::min(cdiv(rows_bound, 64), 1024u));
     const u32 chunk = std::min(kRareGrpChunk, std::max(1u, (u32)env_int("SKX_RARE_CHUNK", (int)kRareGrpChunk)));  // experiment knob: groups per turn
-    hipLaunchKernelGGL(rare_to_mq_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, mq, nq_rows, n_pad / 64, rowany, grp_any, only_if, chunk);
+    static const bool sparse_off = env_int("SKX_RARE_SPARSE_WRITES", 1) == 0;  // experiment knob: 0 = every word of every row, as until round 6
+    hipLaunchKernelGGL(rare_to_mq_kernel, dim3(blocks), dim3(256), 0, st, sslot, n_d, ri, mq, nq_rows, n_pad / 64, rowany, grp_any, only_if, chunk,
+                       sparse_off ? nullptr : ext);
+    if (ext) hipLaunchKernelGGL(mq_extent_kernel, dim3(1), dim3(1), 0, st, ext, nq_rows, n_d, only_if);
 }
+u32 mq_any_stride() { return kAnyStride; }
 void launch_nd_from_nq(hipStream_t st, const u32* n_q, u32* n_d, u32* h_words) {
     hipLaunchKernelGGL(nd_from_nq_kernel, dim3(1), dim3(1), 0, st, n_q, n_d, h_words);
 }

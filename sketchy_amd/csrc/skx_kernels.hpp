@@ -150,8 +150,10 @@ void launch_classify(hipStream_t st, const u64* q, const u32* n_q, u32 q_bound, 
 // bits of the rows behind the dense ones, from the genome lists: atomicOr into m_bits (and *m_dirty = 1)
 // the rare rows straight into the group-major matrix (rows n_d[2] .. of Mq, their words of rowany, grp_any): references with bit rows
 // for every list longer than 8 genomes (RareIndex::mlong) -- then M holds the dense rows only and launch_transpose_bits is given n_d + 2
+// ext = {row stride, clean rows} of the buffer set's (Mq, rowany) pair (device; see rare_to_mq_kernel): read, then brought up to date
 void launch_rare_to_mq(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* mq, u32 nq_rows, u32 n_pad, u64* rowany,
-                       u32* grp_any, u32 rows_bound, const u32* only_if);
+                       u32* grp_any, u32 rows_bound, const u32* only_if, u32* ext);
+u32 mq_any_stride();  // the stride value of arrays that were zeroed at allocation (clean under any stride)
 void launch_sparse_fill(hipStream_t st, const u32* sslot, const u32* n_d, const RareIndex& ri, u64* m_bits, u32 n_pad, u32* m_dirty,
                         u32 rows_bound, const u32* only_if = nullptr /* device flag: run only when it is non-zero */);
 // n_d = {dense rows, other rows, first other row (dense rows rounded up to 64), rows in all} -- what launch_classify leaves; for a
