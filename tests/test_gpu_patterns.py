@@ -171,3 +171,36 @@ def test_same_rows_without_the_patterns(snp):
     assert int(outs[0][2]) > 0 and int(outs[1][2]) == 0      # patterns on / off
     assert outs[0][1] == outs[1][1]                           # same rows, same table
     assert int(outs[0][3]) > 0                                # compact rankings happened
+
+
+def test_rare_rows_stay_exact_through_stride_changes_and_resets(snp):
+    """The rare rows of a pass that ranks on everything are written into the group-major matrix as "only what changed" while a buffer
+    set keeps its row stride, in full after a stride change (rare_to_mq_kernel).  Pushes of very different sizes, with
+    table resets between them, alternate the two; every small push asks for the per-read x per-genome counts (src/sketchy.rs:425-438),
+    which read EVERY bit of the rows its pairs touch -- a stale bit of an earlier pass would show."""
+    from oracle import oracle as orc
+    from sketchy_amd import api
+    R, ref, bases, offsets = snp["R"], snp["ref"], snp["bases"], snp["offsets"]
+    S = api.SumOfSharedHashes(R, top=1, max_batch_reads=B, max_batch_bases=int(np.max(offsets[B::B] - offsets[:-B:B])))
+    col = np.full(N, S_, np.uint32)
+    cum, pos = None, 0
+    plan = [B, 300, 64, B, 257, 4096, 300, "reset", 300, B, 1, 2048, "reset", B, B, 129]
+    for step in plan:
+        if step == "reset":
+            S.reset(); cum = None
+            continue
+        n = int(step)
+        cut = np.ascontiguousarray(offsets[pos:pos + n + 1])
+        small = n <= 300
+        got = S.push(bases, cut, want_shared=small)
+        if small:
+            e = orc.stream(16, 0, S_, ref, col, bases, cut, top_k=1, want_shared=True, cum=cum)
+            np.testing.assert_array_equal(got["shared"], e["shared"], err_msg=f"shared counts of the push of {n} at read {pos}")
+        else:
+            e = orc.stream_fast(16, 0, S_, ref, None, bases, cut, top_k=1, cum=cum, rows=True)
+        cum = e["cum"]
+        np.testing.assert_array_equal(got["topk_sum"], e["topk_sum"], err_msg=f"push of {n} at read {pos}")
+        np.testing.assert_array_equal(got["topk_idx"], e["topk_idx"], err_msg=f"push of {n} at read {pos}")
+        pos += n
+    np.testing.assert_array_equal(S.table(), cum)
+    S.close()
